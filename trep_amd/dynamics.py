@@ -1,0 +1,222 @@
+"""Potentials, forces and holonomic constraints supported by the device path.
+
+Host-side parameter holders only; the arithmetic lives in the HIP library.
+Reference classes mirrored (constructor arguments, attribute names, ordering
+side effects such as *when* a Distance constraint creates its kinematic length
+config):
+
+  Potential / Gravity       trep/potential.py:7-45,  trep/potentials/gravity.py:6-30
+  Force / Damping / ConfigForce
+                            trep/force.py:6-30, trep/forces/damping.py:8-58,
+                            trep/forces/configforce.py:5-25
+  Constraint / Distance / PointToPoint{1,2,3}D
+                            trep/constraint.py:6-55, trep/constraints/distance.py:14-79,
+                            trep/constraints/point.py:5-108
+
+Types the reference has but no BASELINE config uses (springs, wrenches, linear
+damper, point-on-plane, Python-defined callbacks) are out of scope.
+"""
+import numpy as np
+
+from .config import Config, Input
+
+
+class Potential(object):
+    def __init__(self, system, name=None):
+        self._system = system
+        self.name = name
+        system._add_potential(self)
+
+    system = property(lambda self: self._system)
+
+
+class Gravity(Potential):
+    """V = -sum_masses m * g . p   (potentials/gravity.c:12-25)."""
+
+    def __init__(self, system, gravity=(0.0, 0.0, -9.8), name=None):
+        Potential.__init__(self, system, name)
+        self.gravity = gravity
+
+    def __repr__(self):
+        return "<Gravity %f %f %f>" % tuple(self.gravity)
+
+    @property
+    def gravity(self):
+        return np.array(self._gravity)
+
+    @gravity.setter
+    def gravity(self, g):
+        self._gravity = (float(g[0]), float(g[1]), float(g[2]))
+        self._system._structure_changed()
+
+
+class Force(object):
+    def __init__(self, system, name=None):
+        self._system = system
+        self.name = name
+        system._add_force(self)
+
+    system = property(lambda self: self._system)
+
+    def _create_input(self, name=None):
+        new_input = Input(self._system, name)
+        new_input._force = self
+        return new_input
+
+
+class Damping(Force):
+    """f_i = -c_i * dq_i on every dynamic config (forces/damping.c:13-27)."""
+
+    def __init__(self, system, default=0.0, coefficients={}, name=None):
+        Force.__init__(self, system, name)
+        self._default = float(default)
+        self.coefficients = {}
+        for config, coeff in coefficients.items():
+            self.coefficients[system.get_config(config)] = float(coeff)
+
+    def coefficient_array(self):
+        """One coefficient per dynamic config, in system.dyn_configs order."""
+        out = np.ones(self._system.nQd, dtype=np.float64) * self._default
+        for config, coeff in self.coefficients.items():
+            out[config.index] = coeff
+        return out
+
+    def get_damping_coefficient(self, config):
+        config = self._system.get_config(config)
+        if config is None:
+            raise ValueError("Couldn't find config")
+        return self.coefficients.get(config, self._default)
+
+    def set_damping_coefficient(self, config, coeff):
+        if coeff is None:
+            self.coefficients.pop(self._system.get_config(config), None)
+        else:
+            self.coefficients[self._system.get_config(config)] = float(coeff)
+        self._system._structure_changed()
+
+    @property
+    def default(self):
+        return self._default
+
+    @default.setter
+    def default(self, value):
+        self._default = float(value)
+        self._system._structure_changed()
+
+
+class ConfigForce(Force):
+    """Generalized force u applied directly to one config (forces/configforce.c:13-37)."""
+
+    def __init__(self, system, config, finput, name=None):
+        Force.__init__(self, system, name)
+        if not system.get_config(config):
+            raise ValueError("Could not find config %r" % config)
+        self._config = system.get_config(config)
+        self._input = self._create_input(finput)
+
+    finput = property(lambda self: self._input)
+    config = property(lambda self: self._config)
+
+
+class Constraint(object):
+    def __init__(self, system, name=None, tolerance=1e-10):
+        self._system = system
+        self.name = name
+        self.tolerance = tolerance
+        self._index = -1
+        system._add_constraint(self)
+
+    system = property(lambda self: self._system)
+
+    @property
+    def index(self):
+        self._system._sync()
+        return self._index
+
+    def get_actual_distance(self):
+        p1 = self.frame1.p()
+        p2 = self.frame2.p()
+        return ((p1[0] - p2[0]) ** 2.0 + (p1[1] - p2[1]) ** 2.0 + (p1[2] - p2[2]) ** 2.0) ** 0.5
+
+
+class Distance(Constraint):
+    """h = |p1 - p2|^2 - d^2, d constant or a new kinematic config (constraints/distance.c:16-33)."""
+
+    def __init__(self, system, frame1, frame2, distance, name=None):
+        Constraint.__init__(self, system, name)
+        assert frame1 is not None
+        assert frame2 is not None
+        self._frame1 = system.get_frame(frame1)
+        self._frame2 = system.get_frame(frame2)
+        if isinstance(distance, str):
+            self._config = Config(system, name=distance, kinematic=True)
+            self._distance = 0.0
+        else:
+            self._config = None
+            self._distance = float(distance)
+
+    def __repr__(self):
+        mid = "'%s'" % self._config.name if self._config else "%f" % self._distance
+        return "<DistanceConstraint '%s' %s '%s'>" % (self.frame1.name, mid, self.frame2.name)
+
+    config = property(lambda self: self._config)
+    frame1 = property(lambda self: self._frame1)
+    frame2 = property(lambda self: self._frame2)
+
+    @property
+    def distance(self):
+        return self._config.q if self._config else self._distance
+
+    @distance.setter
+    def distance(self, value):
+        if self._config:
+            self._config.q = value
+        else:
+            self._distance = float(value)
+            self._system._structure_changed()
+
+
+class PointToPoint1D(Constraint):
+    """h = (p1 - p2)[axis]   (constraints/point.c:16-27)."""
+
+    _AXES = {"x": 0, "y": 1, "z": 2, "X": 0, "Y": 1, "Z": 2}
+
+    def __init__(self, system, axis, frame1, frame2, name=None):
+        Constraint.__init__(self, system, name)
+        self._frame1 = system.get_frame(frame1)
+        self._frame2 = system.get_frame(frame2)
+        self.axis = axis
+        self._component = self._AXES[axis]
+
+    def __repr__(self):
+        return "<PointToPointConstraint %s-axis '%s' '%s'>" % (self.axis, self.frame1.name, self.frame2.name)
+
+    frame1 = property(lambda self: self._frame1)
+    frame2 = property(lambda self: self._frame2)
+    component = property(lambda self: self._component)
+
+
+class _PointGroup(object):
+    """PointToPoint2D/3D are not constraints themselves: they add 1-D ones."""
+
+    def __init__(self, system, axes, frame1, frame2, name):
+        assert frame1 is not None
+        assert frame2 is not None
+        self.frame1 = system.get_frame(frame1)
+        self.frame2 = system.get_frame(frame2)
+        for axis in axes:
+            PointToPoint1D(system, axis, frame1, frame2, name)
+
+    get_actual_distance = Constraint.get_actual_distance
+
+
+class PointToPoint3D(_PointGroup):
+    def __init__(self, system, frame1, frame2, name=None):
+        _PointGroup.__init__(self, system, "xyz", frame1, frame2, name)
+
+
+class PointToPoint2D(_PointGroup):
+    _PLANES = {"yz": "yz", "zy": "yz", "xz": "xz", "zx": "xz", "xy": "xy", "yx": "xy"}
+
+    def __init__(self, system, plane, frame1, frame2, name=None):
+        _PointGroup.__init__(self, system, self._PLANES[plane.lower()], frame1, frame2, name)

@@ -1,0 +1,2 @@
+"""Namespace mirror of ``trep.forces`` (reference: trep/forces/__init__.py)."""
+from .dynamics import Damping, ConfigForce  # noqa: F401

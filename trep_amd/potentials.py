@@ -1,0 +1,2 @@
+"""Namespace mirror of ``trep.potentials`` (reference: trep/potentials/__init__.py)."""
+from .dynamics import Gravity  # noqa: F401

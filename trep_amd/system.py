@@ -1,0 +1,261 @@
+"""``System``: the container that owns the frame tree, coordinates, potentials,
+forces and constraints, and derives the integer topology tables from them.
+
+Mirrors the model-building surface of the reference's ``trep.System``
+(/root/reference/trep/system.py:22-158, 283-291, 306-660) and its "structure
+sync" (system.py:672-771, frame.py:658-691).  The tables computed by ``_sync``
+(frame order, configs = dyn + kin, config_gen, index/k_index, masses,
+cache_index, config.masses) are exactly what the device library consumes
+(``trep_amd.descriptor``) and are checked bit-for-bit against tables dumped from
+the reference (tests/test_topology.py).
+
+Continuous dynamics (System.f & friends), SLSQP constraint satisfaction and
+.mat I/O are outside the MidpointVI hot path and are not provided.
+"""
+import numpy as np
+
+from .config import Config, Input
+from .frame import Frame, WORLD
+
+
+class System(object):
+    def __init__(self):
+        self._dyn_configs = tuple()
+        self._kin_configs = tuple()
+        self._potentials = tuple()
+        self._forces = tuple()
+        self._inputs = tuple()
+        self._constraints = tuple()
+        self._frames = tuple()
+        self._configs = tuple()
+        self._masses = tuple()
+        self._time = 0.0
+        self._hold = 0
+        self._dirty = True
+        self._structure_version = 0
+        self._structure_changed_funcs = []
+        self._world_frame = Frame(self, WORLD, None, name="World")
+
+    def __repr__(self):
+        return "<System %d configs, %d frames, %d potentials, %d constraints, %d forces, %d inputs>" % (
+            len(self.configs), len(self.frames), len(self.potentials),
+            len(self.constraints), len(self.forces), len(self.inputs))
+
+    # -- registration (called by the model objects' constructors) -------------
+    def _register_config(self, config):
+        if config.kinematic:
+            self._kin_configs += (config,)
+        else:
+            self._dyn_configs += (config,)
+        self._structure_changed()
+
+    def _register_input(self, finput):
+        self._inputs += (finput,)
+        self._structure_changed()
+
+    def _add_potential(self, potential):
+        self._potentials += (potential,)
+        self._structure_changed()
+
+    def _add_force(self, force):
+        self._forces += (force,)
+        self._structure_changed()
+
+    def _add_constraint(self, constraint):
+        self._constraints += (constraint,)
+        self._structure_changed()
+
+    # -- structure sync -------------------------------------------------------
+    def hold_structure_changes(self):
+        self._hold += 1
+
+    def resume_structure_changes(self):
+        if self._hold == 0:
+            raise Exception("System.resume_structure_changes() called when _hold_structure_changes is 0")
+        self._hold -= 1
+        if self._hold == 0:
+            self._structure_changed()
+
+    def add_structure_changed_func(self, function):
+        self._structure_changed_funcs.append(function)
+
+    def _structure_changed(self):
+        self._dirty = True
+        self._structure_version += 1
+        if self._hold == 0:
+            for func in list(self._structure_changed_funcs):
+                func()
+
+    def _sync(self):
+        """Recompute every derived table (lazily, once per structural change)."""
+        if not self._dirty:
+            return
+        self._dirty = False
+        self._frames = tuple(self._world_frame.flatten_tree())
+        self._configs = self._dyn_configs + self._kin_configs
+        nq = len(self._configs)
+
+        # config_gen = number of variable frames strictly above the driven frame
+        # on its path from the world frame; configs that drive no frame keep nq.
+        for config in self._configs:
+            config._config_gen = nq
+        stack = [(self._world_frame, 0)]
+        while stack:
+            frame, depth = stack.pop()
+            if frame._config is not None:
+                frame._config._config_gen = depth
+                depth += 1
+            for child in frame._children:
+                stack.append((child, depth))
+
+        for i, config in enumerate(self._configs):
+            config._index = i
+            config._k_index = -1
+        for i, config in enumerate(self._kin_configs):
+            config._k_index = i
+        for i, constraint in enumerate(self._constraints):
+            constraint._index = i
+        for i, finput in enumerate(self._inputs):
+            finput._index = i
+
+        self._masses = tuple(f for f in self._frames
+                             if f._mass != 0.0 or f._Ixx != 0.0 or f._Iyy != 0.0 or f._Izz != 0.0)
+
+        # cache_index: configs on the path world -> frame, padded with None to nq+1.
+        for frame in self._frames:
+            path = []
+            f = frame
+            while f is not None:
+                if f._config is not None:
+                    path.append(f._config)
+                f = f._parent
+            path.reverse()
+            frame._cache_size = len(path)
+            frame._cache_index = tuple(path + [None] * (nq + 1 - len(path)))
+
+        for config in self._configs:
+            config._masses = tuple(f for f in self._masses if config in f._cache_index[:f._cache_size])
+
+    # -- sizes ------------------------------------------------------------------
+    nQ = property(lambda self: len(self.configs))
+    nQd = property(lambda self: len(self._dyn_configs))
+    nQk = property(lambda self: len(self._kin_configs))
+    nu = property(lambda self: len(self._inputs))
+    nc = property(lambda self: len(self._constraints))
+
+    @property
+    def t(self):
+        return self._time
+
+    @t.setter
+    def t(self, value):
+        self._time = value
+
+    # -- collections --------------------------------------------------------------
+    world_frame = property(lambda self: self._world_frame)
+    dyn_configs = property(lambda self: self._dyn_configs)
+    kin_configs = property(lambda self: self._kin_configs)
+    potentials = property(lambda self: self._potentials)
+    forces = property(lambda self: self._forces)
+    inputs = property(lambda self: self._inputs)
+    constraints = property(lambda self: self._constraints)
+
+    @property
+    def frames(self):
+        self._sync()
+        return self._frames
+
+    @property
+    def configs(self):
+        self._sync()
+        return self._configs
+
+    @property
+    def masses(self):
+        self._sync()
+        return self._masses
+
+    # -- lookup -------------------------------------------------------------------
+    @staticmethod
+    def _get_object(identifier, objtype, array):
+        if identifier is None:
+            return None
+        if isinstance(identifier, objtype):
+            return identifier
+        if isinstance(identifier, (int, np.integer)):
+            return array[identifier]
+        if isinstance(identifier, str):
+            for item in array:
+                if item.name == identifier:
+                    return item
+            raise KeyError("%s with name '%s' not found" % (objtype, identifier))
+        raise TypeError()
+
+    def get_frame(self, identifier):
+        return self._get_object(identifier, Frame, self.frames)
+
+    def get_config(self, identifier):
+        return self._get_object(identifier, Config, self.configs)
+
+    def get_input(self, identifier):
+        return self._get_object(identifier, Input, self.inputs)
+
+    def get_potential(self, identifier):
+        from .dynamics import Potential
+        return self._get_object(identifier, Potential, self.potentials)
+
+    def get_force(self, identifier):
+        from .dynamics import Force
+        return self._get_object(identifier, Force, self.forces)
+
+    def get_constraint(self, identifier):
+        from .dynamics import Constraint
+        return self._get_object(identifier, Constraint, self.constraints)
+
+    def import_frames(self, children):
+        self._world_frame.import_frames(children)
+
+    # -- state vectors ---------------------------------------------------------------
+    @staticmethod
+    def _assign(items, attr, value, lookup):
+        if isinstance(value, (int, float)):
+            for it in items:
+                setattr(it, attr, value)
+        elif isinstance(value, dict):
+            for name, v in value.items():
+                setattr(lookup(name), attr, v)
+        else:
+            for it, v in zip(items, value):
+                setattr(it, attr, v)
+
+    def _state_prop(collection, attr, lookup="get_config"):
+        def getter(self):
+            return np.array([getattr(x, attr) for x in getattr(self, collection)], dtype=float)
+
+        def setter(self, value):
+            self._assign(getattr(self, collection), attr, value, getattr(self, lookup))
+        return property(getter, setter)
+
+    q = _state_prop("configs", "q")
+    dq = _state_prop("configs", "dq")
+    ddq = _state_prop("configs", "ddq")
+    qd = _state_prop("dyn_configs", "q")
+    dqd = _state_prop("dyn_configs", "dq")
+    ddqd = _state_prop("dyn_configs", "ddq")
+    qk = _state_prop("kin_configs", "q")
+    dqk = _state_prop("kin_configs", "dq")
+    ddqk = _state_prop("kin_configs", "ddq")
+    u = _state_prop("inputs", "u", "get_input")
+    del _state_prop
+
+    def set_state(self, q=None, dq=None, u=None, ddqk=None, t=None):
+        if q is not None:
+            self.q = q
+        if dq is not None:
+            self.dq = dq
+        if u is not None:
+            self.u = u
+        if ddqk is not None:
+            self.ddqk = ddqk
+        if t is not None:
+            self.t = t

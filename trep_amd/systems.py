@@ -1,0 +1,149 @@
+"""Builders for the BASELINE.json benchmark systems (host-side model code).
+
+Each function rebuilds, with this package's model API, the mechanical system a
+reference example script defines:
+
+  pendulum(links)      examples/pendulum.py:36-71        (RX joints, unit point masses)
+  pend_on_cart()       examples/pend-on-cart-optimization.py:48-64
+  scissor_lift(n)      examples/scissor.py:53-105        (closed chain, PointToPoint2D)
+  puppet()             trep/puppets/puppets.py:220-253   (Puppet(string_constraints=True))
+
+plus the synthetic initial conditions SURVEY.md §8(d) prescribes for each.
+"""
+import math
+
+import numpy as np
+
+
+
+def _api(api):
+    """The model API to build with: this package by default, or any module exposing the same
+    names (tools/gen_golden.py passes the reference's ``trep`` to build the identical system there)."""
+    if api is None:
+        import trep_amd as api
+    return api
+
+
+def pendulum(links=1, q0=math.pi / 4.0, api=None):
+    T = _api(api)
+    system = T.System()
+    T.potentials.Gravity(system, name="Gravity")
+    parent = system.world_frame
+    for link in range(links):
+        joint = T.Frame(parent, T.RX, "link-%d" % link, "link-%d" % link)
+        parent = T.Frame(joint, T.TZ, -1)
+        parent.set_mass(1.0)
+    system.get_config("link-0").q = q0
+    return system
+
+
+def pend_on_cart(torque_force=False, api=None):
+    T = _api(api)
+    system = T.System()
+    system.import_frames([
+        T.tx('x', name='Cart', mass=10.0), [
+            T.rz('theta', name="PendulumBase"), [
+                T.ty(-1.0, name="Pendulum", mass=1.0)]]])
+    T.potentials.Gravity(system, (0, -9.8, 0))
+    T.forces.Damping(system, 0.01)
+    T.forces.ConfigForce(system, 'x', 'x-force')
+    if torque_force:
+        T.forces.ConfigForce(system, 'theta', 'theta-force')
+    return system
+
+
+def scissor_lift(segments=4, theta_0=0.05 * math.pi, m_link=1.0, I_link=1.0, L_link=5.0, m_slider=1.0,
+                 api=None):
+    """Scissor lift at its analytic closed configuration (no constraint solver needed)."""
+    T = _api(api)
+    Frame, RY, TX = T.Frame, T.RY, T.TX
+    system = T.System()
+    T.potentials.Gravity(system, name="Gravity")
+    slider = Frame(system.world_frame, TX, "SLIDER")
+    slider.config.q = L_link * math.cos(theta_0)
+    slider.set_mass(m_slider)
+    left, right = system.world_frame, slider
+    for link in range(segments):
+        left = Frame(left, RY, "L%02d" % link, "L%02d" % link)
+        left.config.q = theta_0 if link == 0 else math.pi + 2.0 * theta_0
+        left_mid = Frame(left, TX, L_link / 2.0)
+        left_mid.set_mass(m_link, I_link, I_link, I_link)
+        left_end = Frame(left, TX, L_link)
+        right = Frame(right, RY, "R%02d" % link, "R%02d" % link)
+        right.config.q = math.pi - theta_0 if link == 0 else math.pi - 2.0 * theta_0
+        right_mid = Frame(right, TX, L_link / 2.0)
+        right_mid.set_mass(m_link, I_link, I_link, I_link)
+        right_end = Frame(right, TX, L_link)
+        T.constraints.PointToPoint2D(system, 'xz', left_mid, right_mid)
+        left, right = right_end, left_end  # the two sides swap at every level
+    return system
+
+
+def scissor_q(system, theta_0, L_link=5.0):
+    """Analytic closed configuration of scissor_lift for opening angle theta_0."""
+    q = {}
+    for c in system.configs:
+        if c.name == "SLIDER":
+            q[c.name] = L_link * math.cos(theta_0)
+        elif c.name == "L00":
+            q[c.name] = theta_0
+        elif c.name == "R00":
+            q[c.name] = math.pi - theta_0
+        elif c.name.startswith("L"):
+            q[c.name] = math.pi + 2.0 * theta_0
+        else:
+            q[c.name] = math.pi - 2.0 * theta_0
+    return np.array([q[c.name] for c in system.configs])
+
+
+def puppet(api=None):
+    T = _api(api)
+    return T.puppets.Puppet(joint_forces=False, string_forces=False, string_constraints=True)
+
+
+# Base pose of the reference's puppet-optimization example
+# (examples/puppet-optimization.py:32-47).
+PUPPET_BASE_POSE = {
+    'torso_rx': -0.05, 'torso_tz': 0.0,
+    'lelbow_rx': 1.57, 'relbow_rx': 1.57,
+    'lhip_rx': math.pi / 2 - 0.6, 'rhip_rx': math.pi / 2 - 0.6,
+    'lknee_rx': -math.pi / 2 + 0.6, 'rknee_rx': -math.pi / 2 + 0.6,
+}
+PUPPET_LIMB_JOINTS = [s + j for s in 'lr' for j in ('hip_rz', 'hip_ry', 'hip_rx', 'knee_rx',
+                                                    'shoulder_rz', 'shoulder_ry', 'shoulder_rx', 'elbow_rx')]
+
+
+def puppet_initial_conditions(system, batch, seed=20250 + 3):
+    """[batch][nq] constraint-consistent puppet poses: base pose + seeded perturbation, then
+    ``project_string_controls`` semantics (strings vertical above their hooks, exact lengths)."""
+    rng = np.random.default_rng(seed)
+    names = [c.name for c in system.configs]
+    Q = np.zeros((batch, system.nQ))
+    for b in range(batch):
+        system.q = 0.0
+        system.q = PUPPET_BASE_POSE
+        for j in PUPPET_LIMB_JOINTS:
+            c = system.get_config(j)
+            c.q = c.q + rng.uniform(-0.05, 0.05)
+        for j in ('torso_rx', 'torso_ry'):
+            c = system.get_config(j)
+            c.q = c.q + rng.uniform(-0.02, 0.02)
+        system.project_string_controls()
+        Q[b] = system.q
+    assert names == [c.name for c in system.configs]
+    return Q
+
+
+def puppet_string_schedule(system, k2_0, n_steps, dt, t0=0.0):
+    """Kinematic inputs k2[b, k, :] for n_steps steps: the four limb string lengths move by
+    0.1*sin(0.6*pi*t) with the sign pattern of examples/puppet-optimization.py:79-82, t being the
+    time at the START of step k (the script evaluates the sine at mvi.t1 after the shift)."""
+    k2_0 = np.asarray(k2_0, dtype=float)
+    K = np.repeat(k2_0[:, None, :], n_steps, axis=1)
+    signs = {'left_leg_string-length': -1.0, 'right_leg_string-length': 1.0,
+             'left_arm_string-length': 1.0, 'right_arm_string-length': -1.0}
+    t = t0 + dt * np.arange(n_steps)
+    wave = 0.1 * np.sin(0.6 * math.pi * t)
+    for name, sgn in signs.items():
+        K[:, :, system.get_config(name).k_index] += sgn * wave[None, :]
+    return K
