@@ -1,0 +1,40 @@
+"""Bit-exact frame indexing / tree topology vs tables dumped from the reference (SURVEY.md §8 a-T)."""
+import numpy as np
+import pytest
+
+from common import BUILDERS, build, golden
+
+
+@pytest.mark.parametrize("name", sorted(BUILDERS))
+def test_topology_tables_match_reference(name):
+    g = golden(name)
+    system, d = build(name)
+    assert [str(f.name) for f in system.frames] == list(g["topo_frame_names"])
+    assert [str(c.name) for c in system.configs] == list(g["topo_config_names"])
+    sizes = [d.n_configs, d.n_dyn, d.n_kin, d.n_inputs, d.n_constraints, d.n_frames]
+    assert sizes == list(g["topo_sizes"])
+    for key in ["frame_transform", "frame_parent", "frame_config", "frame_cache_size", "frame_cache_index",
+                "config_kinematic", "config_gen", "config_k_index", "masses", "config_masses_off",
+                "config_masses"]:
+        ours = getattr(d, key)
+        ref = g["topo_" + key]
+        assert ours.dtype == np.int32
+        assert np.array_equal(ours, ref), key
+
+
+def test_puppet_sizes():
+    system, d = build("puppet40")
+    assert (d.n_configs, d.n_dyn, d.n_kin, d.n_constraints, d.n_frames, d.n_masses) == (40, 22, 18, 6, 86, 10)
+    depth = d.frame_cache_size
+    assert depth.max() == 10
+    assert int(depth.sum()) == 609  # SURVEY.md Appendix E, "all frames"
+
+
+def test_uses_config_and_lookup():
+    system, _ = build("puppet40")
+    knee = system.get_config("lknee_rx")
+    assert system.get_frame("ltibia_mass").uses_config(knee)
+    assert not system.get_frame("rtibia_mass").uses_config(knee)
+    assert len(system.get_config("torso_tx").masses) == 10
+    assert len(knee.masses) == 1
+    assert system.get_config("left_arm_string-length").config_gen == system.nQ

@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/ from the REAL reference.
+
+Runs only in the build container: imports the Python-3 working copy of the
+reference that tools/build_reference.py puts in /tmp/trep_ref, builds each
+BASELINE system there with the same builder code this package uses
+(trep_amd.systems, pointed at the reference's API), runs the reference's own
+MidpointVI / DSystem and records inputs and outputs.  The .npz files hold data
+only (numbers and names), never reference source.
+
+Recorded per system:
+  * topology tables (frame order/names, parents, transforms, configs, config_gen,
+    cache_index, masses) for the bit-exact topology test;
+  * free-running rollouts (q2, p2, lambda1, Newton iterations per step) from seeded
+    synthetic initial conditions and inputs -- every step is also a teacher-forced
+    case, because (q, p, lambda) at step k are the complete inputs of step k+1;
+  * first-derivative arrays at several steps; second-derivative tensors (full for
+    the small systems, selected + z-contracted for the puppet);
+  * DSystem captures: set(X[k],U[k],k,xk_hint) -> f, fdx, fdu, fdxdx(z), fdxdu(z), fdudu(z).
+"""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/tmp/trep_ref")
+
+import trep  # noqa: E402  (the reference, Python-3 working copy)
+import trep.puppets  # noqa: E402
+import trep.discopt  # noqa: E402
+from trep_amd import systems  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+DT = 0.01
+D1 = ["q2_dq1", "q2_dp1", "q2_du1", "q2_dk2", "p2_dq1", "p2_dp1", "p2_du1", "p2_dk2",
+      "l1_dq1", "l1_dp1", "l1_du1", "l1_dk2"]
+PAIRS = ["dq1dq1", "dq1dp1", "dq1du1", "dq1dk2", "dp1dp1", "dp1du1", "dp1dk2", "du1du1", "du1dk2", "dk2dk2"]
+CODES = {"WORLD": 0, "TX": 1, "TY": 2, "TZ": 3, "RX": 4, "RY": 5, "RZ": 6, "CONST_SE3": 7}
+
+
+def topology(system):
+    frames, configs = system.frames, system.configs
+    fidx = {id(f): i for i, f in enumerate(frames)}
+    cidx = {id(c): i for i, c in enumerate(configs)}
+    t = {}
+    t["topo_frame_names"] = np.array([str(f.name) for f in frames])
+    t["topo_config_names"] = np.array([str(c.name) for c in configs])
+    t["topo_frame_transform"] = np.array([CODES[str(f.transform_type)] for f in frames], dtype=np.int32)
+    t["topo_frame_parent"] = np.array([-1 if f.parent is None else fidx[id(f.parent)] for f in frames], dtype=np.int32)
+    t["topo_frame_config"] = np.array([-1 if f.config is None else cidx[id(f.config)] for f in frames], dtype=np.int32)
+    t["topo_frame_cache_size"] = np.array([f._cache_size for f in frames], dtype=np.int32)
+    t["topo_frame_cache_index"] = np.array(
+        [[-1 if c is None else cidx[id(c)] for c in f._cache_index] for f in frames], dtype=np.int32).reshape(-1)
+    t["topo_config_kinematic"] = np.array([1 if c.kinematic else 0 for c in configs], dtype=np.int32)
+    t["topo_config_gen"] = np.array([c._config_gen for c in configs], dtype=np.int32)
+    t["topo_config_k_index"] = np.array([c.k_index for c in configs], dtype=np.int32)
+    t["topo_masses"] = np.array([fidx[id(f)] for f in system.masses], dtype=np.int32)
+    off, cm = [0], []
+    for c in configs:
+        cm += [fidx[id(f)] for f in c.masses]
+        off.append(len(cm))
+    t["topo_config_masses_off"] = np.array(off, dtype=np.int32)
+    t["topo_config_masses"] = np.array(cm, dtype=np.int32)
+    t["topo_sizes"] = np.array([system.nQ, system.nQd, system.nQk, system.nu, system.nc, len(frames)], dtype=np.int32)
+    return t
+
+
+def rollout(system, q0, U, K, n_steps, deriv_steps=(), deriv2_full=False, deriv2_select=()):
+    """Free-running reference rollout from initialize_from_configs(0, q0, DT, q0)."""
+    mvi = trep.MidpointVI(system, num_threads=1)
+    mvi.initialize_from_configs(0.0, q0, DT, q0)
+    nd = mvi.nd
+    Q, P, LAM, IT = [mvi.q2], [mvi.p2], [mvi.lambda1], []
+    extra = {}
+    for k in range(n_steps):
+        it = mvi.step(mvi.t2 + DT, U[k], K[k])
+        Q.append(mvi.q2); P.append(mvi.p2); LAM.append(mvi.lambda1); IT.append(it)
+        if (k + 1) in deriv_steps:
+            mvi._calc_deriv2()
+            for n in D1:
+                extra["d1_%d_%s" % (k + 1, n)] = getattr(mvi, "_" + n).copy()
+            for pr in PAIRS:
+                for pre in ("q2_", "p2_", "l1_"):
+                    name = pre + pr
+                    if deriv2_full or name in deriv2_select:
+                        extra["d2_%d_%s" % (k + 1, name)] = getattr(mvi, "_" + name).copy()
+            extra["f_%d" % (k + 1)] = mvi.calc_f()
+    return dict(Q=np.array(Q), P=np.array(P), LAM=np.array(LAM).reshape(n_steps + 1, -1),
+                IT=np.array(IT, dtype=np.int32), **extra)
+
+
+def dsystem_captures(system, Q, P, U, K, ks, seed):
+    """DSystem.set(X[k],U[k],k,xk_hint=X[k+1]) -> f, A, B and z-contracted second-order terms."""
+    n = len(Q)
+    t = DT * np.arange(n)
+    mvi = trep.MidpointVI(system, num_threads=1)
+    dsys = trep.discopt.DSystem(mvi, t)
+    nk, nd = system.nQk, system.nQd
+    V = np.zeros((n, nk))
+    V[1:] = (Q[1:, nd:] - Q[:-1, nd:]) / DT
+    X, Uin = dsys.build_trajectory(Q, P, V, U[:n - 1], K[:n - 1])
+    rng = np.random.default_rng(seed)
+    Z = rng.standard_normal((2, dsys.nX))
+    out = {"ds_k": np.array(ks, dtype=np.int32), "ds_Z": Z, "ds_X": X, "ds_U": Uin}
+    for k in ks:
+        dsys.set(X[k], Uin[k], k, xk_hint=X[k + 1])
+        out["ds_%d_f" % k] = dsys.f()
+        out["ds_%d_A" % k] = dsys.fdx()
+        out["ds_%d_B" % k] = dsys.fdu()
+        out["ds_%d_lambda" % k] = mvi.lambda1
+        for zi in range(2):
+            out["ds_%d_fdxdx_%d" % (k, zi)] = dsys.fdxdx(Z[zi])
+            out["ds_%d_fdxdu_%d" % (k, zi)] = dsys.fdxdu(Z[zi])
+            out["ds_%d_fdudu_%d" % (k, zi)] = dsys.fdudu(Z[zi])
+    return out
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%.1f kB)" % (path, os.path.getsize(path) / 1e3))
+
+
+def gen_pendulum(links, n_steps, name):
+    system = systems.pendulum(links, api=trep)
+    q0 = system.q
+    U = np.zeros((n_steps, 0)); K = np.zeros((n_steps, 0))
+    r = rollout(system, q0, U, K, n_steps, deriv_steps=(1, 50, n_steps), deriv2_full=True)
+    ds = dsystem_captures(system, r["Q"][:60], r["P"][:60], U, K, (0, 10, 50), seed=11)
+    save(name, q0=q0, U=U, K=K, dt=DT, **topology(system), **r, **ds)
+
+
+def gen_known_answer():
+    """The reference's own known-answer case (examples/papers/tase2012/pend-single-step.py:10-41):
+    1-DOF pendulum m=l=1, g=9.8, q=0.2, p=0.5, u=0.8, dt=0.1."""
+    s = trep.System()
+    s.import_frames([trep.rx('theta', name='pend_angle'), [trep.tz(-1.0, name='pend_mass', mass=1.0)]])
+    trep.potentials.Gravity(s, (0, 0, -9.8))
+    trep.forces.ConfigForce(s, 'theta', 'theta-torque')
+    mvi = trep.MidpointVI(s, num_threads=1)
+    mvi.initialize_from_state(0.0, np.array([0.2]), np.array([0.5]))
+    it = mvi.step(0.1, np.array([0.8]))
+    mvi._calc_deriv2()
+    out = dict(q2=mvi.q2, p2=mvi.p2, iterations=np.array([it]))
+    for n in ("q2_dq1", "q2_dp1", "q2_du1", "p2_dq1", "p2_dp1", "p2_du1"):
+        out[n] = getattr(mvi, "_" + n).copy()
+    for n in ("q2_dq1dq1", "p2_dq1dq1", "q2_du1du1", "q2_dq1du1", "p2_dq1du1", "q2_dp1dp1"):
+        out[n] = getattr(mvi, "_" + n).copy()
+    save("known_answer_pendulum", **out)
+
+
+def gen_cart():
+    system = systems.pend_on_cart(api=trep)
+    rng = np.random.default_rng(20250 + 2)
+    B, N = 4, 200
+    x0 = rng.uniform(-1, 1, size=4096)[:B]
+    th0 = rng.uniform(-np.pi, np.pi, size=4096)[:B]
+    Uall = rng.standard_normal((4096, N, 1))[:B] * 2.0
+    K = np.zeros((N, 0))
+    arrays = dict(dt=DT, **topology(system))
+    for b in range(B):
+        q0 = np.array([x0[b], th0[b]])
+        r = rollout(system, q0, Uall[b], K, N, deriv_steps=(1, 50, N) if b == 0 else (), deriv2_full=True)
+        for key, val in r.items():
+            arrays["b%d_%s" % (b, key)] = val
+        arrays["b%d_q0" % b] = q0
+        arrays["b%d_U" % b] = Uall[b]
+    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], Uall[0], K, (0, 10, 100), seed=12)
+    save("pend_on_cart", **arrays, **ds)
+
+
+def gen_scissor():
+    system = systems.scissor_lift(4, api=trep)
+    rng = np.random.default_rng(20250 + 5)
+    B, N = 2, 200
+    th = rng.uniform(0.03 * np.pi, 0.12 * np.pi, size=4096)[:B]
+    U = np.zeros((N, 0)); K = np.zeros((N, 0))
+    arrays = dict(dt=DT, theta0=th, **topology(system))
+    for b in range(B):
+        q0 = systems.scissor_q(system, th[b])
+        r = rollout(system, q0, U, K, N, deriv_steps=(1, 50, N) if b == 0 else (), deriv2_full=True)
+        for key, val in r.items():
+            arrays["b%d_%s" % (b, key)] = val
+        arrays["b%d_q0" % b] = q0
+    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], U, K, (0, 10, 100), seed=13)
+    save("scissor4", **arrays, **ds)
+
+
+def gen_puppet():
+    system = systems.puppet(api=trep)
+    B, N = 2, 200
+    Q0 = systems.puppet_initial_conditions(system, B)
+    nd = system.nQd
+    Kall = systems.puppet_string_schedule(system, Q0[:, nd:], N, DT)
+    U = np.zeros((N, 0))
+    arrays = dict(dt=DT, **topology(system))
+    select = ("q2_dq1dq1", "p2_dq1dk2", "l1_dk2dk2", "q2_dp1dp1", "p2_dk2dk2")
+    for b in range(B):
+        r = rollout(system, Q0[b], U, Kall[b], N, deriv_steps=(1, 100) if b == 0 else (),
+                    deriv2_select=select)
+        for key, val in r.items():
+            arrays["b%d_%s" % (b, key)] = val
+        arrays["b%d_q0" % b] = Q0[b]
+        arrays["b%d_K" % b] = Kall[b]
+    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], U, Kall[0], (0, 10, 100), seed=14)
+    # the base-pose first step quoted in SURVEY.md Appendix A
+    system.q = 0.0
+    system.q = systems.PUPPET_BASE_POSE
+    system.project_string_controls()
+    q0 = system.q
+    mvi = trep.MidpointVI(system, num_threads=1)
+    mvi.initialize_from_configs(0.0, q0, DT, q0)
+    it = mvi.step(2 * DT, (), q0[nd:])
+    arrays.update(base_q0=q0, base_q2=mvi.q2, base_p2=mvi.p2, base_lambda1=mvi.lambda1, base_it=np.array([it]))
+    save("puppet40", **arrays, **ds)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet"]
+    if "known" in which:
+        gen_known_answer()
+    if "pend1" in which:
+        gen_pendulum(1, 1000, "pendulum1")
+    if "pend5" in which:
+        gen_pendulum(5, 200, "pendulum5")
+    if "cart" in which:
+        gen_cart()
+    if "scissor" in which:
+        gen_scissor()
+    if "puppet" in which:
+        gen_puppet()
