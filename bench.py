@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- DEL-steps/s x batch for the ~40-DOF puppet (BASELINE.json metric), 1..8 MI355X.
+
+One "step" (in the driver's sense: --steps K, --warmup W) is one pass of the hot path over one
+batch: a device-resident rollout of N_ROLLOUT = 200 MidpointVI steps for BATCH = 8192 independent
+puppet trajectories per GPU, in ONE kernel launch, inputs (initial state, kinematic string schedule
+K[b,k,:]) already resident in HBM, states X[b,k,:] written back to HBM.  value = DEL steps of all
+ranks / wall time between barriers.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: the batch shards trivially (weak scaling: 8192 trajectories per GPU), no data-path
+collective; after each rollout the ranks all-gather the terminal states [B_local][nX] over
+RCCL/xGMI (what a discopt line-search consumes).  torch is used only for that (process group,
+barrier, the gather buffer); the product path itself is libtrepamd.so through ctypes.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X datasheet, vector fp64 (secondary figure; the path is fp64-VALU bound)
+REFERENCE_TREP_STEPS_PER_S = 345.0  # reference _trep, 1 Xeon 2.1 GHz core, Puppet-40
+
+
+def build_workload(args, rank):
+    from trep_amd import systems
+    system = systems.puppet()
+    B, N, dt = args.batch, args.rollout_steps, 0.01
+    nd = system.nQd
+    # 256 distinct seeded initial conditions, tiled over the batch (building 8192 host-side FK poses
+    # in Python would dominate start-up); each rank takes its own seed so shards differ.
+    distinct = min(B, 256)
+    base = systems.puppet_initial_conditions(system, distinct, seed=20250 + 3 + 1000 * rank)
+    Q0 = np.tile(base, ((B + distinct - 1) // distinct, 1))[:B]
+    K = systems.puppet_string_schedule(system, Q0[:, nd:], N, dt)
+    return system, Q0, K, dt
+
+
+def cpu_baseline(system, Q0, K, dt, budget_s=12.0):
+    """Oracle (C restatement of the reference, 1 thread) on a bounded sample of the same workload."""
+    from trep_amd import descriptor
+    from oracle.oracle import OracleMVI
+    o = OracleMVI(descriptor.flatten(system))
+    steps = 0
+    t0 = time.perf_counter()
+    b = 0
+    chunk = 50
+    while time.perf_counter() - t0 < budget_s and b < len(Q0):
+        o.initialize_from_configs(0.0, Q0[b], dt, Q0[b])
+        k = 0
+        while k < K.shape[1] and time.perf_counter() - t0 < budget_s:
+            n = min(chunk, K.shape[1] - k)
+            o.rollout(n, dt, None, K[b, k:k + n], want_X=False)
+            k += n
+            steps += n
+        b += 1
+    el = time.perf_counter() - t0
+    return {"value": steps / el, "unit": "DEL-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d puppet-40 DEL steps of the same rollouts, oracle/libtreporacle.so single thread, %.1f s" % (steps, el),
+            "reference_trep_single_core_steps_per_s": REFERENCE_TREP_STEPS_PER_S}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8192, help="trajectories per GPU")
+    ap.add_argument("--rollout-steps", type=int, default=200, help="DEL steps per trajectory per pass")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-x", action="store_true", help="do not write the state trajectory X to HBM")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        # torch first: its bundled HIP runtime (same SONAME) is then the single runtime of the process
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import trep_amd
+
+    system, Q0, K, dt = build_workload(args, rank)
+    B, N = args.batch, args.rollout_steps
+    mvi = trep_amd.BatchMidpointVI(system, B, device=local_rank)
+    nX, nU, nc = mvi.nX, mvi.nU, mvi.nc
+    K_dev = mvi.device_array(K)
+    gather = None
+    if world > 1:
+        X_t = None if args.no_x else torch.empty((B, N + 1, nX), dtype=torch.float64, device="cuda")
+        X_dev = None if X_t is None else X_t.data_ptr()
+        gather = torch.empty((world * B, nX), dtype=torch.float64, device="cuda")
+        term = torch.empty((B, nX), dtype=torch.float64, device="cuda")
+    else:
+        X_dev = None if args.no_x else mvi.device_empty(B * (N + 1) * nX)
+
+    def reset():
+        mvi.initialize_from_configs(0.0, Q0, dt, Q0)
+
+    def one_pass():
+        mvi.restore()   # device-to-device: every pass integrates the same 200-step window
+        mvi.rollout_device(N, dt, None, K_dev, X_dev)
+        if world > 1:
+            mvi.synchronize()
+            if X_t is not None:
+                term.copy_(X_t[:, N, :])
+            dist.all_gather_into_tensor(gather, term)
+
+    def sync():
+        mvi.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    reset()
+    mvi.snapshot()
+    for _ in range(args.warmup):
+        one_pass()
+    sync()
+    mvi.timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    n_launch, kernel_ms = mvi.timing(reset=True)
+    iters, status = mvi.status()
+    total_iters = int(iters.sum())
+    n_failed = int((status != 0).sum())
+
+    if rank == 0:
+        del_steps = float(world) * B * N * args.steps
+        value = del_steps / elapsed
+        avg_kernel_s = kernel_ms / 1e3 / max(n_launch, 1)
+        bytes_per_step = 8.0 * (2 * nX + nU + nc)   # read X_k, U_k; write X_k+1, lambda
+        algo_bytes = bytes_per_step * B * N
+        achieved = algo_bytes / avg_kernel_s / 1e9
+        out = {
+            "metric": "DEL-steps/sec x batch (puppet ~40-DOF, fp64)",
+            "value": value, "unit": "DEL-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Puppet(string_constraints=True) nq=40 nd=22 nk=18 nc=6, batch=%d rollouts per GPU x %d DEL steps, dt=0.01" % (B, N),
+                       "global_batch": world * B, "rollout_steps": N, "parallelism": "batch-shard x%d" % world,
+                       "team": mvi.info()["team"], "lds_bytes_per_trajectory": mvi.info()["lds_bytes_per_trajectory"],
+                       "newton_iterations_per_step": total_iters / float(B * N), "failed_trajectories": n_failed,
+                       "writes_X": not args.no_x},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_run<%d> (rollout)" % mvi.info()["team"],
+                         "kernel_avg_ms": 1e3 * avg_kernel_s, "launches": n_launch,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "path is fp64-VALU/LDS-latency bound, not HBM bound (SURVEY.md §8d)"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(system, Q0, K, dt)
+            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    mvi.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

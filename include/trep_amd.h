@@ -109,6 +109,10 @@ void tg_system_destroy(tg_system *sys);
 /* sizes: out[0..5] = nq, nd, nk, nu, nc, nX(=nq+nd+nk) */
 int tg_system_sizes(const tg_system *sys, int32_t out[6]);
 
+/* Introspection: out[0..7] = team size (lanes per trajectory), LDS bytes per trajectory, joints,
+ * levels, bodies, (body,config) items, (item,item) pairs, constraint-Jacobian items. */
+int tg_system_info(const tg_system *sys, int32_t out[8]);
+
 /* A batch of `batch` independent trajectories of `sys` resident on HIP device `device`. */
 tg_batch *tg_batch_create(tg_system *sys, int32_t batch, int32_t device);
 void tg_batch_destroy(tg_batch *b);
@@ -155,6 +159,12 @@ int tg_batch_rollout(tg_batch *b, int32_t n_steps, double dt, const double *U_de
                      const double *K_dev, double *X_dev, int32_t max_iterations);
 int tg_batch_rollout_stats(tg_batch *b, int64_t *total_iterations, int32_t *n_failed);
 int tg_batch_status(tg_batch *b, int32_t *iterations_out, int32_t *status_out);
+
+/* Device-side snapshot / restore of the whole integrator state (q1,q2,p1,p2,lambda1,u1,t1,t2):
+ * asynchronous device-to-device copies on the batch's stream.  Lets a caller replay rollouts from
+ * the same state (line-search candidates, benchmarks) without touching the host. */
+int tg_batch_snapshot(tg_batch *b);
+int tg_batch_restore(tg_batch *b);
 
 /* First derivatives of the last solved step (reference MidpointVI_calc_deriv1,
  * midpointvi.c:1100-1120); results are read with tg_batch_get(TG_F_Q2_DQ1 ...). */

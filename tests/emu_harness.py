@@ -1,0 +1,104 @@
+"""ctypes driver for tests/emu/libtrepamd_emu.so: the device kernel source compiled for the host
+(TEAM = 1).  Test infrastructure only; lets the CPU suite exercise the kernel logic without a GPU."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_LIB = None
+
+_D = ctypes.POINTER(ctypes.c_double)
+_I = ctypes.POINTER(ctypes.c_int)
+
+
+class RunArgs(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_int), ("n_steps", ctypes.c_int), ("max_iterations", ctypes.c_int),
+                ("mode", ctypes.c_int), ("first_is_init", ctypes.c_int),
+                ("dt", ctypes.c_double), ("t1", ctypes.c_double), ("t2", ctypes.c_double),
+                ("tolerance", ctypes.c_double),
+                ("q1", _D), ("q2", _D), ("p1", _D), ("p2", _D), ("lam", _D), ("u1", _D),
+                ("U", _D), ("K", _D), ("q2_hint", _D), ("lam_hint", _D), ("X", _D), ("f_out", _D),
+                ("iters", _I), ("status", _I)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "emu", "libtrepamd_emu.so")
+        srcs = [os.path.join(_HERE, "emu", "emu.cpp"),
+                os.path.join(_ROOT, "trep_amd", "csrc", "mvi_core.hpp"),
+                os.path.join(_ROOT, "trep_amd", "csrc", "program.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]], check=True)
+        L = ctypes.CDLL(so)
+        L.emu_create.restype = ctypes.c_void_p
+        L.emu_create.argtypes = [ctypes.c_void_p]
+        L.emu_destroy.argtypes = [ctypes.c_void_p]
+        L.emu_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.emu_lds_doubles.argtypes = [ctypes.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return None if a is None or a.size == 0 else a.ctypes.data_as(_D)
+
+
+class EmuBatch(object):
+    """Batch state + the three kernel modes, mirroring what tg_batch_* does on the device."""
+
+    def __init__(self, desc, batch, tolerance=1e-10):
+        self.L = lib()
+        self.h = self.L.emu_create(ctypes.addressof(desc.struct))
+        assert self.h
+        self.desc = desc
+        self.B = batch
+        self.nq, self.nd, self.nk = int(desc.n_configs), int(desc.n_dyn), int(desc.n_kin)
+        self.nu, self.nc = int(desc.n_inputs), int(desc.n_constraints)
+        self.nX = self.nq + self.nd + self.nk
+        z = lambda w: np.zeros((batch, w))
+        self.q1, self.q2, self.p1, self.p2, self.lam, self.u1 = z(self.nq), z(self.nq), z(self.nd), z(self.nd), z(self.nc), z(self.nu)
+        self.iters = np.zeros(batch, dtype=np.int32)
+        self.status = np.zeros(batch, dtype=np.int32)
+        self.t1 = self.t2 = 0.0
+        self.tol = tolerance
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.emu_destroy(self.h)
+            self.h = None
+
+    def _args(self, mode, n_steps=0, dt=0.0, U=None, K=None, X=None, f=None, q2_hint=None, lam_hint=None, max_it=200):
+        a = RunArgs()
+        a.batch, a.n_steps, a.max_iterations, a.mode = self.B, n_steps, max_it, mode
+        a.dt, a.t1, a.t2, a.tolerance = dt, self.t1, self.t2, self.tol
+        a.q1, a.q2, a.p1, a.p2, a.lam, a.u1 = _p(self.q1), _p(self.q2), _p(self.p1), _p(self.p2), _p(self.lam), _p(self.u1)
+        a.U, a.K, a.X, a.f_out, a.q2_hint, a.lam_hint = _p(U), _p(K), _p(X), _p(f), _p(q2_hint), _p(lam_hint)
+        a.iters = self.iters.ctypes.data_as(_I)
+        a.status = self.status.ctypes.data_as(_I)
+        return a
+
+    def initialize_from_configs(self, t0, Q0, t1, Q1):
+        self.t1, self.t2 = t0, t1
+        self.q1[:], self.q2[:] = Q0, Q1
+        a = self._args(1)
+        self.L.emu_run(self.h, ctypes.byref(a))
+        self.lam[:] = 0.0
+
+    def calc_f(self):
+        f = np.zeros((self.B, self.nd + self.nc))
+        a = self._args(2, f=f)
+        self.L.emu_run(self.h, ctypes.byref(a))
+        return f
+
+    def rollout(self, n_steps, dt, U=None, K=None, want_X=True, q2_hint=None, lam_hint=None):
+        U = None if U is None else np.ascontiguousarray(U, dtype=float)
+        K = None if K is None else np.ascontiguousarray(K, dtype=float)
+        X = np.zeros((self.B, n_steps + 1, self.nX)) if want_X else None
+        a = self._args(0, n_steps, dt, U, K, X, q2_hint=q2_hint, lam_hint=lam_hint)
+        self.L.emu_run(self.h, ctypes.byref(a))
+        self.t1, self.t2 = self.t2 + (n_steps - 1) * dt, self.t2 + n_steps * dt
+        return X

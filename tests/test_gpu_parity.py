@@ -1,0 +1,213 @@
+"""Parity of the HIP path (through the C ABI, on a real MI355X) with the reference golden vectors,
+the oracle, and size-independent properties at the BASELINE batch sizes."""
+import numpy as np
+import pytest
+
+from common import BUILDERS, build, golden, trajectories, relerr
+
+pytestmark = pytest.mark.gpu
+
+DT = 0.01
+TOL = 1e-10  # BASELINE.json north_star: fp64 state within 1e-10 of the reference
+
+
+def _batch(system, B):
+    import trep_amd
+    return trep_amd.BatchMidpointVI(system, B)
+
+
+def test_library_reports_device():
+    from trep_amd import _lib
+    assert _lib.lib().tg_device_count() >= 1
+    assert b"gfx950" in _lib.lib().tg_version()
+
+
+def test_known_answer_single_pendulum():
+    """examples/papers/tase2012/pend-single-step.py:32-41 through the drop-in MidpointVI."""
+    import trep_amd as T
+    g = golden("known_answer_pendulum")
+    s = T.System()
+    s.import_frames([T.rx('theta', name='pend_angle'), [T.tz(-1.0, name='pend_mass', mass=1.0)]])
+    T.potentials.Gravity(s, (0, 0, -9.8))
+    T.forces.ConfigForce(s, 'theta', 'theta-torque')
+    mvi = T.MidpointVI(s)
+    mvi.initialize_from_state(0.0, np.array([0.2]), np.array([0.5]))
+    assert mvi.step(0.1, np.array([0.8])) == 2
+    assert abs(mvi.q2[0] - 0.2471361941555716) < 1e-13
+    assert abs(mvi.q2[0] - g["q2"][0]) < 1e-14
+    assert abs(mvi.p2[0] - g["p2"][0]) < 1e-14
+    assert abs(mvi.t1 - 0.0) < 1e-15 and abs(mvi.t2 - 0.1) < 1e-15
+    assert abs(mvi.p1[0] - 0.5) < 1e-15 and abs(mvi.q1[0] - 0.2) < 1e-15
+
+
+@pytest.mark.parametrize("name", sorted(BUILDERS))
+def test_rollout_matches_reference(name):
+    g = golden(name)
+    system, d = build(name)
+    trajs = trajectories(name)
+    B = len(trajs)
+    n = len(g[trajs[0][0] + "IT"])
+    mvi = _batch(system, B)
+    Q0 = np.array([t[1] for t in trajs])
+    mvi.initialize_from_configs(0.0, Q0, DT, Q0)
+    P0 = mvi.p2
+    for b, (prefix, _, _, _) in enumerate(trajs):
+        assert relerr(P0[b], g[prefix + "P"][0]) < 1e-12
+    U = np.array([t[2] for t in trajs])
+    K = np.array([t[3] for t in trajs])
+    X = mvi.rollout(n, DT, U, K)
+    iters, status = mvi.status()
+    assert (status == 0).all()
+    nq, nd = d.n_configs, d.n_dyn
+    lam = mvi.lambda1
+    for b, (prefix, _, _, _) in enumerate(trajs):
+        assert relerr(X[b, :, :nq], g[prefix + "Q"]) < TOL, name
+        assert relerr(X[b, :, nq:nq + nd], g[prefix + "P"]) < 1e-9, name
+        assert relerr(lam[b], g[prefix + "LAM"][n]) < 1e-7
+        assert abs(int(iters[b]) - int(g[prefix + "IT"].sum())) <= max(2, n // 100)
+    t1, t2 = mvi.times()
+    assert abs(t2 - (n + 1) * DT) < 1e-12 and abs(t1 - n * DT) < 1e-12
+    mvi.close()
+
+
+@pytest.mark.parametrize("name", ["pend_on_cart", "puppet40", "scissor4"])
+def test_stepwise_api_matches_reference(name):
+    """MidpointVI.step() called once per step (teacher-forced from the reference's states)."""
+    import trep_amd
+    g = golden(name)
+    system, d = build(name)
+    prefix, q0, U, K = trajectories(name)[0]
+    Q, P, LAM, IT = g[prefix + "Q"], g[prefix + "P"], g[prefix + "LAM"], g[prefix + "IT"]
+    mvi = trep_amd.MidpointVI(system)
+    for k in [0, 1, 2, 9, 49, len(Q) - 2]:
+        mvi.initialize_from_state((k + 1) * DT, Q[k], P[k], LAM[k])
+        it = mvi.step((k + 2) * DT, U[k], K[k])
+        assert abs(it - IT[k]) <= (0 if k < 100 else 1)
+        assert relerr(mvi.q2, Q[k + 1]) < 1e-11
+        assert relerr(mvi.p2, P[k + 1]) < 1e-10
+        assert relerr(mvi.lambda1, LAM[k + 1]) < 1e-8
+        assert relerr(mvi.q1, Q[k]) == 0.0 and relerr(mvi.p1, P[k]) == 0.0
+
+
+def test_free_running_steps_pendulum_1000():
+    """BASELINE configs[0]: examples/pendulum.py, 1 link, 1000 steps."""
+    import trep_amd
+    g = golden("pendulum1")
+    system, d = build("pendulum1")
+    mvi = trep_amd.MidpointVI(system)
+    q0 = g["q0"]
+    mvi.initialize_from_configs(0.0, q0, DT, q0)
+    its = []
+    for k in range(200):
+        its.append(mvi.step(mvi.t2 + DT))
+        assert abs(mvi.q2[0] - g["Q"][k + 1][0]) < TOL
+    assert its == list(g["IT"][:200])
+    b = trep_amd.BatchMidpointVI(system, 1)
+    b.initialize_from_configs(0.0, q0[None, :], DT, q0[None, :])
+    X = b.rollout(1000, DT)
+    assert relerr(X[0, :, 0], g["Q"][:, 0]) < TOL
+
+
+def test_residual_matches_oracle():
+    from oracle.oracle import OracleMVI
+    system, d = build("puppet40")
+    g = golden("puppet40")
+    rng = np.random.default_rng(5)
+    B = 8
+    mvi = _batch(system, B)
+    q1 = np.repeat(g["b0_Q"][10][None, :], B, 0)
+    q2 = q1.copy()
+    q2[:, :d.n_dyn] += rng.uniform(-1e-3, 1e-3, (B, d.n_dyn))
+    q2[:, d.n_dyn:] = g["b0_K"][10]
+    p1 = np.repeat(g["b0_P"][10][None, :], B, 0)
+    lam = np.repeat(g["b0_LAM"][10][None, :], B, 0)
+    mvi.set_times(0.1, 0.11)
+    mvi.q1, mvi.q2, mvi.p1, mvi.lambda1 = q1, q2, p1, lam
+    f = mvi.calc_f()
+    o = OracleMVI(d)
+    for b in range(B):
+        o.q1, o.q2, o.p1, o.lambda1 = q1[b], q2[b], p1[b], lam[b]
+        o.set_times(0.1, 0.11)
+        assert relerr(f[b], o.calc_f()) < 1e-12
+
+
+@pytest.mark.parametrize("name,B,N", [("puppet40", 48, 40), ("scissor4", 33, 60), ("pend_on_cart", 67, 100)])
+def test_random_batch_matches_oracle(name, B, N):
+    """Seeded random initial conditions / inputs, HIP vs oracle, ragged batch sizes."""
+    from oracle.oracle import OracleMVI
+    from trep_amd import systems
+    system, d = build(name)
+    rng = np.random.default_rng(99)
+    nq, nd, nk, nu = d.n_configs, d.n_dyn, d.n_kin, d.n_inputs
+    if name == "puppet40":
+        Q0 = systems.puppet_initial_conditions(system, B, seed=7)
+        K = systems.puppet_string_schedule(system, Q0[:, nd:], N, DT)
+        U = np.zeros((B, N, 0))
+    elif name == "scissor4":
+        th = rng.uniform(0.03 * np.pi, 0.12 * np.pi, B)
+        Q0 = np.array([systems.scissor_q(system, t) for t in th])
+        K = np.zeros((B, N, 0)); U = np.zeros((B, N, 0))
+    else:
+        Q0 = np.stack([rng.uniform(-1, 1, B), rng.uniform(-np.pi, np.pi, B)], 1)
+        U = rng.standard_normal((B, N, 1)) * 2.0
+        K = np.zeros((B, N, 0))
+    mvi = _batch(system, B)
+    mvi.initialize_from_configs(0.0, Q0, DT, Q0)
+    X = mvi.rollout(N, DT, U, K)
+    iters, status = mvi.status()
+    assert (status == 0).all()
+    o = OracleMVI(d)
+    for b in range(B):
+        o.initialize_from_configs(0.0, Q0[b], DT, Q0[b])
+        Xo, tot = o.rollout(N, DT, U[b], K[b])
+        assert relerr(X[b], Xo) < TOL, (name, b)
+        assert abs(tot - iters[b]) <= 1
+    mvi.close()
+
+
+def test_full_size_properties_puppet():
+    """BASELINE puppet size (B=8192, N=200): every trajectory converges, the DEL residual of the final
+    state vanishes, and results do not depend on batch composition (bit-identical sub-batch)."""
+    from trep_amd import systems
+    system, d = build("puppet40")
+    B, N = 8192, 200
+    nd = d.n_dyn
+    base = systems.puppet_initial_conditions(system, 64, seed=20250 + 3)
+    Q0 = np.tile(base, (B // 64, 1))
+    K = systems.puppet_string_schedule(system, Q0[:, nd:], N, DT)
+    mvi = _batch(system, B)
+    mvi.initialize_from_configs(0.0, Q0, DT, Q0)
+    K_dev = mvi.device_array(K)
+    mvi.rollout_device(N, DT, None, K_dev, None)
+    mvi.synchronize()
+    iters, status = mvi.status()
+    assert (status == 0).all()
+    assert 2.0 <= iters.mean() / N <= 3.2   # reference: 2.57 Newton iterations per step
+    f = mvi.calc_f()
+    assert np.linalg.norm(f[:, :nd], axis=1).max() < 1e-10
+    assert np.abs(f[:, nd:]).max() < 1e-10
+    q2 = mvi.q2
+    assert np.array_equal(q2[:64], q2[64:128])      # duplicates are bit-identical
+    sub = _batch(system, 64)
+    sub.initialize_from_configs(0.0, base, DT, base)
+    sub.rollout(N, DT, None, K[:64])
+    assert np.array_equal(sub.q2, q2[:64])          # independent of batch size / placement
+    mvi.close(); sub.close()
+
+
+def test_failure_statuses_and_edge_cases():
+    import trep_amd
+    system, d = build("pend_on_cart")
+    mvi = _batch(system, 5)
+    q0 = np.array([[0.1 * b, 1.0 + 0.1 * b] for b in range(5)])
+    mvi.initialize_from_configs(0.0, q0, DT, q0)
+    it, st = mvi.step(2 * DT, np.ones((5, 1)), None, max_iterations=0)
+    assert (st == 1).all()                         # one Newton step is not enough: not converged
+    mvi.initialize_from_configs(0.0, q0, DT, q0)
+    it, st = mvi.step(2 * DT, np.ones((5, 1)), None)
+    assert (st == 0).all() and (it >= 1).all()
+    one = trep_amd.MidpointVI(system)
+    one.initialize_from_configs(0.0, q0[0], DT, q0[0])
+    with pytest.raises(trep_amd.ConvergenceError):
+        one.step(2 * DT, [1.0], max_iterations=0)
+    mvi.close()

@@ -1,0 +1,106 @@
+"""ctypes binding of libtrepamd.so (the HIP library; C ABI in include/trep_amd.h).
+
+There is deliberately no fallback: if the shared library is missing or no HIP
+device is visible, the integrator raises instead of computing anything on the CPU.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .descriptor import SystemDescStruct
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrepamd.so")
+_LIB = None
+
+_c_dp = ctypes.POINTER(ctypes.c_double)
+_c_ip = ctypes.POINTER(ctypes.c_int32)
+
+# field ids of include/trep_amd.h
+F_Q1, F_Q2, F_P1, F_P2, F_U1, F_LAMBDA1 = 0, 1, 2, 3, 4, 5
+OK, NOT_CONVERGED, SINGULAR = 0, 1, 2
+
+_SIGNATURES = {
+    "tg_version": (ctypes.c_char_p, []),
+    "tg_last_error": (ctypes.c_char_p, []),
+    "tg_device_count": (ctypes.c_int, []),
+    "tg_system_create": (ctypes.c_void_p, [ctypes.POINTER(SystemDescStruct)]),
+    "tg_system_destroy": (None, [ctypes.c_void_p]),
+    "tg_system_sizes": (ctypes.c_int, [ctypes.c_void_p, _c_ip]),
+    "tg_system_info": (ctypes.c_int, [ctypes.c_void_p, _c_ip]),
+    "tg_batch_create": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]),
+    "tg_batch_destroy": (None, [ctypes.c_void_p]),
+    "tg_batch_set_tolerance": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double]),
+    "tg_batch_set_times": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]),
+    "tg_batch_get_times": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp]),
+    "tg_batch_set": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
+    "tg_batch_get": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
+    "tg_batch_field_width": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    "tg_batch_calc_p2": (ctypes.c_int, [ctypes.c_void_p]),
+    "tg_batch_calc_f": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "tg_batch_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                     ctypes.c_void_p]),
+    "tg_batch_rollout": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_double, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
+    "tg_batch_rollout_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), _c_ip]),
+    "tg_batch_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "tg_batch_deriv1": (ctypes.c_int, [ctypes.c_void_p]),
+    "tg_batch_snapshot": (ctypes.c_int, [ctypes.c_void_p]),
+    "tg_batch_restore": (ctypes.c_int, [ctypes.c_void_p]),
+    "tg_device_alloc": (ctypes.c_void_p, [ctypes.c_int32, ctypes.c_uint64]),
+    "tg_device_free": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p]),
+    "tg_memcpy_h2d": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
+    "tg_memcpy_d2h": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
+    "tg_batch_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
+    "tg_batch_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "tg_batch_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _c_ip, _c_dp]),
+}
+
+
+class LibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libtrepamd.so (once).  Raises LibraryError if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise LibraryError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _LIB = L
+    return _LIB
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc):
+    if rc != 0:
+        raise LibraryError("libtrepamd error %d: %s" % (rc, lib().tg_last_error().decode()))
+
+
+def require_device():
+    n = lib().tg_device_count()
+    if n <= 0:
+        raise LibraryError("no HIP device visible; trep_amd has no CPU execution path")
+    return n
+
+
+def as_f64(a, shape):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.shape != tuple(shape):
+        raise ValueError("expected array of shape %r, got %r" % (tuple(shape), a.shape))
+    return a
+
+
+def ptr(a):
+    return None if a is None or a.size == 0 else a.ctypes.data

@@ -1,0 +1,518 @@
+// mvi_core.hpp -- the batched MidpointVI DEL step, written once for the device.
+//
+// One *team* of TEAM lanes (TEAM = 64: one wavefront per trajectory; smaller teams for small
+// systems) advances one trajectory; all of a trajectory's working data lives in the team's LDS
+// slice (layout: DevProg::o_*).  Work is organised as phases: inside a phase every lane processes
+// independent items `for (i = lane; i < n; i += TEAM)`, phases are separated by TG_SYNC().
+//
+// Math (equal to the reference's cached-table algorithm, verified to 1e-15 against
+// the oracle): world poses G_j of the variable frames by a level-ordered sweep; body Jacobian
+// columns J_{F,k} = Ad_{g_F}^{-1} s_k; v_F = sum_k J_k dq_k; with P_j = sum_{k<j} J_k dq_k and
+// [a,b] = ad_a b:   dv/dq_j = W_j = [P_j, J_j],   dJ_i/dq_j = [J_i, J_j] (i<j, else 0),
+//                   d2v/dq_i dq_j = [W_i, J_j] (i<=j).
+// These give L_dq, L_ddq, L_dqdq, L_ddqdq, L_ddqddq (reference system.c:129-557) and with them the
+// DEL residual and Newton matrix of midpointvi.c:533-670.  Constraint values/Jacobians use
+// dp_E/dq_k = w_k x (p_E - p_k) (rotary joint) or the joint axis (prismatic).
+//
+// The same source is compiled (a) by hipcc for gfx950 (trepamd.hip) and (b) by g++ with TEAM=1 as a
+// host emulation used ONLY by the CPU test-suite to check the kernel logic where no GPU exists
+// (tests/emu).  The product library contains no CPU path.
+#pragma once
+#include <cmath>
+
+#include "program.hpp"
+
+#if defined(__HIPCC__)
+#define TG_HD __host__ __device__ __forceinline__
+#define TG_SYNC() __syncthreads()
+#else
+#define TG_HD inline
+#define TG_SYNC() ((void)0)
+#endif
+
+#define TG_FOR(idx, n) for (int idx = lane; idx < (n); idx += TEAM)
+
+namespace tg {
+
+enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2 };
+
+struct RunArgs {
+    int batch, n_steps, max_iterations, mode, first_is_init;
+    double dt, t1, t2, tolerance;
+    double *q1, *q2, *p1, *p2, *lam, *u1;  // batch state, row-major [batch][width]
+    const double *U, *K;                   // [batch][n_steps][nu], [batch][n_steps][nk]
+    const double *q2_hint, *lam_hint;      // [batch][nd], [batch][nc] or null
+    double *X;                             // [batch][n_steps+1][nX] or null
+    double *f_out;                         // MODE_CALC_F: [batch][nf]
+    int *iters, *status;                   // [batch]
+};
+
+TG_HD void tg_sincos(double x, double *s, double *c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(x, s, c);
+#else
+    *s = std::sin(x);
+    *c = std::cos(x);
+#endif
+}
+
+// [a,b] = ad_a b for twists stored (v, w)
+TG_HD void bracket(const double *a, const double *b, double *r) {
+    r[0] = a[4] * b[2] - a[5] * b[1] + a[1] * b[5] - a[2] * b[4];
+    r[1] = a[5] * b[0] - a[3] * b[2] + a[2] * b[3] - a[0] * b[5];
+    r[2] = a[3] * b[1] - a[4] * b[0] + a[0] * b[4] - a[1] * b[3];
+    r[3] = a[4] * b[5] - a[5] * b[4];
+    r[4] = a[5] * b[3] - a[3] * b[5];
+    r[5] = a[3] * b[4] - a[4] * b[3];
+}
+TG_HD double inner6(const double *I, const double *a, const double *b) {
+    return I[0] * (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]) + I[1] * (a[3] * b[3]) + I[2] * (a[4] * b[4]) +
+           I[3] * (a[5] * b[5]);
+}
+
+template <int TEAM>
+struct Core {
+    const DevProg &P;
+    double *S;
+    int lane;
+    double dt;
+
+    TG_HD Core(const DevProg &p, double *s, int l, double dt_) : P(p), S(s), lane(l), dt(dt_) {}
+
+    // configuration value at the evaluation point: 0 midpoint, 1 q1, 2 q2 (midpointvi.c:401-457)
+    TG_HD double qval(int sel, int c) const {
+        double a = S[P.o_q1 + c], b = S[P.o_q2 + c];
+        return sel == 0 ? 0.5 * (b + a) : (sel == 1 ? a : b);
+    }
+
+    // ---- world poses of all joints, level by level; 12 lanes per joint ------------------------------
+    TG_HD void pose_sweep(bool on, int sel) {
+        double *sc = S + P.o_sc, *G = S + P.o_G;
+        if (on) TG_FOR(j, P.n_joints) {
+            double x = qval(sel, P.j_cfg[j]);
+            if (P.j_kind[j] >= TG_RX) tg_sincos(x, &sc[2 * j], &sc[2 * j + 1]);
+            else sc[2 * j] = x;
+        }
+        TG_SYNC();
+        for (int L = 0; L < P.n_levels; L++) {
+            const int j0 = P.level_off[L], cnt = P.level_off[L + 1] - j0;
+            if (on) TG_FOR(idx, 12 * cnt) {
+                const int j = j0 + idx / 12, e = idx % 12, r = e >> 2, c = e & 3;
+                const int parent = P.j_parent[j];
+                double g0, g1, g2, g3;
+                if (parent < 0) { g0 = (r == 0); g1 = (r == 1); g2 = (r == 2); g3 = 0.0; }
+                else { const double *gp = G + 12 * parent + 4 * r; g0 = gp[0]; g1 = gp[1]; g2 = gp[2]; g3 = gp[3]; }
+                const bool ident = P.j_pre_ident[j] != 0;
+                const double *pre = P.j_pre + 12 * j;
+                auto mcol = [&](int col) -> double {
+                    if (ident) return col == 0 ? g0 : (col == 1 ? g1 : (col == 2 ? g2 : g3));
+                    double v = g0 * pre[col] + g1 * pre[4 + col] + g2 * pre[8 + col];
+                    return col == 3 ? v + g3 : v;
+                };
+                const int kind = P.j_kind[j];
+                double val;
+                if (kind <= TG_TZ) {
+                    val = mcol(c);
+                    if (c == 3) val += sc[2 * j] * mcol(kind - TG_TX);
+                } else {
+                    const int a = kind - TG_RX, b = (a + 1) % 3, cc = (a + 2) % 3;
+                    const double sn = sc[2 * j], cs = sc[2 * j + 1];
+                    if (c == 3 || c == a) val = mcol(c);
+                    else if (c == b) val = cs * mcol(b) + sn * mcol(cc);
+                    else val = cs * mcol(cc) - sn * mcol(b);
+                }
+                G[12 * j + e] = val;
+            }
+            TG_SYNC();
+        }
+    }
+
+    // ---- poses of the massive frames and positions of the constraint end points --------------------
+    TG_HD void attach_points(bool on, bool bodies, bool endpoints) {
+        const double *G = S + P.o_G;
+        if (on && bodies) TG_FOR(idx, 12 * P.n_bodies) {
+            const int b = idx / 12, e = idx % 12, r = e >> 2, c = e & 3;
+            const double *C = P.b_C + 12 * b;
+            const int anchor = P.b_anchor[b];
+            double val;
+            if (anchor < 0) val = C[e];
+            else {
+                const double *g = G + 12 * anchor + 4 * r;
+                val = g[0] * C[c] + g[1] * C[4 + c] + g[2] * C[8 + c];
+                if (c == 3) val += g[3];
+            }
+            S[P.o_gB + idx] = val;
+        }
+        if (on && endpoints) TG_FOR(idx, 3 * P.n_endpoints) {
+            const int e = idx / 3, r = idx % 3;
+            const double *o = P.e_off + 3 * e;
+            const int anchor = P.e_anchor[e];
+            double val;
+            if (anchor < 0) val = o[r];
+            else { const double *g = G + 12 * anchor + 4 * r; val = g[0] * o[0] + g[1] * o[1] + g[2] * o[2] + g[3]; }
+            S[P.o_pE + idx] = val;
+        }
+        TG_SYNC();
+    }
+
+    // ---- body Jacobian columns J_{F,k} and gravity in body coordinates ------------------------------
+    TG_HD void jacobians(bool on) {
+        const double *G = S + P.o_G;
+        if (on) TG_FOR(it, P.n_items) {
+            const int b = P.it_body[it], j = P.it_joint[it], kind = P.j_kind[j];
+            const double *gb = S + P.o_gB + 12 * b, *gj = G + 12 * j;
+            double *J = S + P.o_J + 6 * it;
+            double lin[3], ang[3];
+            if (kind <= TG_TZ) {
+                const int a = kind - TG_TX;
+                lin[0] = gj[a]; lin[1] = gj[4 + a]; lin[2] = gj[8 + a];
+                ang[0] = ang[1] = ang[2] = 0.0;
+            } else {
+                const int a = kind - TG_RX;
+                ang[0] = gj[a]; ang[1] = gj[4 + a]; ang[2] = gj[8 + a];
+                const double dx = gb[3] - gj[3], dy = gb[7] - gj[7], dz = gb[11] - gj[11];
+                lin[0] = ang[1] * dz - ang[2] * dy; lin[1] = ang[2] * dx - ang[0] * dz; lin[2] = ang[0] * dy - ang[1] * dx;
+            }
+            for (int r = 0; r < 3; r++) {  // R_F^T applied to both parts
+                J[r] = gb[r] * lin[0] + gb[4 + r] * lin[1] + gb[8 + r] * lin[2];
+                J[3 + r] = gb[r] * ang[0] + gb[4 + r] * ang[1] + gb[8 + r] * ang[2];
+            }
+        }
+        if (on) TG_FOR(idx, 3 * P.n_bodies) {
+            const int b = idx / 3, r = idx % 3;
+            const double *gb = S + P.o_gB + 12 * b;
+            S[P.o_gam + idx] = gb[r] * P.grav[0] + gb[4 + r] * P.grav[1] + gb[8 + r] * P.grav[2];
+        }
+        TG_SYNC();
+    }
+
+    // ---- prefix velocities, W_j = [P_j, J_j], body velocity v_F --------------------------------------
+    TG_HD void velocities(bool on) {
+        const double *dq = S + P.o_dq;
+        if (on) TG_FOR(it, P.n_items) {
+            const int b = P.it_body[it], first = P.b_item_off[b], last = P.b_item_off[b + 1] - 1;
+            double Pp[6] = {0, 0, 0, 0, 0, 0};
+            for (int k = first; k < it; k++) {
+                const double *Jk = S + P.o_J + 6 * k;
+                const double r = dq[P.it_cfg[k]];
+                for (int m = 0; m < 6; m++) Pp[m] += Jk[m] * r;
+            }
+            const double *J = S + P.o_J + 6 * it;
+            bracket(Pp, J, S + P.o_W + 6 * it);
+            if (it == last) {
+                const double r = dq[P.it_cfg[it]];
+                for (int m = 0; m < 6; m++) S[P.o_vB + 6 * b + m] = Pp[m] + J[m] * r;
+            }
+        }
+        if (on) TG_FOR(b, P.n_bodies) {
+            if (P.b_item_off[b + 1] == P.b_item_off[b])
+                for (int m = 0; m < 6; m++) S[P.o_vB + 6 * b + m] = 0.0;
+        }
+        TG_SYNC();
+    }
+
+    // ---- L_dq, L_ddq per config and the dynamic part of the DEL residual (midpointvi.c:533-551) -------
+    TG_HD void residual_dyn(bool on) {
+        if (on) TG_FOR(i, P.nd) {
+            double ldq = 0.0, lddq = 0.0;
+            for (int n = P.cfg_item_off[i]; n < P.cfg_item_off[i + 1]; n++) {
+                const int it = P.cfg_items[n], b = P.it_body[it];
+                const double *I = P.b_inertia + 4 * b, *v = S + P.o_vB + 6 * b;
+                const double *J = S + P.o_J + 6 * it, *W = S + P.o_W + 6 * it, *gam = S + P.o_gam + 3 * b;
+                lddq += inner6(I, J, v);
+                ldq += inner6(I, W, v) + I[0] * (gam[0] * J[0] + gam[1] * J[1] + gam[2] * J[2]);
+            }
+            S[P.o_Ldq + i] = ldq; S[P.o_Lddq + i] = lddq;
+            double force = -P.damp[i] * S[P.o_dq + i];
+            for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
+            double f = S[P.o_p1 + i] + (0.5 * dt * ldq - lddq) + dt * force;
+            for (int c = 0; c < P.nc; c++) f -= S[P.o_Dh1 + c * P.nq + i] * S[P.o_lam + c];
+            S[P.o_f + i] = f;
+        }
+        TG_SYNC();
+    }
+
+    // d p_E / d q_k in world coordinates
+    TG_HD void dpos(int e, int j, double *d) const {
+        const double *gj = S + P.o_G + 12 * j;
+        const int kind = P.j_kind[j];
+        if (kind <= TG_TZ) { const int a = kind - TG_TX; d[0] = gj[a]; d[1] = gj[4 + a]; d[2] = gj[8 + a]; }
+        else {
+            const int a = kind - TG_RX;
+            const double wx = gj[a], wy = gj[4 + a], wz = gj[8 + a];
+            const double *pe = S + P.o_pE + 3 * e;
+            const double dx = pe[0] - gj[3], dy = pe[1] - gj[7], dz = pe[2] - gj[11];
+            d[0] = wy * dz - wz * dy; d[1] = wz * dx - wx * dz; d[2] = wx * dy - wy * dx;
+        }
+    }
+
+    // ---- constraint values (into f[nd..]) and Jacobian Dh (into dest) at the swept state -------------
+    // distance.c:16-63, point.c:16-38.  `sel` picks the config vector for the length configs.
+    TG_HD void constraints(bool on, int sel, bool want_h, double *Dh) {
+        if (on && want_h) TG_FOR(c, P.nc) {
+            const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
+            const double vx = a[0] - b[0], vy = a[1] - b[1], vz = a[2] - b[2];
+            double h;
+            if (P.c_type[c] == TG_CONSTRAINT_POINT) h = P.c_comp[c] == 0 ? vx : (P.c_comp[c] == 1 ? vy : vz);
+            else {
+                const double len = P.c_cfg[c] >= 0 ? qval(sel, P.c_cfg[c]) : P.c_dist[c];
+                h = (vx * vx + vy * vy + vz * vz) - len * len;
+            }
+            S[P.o_f + P.nd + c] = h;
+        }
+        if (on) TG_FOR(n, P.n_dh) {
+            const int c = P.dh_c[n], k = P.dh_cfg[n], j = P.dh_joint[n], side = P.dh_side[n];
+            double d1[3] = {0, 0, 0}, d2[3] = {0, 0, 0};
+            if (side & 1) dpos(P.c_e1[c], j, d1);
+            if (side & 2) dpos(P.c_e2[c], j, d2);
+            const double dx = d1[0] - d2[0], dy = d1[1] - d2[1], dz = d1[2] - d2[2];
+            double val;
+            if (P.c_type[c] == TG_CONSTRAINT_POINT) val = P.c_comp[c] == 0 ? dx : (P.c_comp[c] == 1 ? dy : dz);
+            else {
+                const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
+                val = (a[0] - b[0]) * dx + (a[1] - b[1]) * dy + (a[2] - b[2]) * dz;
+                if (side & 4) val -= qval(sel, k);
+                val *= 2.0;
+            }
+            Dh[c * P.nq + k] = val;
+        }
+        TG_SYNC();
+    }
+
+    // ---- Newton matrix [Df | f] (midpointvi.c:577-670) ---------------------------------------------------
+    TG_HD void newton_matrix(bool on) {
+        const int nd = P.nd, nf = P.nf, ld = P.df_ld;
+        double *A = S + P.o_Df;
+        if (on) TG_FOR(idx, nf * (nf + 1)) {
+            const int r = idx / (nf + 1), c = idx % (nf + 1);
+            double val;
+            if (c == nf) val = S[P.o_f + r];
+            else if (r < nd) val = c < nd ? (r == c ? -P.damp[r] : 0.0) : -S[P.o_Dh1 + (c - nd) * P.nq + r];
+            else val = c < nd ? S[P.o_Dh2 + (r - nd) * P.nq + c] : 0.0;
+            A[r * ld + c] = val;
+        }
+        TG_SYNC();
+        const double qdt = 0.25 * dt, rdt = 1.0 / dt;
+        for (int b = 0; b < P.n_bodies; b++) {
+            const int p0 = P.b_pair_off[b], np = P.b_pair_off[b + 1] - p0;
+            const double *I = P.b_inertia + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
+            if (on) TG_FOR(pp, np) {
+                const int ia = P.pair_a[p0 + pp], ib = P.pair_b[p0 + pp];
+                const int ca = P.it_cfg[ia], cb = P.it_cfg[ib];
+                if (ca >= nd || cb >= nd) continue;
+                const double *Ja = S + P.o_J + 6 * ia, *Jb = S + P.o_J + 6 * ib;
+                const double *Wa = S + P.o_W + 6 * ia, *Wb = S + P.o_W + 6 * ib;
+                double t[6];
+                bracket(Wa, Jb, t);
+                // L_dqdq(a,b) (system.c:158-202) with -V_dqdq = m gam . (w_a x v_b)
+                double lqq = inner6(I, t, v) + inner6(I, Wa, Wb) +
+                             I[0] * (gam[0] * (Ja[4] * Jb[2] - Ja[5] * Jb[1]) + gam[1] * (Ja[5] * Jb[0] - Ja[3] * Jb[2]) +
+                                     gam[2] * (Ja[3] * Jb[1] - Ja[4] * Jb[0]));
+                const double mab = inner6(I, Ja, Jb);  // L_ddqddq (system.c:459-489)
+                const double sym = qdt * lqq - rdt * mab;
+                if (ia == ib) {
+                    A[ca * ld + ca] += sym;
+                } else {
+                    bracket(Ja, Jb, t);
+                    const double c_ab = inner6(I, t, v) + inner6(I, Ja, Wb);  // L_ddqdq(dq a, q b) (system.c:294-334)
+                    const double c_ba = inner6(I, Jb, Wa);                    // L_ddqdq(dq b, q a)
+                    const double skew = 0.5 * (c_ba - c_ab);
+                    A[ca * ld + cb] += sym + skew;
+                    A[cb * ld + ca] += sym - skew;
+                }
+            }
+            TG_SYNC();
+        }
+    }
+
+    // ---- Gauss-Jordan on [A | rhs] with implicit-scaled partial pivoting (pivot rule of
+    //      math-code.c:337-432).  n_rhs right-hand-side columns follow the n matrix columns.
+    //      Returns false (team-uniform) if a scaled pivot is <= 1e-20.  Solution left in the rhs
+    //      columns divided through, i.e. A[i][n + r] = x_i.
+    TG_HD bool gauss_jordan(bool on, double *A, int n, int n_rhs, int ld, double *scal) {
+        bool ok = true;
+        if (on) TG_FOR(i, n) {
+            double s = -1.0;
+            for (int j = 0; j < n; j++) { const double a = fabs(A[i * ld + j]); if (a > s) s = a; }
+            scal[i] = 1.0 / s;
+        }
+        TG_SYNC();
+        const int w = n + n_rhs;
+        for (int k = 0; k < n; k++) {
+            int piv = k;
+            if (on && ok) {
+                double best = -1.0;
+                for (int i = k; i < n; i++) {
+                    const double a = fabs(A[i * ld + k] * scal[i]);
+                    if (a > best) { best = a; piv = i; }
+                }
+                if (!(best > 1.0e-20)) ok = false;
+            }
+            TG_SYNC();
+            if (on && ok && piv != k) {
+                TG_FOR(jj, w - k) {
+                    const int j = k + jj;
+                    const double t = A[k * ld + j]; A[k * ld + j] = A[piv * ld + j]; A[piv * ld + j] = t;
+                }
+                if (lane == 0) scal[piv] = scal[k];
+            }
+            TG_SYNC();
+            if (on && ok) {
+                const double rinv = 1.0 / A[k * ld + k];
+                const int cols = w - k - 1;
+                TG_FOR(idx, (n - 1) * cols) {
+                    int i = idx / cols;
+                    if (i >= k) i++;
+                    const int j = k + 1 + idx % cols;
+                    A[i * ld + j] -= (A[i * ld + k] * rinv) * A[k * ld + j];
+                }
+            }
+            TG_SYNC();
+        }
+        if (on && ok) TG_FOR(idx, n * n_rhs) {
+            const int i = idx / n_rhs, r = idx % n_rhs;
+            A[i * ld + n + r] /= A[i * ld + i];
+        }
+        TG_SYNC();
+        return ok;
+    }
+
+    // team-uniform convergence test (midpointvi.c:672-689)
+    TG_HD bool solved(double tolerance) const {
+        double norm = 0.0;
+        for (int i = 0; i < P.nd; i++) norm += S[P.o_f + i] * S[P.o_f + i];
+        if (sqrt(norm) > tolerance) return false;
+        for (int c = 0; c < P.nc; c++) if (fabs(S[P.o_f + P.nd + c]) > P.c_tol[c]) return false;
+        return true;
+    }
+
+    // midpoint evaluation shared by every mode: rates, poses, Jacobians, velocities, residual
+    TG_HD void eval_midpoint(bool on) {
+        if (on) TG_FOR(i, P.nq) S[P.o_dq + i] = (S[P.o_q2 + i] - S[P.o_q1 + i]) / dt;
+        TG_SYNC();
+        pose_sweep(on, 0);
+        attach_points(on, true, false);
+        jacobians(on);
+        velocities(on);
+        residual_dyn(on);
+    }
+    TG_HD void eval_constraints(bool on, int sel, bool want_h, double *Dh) {
+        if (P.nc == 0) return;
+        pose_sweep(on, sel);
+        attach_points(on, false, true);
+        constraints(on, sel, want_h, Dh);
+    }
+};
+
+// One trajectory (team) of a launch.  `traj` may be >= batch (idle team): it still takes part in
+// every TG_SYNC.
+template <int TEAM>
+TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lane, int traj) {
+    const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc;
+    const bool live = traj < A.batch;
+    const size_t t = (size_t)(live ? traj : 0);
+    double dt = A.mode == MODE_ROLLOUT ? A.dt : (A.t2 - A.t1);
+    Core<TEAM> core(P, S, lane, dt);
+
+    // ---- load state ----------------------------------------------------------------------------------
+    if (live) {
+        TG_FOR(i, nq) { S[P.o_q1 + i] = A.q1[t * nq + i]; S[P.o_q2 + i] = A.q2[t * nq + i]; }
+        TG_FOR(i, nd) S[P.o_p1 + i] = (A.mode == MODE_ROLLOUT) ? A.p2[t * nd + i] : A.p1[t * nd + i];
+        TG_FOR(i, nc) S[P.o_lam + i] = A.lam[t * nc + i];
+        TG_FOR(i, nu) S[P.o_u + i] = A.u1[t * nu + i];
+        TG_FOR(i, nc * nq) { S[P.o_Dh1 + i] = 0.0; S[P.o_Dh2 + i] = 0.0; }
+    }
+    TG_SYNC();
+
+    if (A.mode == MODE_CALC_P2) {  // MidpointVI.calc_p2: midpointvi.c:491-504
+        core.eval_midpoint(live);
+        if (live) TG_FOR(i, nd) A.p2[t * nd + i] = 0.5 * dt * S[P.o_Ldq + i] + S[P.o_Lddq + i];
+        return;
+    }
+    if (A.mode == MODE_CALC_F) {  // MidpointVI.calc_f: midpointvi.c:567-575
+        core.eval_constraints(live, 1, false, S + P.o_Dh1);
+        core.eval_midpoint(live);
+        core.eval_constraints(live, 2, true, S + P.o_Dh2);
+        if (live) TG_FOR(i, P.nf) A.f_out[t * P.nf + i] = S[P.o_f + i];
+        return;
+    }
+
+    // ---- rollout ----------------------------------------------------------------------------------------
+    const int nX = P.nX;
+    if (live && A.X) {  // X_0 = [q2; p2; v2] of the incoming state (dsystem.py:276-281, midpointvi.py:325-332)
+        double *x = A.X + t * (size_t)(A.n_steps + 1) * nX;
+        TG_FOR(i, nq) x[i] = S[P.o_q2 + i];
+        TG_FOR(i, nd) x[nq + i] = S[P.o_p1 + i];
+        TG_FOR(i, nk) x[nq + nd + i] = (A.t2 != A.t1) ? (S[P.o_q2 + nd + i] - S[P.o_q1 + nd + i]) / (A.t2 - A.t1) : 0.0;
+    }
+    bool failed = false;
+    int status = TG_OK, total_iters = 0;
+    for (int step = 0; step < A.n_steps; step++) {
+        const bool on = live && !failed;
+        // advance: q1 <- q2, (p1 already holds p2), inputs, kinematic targets, hints (midpointvi.py:188-197)
+        if (on) {
+            TG_FOR(i, nq) S[P.o_q1 + i] = S[P.o_q2 + i];
+            TG_FOR(i, nu) S[P.o_u + i] = A.U[(t * A.n_steps + step) * nu + i];
+            // the momentum entering the last step is the state's p1 afterwards (midpointvi.py:189)
+            if (step == A.n_steps - 1) TG_FOR(i, nd) A.p1[t * nd + i] = S[P.o_p1 + i];
+        }
+        TG_SYNC();
+        if (on) {
+            TG_FOR(i, nk) S[P.o_q2 + nd + i] = A.K[(t * A.n_steps + step) * nk + i];
+            if (A.q2_hint && step == 0) TG_FOR(i, nd) S[P.o_q2 + i] = A.q2_hint[t * nd + i];
+            if (A.lam_hint && step == 0) TG_FOR(i, nc) S[P.o_lam + i] = A.lam_hint[t * nc + i];
+        }
+        TG_SYNC();
+        // Dh at q1, held fixed during the solve (midpointvi.c:705-707).  After the first step it is the
+        // Dh2 of the previous step's converged q2 (same point, same inputs), so only step 0 sweeps.
+        if (step == 0) core.eval_constraints(on, 1, false, S + P.o_Dh1);
+        else if (nc) {
+            if (on) TG_FOR(i, nc * nq) S[P.o_Dh1 + i] = S[P.o_Dh2 + i];
+            TG_SYNC();
+        }
+        int iterations = 0;
+        bool done = !on;
+        for (;;) {
+            core.eval_midpoint(!done);
+            core.eval_constraints(!done, 2, true, S + P.o_Dh2);
+            if (!done && core.solved(A.tolerance)) done = true;
+            if (!done && iterations > A.max_iterations) { done = true; failed = true; status = TG_NOT_CONVERGED; }
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (__syncthreads_and(done ? 1 : 0)) break;
+#else
+            if (done) break;
+#endif
+            core.newton_matrix(!done);
+            const bool ok = core.gauss_jordan(!done, S + P.o_Df, P.nf, 1, P.df_ld, S + P.o_scal);
+            if (!done && !ok) { done = true; failed = true; status = TG_SINGULAR; }
+            if (!done) {
+                TG_FOR(i, nd) S[P.o_q2 + i] -= S[P.o_Df + i * P.df_ld + P.nf];
+                TG_FOR(c, nc) S[P.o_lam + c] -= S[P.o_Df + (nd + c) * P.df_ld + P.nf];
+                iterations++;
+            }
+            TG_SYNC();
+        }
+        if (on && !failed) {
+            total_iters += iterations;
+            // p2 = D2L2 at the converged midpoint (midpointvi.c:742-743); it becomes p1 of the next step
+            TG_FOR(i, nd) S[P.o_p1 + i] = 0.5 * dt * S[P.o_Ldq + i] + S[P.o_Lddq + i];
+        }
+        TG_SYNC();
+        if (on && !failed && A.X) {
+            double *x = A.X + (t * (size_t)(A.n_steps + 1) + step + 1) * nX;
+            TG_FOR(i, nq) x[i] = S[P.o_q2 + i];
+            TG_FOR(i, nd) x[nq + i] = S[P.o_p1 + i];
+            TG_FOR(i, nk) x[nq + nd + i] = (S[P.o_q2 + nd + i] - S[P.o_q1 + nd + i]) / dt;
+        }
+    }
+    // ---- write back q1, q2, p2, lambda1, u1 (p1 was stored when the last step started) ----------------------
+    if (live) {
+        TG_FOR(i, nq) { A.q1[t * nq + i] = S[P.o_q1 + i]; A.q2[t * nq + i] = S[P.o_q2 + i]; }
+        TG_FOR(i, nd) A.p2[t * nd + i] = S[P.o_p1 + i];
+        TG_FOR(i, nc) A.lam[t * nc + i] = S[P.o_lam + i];
+        TG_FOR(i, nu) A.u1[t * nu + i] = S[P.o_u + i];
+        if (lane == 0) { A.iters[t] = total_iters; A.status[t] = status; }
+    }
+}
+
+}  // namespace tg

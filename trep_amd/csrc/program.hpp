@@ -1,0 +1,262 @@
+// program.hpp -- host-side "topology compiler": tg_system_desc -> flat device schedule.
+//
+// The reference walks its frame tree recursively and keeps per-frame tables of 4x4 derivative
+// matrices (frame.c:839-2193).  The device path uses an algebraically equal formulation that needs
+// no such tables: world poses of the *variable* frames ("joints"), body Jacobians
+// J_{F,k} = Ad_{g_F^-1} s_k of every massive frame F w.r.t. every config k on its path, and Lie
+// brackets of those 6-vectors for all higher derivatives.  This file flattens the tree into the
+// index tables that formulation needs: joints sorted by depth level with constant pre-transforms
+// (chains of fixed frames are multiplied out here, once), bodies, (body, path-config) items,
+// (item, item) pairs, constraint end points and constraint-Jacobian items.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/trep_amd.h"
+
+namespace tg {
+
+// Plain-old-data view handed to the kernels (device pointers when on the GPU).
+struct DevProg {
+    int nq, nd, nk, nu, nc, nf, nX;
+    int n_joints, n_levels, n_bodies, n_items, n_pairs, n_endpoints, n_dh, n_cf, n_cfgitems;
+    double grav[3];
+    const int *level_off;     // [n_levels+1]
+    const int *j_parent;      // [n_joints] parent joint or -1
+    const int *j_kind;        // [n_joints] TG_TX..TG_RZ
+    const int *j_cfg;         // [n_joints]
+    const int *j_pre_ident;   // [n_joints] 1 if the constant pre-transform is the identity
+    const double *j_pre;      // [n_joints*12]
+    const int *b_anchor;      // [n_bodies] joint or -1
+    const double *b_C;        // [n_bodies*12]
+    const double *b_inertia;  // [n_bodies*4]
+    const int *b_item_off;    // [n_bodies+1]
+    const int *b_pair_off;    // [n_bodies+1]
+    const int *it_body;       // [n_items]
+    const int *it_joint;      // [n_items]
+    const int *it_cfg;        // [n_items]
+    const int *pair_a;        // [n_pairs] item index of the config nearer the root
+    const int *pair_b;        // [n_pairs] item index of the config nearer the body (may equal pair_a)
+    const int *cfg_item_off;  // [nq+1] CSR config -> items
+    const int *cfg_items;     // [n_items]
+    const int *e_anchor;      // [n_endpoints]
+    const double *e_off;      // [n_endpoints*3]
+    const int *c_type, *c_e1, *c_e2, *c_cfg, *c_comp;
+    const double *c_dist, *c_tol;
+    const int *dh_c, *dh_cfg, *dh_joint, *dh_side; // side: bit0 on e1's path, bit1 on e2's path, bit2 length config
+    const double *damp;       // [nd] summed damping coefficients
+    const int *cf_cfg, *cf_in;
+    // LDS layout (offsets in doubles from the team's base)
+    int o_q1, o_q2, o_p1, o_lam, o_u, o_dq, o_f, o_sc, o_G, o_gB, o_pE, o_J, o_W, o_vB, o_gam, o_Ldq, o_Lddq,
+        o_Dh1, o_Dh2, o_Df, o_scal, o_misc;
+    int df_ld;
+    int lds_per_team;
+};
+
+struct HostProgram {
+    DevProg p{};  // sizes + LDS layout filled; pointers left null (set by the owner)
+    std::vector<int> level_off, j_parent, j_kind, j_cfg, j_pre_ident;
+    std::vector<double> j_pre;
+    std::vector<int> b_anchor;
+    std::vector<double> b_C, b_inertia;
+    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items;
+    std::vector<int> e_anchor;
+    std::vector<double> e_off;
+    std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
+    std::vector<double> c_dist, c_tol;
+    std::vector<int> dh_c, dh_cfg, dh_joint, dh_side;
+    std::vector<double> damp;
+    std::vector<int> cf_cfg, cf_in;
+    int max_depth = 0;
+};
+
+namespace detail {
+struct M34 {  // row-major 3x4 rigid transform
+    double m[12];
+};
+inline M34 ident() {
+    M34 r{};
+    r.m[0] = r.m[5] = r.m[10] = 1.0;
+    return r;
+}
+inline M34 mul(const M34 &a, const M34 &b) {
+    M34 r{};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = (j == 3) ? a.m[4 * i + 3] : 0.0;
+            for (int k = 0; k < 3; k++) s += a.m[4 * i + k] * b.m[4 * k + j];
+            r.m[4 * i + j] = s;
+        }
+    return r;
+}
+inline bool is_ident(const M34 &a) {
+    M34 i = ident();
+    return std::memcmp(a.m, i.m, sizeof(a.m)) == 0;
+}
+// local transform of a FIXED frame (frame.c:839-1068 with x = frame->value, or the stored SE(3))
+inline M34 fixed_local(const tg_system_desc *d, int f) {
+    int t = d->frame_transform[f];
+    M34 r = ident();
+    double x = d->frame_value[f];
+    if (t == TG_CONST_SE3) {
+        std::memcpy(r.m, d->frame_lg + 12 * (size_t)f, sizeof(r.m));
+    } else if (t == TG_TX || t == TG_TY || t == TG_TZ) {
+        r.m[4 * (t - TG_TX) + 3] = x;
+    } else if (t == TG_RX) {
+        r.m[5] = std::cos(x); r.m[6] = -std::sin(x); r.m[9] = std::sin(x); r.m[10] = std::cos(x);
+    } else if (t == TG_RY) {
+        r.m[0] = std::cos(x); r.m[2] = std::sin(x); r.m[8] = -std::sin(x); r.m[10] = std::cos(x);
+    } else if (t == TG_RZ) {
+        r.m[0] = std::cos(x); r.m[1] = -std::sin(x); r.m[4] = std::sin(x); r.m[5] = std::cos(x);
+    }
+    return r;
+}
+}  // namespace detail
+
+inline HostProgram build_program(const tg_system_desc *d) {
+    using namespace detail;
+    HostProgram H;
+    const int nfr = d->n_frames, nq = d->n_configs, nd = d->n_dyn, nc = d->n_constraints;
+    if (nd + d->n_kin != nq) throw std::runtime_error("n_dyn + n_kin != n_configs");
+    for (int f = 0; f < nfr; f++) {
+        int t = d->frame_transform[f];
+        if (t < TG_WORLD || t > TG_CONST_SE3) throw std::runtime_error("unknown frame transform");
+        if (d->frame_config[f] >= 0 && (t < TG_TX || t > TG_RZ)) throw std::runtime_error("config on a non-parametric frame");
+        if (f > 0 && (d->frame_parent[f] < 0 || d->frame_parent[f] >= f)) throw std::runtime_error("frames must be listed parent-first");
+    }
+    // joints = variable frames, sorted by (level, frame index); level = config_gen of the driving config
+    std::vector<int> jframes;
+    int n_levels = 0;
+    for (int f = 0; f < nfr; f++)
+        if (d->frame_config[f] >= 0) {
+            jframes.push_back(f);
+            n_levels = std::max(n_levels, d->config_gen[d->frame_config[f]] + 1);
+        }
+    std::vector<int> order;
+    H.level_off.assign(n_levels + 1, 0);
+    for (int L = 0; L < n_levels; L++) {
+        for (int f : jframes)
+            if (d->config_gen[d->frame_config[f]] == L) order.push_back(f);
+        H.level_off[L + 1] = (int)order.size();
+    }
+    std::vector<int> joint_of_frame(nfr, -1), joint_of_cfg(nq, -1);
+    for (size_t j = 0; j < order.size(); j++) {
+        joint_of_frame[order[j]] = (int)j;
+        joint_of_cfg[d->frame_config[order[j]]] = (int)j;
+    }
+    // anchor (nearest variable ancestor-or-self) and constant offset from it, for every frame
+    std::vector<int> anchor(nfr, -1);
+    std::vector<M34> offset(nfr, ident());
+    for (int f = 1; f < nfr; f++) {
+        if (d->frame_config[f] >= 0) {
+            anchor[f] = joint_of_frame[f];
+            offset[f] = ident();
+        } else {
+            int p = d->frame_parent[f];
+            anchor[f] = anchor[p];
+            offset[f] = mul(offset[p], fixed_local(d, f));
+        }
+    }
+    const int nj = (int)order.size();
+    H.j_parent.resize(nj); H.j_kind.resize(nj); H.j_cfg.resize(nj); H.j_pre_ident.resize(nj); H.j_pre.resize(12 * (size_t)nj);
+    for (int j = 0; j < nj; j++) {
+        int f = order[j], p = d->frame_parent[f];
+        H.j_parent[j] = anchor[p];
+        H.j_kind[j] = d->frame_transform[f];
+        H.j_cfg[j] = d->frame_config[f];
+        H.j_pre_ident[j] = is_ident(offset[p]) ? 1 : 0;
+        std::memcpy(&H.j_pre[12 * (size_t)j], offset[p].m, sizeof(offset[p].m));
+        if (H.j_parent[j] >= 0 && H.j_parent[j] >= j) throw std::runtime_error("joint ordering error");
+    }
+    // bodies and (body, path config) items
+    const int nb = d->n_masses;
+    H.b_anchor.resize(nb); H.b_C.resize(12 * (size_t)nb); H.b_inertia.resize(4 * (size_t)nb);
+    H.b_item_off.assign(nb + 1, 0); H.b_pair_off.assign(nb + 1, 0);
+    for (int b = 0; b < nb; b++) {
+        int f = d->masses[b];
+        H.b_anchor[b] = anchor[f];
+        std::memcpy(&H.b_C[12 * (size_t)b], offset[f].m, sizeof(offset[f].m));
+        std::memcpy(&H.b_inertia[4 * (size_t)b], d->frame_inertia + 4 * (size_t)f, 4 * sizeof(double));
+        int n = d->frame_cache_size[f];
+        H.max_depth = std::max(H.max_depth, n);
+        int first = (int)H.it_body.size();
+        for (int i = 0; i < n; i++) {
+            int c = d->frame_cache_index[(size_t)f * (nq + 1) + i];
+            if (c < 0 || joint_of_cfg[c] < 0) throw std::runtime_error("path config without a frame");
+            H.it_body.push_back(b); H.it_joint.push_back(joint_of_cfg[c]); H.it_cfg.push_back(c);
+        }
+        H.b_item_off[b + 1] = (int)H.it_body.size();
+        for (int i = 0; i < n; i++)
+            for (int j = i; j < n; j++) { H.pair_a.push_back(first + i); H.pair_b.push_back(first + j); }
+        H.b_pair_off[b + 1] = (int)H.pair_a.size();
+    }
+    const int nitems = (int)H.it_body.size();
+    H.cfg_item_off.assign(nq + 1, 0);
+    for (int c = 0; c < nq; c++) {
+        for (int it = 0; it < nitems; it++)
+            if (H.it_cfg[it] == c) H.cfg_items.push_back(it);
+        H.cfg_item_off[c + 1] = (int)H.cfg_items.size();
+    }
+    // constraint end points (unique frames) and constraint-Jacobian items
+    std::map<int, int> ep_of_frame;
+    auto endpoint = [&](int f) {
+        auto it = ep_of_frame.find(f);
+        if (it != ep_of_frame.end()) return it->second;
+        int e = (int)H.e_anchor.size();
+        ep_of_frame[f] = e;
+        H.e_anchor.push_back(anchor[f]);
+        H.e_off.push_back(offset[f].m[3]); H.e_off.push_back(offset[f].m[7]); H.e_off.push_back(offset[f].m[11]);
+        return e;
+    };
+    for (int c = 0; c < nc; c++) {
+        int t = d->constraint_type[c];
+        if (t != TG_CONSTRAINT_DISTANCE && t != TG_CONSTRAINT_POINT) throw std::runtime_error("unknown constraint type");
+        int f1 = d->constraint_frame1[c], f2 = d->constraint_frame2[c];
+        H.c_type.push_back(t); H.c_e1.push_back(endpoint(f1)); H.c_e2.push_back(endpoint(f2));
+        int lc = (t == TG_CONSTRAINT_DISTANCE) ? d->constraint_config[c] : -1;
+        H.c_cfg.push_back(lc); H.c_comp.push_back(d->constraint_component[c]);
+        H.c_dist.push_back(d->constraint_distance[c]); H.c_tol.push_back(d->constraint_tolerance[c]);
+        for (int k = 0; k < nq; k++) {
+            int g = d->config_gen[k];
+            bool on1 = d->frame_cache_index[(size_t)f1 * (nq + 1) + g] == k;
+            bool on2 = d->frame_cache_index[(size_t)f2 * (nq + 1) + g] == k;
+            bool isl = (k == lc);
+            if (!on1 && !on2 && !isl) continue;
+            H.dh_c.push_back(c); H.dh_cfg.push_back(k); H.dh_joint.push_back(joint_of_cfg[k]);
+            H.dh_side.push_back((on1 ? 1 : 0) | (on2 ? 2 : 0) | (isl ? 4 : 0));
+        }
+    }
+    // forces / potentials
+    H.damp.assign(nd, 0.0);
+    for (int i = 0; i < d->n_damping; i++)
+        for (int k = 0; k < nd; k++) H.damp[k] += d->damping[(size_t)i * nd + k];
+    for (int i = 0; i < d->n_config_forces; i++) {
+        H.cf_cfg.push_back(d->config_force_config[i]); H.cf_in.push_back(d->config_force_input[i]);
+    }
+    DevProg &P = H.p;
+    P.nq = nq; P.nd = nd; P.nk = d->n_kin; P.nu = d->n_inputs; P.nc = nc; P.nf = nd + nc; P.nX = nq + nd + d->n_kin;
+    P.n_joints = nj; P.n_levels = n_levels; P.n_bodies = nb; P.n_items = nitems; P.n_pairs = (int)H.pair_a.size();
+    P.n_endpoints = (int)H.e_anchor.size(); P.n_dh = (int)H.dh_c.size(); P.n_cf = (int)H.cf_cfg.size();
+    P.n_cfgitems = (int)H.cfg_items.size();
+    P.grav[0] = P.grav[1] = P.grav[2] = 0.0;
+    for (int i = 0; i < d->n_gravity; i++)
+        for (int k = 0; k < 3; k++) P.grav[k] += d->gravity[3 * (size_t)i + k];
+    // LDS layout
+    int off = 0;
+    auto take = [&](int n) { int o = off; off += (n > 0 ? n : 0); return o; };
+    P.o_q1 = take(nq); P.o_q2 = take(nq); P.o_p1 = take(nd); P.o_lam = take(nc); P.o_u = take(P.nu); P.o_dq = take(nq);
+    P.o_f = take(P.nf); P.o_sc = take(2 * nj); P.o_G = take(12 * nj); P.o_gB = take(12 * nb); P.o_pE = take(3 * P.n_endpoints);
+    P.o_J = take(6 * nitems); P.o_W = take(6 * nitems); P.o_vB = take(6 * nb); P.o_gam = take(3 * nb);
+    P.o_Ldq = take(nq); P.o_Lddq = take(nq); P.o_Dh1 = take(nc * nq); P.o_Dh2 = take(nc * nq);
+    P.df_ld = (P.nf + 1) | 1;  // augmented with the right-hand side; odd stride avoids LDS bank conflicts
+    P.o_Df = take(P.nf * P.df_ld); P.o_scal = take(P.nf); P.o_misc = take(8);
+    P.lds_per_team = (off + 1) & ~1;
+    return H;
+}
+
+}  // namespace tg

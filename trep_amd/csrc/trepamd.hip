@@ -1,0 +1,470 @@
+// trepamd.hip -- libtrepamd.so: gfx950 kernels + the C ABI of include/trep_amd.h.
+//
+// Launch geometry: one 64-thread workgroup (exactly one CDNA4 wavefront) holds 64/TEAM teams, one
+// trajectory per team; the grid is ceil(batch / teams-per-block) workgroups, i.e. >> 256 CUs for
+// the benchmark batches.  Single-wave workgroups make every __syncthreads() a wave-local
+// s_waitcnt (no cross-wave barrier) and let the LDS slice of a trajectory be private to its wave.
+// Trajectories are independent, so there is no inter-workgroup communication at all.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mvi_core.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(TG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <int TEAM>
+__global__ __launch_bounds__(64) void k_run(const tg::DevProg P, const tg::RunArgs A) {
+    extern __shared__ double lds[];
+    const int team = threadIdx.x / TEAM, lane = threadIdx.x % TEAM;
+    const int traj = blockIdx.x * (64 / TEAM) + team;
+    tg::run_trajectory<TEAM>(P, A, lds + (size_t)team * P.lds_per_team, lane, traj);
+}
+
+}  // namespace
+
+struct tg_system {
+    tg::HostProgram H;
+    int team = 64;
+};
+
+struct tg_batch {
+    tg_system *sys = nullptr;
+    int batch = 0, device = 0;
+    tg::DevProg P{};           // device-pointer view
+    int *d_ints = nullptr;
+    double *d_dbls = nullptr;
+    double *q1 = nullptr, *q2 = nullptr, *p1 = nullptr, *p2 = nullptr, *lam = nullptr, *u1 = nullptr;
+    double *stage_u = nullptr, *stage_k = nullptr, *stage_qh = nullptr, *stage_lh = nullptr, *f_out = nullptr;
+    int *iters = nullptr, *status = nullptr;
+    double *snap = nullptr;    // snapshot of (q1,q2,p1,p2,lam,u1)
+    double snap_t1 = 0.0, snap_t2 = 0.0;
+    long long total_iters = 0;
+    double t1 = 0.0, t2 = 0.0, tolerance = 1.0e-10;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<hipEvent_t> pool;
+};
+
+namespace {
+
+int widths(const tg_batch *b, int field) {
+    const tg::DevProg &P = b->P;
+    switch (field) {
+    case TG_F_Q1: case TG_F_Q2: return P.nq;
+    case TG_F_P1: case TG_F_P2: return P.nd;
+    case TG_F_U1: return P.nu;
+    case TG_F_LAMBDA1: return P.nc;
+    default: return -1;
+    }
+}
+double *field_ptr(tg_batch *b, int field) {
+    switch (field) {
+    case TG_F_Q1: return b->q1;
+    case TG_F_Q2: return b->q2;
+    case TG_F_P1: return b->p1;
+    case TG_F_P2: return b->p2;
+    case TG_F_U1: return b->u1;
+    case TG_F_LAMBDA1: return b->lam;
+    default: return nullptr;
+    }
+}
+
+int pick_team(const tg::HostProgram &H) {
+    if (const char *env = std::getenv("TREPAMD_TEAM")) {
+        int t = std::atoi(env);
+        if (t == 1 || t == 4 || t == 16 || t == 64) return t;
+    }
+    const tg::DevProg &P = H.p;
+    int width = std::max(P.n_items, (P.nf * (P.nf + 1)) / 4);
+    int team = width > 32 ? 64 : (width > 8 ? 16 : (width > 2 ? 4 : 1));
+    // the block's LDS (all teams) must fit the 64 KiB a workgroup may use without opting in
+    while (team < 64 && (size_t)(64 / team) * P.lds_per_team * sizeof(double) > 64 * 1024) team *= 4;
+    return team;
+}
+
+template <typename T>
+void append(std::vector<T> &pool, const std::vector<T> &v, size_t &off) {
+    off = pool.size();
+    pool.insert(pool.end(), v.begin(), v.end());
+    while (pool.size() % 2) pool.push_back(T());
+}
+
+int launch(tg_batch *b, tg::RunArgs &A) {
+    const int team = b->sys->team, per_block = 64 / team;
+    const int grid = (A.batch + per_block - 1) / per_block;
+    const size_t lds = (size_t)per_block * b->P.lds_per_team * sizeof(double);
+    hipEvent_t e0, e1;
+    if (b->pool.size() >= 2) { e0 = b->pool.back(); b->pool.pop_back(); e1 = b->pool.back(); b->pool.pop_back(); }
+    else { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); }
+    HIP_TRY(hipEventRecord(e0, b->stream));
+    switch (team) {
+    case 64: hipLaunchKernelGGL(k_run<64>, dim3(grid), dim3(64), lds, b->stream, b->P, A); break;
+    case 16: hipLaunchKernelGGL(k_run<16>, dim3(grid), dim3(64), lds, b->stream, b->P, A); break;
+    case 4: hipLaunchKernelGGL(k_run<4>, dim3(grid), dim3(64), lds, b->stream, b->P, A); break;
+    default: hipLaunchKernelGGL(k_run<1>, dim3(grid), dim3(64), lds, b->stream, b->P, A); break;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, b->stream));
+    b->events.emplace_back(e0, e1);
+    return TG_SUCCESS;
+}
+
+tg::RunArgs base_args(tg_batch *b, int mode) {
+    tg::RunArgs A{};
+    A.batch = b->batch; A.mode = mode; A.max_iterations = 200;
+    A.t1 = b->t1; A.t2 = b->t2; A.tolerance = b->tolerance;
+    A.q1 = b->q1; A.q2 = b->q2; A.p1 = b->p1; A.p2 = b->p2; A.lam = b->lam; A.u1 = b->u1;
+    A.iters = b->iters; A.status = b->status; A.f_out = b->f_out;
+    return A;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *tg_version(void) { return "trep_amd 0.1 (gfx950)"; }
+const char *tg_last_error(void) { return g_error.c_str(); }
+
+int tg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+tg_system *tg_system_create(const tg_system_desc *desc) {
+    if (!desc) { fail(TG_ERR_INVALID, "null descriptor"); return nullptr; }
+    try {
+        tg_system *s = new tg_system();
+        s->H = tg::build_program(desc);
+        s->team = pick_team(s->H);
+        return s;
+    } catch (const std::exception &e) {
+        fail(TG_ERR_INVALID, e.what());
+        return nullptr;
+    }
+}
+void tg_system_destroy(tg_system *sys) { delete sys; }
+
+int tg_system_sizes(const tg_system *sys, int32_t out[6]) {
+    if (!sys) return fail(TG_ERR_INVALID, "null system");
+    const tg::DevProg &P = sys->H.p;
+    out[0] = P.nq; out[1] = P.nd; out[2] = P.nk; out[3] = P.nu; out[4] = P.nc; out[5] = P.nX;
+    return TG_SUCCESS;
+}
+
+/* Introspection used by bench.py / DESIGN.md: team size, LDS bytes per trajectory, schedule sizes. */
+int tg_system_info(const tg_system *sys, int32_t out[8]) {
+    if (!sys) return fail(TG_ERR_INVALID, "null system");
+    const tg::DevProg &P = sys->H.p;
+    out[0] = sys->team; out[1] = (int32_t)(P.lds_per_team * sizeof(double)); out[2] = P.n_joints; out[3] = P.n_levels;
+    out[4] = P.n_bodies; out[5] = P.n_items; out[6] = P.n_pairs; out[7] = P.n_dh;
+    return TG_SUCCESS;
+}
+
+tg_batch *tg_batch_create(tg_system *sys, int32_t batch, int32_t device) {
+    if (!sys || batch <= 0) { fail(TG_ERR_INVALID, "bad arguments"); return nullptr; }
+    int ndev = tg_device_count();
+    if (ndev <= 0) { fail(TG_ERR_HIP, "no HIP device visible: libtrepamd has no CPU path"); return nullptr; }
+    if (device < 0 || device >= ndev) { fail(TG_ERR_INVALID, "device index out of range"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { fail(TG_ERR_HIP, "hipSetDevice failed"); return nullptr; }
+    tg_batch *b = new tg_batch();
+    b->sys = sys; b->batch = batch; b->device = device;
+    const tg::HostProgram &H = sys->H;
+    b->P = H.p;
+    // pack all index / constant tables into two device buffers
+    std::vector<int> ints;
+    std::vector<double> dbls;
+    size_t oi[24], od[8];
+    append(ints, H.level_off, oi[0]); append(ints, H.j_parent, oi[1]); append(ints, H.j_kind, oi[2]);
+    append(ints, H.j_cfg, oi[3]); append(ints, H.j_pre_ident, oi[4]); append(ints, H.b_anchor, oi[5]);
+    append(ints, H.b_item_off, oi[6]); append(ints, H.b_pair_off, oi[7]); append(ints, H.it_body, oi[8]);
+    append(ints, H.it_joint, oi[9]); append(ints, H.it_cfg, oi[10]); append(ints, H.pair_a, oi[11]);
+    append(ints, H.pair_b, oi[12]); append(ints, H.cfg_item_off, oi[13]); append(ints, H.cfg_items, oi[14]);
+    append(ints, H.e_anchor, oi[15]); append(ints, H.c_type, oi[16]); append(ints, H.c_e1, oi[17]);
+    append(ints, H.c_e2, oi[18]); append(ints, H.c_cfg, oi[19]); append(ints, H.c_comp, oi[20]);
+    append(ints, H.dh_c, oi[21]); append(ints, H.dh_cfg, oi[22]); append(ints, H.dh_joint, oi[23]);
+    size_t o_side, o_cfc, o_cfi;
+    append(ints, H.dh_side, o_side); append(ints, H.cf_cfg, o_cfc); append(ints, H.cf_in, o_cfi);
+    append(dbls, H.j_pre, od[0]); append(dbls, H.b_C, od[1]); append(dbls, H.b_inertia, od[2]);
+    append(dbls, H.e_off, od[3]); append(dbls, H.c_dist, od[4]); append(dbls, H.c_tol, od[5]); append(dbls, H.damp, od[6]);
+    ints.push_back(0); dbls.push_back(0.0);
+    bool ok = hipMalloc(&b->d_ints, ints.size() * sizeof(int)) == hipSuccess &&
+              hipMalloc(&b->d_dbls, dbls.size() * sizeof(double)) == hipSuccess &&
+              hipMemcpy(b->d_ints, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(b->d_dbls, dbls.data(), dbls.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    tg::DevProg &P = b->P;
+    const int *I = b->d_ints; const double *D = b->d_dbls;
+    P.level_off = I + oi[0]; P.j_parent = I + oi[1]; P.j_kind = I + oi[2]; P.j_cfg = I + oi[3]; P.j_pre_ident = I + oi[4];
+    P.b_anchor = I + oi[5]; P.b_item_off = I + oi[6]; P.b_pair_off = I + oi[7]; P.it_body = I + oi[8];
+    P.it_joint = I + oi[9]; P.it_cfg = I + oi[10]; P.pair_a = I + oi[11]; P.pair_b = I + oi[12];
+    P.cfg_item_off = I + oi[13]; P.cfg_items = I + oi[14]; P.e_anchor = I + oi[15]; P.c_type = I + oi[16];
+    P.c_e1 = I + oi[17]; P.c_e2 = I + oi[18]; P.c_cfg = I + oi[19]; P.c_comp = I + oi[20];
+    P.dh_c = I + oi[21]; P.dh_cfg = I + oi[22]; P.dh_joint = I + oi[23]; P.dh_side = I + o_side;
+    P.cf_cfg = I + o_cfc; P.cf_in = I + o_cfi;
+    P.j_pre = D + od[0]; P.b_C = D + od[1]; P.b_inertia = D + od[2]; P.e_off = D + od[3];
+    P.c_dist = D + od[4]; P.c_tol = D + od[5]; P.damp = D + od[6];
+    auto dalloc = [&](double **p, size_t n) {
+        if (!ok) return;
+        ok = hipMalloc(p, (n ? n : 1) * sizeof(double)) == hipSuccess && hipMemset(*p, 0, (n ? n : 1) * sizeof(double)) == hipSuccess;
+    };
+    const size_t B = (size_t)batch;
+    dalloc(&b->q1, B * P.nq); dalloc(&b->q2, B * P.nq); dalloc(&b->p1, B * P.nd); dalloc(&b->p2, B * P.nd);
+    dalloc(&b->lam, B * P.nc); dalloc(&b->u1, B * P.nu);
+    dalloc(&b->stage_u, B * P.nu); dalloc(&b->stage_k, B * P.nk); dalloc(&b->stage_qh, B * P.nd); dalloc(&b->stage_lh, B * P.nc);
+    dalloc(&b->f_out, B * P.nf);
+    dalloc(&b->snap, B * (2 * (size_t)P.nq + 2 * (size_t)P.nd + P.nc + P.nu));
+    if (ok) ok = hipMalloc(&b->iters, B * sizeof(int)) == hipSuccess && hipMalloc(&b->status, B * sizeof(int)) == hipSuccess &&
+                 hipMemset(b->iters, 0, B * sizeof(int)) == hipSuccess && hipMemset(b->status, 0, B * sizeof(int)) == hipSuccess;
+    if (ok) ok = hipStreamCreate(&b->stream) == hipSuccess;
+    if (!ok) { fail(TG_ERR_HIP, "device allocation failed"); tg_batch_destroy(b); return nullptr; }
+    return b;
+}
+
+void tg_batch_destroy(tg_batch *b) {
+    if (!b) return;
+    hipSetDevice(b->device);
+    if (b->stream) hipStreamSynchronize(b->stream);
+    for (auto &e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto &e : b->pool) hipEventDestroy(e);
+    void *ptrs[] = {b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
+                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap};
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (b->stream && b->own_stream) hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int tg_batch_set_tolerance(tg_batch *b, double tolerance) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    b->tolerance = tolerance;
+    return TG_SUCCESS;
+}
+int tg_batch_set_times(tg_batch *b, double t1, double t2) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    b->t1 = t1; b->t2 = t2;
+    return TG_SUCCESS;
+}
+int tg_batch_get_times(const tg_batch *b, double *t1, double *t2) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    *t1 = b->t1; *t2 = b->t2;
+    return TG_SUCCESS;
+}
+int tg_batch_field_width(const tg_batch *b, int32_t field) { return b ? widths(b, field) : -1; }
+
+int tg_batch_set(tg_batch *b, int32_t field, const double *host) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    int w = widths(b, field);
+    double *dst = field_ptr(b, field);
+    if (w < 0 || !dst) return fail(TG_ERR_INVALID, "unknown or read-only field");
+    if (w == 0) return TG_SUCCESS;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpyAsync(dst, host, (size_t)b->batch * w * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return TG_SUCCESS;
+}
+int tg_batch_get(tg_batch *b, int32_t field, double *host) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    int w = widths(b, field);
+    double *src = field_ptr(b, field);
+    if (w < 0 || !src) return fail(TG_ERR_INVALID, "unknown field");
+    if (w == 0) return TG_SUCCESS;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpyAsync(host, src, (size_t)b->batch * w * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return TG_SUCCESS;
+}
+
+int tg_batch_calc_p2(tg_batch *b) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    if (b->t2 == b->t1) return fail(TG_ERR_STATE, "calc_p2 needs t2 != t1");
+    HIP_TRY(hipSetDevice(b->device));
+    tg::RunArgs A = base_args(b, tg::MODE_CALC_P2);
+    int rc = launch(b, A);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return TG_SUCCESS;
+}
+
+int tg_batch_calc_f(tg_batch *b, double *f_host) {
+    if (!b || !f_host) return fail(TG_ERR_INVALID, "null argument");
+    if (b->t2 == b->t1) return fail(TG_ERR_STATE, "calc_f needs t2 != t1");
+    HIP_TRY(hipSetDevice(b->device));
+    tg::RunArgs A = base_args(b, tg::MODE_CALC_F);
+    int rc = launch(b, A);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(f_host, b->f_out, (size_t)b->batch * b->P.nf * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return TG_SUCCESS;
+}
+
+int tg_batch_status(tg_batch *b, int32_t *iterations_out, int32_t *status_out) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    HIP_TRY(hipSetDevice(b->device));
+    if (iterations_out) HIP_TRY(hipMemcpyAsync(iterations_out, b->iters, (size_t)b->batch * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    if (status_out) HIP_TRY(hipMemcpyAsync(status_out, b->status, (size_t)b->batch * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return TG_SUCCESS;
+}
+
+int tg_batch_step(tg_batch *b, double t2_new, const double *u1_host, const double *k2_host, const double *q2_hint_host,
+                  const double *lambda_hint_host, int32_t max_iterations, int32_t *iterations_out, int32_t *status_out) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    const tg::DevProg &P = b->P;
+    if ((P.nu && !u1_host) || (P.nk && !k2_host)) return fail(TG_ERR_INVALID, "u1 / k2 required");
+    if (t2_new == b->t2) return fail(TG_ERR_STATE, "step needs t2_new != t2");
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t B = (size_t)b->batch;
+    if (P.nu) HIP_TRY(hipMemcpyAsync(b->stage_u, u1_host, B * P.nu * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    if (P.nk) HIP_TRY(hipMemcpyAsync(b->stage_k, k2_host, B * P.nk * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    if (q2_hint_host) HIP_TRY(hipMemcpyAsync(b->stage_qh, q2_hint_host, B * P.nd * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    if (lambda_hint_host && P.nc) HIP_TRY(hipMemcpyAsync(b->stage_lh, lambda_hint_host, B * P.nc * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    tg::RunArgs A = base_args(b, tg::MODE_ROLLOUT);
+    A.n_steps = 1; A.dt = t2_new - b->t2; A.max_iterations = max_iterations;
+    A.U = b->stage_u; A.K = b->stage_k;
+    A.q2_hint = q2_hint_host ? b->stage_qh : nullptr;
+    A.lam_hint = (lambda_hint_host && P.nc) ? b->stage_lh : nullptr;
+    int rc = launch(b, A);
+    if (rc) return rc;
+    b->t1 = b->t2; b->t2 = t2_new;
+    return tg_batch_status(b, iterations_out, status_out);
+}
+
+int tg_batch_rollout(tg_batch *b, int32_t n_steps, double dt, const double *U_dev, const double *K_dev, double *X_dev,
+                     int32_t max_iterations) {
+    if (!b || n_steps <= 0 || dt == 0.0) return fail(TG_ERR_INVALID, "bad arguments");
+    const tg::DevProg &P = b->P;
+    if ((P.nu && !U_dev) || (P.nk && !K_dev)) return fail(TG_ERR_INVALID, "U / K device buffers required");
+    HIP_TRY(hipSetDevice(b->device));
+    tg::RunArgs A = base_args(b, tg::MODE_ROLLOUT);
+    A.n_steps = n_steps; A.dt = dt; A.max_iterations = max_iterations;
+    A.U = U_dev; A.K = K_dev; A.X = X_dev;
+    int rc = launch(b, A);
+    if (rc) return rc;
+    b->t1 = b->t2 + (n_steps - 1) * dt;
+    b->t2 = b->t2 + n_steps * dt;
+    return TG_SUCCESS;
+}
+
+int tg_batch_rollout_stats(tg_batch *b, int64_t *total_iterations, int32_t *n_failed) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    std::vector<int> it(b->batch), st(b->batch);
+    int rc = tg_batch_status(b, it.data(), st.data());
+    if (rc) return rc;
+    int64_t tot = 0; int nf = 0;
+    for (int i = 0; i < b->batch; i++) { tot += it[i]; nf += (st[i] != TG_OK); }
+    if (total_iterations) *total_iterations = tot;
+    if (n_failed) *n_failed = nf;
+    return TG_SUCCESS;
+}
+
+static int snapshot_copy(tg_batch *b, bool save) {
+    const tg::DevProg &P = b->P;
+    const size_t B = (size_t)b->batch;
+    double *fields[6] = {b->q1, b->q2, b->p1, b->p2, b->lam, b->u1};
+    const size_t w[6] = {(size_t)P.nq, (size_t)P.nq, (size_t)P.nd, (size_t)P.nd, (size_t)P.nc, (size_t)P.nu};
+    size_t off = 0;
+    for (int i = 0; i < 6; i++) {
+        if (w[i]) {
+            double *dst = save ? b->snap + off : fields[i];
+            const double *src = save ? fields[i] : b->snap + off;
+            HIP_TRY(hipMemcpyAsync(dst, src, B * w[i] * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+        }
+        off += B * w[i];
+    }
+    return TG_SUCCESS;
+}
+
+int tg_batch_snapshot(tg_batch *b) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    HIP_TRY(hipSetDevice(b->device));
+    b->snap_t1 = b->t1; b->snap_t2 = b->t2;
+    return snapshot_copy(b, true);
+}
+
+int tg_batch_restore(tg_batch *b) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    HIP_TRY(hipSetDevice(b->device));
+    b->t1 = b->snap_t1; b->t2 = b->snap_t2;
+    return snapshot_copy(b, false);
+}
+
+int tg_batch_deriv1(tg_batch *b) {
+    (void)b;
+    return fail(TG_ERR_UNSUPPORTED, "deriv1 kernel not built yet");
+}
+
+void *tg_device_alloc(int32_t device, uint64_t bytes) {
+    void *p = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) { fail(TG_ERR_HIP, "hipMalloc failed"); return nullptr; }
+    return p;
+}
+int tg_device_free(int32_t device, void *ptr) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(ptr));
+    return TG_SUCCESS;
+}
+int tg_memcpy_h2d(int32_t device, void *dst_dev, const void *src_host, uint64_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return TG_SUCCESS;
+}
+int tg_memcpy_d2h(int32_t device, void *dst_host, const void *src_dev, uint64_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return TG_SUCCESS;
+}
+
+int tg_batch_synchronize(tg_batch *b) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return TG_SUCCESS;
+}
+
+int tg_batch_set_stream(tg_batch *b, void *hip_stream) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (b->own_stream && b->stream) HIP_TRY(hipStreamDestroy(b->stream));
+    if (hip_stream) { b->stream = (hipStream_t)hip_stream; b->own_stream = false; }
+    else { HIP_TRY(hipStreamCreate(&b->stream)); b->own_stream = true; }
+    return TG_SUCCESS;
+}
+
+int tg_batch_timing(tg_batch *b, int32_t reset, int32_t *n_launches, double *total_ms) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    double ms = 0.0;
+    for (auto &e : b->events) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, e.first, e.second));
+        ms += t;
+    }
+    if (n_launches) *n_launches = (int32_t)b->events.size();
+    if (total_ms) *total_ms = ms;
+    if (reset) {
+        for (auto &e : b->events) { b->pool.push_back(e.first); b->pool.push_back(e.second); }
+        b->events.clear();
+    }
+    return TG_SUCCESS;
+}
+
+}  // extern "C"

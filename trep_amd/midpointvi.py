@@ -1,6 +1,358 @@
-class MidpointVI(object):
-    pass
+"""MidpointVI: the midpoint variational integrator, executed on the MI355X.
+
+``BatchMidpointVI`` advances B independent trajectories of one ``System`` at
+once on a HIP device; ``MidpointVI`` is the B = 1 shell that keeps the reference
+API (/root/reference/trep/midpointvi.py:19-332: initialize_from_state /
+initialize_from_configs / step / calc_f, the t/q/p/u/lambda properties, v2) so
+the reference's example scripts run unmodified against this package.
+
+All numerical work happens in libtrepamd.so (HIP, gfx950) through the C ABI of
+include/trep_amd.h.  State lives in device memory; the properties copy it
+in/out.  There is no CPU execution path: without the library or without a GPU
+every call raises.
+"""
+import numpy as np
+
+from . import _lib
+from .descriptor import flatten
+from .errors import ConvergenceError
 
 
 class BatchMidpointVI(object):
-    pass
+    """B trajectories of ``system`` on HIP device ``device`` (state arrays are [B][width])."""
+
+    def __init__(self, system, batch, tolerance=1e-10, device=0):
+        self._system = system
+        self._batch = int(batch)
+        self._device = int(device)
+        self._L = _lib.lib()
+        _lib.require_device()
+        self._desc = flatten(system)
+        self._structure_version = system._structure_version
+        self._sys_h = self._L.tg_system_create(self._desc.byref())
+        if not self._sys_h:
+            raise _lib.LibraryError(self._L.tg_last_error().decode())
+        self._h = self._L.tg_batch_create(self._sys_h, self._batch, self._device)
+        if not self._h:
+            msg = self._L.tg_last_error().decode()
+            self._L.tg_system_destroy(self._sys_h)
+            self._sys_h = None
+            raise _lib.LibraryError(msg)
+        self.tolerance = tolerance
+        self._owned_dev = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for p in self._owned_dev:
+                self._L.tg_device_free(self._device, p)
+            self._owned_dev = []
+            self._L.tg_batch_destroy(self._h)
+            self._h = None
+        if getattr(self, "_sys_h", None):
+            self._L.tg_system_destroy(self._sys_h)
+            self._sys_h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- sizes ---------------------------------------------------------------------------
+    system = property(lambda self: self._system)
+    batch = property(lambda self: self._batch)
+    device = property(lambda self: self._device)
+    nq = property(lambda self: int(self._desc.n_configs))
+    nd = property(lambda self: int(self._desc.n_dyn))
+    nk = property(lambda self: int(self._desc.n_kin))
+    nu = property(lambda self: int(self._desc.n_inputs))
+    nc = property(lambda self: int(self._desc.n_constraints))
+    nX = property(lambda self: self.nq + self.nd + self.nk)
+    nU = property(lambda self: self.nu + self.nk)
+
+    def info(self):
+        out = (np.zeros(8, dtype=np.int32))
+        _lib.check(self._L.tg_system_info(self._sys_h, out.ctypes.data_as(_lib._c_ip)))
+        keys = ["team", "lds_bytes_per_trajectory", "joints", "levels", "bodies", "items", "pairs", "dh_items"]
+        return dict(zip(keys, (int(v) for v in out)))
+
+    # -- state ---------------------------------------------------------------------------
+    @property
+    def tolerance(self):
+        return self._tolerance
+
+    @tolerance.setter
+    def tolerance(self, value):
+        self._tolerance = float(value)
+        _lib.check(self._L.tg_batch_set_tolerance(self._h, self._tolerance))
+
+    def times(self):
+        import ctypes
+        a, b = ctypes.c_double(), ctypes.c_double()
+        _lib.check(self._L.tg_batch_get_times(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def set_times(self, t1, t2):
+        _lib.check(self._L.tg_batch_set_times(self._h, float(t1), float(t2)))
+
+    def _get(self, field, width):
+        out = np.zeros((self._batch, width))
+        if width:
+            _lib.check(self._L.tg_batch_get(self._h, field, out.ctypes.data))
+        return out
+
+    def _set(self, field, width, value):
+        arr = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=np.float64), (self._batch, width)))
+        if width:
+            _lib.check(self._L.tg_batch_set(self._h, field, arr.ctypes.data))
+
+    def _field(field, width_attr):
+        def getter(self):
+            return self._get(field, getattr(self, width_attr))
+
+        def setter(self, value):
+            self._set(field, getattr(self, width_attr), value)
+        return property(getter, setter)
+
+    q1 = _field(_lib.F_Q1, "nq")
+    q2 = _field(_lib.F_Q2, "nq")
+    p1 = _field(_lib.F_P1, "nd")
+    p2 = _field(_lib.F_P2, "nd")
+    u1 = _field(_lib.F_U1, "nu")
+    lambda1 = _field(_lib.F_LAMBDA1, "nc")
+    del _field
+
+    # -- reference semantics, batched -------------------------------------------------------------
+    def initialize_from_state(self, t1, q1, p1, lambda1=None):
+        """midpointvi.py:138-153: (t2,q2,p2) <- (t1,q1,p1), lambda1 <- given or 0."""
+        self.set_times(t1, t1)
+        self.q1 = q1
+        self.p1 = p1
+        self.q2 = q1
+        self.p2 = p1
+        self.lambda1 = np.zeros((self._batch, self.nc)) if lambda1 is None else lambda1
+
+    def initialize_from_configs(self, t0, q0, t1, q1, lambda1=None):
+        """midpointvi.py:155-172: p2 = D2L2(q0, q1) computed on the device."""
+        self.set_times(t0, t1)
+        self.q1 = q0
+        self.q2 = q1
+        _lib.check(self._L.tg_batch_calc_p2(self._h))
+        self.lambda1 = np.zeros((self._batch, self.nc)) if lambda1 is None else lambda1
+
+    def calc_p2(self):
+        _lib.check(self._L.tg_batch_calc_p2(self._h))
+
+    def calc_f(self):
+        out = np.zeros((self._batch, self.nd + self.nc))
+        _lib.check(self._L.tg_batch_calc_f(self._h, out.ctypes.data))
+        return out
+
+    def step(self, t2, u1=None, k2=None, max_iterations=200, q2_hint=None, lambda1_hint=None):
+        """One MidpointVI.step for every trajectory.  Returns (iterations[B], status[B])."""
+        B = self._batch
+        u = None if self.nu == 0 else _lib.as_f64(np.broadcast_to(np.asarray(u1, dtype=float), (B, self.nu)), (B, self.nu))
+        k = None if self.nk == 0 else _lib.as_f64(np.broadcast_to(np.asarray(k2, dtype=float), (B, self.nk)), (B, self.nk))
+        qh = None if q2_hint is None else np.ascontiguousarray(
+            np.broadcast_to(np.asarray(q2_hint, dtype=float)[..., :self.nd], (B, self.nd)))
+        lh = None if lambda1_hint is None or self.nc == 0 else _lib.as_f64(
+            np.broadcast_to(np.asarray(lambda1_hint, dtype=float), (B, self.nc)), (B, self.nc))
+        iters = np.zeros(B, dtype=np.int32)
+        status = np.zeros(B, dtype=np.int32)
+        _lib.check(self._L.tg_batch_step(self._h, float(t2), _lib.ptr(u), _lib.ptr(k), _lib.ptr(qh), _lib.ptr(lh),
+                                         int(max_iterations), iters.ctypes.data, status.ctypes.data))
+        return iters, status
+
+    # -- device-resident rollouts ------------------------------------------------------------------
+    def device_array(self, host):
+        """Upload a host array; returns a device pointer owned by this batch."""
+        host = np.ascontiguousarray(host, dtype=np.float64)
+        p = self._L.tg_device_alloc(self._device, max(host.nbytes, 8))
+        if not p:
+            raise _lib.LibraryError(self._L.tg_last_error().decode())
+        if host.nbytes:
+            _lib.check(self._L.tg_memcpy_h2d(self._device, p, host.ctypes.data, host.nbytes))
+        self._owned_dev.append(p)
+        return p
+
+    def device_empty(self, n_doubles):
+        p = self._L.tg_device_alloc(self._device, max(8 * int(n_doubles), 8))
+        if not p:
+            raise _lib.LibraryError(self._L.tg_last_error().decode())
+        self._owned_dev.append(p)
+        return p
+
+    def download(self, dev_ptr, shape):
+        out = np.zeros(shape)
+        if out.nbytes:
+            _lib.check(self._L.tg_memcpy_d2h(self._device, out.ctypes.data, dev_ptr, out.nbytes))
+        return out
+
+    def rollout_device(self, n_steps, dt, U_dev=None, K_dev=None, X_dev=None, max_iterations=200):
+        """Asynchronous n_steps-step rollout entirely on the device (one kernel launch)."""
+        _lib.check(self._L.tg_batch_rollout(self._h, int(n_steps), float(dt), U_dev, K_dev, X_dev,
+                                            int(max_iterations)))
+
+    def rollout(self, n_steps, dt, U=None, K=None, max_iterations=200):
+        """Convenience: upload U [B][N][nu] / K [B][N][nk], roll out, download X [B][N+1][nX]."""
+        B = self._batch
+        U_dev = self.device_array(_lib.as_f64(U, (B, n_steps, self.nu))) if self.nu else None
+        K_dev = self.device_array(_lib.as_f64(K, (B, n_steps, self.nk))) if self.nk else None
+        X_dev = self.device_empty(B * (n_steps + 1) * self.nX)
+        self.rollout_device(n_steps, dt, U_dev, K_dev, X_dev, max_iterations)
+        self.synchronize()
+        X = self.download(X_dev, (B, n_steps + 1, self.nX))
+        for p in (U_dev, K_dev, X_dev):
+            if p:
+                self._L.tg_device_free(self._device, p)
+                self._owned_dev.remove(p)
+        return X
+
+    def snapshot(self):
+        """Save the integrator state on the device (replayed by restore())."""
+        _lib.check(self._L.tg_batch_snapshot(self._h))
+
+    def restore(self):
+        _lib.check(self._L.tg_batch_restore(self._h))
+
+    def status(self):
+        iters = np.zeros(self._batch, dtype=np.int32)
+        status = np.zeros(self._batch, dtype=np.int32)
+        _lib.check(self._L.tg_batch_status(self._h, iters.ctypes.data, status.ctypes.data))
+        return iters, status
+
+    def synchronize(self):
+        _lib.check(self._L.tg_batch_synchronize(self._h))
+
+    def set_stream(self, hip_stream):
+        _lib.check(self._L.tg_batch_set_stream(self._h, hip_stream))
+
+    def timing(self, reset=True):
+        """(number of kernel launches, summed HIP-event duration in ms) since the last reset."""
+        import ctypes
+        n = ctypes.c_int32()
+        ms = ctypes.c_double()
+        _lib.check(self._L.tg_batch_timing(self._h, 1 if reset else 0, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
+
+class MidpointVI(object):
+    """Drop-in for ``trep.MidpointVI`` (one trajectory) on top of a batch of one."""
+
+    def __init__(self, system, tolerance=1e-10, num_threads=None, device=0):
+        # num_threads: accepted and ignored (the reference's pthread pool, midpointvi.c:9-293,
+        # is replaced by GPU parallelism).
+        self._system = system
+        self._device = device
+        self._tolerance = tolerance
+        self._b = None
+        self._cache = 0
+        self._rebuild()
+        system.add_structure_changed_func(self._structure_updated)
+
+    def _structure_updated(self):
+        self._stale = True
+
+    def _rebuild(self):
+        if self._b is not None:
+            self._b.close()
+        self._b = BatchMidpointVI(self._system, 1, self._tolerance, self._device)
+        self._stale = False
+
+    def _batch(self):
+        if self._stale:
+            self._rebuild()
+        return self._b
+
+    def __repr__(self):
+        return "<MidpointVI t1=%f t2=%f nd=%d nk=%d nc=%d nu=%d>" % (self.t1, self.t2, self.nd, self.nk, self.nc, self.nu)
+
+    system = property(lambda self: self._system)
+    nq = property(lambda self: self._batch().nq)
+    nd = property(lambda self: self._batch().nd)
+    nk = property(lambda self: self._batch().nk)
+    nu = property(lambda self: self._batch().nu)
+    nc = property(lambda self: self._batch().nc)
+
+    @property
+    def tolerance(self):
+        return self._tolerance
+
+    @tolerance.setter
+    def tolerance(self, value):
+        self._tolerance = value
+        self._batch().tolerance = value
+
+    def _vec(name):
+        def getter(self):
+            return getattr(self._batch(), name)[0].copy()
+
+        def setter(self, value):
+            self._cache = 0
+            setattr(self._batch(), name, np.asarray(value, dtype=float)[None, :])
+        return property(getter, setter)
+
+    q1 = _vec("q1")
+    q2 = _vec("q2")
+    p1 = _vec("p1")
+    p2 = _vec("p2")
+    u1 = _vec("u1")
+    lambda1 = _vec("lambda1")
+    del _vec
+
+    @property
+    def t1(self):
+        return self._batch().times()[0]
+
+    @t1.setter
+    def t1(self, t):
+        self._cache = 0
+        self._batch().set_times(t, self.t2)
+
+    @property
+    def t2(self):
+        return self._batch().times()[1]
+
+    @t2.setter
+    def t2(self, t):
+        self._cache = 0
+        self._batch().set_times(self.t1, t)
+
+    @property
+    def v2(self):
+        """Discrete kinematic velocity (q2k - q1k)/(t2 - t1) (midpointvi.py:325-332)."""
+        t1, t2 = self._batch().times()
+        if t2 != t1:
+            return ((self.q2 - self.q1) / (t2 - t1))[self.nd:]
+        return None
+
+    def initialize_from_state(self, t1, q1, p1, lambda1=None):
+        self._cache = 0
+        self._batch().initialize_from_state(t1, np.asarray(q1, dtype=float)[None, :], np.asarray(p1, dtype=float)[None, :],
+                                            None if lambda1 is None else np.asarray(lambda1, dtype=float)[None, :])
+
+    def initialize_from_configs(self, t0, q0, t1, q1, lambda1=None):
+        self._cache = 0
+        self._batch().initialize_from_configs(t0, np.asarray(q0, dtype=float)[None, :], t1, np.asarray(q1, dtype=float)[None, :],
+                                              None if lambda1 is None else np.asarray(lambda1, dtype=float)[None, :])
+
+    def calc_p2(self):
+        self._batch().calc_p2()
+
+    def calc_f(self):
+        return self._batch().calc_f()[0]
+
+    def step(self, t2, u1=tuple(), k2=tuple(), max_iterations=200, q2_hint=None, lambda1_hint=None):
+        """Advance to t2; returns the Newton iteration count, raises ConvergenceError like the
+        reference (midpointvi.py:174-201; midpointvi.c:715-718; singular -> :198-201)."""
+        u1 = np.array(u1, dtype=float)
+        k2 = np.array(k2, dtype=float)
+        assert u1.shape == (self.nu,)
+        assert k2.shape == (self.nk,)
+        iters, status = self._batch().step(t2, u1[None, :], k2[None, :], max_iterations, q2_hint, lambda1_hint)
+        if status[0] == _lib.NOT_CONVERGED:
+            raise ConvergenceError("failed to converge after %d iterations" % (max_iterations + 1))
+        if status[0] == _lib.SINGULAR:
+            raise ConvergenceError("Singular derivative of DEL at t=%s" % t2)
+        self._cache = 1
+        return int(iters[0])
