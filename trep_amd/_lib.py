@@ -11,7 +11,8 @@ import numpy as np
 from .descriptor import SystemDescStruct
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrepamd.so")
+# TREPAMD_LIB may point at a diagnostic build of the same HIP library (e.g. libtrepamd_prof.so)
+LIB_PATH = os.environ.get("TREPAMD_LIB") or os.path.join(_HERE, "libtrepamd.so")
 _LIB = None
 
 _c_dp = ctypes.POINTER(ctypes.c_double)

@@ -32,6 +32,19 @@
 
 #define TG_FOR(idx, n) for (int idx = lane; idx < (n); idx += TEAM)
 
+#if defined(__HIPCC__)
+// ROCm device-library wavefront reduction (DPP based); declared in hip/amd_detail only behind an opt-in macro
+extern "C" __device__ __attribute__((const)) unsigned long long __ockl_wfred_max_u64(unsigned long long);
+#endif
+
+// Diagnostic build only (-DTG_PROFILE, `make prof`): per-phase cycle accumulation with s_memtime.
+// Never enabled in the product library; the stamps never feed an output value.
+#if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define TG_STAMP(id) do { long long t_ = (long long)__builtin_amdgcn_s_memtime(); prof[id] += t_ - prof_last; prof_last = t_; } while (0)
+#else
+#define TG_STAMP(id) ((void)0)
+#endif
+
 namespace tg {
 
 enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2 };
@@ -45,6 +58,7 @@ struct RunArgs {
     double *X;                             // [batch][n_steps+1][nX] or null
     double *f_out;                         // MODE_CALC_F: [batch][nf]
     int *iters, *status;                   // [batch]
+    long long *prof_out;                   // diagnostic build: [16] cycle counters of trajectory 0
 };
 
 TG_HD void tg_sincos(double x, double *s, double *c) {
@@ -70,12 +84,37 @@ TG_HD double inner6(const double *I, const double *a, const double *b) {
            I[3] * (a[5] * b[5]);
 }
 
+// smallest c with 2^c >= cols, capped at log2(TEAM)
+template <int TEAM>
+TG_HD int tile_log2(int cols) {
+    int c = 0;
+    while ((1 << c) < cols && (1 << c) < TEAM) c++;
+    return c;
+}
+
+// arg-max over the team; ties resolve to the smaller index (first maximum, as a serial scan finds)
+template <int TEAM>
+TG_HD void team_argmax(double &v, int &i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int m = TEAM / 2; m >= 1; m >>= 1) {
+        const double ov = __shfl_xor(v, m, TEAM);
+        const int oi = __shfl_xor(i, m, TEAM);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+#else
+    (void)v; (void)i;
+#endif
+}
+
 template <int TEAM>
 struct Core {
     const DevProg &P;
     double *S;
     int lane;
     double dt;
+    long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_last = 0;
 
     TG_HD Core(const DevProg &p, double *s, int l, double dt_) : P(p), S(s), lane(l), dt(dt_) {}
 
@@ -226,7 +265,7 @@ struct Core {
             double force = -P.damp[i] * S[P.o_dq + i];
             for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
             double f = S[P.o_p1 + i] + (0.5 * dt * ldq - lddq) + dt * force;
-            for (int c = 0; c < P.nc; c++) f -= S[P.o_Dh1 + c * P.nq + i] * S[P.o_lam + c];
+            for (int c = 0; c < P.nc; c++) f -= S[P.o_Dh1 + c * P.dh_ld + i] * S[P.o_lam + c];
             S[P.o_f + i] = f;
         }
         TG_SYNC();
@@ -274,7 +313,7 @@ struct Core {
                 if (side & 4) val -= qval(sel, k);
                 val *= 2.0;
             }
-            Dh[c * P.nq + k] = val;
+            if (k < P.dh_ld) Dh[c * P.dh_ld + k] = val;
         }
         TG_SYNC();
     }
@@ -283,15 +322,19 @@ struct Core {
     TG_HD void newton_matrix(bool on) {
         const int nd = P.nd, nf = P.nf, ld = P.df_ld;
         double *A = S + P.o_Df;
-        if (on) TG_FOR(idx, nf * (nf + 1)) {
-            const int r = idx / (nf + 1), c = idx % (nf + 1);
-            double val;
-            if (c == nf) val = S[P.o_f + r];
-            else if (r < nd) val = c < nd ? (r == c ? -P.damp[r] : 0.0) : -S[P.o_Dh1 + (c - nd) * P.nq + r];
-            else val = c < nd ? S[P.o_Dh2 + (r - nd) * P.nq + c] : 0.0;
-            A[r * ld + c] = val;
+        if (on) {
+            const int cwl = tile_log2<TEAM>(nf + 1), cw = 1 << cwl, rstep = TEAM >> cwl;
+            for (int r = lane >> cwl; r < nf; r += rstep)
+                for (int c = lane & (cw - 1); c <= nf; c += cw) {
+                    double val;
+                    if (c == nf) val = S[P.o_f + r];
+                    else if (r < nd) val = c < nd ? (r == c ? -P.damp[r] : 0.0) : -S[P.o_Dh1 + (c - nd) * P.dh_ld + r];
+                    else val = c < nd ? S[P.o_Dh2 + (r - nd) * P.dh_ld + c] : 0.0;
+                    A[r * ld + c] = val;
+                }
         }
         TG_SYNC();
+        TG_STAMP(7);
         const double qdt = 0.25 * dt, rdt = 1.0 / dt;
         for (int b = 0; b < P.n_bodies; b++) {
             const int p0 = P.b_pair_off[b], np = P.b_pair_off[b + 1] - p0;
@@ -323,12 +366,15 @@ struct Core {
             }
             TG_SYNC();
         }
+        TG_STAMP(8);
     }
 
     // ---- Gauss-Jordan on [A | rhs] with implicit-scaled partial pivoting (pivot rule of
     //      math-code.c:337-432).  n_rhs right-hand-side columns follow the n matrix columns.
     //      Returns false (team-uniform) if a scaled pivot is <= 1e-20.  Solution left in the rhs
     //      columns divided through, i.e. A[i][n + r] = x_i.
+    //      Lane mapping is 2-D (row group x power-of-two column tile) so the inner loops need no
+    //      integer division; the pivot is an arg-max butterfly over the team.
     TG_HD bool gauss_jordan(bool on, double *A, int n, int n_rhs, int ld, double *scal) {
         bool ok = true;
         if (on) TG_FOR(i, n) {
@@ -337,45 +383,128 @@ struct Core {
             scal[i] = 1.0 / s;
         }
         TG_SYNC();
+        TG_STAMP(9);
         const int w = n + n_rhs;
         for (int k = 0; k < n; k++) {
+            double best = -1.0;
             int piv = k;
             if (on && ok) {
-                double best = -1.0;
-                for (int i = k; i < n; i++) {
+                for (int i = k + lane; i < n; i += TEAM) {
                     const double a = fabs(A[i * ld + k] * scal[i]);
                     if (a > best) { best = a; piv = i; }
                 }
-                if (!(best > 1.0e-20)) ok = false;
             }
-            TG_SYNC();
-            if (on && ok && piv != k) {
-                TG_FOR(jj, w - k) {
-                    const int j = k + jj;
+            team_argmax<TEAM>(best, piv);
+            if (on && ok && !(best > 1.0e-20)) ok = false;
+            const bool go = on && ok;
+            if (go && piv != k) {
+                for (int j = k + lane; j < w; j += TEAM) {
                     const double t = A[k * ld + j]; A[k * ld + j] = A[piv * ld + j]; A[piv * ld + j] = t;
                 }
                 if (lane == 0) scal[piv] = scal[k];
             }
             TG_SYNC();
-            if (on && ok) {
+            TG_STAMP(10);
+            if (go) {
+                const int cols = w - k - 1;              // columns k+1 .. w-1 are updated
+                const int cwl = tile_log2<TEAM>(cols);   // column tile = 2^cwl lanes, rows share the rest
+                const int cw = 1 << cwl, rstep = TEAM >> cwl;
+                const int jc = lane & (cw - 1);
                 const double rinv = 1.0 / A[k * ld + k];
-                const int cols = w - k - 1;
-                TG_FOR(idx, (n - 1) * cols) {
-                    int i = idx / cols;
-                    if (i >= k) i++;
-                    const int j = k + 1 + idx % cols;
-                    A[i * ld + j] -= (A[i * ld + k] * rinv) * A[k * ld + j];
+                for (int i = lane >> cwl; i < n; i += rstep) {
+                    if (i == k) continue;
+                    const double l = A[i * ld + k] * rinv;
+                    for (int j = k + 1 + jc; j < w; j += cw) A[i * ld + j] -= l * A[k * ld + j];
                 }
             }
             TG_SYNC();
+            TG_STAMP(11);
         }
-        if (on && ok) TG_FOR(idx, n * n_rhs) {
-            const int i = idx / n_rhs, r = idx % n_rhs;
-            A[i * ld + n + r] /= A[i * ld + i];
+        if (on && ok) {
+            for (int i = lane; i < n; i += TEAM) {
+                const double dinv = 1.0 / A[i * ld + i];
+                for (int r = 0; r < n_rhs; r++) A[i * ld + n + r] *= dinv;
+            }
         }
         TG_SYNC();
         return ok;
     }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    // ---- Gauss-Jordan with one matrix ROW PER LANE held in registers (n <= TEAM, n <= NCOL) -----------
+    //      Same pivot rule as gauss_jordan() but pivoting "in place": rows never move, the lane that owns
+    //      the pivot row of step k broadcasts it (v_readlane for a full-wave team, ds_bpermute otherwise)
+    //      and every other lane eliminates in registers.  No LDS traffic inside the k loop.
+    //      Reads [A | rhs(1 column)] from LDS, leaves x in A[i*ld + n] like gauss_jordan().
+    template <int NCOL>
+    __device__ bool gj_rows(bool on, double *A, int n, int ld) {
+        double row[NCOL], rhs = 0.0, scale = 0.0, diag = 1.0;
+        int mycol = -1;
+        const bool mine = on && lane < n;
+#pragma unroll
+        for (int j = 0; j < NCOL; j++) row[j] = (mine && j < n) ? A[lane * ld + j] : 0.0;
+        if (mine) {
+            rhs = A[lane * ld + n];
+            double s = -1.0;
+#pragma unroll
+            for (int j = 0; j < NCOL; j++) { const double a = fabs(row[j]); if (j < n && a > s) s = a; }
+            scale = 1.0 / s;
+        }
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NCOL; k++) {
+            if (k < n) {
+                // arg-max of |a_ik| * scale_i over the rows not yet used as pivots: the magnitude's bit
+                // pattern is monotone, so one u64 max carries the lane index in its 6 low bits.
+                const double cand = (mine && mycol < 0) ? fabs(row[k] * scale) : 0.0;
+                unsigned long long key = ((unsigned long long)__double_as_longlong(cand) & ~0x3FULL) | (unsigned long long)(63 - (lane & 63));
+                int piv;
+                double best;
+                if (TEAM == 64) {
+                    key = __ockl_wfred_max_u64(key);
+                } else {
+#pragma unroll
+                    for (int m = TEAM / 2; m >= 1; m >>= 1) {
+                        const unsigned long long o = __shfl_xor(key, m, TEAM);
+                        key = o > key ? o : key;
+                    }
+                }
+                piv = 63 - (int)(key & 0x3FULL);
+                best = __longlong_as_double((long long)(key & ~0x3FULL));
+                if (TEAM != 64) piv = (piv & (TEAM - 1));
+                if (on && ok && !(best > 1.0e-20)) ok = false;
+                const bool go = on && ok;
+                // broadcast the pivot row (columns k..n-1 and the rhs)
+                const int src = (TEAM == 64) ? __builtin_amdgcn_readfirstlane(piv) : piv;
+                auto bcast = [&](double v) -> double {
+                    if (TEAM == 64) {
+                        const long long b = __double_as_longlong(v);
+                        const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFLL), src);
+                        const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+                        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+                    }
+                    return __shfl(v, src, TEAM);
+                };
+                const double pkk = bcast(row[k]);
+                const double prhs = bcast(rhs);
+                const bool is_piv = mine && (lane & (TEAM - 1)) == src;
+                const double l = (go && mine && !is_piv) ? row[k] / pkk : 0.0;
+#pragma unroll
+                for (int j = k + 1; j < NCOL; j++) {
+                    if (j < n) {
+                        const double pkj = bcast(row[j]);
+                        row[j] -= l * pkj;
+                    }
+                }
+                rhs -= l * prhs;
+                if (go && is_piv) { mycol = k; diag = row[k]; }
+            }
+        }
+        if (mine && ok && mycol >= 0) A[mycol * ld + n] = rhs / diag;
+        TG_SYNC();
+        return ok;
+    }
+#endif
 
     // team-uniform convergence test (midpointvi.c:672-689)
     TG_HD bool solved(double tolerance) const {
@@ -390,17 +519,24 @@ struct Core {
     TG_HD void eval_midpoint(bool on) {
         if (on) TG_FOR(i, P.nq) S[P.o_dq + i] = (S[P.o_q2 + i] - S[P.o_q1 + i]) / dt;
         TG_SYNC();
+        TG_STAMP(0);
         pose_sweep(on, 0);
+        TG_STAMP(1);
         attach_points(on, true, false);
         jacobians(on);
+        TG_STAMP(2);
         velocities(on);
+        TG_STAMP(3);
         residual_dyn(on);
+        TG_STAMP(4);
     }
     TG_HD void eval_constraints(bool on, int sel, bool want_h, double *Dh) {
         if (P.nc == 0) return;
         pose_sweep(on, sel);
+        TG_STAMP(5);
         attach_points(on, false, true);
         constraints(on, sel, want_h, Dh);
+        TG_STAMP(6);
     }
 };
 
@@ -413,6 +549,9 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
     const size_t t = (size_t)(live ? traj : 0);
     double dt = A.mode == MODE_ROLLOUT ? A.dt : (A.t2 - A.t1);
     Core<TEAM> core(P, S, lane, dt);
+#if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    core.prof_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
 
     // ---- load state ----------------------------------------------------------------------------------
     if (live) {
@@ -420,7 +559,7 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
         TG_FOR(i, nd) S[P.o_p1 + i] = (A.mode == MODE_ROLLOUT) ? A.p2[t * nd + i] : A.p1[t * nd + i];
         TG_FOR(i, nc) S[P.o_lam + i] = A.lam[t * nc + i];
         TG_FOR(i, nu) S[P.o_u + i] = A.u1[t * nu + i];
-        TG_FOR(i, nc * nq) { S[P.o_Dh1 + i] = 0.0; S[P.o_Dh2 + i] = 0.0; }
+        TG_FOR(i, nc * P.dh_ld) { S[P.o_Dh1 + i] = 0.0; S[P.o_Dh2 + i] = 0.0; }
     }
     TG_SYNC();
 
@@ -467,7 +606,7 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
         // Dh2 of the previous step's converged q2 (same point, same inputs), so only step 0 sweeps.
         if (step == 0) core.eval_constraints(on, 1, false, S + P.o_Dh1);
         else if (nc) {
-            if (on) TG_FOR(i, nc * nq) S[P.o_Dh1 + i] = S[P.o_Dh2 + i];
+            if (on) TG_FOR(i, nc * P.dh_ld) S[P.o_Dh1 + i] = S[P.o_Dh2 + i];
             TG_SYNC();
         }
         int iterations = 0;
@@ -476,6 +615,9 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
             core.eval_midpoint(!done);
             core.eval_constraints(!done, 2, true, S + P.o_Dh2);
             if (!done && core.solved(A.tolerance)) done = true;
+#if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+            { long long t_ = (long long)__builtin_amdgcn_s_memtime(); core.prof[12] += t_ - core.prof_last; core.prof_last = t_; }
+#endif
             if (!done && iterations > A.max_iterations) { done = true; failed = true; status = TG_NOT_CONVERGED; }
 #if defined(__HIP_DEVICE_COMPILE__)
             if (__syncthreads_and(done ? 1 : 0)) break;
@@ -483,7 +625,13 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
             if (done) break;
 #endif
             core.newton_matrix(!done);
-            const bool ok = core.gauss_jordan(!done, S + P.o_Df, P.nf, 1, P.df_ld, S + P.o_scal);
+            bool ok;
+#if defined(__HIP_DEVICE_COMPILE__)
+            constexpr int NCOL = TEAM == 64 ? 32 : (TEAM > 1 ? TEAM : 2);
+            if (TEAM > 1 && P.nf <= TEAM && P.nf <= NCOL) ok = core.template gj_rows<NCOL>(!done, S + P.o_Df, P.nf, P.df_ld);
+            else
+#endif
+                ok = core.gauss_jordan(!done, S + P.o_Df, P.nf, 1, P.df_ld, S + P.o_scal);
             if (!done && !ok) { done = true; failed = true; status = TG_SINGULAR; }
             if (!done) {
                 TG_FOR(i, nd) S[P.o_q2 + i] -= S[P.o_Df + i * P.df_ld + P.nf];
@@ -506,6 +654,13 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
         }
     }
     // ---- write back q1, q2, p2, lambda1, u1 (p1 was stored when the last step started) ----------------------
+#if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    if (A.prof_out && traj == 0 && lane == 0) {
+        long long t_ = (long long)__builtin_amdgcn_s_memtime();
+        core.prof[13] += t_ - core.prof_last;
+        for (int i = 0; i < 16; i++) A.prof_out[i] = core.prof[i];
+    }
+#endif
     if (live) {
         TG_FOR(i, nq) { A.q1[t * nq + i] = S[P.o_q1 + i]; A.q2[t * nq + i] = S[P.o_q2 + i]; }
         TG_FOR(i, nd) A.p2[t * nd + i] = S[P.o_p1 + i];

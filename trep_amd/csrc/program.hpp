@@ -55,6 +55,7 @@ struct DevProg {
     int o_q1, o_q2, o_p1, o_lam, o_u, o_dq, o_f, o_sc, o_G, o_gB, o_pE, o_J, o_W, o_vB, o_gam, o_Ldq, o_Lddq,
         o_Dh1, o_Dh2, o_Df, o_scal, o_misc;
     int df_ld;
+    int dh_ld;                // leading dimension of the Dh1/Dh2 arrays in LDS (nd: dynamic columns only)
     int lds_per_team;
 };
 
@@ -246,15 +247,23 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.grav[0] = P.grav[1] = P.grav[2] = 0.0;
     for (int i = 0; i < d->n_gravity; i++)
         for (int k = 0; k < 3; k++) P.grav[k] += d->gravity[3 * (size_t)i + k];
-    // LDS layout
+    // LDS layout.  The Newton matrix is only alive between its assembly and the solve, the joint /
+    // body poses only between the pose sweep and the Jacobians / constraints, so they share storage.
     int off = 0;
     auto take = [&](int n) { int o = off; off += (n > 0 ? n : 0); return o; };
+    P.dh_ld = nd;
     P.o_q1 = take(nq); P.o_q2 = take(nq); P.o_p1 = take(nd); P.o_lam = take(nc); P.o_u = take(P.nu); P.o_dq = take(nq);
-    P.o_f = take(P.nf); P.o_sc = take(2 * nj); P.o_G = take(12 * nj); P.o_gB = take(12 * nb); P.o_pE = take(3 * P.n_endpoints);
+    P.o_f = take(P.nf);
     P.o_J = take(6 * nitems); P.o_W = take(6 * nitems); P.o_vB = take(6 * nb); P.o_gam = take(3 * nb);
-    P.o_Ldq = take(nq); P.o_Lddq = take(nq); P.o_Dh1 = take(nc * nq); P.o_Dh2 = take(nc * nq);
+    P.o_Ldq = take(nd); P.o_Lddq = take(nd); P.o_Dh1 = take(nc * P.dh_ld); P.o_Dh2 = take(nc * P.dh_ld);
+    P.o_scal = take(P.nf); P.o_misc = take(2);
     P.df_ld = (P.nf + 1) | 1;  // augmented with the right-hand side; odd stride avoids LDS bank conflicts
-    P.o_Df = take(P.nf * P.df_ld); P.o_scal = take(P.nf); P.o_misc = take(8);
+    const int shared0 = off;
+    P.o_Df = take(P.nf * P.df_ld);
+    const int end_df = off;
+    off = shared0;
+    P.o_sc = take(2 * nj); P.o_G = take(12 * nj); P.o_gB = take(12 * nb); P.o_pE = take(3 * P.n_endpoints);
+    off = std::max(off, end_df);
     P.lds_per_team = (off + 1) & ~1;
     return H;
 }

@@ -53,6 +53,7 @@ struct tg_batch {
     double *q1 = nullptr, *q2 = nullptr, *p1 = nullptr, *p2 = nullptr, *lam = nullptr, *u1 = nullptr;
     double *stage_u = nullptr, *stage_k = nullptr, *stage_qh = nullptr, *stage_lh = nullptr, *f_out = nullptr;
     int *iters = nullptr, *status = nullptr;
+    long long *prof = nullptr; // diagnostic build only (TG_PROFILE)
     double *snap = nullptr;    // snapshot of (q1,q2,p1,p2,lam,u1)
     double snap_t1 = 0.0, snap_t2 = 0.0;
     long long total_iters = 0;
@@ -133,6 +134,7 @@ tg::RunArgs base_args(tg_batch *b, int mode) {
     A.t1 = b->t1; A.t2 = b->t2; A.tolerance = b->tolerance;
     A.q1 = b->q1; A.q2 = b->q2; A.p1 = b->p1; A.p2 = b->p2; A.lam = b->lam; A.u1 = b->u1;
     A.iters = b->iters; A.status = b->status; A.f_out = b->f_out;
+    A.prof_out = b->prof;
     return A;
 }
 
@@ -233,6 +235,9 @@ tg_batch *tg_batch_create(tg_system *sys, int32_t batch, int32_t device) {
     dalloc(&b->snap, B * (2 * (size_t)P.nq + 2 * (size_t)P.nd + P.nc + P.nu));
     if (ok) ok = hipMalloc(&b->iters, B * sizeof(int)) == hipSuccess && hipMalloc(&b->status, B * sizeof(int)) == hipSuccess &&
                  hipMemset(b->iters, 0, B * sizeof(int)) == hipSuccess && hipMemset(b->status, 0, B * sizeof(int)) == hipSuccess;
+#if defined(TG_PROFILE)
+    if (ok) ok = hipMalloc(&b->prof, 16 * sizeof(long long)) == hipSuccess && hipMemset(b->prof, 0, 16 * sizeof(long long)) == hipSuccess;
+#endif
     if (ok) ok = hipStreamCreate(&b->stream) == hipSuccess;
     if (!ok) { fail(TG_ERR_HIP, "device allocation failed"); tg_batch_destroy(b); return nullptr; }
     return b;
@@ -403,6 +408,16 @@ int tg_batch_restore(tg_batch *b) {
     HIP_TRY(hipSetDevice(b->device));
     b->t1 = b->snap_t1; b->t2 = b->snap_t2;
     return snapshot_copy(b, false);
+}
+
+/* Diagnostic build (make prof): per-phase cycle counters of trajectory 0 of the last launch. */
+int tg_batch_profile(tg_batch *b, int64_t out[16]) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    if (!b->prof) return fail(TG_ERR_UNSUPPORTED, "library was not built with TG_PROFILE");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(out, b->prof, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    return TG_SUCCESS;
 }
 
 int tg_batch_deriv1(tg_batch *b) {
