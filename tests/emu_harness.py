@@ -21,7 +21,7 @@ class RunArgs(ctypes.Structure):
                 ("tolerance", ctypes.c_double),
                 ("q1", _D), ("q2", _D), ("p1", _D), ("p2", _D), ("lam", _D), ("u1", _D),
                 ("U", _D), ("K", _D), ("q2_hint", _D), ("lam_hint", _D), ("X", _D), ("f_out", _D),
-                ("iters", _I), ("status", _I)]
+                ("d1", _D * 12), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p)]
 
 
 def lib():
@@ -93,6 +93,19 @@ class EmuBatch(object):
         a = self._args(2, f=f)
         self.L.emu_run(self.h, ctypes.byref(a))
         return f
+
+    def deriv1(self):
+        """Returns {name: [B][var][out]} for the 12 first-derivative arrays of the last solved step."""
+        rows = {"dq1": self.nq, "dp1": self.nd, "du1": self.nu, "dk2": self.nk}
+        outs = {}
+        a = self._args(3)
+        for oi, (pre, width) in enumerate((("q2", self.nd), ("p2", self.nd), ("l1", self.nc))):
+            for ki, var in enumerate(("dq1", "dp1", "du1", "dk2")):
+                arr = np.zeros((self.B, rows[var], width))
+                outs["%s_%s" % (pre, var)] = arr
+                a.d1[4 * oi + ki] = arr.ctypes.data_as(_D) if arr.size else ctypes.cast(0, _D)
+        self.L.emu_run(self.h, ctypes.byref(a))
+        return outs
 
     def rollout(self, n_steps, dt, U=None, K=None, want_X=True, q2_hint=None, lam_hint=None):
         U = None if U is None else np.ascontiguousarray(U, dtype=float)

@@ -211,3 +211,47 @@ def test_failure_statuses_and_edge_cases():
     with pytest.raises(trep_amd.ConvergenceError):
         one.step(2 * DT, [1.0], max_iterations=0)
     mvi.close()
+
+
+@pytest.mark.parametrize("name", sorted(BUILDERS))
+def test_first_derivatives_match_reference(name):
+    """A_k / B_k ingredients: the twelve deriv1 arrays after a teacher-forced step."""
+    import trep_amd
+    from common import D1
+    g = golden(name)
+    system, d = build(name)
+    prefix, q0, U, K = trajectories(name)[0]
+    Q, P, LAM = g[prefix + "Q"], g[prefix + "P"], g[prefix + "LAM"]
+    steps = sorted(int(k.split("_")[-3]) for k in g if k.startswith(prefix + "d1_") and k.endswith("q2_dq1"))
+    B = 3  # same case in every slot: also checks batch independence
+    mvi = trep_amd.BatchMidpointVI(system, B)
+    for s_ in steps:
+        k = s_ - 1
+        mvi.initialize_from_state((k + 1) * DT, Q[k], P[k], LAM[k])
+        it, st = mvi.step((k + 2) * DT, U[k] if U.shape[1] else None, K[k] if K.shape[1] else None)
+        assert (st == 0).all()
+        mvi.calc_deriv1()
+        for n in D1:
+            got = mvi.deriv1(n)
+            assert relerr(got[0], g["%sd1_%d_%s" % (prefix, s_, n)]) < 1e-9, (name, s_, n)
+            assert np.array_equal(got[0], got[2])
+    mvi.close()
+
+
+def test_deriv1_accessors_dropin():
+    """MidpointVI.q2_dq1(...) etc. keep the reference's indexing semantics (midpointvi.py:337-371)."""
+    import trep_amd
+    g = golden("pend_on_cart")
+    system, d = build("pend_on_cart")
+    mvi = trep_amd.MidpointVI(system)
+    Q, P, LAM, U = g["b0_Q"], g["b0_P"], g["b0_LAM"], g["b0_U"]
+    mvi.initialize_from_state(DT, Q[0], P[0], LAM[0])
+    with pytest.raises(Exception):
+        mvi.q2_dq1()
+    mvi.step(2 * DT, U[0])
+    ref = g["b0_d1_1_q2_dq1"]
+    assert relerr(mvi.q2_dq1(), ref.T) < 1e-10
+    x, th = system.get_config("x"), system.get_config("theta")
+    assert abs(mvi.q2_dq1(th, x) - ref[0, 1]) < 1e-10
+    assert relerr(mvi.p2_du1(), g["b0_d1_1_p2_du1"].T) < 1e-10
+    assert mvi.q2_dk2().shape == (2, 0)

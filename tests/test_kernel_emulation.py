@@ -55,3 +55,23 @@ def test_emulated_residual_matches_oracle():
     e.t1, e.t2 = 0.1, 0.11
     f = e.calc_f()[0]
     assert relerr(f, f_ref) < 1e-12
+
+
+@pytest.mark.parametrize("name", sorted(BUILDERS))
+def test_emulated_first_derivatives_match_reference(name):
+    from common import D1
+    g = golden(name)
+    system, d = build(name)
+    prefix, q0, U, K = trajectories(name)[0]
+    Q, P, LAM = g[prefix + "Q"], g[prefix + "P"], g[prefix + "LAM"]
+    steps = sorted(int(k.split("_")[-3]) for k in g if k.startswith(prefix + "d1_") and k.endswith("q2_dq1"))
+    for s_ in steps:
+        k = s_ - 1
+        e = EmuBatch(d, 1)
+        e.t1 = e.t2 = (k + 1) * DT
+        e.q1[0], e.q2[0], e.p1[0], e.p2[0], e.lam[0] = Q[k], Q[k], P[k], P[k], LAM[k]
+        e.rollout(1, DT, U[None, k:k + 1], K[None, k:k + 1], want_X=False)
+        assert relerr(e.q2[0], Q[k + 1]) < 1e-11
+        out = e.deriv1()
+        for n in D1:
+            assert relerr(out[n][0], g["%sd1_%d_%s" % (prefix, s_, n)]) < 1e-9, (name, s_, n)

@@ -20,6 +20,7 @@ _c_ip = ctypes.POINTER(ctypes.c_int32)
 
 # field ids of include/trep_amd.h
 F_Q1, F_Q2, F_P1, F_P2, F_U1, F_LAMBDA1 = 0, 1, 2, 3, 4, 5
+F_D1_BASE = 10  # TG_F_Q2_DQ1; order q2_d{q1,p1,u1,k2}, p2_d*, l1_d*
 OK, NOT_CONVERGED, SINGULAR = 0, 1, 2
 
 _SIGNATURES = {

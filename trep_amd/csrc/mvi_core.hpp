@@ -47,7 +47,7 @@ extern "C" __device__ __attribute__((const)) unsigned long long __ockl_wfred_max
 
 namespace tg {
 
-enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2 };
+enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3 };
 
 struct RunArgs {
     int batch, n_steps, max_iterations, mode, first_is_init;
@@ -57,6 +57,7 @@ struct RunArgs {
     const double *q2_hint, *lam_hint;      // [batch][nd], [batch][nc] or null
     double *X;                             // [batch][n_steps+1][nX] or null
     double *f_out;                         // MODE_CALC_F: [batch][nf]
+    double *d1[12];                        // MODE_DERIV1 outputs q2_d{q1,p1,u1,k2}, p2_d*, l1_d*: [batch][var][out]
     int *iters, *status;                   // [batch]
     long long *prof_out;                   // diagnostic build: [16] cycle counters of trajectory 0
 };
@@ -287,7 +288,7 @@ struct Core {
 
     // ---- constraint values (into f[nd..]) and Jacobian Dh (into dest) at the swept state -------------
     // distance.c:16-63, point.c:16-38.  `sel` picks the config vector for the length configs.
-    TG_HD void constraints(bool on, int sel, bool want_h, double *Dh) {
+    TG_HD void constraints(bool on, int sel, bool want_h, double *Dh, int ld) {
         if (on && want_h) TG_FOR(c, P.nc) {
             const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
             const double vx = a[0] - b[0], vy = a[1] - b[1], vz = a[2] - b[2];
@@ -313,7 +314,7 @@ struct Core {
                 if (side & 4) val -= qval(sel, k);
                 val *= 2.0;
             }
-            if (k < P.dh_ld) Dh[c * P.dh_ld + k] = val;
+            if (k < ld) Dh[c * ld + k] = val;
         }
         TG_SYNC();
     }
@@ -506,6 +507,171 @@ struct Core {
     }
 #endif
 
+    // =====================================================================================================
+    // First derivatives of the step map (reference MidpointVI_calc_deriv1, midpointvi.c:749-1120).
+    // The reference factors M2 and the projected matrix -Dh2 M2^-1 Dh1T separately and solves each
+    // derivative variable in turn; here all nq+nd+nu+nk right-hand sides are appended to the SAME
+    // Newton/KKT matrix [[M2, -Dh1T],[Dh2, 0]] (M2 = Df11 at the solution) and eliminated together.
+    // =====================================================================================================
+
+    // sum_c lambda_c h_c,dqdq(q_i, q_o) added to the q1 right-hand sides (calc_h1_deriv1 :864-889 and
+    // the DDh1T term of calc_deriv1 :964-966); state q1 must be swept, pE valid.
+    TG_HD void constraint_hessian_rhs(bool on, double *AUG, int ld) {
+        const int nq = P.nq, nd = P.nd, nf = P.nf;
+        if (on) {
+            const int cwl = tile_log2<TEAM>(nd), cw = 1 << cwl, rstep = TEAM >> cwl;
+            for (int i = lane >> cwl; i < nq; i += rstep)
+                for (int o = lane & (cw - 1); o < nd; o += cw) {
+                    double acc = 0.0;
+                    for (int c = 0; c < P.nc; c++) {
+                        const int ni = P.dh_lookup[c * nq + i], no = P.dh_lookup[c * nq + o];
+                        if (ni < 0 || no < 0) continue;
+                        const int si = P.dh_side[ni], so = P.dh_side[no], ji = P.dh_joint[ni], jo = P.dh_joint[no];
+                        double hqq = 0.0;
+                        if (ji >= 0 && jo >= 0) {
+                            const int e1 = P.c_e1[c], e2 = P.c_e2[c];
+                            double di1[3] = {0, 0, 0}, do1[3] = {0, 0, 0}, di2[3] = {0, 0, 0}, do2[3] = {0, 0, 0};
+                            if (si & 1) dpos(e1, ji, di1);
+                            if (so & 1) dpos(e1, jo, do1);
+                            if (si & 2) dpos(e2, ji, di2);
+                            if (so & 2) dpos(e2, jo, do2);
+                            // second derivative of each end point: w_a x d_b with a the joint nearer the root
+                            const int ja = ji < jo ? ji : jo;
+                            double dd[3] = {0, 0, 0};
+                            if (P.j_kind[ja] >= TG_RX) {
+                                const double *ga = S + P.o_G + 12 * ja;
+                                const int ax = P.j_kind[ja] - TG_RX;
+                                const double wx = ga[ax], wy = ga[4 + ax], wz = ga[8 + ax];
+                                if ((si & 1) && (so & 1)) {
+                                    const double *db = ji < jo ? do1 : di1;
+                                    dd[0] += wy * db[2] - wz * db[1]; dd[1] += wz * db[0] - wx * db[2]; dd[2] += wx * db[1] - wy * db[0];
+                                }
+                                if ((si & 2) && (so & 2)) {
+                                    const double *db = ji < jo ? do2 : di2;
+                                    dd[0] -= wy * db[2] - wz * db[1]; dd[1] -= wz * db[0] - wx * db[2]; dd[2] -= wx * db[1] - wy * db[0];
+                                }
+                            }
+                            if (P.c_type[c] == TG_CONSTRAINT_POINT) hqq = dd[P.c_comp[c]];
+                            else {
+                                const double *a = S + P.o_pE + 3 * e1, *b = S + P.o_pE + 3 * e2;
+                                const double vx = a[0] - b[0], vy = a[1] - b[1], vz = a[2] - b[2];
+                                hqq = 2.0 * ((di1[0] - di2[0]) * (do1[0] - do2[0]) + (di1[1] - di2[1]) * (do1[1] - do2[1]) +
+                                             (di1[2] - di2[2]) * (do1[2] - do2[2]) + vx * dd[0] + vy * dd[1] + vz * dd[2]);
+                            }
+                        } else if ((si & 4) && (so & 4) && i == o) {
+                            hqq = -2.0;  // distance.c:90-93: both are the string-length config
+                        }
+                        acc += hqq * S[P.o_lam + c];
+                    }
+                    AUG[o * ld + nf + i] += acc;
+                }
+        }
+        TG_SYNC();
+    }
+
+    TG_HD void deriv1(bool on, const RunArgs &A, size_t t) {
+        const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nf = P.nf;
+        const int ld = P.d_aug_ld, R = P.d_nrhs, w = nf + R;
+        double *AUG = S + P.d_o_AUG, *T12 = S + P.d_o_T12, *T22 = S + P.d_o_T22;
+        double *Dh1 = S + P.d_o_Dh1, *Dh2 = S + P.d_o_Dh2;
+        const int c_q1 = nf, c_p1 = nf + nq, c_u1 = nf + nq + nd, c_k2 = nf + nq + nd + nu;
+        if (on) {
+            TG_FOR(i, nf * ld) AUG[i] = 0.0;
+            TG_FOR(i, nq * nd) { T12[i] = 0.0; T22[i] = 0.0; }
+            TG_FOR(i, nc * nq) { Dh1[i] = 0.0; Dh2[i] = 0.0; }
+        }
+        TG_SYNC();
+        // constraints at q1: Jacobian (held in the KKT matrix) and lambda-weighted Hessian
+        if (nc) {
+            pose_sweep(on, 1);
+            attach_points(on, false, true);
+            constraints(on, 1, false, Dh1, nq);
+            constraint_hessian_rhs(on, AUG, ld);
+            pose_sweep(on, 2);
+            attach_points(on, false, true);
+            constraints(on, 2, false, Dh2, nq);
+        }
+        eval_midpoint(on);
+        // constant blocks: forces (damping.c:21-27, configforce.c:27-33), -Dh1T, Dh2, unit p1 columns, k2 constraint rows
+        if (on) {
+            TG_FOR(o, nd) {
+                AUG[o * ld + o] -= P.damp[o];              // D2D1L2_D2fm2: + dF_o/d(dq_o)
+                AUG[o * ld + c_q1 + o] -= P.damp[o];       // -(D1D1L2_D1fm2): -( - dF_o/d(dq_o) )
+                AUG[o * ld + c_p1 + o] = -1.0;
+                for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == o) AUG[o * ld + c_u1 + P.cf_in[k]] -= dt;
+                for (int c = 0; c < nc; c++) AUG[o * ld + nd + c] = -Dh1[c * nq + o];
+            }
+            TG_FOR(c, nc) {
+                for (int o = 0; o < nd; o++) AUG[(nd + c) * ld + o] = Dh2[c * nq + o];
+                for (int i = 0; i < nk; i++) AUG[(nd + c) * ld + c_k2 + i] = -Dh2[c * nq + nd + i];
+            }
+        }
+        TG_SYNC();
+        // second-order discrete-Lagrangian tables from the (item,item) pairs (calc_deriv1_cache :749-861):
+        //   a = dt/4 L_qq, b = L_dqdq/dt, c(r,o) = 1/2 L(dq_r, q_o);  D1D1 = a+b-c-cT, D2D1 = a-b+c-cT,
+        //   D1D2 = a-b-c+cT, D2D2 = a+b+c+cT.
+        const double qdt = 0.25 * dt, rdt = 1.0 / dt;
+        for (int b = 0; b < P.n_bodies; b++) {
+            const int p0 = P.b_pair_off[b], np = P.b_pair_off[b + 1] - p0;
+            const double *I = P.b_inertia + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
+            if (on) TG_FOR(pp, np) {
+                const int ia = P.pair_a[p0 + pp], ib = P.pair_b[p0 + pp];
+                const int ca = P.it_cfg[ia], cb = P.it_cfg[ib];
+                if (ca >= nd && cb >= nd) continue;
+                const double *Ja = S + P.o_J + 6 * ia, *Jb = S + P.o_J + 6 * ib;
+                const double *Wa = S + P.o_W + 6 * ia, *Wb = S + P.o_W + 6 * ib;
+                double tb[6];
+                bracket(Wa, Jb, tb);
+                const double lqq = inner6(I, tb, v) + inner6(I, Wa, Wb) +
+                                   I[0] * (gam[0] * (Ja[4] * Jb[2] - Ja[5] * Jb[1]) + gam[1] * (Ja[5] * Jb[0] - Ja[3] * Jb[2]) +
+                                           gam[2] * (Ja[3] * Jb[1] - Ja[4] * Jb[0]));
+                const double a_ = qdt * lqq, b_ = rdt * inner6(I, Ja, Jb);
+                double c_ab, c_ba;
+                if (ia == ib) { c_ab = c_ba = 0.5 * inner6(I, Ja, Wa); }
+                else {
+                    bracket(Ja, Jb, tb);
+                    c_ab = 0.5 * (inner6(I, tb, v) + inner6(I, Ja, Wb));
+                    c_ba = 0.5 * inner6(I, Jb, Wa);
+                }
+                auto add = [&](int r, int o, double c_ro, double c_or) {
+                    if (o >= nd) return;
+                    AUG[o * ld + c_q1 + r] -= a_ + b_ - c_ro - c_or;
+                    const double d21 = a_ - b_ + c_ro - c_or;
+                    if (r < nd) AUG[o * ld + r] += d21;
+                    else AUG[o * ld + c_k2 + (r - nd)] -= d21;
+                    T12[r * nd + o] += a_ - b_ - c_ro + c_or;
+                    T22[r * nd + o] += a_ + b_ + c_ro + c_or;
+                };
+                add(ca, cb, c_ab, c_ba);
+                if (ia != ib) add(cb, ca, c_ba, c_ab);
+            }
+            TG_SYNC();
+        }
+        const bool ok = gauss_jordan(on, AUG, nf, R, ld, S + P.o_scal);
+        // outputs in the reference layout [derivative variable][output] (trep.h:425-437)
+        if (on) {
+            const int cwl = tile_log2<TEAM>(nd), cw = 1 << cwl, rstep = TEAM >> cwl;
+            for (int vv = lane >> cwl; vv < R; vv += rstep) {
+                int kind, i;
+                if (vv < nq) { kind = 0; i = vv; }
+                else if (vv < nq + nd) { kind = 1; i = vv - nq; }
+                else if (vv < nq + nd + nu) { kind = 2; i = vv - nq - nd; }
+                else { kind = 3; i = vv - nq - nd - nu; }
+                const int rows = kind == 0 ? nq : (kind == 1 ? nd : (kind == 2 ? nu : nk));
+                for (int o = lane & (cw - 1); o < nd; o += cw) {
+                    const double x = ok ? AUG[o * ld + nf + vv] : NAN;
+                    double p = kind == 0 ? T12[i * nd + o] : (kind == 3 ? T22[(nd + i) * nd + o] : 0.0);
+                    for (int i2 = 0; i2 < nd; i2++) p += T22[i2 * nd + o] * AUG[i2 * ld + nf + vv];
+                    A.d1[kind][(t * rows + i) * nd + o] = x;
+                    A.d1[4 + kind][(t * rows + i) * nd + o] = ok ? p : NAN;
+                }
+                for (int c = lane & (cw - 1); c < nc; c += cw)
+                    A.d1[8 + kind][(t * rows + i) * nc + c] = ok ? AUG[(nd + c) * ld + nf + vv] : NAN;
+            }
+        }
+        (void)w;
+    }
+
     // team-uniform convergence test (midpointvi.c:672-689)
     TG_HD bool solved(double tolerance) const {
         double norm = 0.0;
@@ -530,12 +696,13 @@ struct Core {
         residual_dyn(on);
         TG_STAMP(4);
     }
-    TG_HD void eval_constraints(bool on, int sel, bool want_h, double *Dh) {
+    TG_HD void eval_constraints(bool on, int sel, bool want_h, double *Dh, int ld = -1) {
         if (P.nc == 0) return;
+        if (ld < 0) ld = P.dh_ld;
         pose_sweep(on, sel);
         TG_STAMP(5);
         attach_points(on, false, true);
-        constraints(on, sel, want_h, Dh);
+        constraints(on, sel, want_h, Dh, ld);
         TG_STAMP(6);
     }
 };
@@ -566,6 +733,10 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
     if (A.mode == MODE_CALC_P2) {  // MidpointVI.calc_p2: midpointvi.c:491-504
         core.eval_midpoint(live);
         if (live) TG_FOR(i, nd) A.p2[t * nd + i] = 0.5 * dt * S[P.o_Ldq + i] + S[P.o_Lddq + i];
+        return;
+    }
+    if (A.mode == MODE_DERIV1) {
+        core.deriv1(live, A, t);
         return;
     }
     if (A.mode == MODE_CALC_F) {  // MidpointVI.calc_f: midpointvi.c:567-575

@@ -48,6 +48,7 @@ struct DevProg {
     const double *e_off;      // [n_endpoints*3]
     const int *c_type, *c_e1, *c_e2, *c_cfg, *c_comp;
     const double *c_dist, *c_tol;
+    const int *dh_lookup;     // [nc*nq] index into the dh items of (constraint, config), -1 if independent
     const int *dh_c, *dh_cfg, *dh_joint, *dh_side; // side: bit0 on e1's path, bit1 on e2's path, bit2 length config
     const double *damp;       // [nd] summed damping coefficients
     const int *cf_cfg, *cf_in;
@@ -57,6 +58,8 @@ struct DevProg {
     int df_ld;
     int dh_ld;                // leading dimension of the Dh1/Dh2 arrays in LDS (nd: dynamic columns only)
     int lds_per_team;
+    // first-derivative kernel: extra arrays appended after the step layout
+    int d_o_Dh1, d_o_Dh2, d_o_AUG, d_aug_ld, d_o_T12, d_o_T22, d_nrhs, d_lds_per_team;
 };
 
 struct HostProgram {
@@ -70,7 +73,7 @@ struct HostProgram {
     std::vector<double> e_off;
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
     std::vector<double> c_dist, c_tol;
-    std::vector<int> dh_c, dh_cfg, dh_joint, dh_side;
+    std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup;
     std::vector<double> damp;
     std::vector<int> cf_cfg, cf_in;
     int max_depth = 0;
@@ -214,6 +217,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
         H.e_off.push_back(offset[f].m[3]); H.e_off.push_back(offset[f].m[7]); H.e_off.push_back(offset[f].m[11]);
         return e;
     };
+    H.dh_lookup.assign((size_t)nc * nq, -1);
     for (int c = 0; c < nc; c++) {
         int t = d->constraint_type[c];
         if (t != TG_CONSTRAINT_DISTANCE && t != TG_CONSTRAINT_POINT) throw std::runtime_error("unknown constraint type");
@@ -228,6 +232,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
             bool on2 = d->frame_cache_index[(size_t)f2 * (nq + 1) + g] == k;
             bool isl = (k == lc);
             if (!on1 && !on2 && !isl) continue;
+            H.dh_lookup[(size_t)c * nq + k] = (int)H.dh_c.size();
             H.dh_c.push_back(c); H.dh_cfg.push_back(k); H.dh_joint.push_back(joint_of_cfg[k]);
             H.dh_side.push_back((on1 ? 1 : 0) | (on2 ? 2 : 0) | (isl ? 4 : 0));
         }
@@ -265,6 +270,15 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.o_sc = take(2 * nj); P.o_G = take(12 * nj); P.o_gB = take(12 * nb); P.o_pE = take(3 * P.n_endpoints);
     off = std::max(off, end_df);
     P.lds_per_team = (off + 1) & ~1;
+    // first-derivative kernel (MODE_DERIV1): full-width constraint Jacobians, the augmented KKT matrix
+    // [Df | one right-hand side per derivative variable] and the two D.D2L2 tables
+    off = P.lds_per_team;
+    P.d_nrhs = nq + nd + P.nu + P.nk;
+    P.d_o_Dh1 = take(nc * nq); P.d_o_Dh2 = take(nc * nq);
+    P.d_aug_ld = (P.nf + P.d_nrhs) | 1;
+    P.d_o_AUG = take(P.nf * P.d_aug_ld);
+    P.d_o_T12 = take(nq * nd); P.d_o_T22 = take(nq * nd);
+    P.d_lds_per_team = (off + 1) & ~1;
     return H;
 }
 

@@ -34,7 +34,8 @@ __global__ __launch_bounds__(64) void k_run(const tg::DevProg P, const tg::RunAr
     extern __shared__ double lds[];
     const int team = threadIdx.x / TEAM, lane = threadIdx.x % TEAM;
     const int traj = blockIdx.x * (64 / TEAM) + team;
-    tg::run_trajectory<TEAM>(P, A, lds + (size_t)team * P.lds_per_team, lane, traj);
+    const int stride = A.mode == tg::MODE_DERIV1 ? P.d_lds_per_team : P.lds_per_team;
+    tg::run_trajectory<TEAM>(P, A, lds + (size_t)team * stride, lane, traj);
 }
 
 }  // namespace
@@ -53,6 +54,8 @@ struct tg_batch {
     double *q1 = nullptr, *q2 = nullptr, *p1 = nullptr, *p2 = nullptr, *lam = nullptr, *u1 = nullptr;
     double *stage_u = nullptr, *stage_k = nullptr, *stage_qh = nullptr, *stage_lh = nullptr, *f_out = nullptr;
     int *iters = nullptr, *status = nullptr;
+    double *d1[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool have_d1 = false;
     long long *prof = nullptr; // diagnostic build only (TG_PROFILE)
     double *snap = nullptr;    // snapshot of (q1,q2,p1,p2,lam,u1)
     double snap_t1 = 0.0, snap_t2 = 0.0;
@@ -73,8 +76,14 @@ int widths(const tg_batch *b, int field) {
     case TG_F_P1: case TG_F_P2: return P.nd;
     case TG_F_U1: return P.nu;
     case TG_F_LAMBDA1: return P.nc;
-    default: return -1;
+    default: break;
     }
+    if (field >= TG_F_Q2_DQ1 && field <= TG_F_L1_DK2) {
+        const int k = field - TG_F_Q2_DQ1, var = k % 4, out = k / 4;
+        const int rows = var == 0 ? P.nq : (var == 1 ? P.nd : (var == 2 ? P.nu : P.nk));
+        return rows * (out == 2 ? P.nc : P.nd);
+    }
+    return -1;
 }
 double *field_ptr(tg_batch *b, int field) {
     switch (field) {
@@ -84,8 +93,10 @@ double *field_ptr(tg_batch *b, int field) {
     case TG_F_P2: return b->p2;
     case TG_F_U1: return b->u1;
     case TG_F_LAMBDA1: return b->lam;
-    default: return nullptr;
+    default: break;
     }
+    if (field >= TG_F_Q2_DQ1 && field <= TG_F_L1_DK2) return b->d1[field - TG_F_Q2_DQ1];
+    return nullptr;
 }
 
 int pick_team(const tg::HostProgram &H) {
@@ -108,10 +119,21 @@ void append(std::vector<T> &pool, const std::vector<T> &v, size_t &off) {
     while (pool.size() % 2) pool.push_back(T());
 }
 
+template <int TEAM>
+int allow_lds(size_t bytes) {
+    if (bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<TEAM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return TG_SUCCESS;
+}
+
 int launch(tg_batch *b, tg::RunArgs &A) {
     const int team = b->sys->team, per_block = 64 / team;
     const int grid = (A.batch + per_block - 1) / per_block;
-    const size_t lds = (size_t)per_block * b->P.lds_per_team * sizeof(double);
+    const int per_team = A.mode == tg::MODE_DERIV1 ? b->P.d_lds_per_team : b->P.lds_per_team;
+    const size_t lds = (size_t)per_block * per_team * sizeof(double);
+    if (lds > 160 * 1024) return fail(TG_ERR_UNSUPPORTED, "system too large for the LDS-resident kernel");
+    int rc = team == 64 ? allow_lds<64>(lds) : (team == 16 ? allow_lds<16>(lds) : (team == 4 ? allow_lds<4>(lds) : allow_lds<1>(lds)));
+    if (rc) return rc;
     hipEvent_t e0, e1;
     if (b->pool.size() >= 2) { e0 = b->pool.back(); b->pool.pop_back(); e1 = b->pool.back(); b->pool.pop_back(); }
     else { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); }
@@ -135,6 +157,7 @@ tg::RunArgs base_args(tg_batch *b, int mode) {
     A.q1 = b->q1; A.q2 = b->q2; A.p1 = b->p1; A.p2 = b->p2; A.lam = b->lam; A.u1 = b->u1;
     A.iters = b->iters; A.status = b->status; A.f_out = b->f_out;
     A.prof_out = b->prof;
+    for (int i = 0; i < 12; i++) A.d1[i] = b->d1[i];
     return A;
 }
 
@@ -204,7 +227,9 @@ tg_batch *tg_batch_create(tg_system *sys, int32_t batch, int32_t device) {
     append(ints, H.c_e2, oi[18]); append(ints, H.c_cfg, oi[19]); append(ints, H.c_comp, oi[20]);
     append(ints, H.dh_c, oi[21]); append(ints, H.dh_cfg, oi[22]); append(ints, H.dh_joint, oi[23]);
     size_t o_side, o_cfc, o_cfi;
+    size_t o_lookup;
     append(ints, H.dh_side, o_side); append(ints, H.cf_cfg, o_cfc); append(ints, H.cf_in, o_cfi);
+    append(ints, H.dh_lookup, o_lookup);
     append(dbls, H.j_pre, od[0]); append(dbls, H.b_C, od[1]); append(dbls, H.b_inertia, od[2]);
     append(dbls, H.e_off, od[3]); append(dbls, H.c_dist, od[4]); append(dbls, H.c_tol, od[5]); append(dbls, H.damp, od[6]);
     ints.push_back(0); dbls.push_back(0.0);
@@ -220,7 +245,7 @@ tg_batch *tg_batch_create(tg_system *sys, int32_t batch, int32_t device) {
     P.cfg_item_off = I + oi[13]; P.cfg_items = I + oi[14]; P.e_anchor = I + oi[15]; P.c_type = I + oi[16];
     P.c_e1 = I + oi[17]; P.c_e2 = I + oi[18]; P.c_cfg = I + oi[19]; P.c_comp = I + oi[20];
     P.dh_c = I + oi[21]; P.dh_cfg = I + oi[22]; P.dh_joint = I + oi[23]; P.dh_side = I + o_side;
-    P.cf_cfg = I + o_cfc; P.cf_in = I + o_cfi;
+    P.cf_cfg = I + o_cfc; P.cf_in = I + o_cfi; P.dh_lookup = I + o_lookup;
     P.j_pre = D + od[0]; P.b_C = D + od[1]; P.b_inertia = D + od[2]; P.e_off = D + od[3];
     P.c_dist = D + od[4]; P.c_tol = D + od[5]; P.damp = D + od[6];
     auto dalloc = [&](double **p, size_t n) {
@@ -232,6 +257,11 @@ tg_batch *tg_batch_create(tg_system *sys, int32_t batch, int32_t device) {
     dalloc(&b->lam, B * P.nc); dalloc(&b->u1, B * P.nu);
     dalloc(&b->stage_u, B * P.nu); dalloc(&b->stage_k, B * P.nk); dalloc(&b->stage_qh, B * P.nd); dalloc(&b->stage_lh, B * P.nc);
     dalloc(&b->f_out, B * P.nf);
+    for (int k = 0; k < 12; k++) {
+        const int var = k % 4, out = k / 4;
+        const size_t rows = var == 0 ? P.nq : (var == 1 ? P.nd : (var == 2 ? P.nu : P.nk));
+        dalloc(&b->d1[k], B * rows * (out == 2 ? P.nc : P.nd));
+    }
     dalloc(&b->snap, B * (2 * (size_t)P.nq + 2 * (size_t)P.nd + P.nc + P.nu));
     if (ok) ok = hipMalloc(&b->iters, B * sizeof(int)) == hipSuccess && hipMalloc(&b->status, B * sizeof(int)) == hipSuccess &&
                  hipMemset(b->iters, 0, B * sizeof(int)) == hipSuccess && hipMemset(b->status, 0, B * sizeof(int)) == hipSuccess;
@@ -250,7 +280,8 @@ void tg_batch_destroy(tg_batch *b) {
     for (auto &e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : b->pool) hipEventDestroy(e);
     void *ptrs[] = {b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
-                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap};
+                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap,
+                    b->d1[0], b->d1[1], b->d1[2], b->d1[3], b->d1[4], b->d1[5], b->d1[6], b->d1[7], b->d1[8], b->d1[9], b->d1[10], b->d1[11]};
     for (void *p : ptrs) if (p) hipFree(p);
     if (b->stream && b->own_stream) hipStreamDestroy(b->stream);
     delete b;
@@ -421,8 +452,15 @@ int tg_batch_profile(tg_batch *b, int64_t out[16]) {
 }
 
 int tg_batch_deriv1(tg_batch *b) {
-    (void)b;
-    return fail(TG_ERR_UNSUPPORTED, "deriv1 kernel not built yet");
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    if (b->t2 == b->t1) return fail(TG_ERR_STATE, "Integrator has not solved the next time step yet.");
+    HIP_TRY(hipSetDevice(b->device));
+    tg::RunArgs A = base_args(b, tg::MODE_DERIV1);
+    int rc = launch(b, A);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    b->have_d1 = true;
+    return TG_SUCCESS;
 }
 
 void *tg_device_alloc(int32_t device, uint64_t bytes) {

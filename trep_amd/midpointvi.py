@@ -148,6 +148,24 @@ class BatchMidpointVI(object):
         _lib.check(self._L.tg_batch_calc_f(self._h, out.ctypes.data))
         return out
 
+    # -- first derivatives (reference MidpointVI_calc_deriv1, midpointvi.c:1100-1120) -----------------
+    D1_NAMES = ["q2_dq1", "q2_dp1", "q2_du1", "q2_dk2", "p2_dq1", "p2_dp1", "p2_du1", "p2_dk2",
+                "l1_dq1", "l1_dp1", "l1_du1", "l1_dk2"]
+
+    def calc_deriv1(self):
+        """Compute all twelve first-derivative arrays of the last solved step on the device."""
+        _lib.check(self._L.tg_batch_deriv1(self._h))
+
+    def deriv1(self, name):
+        """[B][derivative variable][output] (the reference's C layout, trep.h:425-437)."""
+        k = self.D1_NAMES.index(name)
+        rows = (self.nq, self.nd, self.nu, self.nk)[k % 4]
+        width = self.nc if k // 4 == 2 else self.nd
+        out = np.zeros((self._batch, rows, width))
+        if out.size:
+            _lib.check(self._L.tg_batch_get(self._h, _lib.F_D1_BASE + k, out.ctypes.data))
+        return out
+
     def step(self, t2, u1=None, k2=None, max_iterations=200, q2_hint=None, lambda1_hint=None):
         """One MidpointVI.step for every trajectory.  Returns (iterations[B], status[B])."""
         B = self._batch
@@ -325,6 +343,50 @@ class MidpointVI(object):
         if t2 != t1:
             return ((self.q2 - self.q1) / (t2 - t1))[self.nd:]
         return None
+
+    # -- derivative accessors (midpointvi.py:337-371, 474-506, 604-640): Config / Input / Constraint
+    #    objects or None (= whole axis) select entries; the result is output-major like the reference.
+    def _calc_deriv1(self):
+        if self._cache & 2:
+            return
+        if not (self._cache & 1):
+            raise Exception("Integrator has not solved of the next time step yet.")
+        b = self._batch()
+        b.calc_deriv1()
+        self._d1 = dict((n, b.deriv1(n)[0]) for n in b.D1_NAMES)
+        self._cache |= 2
+
+    @staticmethod
+    def _index(obj, kind):
+        if obj is None:
+            return slice(None)
+        if kind == "k":
+            assert obj.kinematic
+            return obj.k_index
+        if kind == "d":
+            assert not obj.kinematic
+        return obj.index
+
+    def _d1_accessor(name, out_kind, var_kind):
+        def accessor(self, out=None, var=None):
+            self._calc_deriv1()
+            return self._d1[name][self._index(var, var_kind), self._index(out, out_kind)].T.copy()
+        accessor.__name__ = name
+        return accessor
+
+    q2_dq1 = _d1_accessor("q2_dq1", "d", "q")
+    q2_dp1 = _d1_accessor("q2_dp1", "d", "d")
+    q2_du1 = _d1_accessor("q2_du1", "d", "u")
+    q2_dk2 = _d1_accessor("q2_dk2", "d", "k")
+    p2_dq1 = _d1_accessor("p2_dq1", "d", "q")
+    p2_dp1 = _d1_accessor("p2_dp1", "d", "d")
+    p2_du1 = _d1_accessor("p2_du1", "d", "u")
+    p2_dk2 = _d1_accessor("p2_dk2", "d", "k")
+    lambda1_dq1 = _d1_accessor("l1_dq1", "c", "q")
+    lambda1_dp1 = _d1_accessor("l1_dp1", "c", "d")
+    lambda1_du1 = _d1_accessor("l1_du1", "c", "u")
+    lambda1_dk2 = _d1_accessor("l1_dk2", "c", "k")
+    del _d1_accessor
 
     def initialize_from_state(self, t1, q1, p1, lambda1=None):
         self._cache = 0
