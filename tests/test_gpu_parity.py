@@ -255,3 +255,32 @@ def test_deriv1_accessors_dropin():
     assert abs(mvi.q2_dq1(th, x) - ref[0, 1]) < 1e-10
     assert relerr(mvi.p2_du1(), g["b0_d1_1_p2_du1"].T) < 1e-10
     assert mvi.q2_dk2().shape == (2, 0)
+
+
+@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "pendulum5"])
+def test_dsystem_linearization_matches_reference(name):
+    """DSystem.set(X[k],U[k],k,xk_hint=X[k+1]) -> f, fdx (A_k), fdu (B_k) vs the reference's DSystem."""
+    import trep_amd
+    from trep_amd import discopt
+    g = golden(name)
+    system, d = build(name)
+    X, U = g["ds_X"], g["ds_U"]
+    t = DT * np.arange(len(X))
+    one = discopt.DSystem(trep_amd.MidpointVI(system), t)
+    ks = [int(k) for k in g["ds_k"]]
+    for k in ks:
+        one.set(X[k], U[k], k, xk_hint=X[k + 1])
+        assert relerr(one.f(), g["ds_%d_f" % k]) < 1e-10
+        assert relerr(one.fdx(), g["ds_%d_A" % k]) < 1e-9
+        assert relerr(one.fdu(), g["ds_%d_B" % k]) < 1e-9
+    # batched: all captured k of the trajectory in one batch is not possible (different t), so
+    # replicate one k across a small batch instead
+    k = ks[1]
+    bd = discopt.BatchDSystem(system, t, 4)
+    it, st = bd.set(np.tile(X[k], (4, 1)), np.tile(U[k], (4, 1)), k, Xk_hint=np.tile(X[k + 1], (4, 1)))
+    assert (st == 0).all()
+    A, B = bd.linearize()
+    assert relerr(bd.f()[3], g["ds_%d_f" % k]) < 1e-10
+    assert relerr(A[3], g["ds_%d_A" % k]) < 1e-9 and relerr(B[0], g["ds_%d_B" % k]) < 1e-9
+    lin = one.linearize_trajectory(X[:4], U[:3])
+    assert lin.A.shape == (3, one.nX, one.nX) and lin.B.shape == (3, one.nX, one.nU)

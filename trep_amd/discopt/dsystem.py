@@ -1,0 +1,247 @@
+"""DSystem: the variational integrator seen as a discrete system X[k+1] = f(X[k], U[k], k).
+
+Mirror of the reference's ``trep.discopt.DSystem`` (/root/reference/trep/discopt/dsystem.py:11-423)
+for the part that sits directly on the MidpointVI hot path: state/input packing
+  X[k] = [Q[k]; p[k]; v[k]],  v[k] = (rho[k] - rho[k-1]) / (t[k] - t[k-1]),  U[k] = [u[k]; rho[k+1]],
+``set`` / ``step`` / ``f`` / ``fdx`` / ``fdu`` / ``linearize_trajectory``.  The integrator underneath
+is the HIP one.  Second-order terms (fdxdx, fdxdu, fdudu) need the deriv2 kernel (next round).
+
+``BatchDSystem`` is the batched counterpart: B trajectories share the time base; ``linearize``
+returns A [B][nX][nX], B [B][nX][nU] for every trajectory of the batch from one deriv1 launch.
+"""
+from collections import namedtuple
+
+import numpy as np
+
+from ..midpointvi import BatchMidpointVI
+
+
+class _Packing(object):
+    def _setup_packing(self, system, t):
+        self._time = np.array(t, dtype=float).squeeze()
+        self._nQ = len(system.configs)
+        self._np = len(system.dyn_configs)
+        self._nv = len(system.kin_configs)
+        self._nu = len(system.inputs)
+        self._nrho = len(system.kin_configs)
+        self._nX = self._nQ + self._np + self._nv
+        self._nU = self._nu + self._nrho
+        self._slice_Q = slice(0, self._nQ)
+        self._slice_Qd = slice(0, self._np)
+        self._slice_Qk = slice(self._np, self._nQ)
+        self._slice_p = slice(self._nQ, self._nQ + self._np)
+        self._slice_v = slice(self._nQ + self._np, self._nX)
+        self._slice_u = slice(0, self._nu)
+        self._slice_rho = slice(self._nu, self._nU)
+        self.trajectory_return = namedtuple('trajectory', 'X U')
+        self.split_state_return = namedtuple('split_state', 'Q p v')
+        self.split_input_return = namedtuple('split_input', 'u rho')
+        self.split_trajectory_return = namedtuple('split_trajectory', 'Q p v u rho')
+        self.linearization_return = namedtuple('linearization', 'A B')
+
+    nX = property(lambda self: self._nX)
+    nU = property(lambda self: self._nU)
+
+    @property
+    def time(self):
+        return self._time
+
+    @time.setter
+    def time(self, t):
+        t = np.array(t, dtype=float).squeeze()
+        assert t.ndim == 1
+        self._time = t
+
+    def kf(self):
+        return len(self._time) - 1
+
+    def build_state(self, Q=None, p=None, v=None):
+        X = np.zeros((self._nX,))
+        if Q is not None:
+            X[self._slice_Q] = Q
+        if p is not None:
+            X[self._slice_p] = p
+        if v is not None:
+            X[self._slice_v] = v
+        return X
+
+    def build_input(self, u=None, rho=None):
+        U = np.zeros((self._nU,))
+        if u is not None:
+            U[self._slice_u] = u
+        if rho is not None:
+            U[self._slice_rho] = rho
+        return U
+
+    def build_trajectory(self, Q=None, p=None, v=None, u=None, rho=None):
+        n = len(self._time)
+        for name, val, want in (('Q', Q, n), ('p', p, n), ('v', v, n), ('u', u, n - 1), ('rho', rho, n - 1)):
+            if val is not None and len(val) != want:
+                raise Exception("Invalid length for %s (expected %d)" % (name, want))
+        X = np.zeros((n, self._nX))
+        U = np.zeros((n - 1, self._nU))
+        if Q is not None:
+            X[:, self._slice_Q] = Q
+        if p is not None:
+            X[:, self._slice_p] = p
+        if v is not None:
+            X[:, self._slice_v] = v
+        if u is not None:
+            U[:, self._slice_u] = u
+        if rho is not None:
+            U[:, self._slice_rho] = rho
+        return self.trajectory_return(X, U)
+
+    def split_state(self, X=None):
+        if X is None:
+            X = np.zeros(self._nX)
+        return self.split_state_return(X[..., self._slice_Q], X[..., self._slice_p], X[..., self._slice_v])
+
+    def split_input(self, U=None):
+        if U is None:
+            U = np.zeros(self._nU)
+        return self.split_input_return(U[..., self._slice_u], U[..., self._slice_rho])
+
+    def split_trajectory(self, X=None, U=None):
+        if X is None and U is None:
+            X = np.zeros((len(self._time), self._nX))
+            U = np.zeros((len(self._time) - 1, self._nU))
+        elif X is None:
+            X = np.zeros((U.shape[0] + 1, self._nX))
+        elif U is None:
+            U = np.zeros((X.shape[0] - 1, self._nU))
+        return self.split_trajectory_return(X[:, self._slice_Q], X[:, self._slice_p], X[:, self._slice_v],
+                                            U[:, self._slice_u], U[:, self._slice_rho])
+
+    def _assemble(self, dt, q2_dq1, q2_dp1, q2_du1, q2_dk2, p2_dq1, p2_dp1, p2_du1, p2_dk2):
+        """A = fdx, B = fdu from output-major derivative blocks (dsystem.py:284-317)."""
+        A = np.zeros((self._nX, self._nX))
+        A[self._slice_Qd, self._slice_Q] = q2_dq1
+        A[self._slice_Qd, self._slice_p] = q2_dp1
+        A[self._slice_p, self._slice_Q] = p2_dq1
+        A[self._slice_p, self._slice_p] = p2_dp1
+        A[self._slice_v, self._slice_Qk] = np.diag(np.ones(self._nv) * -1.0 / dt)
+        Bm = np.zeros((self._nX, self._nU))
+        Bm[self._slice_Qd, self._slice_u] = q2_du1
+        Bm[self._slice_Qd, self._slice_rho] = q2_dk2
+        Bm[self._slice_Qk, self._slice_rho] = np.eye(self._nrho)
+        Bm[self._slice_p, self._slice_u] = p2_du1
+        Bm[self._slice_p, self._slice_rho] = p2_dk2
+        Bm[self._slice_v, self._slice_rho] = np.diag(np.ones(self._nrho) * 1.0 / dt)
+        return A, Bm
+
+
+class DSystem(_Packing):
+    def __init__(self, varint, t):
+        self.varint = varint
+        self._xk = None
+        self._uk = None
+        self._k = None
+        self._setup_packing(varint.system, t)
+
+    system = property(lambda self: self.varint.system)
+    xk = property(lambda self: self._xk.copy())
+    uk = property(lambda self: self._uk.copy())
+    k = property(lambda self: self._k)
+
+    def set(self, xk, uk, k, xk_hint=None, lambda_hint=None):
+        self._k = k
+        self._xk = xk.copy()
+        self._uk = uk.copy()
+        (q1, p1, v1) = self.split_state(xk)
+        (u1, rho2) = self.split_input(uk)
+        t1 = self._time[self._k + 0]
+        t2 = self._time[self._k + 1]
+        q2_hint = None
+        if xk_hint is not None:
+            q2_hint = self.split_state(xk_hint)[0][:self.varint.nd]
+        self.varint.initialize_from_state(t1, q1, p1)
+        self.varint.step(t2, u1, rho2, q2_hint=q2_hint, lambda1_hint=lambda_hint)
+
+    def step(self, uk, xk_hint=None, lambda_hint=None):
+        self._xk = self.f()
+        self._uk = uk.copy()
+        self._k += 1
+        (u1, rho2) = self.split_input(uk)
+        t2 = self._time[self._k + 1]
+        q2_hint = None
+        if xk_hint is not None:
+            q2_hint = self.split_state(xk_hint)[0][:self.varint.nd]
+        self.varint.step(t2, u1, rho2, q2_hint=q2_hint, lambda1_hint=lambda_hint)
+
+    def f(self):
+        return self.build_state(self.varint.q2, self.varint.p2, self.varint.v2)
+
+    def _dt(self):
+        return self._time[self._k + 1] - self._time[self._k + 0]
+
+    def fdx(self):
+        v = self.varint
+        return self._assemble(self._dt(), v.q2_dq1(), v.q2_dp1(), v.q2_du1(), v.q2_dk2(),
+                              v.p2_dq1(), v.p2_dp1(), v.p2_du1(), v.p2_dk2())[0]
+
+    def fdu(self):
+        v = self.varint
+        return self._assemble(self._dt(), v.q2_dq1(), v.q2_dp1(), v.q2_du1(), v.q2_dk2(),
+                              v.p2_dq1(), v.p2_dp1(), v.p2_du1(), v.p2_dk2())[1]
+
+    def fdxdx(self, z):
+        raise NotImplementedError("second derivatives need the deriv2 kernel (DESIGN.md: next)")
+
+    fdxdu = fdudu = fdxdx
+
+    def linearize_trajectory(self, X, U):
+        A = np.zeros((len(X) - 1, self.nX, self.nX))
+        B = np.zeros((len(X) - 1, self.nX, self.nU))
+        for k in range(len(X) - 1):
+            self.set(X[k], U[k], k, xk_hint=X[k + 1])
+            A[k] = self.fdx()
+            B[k] = self.fdu()
+        return self.linearization_return(A, B)
+
+
+class BatchDSystem(_Packing):
+    """B independent copies of the discrete system on one GPU."""
+
+    def __init__(self, system, t, batch, device=0, tolerance=1e-10):
+        self.varint = BatchMidpointVI(system, batch, tolerance=tolerance, device=device)
+        self._setup_packing(system, t)
+        self._k = None
+
+    system = property(lambda self: self.varint.system)
+    batch = property(lambda self: self.varint.batch)
+    k = property(lambda self: self._k)
+
+    def set(self, Xk, Uk, k, Xk_hint=None, lambda_hint=None):
+        """Xk [B][nX], Uk [B][nU]; returns (iterations[B], status[B])."""
+        self._k = k
+        Q, p, _ = self.split_state(Xk)
+        u, rho = self.split_input(Uk)
+        t1, t2 = self._time[k], self._time[k + 1]
+        hint = None if Xk_hint is None else self.split_state(Xk_hint)[0][:, :self.varint.nd]
+        self.varint.initialize_from_state(t1, Q, p)
+        return self.varint.step(t2, u if self._nu else None, rho if self._nrho else None,
+                                q2_hint=hint, lambda1_hint=lambda_hint)
+
+    def f(self):
+        v = self.varint
+        q1, q2 = v.q1, v.q2
+        t1, t2 = v.times()
+        X = np.zeros((v.batch, self._nX))
+        X[:, self._slice_Q] = q2
+        X[:, self._slice_p] = v.p2
+        X[:, self._slice_v] = (q2 - q1)[:, self._np:] / (t2 - t1)
+        return X
+
+    def linearize(self):
+        """A [B][nX][nX], B [B][nX][nU] at the current step (one deriv1 launch for the batch)."""
+        v = self.varint
+        v.calc_deriv1()
+        d = dict((n, np.swapaxes(v.deriv1(n), 1, 2)) for n in v.D1_NAMES[:8])  # -> output-major
+        dt = self._time[self._k + 1] - self._time[self._k]
+        A = np.zeros((v.batch, self._nX, self._nX))
+        B = np.zeros((v.batch, self._nX, self._nU))
+        for b in range(v.batch):
+            A[b], B[b] = self._assemble(dt, d["q2_dq1"][b], d["q2_dp1"][b], d["q2_du1"][b], d["q2_dk2"][b],
+                                        d["p2_dq1"][b], d["p2_dp1"][b], d["p2_du1"][b], d["p2_dk2"][b])
+        return self.linearization_return(A, B)
