@@ -170,6 +170,17 @@ int tg_batch_restore(tg_batch *b);
  * midpointvi.c:1100-1120); results are read with tg_batch_get(TG_F_Q2_DQ1 ...). */
 int tg_batch_deriv1(tg_batch *b);
 
+/*
+ * Second derivatives of the last solved step, contracted with z over the output index
+ * (reference MidpointVI_calc_deriv2, midpointvi.c:2516-2545, as consumed by DSystem.fdxdx / fdxdu /
+ * fdudu, trep/discopt/dsystem.py:320-386):
+ *   hz[b][A][B] = sum_o z[b][o] * q2_dAdB[A][B][o] + z[b][nq+o] * p2_dAdB[A][B][o]
+ * with the derivative variables ordered A,B in (q1[nq], p1[nd], u1[nu], k2[nk]); R = nq+nd+nu+nk.
+ * z_host [batch][nX] (only the Qd and p parts are read, like the reference), hz_host [batch][R][R].
+ * The full [A][B][out] tensors are never materialised.
+ */
+int tg_batch_deriv2_contract(tg_batch *b, const double *z_host, double *hz_host);
+
 /* Device memory helpers so a host language without a HIP binding can stage inputs. */
 void *tg_device_alloc(int32_t device, uint64_t bytes);
 int tg_device_free(int32_t device, void *ptr);

@@ -39,7 +39,7 @@ void *emu_create(const tg_system_desc *d) {
     P.e_anchor = H.e_anchor.data(); P.e_off = H.e_off.data();
     P.c_type = H.c_type.data(); P.c_e1 = H.c_e1.data(); P.c_e2 = H.c_e2.data(); P.c_cfg = H.c_cfg.data();
     P.c_comp = H.c_comp.data(); P.c_dist = H.c_dist.data(); P.c_tol = H.c_tol.data();
-    P.dh_lookup = H.dh_lookup.data();
+    P.dh_lookup = H.dh_lookup.data(); P.cu_off = H.cu_off.data();
     P.dh_c = H.dh_c.data(); P.dh_cfg = H.dh_cfg.data(); P.dh_joint = H.dh_joint.data(); P.dh_side = H.dh_side.data();
     P.damp = H.damp.data(); P.cf_cfg = H.cf_cfg.data(); P.cf_in = H.cf_in.data();
     return e;
@@ -52,7 +52,7 @@ int emu_lds_doubles(void *h) { return ((Emu *)h)->P.lds_per_team; }
 // Runs every trajectory of the batch through the kernel body, one after the other.
 void emu_run(void *h, const tg::RunArgs *args) {
     Emu *e = (Emu *)h;
-    std::vector<double> lds((size_t)std::max(e->P.lds_per_team, e->P.d_lds_per_team));
+    std::vector<double> lds((size_t)std::max(std::max(e->P.lds_per_team, e->P.d_lds_per_team), e->P.e_lds_per_team));
     for (int t = 0; t < args->batch; t++) {
         std::fill(lds.begin(), lds.end(), 0.0);
         tg::run_trajectory<1>(e->P, *args, lds.data(), 0, t);

@@ -21,7 +21,7 @@ class RunArgs(ctypes.Structure):
                 ("tolerance", ctypes.c_double),
                 ("q1", _D), ("q2", _D), ("p1", _D), ("p2", _D), ("lam", _D), ("u1", _D),
                 ("U", _D), ("K", _D), ("q2_hint", _D), ("lam_hint", _D), ("X", _D), ("f_out", _D),
-                ("d1", _D * 12), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p)]
+                ("d1", _D * 12), ("z", _D), ("hz", _D), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p)]
 
 
 def lib():
@@ -106,6 +106,16 @@ class EmuBatch(object):
                 a.d1[4 * oi + ki] = arr.ctypes.data_as(_D) if arr.size else ctypes.cast(0, _D)
         self.L.emu_run(self.h, ctypes.byref(a))
         return outs
+
+    def deriv2z(self, Z):
+        """HZ [B][R][R]: second derivatives of the step map contracted with z = Z[b] (nX)."""
+        R = self.nq + self.nd + self.nu + self.nk
+        Z = np.ascontiguousarray(Z, dtype=float)
+        HZ = np.zeros((self.B, R, R))
+        a = self._args(4)
+        a.z, a.hz = _p(Z), _p(HZ)
+        self.L.emu_run(self.h, ctypes.byref(a))
+        return HZ
 
     def rollout(self, n_steps, dt, U=None, K=None, want_X=True, q2_hint=None, lam_hint=None):
         U = None if U is None else np.ascontiguousarray(U, dtype=float)

@@ -284,3 +284,54 @@ def test_dsystem_linearization_matches_reference(name):
     assert relerr(A[3], g["ds_%d_A" % k]) < 1e-9 and relerr(B[0], g["ds_%d_B" % k]) < 1e-9
     lin = one.linearize_trajectory(X[:4], U[:3])
     assert lin.A.shape == (3, one.nX, one.nX) and lin.B.shape == (3, one.nX, one.nU)
+
+
+@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "pendulum5"])
+def test_dsystem_second_order_matches_reference(name):
+    """fdxdx(z), fdxdu(z), fdudu(z) vs the reference DSystem (dsystem.py:320-386) for two z."""
+    import trep_amd
+    from trep_amd import discopt
+    g = golden(name)
+    system, d = build(name)
+    X, U, Z = g["ds_X"], g["ds_U"], g["ds_Z"]
+    t = DT * np.arange(len(X))
+    one = discopt.DSystem(trep_amd.MidpointVI(system), t)
+    for k in [int(k) for k in g["ds_k"]]:
+        one.set(X[k], U[k], k, xk_hint=X[k + 1])
+        for zi in range(2):
+            assert relerr(one.fdxdx(Z[zi]), g["ds_%d_fdxdx_%d" % (k, zi)]) < 1e-8, (name, k)
+            assert relerr(one.fdxdu(Z[zi]), g["ds_%d_fdxdu_%d" % (k, zi)]) < 1e-8, (name, k)
+            assert relerr(one.fdudu(Z[zi]), g["ds_%d_fdudu_%d" % (k, zi)]) < 1e-8, (name, k)
+    k = int(g["ds_k"][1])
+    bd = discopt.BatchDSystem(system, t, 3)
+    bd.set(np.tile(X[k], (3, 1)), np.tile(U[k], (3, 1)), k, Xk_hint=np.tile(X[k + 1], (3, 1)))
+    xx, xu, uu = bd.second_order(np.stack([Z[0], Z[1], Z[0]]))
+    assert relerr(xx[1], g["ds_%d_fdxdx_1" % k]) < 1e-8 and relerr(uu[2], g["ds_%d_fdudu_0" % k]) < 1e-8
+    assert np.array_equal(xx[0], xx[2])
+
+
+@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40"])
+def test_full_second_derivative_tensors_match_reference(name):
+    """MidpointVI.q2_dq1dq1() ... p2_dk2dk2() accessors vs the reference's [A][B][out] tensors."""
+    import trep_amd
+    g = golden(name)
+    system, d = build(name)
+    prefix, q0, U, K = trajectories(name)[0]
+    Q, P, LAM = g[prefix + "Q"], g[prefix + "P"], g[prefix + "LAM"]
+    keys = [k for k in g if k.startswith(prefix + "d2_") and not k.split("_", 3)[3].startswith("l1")]
+    step = sorted(set(int(k.split("_")[-3]) for k in keys))[0]
+    k0 = step - 1
+    mvi = trep_amd.MidpointVI(system)
+    mvi.initialize_from_state((k0 + 1) * DT, Q[k0], P[k0], LAM[k0])
+    mvi.step((k0 + 2) * DT, U[k0], K[k0])
+    checked = 0
+    for key in keys:
+        parts = key.split("_")
+        if int(parts[-3]) != step:
+            continue
+        nm = parts[-2] + "_" + parts[-1]
+        got = getattr(mvi, nm)()
+        assert got.shape == g[key].shape
+        assert relerr(got, g[key]) < 1e-8, (name, nm)
+        checked += 1
+    assert checked >= 4

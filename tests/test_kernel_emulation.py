@@ -75,3 +75,44 @@ def test_emulated_first_derivatives_match_reference(name):
         out = e.deriv1()
         for n in D1:
             assert relerr(out[n][0], g["%sd1_%d_%s" % (prefix, s_, n)]) < 1e-9, (name, s_, n)
+
+
+def oracle_hz(o, d, z):
+    """z-contracted second derivatives assembled from the oracle's ten [A][B][out] tensor pairs."""
+    nq, nd, nk, nu = d.n_configs, d.n_dyn, d.n_kin, d.n_inputs
+    cnt = {"dq1": nq, "dp1": nd, "du1": nu, "dk2": nk}
+    off = {"dq1": 0, "dp1": nq, "du1": nq + nd, "dk2": nq + nd + nu}
+    R = nq + nd + nu + nk
+    zq, zp = z[:nd], z[nq:nq + nd]
+    HZ = np.zeros((R, R))
+    names = ["dq1", "dp1", "du1", "dk2"]
+    for ia, a in enumerate(names):
+        for b in names[ia:]:
+            if cnt[a] == 0 or cnt[b] == 0:
+                continue
+            blk = o.deriv2("q2_" + a + b) @ zq + o.deriv2("p2_" + a + b) @ zp
+            HZ[off[a]:off[a] + cnt[a], off[b]:off[b] + cnt[b]] = blk
+            HZ[off[b]:off[b] + cnt[b], off[a]:off[a] + cnt[a]] = blk.T
+    return HZ
+
+
+@pytest.mark.parametrize("name", sorted(BUILDERS))
+def test_emulated_contracted_second_derivatives_match_oracle(name):
+    g = golden(name)
+    system, d = build(name)
+    prefix, q0, U, K = trajectories(name)[0]
+    Q, P, LAM = g[prefix + "Q"], g[prefix + "P"], g[prefix + "LAM"]
+    rng = np.random.default_rng(3)
+    k = 9
+    e = EmuBatch(d, 1)
+    e.t1 = e.t2 = (k + 1) * DT
+    e.q1[0], e.q2[0], e.p1[0], e.p2[0], e.lam[0] = Q[k], Q[k], P[k], P[k], LAM[k]
+    e.rollout(1, DT, U[None, k:k + 1], K[None, k:k + 1], want_X=False)
+    o = OracleMVI(d)
+    o.initialize_from_state((k + 1) * DT, Q[k], P[k], LAM[k])
+    o.step((k + 2) * DT, U[k], K[k])
+    o.calc_deriv2()
+    z = rng.standard_normal(e.nX)
+    HZ = e.deriv2z(z[None, :])[0]
+    ref = oracle_hz(o, d, z)
+    assert relerr(HZ, ref) < 1e-8, name

@@ -47,7 +47,7 @@ extern "C" __device__ __attribute__((const)) unsigned long long __ockl_wfred_max
 
 namespace tg {
 
-enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3 };
+enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3, MODE_DERIV2Z = 4 };
 
 struct RunArgs {
     int batch, n_steps, max_iterations, mode, first_is_init;
@@ -58,6 +58,8 @@ struct RunArgs {
     double *X;                             // [batch][n_steps+1][nX] or null
     double *f_out;                         // MODE_CALC_F: [batch][nf]
     double *d1[12];                        // MODE_DERIV1 outputs q2_d{q1,p1,u1,k2}, p2_d*, l1_d*: [batch][var][out]
+    const double *z;                       // MODE_DERIV2Z: [batch][nX] contraction vector
+    double *hz;                            // MODE_DERIV2Z: [batch][R][R], R = nq+nd+nu+nk
     int *iters, *status;                   // [batch]
     long long *prof_out;                   // diagnostic build: [16] cycle counters of trajectory 0
 };
@@ -569,9 +571,10 @@ struct Core {
         TG_SYNC();
     }
 
-    TG_HD void deriv1(bool on, const RunArgs &A, size_t t) {
+    // builds and solves the augmented KKT system; `extra` appends nc unit columns e_{nd+c}
+    TG_HD bool deriv1_solve(bool on, bool extra) {
         const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nf = P.nf;
-        const int ld = P.d_aug_ld, R = P.d_nrhs, w = nf + R;
+        const int ld = P.d_aug_ld, R = P.d_nrhs;
         double *AUG = S + P.d_o_AUG, *T12 = S + P.d_o_T12, *T22 = S + P.d_o_T22;
         double *Dh1 = S + P.d_o_Dh1, *Dh2 = S + P.d_o_Dh2;
         const int c_q1 = nf, c_p1 = nf + nq, c_u1 = nf + nq + nd, c_k2 = nf + nq + nd + nu;
@@ -604,6 +607,7 @@ struct Core {
             TG_FOR(c, nc) {
                 for (int o = 0; o < nd; o++) AUG[(nd + c) * ld + o] = Dh2[c * nq + o];
                 for (int i = 0; i < nk; i++) AUG[(nd + c) * ld + c_k2 + i] = -Dh2[c * nq + nd + i];
+                if (extra) AUG[(nd + c) * ld + nf + R + c] = 1.0;
             }
         }
         TG_SYNC();
@@ -647,7 +651,14 @@ struct Core {
             }
             TG_SYNC();
         }
-        const bool ok = gauss_jordan(on, AUG, nf, R, ld, S + P.o_scal);
+        return gauss_jordan(on, AUG, nf, R + (extra ? nc : 0), ld, S + P.o_scal);
+    }
+
+    TG_HD void deriv1(bool on, const RunArgs &A, size_t t) {
+        const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nf = P.nf;
+        const int ld = P.d_aug_ld, R = P.d_nrhs;
+        double *AUG = S + P.d_o_AUG, *T12 = S + P.d_o_T12, *T22 = S + P.d_o_T22;
+        const bool ok = deriv1_solve(on, false);
         // outputs in the reference layout [derivative variable][output] (trep.h:425-437)
         if (on) {
             const int cwl = tile_log2<TEAM>(nd), cw = 1 << cwl, rstep = TEAM >> cwl;
@@ -669,7 +680,290 @@ struct Core {
                     A.d1[8 + kind][(t * rows + i) * nc + c] = ok ? AUG[(nd + c) * ld + nf + vv] : NAN;
             }
         }
-        (void)w;
+    }
+
+    // =====================================================================================================
+    // Second derivatives, contracted with z over the output index (what DSystem.fdxdx/fdxdu/fdudu consume,
+    // dsystem.py:320-386): HZ[a][b] = sum_o z_Qd[o] q2''[a][b][o] + z_p[o] p2''[a][b][o] for all pairs of the
+    // derivative variables (q1, p1, u1, k2).  The reference materialises six nq x nq x nd tables and ten
+    // [A][B][out] tensors (midpointvi.c:1122-2545); here the contraction is pushed through the
+    // implicit-function solve with one adjoint vector w = K^-T [z_Qd + D2D2L2 z_p ; 0], so only three
+    // nq x nq contracted Hessians are ever formed:
+    //   H11 = sum_o -w_o (D1D1D1L2 - sum_c lambda_c DDDh1T)[.,.,o] + z_p,o D1D1D2L2[.,.,o]
+    //   H12 = sum_o -w_o D1D2D1L2[.,.,o] + z_p,o D1D2D2L2[.,.,o]
+    //   H22 = sum_o -w_o D2D2D1L2[.,.,o] + z_p,o D2D2D2L2[.,.,o] - sum_c w_lambda,c DDh2[c]
+    // and HZ[a][b] = H11[a1][b1] + (H12 y_b + G1 l_b)[a1] + (H12 y_a + G1 l_a)[b1] + y_a^T H22 y_b with the
+    // first-derivative tangents y (slot-2 configs) and l (multipliers); G1[i][c] = sum_o w_o DDh1T[i][o][c].
+    // Third-order Lagrangian derivatives come from nested brackets: d3v = [[W_i,J_j],J_k], d2J_i = [[J_i,J_j],J_k].
+    // =====================================================================================================
+    TG_HD void pos_d2(int e, int ja, int jb, double *out) const {  // d2 p_E / dq_a dq_b, ja nearer the root
+        out[0] = out[1] = out[2] = 0.0;
+        if (P.j_kind[ja] < TG_RX) return;
+        const double *ga = S + P.o_G + 12 * ja;
+        const int ax = P.j_kind[ja] - TG_RX;
+        const double wx = ga[ax], wy = ga[4 + ax], wz = ga[8 + ax];
+        double d[3];
+        dpos(e, jb, d);
+        out[0] = wy * d[2] - wz * d[1]; out[1] = wz * d[0] - wx * d[2]; out[2] = wx * d[1] - wy * d[0];
+    }
+    TG_HD void pos_d3(int e, int ja, int jb, int jc, double *out) const {  // ja <= jb <= jc along the path
+        out[0] = out[1] = out[2] = 0.0;
+        if (P.j_kind[ja] < TG_RX) return;
+        double d[3];
+        pos_d2(e, jb, jc, d);
+        const double *ga = S + P.o_G + 12 * ja;
+        const int ax = P.j_kind[ja] - TG_RX;
+        const double wx = ga[ax], wy = ga[4 + ax], wz = ga[8 + ax];
+        out[0] = wy * d[2] - wz * d[1]; out[1] = wz * d[0] - wx * d[2]; out[2] = wx * d[1] - wy * d[0];
+    }
+    // difference (end point 1 - end point 2) of the 1st/2nd/3rd position derivative of constraint c
+    TG_HD void cdiff1(int c, int n, double *v) const {
+        double a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+        const int s = P.dh_side[n], j = P.dh_joint[n];
+        if (j >= 0 && (s & 1)) dpos(P.c_e1[c], j, a);
+        if (j >= 0 && (s & 2)) dpos(P.c_e2[c], j, b);
+        v[0] = a[0] - b[0]; v[1] = a[1] - b[1]; v[2] = a[2] - b[2];
+    }
+    TG_HD void cdiff2(int c, int n1, int n2, double *v) const {
+        double a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+        int j1 = P.dh_joint[n1], j2 = P.dh_joint[n2];
+        const int s = P.dh_side[n1] & P.dh_side[n2];
+        if (j1 >= 0 && j2 >= 0) {
+            if (j1 > j2) { const int t_ = j1; j1 = j2; j2 = t_; }
+            if (s & 1) pos_d2(P.c_e1[c], j1, j2, a);
+            if (s & 2) pos_d2(P.c_e2[c], j1, j2, b);
+        }
+        v[0] = a[0] - b[0]; v[1] = a[1] - b[1]; v[2] = a[2] - b[2];
+    }
+    TG_HD void cdiff3(int c, int n1, int n2, int n3, double *v) const {
+        double a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+        int j1 = P.dh_joint[n1], j2 = P.dh_joint[n2], j3 = P.dh_joint[n3];
+        const int s = P.dh_side[n1] & P.dh_side[n2] & P.dh_side[n3];
+        if (j1 >= 0 && j2 >= 0 && j3 >= 0) {
+            if (j1 > j2) { const int t_ = j1; j1 = j2; j2 = t_; }
+            if (j2 > j3) { const int t_ = j2; j2 = j3; j3 = t_; }
+            if (j1 > j2) { const int t_ = j1; j1 = j2; j2 = t_; }
+            if (s & 1) pos_d3(P.c_e1[c], j1, j2, j3, a);
+            if (s & 2) pos_d3(P.c_e2[c], j1, j2, j3, b);
+        }
+        v[0] = a[0] - b[0]; v[1] = a[1] - b[1]; v[2] = a[2] - b[2];
+    }
+    // h_c,dqdq for two dependent configs given by their dh items (distance.c:65-98, point.c:40-46)
+    TG_HD double con_d2(int c, int n1, int n2) const {
+        double v12[3];
+        cdiff2(c, n1, n2, v12);
+        if (P.c_type[c] == TG_CONSTRAINT_POINT) return v12[P.c_comp[c]];
+        double v1[3], v2[3];
+        cdiff1(c, n1, v1); cdiff1(c, n2, v2);
+        const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
+        double h = v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2] + (a[0] - b[0]) * v12[0] + (a[1] - b[1]) * v12[1] + (a[2] - b[2]) * v12[2];
+        if ((P.dh_side[n1] & 4) && n1 == n2) h -= 1.0;
+        return 2.0 * h;
+    }
+    // h_c,dqdqdq (distance.c:100-133, point.c:48-54); zero when any argument is the string-length config
+    TG_HD double con_d3(int c, int n1, int n2, int n3) const {
+        if (P.dh_joint[n1] < 0 || P.dh_joint[n2] < 0 || P.dh_joint[n3] < 0) return 0.0;
+        double v123[3];
+        cdiff3(c, n1, n2, n3, v123);
+        if (P.c_type[c] == TG_CONSTRAINT_POINT) return v123[P.c_comp[c]];
+        double v1[3], v2[3], v3[3], v12[3], v13[3], v23[3];
+        cdiff1(c, n1, v1); cdiff1(c, n2, v2); cdiff1(c, n3, v3);
+        cdiff2(c, n1, n2, v12); cdiff2(c, n1, n3, v13); cdiff2(c, n2, n3, v23);
+        const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
+        return 2.0 * (v1[0] * v23[0] + v1[1] * v23[1] + v1[2] * v23[2] + v2[0] * v13[0] + v2[1] * v13[1] + v2[2] * v13[2] +
+                      v3[0] * v12[0] + v3[1] * v12[1] + v3[2] * v12[2] +
+                      (a[0] - b[0]) * v123[0] + (a[1] - b[1]) * v123[1] + (a[2] - b[2]) * v123[2]);
+    }
+
+    // third-order Lagrangian pieces of one body for an ORDERED triple of path items (x, y, o)
+    struct Third { double q, dx, dy, dO, eo, ey, ex; };
+    TG_HD void sort2(int &a, int &b) const { if (a > b) { const int t_ = a; a = b; b = t_; } }
+    TG_HD void vel2(int x, int y, double *out) const {  // d2v/dq_x dq_y = [W_min, J_max]
+        sort2(x, y);
+        bracket(S + P.o_W + 6 * x, S + P.o_J + 6 * y, out);
+    }
+    TG_HD bool jac1(int x, int y, double *out) const {  // dJ_x/dq_y = [J_x, J_y] if x < y
+        if (!(x < y)) { for (int m = 0; m < 6; m++) out[m] = 0.0; return false; }
+        bracket(S + P.o_J + 6 * x, S + P.o_J + 6 * y, out);
+        return true;
+    }
+    TG_HD double ldqq(const double *I, const double *v, int x, int y, int z, const double *v2yz) const {
+        // L_ddqdqdq(dq x; q y, q z) (system.c:336-393)
+        const double *Jx = S + P.o_J + 6 * x;
+        double t1[6], t2[6], acc = inner6(I, Jx, v2yz);
+        if (jac1(x, y, t1)) acc += inner6(I, t1, S + P.o_W + 6 * z);
+        if (jac1(x, z, t1)) acc += inner6(I, t1, S + P.o_W + 6 * y);
+        int a = y, b = z;
+        sort2(a, b);
+        if (x < a) { bracket(Jx, S + P.o_J + 6 * a, t1); bracket(t1, S + P.o_J + 6 * b, t2); acc += inner6(I, t2, v); }
+        return acc;
+    }
+    TG_HD double lddq(const double *I, int x, int y, int z) const {  // L_ddqddqdq(dq x, dq y; q z) (system.c:491-530)
+        double t1[6], acc = 0.0;
+        if (jac1(x, z, t1)) acc += inner6(I, t1, S + P.o_J + 6 * y);
+        if (jac1(y, z, t1)) acc += inner6(I, S + P.o_J + 6 * x, t1);
+        return acc;
+    }
+    TG_HD Third third_order(int b, int x, int y, int o) const {
+        const double *I = P.b_inertia + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
+        double vxy[6], vxo[6], vyo[6], t1[6], t2[6];
+        vel2(x, y, vxy); vel2(x, o, vxo); vel2(y, o, vyo);
+        int a = x, bb = y, c = o;
+        sort2(a, bb); sort2(bb, c); sort2(a, bb);
+        bracket(S + P.o_W + 6 * a, S + P.o_J + 6 * bb, t1);
+        bracket(t1, S + P.o_J + 6 * c, t2);
+        const double *Ja = S + P.o_J + 6 * a, *Jb = S + P.o_J + 6 * bb, *Jc = S + P.o_J + 6 * c;
+        // w_a x (w_b x v_c): third derivative of the body position, for -V_qqq (gravity.c:67-94)
+        const double ux = Jb[4] * Jc[2] - Jb[5] * Jc[1], uy = Jb[5] * Jc[0] - Jb[3] * Jc[2], uz = Jb[3] * Jc[1] - Jb[4] * Jc[0];
+        const double gx = Ja[4] * uz - Ja[5] * uy, gy = Ja[5] * ux - Ja[3] * uz, gz = Ja[3] * uy - Ja[4] * ux;
+        Third r;
+        r.q = inner6(I, S + P.o_W + 6 * x, vyo) + inner6(I, S + P.o_W + 6 * y, vxo) + inner6(I, S + P.o_W + 6 * o, vxy) +
+              inner6(I, v, t2) + I[0] * (gam[0] * gx + gam[1] * gy + gam[2] * gz);   // L_dqdqdq (system.c:204-268)
+        r.dx = ldqq(I, v, x, y, o, vyo); r.dy = ldqq(I, v, y, x, o, vxo); r.dO = ldqq(I, v, o, x, y, vxy);
+        r.eo = lddq(I, x, y, o); r.ey = lddq(I, x, o, y); r.ex = lddq(I, y, o, x);
+        return r;
+    }
+
+    TG_HD void deriv2z(bool on, const RunArgs &A, size_t t) {
+        const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nf = P.nf;
+        const int ld = P.d_aug_ld, R = P.d_nrhs;
+        double *AUG = S + P.d_o_AUG, *T22 = S + P.d_o_T22;
+        double *H11 = S + P.e_o_H11, *H12 = S + P.e_o_H12, *H22 = S + P.e_o_H22, *G1 = S + P.e_o_G1;
+        double *w = S + P.e_o_w, *zq = S + P.e_o_zq, *zp = S + P.e_o_zp, *vec = S + P.e_o_vec;
+        const int c_p1 = nf + nq, c_ex = nf + R;
+        const bool ok = deriv1_solve(on, true);
+        if (on) {
+            TG_FOR(i, nq * nq) { H11[i] = 0.0; H12[i] = 0.0; H22[i] = 0.0; }
+            TG_FOR(i, nq * nc) G1[i] = 0.0;
+            TG_FOR(i, nd) { zq[i] = A.z[t * P.nX + i]; zp[i] = A.z[t * P.nX + nq + i]; }
+        }
+        TG_SYNC();
+        // r = z_Qd + D2D2L2[:nd] z_p  (kept in vec[0..nd)), then w = Kinv^T [r; 0]
+        if (on) TG_FOR(i, nd) {
+            double r = zq[i];
+            for (int o = 0; o < nd; o++) r += T22[i * nd + o] * zp[o];
+            vec[i] = r;
+        }
+        TG_SYNC();
+        if (on) TG_FOR(j, nf) {
+            double acc = 0.0;
+            for (int i = 0; i < nd; i++) {
+                const double kinv = j < nd ? -AUG[i * ld + c_p1 + j] : AUG[i * ld + c_ex + (j - nd)];
+                acc += vec[i] * kinv;
+            }
+            w[j] = acc;
+        }
+        TG_SYNC();
+        // ---- constraints at q1: G1 and the lambda-weighted third derivative (calc_h1_deriv2 :1559-1595) -----
+        if (nc) {
+            pose_sweep(on, 1);
+            attach_points(on, false, true);
+            for (int c = 0; c < nc; c++) {
+                const int n0 = P.cu_off[c], cnt = P.cu_off[c + 1] - n0;
+                if (on) {
+                    const int cwl = tile_log2<TEAM>(cnt), cw = 1 << cwl, rstep = TEAM >> cwl;
+                    for (int a = lane >> cwl; a < cnt; a += rstep)
+                        for (int bq = lane & (cw - 1); bq < cnt; bq += cw) {
+                            const int na = n0 + a, nb = n0 + bq, ka = P.dh_cfg[na], kb = P.dh_cfg[nb];
+                            double acc = 0.0;
+                            for (int oo = 0; oo < cnt; oo++) {
+                                const int no = n0 + oo, ko = P.dh_cfg[no];
+                                if (ko >= nd) continue;
+                                acc += w[ko] * con_d3(c, na, nb, no);
+                            }
+                            H11[ka * nq + kb] += S[P.o_lam + c] * acc;
+                            if (bq == 0) {  // G1[ka][c] = sum_o w_o h_c,dqdq(ka, o)
+                                double g = 0.0;
+                                for (int oo = 0; oo < cnt; oo++) {
+                                    const int no = n0 + oo, ko = P.dh_cfg[no];
+                                    if (ko < nd) g += w[ko] * con_d2(c, na, no);
+                                }
+                                G1[ka * nc + c] = g;
+                            }
+                        }
+                }
+                TG_SYNC();
+            }
+            // ---- constraints at q2: H22 -= sum_c w_lambda,c DDh2[c] (calc_h2_deriv2 :1597-1622) -------------
+            pose_sweep(on, 2);
+            attach_points(on, false, true);
+            for (int c = 0; c < nc; c++) {
+                const int n0 = P.cu_off[c], cnt = P.cu_off[c + 1] - n0;
+                if (on) {
+                    const int cwl = tile_log2<TEAM>(cnt), cw = 1 << cwl, rstep = TEAM >> cwl;
+                    for (int a = lane >> cwl; a < cnt; a += rstep)
+                        for (int bq = lane & (cw - 1); bq < cnt; bq += cw) {
+                            const int na = n0 + a, nb = n0 + bq;
+                            H22[P.dh_cfg[na] * nq + P.dh_cfg[nb]] -= w[nd + c] * con_d2(c, na, nb);
+                        }
+                }
+                TG_SYNC();
+            }
+        }
+        // ---- midpoint: third-order discrete-Lagrangian tables contracted on the fly --------------------------
+        eval_midpoint(on);
+        const double c8 = 0.125 * dt, c2 = 0.5 / dt;
+        for (int b = 0; b < P.n_bodies; b++) {
+            const int i0 = P.b_item_off[b], n = P.b_item_off[b + 1] - i0;
+            if (on) {
+                const int cwl = tile_log2<TEAM>(n), cw = 1 << cwl, rstep = TEAM >> cwl;
+                for (int xi = lane >> cwl; xi < n; xi += rstep)
+                    for (int yi = lane & (cw - 1); yi < n; yi += cw) {
+                        const int x = i0 + xi, y = i0 + yi;
+                        double h11 = 0.0, h12 = 0.0, h22 = 0.0;
+                        for (int oi = 0; oi < n; oi++) {
+                            const int o = i0 + oi, ko = P.it_cfg[o];
+                            if (ko >= nd) continue;
+                            const Third T = third_order(b, x, y, o);
+                            const double q = c8 * T.q, dx = 0.25 * T.dx, dy = 0.25 * T.dy, dO = 0.25 * T.dO;
+                            const double eo = c2 * T.eo, ey = c2 * T.ey, ex = c2 * T.ex;
+                            // T(sa,sb,so) = q + sa dx + sb dy + so dO + sa sb eo + sa so ey + sb so ex  (midpointvi.c:1122-1453)
+                            const double t111 = q - dx - dy - dO + eo + ey + ex, t112 = q - dx - dy + dO + eo - ey - ex;
+                            const double t121 = q - dx + dy - dO - eo + ey - ex, t122 = q - dx + dy + dO - eo - ey + ex;
+                            const double t221 = q + dx + dy - dO + eo - ey - ex, t222 = q + dx + dy + dO + eo + ey + ex;
+                            h11 += -w[ko] * t111 + zp[ko] * t112;
+                            h12 += -w[ko] * t121 + zp[ko] * t122;
+                            h22 += -w[ko] * t221 + zp[ko] * t222;
+                        }
+                        const int kx = P.it_cfg[x], ky = P.it_cfg[y];
+                        H11[kx * nq + ky] += h11; H12[kx * nq + ky] += h12; H22[kx * nq + ky] += h22;
+                    }
+            }
+            TG_SYNC();
+        }
+        // ---- assemble HZ[a][b] column by column ------------------------------------------------------------------
+        // tangents: y_b = (x_b, e_i for a k2 variable) with x_b = AUG[0..nd)[nf+b]; l_b = AUG[nd..nf)[nf+b]
+        double *hy = vec, *h12y = vec + nq, *g1l = vec + 2 * nq;
+        const int first_k2 = nq + nd + nu;
+        for (int bcol = 0; bcol < R; bcol++) {
+            if (on) TG_FOR(j, nq) {
+                double a22 = 0.0, a12 = 0.0, ag = 0.0;
+                for (int i2 = 0; i2 < nd; i2++) {
+                    const double yb = AUG[i2 * ld + nf + bcol];
+                    a22 += H22[j * nq + i2] * yb; a12 += H12[j * nq + i2] * yb;
+                }
+                if (bcol >= first_k2) { a22 += H22[j * nq + nd + (bcol - first_k2)]; a12 += H12[j * nq + nd + (bcol - first_k2)]; }
+                for (int c = 0; c < nc; c++) ag += G1[j * nc + c] * AUG[(nd + c) * ld + nf + bcol];
+                hy[j] = a22; h12y[j] = a12; g1l[j] = ag;
+            }
+            TG_SYNC();
+            if (on) TG_FOR(a, R) {
+                double acc = 0.0;
+                for (int i2 = 0; i2 < nd; i2++) acc += AUG[i2 * ld + nf + a] * hy[i2];
+                if (a >= first_k2) acc += hy[nd + (a - first_k2)];
+                if (a < nq) acc += h12y[a] + g1l[a];
+                if (bcol < nq) {
+                    double s12 = 0.0, sg = 0.0;
+                    for (int i2 = 0; i2 < nd; i2++) s12 += H12[bcol * nq + i2] * AUG[i2 * ld + nf + a];
+                    if (a >= first_k2) s12 += H12[bcol * nq + nd + (a - first_k2)];
+                    for (int c = 0; c < nc; c++) sg += G1[bcol * nc + c] * AUG[(nd + c) * ld + nf + a];
+                    acc += s12 + sg;
+                    if (a < nq) acc += H11[a * nq + bcol];
+                }
+                A.hz[(t * R + a) * R + bcol] = ok ? acc : NAN;
+            }
+            TG_SYNC();
+        }
     }
 
     // team-uniform convergence test (midpointvi.c:672-689)
@@ -737,6 +1031,10 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
     }
     if (A.mode == MODE_DERIV1) {
         core.deriv1(live, A, t);
+        return;
+    }
+    if (A.mode == MODE_DERIV2Z) {
+        core.deriv2z(live, A, t);
         return;
     }
     if (A.mode == MODE_CALC_F) {  // MidpointVI.calc_f: midpointvi.c:567-575

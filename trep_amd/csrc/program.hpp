@@ -60,6 +60,9 @@ struct DevProg {
     int lds_per_team;
     // first-derivative kernel: extra arrays appended after the step layout
     int d_o_Dh1, d_o_Dh2, d_o_AUG, d_aug_ld, d_o_T12, d_o_T22, d_nrhs, d_lds_per_team;
+    // z-contracted second-derivative kernel: contracted Hessians H11/H12/H22 [nq][nq], G1 [nq][nc], vectors
+    const int *cu_off;        // [nc+1] dh items of each constraint (its dependent configs)
+    int e_o_H11, e_o_H12, e_o_H22, e_o_G1, e_o_w, e_o_zq, e_o_zp, e_o_vec, e_lds_per_team;
 };
 
 struct HostProgram {
@@ -73,7 +76,7 @@ struct HostProgram {
     std::vector<double> e_off;
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
     std::vector<double> c_dist, c_tol;
-    std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup;
+    std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
     std::vector<double> damp;
     std::vector<int> cf_cfg, cf_in;
     int max_depth = 0;
@@ -237,6 +240,9 @@ inline HostProgram build_program(const tg_system_desc *d) {
             H.dh_side.push_back((on1 ? 1 : 0) | (on2 ? 2 : 0) | (isl ? 4 : 0));
         }
     }
+    H.cu_off.assign(nc + 1, 0);
+    for (size_t n = 0; n < H.dh_c.size(); n++) H.cu_off[H.dh_c[n] + 1] = (int)n + 1;
+    for (int c = 0; c < nc; c++) if (H.cu_off[c + 1] < H.cu_off[c]) H.cu_off[c + 1] = H.cu_off[c];
     // forces / potentials
     H.damp.assign(nd, 0.0);
     for (int i = 0; i < d->n_damping; i++)
@@ -275,10 +281,14 @@ inline HostProgram build_program(const tg_system_desc *d) {
     off = P.lds_per_team;
     P.d_nrhs = nq + nd + P.nu + P.nk;
     P.d_o_Dh1 = take(nc * nq); P.d_o_Dh2 = take(nc * nq);
-    P.d_aug_ld = (P.nf + P.d_nrhs) | 1;
+    P.d_aug_ld = (P.nf + P.d_nrhs + nc) | 1;  // + nc unit columns used by the second-derivative adjoint
     P.d_o_AUG = take(P.nf * P.d_aug_ld);
     P.d_o_T12 = take(nq * nd); P.d_o_T22 = take(nq * nd);
     P.d_lds_per_team = (off + 1) & ~1;
+    // second-derivative (z-contracted) kernel: appended after the deriv1 layout
+    P.e_o_H11 = take(nq * nq); P.e_o_H12 = take(nq * nq); P.e_o_H22 = take(nq * nq); P.e_o_G1 = take(nq * nc);
+    P.e_o_w = take(P.nf); P.e_o_zq = take(nd); P.e_o_zp = take(nd); P.e_o_vec = take(3 * nq);
+    P.e_lds_per_team = (off + 1) & ~1;
     return H;
 }
 

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64) void k_run(const tg::DevProg P, const tg::RunAr
     extern __shared__ double lds[];
     const int team = threadIdx.x / TEAM, lane = threadIdx.x % TEAM;
     const int traj = blockIdx.x * (64 / TEAM) + team;
-    const int stride = A.mode == tg::MODE_DERIV1 ? P.d_lds_per_team : P.lds_per_team;
+    const int stride = A.mode == tg::MODE_DERIV2Z ? P.e_lds_per_team : (A.mode == tg::MODE_DERIV1 ? P.d_lds_per_team : P.lds_per_team);
     tg::run_trajectory<TEAM>(P, A, lds + (size_t)team * stride, lane, traj);
 }
 
@@ -54,6 +54,7 @@ struct tg_batch {
     double *q1 = nullptr, *q2 = nullptr, *p1 = nullptr, *p2 = nullptr, *lam = nullptr, *u1 = nullptr;
     double *stage_u = nullptr, *stage_k = nullptr, *stage_qh = nullptr, *stage_lh = nullptr, *f_out = nullptr;
     int *iters = nullptr, *status = nullptr;
+    double *z_dev = nullptr, *hz_dev = nullptr;
     double *d1[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool have_d1 = false;
     long long *prof = nullptr; // diagnostic build only (TG_PROFILE)
@@ -129,7 +130,7 @@ int allow_lds(size_t bytes) {
 int launch(tg_batch *b, tg::RunArgs &A) {
     const int team = b->sys->team, per_block = 64 / team;
     const int grid = (A.batch + per_block - 1) / per_block;
-    const int per_team = A.mode == tg::MODE_DERIV1 ? b->P.d_lds_per_team : b->P.lds_per_team;
+    const int per_team = A.mode == tg::MODE_DERIV2Z ? b->P.e_lds_per_team : (A.mode == tg::MODE_DERIV1 ? b->P.d_lds_per_team : b->P.lds_per_team);
     const size_t lds = (size_t)per_block * per_team * sizeof(double);
     if (lds > 160 * 1024) return fail(TG_ERR_UNSUPPORTED, "system too large for the LDS-resident kernel");
     int rc = team == 64 ? allow_lds<64>(lds) : (team == 16 ? allow_lds<16>(lds) : (team == 4 ? allow_lds<4>(lds) : allow_lds<1>(lds)));
@@ -158,6 +159,7 @@ tg::RunArgs base_args(tg_batch *b, int mode) {
     A.iters = b->iters; A.status = b->status; A.f_out = b->f_out;
     A.prof_out = b->prof;
     for (int i = 0; i < 12; i++) A.d1[i] = b->d1[i];
+    A.z = b->z_dev; A.hz = b->hz_dev;
     return A;
 }
 
@@ -227,9 +229,9 @@ tg_batch *tg_batch_create(tg_system *sys, int32_t batch, int32_t device) {
     append(ints, H.c_e2, oi[18]); append(ints, H.c_cfg, oi[19]); append(ints, H.c_comp, oi[20]);
     append(ints, H.dh_c, oi[21]); append(ints, H.dh_cfg, oi[22]); append(ints, H.dh_joint, oi[23]);
     size_t o_side, o_cfc, o_cfi;
-    size_t o_lookup;
+    size_t o_lookup, o_cu;
     append(ints, H.dh_side, o_side); append(ints, H.cf_cfg, o_cfc); append(ints, H.cf_in, o_cfi);
-    append(ints, H.dh_lookup, o_lookup);
+    append(ints, H.dh_lookup, o_lookup); append(ints, H.cu_off, o_cu);
     append(dbls, H.j_pre, od[0]); append(dbls, H.b_C, od[1]); append(dbls, H.b_inertia, od[2]);
     append(dbls, H.e_off, od[3]); append(dbls, H.c_dist, od[4]); append(dbls, H.c_tol, od[5]); append(dbls, H.damp, od[6]);
     ints.push_back(0); dbls.push_back(0.0);
@@ -245,7 +247,7 @@ tg_batch *tg_batch_create(tg_system *sys, int32_t batch, int32_t device) {
     P.cfg_item_off = I + oi[13]; P.cfg_items = I + oi[14]; P.e_anchor = I + oi[15]; P.c_type = I + oi[16];
     P.c_e1 = I + oi[17]; P.c_e2 = I + oi[18]; P.c_cfg = I + oi[19]; P.c_comp = I + oi[20];
     P.dh_c = I + oi[21]; P.dh_cfg = I + oi[22]; P.dh_joint = I + oi[23]; P.dh_side = I + o_side;
-    P.cf_cfg = I + o_cfc; P.cf_in = I + o_cfi; P.dh_lookup = I + o_lookup;
+    P.cf_cfg = I + o_cfc; P.cf_in = I + o_cfi; P.dh_lookup = I + o_lookup; P.cu_off = I + o_cu;
     P.j_pre = D + od[0]; P.b_C = D + od[1]; P.b_inertia = D + od[2]; P.e_off = D + od[3];
     P.c_dist = D + od[4]; P.c_tol = D + od[5]; P.damp = D + od[6];
     auto dalloc = [&](double **p, size_t n) {
@@ -257,6 +259,7 @@ tg_batch *tg_batch_create(tg_system *sys, int32_t batch, int32_t device) {
     dalloc(&b->lam, B * P.nc); dalloc(&b->u1, B * P.nu);
     dalloc(&b->stage_u, B * P.nu); dalloc(&b->stage_k, B * P.nk); dalloc(&b->stage_qh, B * P.nd); dalloc(&b->stage_lh, B * P.nc);
     dalloc(&b->f_out, B * P.nf);
+    dalloc(&b->z_dev, B * P.nX); dalloc(&b->hz_dev, B * (size_t)P.d_nrhs * P.d_nrhs);
     for (int k = 0; k < 12; k++) {
         const int var = k % 4, out = k / 4;
         const size_t rows = var == 0 ? P.nq : (var == 1 ? P.nd : (var == 2 ? P.nu : P.nk));
@@ -280,7 +283,7 @@ void tg_batch_destroy(tg_batch *b) {
     for (auto &e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : b->pool) hipEventDestroy(e);
     void *ptrs[] = {b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
-                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap,
+                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev,
                     b->d1[0], b->d1[1], b->d1[2], b->d1[3], b->d1[4], b->d1[5], b->d1[6], b->d1[7], b->d1[8], b->d1[9], b->d1[10], b->d1[11]};
     for (void *p : ptrs) if (p) hipFree(p);
     if (b->stream && b->own_stream) hipStreamDestroy(b->stream);
@@ -460,6 +463,20 @@ int tg_batch_deriv1(tg_batch *b) {
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(b->stream));
     b->have_d1 = true;
+    return TG_SUCCESS;
+}
+
+int tg_batch_deriv2_contract(tg_batch *b, const double *z_host, double *hz_host) {
+    if (!b || !z_host || !hz_host) return fail(TG_ERR_INVALID, "null argument");
+    if (b->t2 == b->t1) return fail(TG_ERR_STATE, "Integrator has not solved the next time step yet.");
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t B = (size_t)b->batch, R = (size_t)b->P.d_nrhs;
+    HIP_TRY(hipMemcpyAsync(b->z_dev, z_host, B * b->P.nX * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    tg::RunArgs A = base_args(b, tg::MODE_DERIV2Z);
+    int rc = launch(b, A);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(hz_host, b->hz_dev, B * R * R * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
     return TG_SUCCESS;
 }
 

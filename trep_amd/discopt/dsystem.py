@@ -4,7 +4,7 @@ Mirror of the reference's ``trep.discopt.DSystem`` (/root/reference/trep/discopt
 for the part that sits directly on the MidpointVI hot path: state/input packing
   X[k] = [Q[k]; p[k]; v[k]],  v[k] = (rho[k] - rho[k-1]) / (t[k] - t[k-1]),  U[k] = [u[k]; rho[k+1]],
 ``set`` / ``step`` / ``f`` / ``fdx`` / ``fdu`` / ``linearize_trajectory``.  The integrator underneath
-is the HIP one.  Second-order terms (fdxdx, fdxdu, fdudu) need the deriv2 kernel (next round).
+is the HIP one.  Second-order terms (fdxdx, fdxdu, fdudu) come from the z-contracted deriv2 kernel.
 
 ``BatchDSystem`` is the batched counterpart: B trajectories share the time base; ``linearize``
 returns A [B][nX][nX], B [B][nX][nU] for every trajectory of the batch from one deriv1 launch.
@@ -113,6 +113,25 @@ class _Packing(object):
         return self.split_trajectory_return(X[:, self._slice_Q], X[:, self._slice_p], X[:, self._slice_v],
                                             U[:, self._slice_u], U[:, self._slice_rho])
 
+    def _split_hz(self, hz):
+        """(fdxdx, fdxdu, fdudu) from HZ [R][R], variables ordered (q1, p1, u1, k2) (dsystem.py:320-386)."""
+        nQ, npp, nu, nk = self._nQ, self._np, self._nu, self._nrho
+        q1 = slice(0, nQ); p1 = slice(nQ, nQ + npp); u1 = slice(nQ + npp, nQ + npp + nu); k2 = slice(nQ + npp + nu, nQ + npp + nu + nk)
+        xx = np.zeros((self._nX, self._nX)); xu = np.zeros((self._nX, self._nU)); uu = np.zeros((self._nU, self._nU))
+        xx[self._slice_Q, self._slice_Q] = hz[q1, q1]
+        xx[self._slice_Q, self._slice_p] = hz[q1, p1]
+        xx[self._slice_p, self._slice_Q] = hz[p1, q1]
+        xx[self._slice_p, self._slice_p] = hz[p1, p1]
+        xu[self._slice_Q, self._slice_u] = hz[q1, u1]
+        xu[self._slice_Q, self._slice_rho] = hz[q1, k2]
+        xu[self._slice_p, self._slice_u] = hz[p1, u1]
+        xu[self._slice_p, self._slice_rho] = hz[p1, k2]
+        uu[self._slice_u, self._slice_u] = hz[u1, u1]
+        uu[self._slice_u, self._slice_rho] = hz[u1, k2]
+        uu[self._slice_rho, self._slice_u] = hz[k2, u1]
+        uu[self._slice_rho, self._slice_rho] = hz[k2, k2]
+        return xx, xu, uu
+
     def _assemble(self, dt, q2_dq1, q2_dp1, q2_du1, q2_dk2, p2_dq1, p2_dp1, p2_du1, p2_dk2):
         """A = fdx, B = fdu from output-major derivative blocks (dsystem.py:284-317)."""
         A = np.zeros((self._nX, self._nX))
@@ -185,10 +204,19 @@ class DSystem(_Packing):
         return self._assemble(self._dt(), v.q2_dq1(), v.q2_dp1(), v.q2_du1(), v.q2_dk2(),
                               v.p2_dq1(), v.p2_dp1(), v.p2_du1(), v.p2_dk2())[1]
 
-    def fdxdx(self, z):
-        raise NotImplementedError("second derivatives need the deriv2 kernel (DESIGN.md: next)")
+    def _second_order(self, z):
+        hz = self.varint.deriv2_contract(z)
+        return self._split_hz(hz)
 
-    fdxdu = fdudu = fdxdx
+    def fdxdx(self, z):
+        """Second derivative of f w.r.t. the state, outputs contracted with z (dsystem.py:320-338)."""
+        return self._second_order(z)[0]
+
+    def fdxdu(self, z):
+        return self._second_order(z)[1]
+
+    def fdudu(self, z):
+        return self._second_order(z)[2]
 
     def linearize_trajectory(self, X, U):
         A = np.zeros((len(X) - 1, self.nX, self.nX))
@@ -198,6 +226,12 @@ class DSystem(_Packing):
             A[k] = self.fdx()
             B[k] = self.fdu()
         return self.linearization_return(A, B)
+
+    def second_order(self, Z):
+        """(fdxdx, fdxdu, fdudu) for every trajectory: Z [B][nX] -> [B][nX][nX], [B][nX][nU], [B][nU][nU]."""
+        hz = self.varint.deriv2_contract(Z)
+        parts = [self._split_hz(hz[b]) for b in range(self.varint.batch)]
+        return tuple(np.array([p[i] for p in parts]) for i in range(3))
 
 
 class BatchDSystem(_Packing):
@@ -245,3 +279,9 @@ class BatchDSystem(_Packing):
             A[b], B[b] = self._assemble(dt, d["q2_dq1"][b], d["q2_dp1"][b], d["q2_du1"][b], d["q2_dk2"][b],
                                         d["p2_dq1"][b], d["p2_dp1"][b], d["p2_du1"][b], d["p2_dk2"][b])
         return self.linearization_return(A, B)
+
+    def second_order(self, Z):
+        """(fdxdx, fdxdu, fdudu) for every trajectory: Z [B][nX] -> [B][nX][nX], [B][nX][nU], [B][nU][nU]."""
+        hz = self.varint.deriv2_contract(Z)
+        parts = [self._split_hz(hz[b]) for b in range(self.varint.batch)]
+        return tuple(np.array([p[i] for p in parts]) for i in range(3))

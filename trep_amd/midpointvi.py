@@ -166,6 +166,16 @@ class BatchMidpointVI(object):
             _lib.check(self._L.tg_batch_get(self._h, _lib.F_D1_BASE + k, out.ctypes.data))
         return out
 
+    def deriv2_contract(self, Z):
+        """Second derivatives contracted with Z [B][nX] over the output index: HZ [B][R][R] with the
+        derivative variables ordered (q1[nq], p1[nd], u1[nu], k2[nk]).  HZ[b][A][B] =
+        sum_o Z[b][o] q2_dAdB[A][B][o] + Z[b][nq+o] p2_dAdB[A][B][o] (what DSystem.fdxdx/fdxdu/fdudu use)."""
+        R = self.nq + self.nd + self.nu + self.nk
+        Z = _lib.as_f64(np.broadcast_to(np.asarray(Z, dtype=float), (self._batch, self.nX)), (self._batch, self.nX))
+        HZ = np.zeros((self._batch, R, R))
+        _lib.check(self._L.tg_batch_deriv2_contract(self._h, Z.ctypes.data, HZ.ctypes.data))
+        return HZ
+
     def step(self, t2, u1=None, k2=None, max_iterations=200, q2_hint=None, lambda1_hint=None):
         """One MidpointVI.step for every trajectory.  Returns (iterations[B], status[B])."""
         B = self._batch
@@ -355,6 +365,56 @@ class MidpointVI(object):
         b.calc_deriv1()
         self._d1 = dict((n, b.deriv1(n)[0]) for n in b.D1_NAMES)
         self._cache |= 2
+
+    def deriv2_contract(self, z):
+        """HZ [R][R] for one contraction vector z (nX); see BatchMidpointVI.deriv2_contract."""
+        if not (self._cache & 1):
+            raise Exception("Integrator has not solved of the next time step yet.")
+        return self._batch().deriv2_contract(np.asarray(z, dtype=float)[None, :])[0]
+
+    # -- full second-derivative tensors (midpointvi.py:373-469, 508-600): assembled from 2*nd unit-vector
+    #    contractions run as ONE batched launch on a helper batch holding copies of the solved step.
+    def _calc_deriv2(self):
+        if self._cache & 4:
+            return
+        if not (self._cache & 1):
+            raise Exception("Integrator has not solved of the next time step yet.")
+        b = self._batch()
+        nd, nq, nu, nk = b.nd, b.nq, b.nu, b.nk
+        if getattr(self, "_b2", None) is None or self._b2_version != self._system._structure_version:
+            self._b2 = BatchMidpointVI(self._system, max(2 * nd, 1), self._tolerance, self._device)
+            self._b2_version = self._system._structure_version
+        h = self._b2
+        h.set_times(*b.times())
+        for name in ("q1", "q2", "p1", "p2", "u1", "lambda1"):
+            setattr(h, name, getattr(b, name)[0])
+        Z = np.zeros((2 * nd, b.nX))
+        Z[np.arange(nd), np.arange(nd)] = 1.0
+        Z[nd + np.arange(nd), nq + np.arange(nd)] = 1.0
+        HZ = h.deriv2_contract(Z)
+        off = {"dq1": (0, nq), "dp1": (nq, nd), "du1": (nq + nd, nu), "dk2": (nq + nd + nu, nk)}
+        self._d2 = {}
+        names = ["dq1", "dp1", "du1", "dk2"]
+        for ia, a in enumerate(names):
+            for bname in names[ia:]:
+                (oa, na), (ob, nb) = off[a], off[bname]
+                blk = HZ[:, oa:oa + na, ob:ob + nb]
+                self._d2["q2_" + a + bname] = np.ascontiguousarray(np.moveaxis(blk[:nd], 0, 2))
+                self._d2["p2_" + a + bname] = np.ascontiguousarray(np.moveaxis(blk[nd:], 0, 2))
+        self._cache |= 4
+
+    def _d2_accessor(name, kinds):
+        def accessor(self, out=None, var1=None, var2=None):
+            self._calc_deriv2()
+            return self._d2[name][self._index(var1, kinds[0]), self._index(var2, kinds[1]), self._index(out, "d")].copy()
+        accessor.__name__ = name
+        return accessor
+
+    for _pre in ("q2", "p2"):
+        for _pair, _kinds in (("dq1dq1", "qq"), ("dq1dp1", "qd"), ("dq1du1", "qu"), ("dq1dk2", "qk"), ("dp1dp1", "dd"),
+                              ("dp1du1", "du"), ("dp1dk2", "dk"), ("du1du1", "uu"), ("du1dk2", "uk"), ("dk2dk2", "kk")):
+            locals()["%s_%s" % (_pre, _pair)] = _d2_accessor("%s_%s" % (_pre, _pair), _kinds)
+    del _d2_accessor, _pre, _pair, _kinds
 
     @staticmethod
     def _index(obj, kind):
