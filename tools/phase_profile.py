@@ -9,7 +9,7 @@ from trep_amd import systems, _lib
 
 NAMES = ["rates/other", "pose sweep (mid)", "attach+jacobians", "velocities", "residual", "pose sweep (q1/q2)",
          "attach+constraints", "newton init", "newton pairs", "GJ scales", "GJ pivot+swap", "GJ eliminate",
-         "converged?", "tail", "", ""]
+         "converged?", "tail", "(sincos part of sweeps)", ""]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 system = systems.puppet()

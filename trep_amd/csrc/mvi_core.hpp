@@ -127,43 +127,38 @@ struct Core {
         return sel == 0 ? 0.5 * (b + a) : (sel == 1 ? a : b);
     }
 
-    // ---- world poses of all joints, level by level; 12 lanes per joint ------------------------------
+    // ---- world poses of all joints ---------------------------------------------------------------------
+    // (1) sin/cos (or the displacement) per joint; (2) every joint's LOCAL transform pre_j * lg(q_j) from
+    // host-made coefficient rows (branch-free: entry = A + B*s1 + C*s0); (3) level by level
+    // G_j = G_parent(j) * local_j in place, one lane per (joint, column): a lane reads only its own
+    // column of the local transform, so there is no intra-joint hazard for any team size.
     TG_HD void pose_sweep(bool on, int sel) {
         double *sc = S + P.o_sc, *G = S + P.o_G;
         if (on) TG_FOR(j, P.n_joints) {
-            double x = qval(sel, P.j_cfg[j]);
+            const double x = qval(sel, P.j_cfg[j]);
             if (P.j_kind[j] >= TG_RX) tg_sincos(x, &sc[2 * j], &sc[2 * j + 1]);
-            else sc[2 * j] = x;
+            else { sc[2 * j] = x; sc[2 * j + 1] = 0.0; }
         }
         TG_SYNC();
-        for (int L = 0; L < P.n_levels; L++) {
+        if (on) TG_FOR(idx, 16 * P.n_joints) {
+            const int j = idx >> 4, e = idx & 15;
+            if (e < 12) {
+                const double *k = P.jcoef + 4 * (size_t)idx;
+                G[12 * j + e] = k[0] + k[1] * sc[2 * j + 1] + k[2] * sc[2 * j];
+            }
+        }
+        TG_SYNC();
+        for (int L = 1; L < P.n_levels; L++) {
             const int j0 = P.level_off[L], cnt = P.level_off[L + 1] - j0;
-            if (on) TG_FOR(idx, 12 * cnt) {
-                const int j = j0 + idx / 12, e = idx % 12, r = e >> 2, c = e & 3;
-                const int parent = P.j_parent[j];
-                double g0, g1, g2, g3;
-                if (parent < 0) { g0 = (r == 0); g1 = (r == 1); g2 = (r == 2); g3 = 0.0; }
-                else { const double *gp = G + 12 * parent + 4 * r; g0 = gp[0]; g1 = gp[1]; g2 = gp[2]; g3 = gp[3]; }
-                const bool ident = P.j_pre_ident[j] != 0;
-                const double *pre = P.j_pre + 12 * j;
-                auto mcol = [&](int col) -> double {
-                    if (ident) return col == 0 ? g0 : (col == 1 ? g1 : (col == 2 ? g2 : g3));
-                    double v = g0 * pre[col] + g1 * pre[4 + col] + g2 * pre[8 + col];
-                    return col == 3 ? v + g3 : v;
-                };
-                const int kind = P.j_kind[j];
-                double val;
-                if (kind <= TG_TZ) {
-                    val = mcol(c);
-                    if (c == 3) val += sc[2 * j] * mcol(kind - TG_TX);
-                } else {
-                    const int a = kind - TG_RX, b = (a + 1) % 3, cc = (a + 2) % 3;
-                    const double sn = sc[2 * j], cs = sc[2 * j + 1];
-                    if (c == 3 || c == a) val = mcol(c);
-                    else if (c == b) val = cs * mcol(b) + sn * mcol(cc);
-                    else val = cs * mcol(cc) - sn * mcol(b);
-                }
-                G[12 * j + e] = val;
+            if (on) TG_FOR(idx, 4 * cnt) {
+                const int j = j0 + (idx >> 2), c = idx & 3;
+                const double *gp = G + 12 * P.j_parent[j];
+                double *gj = G + 12 * j;
+                const double m0 = gj[c], m1 = gj[4 + c], m2 = gj[8 + c], t3 = (c == 3) ? 1.0 : 0.0;
+                const double v0 = gp[0] * m0 + gp[1] * m1 + gp[2] * m2 + t3 * gp[3];
+                const double v1 = gp[4] * m0 + gp[5] * m1 + gp[6] * m2 + t3 * gp[7];
+                const double v2 = gp[8] * m0 + gp[9] * m1 + gp[10] * m2 + t3 * gp[11];
+                gj[c] = v0; gj[4 + c] = v1; gj[8 + c] = v2;
             }
             TG_SYNC();
         }
@@ -1003,12 +998,14 @@ struct Core {
 
 // One trajectory (team) of a launch.  `traj` may be >= batch (idle team): it still takes part in
 // every TG_SYNC.
-template <int TEAM>
+// MODE is a compile-time parameter so that every kernel mode gets its own register allocation (the
+// derivative modes are far larger than the rollout loop).
+template <int TEAM, int MODE>
 TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lane, int traj) {
     const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc;
     const bool live = traj < A.batch;
     const size_t t = (size_t)(live ? traj : 0);
-    double dt = A.mode == MODE_ROLLOUT ? A.dt : (A.t2 - A.t1);
+    double dt = MODE == MODE_ROLLOUT ? A.dt : (A.t2 - A.t1);
     Core<TEAM> core(P, S, lane, dt);
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     core.prof_last = (long long)__builtin_amdgcn_s_memtime();
@@ -1017,27 +1014,27 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
     // ---- load state ----------------------------------------------------------------------------------
     if (live) {
         TG_FOR(i, nq) { S[P.o_q1 + i] = A.q1[t * nq + i]; S[P.o_q2 + i] = A.q2[t * nq + i]; }
-        TG_FOR(i, nd) S[P.o_p1 + i] = (A.mode == MODE_ROLLOUT) ? A.p2[t * nd + i] : A.p1[t * nd + i];
+        TG_FOR(i, nd) S[P.o_p1 + i] = (MODE == MODE_ROLLOUT) ? A.p2[t * nd + i] : A.p1[t * nd + i];
         TG_FOR(i, nc) S[P.o_lam + i] = A.lam[t * nc + i];
         TG_FOR(i, nu) S[P.o_u + i] = A.u1[t * nu + i];
         TG_FOR(i, nc * P.dh_ld) { S[P.o_Dh1 + i] = 0.0; S[P.o_Dh2 + i] = 0.0; }
     }
     TG_SYNC();
 
-    if (A.mode == MODE_CALC_P2) {  // MidpointVI.calc_p2: midpointvi.c:491-504
+    if constexpr (MODE == MODE_CALC_P2) {  // MidpointVI.calc_p2: midpointvi.c:491-504
         core.eval_midpoint(live);
         if (live) TG_FOR(i, nd) A.p2[t * nd + i] = 0.5 * dt * S[P.o_Ldq + i] + S[P.o_Lddq + i];
         return;
     }
-    if (A.mode == MODE_DERIV1) {
+    if constexpr (MODE == MODE_DERIV1) {
         core.deriv1(live, A, t);
         return;
     }
-    if (A.mode == MODE_DERIV2Z) {
+    if constexpr (MODE == MODE_DERIV2Z) {
         core.deriv2z(live, A, t);
         return;
     }
-    if (A.mode == MODE_CALC_F) {  // MidpointVI.calc_f: midpointvi.c:567-575
+    if constexpr (MODE == MODE_CALC_F) {  // MidpointVI.calc_f: midpointvi.c:567-575
         core.eval_constraints(live, 1, false, S + P.o_Dh1);
         core.eval_midpoint(live);
         core.eval_constraints(live, 2, true, S + P.o_Dh2);
@@ -1046,6 +1043,7 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
     }
 
     // ---- rollout ----------------------------------------------------------------------------------------
+    if constexpr (MODE == MODE_ROLLOUT) {
     const int nX = P.nX;
     if (live && A.X) {  // X_0 = [q2; p2; v2] of the incoming state (dsystem.py:276-281, midpointvi.py:325-332)
         double *x = A.X + t * (size_t)(A.n_steps + 1) * nX;
@@ -1136,6 +1134,7 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
         TG_FOR(i, nc) A.lam[t * nc + i] = S[P.o_lam + i];
         TG_FOR(i, nu) A.u1[t * nu + i] = S[P.o_u + i];
         if (lane == 0) { A.iters[t] = total_iters; A.status[t] = status; }
+    }
     }
 }
 

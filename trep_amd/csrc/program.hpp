@@ -32,6 +32,7 @@ struct DevProg {
     const int *j_cfg;         // [n_joints]
     const int *j_pre_ident;   // [n_joints] 1 if the constant pre-transform is the identity
     const double *j_pre;      // [n_joints*12]
+    const double *jcoef;      // [n_joints*16*4]: local transform entry e = A + B cos q + C sin q + D q
     const int *b_anchor;      // [n_bodies] joint or -1
     const double *b_C;        // [n_bodies*12]
     const double *b_inertia;  // [n_bodies*4]
@@ -62,6 +63,7 @@ struct DevProg {
     int d_o_Dh1, d_o_Dh2, d_o_AUG, d_aug_ld, d_o_T12, d_o_T22, d_nrhs, d_lds_per_team;
     // z-contracted second-derivative kernel: contracted Hessians H11/H12/H22 [nq][nq], G1 [nq][nc], vectors
     const int *cu_off;        // [nc+1] dh items of each constraint (its dependent configs)
+    const int *tab_i; const double *tab_d; int n_tab_i, n_tab_d;  // the packed table buffers (all pointers above point into them)
     int e_o_H11, e_o_H12, e_o_H22, e_o_G1, e_o_w, e_o_zq, e_o_zp, e_o_vec, e_lds_per_team;
 };
 
@@ -79,7 +81,14 @@ struct HostProgram {
     std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
     std::vector<double> damp;
     std::vector<int> cf_cfg, cf_in;
+    std::vector<double> jcoef;      // [n_joints*16*4] local-transform coefficients (see pose_sweep)
     int max_depth = 0;
+    // all tables packed into two pools; bind() points a DevProg's table pointers into (copies of) them
+    std::vector<int> ipool;
+    std::vector<double> dpool;
+    std::vector<size_t> ioff, doff;
+    void pack();
+    void bind(DevProg &P, const int *I, const double *D) const;
 };
 
 namespace detail {
@@ -179,6 +188,27 @@ inline HostProgram build_program(const tg_system_desc *d) {
         H.j_pre_ident[j] = is_ident(offset[p]) ? 1 : 0;
         std::memcpy(&H.j_pre[12 * (size_t)j], offset[p].m, sizeof(offset[p].m));
         if (H.j_parent[j] >= 0 && H.j_parent[j] >= j) throw std::runtime_error("joint ordering error");
+    }
+    // local transform of joint j as a function of its coordinate: entry e (row l, column c) of
+    // pre_j * lg(q) = A + B*s1 + C*s0 with (s0, s1) = (sin q, cos q) for a rotary joint and (q, 0) for a
+    // prismatic one -- removes every kind/identity branch from the device sweep.
+    H.jcoef.assign(16 * 4 * (size_t)nj, 0.0);
+    for (int j = 0; j < nj; j++) {
+        const double *pre = &H.j_pre[12 * (size_t)j];
+        const int kind = H.j_kind[j];
+        for (int l = 0; l < 3; l++)
+            for (int c = 0; c < 4; c++) {
+                double *k = &H.jcoef[((size_t)j * 16 + 4 * l + c) * 4];
+                if (kind <= TG_TZ) {
+                    k[0] = pre[4 * l + c];
+                    if (c == 3) k[2] = pre[4 * l + (kind - TG_TX)];
+                } else {
+                    const int a = kind - TG_RX, b = (a + 1) % 3, cc = (a + 2) % 3;
+                    if (c == b) { k[1] = pre[4 * l + b]; k[2] = pre[4 * l + cc]; }
+                    else if (c == cc) { k[1] = pre[4 * l + cc]; k[2] = -pre[4 * l + b]; }
+                    else k[0] = pre[4 * l + c];
+                }
+            }
     }
     // bodies and (body, path config) items
     const int nb = d->n_masses;
@@ -289,7 +319,48 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.e_o_H11 = take(nq * nq); P.e_o_H12 = take(nq * nq); P.e_o_H22 = take(nq * nq); P.e_o_G1 = take(nq * nc);
     P.e_o_w = take(P.nf); P.e_o_zq = take(nd); P.e_o_zp = take(nd); P.e_o_vec = take(3 * nq);
     P.e_lds_per_team = (off + 1) & ~1;
+    H.pack();
     return H;
 }
 
+}  // namespace tg
+
+namespace tg {
+namespace detail {
+template <typename T>
+inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const std::vector<T> &v) {
+    offs.push_back(pool.size());
+    pool.insert(pool.end(), v.begin(), v.end());
+    while (pool.size() % 4) pool.push_back(T());
+}
+}  // namespace detail
+
+#define TG_INT_TABLES(X)                                                                                     \
+    X(level_off) X(j_parent) X(j_kind) X(j_cfg) X(j_pre_ident) X(b_anchor) X(b_item_off) X(b_pair_off) X(it_body) \
+    X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
+    X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off)
+#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp)
+
+inline void HostProgram::pack() {
+    ipool.clear(); dpool.clear(); ioff.clear(); doff.clear();
+#define X(name) detail::pool_append(ipool, ioff, name);
+    TG_INT_TABLES(X)
+#undef X
+#define X(name) detail::pool_append(dpool, doff, name);
+    TG_DBL_TABLES(X)
+#undef X
+    ipool.push_back(0); dpool.push_back(0.0);
+}
+
+inline void HostProgram::bind(DevProg &P, const int *I, const double *D) const {
+    size_t k = 0;
+#define X(name) P.name = I + ioff[k++];
+    TG_INT_TABLES(X)
+#undef X
+    k = 0;
+#define X(name) P.name = D + doff[k++];
+    TG_DBL_TABLES(X)
+#undef X
+    P.tab_i = I; P.tab_d = D; P.n_tab_i = (int)ipool.size(); P.n_tab_d = (int)dpool.size();
+}
 }  // namespace tg

@@ -29,13 +29,33 @@ int fail(int code, const std::string &msg) {
         if (e_ != hipSuccess) return fail(TG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-template <int TEAM>
-__global__ __launch_bounds__(64) void k_run(const tg::DevProg P, const tg::RunArgs A) {
+template <int TEAM, int MODE>
+__global__ __launch_bounds__(64, 2) void k_run(const tg::DevProg P, const tg::RunArgs A) {
     extern __shared__ double lds[];
     const int team = threadIdx.x / TEAM, lane = threadIdx.x % TEAM;
     const int traj = blockIdx.x * (64 / TEAM) + team;
-    const int stride = A.mode == tg::MODE_DERIV2Z ? P.e_lds_per_team : (A.mode == tg::MODE_DERIV1 ? P.d_lds_per_team : P.lds_per_team);
-    tg::run_trajectory<TEAM>(P, A, lds + (size_t)team * stride, lane, traj);
+    const int stride = MODE == tg::MODE_DERIV2Z ? P.e_lds_per_team : (MODE == tg::MODE_DERIV1 ? P.d_lds_per_team : P.lds_per_team);
+#if defined(TG_LDS_TABLES)
+    // EXPERIMENT: stage every schedule table in LDS (per workgroup) to measure the cost of global-table latency
+    tg::DevProg Q = P;
+    double *td = lds + (size_t)(64 / TEAM) * stride;
+    int *ti = (int *)(td + P.n_tab_d);
+    for (int i = threadIdx.x; i < P.n_tab_d; i += 64) td[i] = P.tab_d[i];
+    for (int i = threadIdx.x; i < P.n_tab_i; i += 64) ti[i] = P.tab_i[i];
+    __syncthreads();
+#define RI(f) Q.f = ti + (P.f - P.tab_i)
+#define RD(f) Q.f = td + (P.f - P.tab_d)
+    RI(level_off); RI(j_parent); RI(j_kind); RI(j_cfg); RI(j_pre_ident); RI(b_anchor); RI(b_item_off); RI(b_pair_off);
+    RI(it_body); RI(it_joint); RI(it_cfg); RI(pair_a); RI(pair_b); RI(cfg_item_off); RI(cfg_items); RI(e_anchor);
+    RI(c_type); RI(c_e1); RI(c_e2); RI(c_cfg); RI(c_comp); RI(dh_c); RI(dh_cfg); RI(dh_joint); RI(dh_side);
+    RI(cf_cfg); RI(cf_in); RI(dh_lookup); RI(cu_off);
+    RD(j_pre); RD(jcoef); RD(b_C); RD(b_inertia); RD(e_off); RD(c_dist); RD(c_tol); RD(damp);
+#undef RI
+#undef RD
+    tg::run_trajectory<TEAM, MODE>(Q, A, lds + (size_t)team * stride, lane, traj);
+#else
+    tg::run_trajectory<TEAM, MODE>(P, A, lds + (size_t)team * stride, lane, traj);
+#endif
 }
 
 }  // namespace
@@ -120,31 +140,43 @@ void append(std::vector<T> &pool, const std::vector<T> &v, size_t &off) {
     while (pool.size() % 2) pool.push_back(T());
 }
 
-template <int TEAM>
-int allow_lds(size_t bytes) {
-    if (bytes > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<TEAM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+template <int TEAM, int MODE>
+int launch_one(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<TEAM, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_run<TEAM, MODE>), dim3(grid), dim3(64), lds, b->stream, b->P, A);
     return TG_SUCCESS;
+}
+
+template <int TEAM>
+int launch_team(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
+    switch (A.mode) {
+    case tg::MODE_ROLLOUT: return launch_one<TEAM, tg::MODE_ROLLOUT>(b, A, grid, lds);
+    case tg::MODE_CALC_P2: return launch_one<TEAM, tg::MODE_CALC_P2>(b, A, grid, lds);
+    case tg::MODE_CALC_F: return launch_one<TEAM, tg::MODE_CALC_F>(b, A, grid, lds);
+    case tg::MODE_DERIV1: return launch_one<TEAM, tg::MODE_DERIV1>(b, A, grid, lds);
+    case tg::MODE_DERIV2Z: return launch_one<TEAM, tg::MODE_DERIV2Z>(b, A, grid, lds);
+    default: return fail(TG_ERR_INVALID, "unknown kernel mode");
+    }
 }
 
 int launch(tg_batch *b, tg::RunArgs &A) {
     const int team = b->sys->team, per_block = 64 / team;
     const int grid = (A.batch + per_block - 1) / per_block;
     const int per_team = A.mode == tg::MODE_DERIV2Z ? b->P.e_lds_per_team : (A.mode == tg::MODE_DERIV1 ? b->P.d_lds_per_team : b->P.lds_per_team);
+#if defined(TG_LDS_TABLES)
+    const size_t lds = (size_t)per_block * per_team * sizeof(double) + b->P.n_tab_d * sizeof(double) + b->P.n_tab_i * sizeof(int) + 16;
+#else
     const size_t lds = (size_t)per_block * per_team * sizeof(double);
+#endif
     if (lds > 160 * 1024) return fail(TG_ERR_UNSUPPORTED, "system too large for the LDS-resident kernel");
-    int rc = team == 64 ? allow_lds<64>(lds) : (team == 16 ? allow_lds<16>(lds) : (team == 4 ? allow_lds<4>(lds) : allow_lds<1>(lds)));
-    if (rc) return rc;
     hipEvent_t e0, e1;
     if (b->pool.size() >= 2) { e0 = b->pool.back(); b->pool.pop_back(); e1 = b->pool.back(); b->pool.pop_back(); }
     else { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); }
     HIP_TRY(hipEventRecord(e0, b->stream));
-    switch (team) {
-    case 64: hipLaunchKernelGGL(k_run<64>, dim3(grid), dim3(64), lds, b->stream, b->P, A); break;
-    case 16: hipLaunchKernelGGL(k_run<16>, dim3(grid), dim3(64), lds, b->stream, b->P, A); break;
-    case 4: hipLaunchKernelGGL(k_run<4>, dim3(grid), dim3(64), lds, b->stream, b->P, A); break;
-    default: hipLaunchKernelGGL(k_run<1>, dim3(grid), dim3(64), lds, b->stream, b->P, A); break;
-    }
+    int rc = team == 64 ? launch_team<64>(b, A, grid, lds) : (team == 16 ? launch_team<16>(b, A, grid, lds)
+             : (team == 4 ? launch_team<4>(b, A, grid, lds) : launch_team<1>(b, A, grid, lds)));
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e1, b->stream));
     b->events.emplace_back(e0, e1);
@@ -216,40 +248,15 @@ tg_batch *tg_batch_create(tg_system *sys, int32_t batch, int32_t device) {
     b->sys = sys; b->batch = batch; b->device = device;
     const tg::HostProgram &H = sys->H;
     b->P = H.p;
-    // pack all index / constant tables into two device buffers
-    std::vector<int> ints;
-    std::vector<double> dbls;
-    size_t oi[24], od[8];
-    append(ints, H.level_off, oi[0]); append(ints, H.j_parent, oi[1]); append(ints, H.j_kind, oi[2]);
-    append(ints, H.j_cfg, oi[3]); append(ints, H.j_pre_ident, oi[4]); append(ints, H.b_anchor, oi[5]);
-    append(ints, H.b_item_off, oi[6]); append(ints, H.b_pair_off, oi[7]); append(ints, H.it_body, oi[8]);
-    append(ints, H.it_joint, oi[9]); append(ints, H.it_cfg, oi[10]); append(ints, H.pair_a, oi[11]);
-    append(ints, H.pair_b, oi[12]); append(ints, H.cfg_item_off, oi[13]); append(ints, H.cfg_items, oi[14]);
-    append(ints, H.e_anchor, oi[15]); append(ints, H.c_type, oi[16]); append(ints, H.c_e1, oi[17]);
-    append(ints, H.c_e2, oi[18]); append(ints, H.c_cfg, oi[19]); append(ints, H.c_comp, oi[20]);
-    append(ints, H.dh_c, oi[21]); append(ints, H.dh_cfg, oi[22]); append(ints, H.dh_joint, oi[23]);
-    size_t o_side, o_cfc, o_cfi;
-    size_t o_lookup, o_cu;
-    append(ints, H.dh_side, o_side); append(ints, H.cf_cfg, o_cfc); append(ints, H.cf_in, o_cfi);
-    append(ints, H.dh_lookup, o_lookup); append(ints, H.cu_off, o_cu);
-    append(dbls, H.j_pre, od[0]); append(dbls, H.b_C, od[1]); append(dbls, H.b_inertia, od[2]);
-    append(dbls, H.e_off, od[3]); append(dbls, H.c_dist, od[4]); append(dbls, H.c_tol, od[5]); append(dbls, H.damp, od[6]);
-    ints.push_back(0); dbls.push_back(0.0);
+    // all index / constant tables live in two device buffers; bind() points the DevProg into them
+    const std::vector<int> &ints = H.ipool;
+    const std::vector<double> &dbls = H.dpool;
     bool ok = hipMalloc(&b->d_ints, ints.size() * sizeof(int)) == hipSuccess &&
               hipMalloc(&b->d_dbls, dbls.size() * sizeof(double)) == hipSuccess &&
               hipMemcpy(b->d_ints, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(b->d_dbls, dbls.data(), dbls.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
     tg::DevProg &P = b->P;
-    const int *I = b->d_ints; const double *D = b->d_dbls;
-    P.level_off = I + oi[0]; P.j_parent = I + oi[1]; P.j_kind = I + oi[2]; P.j_cfg = I + oi[3]; P.j_pre_ident = I + oi[4];
-    P.b_anchor = I + oi[5]; P.b_item_off = I + oi[6]; P.b_pair_off = I + oi[7]; P.it_body = I + oi[8];
-    P.it_joint = I + oi[9]; P.it_cfg = I + oi[10]; P.pair_a = I + oi[11]; P.pair_b = I + oi[12];
-    P.cfg_item_off = I + oi[13]; P.cfg_items = I + oi[14]; P.e_anchor = I + oi[15]; P.c_type = I + oi[16];
-    P.c_e1 = I + oi[17]; P.c_e2 = I + oi[18]; P.c_cfg = I + oi[19]; P.c_comp = I + oi[20];
-    P.dh_c = I + oi[21]; P.dh_cfg = I + oi[22]; P.dh_joint = I + oi[23]; P.dh_side = I + o_side;
-    P.cf_cfg = I + o_cfc; P.cf_in = I + o_cfi; P.dh_lookup = I + o_lookup; P.cu_off = I + o_cu;
-    P.j_pre = D + od[0]; P.b_C = D + od[1]; P.b_inertia = D + od[2]; P.e_off = D + od[3];
-    P.c_dist = D + od[4]; P.c_tol = D + od[5]; P.damp = D + od[6];
+    H.bind(P, b->d_ints, b->d_dbls);
     auto dalloc = [&](double **p, size_t n) {
         if (!ok) return;
         ok = hipMalloc(p, (n ? n : 1) * sizeof(double)) == hipSuccess && hipMemset(*p, 0, (n ? n : 1) * sizeof(double)) == hipSuccess;
