@@ -214,6 +214,7 @@ struct Core {
                 J[r] = gb[r] * lin[0] + gb[4 + r] * lin[1] + gb[8 + r] * lin[2];
                 J[3 + r] = gb[r] * ang[0] + gb[4 + r] * ang[1] + gb[8 + r] * ang[2];
             }
+            S[P.o_dqi + it] = S[P.o_dq + P.it_cfg[it]];  // rate of the item's config, for the prefix sums
         }
         if (on) TG_FOR(idx, 3 * P.n_bodies) {
             const int b = idx / 3, r = idx % 3;
@@ -225,19 +226,18 @@ struct Core {
 
     // ---- prefix velocities, W_j = [P_j, J_j], body velocity v_F --------------------------------------
     TG_HD void velocities(bool on) {
-        const double *dq = S + P.o_dq;
         if (on) TG_FOR(it, P.n_items) {
             const int b = P.it_body[it], first = P.b_item_off[b], last = P.b_item_off[b + 1] - 1;
             double Pp[6] = {0, 0, 0, 0, 0, 0};
             for (int k = first; k < it; k++) {
                 const double *Jk = S + P.o_J + 6 * k;
-                const double r = dq[P.it_cfg[k]];
+                const double r = S[P.o_dqi + k];
                 for (int m = 0; m < 6; m++) Pp[m] += Jk[m] * r;
             }
             const double *J = S + P.o_J + 6 * it;
             bracket(Pp, J, S + P.o_W + 6 * it);
             if (it == last) {
-                const double r = dq[P.it_cfg[it]];
+                const double r = S[P.o_dqi + it];
                 for (int m = 0; m < 6; m++) S[P.o_vB + 6 * b + m] = Pp[m] + J[m] * r;
             }
         }
@@ -250,20 +250,29 @@ struct Core {
 
     // ---- L_dq, L_ddq per config and the dynamic part of the DEL residual (midpointvi.c:533-551) -------
     TG_HD void residual_dyn(bool on) {
+        // per-item terms <J,v> and <W,v> + m gam.Jv, stored in config-sorted order in the (now dead) joint
+        // pose area, then one contiguous sum per dynamic config
+        double *terms = S + P.o_G;
+        if (on) TG_FOR(it, P.n_items) {
+            const int b = P.it_body[it], slot = P.it_slot[it];
+            const double *I = P.b_inertia + 4 * b, *v = S + P.o_vB + 6 * b;
+            const double *J = S + P.o_J + 6 * it, *W = S + P.o_W + 6 * it, *gam = S + P.o_gam + 3 * b;
+            terms[2 * slot] = inner6(I, J, v);
+            terms[2 * slot + 1] = inner6(I, W, v) + I[0] * (gam[0] * J[0] + gam[1] * J[1] + gam[2] * J[2]);
+        }
+        TG_SYNC();
         if (on) TG_FOR(i, P.nd) {
             double ldq = 0.0, lddq = 0.0;
-            for (int n = P.cfg_item_off[i]; n < P.cfg_item_off[i + 1]; n++) {
-                const int it = P.cfg_items[n], b = P.it_body[it];
-                const double *I = P.b_inertia + 4 * b, *v = S + P.o_vB + 6 * b;
-                const double *J = S + P.o_J + 6 * it, *W = S + P.o_W + 6 * it, *gam = S + P.o_gam + 3 * b;
-                lddq += inner6(I, J, v);
-                ldq += inner6(I, W, v) + I[0] * (gam[0] * J[0] + gam[1] * J[1] + gam[2] * J[2]);
-            }
+            const int n1 = P.cfg_item_off[i + 1];
+            for (int n = P.cfg_item_off[i]; n < n1; n++) { lddq += terms[2 * n]; ldq += terms[2 * n + 1]; }
             S[P.o_Ldq + i] = ldq; S[P.o_Lddq + i] = lddq;
             double force = -P.damp[i] * S[P.o_dq + i];
             for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
             double f = S[P.o_p1 + i] + (0.5 * dt * ldq - lddq) + dt * force;
-            for (int c = 0; c < P.nc; c++) f -= S[P.o_Dh1 + c * P.dh_ld + i] * S[P.o_lam + c];
+            for (int c = 0; c < P.nc; c++) {
+                const int n = P.dh_lookup[c * P.nq + i];
+                if (n >= 0) f -= S[P.o_Dh1 + n] * S[P.o_lam + c];
+            }
             S[P.o_f + i] = f;
         }
         TG_SYNC();
@@ -311,7 +320,7 @@ struct Core {
                 if (side & 4) val -= qval(sel, k);
                 val *= 2.0;
             }
-            if (k < ld) Dh[c * ld + k] = val;
+            if (ld > 0) Dh[c * ld + k] = val; else Dh[n] = val;
         }
         TG_SYNC();
     }
@@ -326,8 +335,11 @@ struct Core {
                 for (int c = lane & (cw - 1); c <= nf; c += cw) {
                     double val;
                     if (c == nf) val = S[P.o_f + r];
-                    else if (r < nd) val = c < nd ? (r == c ? -P.damp[r] : 0.0) : -S[P.o_Dh1 + (c - nd) * P.dh_ld + r];
-                    else val = c < nd ? S[P.o_Dh2 + (r - nd) * P.dh_ld + c] : 0.0;
+                    else if (r < nd) {
+                        if (c < nd) val = (r == c) ? -P.damp[r] : 0.0;
+                        else { const int n = P.dh_lookup[(c - nd) * P.nq + r]; val = n >= 0 ? -S[P.o_Dh1 + n] : 0.0; }
+                    } else if (c < nd) { const int n = P.dh_lookup[(r - nd) * P.nq + c]; val = n >= 0 ? S[P.o_Dh2 + n] : 0.0; }
+                    else val = 0.0;
                     A[r * ld + c] = val;
                 }
         }
@@ -486,7 +498,11 @@ struct Core {
                 const double pkk = bcast(row[k]);
                 const double prhs = bcast(rhs);
                 const bool is_piv = mine && (lane & (TEAM - 1)) == src;
-                const double l = (go && mine && !is_piv) ? row[k] / pkk : 0.0;
+                // 1/pivot: hardware seed + two Newton steps (the multipliers need not be correctly rounded)
+                double rp = __builtin_amdgcn_rcp(pkk);
+                rp = fma(rp, fma(-pkk, rp, 1.0), rp);
+                rp = fma(rp, fma(-pkk, rp, 1.0), rp);
+                const double l = (go && mine && !is_piv) ? row[k] * rp : 0.0;
 #pragma unroll
                 for (int j = k + 1; j < NCOL; j++) {
                     if (j < n) {
@@ -987,7 +1003,7 @@ struct Core {
     }
     TG_HD void eval_constraints(bool on, int sel, bool want_h, double *Dh, int ld = -1) {
         if (P.nc == 0) return;
-        if (ld < 0) ld = P.dh_ld;
+        if (ld < 0) ld = 0;
         pose_sweep(on, sel);
         TG_STAMP(5);
         attach_points(on, false, true);
@@ -1017,7 +1033,7 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
         TG_FOR(i, nd) S[P.o_p1 + i] = (MODE == MODE_ROLLOUT) ? A.p2[t * nd + i] : A.p1[t * nd + i];
         TG_FOR(i, nc) S[P.o_lam + i] = A.lam[t * nc + i];
         TG_FOR(i, nu) S[P.o_u + i] = A.u1[t * nu + i];
-        TG_FOR(i, nc * P.dh_ld) { S[P.o_Dh1 + i] = 0.0; S[P.o_Dh2 + i] = 0.0; }
+        TG_FOR(i, P.n_dh) { S[P.o_Dh1 + i] = 0.0; S[P.o_Dh2 + i] = 0.0; }
     }
     TG_SYNC();
 
@@ -1073,7 +1089,7 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
         // Dh2 of the previous step's converged q2 (same point, same inputs), so only step 0 sweeps.
         if (step == 0) core.eval_constraints(on, 1, false, S + P.o_Dh1);
         else if (nc) {
-            if (on) TG_FOR(i, nc * P.dh_ld) S[P.o_Dh1 + i] = S[P.o_Dh2 + i];
+            if (on) TG_FOR(i, P.n_dh) S[P.o_Dh1 + i] = S[P.o_Dh2 + i];
             TG_SYNC();
         }
         int iterations = 0;

@@ -45,6 +45,7 @@ struct DevProg {
     const int *pair_b;        // [n_pairs] item index of the config nearer the body (may equal pair_a)
     const int *cfg_item_off;  // [nq+1] CSR config -> items
     const int *cfg_items;     // [n_items]
+    const int *it_slot;       // [n_items] position of the item in the config-sorted order (inverse of cfg_items)
     const int *e_anchor;      // [n_endpoints]
     const double *e_off;      // [n_endpoints*3]
     const int *c_type, *c_e1, *c_e2, *c_cfg, *c_comp;
@@ -55,9 +56,9 @@ struct DevProg {
     const int *cf_cfg, *cf_in;
     // LDS layout (offsets in doubles from the team's base)
     int o_q1, o_q2, o_p1, o_lam, o_u, o_dq, o_f, o_sc, o_G, o_gB, o_pE, o_J, o_W, o_vB, o_gam, o_Ldq, o_Lddq,
-        o_Dh1, o_Dh2, o_Df, o_scal, o_misc;
+        o_Dh1, o_Dh2, o_Df, o_scal, o_misc, o_dqi;
     int df_ld;
-    int dh_ld;                // leading dimension of the Dh1/Dh2 arrays in LDS (nd: dynamic columns only)
+    int dh_ld;                // 0: the step kernel keeps Dh1/Dh2 compact (one value per dh item)
     int lds_per_team;
     // first-derivative kernel: extra arrays appended after the step layout
     int d_o_Dh1, d_o_Dh2, d_o_AUG, d_aug_ld, d_o_T12, d_o_T22, d_nrhs, d_lds_per_team;
@@ -73,7 +74,7 @@ struct HostProgram {
     std::vector<double> j_pre;
     std::vector<int> b_anchor;
     std::vector<double> b_C, b_inertia;
-    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items;
+    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot;
     std::vector<int> e_anchor;
     std::vector<double> e_off;
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
@@ -239,6 +240,8 @@ inline HostProgram build_program(const tg_system_desc *d) {
             if (H.it_cfg[it] == c) H.cfg_items.push_back(it);
         H.cfg_item_off[c + 1] = (int)H.cfg_items.size();
     }
+    H.it_slot.assign(nitems, 0);
+    for (int n = 0; n < nitems; n++) H.it_slot[H.cfg_items[n]] = n;
     // constraint end points (unique frames) and constraint-Jacobian items
     std::map<int, int> ep_of_frame;
     auto endpoint = [&](int f) {
@@ -292,18 +295,21 @@ inline HostProgram build_program(const tg_system_desc *d) {
     // body poses only between the pose sweep and the Jacobians / constraints, so they share storage.
     int off = 0;
     auto take = [&](int n) { int o = off; off += (n > 0 ? n : 0); return o; };
-    P.dh_ld = nd;
+    P.dh_ld = 0;
     P.o_q1 = take(nq); P.o_q2 = take(nq); P.o_p1 = take(nd); P.o_lam = take(nc); P.o_u = take(P.nu); P.o_dq = take(nq);
     P.o_f = take(P.nf);
     P.o_J = take(6 * nitems); P.o_W = take(6 * nitems); P.o_vB = take(6 * nb); P.o_gam = take(3 * nb);
-    P.o_Ldq = take(nd); P.o_Lddq = take(nd); P.o_Dh1 = take(nc * P.dh_ld); P.o_Dh2 = take(nc * P.dh_ld);
+    P.o_Ldq = take(nd); P.o_Lddq = take(nd); P.o_Dh1 = take(P.n_dh); P.o_Dh2 = take(P.n_dh);  // compact: one value per (constraint, dependent config) item
     P.o_scal = take(P.nf); P.o_misc = take(2);
+    P.o_dqi = take(nitems);
     P.df_ld = (P.nf + 1) | 1;  // augmented with the right-hand side; odd stride avoids LDS bank conflicts
     const int shared0 = off;
     P.o_Df = take(P.nf * P.df_ld);
     const int end_df = off;
     off = shared0;
-    P.o_sc = take(2 * nj); P.o_G = take(12 * nj); P.o_gB = take(12 * nb); P.o_pE = take(3 * P.n_endpoints);
+    P.o_sc = take(2 * nj);
+    P.o_G = take(std::max(12 * nj, 2 * nitems));  // also holds the per-item residual terms
+    P.o_gB = take(12 * nb); P.o_pE = take(3 * P.n_endpoints);
     off = std::max(off, end_df);
     P.lds_per_team = (off + 1) & ~1;
     // first-derivative kernel (MODE_DERIV1): full-width constraint Jacobians, the augmented KKT matrix
@@ -338,7 +344,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
 #define TG_INT_TABLES(X)                                                                                     \
     X(level_off) X(j_parent) X(j_kind) X(j_cfg) X(j_pre_ident) X(b_anchor) X(b_item_off) X(b_pair_off) X(it_body) \
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
-    X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off)
+    X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot)
 #define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp)
 
 inline void HostProgram::pack() {
