@@ -35,6 +35,7 @@
 #if defined(__HIPCC__)
 // ROCm device-library wavefront reduction (DPP based); declared in hip/amd_detail only behind an opt-in macro
 extern "C" __device__ __attribute__((const)) unsigned long long __ockl_wfred_max_u64(unsigned long long);
+extern "C" __device__ __attribute__((const)) unsigned int __ockl_wfred_max_u32(unsigned int);
 #endif
 
 // Diagnostic build only (-DTG_PROFILE, `make prof`): per-phase cycle accumulation with s_memtime.
@@ -132,6 +133,29 @@ struct Core {
     // host-made coefficient rows (branch-free: entry = A + B*s1 + C*s0); (3) level by level
     // G_j = G_parent(j) * local_j in place, one lane per (joint, column): a lane reads only its own
     // column of the local transform, so there is no intra-joint hazard for any team size.
+    // Per-lane sweep schedule kept in registers for the whole kernel: for every level, the LDS offsets of
+    // the lane's own joint and of that joint's parent (the mapping lane -> (joint, column) never changes).
+    static constexpr int MAXL = 16;
+    int sweep_sched[MAXL];
+    bool sweep_fast = false;
+    TG_HD void init_sweep_schedule() {
+        sweep_fast = P.n_levels <= MAXL;
+#pragma unroll
+        for (int L = 0; L < MAXL; L++) {
+            int w = -1;
+            if (L >= 1 && L < P.n_levels) {
+                const int j0 = P.level_off[L], cnt = P.level_off[L + 1] - j0;
+                if (4 * cnt > TEAM) sweep_fast = false;
+                if (lane < 4 * cnt) {
+                    const int j = j0 + (lane >> 2);
+                    w = (12 * j) | ((12 * P.j_parent[j]) << 16);
+                }
+            }
+            sweep_sched[L] = w;
+        }
+        if (12 * P.n_joints >= 65536) sweep_fast = false;
+    }
+
     TG_HD void pose_sweep(bool on, int sel) {
         double *sc = S + P.o_sc, *G = S + P.o_G;
         if (on) TG_FOR(j, P.n_joints) {
@@ -140,25 +164,58 @@ struct Core {
             else { sc[2 * j] = x; sc[2 * j + 1] = 0.0; }
         }
         TG_SYNC();
-        if (on) TG_FOR(idx, 16 * P.n_joints) {
-            const int j = idx >> 4, e = idx & 15;
-            if (e < 12) {
-                const double *k = P.jcoef + 4 * (size_t)idx;
-                G[12 * j + e] = k[0] + k[1] * sc[2 * j + 1] + k[2] * sc[2 * j];
+        if (on) {  // local transforms, four independent coefficient rows in flight per lane
+            const int n12 = 12 * P.n_joints;
+            for (int base = lane; base < n12; base += 4 * TEAM) {
+                double k0[4], k1[4], k2[4];
+                int jj[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int idx = base + u * TEAM;
+                    const bool ok = idx < n12;
+                    const int j = ok ? idx / 12 : 0, e = ok ? idx % 12 : 0;
+                    const double *k = P.jcoef + 4 * (size_t)(16 * j + e);
+                    k0[u] = k[0]; k1[u] = k[1]; k2[u] = k[2]; jj[u] = j;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int idx = base + u * TEAM;
+                    if (idx < n12) G[idx] = k0[u] + k1[u] * sc[2 * jj[u] + 1] + k2[u] * sc[2 * jj[u]];
+                }
             }
         }
         TG_SYNC();
+        const int c = lane & 3;
+        const double t3 = (c == 3) ? 1.0 : 0.0;
+        if (sweep_fast) {
+#pragma unroll
+            for (int L = 1; L < MAXL; L++) {
+                if (L >= P.n_levels) break;
+                const int w = sweep_sched[L];
+                if (on && w >= 0) {
+                    double *gj = G + (w & 0xFFFF);
+                    const double *gp = G + (w >> 16);
+                    const double m0 = gj[c], m1 = gj[4 + c], m2 = gj[8 + c];
+                    const double v0 = gp[0] * m0 + gp[1] * m1 + gp[2] * m2 + t3 * gp[3];
+                    const double v1 = gp[4] * m0 + gp[5] * m1 + gp[6] * m2 + t3 * gp[7];
+                    const double v2 = gp[8] * m0 + gp[9] * m1 + gp[10] * m2 + t3 * gp[11];
+                    gj[c] = v0; gj[4 + c] = v1; gj[8 + c] = v2;
+                }
+                TG_SYNC();
+            }
+            return;
+        }
         for (int L = 1; L < P.n_levels; L++) {
             const int j0 = P.level_off[L], cnt = P.level_off[L + 1] - j0;
             if (on) TG_FOR(idx, 4 * cnt) {
-                const int j = j0 + (idx >> 2), c = idx & 3;
+                const int j = j0 + (idx >> 2), cc = idx & 3;
                 const double *gp = G + 12 * P.j_parent[j];
                 double *gj = G + 12 * j;
-                const double m0 = gj[c], m1 = gj[4 + c], m2 = gj[8 + c], t3 = (c == 3) ? 1.0 : 0.0;
-                const double v0 = gp[0] * m0 + gp[1] * m1 + gp[2] * m2 + t3 * gp[3];
-                const double v1 = gp[4] * m0 + gp[5] * m1 + gp[6] * m2 + t3 * gp[7];
-                const double v2 = gp[8] * m0 + gp[9] * m1 + gp[10] * m2 + t3 * gp[11];
-                gj[c] = v0; gj[4 + c] = v1; gj[8 + c] = v2;
+                const double m0 = gj[cc], m1 = gj[4 + cc], m2 = gj[8 + cc], u3 = (cc == 3) ? 1.0 : 0.0;
+                const double v0 = gp[0] * m0 + gp[1] * m1 + gp[2] * m2 + u3 * gp[3];
+                const double v1 = gp[4] * m0 + gp[5] * m1 + gp[6] * m2 + u3 * gp[7];
+                const double v2 = gp[8] * m0 + gp[9] * m1 + gp[10] * m2 + u3 * gp[11];
+                gj[cc] = v0; gj[4 + cc] = v1; gj[8 + cc] = v2;
             }
             TG_SYNC();
         }
@@ -329,19 +386,19 @@ struct Core {
     TG_HD void newton_matrix(bool on) {
         const int nd = P.nd, nf = P.nf, ld = P.df_ld;
         double *A = S + P.o_Df;
+        // zero fill, then the few structurally non-zero constant entries: damping on the diagonal
+        // (damping.c:21-27), the right-hand side f, and -Dh1^T / Dh2 from the (constraint, config) items
+        if (on) TG_FOR(i, nf * ld) A[i] = 0.0;
+        TG_SYNC();
         if (on) {
-            const int cwl = tile_log2<TEAM>(nf + 1), cw = 1 << cwl, rstep = TEAM >> cwl;
-            for (int r = lane >> cwl; r < nf; r += rstep)
-                for (int c = lane & (cw - 1); c <= nf; c += cw) {
-                    double val;
-                    if (c == nf) val = S[P.o_f + r];
-                    else if (r < nd) {
-                        if (c < nd) val = (r == c) ? -P.damp[r] : 0.0;
-                        else { const int n = P.dh_lookup[(c - nd) * P.nq + r]; val = n >= 0 ? -S[P.o_Dh1 + n] : 0.0; }
-                    } else if (c < nd) { const int n = P.dh_lookup[(r - nd) * P.nq + c]; val = n >= 0 ? S[P.o_Dh2 + n] : 0.0; }
-                    else val = 0.0;
-                    A[r * ld + c] = val;
-                }
+            TG_FOR(r, nf) {
+                A[r * ld + nf] = S[P.o_f + r];
+                if (r < nd) A[r * ld + r] = -P.damp[r];
+            }
+            TG_FOR(n, P.n_dh) {
+                const int k = P.dh_cfg[n], c = P.dh_c[n];
+                if (k < nd) { A[k * ld + nd + c] = -S[P.o_Dh1 + n]; A[(nd + c) * ld + k] = S[P.o_Dh2 + n]; }
+            }
         }
         TG_SYNC();
         TG_STAMP(7);
@@ -466,23 +523,23 @@ struct Core {
             if (k < n) {
                 // arg-max of |a_ik| * scale_i over the rows not yet used as pivots: the magnitude's bit
                 // pattern is monotone, so one u64 max carries the lane index in its 6 low bits.
-                const double cand = (mine && mycol < 0) ? fabs(row[k] * scale) : 0.0;
-                unsigned long long key = ((unsigned long long)__double_as_longlong(cand) & ~0x3FULL) | (unsigned long long)(63 - (lane & 63));
-                int piv;
-                double best;
+                // (the magnitude only ranks candidates, so single precision is plenty: one 32-bit wave max
+                // carries the lane index in the 6 low mantissa bits)
+                const float cand = (mine && mycol < 0) ? (float)fabs(row[k] * scale) : 0.0f;
+                unsigned int key = (__float_as_uint(cand) & ~0x3Fu) | (unsigned int)(63 - (lane & 63));
                 if (TEAM == 64) {
-                    key = __ockl_wfred_max_u64(key);
+                    key = __ockl_wfred_max_u32(key);
                 } else {
 #pragma unroll
                     for (int m = TEAM / 2; m >= 1; m >>= 1) {
-                        const unsigned long long o = __shfl_xor(key, m, TEAM);
+                        const unsigned int o = __shfl_xor(key, m, TEAM);
                         key = o > key ? o : key;
                     }
                 }
-                piv = 63 - (int)(key & 0x3FULL);
-                best = __longlong_as_double((long long)(key & ~0x3FULL));
+                int piv = 63 - (int)(key & 0x3Fu);
+                const float best = __uint_as_float(key & ~0x3Fu);
                 if (TEAM != 64) piv = (piv & (TEAM - 1));
-                if (on && ok && !(best > 1.0e-20)) ok = false;
+                if (on && ok && !(best > 1.0e-20f)) ok = false;
                 const bool go = on && ok;
                 // broadcast the pivot row (columns k..n-1 and the rhs)
                 const int src = (TEAM == 64) ? __builtin_amdgcn_readfirstlane(piv) : piv;
@@ -1023,6 +1080,7 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
     const size_t t = (size_t)(live ? traj : 0);
     double dt = MODE == MODE_ROLLOUT ? A.dt : (A.t2 - A.t1);
     Core<TEAM> core(P, S, lane, dt);
+    core.init_sweep_schedule();
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     core.prof_last = (long long)__builtin_amdgcn_s_memtime();
 #endif
@@ -1109,7 +1167,7 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
 #endif
             core.newton_matrix(!done);
             bool ok;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_GJROWS)
             constexpr int NCOL = TEAM == 64 ? 32 : (TEAM > 1 ? TEAM : 2);
             if (TEAM > 1 && P.nf <= TEAM && P.nf <= NCOL) ok = core.template gj_rows<NCOL>(!done, S + P.o_Df, P.nf, P.df_ld);
             else

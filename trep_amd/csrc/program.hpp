@@ -301,7 +301,6 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.o_J = take(6 * nitems); P.o_W = take(6 * nitems); P.o_vB = take(6 * nb); P.o_gam = take(3 * nb);
     P.o_Ldq = take(nd); P.o_Lddq = take(nd); P.o_Dh1 = take(P.n_dh); P.o_Dh2 = take(P.n_dh);  // compact: one value per (constraint, dependent config) item
     P.o_scal = take(P.nf); P.o_misc = take(2);
-    P.o_dqi = take(nitems);
     P.df_ld = (P.nf + 1) | 1;  // augmented with the right-hand side; odd stride avoids LDS bank conflicts
     const int shared0 = off;
     P.o_Df = take(P.nf * P.df_ld);
@@ -310,6 +309,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.o_sc = take(2 * nj);
     P.o_G = take(std::max(12 * nj, 2 * nitems));  // also holds the per-item residual terms
     P.o_gB = take(12 * nb); P.o_pE = take(3 * P.n_endpoints);
+    P.o_dqi = take(nitems);  // per-item rates: alive only while the poses are (Jacobians -> prefix sums)
     off = std::max(off, end_df);
     P.lds_per_team = (off + 1) & ~1;
     // first-derivative kernel (MODE_DERIV1): full-width constraint Jacobians, the augmented KKT matrix
