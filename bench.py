@@ -70,6 +70,22 @@ def cpu_baseline(system, Q0, K, dt, budget_s=12.0):
             "reference_trep_single_core_steps_per_s": REFERENCE_TREP_STEPS_PER_S}
 
 
+def pmc_traffic(batch, rollout_steps):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json), if one
+    exists for exactly this workload; PMC collection needs rocprofv3 around the process, so bench.py
+    cannot measure it live (tools/collect_profile.sh + tools/summarize_pmc.py produce the file)."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("global_batch") == batch and d.get("rollout_steps") == rollout_steps:
+            best = (d["hbm_bytes_per_launch"], os.path.relpath(path, ROOT))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,9 +155,8 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        from trep_amd import distributed
+        elapsed = distributed.max_over_ranks(elapsed, device="cuda")
     n_launch, kernel_ms = mvi.timing(reset=True)
     iters, status = mvi.status()
     total_iters = int(iters.sum())
@@ -154,6 +169,7 @@ def main():
         bytes_per_step = 8.0 * (2 * nX + nU + nc)   # read X_k, U_k; write X_k+1, lambda
         algo_bytes = bytes_per_step * B * N
         achieved = algo_bytes / avg_kernel_s / 1e9
+        traffic = pmc_traffic(B, N) if world == 1 else None
         out = {
             "metric": "DEL-steps/sec x batch (puppet ~40-DOF, fp64)",
             "value": value, "unit": "DEL-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,7 +181,8 @@ def main():
                        "newton_iterations_per_step": total_iters / float(B * N), "failed_trajectories": n_failed,
                        "writes_X": not args.no_x},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
+                         "traffic_source": traffic[1] if traffic else None,
                          "kernel": "k_run<%d> (rollout)" % mvi.info()["team"],
                          "kernel_avg_ms": 1e3 * avg_kernel_s, "launches": n_launch,
                          "algorithmic_bytes_per_launch": algo_bytes,
