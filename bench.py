@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--rollout-steps", type=int, default=200, help="DEL steps per trajectory per pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-x", action="store_true", help="do not write the state trajectory X to HBM")
+    ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank (self-test)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,12 +103,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         # torch first: its bundled HIP runtime (same SONAME) is then the single runtime of the process
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     import trep_amd
 
     system, Q0, K, dt = build_workload(args, rank)
@@ -116,7 +120,7 @@ def main():
     nX, nU, nc = mvi.nX, mvi.nU, mvi.nc
     K_dev = mvi.device_array(K)
     gather = None
-    if world > 1:
+    if use_dist:
         X_t = None if args.no_x else torch.empty((B, N + 1, nX), dtype=torch.float64, device="cuda")
         X_dev = None if X_t is None else X_t.data_ptr()
         gather = torch.empty((world * B, nX), dtype=torch.float64, device="cuda")
@@ -130,7 +134,7 @@ def main():
     def one_pass():
         mvi.restore()   # device-to-device: every pass integrates the same 200-step window
         mvi.rollout_device(N, dt, None, K_dev, X_dev)
-        if world > 1:
+        if use_dist:
             mvi.synchronize()
             if X_t is not None:
                 term.copy_(X_t[:, N, :])
@@ -138,7 +142,7 @@ def main():
 
     def sync():
         mvi.synchronize()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -154,7 +158,7 @@ def main():
         one_pass()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         from trep_amd import distributed
         elapsed = distributed.max_over_ranks(elapsed, device="cuda")
     n_launch, kernel_ms = mvi.timing(reset=True)
@@ -195,7 +199,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     mvi.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

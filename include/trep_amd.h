@@ -157,6 +157,18 @@ int tg_batch_step(tg_batch *b, double t2_new, const double *u1_host, const doubl
  */
 int tg_batch_rollout(tg_batch *b, int32_t n_steps, double dt, const double *U_dev,
                      const double *K_dev, double *X_dev, int32_t max_iterations);
+/*
+ * Closed-loop rollout (the projection operator of trep.discopt: DSystem.project, dsystem.py:426-451, and
+ * DOptimizer.armijo_simulate, doptimizer.py:405-428): the inputs are computed in the kernel,
+ *   U_k = bU_k - Kproj_k (X_k - bX_k),   X_k = [q2; p2; v2],   U_k = [u1; k2],
+ * Kproj_dev [groups][n_steps][nU][nX] with one gain schedule per `group_size` consecutive trajectories
+ * (e.g. all Armijo candidates of one seed), bX_dev [batch][n_steps+1][nX], bU_dev [batch][n_steps][nU].
+ * X_dev [batch][n_steps+1][nX] and U_dev [batch][n_steps][nU] (either may be NULL) receive the projected
+ * trajectory.  Starts from the batch's current (t2, q2, p2, lambda1) like tg_batch_rollout.
+ */
+int tg_batch_rollout_closed_loop(tg_batch *b, int32_t n_steps, double dt, const double *Kproj_dev, int32_t group_size,
+                                 const double *bX_dev, const double *bU_dev, double *X_dev, double *U_dev,
+                                 int32_t max_iterations);
 int tg_batch_rollout_stats(tg_batch *b, int64_t *total_iterations, int32_t *n_failed);
 int tg_batch_status(tg_batch *b, int32_t *iterations_out, int32_t *status_out);
 

@@ -20,7 +20,7 @@ class RunArgs(ctypes.Structure):
                 ("dt", ctypes.c_double), ("t1", ctypes.c_double), ("t2", ctypes.c_double),
                 ("tolerance", ctypes.c_double),
                 ("q1", _D), ("q2", _D), ("p1", _D), ("p2", _D), ("lam", _D), ("u1", _D),
-                ("U", _D), ("K", _D), ("q2_hint", _D), ("lam_hint", _D), ("X", _D), ("f_out", _D),
+                ("U", _D), ("K", _D), ("q2_hint", _D), ("lam_hint", _D), ("Kproj", _D), ("bX", _D), ("bU", _D), ("Uout", _D), ("group_size", ctypes.c_int), ("X", _D), ("f_out", _D),
                 ("d1", _D * 12), ("z", _D), ("hz", _D), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p)]
 
 
@@ -74,6 +74,7 @@ class EmuBatch(object):
     def _args(self, mode, n_steps=0, dt=0.0, U=None, K=None, X=None, f=None, q2_hint=None, lam_hint=None, max_it=200):
         a = RunArgs()
         a.batch, a.n_steps, a.max_iterations, a.mode = self.B, n_steps, max_it, mode
+        a.group_size = 1
         a.dt, a.t1, a.t2, a.tolerance = dt, self.t1, self.t2, self.tol
         a.q1, a.q2, a.p1, a.p2, a.lam, a.u1 = _p(self.q1), _p(self.q2), _p(self.p1), _p(self.p2), _p(self.lam), _p(self.u1)
         a.U, a.K, a.X, a.f_out, a.q2_hint, a.lam_hint = _p(U), _p(K), _p(X), _p(f), _p(q2_hint), _p(lam_hint)
@@ -106,6 +107,19 @@ class EmuBatch(object):
                 a.d1[4 * oi + ki] = arr.ctypes.data_as(_D) if arr.size else ctypes.cast(0, _D)
         self.L.emu_run(self.h, ctypes.byref(a))
         return outs
+
+    def rollout_closed_loop(self, n_steps, dt, Kproj, bX, bU, group_size=1):
+        """U_k = bU_k - Kproj_k (X_k - bX_k) in-kernel; returns (X [B][N+1][nX], U [B][N][nU])."""
+        Kproj = np.ascontiguousarray(Kproj, dtype=float)
+        bX = np.ascontiguousarray(bX, dtype=float)
+        bU = np.ascontiguousarray(bU, dtype=float)
+        X = np.zeros((self.B, n_steps + 1, self.nX))
+        Uo = np.zeros((self.B, n_steps, self.nu + self.nk))
+        a = self._args(0, n_steps, dt, None, None, X)
+        a.Kproj, a.bX, a.bU, a.Uout, a.group_size = _p(Kproj), _p(bX), _p(bU), _p(Uo), group_size
+        self.L.emu_run(self.h, ctypes.byref(a))
+        self.t1, self.t2 = self.t2 + (n_steps - 1) * dt, self.t2 + n_steps * dt
+        return X, Uo
 
     def deriv2z(self, Z):
         """HZ [B][R][R]: second derivatives of the step map contracted with z = Z[b] (nX)."""

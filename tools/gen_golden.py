@@ -218,8 +218,66 @@ def gen_puppet():
     save("puppet40", **arrays, **ds)
 
 
+
+
+def gen_discopt_cart():
+    """One DOptimizer trace on the pend-on-cart problem of examples/pend-on-cart-optimization.py:48-116
+    (torque input enabled, 5 s horizon): a few quasi-Newton then Newton steps; per step the method,
+    cost0, dcost0, accepted Armijo exponent, cost1 and the new trajectory."""
+    from math import pi as mpi, cos
+    system = systems.pend_on_cart(torque_force=True, api=trep)
+    mvi = trep.MidpointVI(system, num_threads=1)
+    t = np.arange(0.0, 5.0, DT)
+    dsys = trep.discopt.DSystem(mvi, t)
+    (X, U) = dsys.build_trajectory()
+    for k in range(dsys.kf()):
+        if k == 0:
+            dsys.set(X[k], U[k], 0)
+        else:
+            dsys.step(U[k])
+        X[k + 1] = dsys.f()
+    amp = 130 * mpi / 180
+    qd = np.zeros((len(t), system.nQ))
+    th = system.get_config('theta').index
+    for i, ti in enumerate(t):
+        if 3.0 <= ti <= 7.0:
+            qd[i, th] = (1 - cos(2 * mpi / 4 * (ti - 3.0))) * amp / 2
+    (Xd, Ud) = dsys.build_trajectory(qd)
+    wq = 0.01 * np.ones(dsys.nX); wq[system.get_config('x').index] = 0.01; wq[th] = 100.0
+    wr = 0.01 * np.ones(dsys.nU)
+    Qc, Rc = np.diag(wq), np.diag(wr)
+    cost = trep.discopt.DCost(Xd, Ud, Qc, Rc)
+
+    class Rec(trep.discopt.DOptimizerMonitor):
+        def __init__(self):
+            self.m = []
+        def armijo_evaluation(self, armijo_iteration, nX, nU, bX, bU, cost, max_cost):
+            self.m.append(armijo_iteration)
+    mon = Rec()
+    opt = trep.discopt.DOptimizer(dsys, cost, monitor=mon)
+    out = dict(t=t, X0=X.copy(), U0=U.copy(), Xd=Xd, Ud=Ud, Q=Qc, R=Rc)
+    methods = ['quasi', 'quasi', 'newton', 'newton', 'newton']
+    (Kproj, dX, dU, Qm, Rm, Sm) = opt.calc_descent_direction(X, U, 'newton')
+    out.update(dd_newton_dX=dX, dd_newton_dU=dU, dd_Kproj=np.array(Kproj),
+               dd_newton_Q=np.array([Qm(k) for k in range(len(X))]),
+               dd_newton_S=np.array([Sm(k) for k in range(len(X) - 1)]),
+               dd_newton_R=np.array([Rm(k) for k in range(len(X) - 1)]))
+    (Kproj, dX, dU, Qm, Rm, Sm) = opt.calc_descent_direction(X, U, 'quasi')
+    out.update(dd_quasi_dX=dX, dd_quasi_dU=dU)
+    out["cost_initial"] = np.array([opt.calc_cost(X, U)])
+    for i, method in enumerate(methods):
+        mon.m = []
+        cost0 = opt.calc_cost(X, U)
+        (done, X, U, dcost0, cost1) = opt.step(i, X, U, method)
+        out["it%d_cost0" % i] = np.array([cost0]); out["it%d_dcost0" % i] = np.array([dcost0])
+        out["it%d_cost1" % i] = np.array([cost1]); out["it%d_m" % i] = np.array([mon.m[-1] if mon.m else -1])
+        out["it%d_X" % i] = X.copy(); out["it%d_U" % i] = U.copy()
+    out["methods"] = np.array(methods)
+    save("discopt_pend_on_cart", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "discopt"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -232,3 +290,5 @@ if __name__ == "__main__":
         gen_scissor()
     if "puppet" in which:
         gen_puppet()
+    if "discopt" in which:
+        gen_discopt_cart()

@@ -46,6 +46,9 @@ _SIGNATURES = {
                                      ctypes.c_void_p]),
     "tg_batch_rollout": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_double, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
+    "tg_batch_rollout_closed_loop": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_double, ctypes.c_void_p,
+                                                    ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_int32]),
     "tg_batch_rollout_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), _c_ip]),
     "tg_batch_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tg_batch_deriv1": (ctypes.c_int, [ctypes.c_void_p]),

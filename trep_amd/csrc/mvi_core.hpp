@@ -56,6 +56,12 @@ struct RunArgs {
     double *q1, *q2, *p1, *p2, *lam, *u1;  // batch state, row-major [batch][width]
     const double *U, *K;                   // [batch][n_steps][nu], [batch][n_steps][nk]
     const double *q2_hint, *lam_hint;      // [batch][nd], [batch][nc] or null
+    // closed-loop rollout (projection operator, reference dsystem.py:426-451, doptimizer.py:405-428):
+    //   U_k = bU_k - Kproj_k (X_k - bX_k);  Kproj [groups][n_steps][nU][nX], one group per `group_size`
+    //   consecutive trajectories; bX [batch][n_steps+1][nX]; bU [batch][n_steps][nU]; Uout like bU or null
+    const double *Kproj, *bX, *bU;
+    double *Uout;
+    int group_size;
     double *X;                             // [batch][n_steps+1][nX] or null
     double *f_out;                         // MODE_CALC_F: [batch][nf]
     double *d1[12];                        // MODE_DERIV1 outputs q2_d{q1,p1,u1,k2}, p2_d*, l1_d*: [batch][var][out]
@@ -1129,16 +1135,37 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
     int status = TG_OK, total_iters = 0;
     for (int step = 0; step < A.n_steps; step++) {
         const bool on = live && !failed;
+        if (A.Kproj) {  // feedback inputs from the state entering this step (before the shift: v needs q1)
+            const int nU = nu + nk;
+            if (on) TG_FOR(j, nU) {
+                const double *Kr = A.Kproj + ((((size_t)(t / A.group_size)) * A.n_steps + step) * nU + j) * nX;
+                const double *bx = A.bX + (t * (size_t)(A.n_steps + 1) + step) * nX;
+                const double dtp = step == 0 ? (A.t2 - A.t1) : dt;
+                double acc = A.bU[(t * A.n_steps + step) * nU + j];
+                if (step > 0)   // X_0 = bX_0 by definition of the projection: no correction at k = 0
+                for (int i = 0; i < nq; i++) acc -= Kr[i] * (S[P.o_q2 + i] - bx[i]);
+                if (step > 0)
+                for (int i = 0; i < nd; i++) acc -= Kr[nq + i] * (S[P.o_p1 + i] - bx[nq + i]);
+                if (step > 0)
+                for (int i = 0; i < nk; i++) {
+                    const double v = dtp != 0.0 ? (S[P.o_q2 + nd + i] - S[P.o_q1 + nd + i]) / dtp : 0.0;
+                    acc -= Kr[nq + nd + i] * (v - bx[nq + nd + i]);
+                }
+                S[P.o_nu + j] = acc;
+                if (A.Uout) A.Uout[(t * A.n_steps + step) * nU + j] = acc;
+            }
+            TG_SYNC();
+        }
         // advance: q1 <- q2, (p1 already holds p2), inputs, kinematic targets, hints (midpointvi.py:188-197)
         if (on) {
             TG_FOR(i, nq) S[P.o_q1 + i] = S[P.o_q2 + i];
-            TG_FOR(i, nu) S[P.o_u + i] = A.U[(t * A.n_steps + step) * nu + i];
+            TG_FOR(i, nu) S[P.o_u + i] = A.Kproj ? S[P.o_nu + i] : A.U[(t * A.n_steps + step) * nu + i];
             // the momentum entering the last step is the state's p1 afterwards (midpointvi.py:189)
             if (step == A.n_steps - 1) TG_FOR(i, nd) A.p1[t * nd + i] = S[P.o_p1 + i];
         }
         TG_SYNC();
         if (on) {
-            TG_FOR(i, nk) S[P.o_q2 + nd + i] = A.K[(t * A.n_steps + step) * nk + i];
+            TG_FOR(i, nk) S[P.o_q2 + nd + i] = A.Kproj ? S[P.o_nu + nu + i] : A.K[(t * A.n_steps + step) * nk + i];
             if (A.q2_hint && step == 0) TG_FOR(i, nd) S[P.o_q2 + i] = A.q2_hint[t * nd + i];
             if (A.lam_hint && step == 0) TG_FOR(i, nc) S[P.o_lam + i] = A.lam_hint[t * nc + i];
         }

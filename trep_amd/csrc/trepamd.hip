@@ -192,6 +192,7 @@ tg::RunArgs base_args(tg_batch *b, int mode) {
     A.prof_out = b->prof;
     for (int i = 0; i < 12; i++) A.d1[i] = b->d1[i];
     A.z = b->z_dev; A.hz = b->hz_dev;
+    A.group_size = 1;
     return A;
 }
 
@@ -401,6 +402,22 @@ int tg_batch_rollout(tg_batch *b, int32_t n_steps, double dt, const double *U_de
     tg::RunArgs A = base_args(b, tg::MODE_ROLLOUT);
     A.n_steps = n_steps; A.dt = dt; A.max_iterations = max_iterations;
     A.U = U_dev; A.K = K_dev; A.X = X_dev;
+    int rc = launch(b, A);
+    if (rc) return rc;
+    b->t1 = b->t2 + (n_steps - 1) * dt;
+    b->t2 = b->t2 + n_steps * dt;
+    return TG_SUCCESS;
+}
+
+int tg_batch_rollout_closed_loop(tg_batch *b, int32_t n_steps, double dt, const double *Kproj_dev, int32_t group_size,
+                                 const double *bX_dev, const double *bU_dev, double *X_dev, double *U_dev,
+                                 int32_t max_iterations) {
+    if (!b || n_steps <= 0 || dt == 0.0 || !Kproj_dev || !bX_dev || !bU_dev || group_size <= 0)
+        return fail(TG_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(b->device));
+    tg::RunArgs A = base_args(b, tg::MODE_ROLLOUT);
+    A.n_steps = n_steps; A.dt = dt; A.max_iterations = max_iterations;
+    A.Kproj = Kproj_dev; A.bX = bX_dev; A.bU = bU_dev; A.Uout = U_dev; A.group_size = group_size; A.X = X_dev;
     int rc = launch(b, A);
     if (rc) return rc;
     b->t1 = b->t2 + (n_steps - 1) * dt;

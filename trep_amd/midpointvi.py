@@ -236,6 +236,26 @@ class BatchMidpointVI(object):
                 self._owned_dev.remove(p)
         return X
 
+    def rollout_closed_loop(self, n_steps, dt, Kproj, bX, bU, group_size=1, max_iterations=200):
+        """Projection-operator rollout: U_k = bU_k - Kproj_k (X_k - bX_k) evaluated in the kernel.
+        Kproj [groups][N][nU][nX], bX [B][N+1][nX], bU [B][N][nU] (host arrays); returns (X, U)."""
+        B, nX, nU = self._batch, self.nX, self.nU
+        groups = (B + group_size - 1) // group_size
+        K_dev = self.device_array(_lib.as_f64(Kproj, (groups, n_steps, nU, nX)))
+        bX_dev = self.device_array(_lib.as_f64(bX, (B, n_steps + 1, nX)))
+        bU_dev = self.device_array(_lib.as_f64(bU, (B, n_steps, nU)))
+        X_dev = self.device_empty(B * (n_steps + 1) * nX)
+        U_dev = self.device_empty(B * n_steps * nU)
+        _lib.check(self._L.tg_batch_rollout_closed_loop(self._h, int(n_steps), float(dt), K_dev, int(group_size),
+                                                        bX_dev, bU_dev, X_dev, U_dev, int(max_iterations)))
+        self.synchronize()
+        X = self.download(X_dev, (B, n_steps + 1, nX))
+        U = self.download(U_dev, (B, n_steps, nU))
+        for p in (K_dev, bX_dev, bU_dev, X_dev, U_dev):
+            self._L.tg_device_free(self._device, p)
+            self._owned_dev.remove(p)
+        return X, U
+
     def snapshot(self):
         """Save the integrator state on the device (replayed by restore())."""
         _lib.check(self._L.tg_batch_snapshot(self._h))
