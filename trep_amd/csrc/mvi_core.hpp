@@ -289,24 +289,25 @@ struct Core {
 
     // ---- prefix velocities, W_j = [P_j, J_j], body velocity v_F --------------------------------------
     TG_HD void velocities(bool on) {
-        if (on) TG_FOR(it, P.n_items) {
-            const int b = P.it_body[it], first = P.b_item_off[b], last = P.b_item_off[b + 1] - 1;
-            double Pp[6] = {0, 0, 0, 0, 0, 0};
-            for (int k = first; k < it; k++) {
-                const double *Jk = S + P.o_J + 6 * k;
-                const double r = S[P.o_dqi + k];
-                for (int m = 0; m < 6; m++) Pp[m] += Jk[m] * r;
+        // (1) one lane per (body, twist component): serial prefix sum along the body's path,
+        //     P_j = sum_{k<j} J_k dq_k written into the W slot of item j, total = body velocity;
+        // (2) one lane per item: W_j = [P_j, J_j] in place.
+        if (on) TG_FOR(idx, 6 * P.n_bodies) {
+            const int b = idx / 6, m = idx % 6;
+            const int first = P.b_item_off[b], last = P.b_item_off[b + 1];
+            double acc = 0.0;
+            for (int k = first; k < last; k++) {
+                S[P.o_W + 6 * k + m] = acc;
+                acc += S[P.o_J + 6 * k + m] * S[P.o_dqi + k];
             }
-            const double *J = S + P.o_J + 6 * it;
-            bracket(Pp, J, S + P.o_W + 6 * it);
-            if (it == last) {
-                const double r = S[P.o_dqi + it];
-                for (int m = 0; m < 6; m++) S[P.o_vB + 6 * b + m] = Pp[m] + J[m] * r;
-            }
+            S[P.o_vB + idx] = acc;
         }
-        if (on) TG_FOR(b, P.n_bodies) {
-            if (P.b_item_off[b + 1] == P.b_item_off[b])
-                for (int m = 0; m < 6; m++) S[P.o_vB + 6 * b + m] = 0.0;
+        TG_SYNC();
+        if (on) TG_FOR(it, P.n_items) {
+            double *W = S + P.o_W + 6 * it;
+            const double *J = S + P.o_J + 6 * it;
+            const double Pp[6] = {W[0], W[1], W[2], W[3], W[4], W[5]};
+            bracket(Pp, J, W);
         }
         TG_SYNC();
     }
@@ -413,8 +414,8 @@ struct Core {
             const int p0 = P.b_pair_off[b], np = P.b_pair_off[b + 1] - p0;
             const double *I = P.b_inertia + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
             if (on) TG_FOR(pp, np) {
-                const int ia = P.pair_a[p0 + pp], ib = P.pair_b[p0 + pp];
-                const int ca = P.it_cfg[ia], cb = P.it_cfg[ib];
+                const int *pw = P.pair4 + 4 * (size_t)(p0 + pp);   // {item a, item b, config a, config b}
+                const int ia = pw[0], ib = pw[1], ca = pw[2], cb = pw[3];
                 if (ca >= nd || cb >= nd) continue;
                 const double *Ja = S + P.o_J + 6 * ia, *Jb = S + P.o_J + 6 * ib;
                 const double *Wa = S + P.o_W + 6 * ia, *Wb = S + P.o_W + 6 * ib;

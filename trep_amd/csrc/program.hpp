@@ -43,6 +43,7 @@ struct DevProg {
     const int *it_cfg;        // [n_items]
     const int *pair_a;        // [n_pairs] item index of the config nearer the root
     const int *pair_b;        // [n_pairs] item index of the config nearer the body (may equal pair_a)
+    const int *pair4;         // [n_pairs*4] {item a, item b, config a, config b}: one 16-byte load per pair
     const int *cfg_item_off;  // [nq+1] CSR config -> items
     const int *cfg_items;     // [n_items]
     const int *it_slot;       // [n_items] position of the item in the config-sorted order (inverse of cfg_items)
@@ -74,7 +75,7 @@ struct HostProgram {
     std::vector<double> j_pre;
     std::vector<int> b_anchor;
     std::vector<double> b_C, b_inertia;
-    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot;
+    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4;
     std::vector<int> e_anchor;
     std::vector<double> e_off;
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
@@ -240,6 +241,10 @@ inline HostProgram build_program(const tg_system_desc *d) {
             if (H.it_cfg[it] == c) H.cfg_items.push_back(it);
         H.cfg_item_off[c + 1] = (int)H.cfg_items.size();
     }
+    for (size_t n = 0; n < H.pair_a.size(); n++) {
+        H.pair4.push_back(H.pair_a[n]); H.pair4.push_back(H.pair_b[n]);
+        H.pair4.push_back(H.it_cfg[H.pair_a[n]]); H.pair4.push_back(H.it_cfg[H.pair_b[n]]);
+    }
     H.it_slot.assign(nitems, 0);
     for (int n = 0; n < nitems; n++) H.it_slot[H.cfg_items[n]] = n;
     // constraint end points (unique frames) and constraint-Jacobian items
@@ -344,7 +349,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
 #define TG_INT_TABLES(X)                                                                                     \
     X(level_off) X(j_parent) X(j_kind) X(j_cfg) X(j_pre_ident) X(b_anchor) X(b_item_off) X(b_pair_off) X(it_body) \
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
-    X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot)
+    X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4)
 #define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp)
 
 inline void HostProgram::pack() {

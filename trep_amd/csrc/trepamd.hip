@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64, 2) void k_run(const tg::DevProg P, const tg::Ru
     RI(level_off); RI(j_parent); RI(j_kind); RI(j_cfg); RI(j_pre_ident); RI(b_anchor); RI(b_item_off); RI(b_pair_off);
     RI(it_body); RI(it_joint); RI(it_cfg); RI(pair_a); RI(pair_b); RI(cfg_item_off); RI(cfg_items); RI(e_anchor);
     RI(c_type); RI(c_e1); RI(c_e2); RI(c_cfg); RI(c_comp); RI(dh_c); RI(dh_cfg); RI(dh_joint); RI(dh_side);
-    RI(cf_cfg); RI(cf_in); RI(dh_lookup); RI(cu_off); RI(it_slot);
+    RI(cf_cfg); RI(cf_in); RI(dh_lookup); RI(cu_off); RI(it_slot); RI(pair4);
     RD(j_pre); RD(jcoef); RD(b_C); RD(b_inertia); RD(e_off); RD(c_dist); RD(c_tol); RD(damp);
 #undef RI
 #undef RD
