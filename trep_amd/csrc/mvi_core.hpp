@@ -89,6 +89,14 @@ TG_HD void bracket(const double *a, const double *b, double *r) {
     r[4] = a[5] * b[3] - a[3] * b[5];
     r[5] = a[3] * b[4] - a[4] * b[3];
 }
+// accumulate into LDS from several lanes at once
+TG_HD void lds_add(double *p, double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    *p += v;
+#endif
+}
 TG_HD double inner6(const double *I, const double *a, const double *b) {
     return I[0] * (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]) + I[1] * (a[3] * b[3]) + I[2] * (a[4] * b[4]) +
            I[3] * (a[5] * b[5]);
@@ -410,36 +418,32 @@ struct Core {
         TG_SYNC();
         TG_STAMP(7);
         const double qdt = 0.25 * dt, rdt = 1.0 / dt;
-        for (int b = 0; b < P.n_bodies; b++) {
-            const int p0 = P.b_pair_off[b], np = P.b_pair_off[b + 1] - p0;
+        // All (item,item) pairs of all bodies in one flat pass; several bodies contribute to the same
+        // matrix entry, so the accumulation uses LDS floating-point atomics (ds_add_f64).  One wavefront
+        // owns the trajectory and its LDS operations retire in order, so the summation order -- and with
+        // it the result -- is the same on every run.
+        if (on) TG_FOR(pp, P.n_npairs) {
+            const int *pw = P.pair4 + 4 * (size_t)pp;
+            const int ia = pw[0], ib = pw[1], ca = pw[2] & 0xFFFF, cb = pw[2] >> 16, b = pw[3];
             const double *I = P.b_inertia + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
-            if (on) TG_FOR(pp, np) {
-                const int *pw = P.pair4 + 4 * (size_t)(p0 + pp);   // {item a, item b, config a, config b}
-                const int ia = pw[0], ib = pw[1], ca = pw[2], cb = pw[3];
-                if (ca >= nd || cb >= nd) continue;
-                const double *Ja = S + P.o_J + 6 * ia, *Jb = S + P.o_J + 6 * ib;
-                const double *Wa = S + P.o_W + 6 * ia, *Wb = S + P.o_W + 6 * ib;
-                double t[6];
-                bracket(Wa, Jb, t);
-                // L_dqdq(a,b) (system.c:158-202) with -V_dqdq = m gam . (w_a x v_b)
-                double lqq = inner6(I, t, v) + inner6(I, Wa, Wb) +
-                             I[0] * (gam[0] * (Ja[4] * Jb[2] - Ja[5] * Jb[1]) + gam[1] * (Ja[5] * Jb[0] - Ja[3] * Jb[2]) +
-                                     gam[2] * (Ja[3] * Jb[1] - Ja[4] * Jb[0]));
-                const double mab = inner6(I, Ja, Jb);  // L_ddqddq (system.c:459-489)
-                const double sym = qdt * lqq - rdt * mab;
-                if (ia == ib) {
-                    A[ca * ld + ca] += sym;
-                } else {
-                    bracket(Ja, Jb, t);
-                    const double c_ab = inner6(I, t, v) + inner6(I, Ja, Wb);  // L_ddqdq(dq a, q b) (system.c:294-334)
-                    const double c_ba = inner6(I, Jb, Wa);                    // L_ddqdq(dq b, q a)
-                    const double skew = 0.5 * (c_ba - c_ab);
-                    A[ca * ld + cb] += sym + skew;
-                    A[cb * ld + ca] += sym - skew;
-                }
-            }
-            TG_SYNC();
+            const double *Ja = S + P.o_J + 6 * ia, *Jb = S + P.o_J + 6 * ib;
+            const double *Wa = S + P.o_W + 6 * ia, *Wb = S + P.o_W + 6 * ib;
+            double t[6];
+            bracket(Wa, Jb, t);
+            // L_dqdq(a,b) (system.c:158-202) with -V_dqdq = m gam . (w_a x v_b)
+            const double lqq = inner6(I, t, v) + inner6(I, Wa, Wb) +
+                               I[0] * (gam[0] * (Ja[4] * Jb[2] - Ja[5] * Jb[1]) + gam[1] * (Ja[5] * Jb[0] - Ja[3] * Jb[2]) +
+                                       gam[2] * (Ja[3] * Jb[1] - Ja[4] * Jb[0]));
+            const double mab = inner6(I, Ja, Jb);  // L_ddqddq (system.c:459-489)
+            const double sym = qdt * lqq - rdt * mab;
+            bracket(Ja, Jb, t);                    // zero when a == b
+            const double c_ab = inner6(I, t, v) + inner6(I, Ja, Wb);  // L_ddqdq(dq a, q b) (system.c:294-334)
+            const double c_ba = inner6(I, Jb, Wa);                    // L_ddqdq(dq b, q a)
+            const double skew = 0.5 * (c_ba - c_ab);                  // exactly 0 for a == b
+            lds_add(&A[ca * ld + cb], sym + skew);
+            if (ia != ib) lds_add(&A[cb * ld + ca], sym - skew);
         }
+        TG_SYNC();
         TG_STAMP(8);
     }
 

@@ -43,7 +43,8 @@ struct DevProg {
     const int *it_cfg;        // [n_items]
     const int *pair_a;        // [n_pairs] item index of the config nearer the root
     const int *pair_b;        // [n_pairs] item index of the config nearer the body (may equal pair_a)
-    const int *pair4;         // [n_pairs*4] {item a, item b, config a, config b}: one 16-byte load per pair
+    const int *pair4;         // [n_npairs*4] dynamic-dynamic pairs only: {item a, item b, config a | config b << 16, body}
+    int n_npairs;
     const int *cfg_item_off;  // [nq+1] CSR config -> items
     const int *cfg_items;     // [n_items]
     const int *it_slot;       // [n_items] position of the item in the config-sorted order (inverse of cfg_items)
@@ -241,9 +242,12 @@ inline HostProgram build_program(const tg_system_desc *d) {
             if (H.it_cfg[it] == c) H.cfg_items.push_back(it);
         H.cfg_item_off[c + 1] = (int)H.cfg_items.size();
     }
-    for (size_t n = 0; n < H.pair_a.size(); n++) {
+    for (size_t n = 0; n < H.pair_a.size(); n++) {   // the Newton matrix only needs dynamic-dynamic pairs
+        const int ca = H.it_cfg[H.pair_a[n]], cb = H.it_cfg[H.pair_b[n]];
+        if (ca >= nd || cb >= nd) continue;
+        if (ca >= 65536 || cb >= 32768) throw std::runtime_error("too many configs for the packed pair table");
         H.pair4.push_back(H.pair_a[n]); H.pair4.push_back(H.pair_b[n]);
-        H.pair4.push_back(H.it_cfg[H.pair_a[n]]); H.pair4.push_back(H.it_cfg[H.pair_b[n]]);
+        H.pair4.push_back(ca | (cb << 16)); H.pair4.push_back(H.it_body[H.pair_a[n]]);
     }
     H.it_slot.assign(nitems, 0);
     for (int n = 0; n < nitems; n++) H.it_slot[H.cfg_items[n]] = n;
@@ -293,6 +297,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.n_joints = nj; P.n_levels = n_levels; P.n_bodies = nb; P.n_items = nitems; P.n_pairs = (int)H.pair_a.size();
     P.n_endpoints = (int)H.e_anchor.size(); P.n_dh = (int)H.dh_c.size(); P.n_cf = (int)H.cf_cfg.size();
     P.n_cfgitems = (int)H.cfg_items.size();
+    P.n_npairs = (int)(H.pair4.size() / 4);
     P.grav[0] = P.grav[1] = P.grav[2] = 0.0;
     for (int i = 0; i < d->n_gravity; i++)
         for (int k = 0; k < 3; k++) P.grav[k] += d->gravity[3 * (size_t)i + k];
