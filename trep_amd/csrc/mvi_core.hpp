@@ -509,81 +509,189 @@ struct Core {
     }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-    // ---- Gauss-Jordan with one matrix ROW PER LANE held in registers (n <= TEAM, n <= NCOL) -----------
+    // ---- Gauss-Jordan on 4x4 REGISTER TILES (full-wave team, n <= 31) -----------------------------------
+    //      The augmented matrix [A | rhs] is cut into 4x4 tiles, one tile per lane (row block rb = lane/8,
+    //      column block cb = lane%8; 7x8 = 56 lanes for the puppet's 28x29).  Per pivot step: the pivot is a
+    //      single 32-bit wave max over (scaled magnitude | row); the lanes that own the pivot ROW publish
+    //      their 4 entries of it, the lanes that own pivot COLUMN k publish their 4 entries of it (two tiny
+    //      LDS vectors); every lane then updates its 16 entries in registers.  Rows never move (in-place
+    //      pivoting, same implicit-scaled rule as math-code.c:337-432).  ~4x fewer instructions per step
+    //      than the row-per-lane variant, which has to broadcast the whole pivot row lane by lane.
+    static __device__ __noinline__ bool gj_tiles(bool on, double *A_generic, int n, int ld, double *scal_generic, int lane) {
+        // the buffers are in LDS: tell the compiler, or a non-inlined function would use slow flat accesses
+        typedef __attribute__((address_space(3))) double lds_double;
+        typedef __attribute__((address_space(3))) int lds_int;
+        lds_double *A = (lds_double *)A_generic;
+        lds_double *scal = (lds_double *)scal_generic;
+        const int rb = lane >> 3, cb = lane & 7;
+        const int nrb = (n + 3) >> 2, ncb = (n + 4) >> 2;   // row blocks, column blocks (rhs = column n)
+        const bool mine = on && rb < nrb && cb < ncb;
+        // implicit scaling factors from the untouched matrix (LDS), one lane per row
+        if (on && lane < n) {
+            double s = -1.0;
+            for (int j = 0; j < n; j++) { const double a = fabs(A[lane * ld + j]); if (a > s) s = a; }
+            scal[lane] = 1.0 / s;
+        }
+        __syncthreads();
+        double t[4][4], sc[4];
+        bool used[4] = {false, false, false, false};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = 4 * rb + i;
+            sc[i] = (mine && row < n) ? scal[row] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int col = 4 * cb + c;
+                t[i][c] = (mine && row < n && col <= n) ? A[row * ld + col] : 0.0;
+            }
+        }
+        __syncthreads();
+        // the matrix now lives in registers: its LDS image becomes scratch
+        lds_double *prow = A, *pcol = A + 32, *diag = A + 64, *rhs = A + 96;
+        lds_int *pivrow = (lds_int *)(A + 128);
+        bool ok = true;
+        for (int kk = 0; kk < nrb; kk++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int k = 4 * kk + r;
+                if (k < n) {
+                    unsigned int key = 0;
+                    if (mine && cb == kk) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int row = 4 * rb + i;
+                            const float cand = (!used[i] && row < n) ? (float)fabs(t[i][r] * sc[i]) : 0.0f;
+                            const unsigned int ki = (__float_as_uint(cand) & ~0x1Fu) | (unsigned int)(31 - row);
+                            key = ki > key ? ki : key;
+                        }
+                    }
+                    key = __ockl_wfred_max_u32(key);
+                    const int piv = __builtin_amdgcn_readfirstlane(31 - (int)(key & 0x1Fu));
+                    const float best = __uint_as_float(key & ~0x1Fu);
+                    if (on && ok && !(best > 1.0e-20f)) ok = false;
+                    const int prb = piv >> 2, pi = piv & 3;
+                    if (mine && rb == prb) {   // publish my 4 entries of the pivot row
+#pragma unroll
+                        for (int c = 0; c < 4; c++)
+                            prow[4 * cb + c] = pi == 0 ? t[0][c] : (pi == 1 ? t[1][c] : (pi == 2 ? t[2][c] : t[3][c]));
+                        used[0] = used[0] || pi == 0; used[1] = used[1] || pi == 1;
+                        used[2] = used[2] || pi == 2; used[3] = used[3] || pi == 3;
+                    }
+                    if (mine && cb == kk) {    // publish my 4 entries of column k
+#pragma unroll
+                        for (int i = 0; i < 4; i++) pcol[4 * rb + i] = t[i][r];
+                    }
+                    __syncthreads();
+                    if (mine && ok) {
+                        const double pkk = prow[k];
+                        double rp = __builtin_amdgcn_rcp(pkk);
+                        rp = fma(rp, fma(-pkk, rp, 1.0), rp);
+                        rp = fma(rp, fma(-pkk, rp, 1.0), rp);
+                        double pr[4], l[4];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) pr[c] = prow[4 * cb + c];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) l[i] = (4 * rb + i == piv) ? 0.0 : pcol[4 * rb + i] * rp;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const bool upd = cb > kk || (cb == kk && c > r);   // only columns right of the pivot
+#pragma unroll
+                            for (int i = 0; i < 4; i++) t[i][c] = upd ? fma(-l[i], pr[c], t[i][c]) : t[i][c];
+                        }
+                        if (lane == 0) { diag[k] = pkk; pivrow[k] = piv; }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        // x_k = rhs(pivot row of k) / pivot_k, returned in the caller's layout A[k*ld + n]
+        const int ccb = n >> 2, cc = n & 3;
+        if (mine && cb == ccb) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                rhs[4 * rb + i] = cc == 0 ? t[i][0] : (cc == 1 ? t[i][1] : (cc == 2 ? t[i][2] : t[i][3]));
+        }
+        __syncthreads();
+        double x = 0.0;
+        if (on && ok && lane < n) x = rhs[pivrow[lane]] / diag[lane];
+        __syncthreads();
+        if (on && ok && lane < n) A[lane * ld + n] = x;
+        __syncthreads();
+        return ok;
+    }
+
+    // ---- Gauss-Jordan with one matrix ROW PER LANE held in registers (n <= N <= TEAM) ---------------------
     //      Same pivot rule as gauss_jordan() but pivoting "in place": rows never move, the lane that owns
     //      the pivot row of step k broadcasts it (v_readlane for a full-wave team, ds_bpermute otherwise)
-    //      and every other lane eliminates in registers.  No LDS traffic inside the k loop.
+    //      and every other lane eliminates in registers.  No LDS traffic inside the k loop.  N is the
+    //      matrix size rounded up to a multiple of 4 (identity padding), so every loop bound is a
+    //      compile-time constant and the body carries no guards.
     //      Reads [A | rhs(1 column)] from LDS, leaves x in A[i*ld + n] like gauss_jordan().
-    template <int NCOL>
-    __device__ bool gj_rows(bool on, double *A, int n, int ld) {
-        double row[NCOL], rhs = 0.0, scale = 0.0, diag = 1.0;
+    template <int N>
+    static __device__ __noinline__ bool gj_rows(bool on, double *A_generic, int n, int ld, int lane) {
+        typedef __attribute__((address_space(3))) double lds_double;
+        lds_double *A = (lds_double *)A_generic;
+        double row[N], rhs = 0.0, scale = 0.0, diag = 1.0;
         int mycol = -1;
-        const bool mine = on && lane < n;
+        const bool mine = on && lane < N;
 #pragma unroll
-        for (int j = 0; j < NCOL; j++) row[j] = (mine && j < n) ? A[lane * ld + j] : 0.0;
+        for (int j = 0; j < N; j++)
+            row[j] = (mine && lane < n && j < n) ? A[lane * ld + j] : ((mine && lane >= n && j == lane) ? 1.0 : 0.0);
         if (mine) {
-            rhs = A[lane * ld + n];
+            rhs = lane < n ? A[lane * ld + n] : 0.0;
             double s = -1.0;
 #pragma unroll
-            for (int j = 0; j < NCOL; j++) { const double a = fabs(row[j]); if (j < n && a > s) s = a; }
+            for (int j = 0; j < N; j++) { const double a = fabs(row[j]); s = a > s ? a : s; }
             scale = 1.0 / s;
         }
         bool ok = true;
 #pragma unroll
-        for (int k = 0; k < NCOL; k++) {
-            if (k < n) {
-                // arg-max of |a_ik| * scale_i over the rows not yet used as pivots: the magnitude's bit
-                // pattern is monotone, so one u64 max carries the lane index in its 6 low bits.
-                // (the magnitude only ranks candidates, so single precision is plenty: one 32-bit wave max
-                // carries the lane index in the 6 low mantissa bits)
-                const float cand = (mine && mycol < 0) ? (float)fabs(row[k] * scale) : 0.0f;
-                unsigned int key = (__float_as_uint(cand) & ~0x3Fu) | (unsigned int)(63 - (lane & 63));
-                if (TEAM == 64) {
-                    key = __ockl_wfred_max_u32(key);
-                } else {
+        for (int k = 0; k < N; k++) {
+            // arg-max of |a_ik| * scale_i over the rows not yet used as pivots; the magnitude only ranks
+            // candidates, so single precision is plenty: one 32-bit wave max carries the lane index in the
+            // 6 low mantissa bits
+            const float cand = (mine && mycol < 0) ? (float)fabs(row[k] * scale) : 0.0f;
+            unsigned int key = (__float_as_uint(cand) & ~0x3Fu) | (unsigned int)(63 - (lane & 63));
+            if (TEAM == 64) {
+                key = __ockl_wfred_max_u32(key);
+            } else {
 #pragma unroll
-                    for (int m = TEAM / 2; m >= 1; m >>= 1) {
-                        const unsigned int o = __shfl_xor(key, m, TEAM);
-                        key = o > key ? o : key;
-                    }
+                for (int m = TEAM / 2; m >= 1; m >>= 1) {
+                    const unsigned int o = __shfl_xor(key, m, TEAM);
+                    key = o > key ? o : key;
                 }
-                int piv = 63 - (int)(key & 0x3Fu);
-                const float best = __uint_as_float(key & ~0x3Fu);
-                if (TEAM != 64) piv = (piv & (TEAM - 1));
-                if (on && ok && !(best > 1.0e-20f)) ok = false;
-                const bool go = on && ok;
-                // broadcast the pivot row (columns k..n-1 and the rhs)
-                const int src = (TEAM == 64) ? __builtin_amdgcn_readfirstlane(piv) : piv;
-                auto bcast = [&](double v) -> double {
-                    if (TEAM == 64) {
-                        const long long b = __double_as_longlong(v);
-                        const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFLL), src);
-                        const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
-                        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-                    }
-                    return __shfl(v, src, TEAM);
-                };
-                const double pkk = bcast(row[k]);
-                const double prhs = bcast(rhs);
-                const bool is_piv = mine && (lane & (TEAM - 1)) == src;
-                // 1/pivot: hardware seed + two Newton steps (the multipliers need not be correctly rounded)
-                double rp = __builtin_amdgcn_rcp(pkk);
-                rp = fma(rp, fma(-pkk, rp, 1.0), rp);
-                rp = fma(rp, fma(-pkk, rp, 1.0), rp);
-                const double l = (go && mine && !is_piv) ? row[k] * rp : 0.0;
-#pragma unroll
-                for (int j = k + 1; j < NCOL; j++) {
-                    if (j < n) {
-                        const double pkj = bcast(row[j]);
-                        row[j] -= l * pkj;
-                    }
-                }
-                rhs -= l * prhs;
-                if (go && is_piv) { mycol = k; diag = row[k]; }
             }
+            int piv = 63 - (int)(key & 0x3Fu);
+            const float best = __uint_as_float(key & ~0x3Fu);
+            if (TEAM != 64) piv = (piv & (TEAM - 1));
+            if (on && ok && !(best > 1.0e-20f)) ok = false;
+            const bool go = on && ok;
+            // broadcast the pivot row (columns k..N-1 and the rhs)
+            const int src = (TEAM == 64) ? __builtin_amdgcn_readfirstlane(piv) : piv;
+            auto bcast = [&](double v) -> double {
+                if (TEAM == 64) {
+                    const long long b = __double_as_longlong(v);
+                    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFLL), src);
+                    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+                    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+                }
+                return __shfl(v, src, TEAM);
+            };
+            const double pkk = bcast(row[k]);
+            const double prhs = bcast(rhs);
+            const bool is_piv = mine && (lane & (TEAM - 1)) == src;
+            // 1/pivot: hardware seed + two Newton steps (the multipliers need not be correctly rounded)
+            double rp = __builtin_amdgcn_rcp(pkk);
+            rp = fma(rp, fma(-pkk, rp, 1.0), rp);
+            rp = fma(rp, fma(-pkk, rp, 1.0), rp);
+            const double l = (go && mine && !is_piv) ? row[k] * rp : 0.0;
+#pragma unroll
+            for (int j = k + 1; j < N; j++) row[j] = fma(-l, bcast(row[j]), row[j]);
+            rhs = fma(-l, prhs, rhs);
+            if (go && is_piv) { mycol = k; diag = row[k]; }
         }
-        if (mine && ok && mycol >= 0) A[mycol * ld + n] = rhs / diag;
-        TG_SYNC();
+        if (mine && ok && mycol >= 0 && mycol < n) A[mycol * ld + n] = rhs / diag;
+        __syncthreads();
         return ok;
     }
 #endif
@@ -1200,9 +1308,20 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
             core.newton_matrix(!done);
             bool ok;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_GJROWS)
-            constexpr int NCOL = TEAM == 64 ? 32 : (TEAM > 1 ? TEAM : 2);
-            if (TEAM > 1 && P.nf <= TEAM && P.nf <= NCOL) ok = core.template gj_rows<NCOL>(!done, S + P.o_Df, P.nf, P.df_ld);
-            else
+            const int nb4 = (P.nf + 3) >> 2;   // matrix size in blocks of 4 rows
+            if (TEAM >= 4 && 4 * nb4 <= TEAM && nb4 <= 8) {
+                double *Ad = S + P.o_Df;
+                switch (nb4) {
+                case 1: ok = Core<TEAM>::template gj_rows<4>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 2: ok = Core<TEAM>::template gj_rows<(TEAM >= 8 ? 8 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 3: ok = Core<TEAM>::template gj_rows<(TEAM >= 12 ? 12 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 4: ok = Core<TEAM>::template gj_rows<(TEAM >= 16 ? 16 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 5: ok = Core<TEAM>::template gj_rows<(TEAM >= 20 ? 20 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 6: ok = Core<TEAM>::template gj_rows<(TEAM >= 24 ? 24 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 7: ok = Core<TEAM>::template gj_rows<(TEAM >= 28 ? 28 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                default: ok = Core<TEAM>::template gj_rows<(TEAM >= 32 ? 32 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                }
+            } else
 #endif
                 ok = core.gauss_jordan(!done, S + P.o_Df, P.nf, 1, P.df_ld, S + P.o_scal);
             if (!done && !ok) { done = true; failed = true; status = TG_SINGULAR; }
