@@ -147,27 +147,24 @@ struct Core {
     // host-made coefficient rows (branch-free: entry = A + B*s1 + C*s0); (3) level by level
     // G_j = G_parent(j) * local_j in place, one lane per (joint, column): a lane reads only its own
     // column of the local transform, so there is no intra-joint hazard for any team size.
-    // Per-lane sweep schedule kept in registers for the whole kernel: for every level, the LDS offsets of
-    // the lane's own joint and of that joint's parent (the mapping lane -> (joint, column) never changes).
-    static constexpr int MAXL = 16;
-    int sweep_sched[MAXL];
+    // Level schedule of the sweep in LDS (written once per kernel): for level L and slot s < 16 the packed
+    // word (offset of the slot's joint | offset of its parent << 16), or -1.  Keeps the level loop rolled and
+    // free of global-memory look-ups.
     bool sweep_fast = false;
     TG_HD void init_sweep_schedule() {
-        sweep_fast = P.n_levels <= MAXL;
-#pragma unroll
-        for (int L = 0; L < MAXL; L++) {
+        sweep_fast = P.sched_ok != 0;
+        if (!sweep_fast) return;
+        int *sched = (int *)(S + P.o_sched);
+        TG_FOR(idx, 16 * P.n_levels) {
+            const int L = idx >> 4, slot = idx & 15;
             int w = -1;
-            if (L >= 1 && L < P.n_levels) {
+            if (L >= 1) {
                 const int j0 = P.level_off[L], cnt = P.level_off[L + 1] - j0;
-                if (4 * cnt > TEAM) sweep_fast = false;
-                if (lane < 4 * cnt) {
-                    const int j = j0 + (lane >> 2);
-                    w = (12 * j) | ((12 * P.j_parent[j]) << 16);
-                }
+                if (slot < cnt) w = (12 * (j0 + slot)) | ((12 * P.j_parent[j0 + slot]) << 16);
             }
-            sweep_sched[L] = w;
+            sched[idx] = w;
         }
-        if (12 * P.n_joints >= 65536) sweep_fast = false;
+        TG_SYNC();
     }
 
     TG_HD void pose_sweep(bool on, int sel) {
@@ -199,21 +196,22 @@ struct Core {
             }
         }
         TG_SYNC();
-        const int c = lane & 3;
-        const double t3 = (c == 3) ? 1.0 : 0.0;
         if (sweep_fast) {
-#pragma unroll
-            for (int L = 1; L < MAXL; L++) {
-                if (L >= P.n_levels) break;
-                const int w = sweep_sched[L];
-                if (on && w >= 0) {
-                    double *gj = G + (w & 0xFFFF);
-                    const double *gp = G + (w >> 16);
-                    const double m0 = gj[c], m1 = gj[4 + c], m2 = gj[8 + c];
-                    const double v0 = gp[0] * m0 + gp[1] * m1 + gp[2] * m2 + t3 * gp[3];
-                    const double v1 = gp[4] * m0 + gp[5] * m1 + gp[6] * m2 + t3 * gp[7];
-                    const double v2 = gp[8] * m0 + gp[9] * m1 + gp[10] * m2 + t3 * gp[11];
-                    gj[c] = v0; gj[4 + c] = v1; gj[8 + c] = v2;
+            const int *sched = (const int *)(S + P.o_sched);
+            for (int L = 1; L < P.n_levels; L++) {
+                if (on) TG_FOR(idx, 64) {          // 16 slots x 4 columns
+                    const int w = sched[16 * L + (idx >> 2)];
+                    if (w >= 0) {
+                        const int cc = idx & 3;
+                        const double u3 = (cc == 3) ? 1.0 : 0.0;
+                        double *gj = G + (w & 0xFFFF);
+                        const double *gp = G + (w >> 16);
+                        const double m0 = gj[cc], m1 = gj[4 + cc], m2 = gj[8 + cc];
+                        const double v0 = gp[0] * m0 + gp[1] * m1 + gp[2] * m2 + u3 * gp[3];
+                        const double v1 = gp[4] * m0 + gp[5] * m1 + gp[6] * m2 + u3 * gp[7];
+                        const double v2 = gp[8] * m0 + gp[9] * m1 + gp[10] * m2 + u3 * gp[11];
+                        gj[cc] = v0; gj[4 + cc] = v1; gj[8 + cc] = v2;
+                    }
                 }
                 TG_SYNC();
             }

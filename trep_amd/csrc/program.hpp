@@ -58,7 +58,8 @@ struct DevProg {
     const int *cf_cfg, *cf_in;
     // LDS layout (offsets in doubles from the team's base)
     int o_q1, o_q2, o_p1, o_lam, o_u, o_dq, o_f, o_sc, o_G, o_gB, o_pE, o_J, o_W, o_vB, o_gam, o_Ldq, o_Lddq,
-        o_Dh1, o_Dh2, o_Df, o_scal, o_misc, o_dqi, o_nu;
+        o_Dh1, o_Dh2, o_Df, o_scal, o_misc, o_dqi, o_nu, o_sched;
+    int sched_ok;             // 1: every level has <= TEAM/4... (checked on the device) and <= 16 joints: LDS level schedule usable
     int df_ld;
     int dh_ld;                // 0: the step kernel keeps Dh1/Dh2 compact (one value per dh item)
     int lds_per_team;
@@ -311,6 +312,10 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.o_J = take(6 * nitems); P.o_W = take(6 * nitems); P.o_vB = take(6 * nb); P.o_gam = take(3 * nb);
     P.o_Ldq = take(nd); P.o_Lddq = take(nd); P.o_Dh1 = take(P.n_dh); P.o_Dh2 = take(P.n_dh);  // compact: one value per (constraint, dependent config) item
     P.o_scal = take(P.nf); P.o_misc = take(2); P.o_nu = take(P.nu + P.nk);
+    // level schedule of the pose sweep: 16 packed words (own offset | parent offset << 16) per level, as ints
+    P.sched_ok = (12 * nj < 65536) ? 1 : 0;
+    for (int L = 1; L < n_levels; L++) if (H.level_off[L + 1] - H.level_off[L] > 16) P.sched_ok = 0;
+    P.o_sched = take(P.sched_ok ? (16 * n_levels + 1) / 2 : 0);
     P.df_ld = (P.nf + 1) | 1;  // augmented with the right-hand side; odd stride avoids LDS bank conflicts
     const int shared0 = off;
     P.o_Df = take(P.nf * P.df_ld);
