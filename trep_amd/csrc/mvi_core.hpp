@@ -30,7 +30,15 @@
 #define TG_SYNC() ((void)0)
 #endif
 
-#define TG_FOR(idx, n) for (int idx = lane; idx < (n); idx += TEAM)
+// The lane index is laundered through an empty asm at the head of every phase loop: the optimiser then
+// cannot hoist lane-derived addresses and table look-ups of ALL phases out of the Newton / step loops
+// (which made it keep hundreds of loop-invariant values alive and spill).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ int tg_opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+#else
+inline int tg_opaque(int x) { return x; }
+#endif
+#define TG_FOR(idx, n) for (int idx = tg_opaque(lane); idx < (n); idx += TEAM)
 
 #if defined(__HIPCC__)
 // ROCm device-library wavefront reduction (DPP based); declared in hip/amd_detail only behind an opt-in macro
@@ -171,7 +179,11 @@ struct Core {
         double *sc = S + P.o_sc, *G = S + P.o_G;
         if (on) TG_FOR(j, P.n_joints) {
             const double x = qval(sel, P.j_cfg[j]);
+#ifndef TG_X_NOSINCOS
             if (P.j_kind[j] >= TG_RX) tg_sincos(x, &sc[2 * j], &sc[2 * j + 1]);
+#else
+            if (P.j_kind[j] >= TG_RX) { sc[2 * j] = x; sc[2 * j + 1] = 1.0 - x; }
+#endif
             else { sc[2 * j] = x; sc[2 * j + 1] = 0.0; }
         }
         TG_SYNC();
@@ -420,6 +432,7 @@ struct Core {
         // matrix entry, so the accumulation uses LDS floating-point atomics (ds_add_f64).  One wavefront
         // owns the trajectory and its LDS operations retire in order, so the summation order -- and with
         // it the result -- is the same on every run.
+#ifndef TG_X_NOPAIRS
         if (on) TG_FOR(pp, P.n_npairs) {
             const int *pw = P.pair4 + 4 * (size_t)pp;
             const int ia = pw[0], ib = pw[1], ca = pw[2] & 0xFFFF, cb = pw[2] >> 16, b = pw[3];
@@ -441,6 +454,7 @@ struct Core {
             lds_add(&A[ca * ld + cb], sym + skew);
             if (ia != ib) lds_add(&A[cb * ld + ca], sym - skew);
         }
+#endif
         TG_SYNC();
         TG_STAMP(8);
     }
