@@ -1313,7 +1313,8 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
 #endif
             if (!done && iterations > A.max_iterations) { done = true; failed = true; status = TG_NOT_CONVERGED; }
 #if defined(__HIP_DEVICE_COMPILE__)
-            if (__syncthreads_and(done ? 1 : 0)) break;
+            // the workgroup is one wavefront: a wave vote replaces the LDS-based block-wide AND
+            if (TEAM == 64 ? done : (__all(done ? 1 : 0) != 0)) break;
 #else
             if (done) break;
 #endif
