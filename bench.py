@@ -32,6 +32,24 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X datasheet, vector fp64 (secondary figur
 REFERENCE_TREP_STEPS_PER_S = 345.0  # reference _trep, 1 Xeon 2.1 GHz core, Puppet-40
 
 
+def build_secondary(args, rank):
+    """BASELINE configs[1] (pend-on-cart) and configs[4] (scissor lift): parity-test systems, benchmarked as
+    secondary lines with the synthetic inputs of SURVEY.md §8(d)."""
+    from trep_amd import systems
+    B, N, dt = args.batch, args.rollout_steps, 0.01
+    if args.system == "cart":
+        system = systems.pend_on_cart()
+        rng = np.random.default_rng(20250 + 2 + 1000 * rank)
+        Q0 = np.stack([rng.uniform(-1, 1, B), rng.uniform(-np.pi, np.pi, B)], 1)
+        U = rng.standard_normal((B, N, 1)) * 2.0
+        return system, Q0, U, None, dt
+    system = systems.scissor_lift(4)
+    rng = np.random.default_rng(20250 + 5 + 1000 * rank)
+    th = rng.uniform(0.03 * np.pi, 0.12 * np.pi, B)
+    Q0 = np.array([systems.scissor_q(system, t) for t in th])
+    return system, Q0, None, None, dt
+
+
 def build_workload(args, rank):
     from trep_amd import systems
     system = systems.puppet()
@@ -95,6 +113,8 @@ def main():
     ap.add_argument("--rollout-steps", type=int, default=200, help="DEL steps per trajectory per pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-x", action="store_true", help="do not write the state trajectory X to HBM")
+    ap.add_argument("--system", choices=["puppet", "cart", "scissor"], default="puppet",
+                    help="puppet = the BASELINE metric; cart / scissor = secondary lines")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank (self-test)")
     args = ap.parse_args()
 
@@ -114,11 +134,17 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     import trep_amd
 
-    system, Q0, K, dt = build_workload(args, rank)
+    U = None
+    if args.system == "puppet":
+        system, Q0, K, dt = build_workload(args, rank)
+    else:
+        system, Q0, U, K, dt = build_secondary(args, rank)
+        args.no_cpu_baseline = True
     B, N = args.batch, args.rollout_steps
     mvi = trep_amd.BatchMidpointVI(system, B, device=local_rank)
     nX, nU, nc = mvi.nX, mvi.nU, mvi.nc
-    K_dev = mvi.device_array(K)
+    K_dev = mvi.device_array(K) if K is not None else None
+    U_dev = mvi.device_array(U) if U is not None else None
     gather = None
     if use_dist:
         X_t = None if args.no_x else torch.empty((B, N + 1, nX), dtype=torch.float64, device="cuda")
@@ -133,7 +159,7 @@ def main():
 
     def one_pass():
         mvi.restore()   # device-to-device: every pass integrates the same 200-step window
-        mvi.rollout_device(N, dt, None, K_dev, X_dev)
+        mvi.rollout_device(N, dt, U_dev, K_dev, X_dev)
         if use_dist:
             mvi.synchronize()
             if X_t is not None:
@@ -175,11 +201,13 @@ def main():
         achieved = algo_bytes / avg_kernel_s / 1e9
         traffic = pmc_traffic(B, N) if world == 1 else None
         out = {
-            "metric": "DEL-steps/sec x batch (puppet ~40-DOF, fp64)",
+            "metric": "DEL-steps/sec x batch (%s, fp64)" % ("puppet ~40-DOF" if args.system == "puppet" else args.system),
             "value": value, "unit": "DEL-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Puppet(string_constraints=True) nq=40 nd=22 nk=18 nc=6, batch=%d rollouts per GPU x %d DEL steps, dt=0.01" % (B, N),
+            "config": {"workload": ("Puppet(string_constraints=True) nq=40 nd=22 nk=18 nc=6" if args.system == "puppet" else
+                                    ("pend-on-cart nd=2 nu=1" if args.system == "cart" else "scissor-4 nd=9 nc=8")) +
+                                   ", batch=%d rollouts per GPU x %d DEL steps, dt=0.01" % (B, N),
                        "global_batch": world * B, "rollout_steps": N, "parallelism": "batch-shard x%d" % world,
                        "team": mvi.info()["team"], "lds_bytes_per_trajectory": mvi.info()["lds_bytes_per_trajectory"],
                        "newton_iterations_per_step": total_iters / float(B * N), "failed_trajectories": n_failed,
