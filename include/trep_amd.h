@@ -206,6 +206,82 @@ int tg_batch_set_stream(tg_batch *b, void *hip_stream);
  * number of launches and the sum of their durations in milliseconds. */
 int tg_batch_timing(tg_batch *b, int32_t reset, int32_t *n_launches, double *total_ms);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Device-side discopt primitives: the direct caller of the MidpointVI path.
+ * Everything below takes DEVICE pointers (tg_device_alloc) and is asynchronous; tg_device_synchronize or any
+ * tg_memcpy_* waits.  "Seeds" are independent optimisation problems of the same system and horizon N:
+ *   X [S][N+1][nX], U [S][N][nU], A [S][N][nX][nX], B [S][N][nX][nU], K [S][N][nU][nX] ...
+ * `select_dev` (optional, int32 [n_problems]) restricts a call to a subset of the seeds.
+ * ------------------------------------------------------------------------------------------------------ */
+
+/* DSystem.set(X[s][k], U[s][k], k, xk_hint = X[s][k+1]) for every (s, k) at once (reference
+ * trep/discopt/dsystem.py:229-251 as used by linearize_trajectory, :406-423, and calc_newton_model,
+ * doptimizer.py:333-335): the batch must hold seeds*horizon trajectories, trajectory t = s*horizon + k;
+ * lambda1 is reset to 0 and the dynamic part of X[s][k+1] is the Newton start, like the reference. */
+int tg_batch_set_from_trajectories(tg_batch *b, int32_t seeds, int32_t horizon, double t0, double dt,
+                                   const double *X_dev, const double *U_dev, int32_t max_iterations);
+/* initialize_from_state(t, Q, p) (midpointvi.py:145-153) with trajectory b's (Q, p) read from the head of the
+ * DSystem state vector X_dev[b*row_stride_doubles ...] = [Q; p; v]; lambda1 <- 0. */
+int tg_batch_initialize_from_state_device(tg_batch *b, double t, const double *X_dev, uint64_t row_stride_doubles);
+/* DSystem.fdx / fdu of every solved step (dsystem.py:284-317): A_dev [batch][nX][nX], B_dev [batch][nX][nU],
+ * written directly by the first-derivative kernel (the twelve reference-layout arrays are not produced). */
+int tg_batch_linearize(tg_batch *b, double *A_dev, double *B_dev);
+/* tg_batch_deriv2_contract with device-resident z [batch][nX] and hz [batch][R][R]. */
+int tg_batch_deriv2_contract_device(tg_batch *b, const double *z_dev, double *hz_dev);
+
+/* Time-varying LQ problem (reference trep/discopt/dlqr.py:41-81; with q_dev = r_dev = NULL and no curvature it
+ * is solve_tv_lqr, dlqr.py:9-38).  Weights: Q_k = Q_dev[s*Q_seed_stride + k*Q_step_stride + ...] (strides in
+ * doubles, 0 = shared), terminal Qf, R_k likewise.  If hz_dev != NULL the z-contracted second derivative of the
+ * dynamics HZ [S][N][hz_R][hz_R] (variables ordered x-part[hz_nx], u-part[nU]) is added on the fly:
+ * Q_k += HZ[:hz_nx,:hz_nx], S_k = HZ[:hz_nx, hz_nx:], R_k += HZ[hz_nx:, hz_nx:]  (the Newton model of
+ * doptimizer.py:319-345).  Outputs: K [S][N][nU][nX], C [S][N][nU] (affine only), P0 [S][nX][nX], b0 [S][nX],
+ * status [S] (TG_OK / TG_SINGULAR). */
+typedef struct tg_lq_problem {
+    int32_t n_problems, horizon, nX, nU;
+    const int32_t *select_dev;
+    const double *A_dev, *B_dev;
+    const double *Q_dev;  int64_t Q_seed_stride, Q_step_stride;
+    const double *Qf_dev; int64_t Qf_seed_stride;
+    const double *R_dev;  int64_t R_seed_stride, R_step_stride;
+    const double *hz_dev; int32_t hz_R, hz_nx;
+    const double *q_dev, *r_dev;          /* [S][N+1][nX], [S][N][nU] or both NULL */
+    double *K_dev, *C_dev, *P0_dev, *b0_dev;
+    int32_t *status_dev;
+} tg_lq_problem;
+int tg_tv_lq(int32_t device, const tg_lq_problem *problem);
+
+/* Backward adjoint of the Newton model (doptimizer.py:319-345): Z[s][k] = z_{k+1}, the vector the second
+ * derivatives of step k are contracted with; z_k = q_k - K_k' r_k + (A_k - B_k K_k)' z_{k+1}, z_N = q_N. */
+int tg_adjoint_sweep(int32_t device, int32_t n_problems, int32_t horizon, int32_t nX, int32_t nU,
+                     const int32_t *select_dev, const double *A_dev, const double *B_dev, const double *K_dev,
+                     const double *q_dev, const double *r_dev, double *Z_dev);
+/* Descent direction from the LQ solution (doptimizer.py:391-402): dU_k = -K_k dX_k - C_k,
+ * dX_{k+1} = A_k dX_k + B_k dU_k, dX_0 = 0; dcost[s] = sum_k q_k.dX_k + r_k.dU_k (calc_dcost, :262-270). */
+int tg_tangent_rollout(int32_t device, int32_t n_problems, int32_t horizon, int32_t nX, int32_t nU,
+                       const int32_t *select_dev, const double *A_dev, const double *B_dev, const double *K_dev,
+                       const double *C_dev, const double *q_dev, const double *r_dev, double *dX_dev, double *dU_dev,
+                       double *dcost_dev);
+/* DCost (trep/discopt/dcost.py:5-118): cost[t] = sum_k 1/2 (x-xd)'Q(x-xd) + 1/2 (u-ud)'R(u-ud) + terminal
+ * with Qf, for n_trajectories trajectories of which `group` consecutive ones share the reference of one seed
+ * (Xd [n/group][N+1][nX], Ud [n/group][N][nU]). */
+int tg_quadratic_cost(int32_t device, int32_t n_trajectories, int32_t group, int32_t horizon, int32_t nX, int32_t nU,
+                      const double *X_dev, const double *U_dev, const double *Xd_dev, const double *Ud_dev,
+                      const double *Q_dev, const double *R_dev, const double *Qf_dev, double *cost_dev);
+/* Its gradients q [S][N+1][nX] (row N = terminal), r [S][N][nU] (dcost.py:62-84). */
+int tg_quadratic_cost_gradients(int32_t device, int32_t n_problems, int32_t horizon, int32_t nX, int32_t nU,
+                                const int32_t *select_dev, const double *X_dev, const double *U_dev,
+                                const double *Xd_dev, const double *Ud_dev, const double *Q_dev, const double *R_dev,
+                                const double *Qf_dev, double *q_dev, double *r_dev);
+/* Armijo candidates (doptimizer.py:436-446): row c = i*n_lambdas + m of bX/bU is X[s_i] + lambda_m dX[s_i]. */
+int tg_armijo_candidates(int32_t device, int32_t n_problems, int32_t n_lambdas, int32_t horizon, int32_t nX,
+                         int32_t nU, const int32_t *select_dev, const double *lambdas_dev, const double *X_dev,
+                         const double *U_dev, const double *dX_dev, const double *dU_dev, double *bX_dev,
+                         double *bU_dev);
+/* dst[dst_rows[i]] = src[src_rows[i]], rows of row_doubles doubles (NULL index = identity). */
+int tg_copy_rows(int32_t device, int32_t n_rows, uint64_t row_doubles, const int32_t *dst_rows_dev,
+                 const int32_t *src_rows_dev, const double *src_dev, double *dst_dev);
+int tg_device_synchronize(int32_t device);
+
 #ifdef __cplusplus
 }
 #endif

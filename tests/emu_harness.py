@@ -21,7 +21,7 @@ class RunArgs(ctypes.Structure):
                 ("tolerance", ctypes.c_double),
                 ("q1", _D), ("q2", _D), ("p1", _D), ("p2", _D), ("lam", _D), ("u1", _D),
                 ("U", _D), ("K", _D), ("q2_hint", _D), ("lam_hint", _D), ("Kproj", _D), ("bX", _D), ("bU", _D), ("Uout", _D), ("group_size", ctypes.c_int), ("X", _D), ("f_out", _D),
-                ("d1", _D * 12), ("z", _D), ("hz", _D), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p)]
+                ("d1", _D * 12), ("A_out", _D), ("B_out", _D), ("z", _D), ("hz", _D), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p)]
 
 
 def lib():
@@ -107,6 +107,16 @@ class EmuBatch(object):
                 a.d1[4 * oi + ki] = arr.ctypes.data_as(_D) if arr.size else ctypes.cast(0, _D)
         self.L.emu_run(self.h, ctypes.byref(a))
         return outs
+
+    def linearize(self):
+        """DSystem.fdx / fdu of the last solved step, written by the deriv1 kernel in A/B form."""
+        nU = self.nu + self.nk
+        A = np.full((self.B, self.nX, self.nX), np.nan)
+        Bm = np.full((self.B, self.nX, nU), np.nan)
+        a = self._args(3)
+        a.A_out, a.B_out = _p(A), _p(Bm)
+        self.L.emu_run(self.h, ctypes.byref(a))
+        return A, Bm
 
     def rollout_closed_loop(self, n_steps, dt, Kproj, bX, bU, group_size=1):
         """U_k = bU_k - Kproj_k (X_k - bX_k) in-kernel; returns (X [B][N+1][nX], U [B][N][nU])."""

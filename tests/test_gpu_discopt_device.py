@@ -1,0 +1,269 @@
+"""Device-side discopt primitives (tg_tv_lq, tg_adjoint_sweep, tg_tangent_rollout, tg_quadratic_cost*, ...) and
+the BatchDOptimizer built on them, against the host numpy implementation of the same formulas
+(trep_amd.discopt.dlqr / DCost / DOptimizer, which tests/test_discopt.py pins to a DOptimizer trace recorded
+from the reference).  Tolerance: 1e-9 relative for the Riccati outputs, 1e-10 for the rest."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from common import golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _pool():
+    from trep_amd.discopt.batch_doptimizer import _DevicePool
+    return _DevicePool(0)
+
+
+def _random_problem(rng, S, N, nX, nU, nxh):
+    A = 0.2 * rng.standard_normal((S, N, nX, nX)) / np.sqrt(nX) + 0.9 * np.eye(nX)
+    B = rng.standard_normal((S, N, nX, nU)) / np.sqrt(nX)
+    Q = rng.standard_normal((nX, nX)); Q = Q.dot(Q.T) / nX + np.eye(nX)
+    Qf = 2.0 * Q
+    R = rng.standard_normal((nU, nU)); R = R.dot(R.T) / nU + np.eye(nU)
+    q = rng.standard_normal((S, N + 1, nX))
+    r = rng.standard_normal((S, N, nU))
+    Rz = nxh + nU
+    hz = 0.05 * rng.standard_normal((S, N, Rz, Rz))
+    hz = hz + np.swapaxes(hz, 2, 3)
+    return A, B, Q, Qf, R, q, r, hz
+
+
+def _host_lq(A, B, Q, Qf, R, q, r, hz, nxh):
+    """numpy reference: dlqr.solve_tv_lq with the Newton-model weights assembled like DSystem._split_hz."""
+    from trep_amd.discopt import dlqr
+    N, nX, nU = A.shape[0], A.shape[1], B.shape[2]
+
+    def Qk(k):
+        if k == N:
+            return Qf
+        M = Q.copy()
+        if hz is not None:
+            M[:nxh, :nxh] += hz[k][:nxh, :nxh]
+        return M
+
+    def Sk(k):
+        M = np.zeros((nX, nU))
+        if hz is not None:
+            M[:nxh, :] = hz[k][:nxh, nxh:]
+        return M
+
+    def Rk(k):
+        return R + (hz[k][nxh:, nxh:] if hz is not None else 0.0)
+
+    if q is None:
+        assert hz is None
+        K, P = dlqr.solve_tv_lqr(A, B, Qk, Rk)
+        return np.array(K), None, P, None
+    K, C, P, b = dlqr.solve_tv_lq(A, B, q, r, Qk, Sk, Rk)
+    return np.array(K), np.array(C), P, b
+
+
+@pytest.mark.parametrize("nX,nU,nxh,N,S", [(4, 1, 4, 40, 3), (18, 3, 12, 25, 2), (80, 18, 62, 30, 3), (90, 10, 70, 8, 1)])
+def test_tv_lq_matches_numpy(nX, nU, nxh, N, S):
+    from trep_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(100 + nX)
+    A, B, Q, Qf, R, q, r, hz = _random_problem(rng, S, N, nX, nU, nxh)
+    pool = _pool()
+    try:
+        dA, dB, dQ, dQf, dR = pool.upload(A), pool.upload(B), pool.upload(Q), pool.upload(Qf), pool.upload(R)
+        dq, dr, dhz = pool.upload(q), pool.upload(r), pool.upload(hz)
+        for mode in ("lqr", "lq", "newton", "subset"):
+            dK, dC = pool.empty((S, N, nU, nX)).set(np.full((S, N, nU, nX), np.nan)), pool.empty((S, N, nU))
+            dP, db, dst = pool.empty((S, nX, nX)), pool.empty((S, nX)), pool.empty((S,), np.int32)
+            p = _lib.LqProblem()
+            p.n_problems, p.horizon, p.nX, p.nU = S, N, nX, nU
+            p.A_dev, p.B_dev = dA.ptr, dB.ptr
+            p.Q_dev, p.Qf_dev, p.R_dev = dQ.ptr, dQf.ptr, dR.ptr
+            p.K_dev, p.C_dev, p.P0_dev, p.b0_dev, p.status_dev = dK.ptr, dC.ptr, dP.ptr, db.ptr, dst.ptr
+            seeds = list(range(S))
+            if mode != "lqr":
+                p.q_dev, p.r_dev = dq.ptr, dr.ptr
+            if mode in ("newton", "subset"):
+                p.hz_dev, p.hz_R, p.hz_nx = dhz.ptr, nxh + nU, nxh
+            if mode == "subset":
+                seeds = [S - 1]
+                sel = pool.upload(np.array(seeds, dtype=np.int32), np.int32)
+                p.select_dev, p.n_problems = sel.ptr, 1
+            _lib.check(L.tg_tv_lq(0, ctypes.byref(p)))
+            K, C, P0, b0, st = dK.get(), dC.get(), dP.get(), db.get(), dst.get()
+            for s in range(S):
+                if s not in seeds:
+                    assert np.isnan(K[s]).all()       # untouched
+                    continue
+                assert st[s] == 0
+                Kh, Ch, Ph, bh = _host_lq(A[s], B[s], Q, Qf, R, None if mode == "lqr" else q[s], None if mode == "lqr" else r[s],
+                                          hz[s] if mode in ("newton", "subset") else None, nxh)
+                assert relerr(K[s], Kh) < 1e-9, (mode, s, relerr(K[s], Kh))
+                assert relerr(P0[s], Ph) < 1e-9, (mode, s)
+                if mode != "lqr":
+                    assert relerr(C[s], Ch) < 1e-9 and relerr(b0[s], bh) < 1e-9, (mode, s)
+    finally:
+        pool.close()
+
+
+def test_sweeps_and_cost_match_numpy():
+    from trep_amd import _lib
+    from trep_amd.discopt import DCost
+    L = _lib.lib()
+    rng = np.random.default_rng(7)
+    S, N, nX, nU, M = 3, 37, 80, 18, 4
+    A, B, Q, Qf, R, q, r, _ = _random_problem(rng, S, N, nX, nU, 62)
+    K = rng.standard_normal((S, N, nU, nX)) * 0.1
+    C = rng.standard_normal((S, N, nU))
+    X, U = rng.standard_normal((S, N + 1, nX)), rng.standard_normal((S, N, nU))
+    Xd, Ud = rng.standard_normal((S, N + 1, nX)), rng.standard_normal((S, N, nU))
+    pool = _pool()
+    try:
+        d = dict((k, pool.upload(v)) for k, v in dict(A=A, B=B, Q=Q, Qf=Qf, R=R, q=q, r=r, K=K, C=C, X=X, U=U, Xd=Xd, Ud=Ud).items())
+        # adjoint (doptimizer.py:319-345)
+        dZ = pool.empty((S, N, nX))
+        _lib.check(L.tg_adjoint_sweep(0, S, N, nX, nU, None, d["A"].ptr, d["B"].ptr, d["K"].ptr, d["q"].ptr, d["r"].ptr, dZ.ptr))
+        Z = dZ.get()
+        for s in range(S):
+            z = q[s, -1]
+            for k in range(N - 1, -1, -1):
+                assert relerr(Z[s, k], z) < 1e-11, (s, k)
+                z = q[s, k] - r[s, k].dot(K[s, k]) + z.dot(A[s, k] - B[s, k].dot(K[s, k]))
+        # tangent rollout + directional derivative (doptimizer.py:391-402, 262-270)
+        ddX, ddU, ddc = pool.empty((S, N + 1, nX)), pool.empty((S, N, nU)), pool.empty((S,))
+        _lib.check(L.tg_tangent_rollout(0, S, N, nX, nU, None, d["A"].ptr, d["B"].ptr, d["K"].ptr, d["C"].ptr, d["q"].ptr, d["r"].ptr,
+                                        ddX.ptr, ddU.ptr, ddc.ptr))
+        dX, dU, dc = ddX.get(), ddU.get(), ddc.get()
+        for s in range(S):
+            x = np.zeros(nX)
+            for k in range(N):
+                assert relerr(dX[s, k], x) < 1e-11
+                u = -K[s, k].dot(x) - C[s, k]
+                assert relerr(dU[s, k], u) < 1e-11
+                x = A[s, k].dot(x) + B[s, k].dot(u)
+            assert relerr(dX[s, N], x) < 1e-11
+            ref = float(np.sum(q[s] * dX[s]) + np.sum(r[s] * dU[s]))
+            assert abs(dc[s] - ref) < 1e-10 * max(1.0, abs(ref))
+        # cost and gradients (dcost.py)
+        dcost, dq2, dr2 = pool.empty((S,)), pool.empty((S, N + 1, nX)), pool.empty((S, N, nU))
+        _lib.check(L.tg_quadratic_cost(0, S, 1, N, nX, nU, d["X"].ptr, d["U"].ptr, d["Xd"].ptr, d["Ud"].ptr, d["Q"].ptr, d["R"].ptr,
+                                       d["Qf"].ptr, dcost.ptr))
+        _lib.check(L.tg_quadratic_cost_gradients(0, S, N, nX, nU, None, d["X"].ptr, d["U"].ptr, d["Xd"].ptr, d["Ud"].ptr, d["Q"].ptr,
+                                                 d["R"].ptr, d["Qf"].ptr, dq2.ptr, dr2.ptr))
+        cost, gq, gr = dcost.get(), dq2.get(), dr2.get()
+        for s in range(S):
+            c = DCost(Xd[s], Ud[s], Q, R, Qf)
+            assert abs(cost[s] - c.total(X[s], U[s])) < 1e-11 * abs(c.total(X[s], U[s]))
+            hq, hr = c.gradients(X[s], U[s])
+            assert relerr(gq[s], hq) < 1e-12 and relerr(gr[s], hr) < 1e-12
+        # candidates and grouped cost, row copies
+        lam = 0.7 ** np.arange(M)
+        dlam, dbX, dbU = pool.upload(lam), pool.empty((S * M, N + 1, nX)), pool.empty((S * M, N, nU))
+        _lib.check(L.tg_armijo_candidates(0, S, M, N, nX, nU, None, dlam.ptr, d["X"].ptr, d["U"].ptr, ddX.ptr, ddU.ptr, dbX.ptr, dbU.ptr))
+        bX, bU = dbX.get().reshape(S, M, N + 1, nX), dbU.get().reshape(S, M, N, nU)
+        assert relerr(bX, X[:, None] + lam[None, :, None, None] * dX[:, None]) < 1e-14   # the device contracts to an fma
+        assert relerr(bU, U[:, None] + lam[None, :, None, None] * dU[:, None]) < 1e-14
+        dcc = pool.empty((S * M,))
+        _lib.check(L.tg_quadratic_cost(0, S * M, M, N, nX, nU, dbX.ptr, dbU.ptr, d["Xd"].ptr, d["Ud"].ptr, d["Q"].ptr, d["R"].ptr,
+                                       d["Qf"].ptr, dcc.ptr))
+        cc = dcc.get().reshape(S, M)
+        for s in range(S):
+            c = DCost(Xd[s], Ud[s], Q, R, Qf)
+            assert relerr(cc[s], c.total(bX[s], bU[s])) < 1e-11
+        rows_a = pool.upload(np.array([2, 0], dtype=np.int32), np.int32)
+        rows_b = pool.upload(np.array([2 * M + 1, 0 * M + 3], dtype=np.int32), np.int32)
+        _lib.check(L.tg_copy_rows(0, 2, (N + 1) * nX, rows_a.ptr, rows_b.ptr, dbX.ptr, d["X"].ptr))
+        X2 = d["X"].get()
+        assert np.array_equal(X2[2], bX[2, 1]) and np.array_equal(X2[0], bX[0, 3]) and np.array_equal(X2[1], X[1])
+    finally:
+        pool.close()
+
+
+def _cart_problem(S):
+    """Perturbed copies of the pend-on-cart problem of the reference trace (tests/golden/discopt_pend_on_cart.npz)."""
+    from trep_amd import systems
+    g = golden("discopt_pend_on_cart")
+    system = systems.pend_on_cart(torque_force=True)
+    rng = np.random.default_rng(5)
+    Xd = np.repeat(g["Xd"][None], S, axis=0)
+    Ud = np.repeat(g["Ud"][None], S, axis=0)
+    Ud[1:] += 0.05 * rng.standard_normal(Ud[1:].shape)
+    return g, system, Xd, Ud
+
+
+def _sequential_steps(dsys, Xd, Ud, Q, R, X0, U0, methods):
+    from trep_amd import discopt
+    out = []
+    for s in range(len(Xd)):
+        opt = discopt.DOptimizer(dsys, discopt.DCost(Xd[s], Ud[s], Q, R))
+        X, U = X0[s].copy(), U0[s].copy()
+        rec = []
+        for i, m in enumerate(methods):
+            r = opt.step(i, X, U, m)
+            rec.append((opt.monitor.cost_history[i], opt.monitor.dcost_history[i], r.cost1, r.nX.copy(), r.nU.copy()))
+            X, U = r.nX, r.nU
+        out.append(rec)
+    return out
+
+
+def test_batch_optimizer_matches_sequential_cart():
+    import trep_amd
+    from trep_amd import discopt
+    S = 5
+    g, system, Xd, Ud = _cart_problem(S)
+    t = g["t"]
+    dsys = discopt.DSystem(trep_amd.MidpointVI(system), t)
+    X0 = np.repeat(g["X0"][None], S, axis=0)
+    U0 = np.repeat(g["U0"][None], S, axis=0)
+    methods = ["quasi", "quasi", "newton", "newton"]
+    ref = _sequential_steps(dsys, Xd, Ud, g["Q"], g["R"], X0, U0, methods)
+    opt = discopt.BatchDOptimizer(dsys, Xd, Ud, g["Q"], g["R"], armijo_chunk=3)
+    try:
+        opt.set_trajectories(X0, U0)
+        for i, m in enumerate(methods):
+            r = opt.step(m)
+            X, U = opt.get_trajectories()
+            for s in range(S):
+                c0, dc0, c1, Xr, Ur = ref[s][i]
+                assert abs(r.cost0[s] - c0) < 1e-9 * max(1.0, abs(c0)), (i, s)
+                assert abs(r.dcost0[s] - dc0) < 1e-7 * max(1.0, abs(dc0)), (i, s, r.dcost0[s], dc0)
+                assert abs(r.cost1[s] - c1) < 1e-8 * max(1.0, abs(c1)), (i, s, r.cost1[s], c1)
+                assert relerr(X[s], Xr) < 1e-7 and relerr(U[s], Ur) < 1e-7, (i, s, relerr(X[s], Xr))
+    finally:
+        opt.close()
+
+
+def test_batch_optimizer_matches_sequential_puppet():
+    import trep_amd
+    from trep_amd import systems, discopt
+    S, N, dt = 3, 40, 0.01
+    system = systems.puppet()
+    nd = system.nQd
+    t = dt * np.arange(N + 1)
+    Q0 = systems.puppet_initial_conditions(system, S, seed=77)
+    K_move = systems.puppet_string_schedule(system, Q0[:, nd:], N, dt)
+    K_still = np.repeat(Q0[:, None, nd:], N, axis=1)
+    sim = trep_amd.BatchMidpointVI(system, S)
+    sim.initialize_from_state(0.0, Q0, np.zeros((S, nd)))
+    Xd = sim.rollout(N, dt, None, K_move)
+    sim.initialize_from_state(0.0, Q0, np.zeros((S, nd)))
+    Xi = sim.rollout(N, dt, None, K_still)
+    sim.close()
+    dsys = discopt.DSystem(trep_amd.MidpointVI(system), t)
+    wq = [100.0] * nd + [1.0] * system.nQk + [1.0] * nd + [1.0] * system.nQk
+    Qc, Rc = np.diag(wq), np.diag([0.1] * system.nQk)
+    methods = ["quasi", "newton"]
+    ref = _sequential_steps(dsys, Xd, K_move, Qc, Rc, Xi, K_still, methods)
+    opt = discopt.BatchDOptimizer(dsys, Xd, K_move, Qc, Rc)
+    try:
+        opt.set_trajectories(Xi, K_still)
+        for i, m in enumerate(methods):
+            r = opt.step(m)
+            X, U = opt.get_trajectories()
+            for s in range(S):
+                c0, dc0, c1, Xr, Ur = ref[s][i]
+                assert abs(r.cost0[s] - c0) < 1e-9 * max(1.0, abs(c0)), (i, s)
+                assert abs(r.dcost0[s] - dc0) < 1e-7 * max(1.0, abs(dc0)), (i, s, r.dcost0[s], dc0)
+                assert abs(r.cost1[s] - c1) < 1e-8 * max(1.0, abs(c1)), (i, s, r.cost1[s], c1)
+                assert relerr(X[s], Xr) < 1e-7 and relerr(U[s], Ur) < 1e-7, (i, s, relerr(X[s], Xr))
+    finally:
+        opt.close()

@@ -75,6 +75,19 @@ def test_emulated_first_derivatives_match_reference(name):
         out = e.deriv1()
         for n in D1:
             assert relerr(out[n][0], g["%sd1_%d_%s" % (prefix, s_, n)]) < 1e-9, (name, s_, n)
+        # the same kernel writing DSystem.fdx / fdu directly (dsystem.py:284-317)
+        A, B = e.linearize()
+        nq, nd, nk, nu = d.n_configs, d.n_dyn, d.n_kin, d.n_inputs
+        nX, nU, nqd = nq + nd + nk, nu + nk, nq + nd
+        Ar, Br = np.zeros((nX, nX)), np.zeros((nX, nU))
+        Ar[:nd, :nq], Ar[:nd, nq:nqd] = out["q2_dq1"][0].T, out["q2_dp1"][0].T
+        Ar[nq:nqd, :nq], Ar[nq:nqd, nq:nqd] = out["p2_dq1"][0].T, out["p2_dp1"][0].T
+        Ar[nqd:, nd:nq] = -np.eye(nk) / DT
+        Br[:nd, :nu], Br[:nd, nu:] = out["q2_du1"][0].T, out["q2_dk2"][0].T
+        Br[nq:nqd, :nu], Br[nq:nqd, nu:] = out["p2_du1"][0].T, out["p2_dk2"][0].T
+        Br[nd:nq, nu:] = np.eye(nk)
+        Br[nqd:, nu:] = np.eye(nk) / DT
+        assert relerr(A[0], Ar) < 1e-13 and relerr(B[0], Br) < 1e-13, (name, s_)   # 1/dt from t2 - t1
 
 
 def oracle_hz(o, d, z):

@@ -23,6 +23,24 @@ F_Q1, F_Q2, F_P1, F_P2, F_U1, F_LAMBDA1 = 0, 1, 2, 3, 4, 5
 F_D1_BASE = 10  # TG_F_Q2_DQ1; order q2_d{q1,p1,u1,k2}, p2_d*, l1_d*
 OK, NOT_CONVERGED, SINGULAR = 0, 1, 2
 
+
+
+class LqProblem(ctypes.Structure):
+    """tg_lq_problem of include/trep_amd.h (device pointers as integers)."""
+    _fields_ = [("n_problems", ctypes.c_int32), ("horizon", ctypes.c_int32), ("nX", ctypes.c_int32), ("nU", ctypes.c_int32),
+                ("select_dev", ctypes.c_void_p),
+                ("A_dev", ctypes.c_void_p), ("B_dev", ctypes.c_void_p),
+                ("Q_dev", ctypes.c_void_p), ("Q_seed_stride", ctypes.c_int64), ("Q_step_stride", ctypes.c_int64),
+                ("Qf_dev", ctypes.c_void_p), ("Qf_seed_stride", ctypes.c_int64),
+                ("R_dev", ctypes.c_void_p), ("R_seed_stride", ctypes.c_int64), ("R_step_stride", ctypes.c_int64),
+                ("hz_dev", ctypes.c_void_p), ("hz_R", ctypes.c_int32), ("hz_nx", ctypes.c_int32),
+                ("q_dev", ctypes.c_void_p), ("r_dev", ctypes.c_void_p),
+                ("K_dev", ctypes.c_void_p), ("C_dev", ctypes.c_void_p), ("P0_dev", ctypes.c_void_p), ("b0_dev", ctypes.c_void_p),
+                ("status_dev", ctypes.c_void_p)]
+
+
+_vp, _i32, _f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_double
+
 _SIGNATURES = {
     "tg_version": (ctypes.c_char_p, []),
     "tg_last_error": (ctypes.c_char_p, []),
@@ -62,6 +80,19 @@ _SIGNATURES = {
     "tg_batch_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
     "tg_batch_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "tg_batch_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _c_ip, _c_dp]),
+    # device-side discopt primitives
+    "tg_batch_set_from_trajectories": (ctypes.c_int, [_vp, _i32, _i32, _f64, _f64, _vp, _vp, _i32]),
+    "tg_batch_linearize": (ctypes.c_int, [_vp, _vp, _vp]),
+    "tg_batch_initialize_from_state_device": (ctypes.c_int, [_vp, _f64, _vp, ctypes.c_uint64]),
+    "tg_batch_deriv2_contract_device": (ctypes.c_int, [_vp, _vp, _vp]),
+    "tg_tv_lq": (ctypes.c_int, [_i32, ctypes.POINTER(LqProblem)]),
+    "tg_adjoint_sweep": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tg_tangent_rollout": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tg_quadratic_cost": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tg_quadratic_cost_gradients": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tg_armijo_candidates": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tg_copy_rows": (ctypes.c_int, [_i32, _i32, ctypes.c_uint64, _vp, _vp, _vp, _vp]),
+    "tg_device_synchronize": (ctypes.c_int, [_i32]),
 }
 
 

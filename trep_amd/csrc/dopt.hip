@@ -1,0 +1,585 @@
+// dopt.hip -- device-side primitives of the discrete trajectory optimiser (the direct caller of the
+// MidpointVI path: reference trep/discopt/dlqr.py:9-81, dcost.py:5-118, doptimizer.py:249-506).
+//
+// One optimisation problem ("seed") = one trajectory X [N+1][nX], U [N][nU] with its linearisation
+// A [N][nX][nX], B [N][nX][nU].  The seed axis is the parallel axis: every kernel below runs one
+// workgroup per seed (the k axis of a Riccati / adjoint / tangent sweep is inherently serial), so
+// S seeds occupy S CUs; the dense nX x nX work of one seed is spread over the 256 lanes of its
+// workgroup with the matrices resident in LDS (P, A_k: 2 x 51 KB for the 40-DOF puppet, nX = 80).
+// MI355X has the same fp64 rate on the vector and the matrix pipes and the operands here are
+// 80 x 80 at most, so the products are register-tiled VALU code (4x4 tiles from LDS), not MFMA.
+//
+// All entry points take DEVICE pointers and run on the device's default stream, which is ordered
+// with the (blocking) streams of the tg_batch objects.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/trep_amd.h"
+
+namespace tg_detail {
+int fail(int code, const std::string &msg);
+}
+
+namespace {
+
+using tg_detail::fail;
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(TG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int LQ_T = 256;  // threads per workgroup of the sweep kernels
+
+__host__ __device__ inline int round_up(int n, int m) { return (n + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------------
+// Time-varying LQ backward sweep (dlqr.py:41-81; with q = r = S = 0 it is solve_tv_lqr, :9-38):
+//   gamma = R_k + B'PB,  Kpart = B'PA + S_k',  [C_k | K_k] = gamma^-1 [B'b + r_k | Kpart],
+//   b <- q_k - K'r_k + (A' - K'B') b,  P <- Q_k + A'PA - Kpart'K,  P <- (P + P')/2.
+// Model weights: Q_k = Qc(+k stride) [+ HZ_k[0:nxh,0:nxh]], S_k = HZ_k[0:nxh, nxh:], R_k = Rc [+ HZ_k[nxh:,nxh:]]
+// where HZ_k is the z-contracted second derivative of the dynamics (tg_batch_deriv2_contract_device),
+// i.e. the Newton model of doptimizer.py:319-345 is assembled on the fly.
+//
+// P (later P A) and A_k live in LDS with the leading dimension padded to a multiple of the tile size TS
+// (padding stays zero); every thread owns ONE TS x TS tile of the nX x nX products in registers, so the
+// 256 threads cover nX <= 16*TS exactly (TS = 5 for the 40-DOF puppet: 16 x 16 tiles of 5 x 5).
+// A_{k-1}, B_{k-1} are prefetched into registers (RI x CI / PB values per thread) while step k computes.
+// ------------------------------------------------------------------------------------------------------
+template <int TS, int RI, int CI, int PB>
+__global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
+    extern __shared__ double lds[];
+    __shared__ int s_piv, s_sing;
+    const int tid = threadIdx.x;
+    const int s = a.select_dev ? a.select_dev[blockIdx.x] : blockIdx.x;
+    const int nX = a.nX, nU = a.nU, N = a.horizon;
+    const int ldx = round_up(nX, TS), nT = ldx / TS, ntiles = nT * nT;
+    const int ldw = nU + 1 + ldx;  // [gamma | B'b + r | Kpart]
+    double *Pm = lds, *Am = Pm + ldx * ldx, *Bm = Am + ldx * ldx, *BtP = Bm + ldx * nU, *Kp = BtP + nU * ldx;
+    double *G = Kp + nU * ldx, *bv = G + nU * ldw, *bn = bv + ldx, *wv = bn + ldx, *rv = wv + nU, *fac = rv + nU;
+    const int lds_doubles = (int)(fac + nU - lds);
+    for (int i = tid; i < lds_doubles; i += LQ_T) lds[i] = 0.0;
+    if (tid == 0) s_sing = 0;
+    __syncthreads();
+
+    const size_t sN = (size_t)s * N;
+    const bool affine = a.q_dev != nullptr;
+    const int nxh = a.hz_nx, hzR = a.hz_R;
+    // terminal condition P_N = Qf, b_N = q_N
+    {
+        const double *Qf = a.Qf_dev + (size_t)s * a.Qf_seed_stride;
+        for (int e = tid; e < nX * nX; e += LQ_T) Pm[(e / nX) * ldx + e % nX] = Qf[e];
+        if (affine) for (int i = tid; i < nX; i += LQ_T) bv[i] = a.q_dev[(sN + s + N) * nX + i];
+    }
+    // prefetch mapping: 8 row groups x 32 columns per pass (256-byte row segments)
+    const int pr0 = tid >> 5, pc0 = tid & 31;
+    double preA[RI * CI], preB[PB];
+    auto prefetch = [&](int k) {
+        const double *Ak = a.A_dev + (sN + k) * (size_t)nX * nX, *Bk = a.B_dev + (sN + k) * (size_t)nX * nU;
+#pragma unroll
+        for (int ri = 0; ri < RI; ri++)
+#pragma unroll
+            for (int ci = 0; ci < CI; ci++) {
+                const int r = pr0 + 8 * ri, c = pc0 + 32 * ci;
+                if (r < nX && c < nX) preA[ri * CI + ci] = Ak[r * nX + c];
+            }
+#pragma unroll
+        for (int i = 0; i < PB; i++) { const int e = tid + i * LQ_T; if (e < nX * nU) preB[i] = Bk[e]; }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int ri = 0; ri < RI; ri++)
+#pragma unroll
+            for (int ci = 0; ci < CI; ci++) {
+                const int r = pr0 + 8 * ri, c = pc0 + 32 * ci;
+                if (r < nX && c < nX) Am[r * ldx + c] = preA[ri * CI + ci];
+            }
+#pragma unroll
+        for (int i = 0; i < PB; i++) { const int e = tid + i * LQ_T; if (e < nX * nU) Bm[e] = preB[i]; }
+    };
+    prefetch(N - 1);
+    commit();
+    __syncthreads();
+
+    const bool has_tile = tid < ntiles;
+    const int i0 = TS * (tid / nT), j0 = TS * (tid % nT);
+    double acc[TS * TS];
+    for (int k = N - 1; k >= 0; k--) {
+        if (k > 0) prefetch(k - 1);
+        const double *hz = a.hz_dev ? a.hz_dev + (sN + k) * (size_t)hzR * hzR : nullptr;
+        // ---- phase 1: PA tile (registers), B'P, B'b ----------------------------------------------------
+        if (has_tile) {
+#pragma unroll
+            for (int e = 0; e < TS * TS; e++) acc[e] = 0.0;
+            for (int m = 0; m < nX; m++) {
+                double pv[TS], av[TS];
+#pragma unroll
+                for (int i = 0; i < TS; i++) pv[i] = Pm[(i0 + i) * ldx + m];
+#pragma unroll
+                for (int j = 0; j < TS; j++) av[j] = Am[m * ldx + j0 + j];
+#pragma unroll
+                for (int i = 0; i < TS; i++)
+#pragma unroll
+                    for (int j = 0; j < TS; j++) acc[TS * i + j] += pv[i] * av[j];
+            }
+        }
+        for (int o = tid; o < nU * nT; o += LQ_T) {  // B'P, 1 x TS tiles
+            const int u = o / nT, c0 = TS * (o % nT);
+            double c[TS];
+#pragma unroll
+            for (int j = 0; j < TS; j++) c[j] = 0.0;
+            for (int i = 0; i < nX; i++) {
+                const double bb = Bm[i * nU + u];
+#pragma unroll
+                for (int j = 0; j < TS; j++) c[j] += bb * Pm[i * ldx + c0 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < TS; j++) BtP[u * ldx + c0 + j] = c[j];
+        }
+        if (affine && tid < nU) {
+            double w = 0.0;
+            for (int i = 0; i < nX; i++) w += Bm[i * nU + tid] * bv[i];
+            wv[tid] = w;
+            rv[tid] = a.r_dev[(sN + k) * nU + tid];
+        }
+        __syncthreads();
+        // ---- phase 2: PA -> LDS (over P), gamma, Kpart = (B'P) A + S' ------------------------------------
+        if (has_tile) {
+#pragma unroll
+            for (int i = 0; i < TS; i++)
+#pragma unroll
+                for (int j = 0; j < TS; j++) Pm[(i0 + i) * ldx + j0 + j] = acc[TS * i + j];
+        }
+        for (int o = tid; o < nU * nU; o += LQ_T) {
+            const int u = o / nU, v = o % nU;
+            double g = a.R_dev[(size_t)s * a.R_seed_stride + (size_t)k * a.R_step_stride + o];
+            if (hz) g += hz[(size_t)(nxh + u) * hzR + nxh + v];
+            for (int j = 0; j < nX; j++) g += BtP[u * ldx + j] * Bm[j * nU + v];
+            G[u * ldw + v] = g;
+        }
+        if (tid < nU) G[tid * ldw + nU] = affine ? wv[tid] + rv[tid] : 0.0;
+        for (int o = tid; o < nU * nT; o += LQ_T) {
+            const int u = o / nT, c0 = TS * (o % nT);
+            double c[TS];
+#pragma unroll
+            for (int j = 0; j < TS; j++) c[j] = (hz && c0 + j < nxh) ? hz[(size_t)(c0 + j) * hzR + nxh + u] : 0.0;
+            for (int i = 0; i < nX; i++) {
+                const double bp = BtP[u * ldx + i];
+#pragma unroll
+                for (int j = 0; j < TS; j++) c[j] += bp * Am[i * ldx + c0 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < TS; j++) { Kp[u * ldx + c0 + j] = c[j]; G[u * ldw + nU + 1 + c0 + j] = c[j]; }
+        }
+        __syncthreads();
+        // ---- phase 3: [C | K] = gamma^-1 [.|.]: Gauss-Jordan with partial pivoting (LAPACK getrf pivot rule) ---
+        for (int p = 0; p < nU; p++) {
+            if (tid == 0) {
+                int best = p; double bm = fabs(G[p * ldw + p]);
+                for (int i = p + 1; i < nU; i++) { const double m = fabs(G[i * ldw + p]); if (m > bm) { bm = m; best = i; } }
+                s_piv = best;
+                if (!(bm > 0.0)) s_sing = 1;
+            }
+            __syncthreads();
+            const int pr = s_piv;
+            if (pr != p) for (int c = p + tid; c < ldw; c += LQ_T) { const double t_ = G[p * ldw + c]; G[p * ldw + c] = G[pr * ldw + c]; G[pr * ldw + c] = t_; }
+            __syncthreads();
+            const double inv = 1.0 / G[p * ldw + p];
+            if (tid < nU) fac[tid] = G[tid * ldw + p];
+            __syncthreads();
+            for (int c = p + 1 + tid; c < ldw; c += LQ_T) G[p * ldw + c] *= inv;
+            __syncthreads();
+            const int wcols = ldw - p - 1;
+            for (int o = tid; o < nU * wcols; o += LQ_T) {
+                const int i = o / wcols, c = p + 1 + o % wcols;
+                if (i != p) G[i * ldw + c] -= fac[i] * G[p * ldw + c];
+            }
+            __syncthreads();
+        }
+        // ---- phase 4: outputs K_k, C_k; new P tile (registers), new b ----------------------------------------
+        {
+            double *Ko = a.K_dev + (sN + k) * (size_t)nU * nX;
+            for (int o = tid; o < nU * nX; o += LQ_T) Ko[o] = G[(o / nX) * ldw + nU + 1 + o % nX];
+            if (a.C_dev && tid < nU) a.C_dev[(sN + k) * nU + tid] = G[tid * ldw + nU];
+        }
+        if (has_tile) {
+            const double *Qk = a.Q_dev + (size_t)s * a.Q_seed_stride + (size_t)k * a.Q_step_stride;
+#pragma unroll
+            for (int i = 0; i < TS; i++)
+#pragma unroll
+                for (int j = 0; j < TS; j++) {
+                    const int r = i0 + i, c = j0 + j;
+                    double q0 = (r < nX && c < nX) ? Qk[(size_t)r * nX + c] : 0.0;
+                    if (hz && r < nxh && c < nxh) q0 += hz[(size_t)r * hzR + c];
+                    acc[TS * i + j] = q0;
+                }
+            for (int m = 0; m < nX; m++) {  // + A' (PA)
+                double av[TS], pv[TS];
+#pragma unroll
+                for (int i = 0; i < TS; i++) av[i] = Am[m * ldx + i0 + i];
+#pragma unroll
+                for (int j = 0; j < TS; j++) pv[j] = Pm[m * ldx + j0 + j];
+#pragma unroll
+                for (int i = 0; i < TS; i++)
+#pragma unroll
+                    for (int j = 0; j < TS; j++) acc[TS * i + j] += av[i] * pv[j];
+            }
+            for (int u = 0; u < nU; u++) {  // - Kpart' K
+                double kv[TS], gv[TS];
+#pragma unroll
+                for (int i = 0; i < TS; i++) kv[i] = Kp[u * ldx + i0 + i];
+#pragma unroll
+                for (int j = 0; j < TS; j++) gv[j] = G[u * ldw + nU + 1 + j0 + j];
+#pragma unroll
+                for (int i = 0; i < TS; i++)
+#pragma unroll
+                    for (int j = 0; j < TS; j++) acc[TS * i + j] -= kv[i] * gv[j];
+            }
+        }
+        if (affine) for (int i = tid; i < nX; i += LQ_T) {
+            double v = a.q_dev[(sN + s + k) * nX + i];
+            for (int m = 0; m < nX; m++) v += Am[m * ldx + i] * bv[m];
+            for (int u = 0; u < nU; u++) v -= G[u * ldw + nU + 1 + i] * (rv[u] + wv[u]);
+            bn[i] = v;
+        }
+        __syncthreads();
+        // ---- phase 5: P <- new tile, b <- new b, next A, B into LDS ---------------------------------------------
+        if (has_tile) {
+#pragma unroll
+            for (int i = 0; i < TS; i++)
+#pragma unroll
+                for (int j = 0; j < TS; j++) Pm[(i0 + i) * ldx + j0 + j] = acc[TS * i + j];
+        }
+        if (affine) for (int i = tid; i < nX; i += LQ_T) bv[i] = bn[i];
+        if (k > 0) commit();
+        __syncthreads();
+        // ---- phase 6: P <- (P + P')/2, one thread per unordered pair --------------------------------------------
+        for (int e = tid; e < nX * nX; e += LQ_T) {
+            const int i = e / nX, j = e % nX;
+            if (i < j) {
+                const double v = 0.5 * (Pm[i * ldx + j] + Pm[j * ldx + i]);
+                Pm[i * ldx + j] = v; Pm[j * ldx + i] = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (a.P0_dev) for (int e = tid; e < nX * nX; e += LQ_T) a.P0_dev[(size_t)s * nX * nX + e] = Pm[(e / nX) * ldx + e % nX];
+    if (a.b0_dev && affine) for (int i = tid; i < nX; i += LQ_T) a.b0_dev[(size_t)s * nX + i] = bv[i];
+    if (a.status_dev && tid == 0) a.status_dev[s] = s_sing ? TG_SINGULAR : TG_OK;
+}
+
+size_t lq_lds_bytes(int nX, int nU, int ts) {
+    const int ldx = round_up(nX, ts), ldw = nU + 1 + ldx;
+    return sizeof(double) * ((size_t)2 * ldx * ldx + (size_t)ldx * nU + 2 * (size_t)nU * ldx + (size_t)nU * ldw + 2 * ldx + 3 * nU);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Matrix-vector sweeps along k (one workgroup per seed, A_k / B_k staged in LDS with a padded row stride).
+// ------------------------------------------------------------------------------------------------------
+constexpr int SW_T = 256;
+
+__device__ inline void stage_ab(const double *Ak, const double *Bk, double *Am, double *Bm, int nX, int nU, int lda, int tid) {
+    for (int e = tid; e < nX * nX; e += SW_T) Am[(e / nX) * lda + e % nX] = Ak[e];
+    for (int e = tid; e < nX * nU; e += SW_T) Bm[e] = Bk[e];
+}
+
+// Backward adjoint of doptimizer.py:319-345: Z_k = z_{k+1} (the vector the second derivatives of step k are
+// contracted with), z_k = q_k - K_k' r_k + (A_k - B_k K_k)' z_{k+1}, z_N = q_N.
+__global__ __launch_bounds__(SW_T) void k_adjoint(int N, int nX, int nU, const int *sel, const double *A, const double *B,
+                                                  const double *K, const double *q, const double *r, double *Z) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, s = sel ? sel[blockIdx.x] : blockIdx.x;
+    const int lda = nX | 1;
+    double *Am = lds, *Bm = Am + nX * lda, *Km = Bm + nX * nU, *z = Km + nU * nX, *zn = z + nX, *w = zn + nX;
+    const size_t sN = (size_t)s * N;
+    for (int i = tid; i < nX; i += SW_T) z[i] = q[(sN + s + N) * nX + i];
+    __syncthreads();
+    for (int k = N - 1; k >= 0; k--) {
+        stage_ab(A + (sN + k) * (size_t)nX * nX, B + (sN + k) * (size_t)nX * nU, Am, Bm, nX, nU, lda, tid);
+        for (int e = tid; e < nU * nX; e += SW_T) Km[e] = K[(sN + k) * (size_t)nU * nX + e];
+        for (int i = tid; i < nX; i += SW_T) Z[(sN + k) * nX + i] = z[i];
+        __syncthreads();
+        if (tid < nU) {  // w = r_k + B' z
+            double v = r[(sN + k) * nU + tid];
+            for (int i = 0; i < nX; i++) v += Bm[i * nU + tid] * z[i];
+            w[tid] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < nX; i += SW_T) {
+            double v = q[(sN + s + k) * nX + i];
+            for (int m = 0; m < nX; m++) v += Am[m * lda + i] * z[m];
+            for (int u = 0; u < nU; u++) v -= Km[u * nX + i] * w[u];
+            zn[i] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < nX; i += SW_T) z[i] = zn[i];
+        __syncthreads();
+    }
+}
+
+// Forward tangent rollout of doptimizer.py:391-402: dU_k = -K_k dX_k - C_k, dX_{k+1} = A_k dX_k + B_k dU_k,
+// dX_0 = 0; also dcost = sum_k q_k.dX_k + r_k.dU_k (calc_dcost, :262-270).
+__global__ __launch_bounds__(SW_T) void k_tangent(int N, int nX, int nU, const int *sel, const double *A, const double *B,
+                                                  const double *K, const double *C, const double *q, const double *r,
+                                                  double *dX, double *dU, double *dcost) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, s = sel ? sel[blockIdx.x] : blockIdx.x;
+    const int lda = nX | 1;
+    double *Am = lds, *Bm = Am + nX * lda, *Km = Bm + nX * nU, *x = Km + nU * lda, *xn = x + nX, *u = xn + nX, *red = u + nU;
+    const size_t sN = (size_t)s * N;
+    for (int i = tid; i < nX; i += SW_T) { x[i] = 0.0; dX[(sN + s) * nX + i] = 0.0; }
+    double part = 0.0;
+    __syncthreads();
+    for (int k = 0; k < N; k++) {
+        stage_ab(A + (sN + k) * (size_t)nX * nX, B + (sN + k) * (size_t)nX * nU, Am, Bm, nX, nU, lda, tid);
+        for (int e = tid; e < nU * nX; e += SW_T) Km[(e / nX) * lda + e % nX] = K[(sN + k) * (size_t)nU * nX + e];
+        __syncthreads();
+        if (tid < nU) {
+            double v = -C[(sN + k) * nU + tid];
+            for (int m = 0; m < nX; m++) v -= Km[tid * lda + m] * x[m];
+            u[tid] = v;
+            dU[(sN + k) * nU + tid] = v;
+            part += r[(sN + k) * nU + tid] * v;
+        }
+        for (int i = tid; i < nX; i += SW_T) part += q[(sN + s + k) * nX + i] * x[i];
+        __syncthreads();
+        for (int i = tid; i < nX; i += SW_T) {
+            double v = 0.0;
+            for (int m = 0; m < nX; m++) v += Am[i * lda + m] * x[m];
+            for (int c = 0; c < nU; c++) v += Bm[i * nU + c] * u[c];
+            xn[i] = v;
+            dX[(sN + s + k + 1) * nX + i] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < nX; i += SW_T) x[i] = xn[i];
+        __syncthreads();
+    }
+    for (int i = tid; i < nX; i += SW_T) part += q[(sN + s + N) * nX + i] * x[i];
+    red[tid] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double t_ = 0.0;
+        for (int i = 0; i < SW_T; i++) t_ += red[i];
+        dcost[s] = t_;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Quadratic tracking cost (dcost.py:5-118): l = 1/2 (x-xd)'Q(x-xd) + 1/2 (u-ud)'R(u-ud), m = 1/2 (x-xd)'Qf(x-xd).
+// Trajectory t of `group` candidates per seed compares against the reference of seed t / group.
+// ------------------------------------------------------------------------------------------------------
+constexpr int CT_T = 256;
+
+__global__ __launch_bounds__(CT_T) void k_cost(int N, int nX, int nU, int group, const double *X, const double *U,
+                                                const double *Xd, const double *Ud, const double *Q, const double *R,
+                                                const double *Qf, double *cost) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t t = blockIdx.x, s = t / group;
+    double *Qt = lds, *Rt = Qt + nX * nX, *Qft = Rt + nU * nU, *dx = Qft + nX * nX + wave * (nX + nU), *du = dx + nX;
+    double *red = Qft + nX * nX + 4 * (nX + nU);
+    for (int e = tid; e < nX * nX; e += CT_T) { Qt[(e % nX) * nX + e / nX] = Q[e]; Qft[(e % nX) * nX + e / nX] = Qf[e]; }
+    for (int e = tid; e < nU * nU; e += CT_T) Rt[(e % nU) * nU + e / nU] = R[e];
+    __syncthreads();
+    double part = 0.0;
+    for (int k0 = 0; k0 <= N; k0 += 4) {  // each wavefront takes one of four consecutive time steps
+        const int k = k0 + wave;
+        if (k <= N) {
+            const double *xk = X + (t * (N + 1) + k) * nX, *xd = Xd + (s * (N + 1) + k) * nX;
+            for (int i = lane; i < nX; i += 64) dx[i] = xk[i] - xd[i];
+            if (k < N) {
+                const double *uk = U + (t * N + k) * nU, *ud = Ud + (s * N + k) * nU;
+                for (int i = lane; i < nU; i += 64) du[i] = uk[i] - ud[i];
+            }
+        }
+        __syncthreads();
+        if (k <= N) {
+            const double *W = k < N ? Qt : Qft;
+            for (int i = lane; i < nX; i += 64) {
+                double v = 0.0;
+                for (int j = 0; j < nX; j++) v += W[j * nX + i] * dx[j];
+                part += 0.5 * dx[i] * v;
+            }
+            if (k < N) for (int i = lane; i < nU; i += 64) {
+                double v = 0.0;
+                for (int j = 0; j < nU; j++) v += Rt[j * nU + i] * du[j];
+                part += 0.5 * du[i] * v;
+            }
+        }
+        __syncthreads();
+    }
+    red[tid] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double t_ = 0.0;
+        for (int i = 0; i < CT_T; i++) t_ += red[i];
+        cost[t] = t_;
+    }
+}
+
+// gradients q_k = (x_k - xd_k)'Q (k < N), q_N = (x_N - xd_N)'Qf, r_k = (u_k - ud_k)'R  (dcost.py:62-84)
+__global__ __launch_bounds__(CT_T) void k_cost_grad(int N, int nX, int nU, const int *sel, const double *X, const double *U,
+                                                     const double *Xd, const double *Ud, const double *Q, const double *R,
+                                                     const double *Qf, double *q, double *r) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x;
+    const size_t s = sel ? sel[blockIdx.y] : blockIdx.y;
+    const int k = blockIdx.x;  // 0..N
+    double *dx = lds, *du = dx + nX;
+    const double *xk = X + (s * (N + 1) + k) * nX, *xd = Xd + (s * (N + 1) + k) * nX;
+    for (int i = tid; i < nX; i += CT_T) dx[i] = xk[i] - xd[i];
+    if (k < N) for (int i = tid; i < nU; i += CT_T) du[i] = U[(s * N + k) * nU + i] - Ud[(s * N + k) * nU + i];
+    __syncthreads();
+    const double *W = k < N ? Q : Qf;
+    for (int j = tid; j < nX; j += CT_T) {
+        double v = 0.0;
+        for (int i = 0; i < nX; i++) v += dx[i] * W[(size_t)i * nX + j];
+        q[(s * (N + 1) + k) * nX + j] = v;
+    }
+    if (k < N) for (int j = tid; j < nU; j += CT_T) {
+        double v = 0.0;
+        for (int i = 0; i < nU; i++) v += du[i] * R[(size_t)i * nU + j];
+        r[(s * N + k) * nU + j] = v;
+    }
+}
+
+// Armijo candidates (doptimizer.py:436-446): bX[s][m] = X[s] + lambda_m dX[s], bU likewise, for the seeds in `sel`.
+// Candidate row c = blockIdx.y * M + m.
+__global__ void k_candidates(int N, int nX, int nU, int M, const int *sel, const double *lambdas, const double *X,
+                             const double *U, const double *dX, const double *dU, double *bX, double *bU) {
+    const size_t row = blockIdx.y, s = sel ? sel[row / M] : row / M;
+    const double lam = lambdas[row % M];
+    const size_t nx = (size_t)(N + 1) * nX, nu = (size_t)N * nU;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nx; e += (size_t)gridDim.x * blockDim.x)
+        bX[row * nx + e] = X[s * nx + e] + lam * dX[s * nx + e];
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nu; e += (size_t)gridDim.x * blockDim.x)
+        bU[row * nu + e] = U[s * nu + e] + lam * dU[s * nu + e];
+}
+
+// dst[dst_rows[i]] = src[src_rows[i]] for rows of `width` doubles (accepting Armijo candidates, gathering sub-batches).
+__global__ void k_copy_rows(int n, size_t width, const int *dst_rows, const int *src_rows, const double *src, double *dst) {
+    for (size_t i = blockIdx.y; i < (size_t)n; i += gridDim.y) {
+        const size_t d = dst_rows ? dst_rows[i] : i, sr = src_rows ? src_rows[i] : i;
+        for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < width; e += (size_t)gridDim.x * blockDim.x)
+            dst[d * width + e] = src[sr * width + e];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tg_tv_lq(int32_t device, const tg_lq_problem *p) {
+    if (!p || p->n_problems <= 0 || p->horizon <= 0 || p->nX <= 0 || p->nU <= 0) return fail(TG_ERR_INVALID, "bad LQ problem sizes");
+    if (!p->A_dev || !p->B_dev || !p->Q_dev || !p->Qf_dev || !p->R_dev || !p->K_dev) return fail(TG_ERR_INVALID, "null LQ buffer");
+    if ((p->q_dev == nullptr) != (p->r_dev == nullptr)) return fail(TG_ERR_INVALID, "q and r must be given together");
+    if (p->hz_dev && (p->hz_R < p->hz_nx + p->nU || p->hz_nx > p->nX)) return fail(TG_ERR_INVALID, "bad curvature block sizes");
+    // size class: tile size TS with nX <= 16*TS (one tile per thread), prefetch registers RI*CI >= nX*ceil(nX/32)/8
+    const int nX = p->nX, nXU = p->nX * p->nU;
+    const int cls = (nX <= 32 && nXU <= 2 * LQ_T) ? 0 : ((nX <= 64 && nXU <= 6 * LQ_T) ? 1 : ((nX <= 80 && nXU <= 8 * LQ_T) ? 2 : ((nX <= 96 && nXU <= 12 * LQ_T) ? 3 : -1)));
+    if (cls < 0) return fail(TG_ERR_UNSUPPORTED, "state dimension too large for the LDS-resident Riccati kernel");
+    const int ts = cls == 0 ? 2 : (cls == 1 ? 4 : (cls == 2 ? 5 : 6));
+    const size_t lds = lq_lds_bytes(p->nX, p->nU, ts);
+    if (lds > 160 * 1024 - 64) return fail(TG_ERR_UNSUPPORTED, "state dimension too large for the LDS-resident Riccati kernel");
+    HIP_TRY(hipSetDevice(device));
+    const void *fn = cls == 0 ? (const void *)k_tv_lq<2, 4, 1, 2> : (cls == 1 ? (const void *)k_tv_lq<4, 8, 2, 6>
+                     : (cls == 2 ? (const void *)k_tv_lq<5, 10, 3, 8> : (const void *)k_tv_lq<6, 12, 3, 12>));
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    switch (cls) {
+    case 0: hipLaunchKernelGGL((k_tv_lq<2, 4, 1, 2>), dim3(p->n_problems), dim3(LQ_T), lds, 0, *p); break;
+    case 1: hipLaunchKernelGGL((k_tv_lq<4, 8, 2, 6>), dim3(p->n_problems), dim3(LQ_T), lds, 0, *p); break;
+    case 2: hipLaunchKernelGGL((k_tv_lq<5, 10, 3, 8>), dim3(p->n_problems), dim3(LQ_T), lds, 0, *p); break;
+    default: hipLaunchKernelGGL((k_tv_lq<6, 12, 3, 12>), dim3(p->n_problems), dim3(LQ_T), lds, 0, *p); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return TG_SUCCESS;
+}
+
+int tg_adjoint_sweep(int32_t device, int32_t n_problems, int32_t horizon, int32_t nX, int32_t nU, const int32_t *select_dev,
+                     const double *A_dev, const double *B_dev, const double *K_dev, const double *q_dev, const double *r_dev,
+                     double *Z_dev) {
+    if (n_problems <= 0 || horizon <= 0 || !A_dev || !B_dev || !K_dev || !q_dev || !r_dev || !Z_dev) return fail(TG_ERR_INVALID, "bad arguments");
+    const size_t lds = sizeof(double) * ((size_t)nX * (nX | 1) + (size_t)nX * nU + (size_t)nU * nX + 2 * nX + nU);
+    if (lds > 160 * 1024 - 64) return fail(TG_ERR_UNSUPPORTED, "state dimension too large");
+    HIP_TRY(hipSetDevice(device));
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_adjoint, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_adjoint, dim3(n_problems), dim3(SW_T), lds, 0, horizon, nX, nU, select_dev, A_dev, B_dev, K_dev, q_dev, r_dev, Z_dev);
+    HIP_TRY(hipGetLastError());
+    return TG_SUCCESS;
+}
+
+int tg_tangent_rollout(int32_t device, int32_t n_problems, int32_t horizon, int32_t nX, int32_t nU, const int32_t *select_dev,
+                       const double *A_dev, const double *B_dev, const double *K_dev, const double *C_dev, const double *q_dev,
+                       const double *r_dev, double *dX_dev, double *dU_dev, double *dcost_dev) {
+    if (n_problems <= 0 || horizon <= 0 || !A_dev || !B_dev || !K_dev || !C_dev || !q_dev || !r_dev || !dX_dev || !dU_dev || !dcost_dev)
+        return fail(TG_ERR_INVALID, "bad arguments");
+    const int lda = nX | 1;
+    const size_t lds = sizeof(double) * ((size_t)nX * lda + (size_t)nX * nU + (size_t)nU * lda + 2 * nX + nU + SW_T);
+    if (lds > 160 * 1024 - 64) return fail(TG_ERR_UNSUPPORTED, "state dimension too large");
+    HIP_TRY(hipSetDevice(device));
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_tangent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_tangent, dim3(n_problems), dim3(SW_T), lds, 0, horizon, nX, nU, select_dev, A_dev, B_dev, K_dev, C_dev, q_dev,
+                       r_dev, dX_dev, dU_dev, dcost_dev);
+    HIP_TRY(hipGetLastError());
+    return TG_SUCCESS;
+}
+
+int tg_quadratic_cost(int32_t device, int32_t n_trajectories, int32_t group, int32_t horizon, int32_t nX, int32_t nU,
+                      const double *X_dev, const double *U_dev, const double *Xd_dev, const double *Ud_dev, const double *Q_dev,
+                      const double *R_dev, const double *Qf_dev, double *cost_dev) {
+    if (n_trajectories <= 0 || group <= 0 || horizon <= 0 || !X_dev || !U_dev || !Xd_dev || !Ud_dev || !Q_dev || !R_dev || !Qf_dev || !cost_dev)
+        return fail(TG_ERR_INVALID, "bad arguments");
+    const size_t lds = sizeof(double) * (2 * (size_t)nX * nX + (size_t)nU * nU + 4 * (size_t)(nX + nU) + CT_T);
+    if (lds > 160 * 1024 - 64) return fail(TG_ERR_UNSUPPORTED, "state dimension too large");
+    HIP_TRY(hipSetDevice(device));
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_cost, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_cost, dim3(n_trajectories), dim3(CT_T), lds, 0, horizon, nX, nU, group, X_dev, U_dev, Xd_dev, Ud_dev, Q_dev, R_dev,
+                       Qf_dev, cost_dev);
+    HIP_TRY(hipGetLastError());
+    return TG_SUCCESS;
+}
+
+int tg_quadratic_cost_gradients(int32_t device, int32_t n_problems, int32_t horizon, int32_t nX, int32_t nU, const int32_t *select_dev,
+                                const double *X_dev, const double *U_dev, const double *Xd_dev, const double *Ud_dev,
+                                const double *Q_dev, const double *R_dev, const double *Qf_dev, double *q_dev, double *r_dev) {
+    if (n_problems <= 0 || horizon <= 0 || !X_dev || !U_dev || !Xd_dev || !Ud_dev || !Q_dev || !R_dev || !Qf_dev || !q_dev || !r_dev)
+        return fail(TG_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(k_cost_grad, dim3(horizon + 1, n_problems), dim3(CT_T), sizeof(double) * (nX + nU), 0, horizon, nX, nU, select_dev,
+                       X_dev, U_dev, Xd_dev, Ud_dev, Q_dev, R_dev, Qf_dev, q_dev, r_dev);
+    HIP_TRY(hipGetLastError());
+    return TG_SUCCESS;
+}
+
+int tg_armijo_candidates(int32_t device, int32_t n_problems, int32_t n_lambdas, int32_t horizon, int32_t nX, int32_t nU,
+                         const int32_t *select_dev, const double *lambdas_dev, const double *X_dev, const double *U_dev,
+                         const double *dX_dev, const double *dU_dev, double *bX_dev, double *bU_dev) {
+    if (n_problems <= 0 || n_lambdas <= 0 || horizon <= 0 || !lambdas_dev || !X_dev || !U_dev || !dX_dev || !dU_dev || !bX_dev || !bU_dev)
+        return fail(TG_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    const int bx = (int)(((size_t)(horizon + 1) * nX + 255) / 256);
+    hipLaunchKernelGGL(k_candidates, dim3(bx > 64 ? 64 : bx, n_problems * n_lambdas), dim3(256), 0, 0, horizon, nX, nU, n_lambdas, select_dev,
+                       lambdas_dev, X_dev, U_dev, dX_dev, dU_dev, bX_dev, bU_dev);
+    HIP_TRY(hipGetLastError());
+    return TG_SUCCESS;
+}
+
+int tg_copy_rows(int32_t device, int32_t n_rows, uint64_t row_doubles, const int32_t *dst_rows_dev, const int32_t *src_rows_dev,
+                 const double *src_dev, double *dst_dev) {
+    if (n_rows <= 0 || !src_dev || !dst_dev) return fail(TG_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    const int bx = (int)((row_doubles + 255) / 256);
+    hipLaunchKernelGGL(k_copy_rows, dim3(bx > 64 ? 64 : (bx < 1 ? 1 : bx), n_rows > 65535 ? 65535 : n_rows), dim3(256), 0, 0, n_rows, (size_t)row_doubles, dst_rows_dev,
+                       src_rows_dev, src_dev, dst_dev);
+    HIP_TRY(hipGetLastError());
+    return TG_SUCCESS;
+}
+
+int tg_device_synchronize(int32_t device) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return TG_SUCCESS;
+}
+
+}  // extern "C"

@@ -73,6 +73,8 @@ struct RunArgs {
     double *X;                             // [batch][n_steps+1][nX] or null
     double *f_out;                         // MODE_CALC_F: [batch][nf]
     double *d1[12];                        // MODE_DERIV1 outputs q2_d{q1,p1,u1,k2}, p2_d*, l1_d*: [batch][var][out]
+    double *A_out, *B_out;                 // MODE_DERIV1, if A_out != null: write DSystem.fdx / fdu instead
+                                           // (dsystem.py:284-317): A [batch][nX][nX], B [batch][nX][nU]
     const double *z;                       // MODE_DERIV2Z: [batch][nX] contraction vector
     double *hz;                            // MODE_DERIV2Z: [batch][R][R], R = nq+nd+nu+nk
     int *iters, *status;                   // [batch]
@@ -858,6 +860,39 @@ struct Core {
         const int ld = P.d_aug_ld, R = P.d_nrhs;
         double *AUG = S + P.d_o_AUG, *T12 = S + P.d_o_T12, *T22 = S + P.d_o_T22;
         const bool ok = deriv1_solve(on, false);
+        if (A.A_out) {
+            // linearisation of the DSystem state map X_{k+1} = f(X_k, U_k), X = [Q; p; v], U = [u; rho]
+            // (dsystem.py:284-317): rows Qd and p hold the transposed derivative blocks, rows Qk / v the
+            // constant entries.  Lanes run along a row, so the global writes are contiguous.
+            if (on) {
+                const int nX = P.nX, nU = nu + nk, nqd = nq + nd;
+                double *Ao = A.A_out + t * (size_t)nX * nX, *Bo = A.B_out + t * (size_t)nX * nU;
+                for (int o = 0; o < nd; o++) TG_FOR(vv, nX + nU) {
+                    double x = NAN, p = NAN;
+                    if (vv >= nqd && vv < nX) { x = 0.0; p = 0.0; }       // columns of the v part of X
+                    else if (ok) {
+                        const int sv = vv < nqd ? vv : vv - nk;           // index among (q1, p1, u1, k2)
+                        const int kind = sv < nq ? 0 : (sv < nqd ? 1 : (sv < nqd + nu ? 2 : 3));
+                        const int i = kind == 0 ? sv : (kind == 3 ? sv - nqd - nu : 0);
+                        x = AUG[o * ld + nf + sv];
+                        p = kind == 0 ? T12[i * nd + o] : (kind == 3 ? T22[(nd + i) * nd + o] : 0.0);
+                        for (int i2 = 0; i2 < nd; i2++) p += T22[i2 * nd + o] * AUG[i2 * ld + nf + sv];
+                    }
+                    if (vv < nX) { Ao[(size_t)o * nX + vv] = x; Ao[(size_t)(nq + o) * nX + vv] = p; }
+                    else { Bo[(size_t)o * nU + vv - nX] = x; Bo[(size_t)(nq + o) * nU + vv - nX] = p; }
+                }
+                const double rdt = 1.0 / dt;
+                for (int i = 0; i < nk; i++) TG_FOR(vv, nX + nU) {        // Qk_{k+1} = rho_k, v_{k+1} = (rho_k - Qk_k)/dt
+                    if (vv < nX) { Ao[(size_t)(nd + i) * nX + vv] = 0.0; Ao[(size_t)(nqd + i) * nX + vv] = vv == nd + i ? -rdt : 0.0; }
+                    else {
+                        const bool hit = vv - nX == nu + i;
+                        Bo[(size_t)(nd + i) * nU + vv - nX] = hit ? 1.0 : 0.0;
+                        Bo[(size_t)(nqd + i) * nU + vv - nX] = hit ? rdt : 0.0;
+                    }
+                }
+            }
+            return;
+        }
         // outputs in the reference layout [derivative variable][output] (trep.h:425-437)
         if (on) {
             const int cwl = tile_log2<TEAM>(nd), cw = 1 << cwl, rstep = TEAM >> cwl;
@@ -1255,6 +1290,10 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
         TG_FOR(i, nq) x[i] = S[P.o_q2 + i];
         TG_FOR(i, nd) x[nq + i] = S[P.o_p1 + i];
         TG_FOR(i, nk) x[nq + nd + i] = (A.t2 != A.t1) ? (S[P.o_q2 + nd + i] - S[P.o_q1 + nd + i]) / (A.t2 - A.t1) : 0.0;
+    }
+    if (live && A.X && A.Kproj) {  // projection: X_0 = bX_0 by definition (dsystem.py:441), including its v part
+        const size_t o0 = t * (size_t)(A.n_steps + 1) * nX;
+        TG_FOR(i, nX) A.X[o0 + i] = A.bX[o0 + i];
     }
     bool failed = false;
     int status = TG_OK, total_iters = 0;

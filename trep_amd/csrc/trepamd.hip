@@ -183,6 +183,26 @@ int launch(tg_batch *b, tg::RunArgs &A) {
     return TG_SUCCESS;
 }
 
+// Host-facing derivative outputs: the twelve first-derivative arrays and the contraction buffers.  Allocated on
+// first use so that batches that only roll out, or that write A/B and HZ into caller-provided device buffers,
+// do not reserve 80+ kB per trajectory.
+int ensure_deriv_buffers(tg_batch *b, bool first, bool second) {
+    const tg::DevProg &P = b->P;
+    const size_t B = (size_t)b->batch;
+    auto dalloc = [&](double **p, size_t n) -> bool {
+        if (*p) return true;
+        return hipMalloc(p, (n ? n : 1) * sizeof(double)) == hipSuccess && hipMemset(*p, 0, (n ? n : 1) * sizeof(double)) == hipSuccess;
+    };
+    bool ok = true;
+    if (first) for (int k = 0; k < 12 && ok; k++) {
+        const int var = k % 4, out = k / 4;
+        const size_t rows = var == 0 ? P.nq : (var == 1 ? P.nd : (var == 2 ? P.nu : P.nk));
+        ok = dalloc(&b->d1[k], B * rows * (out == 2 ? P.nc : P.nd));
+    }
+    if (second && ok) ok = dalloc(&b->z_dev, B * P.nX) && dalloc(&b->hz_dev, B * (size_t)P.d_nrhs * P.d_nrhs);
+    return ok ? TG_SUCCESS : fail(TG_ERR_HIP, "device allocation failed");
+}
+
 tg::RunArgs base_args(tg_batch *b, int mode) {
     tg::RunArgs A{};
     A.batch = b->batch; A.mode = mode; A.max_iterations = 200;
@@ -196,7 +216,39 @@ tg::RunArgs base_args(tg_batch *b, int mode) {
     return A;
 }
 
+// DSystem.set(X[s][k], U[s][k], k, xk_hint = X[s][k+1]) for trajectory t = s*horizon + k (dsystem.py:229-251):
+// state (q2,p2) <- X[s][k] (the step kernel shifts it into slot 1), lambda <- 0, inputs and hint staged.
+__global__ void k_set_from_trajectories(const tg::DevProg P, int seeds, int horizon, const double *X, const double *U,
+                                        double *q1, double *q2, double *p1, double *p2, double *lam, double *su,
+                                        double *sk, double *sqh) {
+    const size_t t = blockIdx.x;
+    const size_t s = t / horizon, k = t % horizon;
+    const double *x0 = X + (s * (horizon + 1) + k) * P.nX, *x1 = x0 + P.nX, *u = U + (s * horizon + k) * (size_t)(P.nu + P.nk);
+    for (int i = threadIdx.x; i < P.nq; i += blockDim.x) { q1[t * P.nq + i] = x0[i]; q2[t * P.nq + i] = x0[i]; }
+    for (int i = threadIdx.x; i < P.nd; i += blockDim.x) {
+        p1[t * P.nd + i] = x0[P.nq + i]; p2[t * P.nd + i] = x0[P.nq + i];
+        sqh[t * P.nd + i] = x1[i];
+    }
+    for (int i = threadIdx.x; i < P.nc; i += blockDim.x) lam[t * P.nc + i] = 0.0;
+    for (int i = threadIdx.x; i < P.nu; i += blockDim.x) su[t * P.nu + i] = u[i];
+    for (int i = threadIdx.x; i < P.nk; i += blockDim.x) sk[t * P.nk + i] = u[P.nu + i];
+}
+
+// initialize_from_state(t, Q, p) with (Q, p) taken from the head of a DSystem state vector X = [Q; p; v]
+__global__ void k_init_from_X(const tg::DevProg P, const double *X, size_t stride, double *q1, double *q2, double *p1,
+                              double *p2, double *lam) {
+    const size_t t = blockIdx.x;
+    const double *x = X + t * stride;
+    for (int i = threadIdx.x; i < P.nq; i += blockDim.x) { q1[t * P.nq + i] = x[i]; q2[t * P.nq + i] = x[i]; }
+    for (int i = threadIdx.x; i < P.nd; i += blockDim.x) { p1[t * P.nd + i] = x[P.nq + i]; p2[t * P.nd + i] = x[P.nq + i]; }
+    for (int i = threadIdx.x; i < P.nc; i += blockDim.x) lam[t * P.nc + i] = 0.0;
+}
+
 }  // namespace
+
+namespace tg_detail {
+int fail(int code, const std::string &msg) { return ::fail(code, msg); }
+}
 
 extern "C" {
 
@@ -267,12 +319,7 @@ tg_batch *tg_batch_create(tg_system *sys, int32_t batch, int32_t device) {
     dalloc(&b->lam, B * P.nc); dalloc(&b->u1, B * P.nu);
     dalloc(&b->stage_u, B * P.nu); dalloc(&b->stage_k, B * P.nk); dalloc(&b->stage_qh, B * P.nd); dalloc(&b->stage_lh, B * P.nc);
     dalloc(&b->f_out, B * P.nf);
-    dalloc(&b->z_dev, B * P.nX); dalloc(&b->hz_dev, B * (size_t)P.d_nrhs * P.d_nrhs);
-    for (int k = 0; k < 12; k++) {
-        const int var = k % 4, out = k / 4;
-        const size_t rows = var == 0 ? P.nq : (var == 1 ? P.nd : (var == 2 ? P.nu : P.nk));
-        dalloc(&b->d1[k], B * rows * (out == 2 ? P.nc : P.nd));
-    }
+    // derivative outputs (d1[12], z, hz) are allocated on first use: ensure_deriv_buffers()
     dalloc(&b->snap, B * (2 * (size_t)P.nq + 2 * (size_t)P.nd + P.nc + P.nu));
     if (ok) ok = hipMalloc(&b->iters, B * sizeof(int)) == hipSuccess && hipMalloc(&b->status, B * sizeof(int)) == hipSuccess &&
                  hipMemset(b->iters, 0, B * sizeof(int)) == hipSuccess && hipMemset(b->status, 0, B * sizeof(int)) == hipSuccess;
@@ -482,8 +529,10 @@ int tg_batch_deriv1(tg_batch *b) {
     if (!b) return fail(TG_ERR_INVALID, "null batch");
     if (b->t2 == b->t1) return fail(TG_ERR_STATE, "Integrator has not solved the next time step yet.");
     HIP_TRY(hipSetDevice(b->device));
+    int rc = ensure_deriv_buffers(b, true, false);
+    if (rc) return rc;
     tg::RunArgs A = base_args(b, tg::MODE_DERIV1);
-    int rc = launch(b, A);
+    rc = launch(b, A);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(b->stream));
     b->have_d1 = true;
@@ -495,6 +544,7 @@ int tg_batch_deriv2_contract(tg_batch *b, const double *z_host, double *hz_host)
     if (b->t2 == b->t1) return fail(TG_ERR_STATE, "Integrator has not solved the next time step yet.");
     HIP_TRY(hipSetDevice(b->device));
     const size_t B = (size_t)b->batch, R = (size_t)b->P.d_nrhs;
+    if (int rc0 = ensure_deriv_buffers(b, false, true)) return rc0;
     HIP_TRY(hipMemcpyAsync(b->z_dev, z_host, B * b->P.nX * sizeof(double), hipMemcpyHostToDevice, b->stream));
     tg::RunArgs A = base_args(b, tg::MODE_DERIV2Z);
     int rc = launch(b, A);
@@ -502,6 +552,53 @@ int tg_batch_deriv2_contract(tg_batch *b, const double *z_host, double *hz_host)
     HIP_TRY(hipMemcpyAsync(hz_host, b->hz_dev, B * R * R * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return TG_SUCCESS;
+}
+
+int tg_batch_deriv2_contract_device(tg_batch *b, const double *z_dev, double *hz_dev) {
+    if (!b || !z_dev || !hz_dev) return fail(TG_ERR_INVALID, "null argument");
+    if (b->t2 == b->t1) return fail(TG_ERR_STATE, "Integrator has not solved the next time step yet.");
+    HIP_TRY(hipSetDevice(b->device));
+    tg::RunArgs A = base_args(b, tg::MODE_DERIV2Z);
+    A.z = z_dev; A.hz = hz_dev;
+    return launch(b, A);
+}
+
+int tg_batch_set_from_trajectories(tg_batch *b, int32_t seeds, int32_t horizon, double t0, double dt, const double *X_dev,
+                                   const double *U_dev, int32_t max_iterations) {
+    if (!b || !X_dev || !U_dev || seeds <= 0 || horizon <= 0 || dt == 0.0) return fail(TG_ERR_INVALID, "bad arguments");
+    if ((int64_t)seeds * horizon != b->batch) return fail(TG_ERR_INVALID, "batch size must be seeds * horizon");
+    HIP_TRY(hipSetDevice(b->device));
+    const tg::DevProg &P = b->P;
+    hipLaunchKernelGGL(k_set_from_trajectories, dim3(b->batch), dim3(64), 0, b->stream, P, seeds, horizon, X_dev, U_dev,
+                       b->q1, b->q2, b->p1, b->p2, b->lam, b->stage_u, b->stage_k, b->stage_qh);
+    HIP_TRY(hipGetLastError());
+    b->t1 = t0; b->t2 = t0;
+    tg::RunArgs A = base_args(b, tg::MODE_ROLLOUT);
+    A.n_steps = 1; A.dt = dt; A.max_iterations = max_iterations;
+    A.U = b->stage_u; A.K = b->stage_k; A.q2_hint = b->stage_qh;
+    int rc = launch(b, A);
+    if (rc) return rc;
+    b->t1 = t0; b->t2 = t0 + dt;
+    return TG_SUCCESS;
+}
+
+int tg_batch_initialize_from_state_device(tg_batch *b, double t, const double *X_dev, uint64_t row_stride_doubles) {
+    if (!b || !X_dev || row_stride_doubles < (uint64_t)(b->P.nq + b->P.nd)) return fail(TG_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(b->device));
+    hipLaunchKernelGGL(k_init_from_X, dim3(b->batch), dim3(64), 0, b->stream, b->P, X_dev, (size_t)row_stride_doubles, b->q1, b->q2,
+                       b->p1, b->p2, b->lam);
+    HIP_TRY(hipGetLastError());
+    b->t1 = t; b->t2 = t;
+    return TG_SUCCESS;
+}
+
+int tg_batch_linearize(tg_batch *b, double *A_dev, double *B_dev) {
+    if (!b || !A_dev || !B_dev) return fail(TG_ERR_INVALID, "null argument");
+    if (b->t2 == b->t1) return fail(TG_ERR_STATE, "Integrator has not solved the next time step yet.");
+    HIP_TRY(hipSetDevice(b->device));
+    tg::RunArgs A = base_args(b, tg::MODE_DERIV1);
+    A.A_out = A_dev; A.B_out = B_dev;
+    return launch(b, A);
 }
 
 void *tg_device_alloc(int32_t device, uint64_t bytes) {

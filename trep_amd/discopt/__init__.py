@@ -3,3 +3,4 @@ from .dcost import DCost  # noqa: F401
 from .dsystem import DSystem, BatchDSystem  # noqa: F401
 from .doptimizer import DOptimizer, DOptimizerMonitor, DOptimizerDefaultMonitor  # noqa: F401
 from .dlqr import solve_tv_lqr, solve_tv_lq  # noqa: F401
+from .batch_doptimizer import BatchDOptimizer  # noqa: F401

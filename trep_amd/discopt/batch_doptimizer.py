@@ -1,0 +1,339 @@
+"""BatchDOptimizer: S independent trajectory-optimisation problems ("seeds") of one system advanced together,
+device resident.
+
+Same algorithm as ``DOptimizer`` (reference trep/discopt/doptimizer.py:207-566: projection-operator descent with
+a steepest / quasi-Newton / Newton LQ model, Armijo search over closed-loop projections, fallback
+newton -> quasi -> steepest) with a quadratic ``DCost`` per seed -- but every stage runs on the GPU for all
+seeds at once and the trajectories, linearisations, gains and candidates never leave HBM:
+
+  stage                                   kernel(s) (include/trep_amd.h)                      parallel axis
+  --------------------------------------  --------------------------------------------------  ---------------
+  DSystem.set + fdx/fdu for all (s,k)     tg_batch_set_from_trajectories, tg_batch_linearize  S*N trajectories
+  projection gain (solve_tv_lqr)          tg_tv_lq                                            S workgroups
+  cost, gradients                         tg_quadratic_cost, tg_quadratic_cost_gradients      S / S*(N+1)
+  Newton model: adjoint + fdxdx/xu/uu(z)  tg_adjoint_sweep, tg_batch_deriv2_contract_device   S / S*N
+  descent direction (solve_tv_lq + dX,dU) tg_tv_lq, tg_tangent_rollout                        S workgroups
+  Armijo candidates, projection, costs    tg_armijo_candidates, tg_batch_rollout_closed_loop  S*M trajectories
+
+Only per-seed scalars (costs, directional derivatives, statuses) come back to the host, which takes the
+accept / fallback / terminate decisions exactly like the reference's ``step``.
+"""
+from collections import namedtuple
+
+import numpy as np
+
+from .. import _lib
+from ..errors import ConvergenceError
+from ..midpointvi import BatchMidpointVI
+
+METHODS = ("steepest", "quasi", "newton")
+
+
+class _DeviceArray(object):
+    """A typed view of a device allocation (owned by a _DevicePool)."""
+
+    def __init__(self, pool, shape, dtype):
+        self.pool, self.shape, self.dtype = pool, tuple(int(x) for x in shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self.ptr = pool._alloc(max(self.nbytes, 8))
+
+    def set(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.shape != self.shape:
+            raise ValueError("expected shape %r, got %r" % (self.shape, host.shape))
+        if self.nbytes:
+            _lib.check(self.pool.L.tg_memcpy_h2d(self.pool.device, self.ptr, host.ctypes.data, self.nbytes))
+        return self
+
+    def get(self):
+        out = np.zeros(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            _lib.check(self.pool.L.tg_memcpy_d2h(self.pool.device, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+
+class _DevicePool(object):
+    def __init__(self, device):
+        self.L = _lib.lib()
+        _lib.require_device()
+        self.device = device
+        self._ptrs = []
+
+    def _alloc(self, nbytes):
+        p = self.L.tg_device_alloc(self.device, nbytes)
+        if not p:
+            raise _lib.LibraryError(self.L.tg_last_error().decode())
+        self._ptrs.append(p)
+        return p
+
+    def empty(self, shape, dtype=np.float64):
+        return _DeviceArray(self, shape, dtype)
+
+    def upload(self, host, dtype=np.float64):
+        host = np.ascontiguousarray(host, dtype=dtype)
+        return _DeviceArray(self, host.shape, dtype).set(host)
+
+    def close(self):
+        for p in self._ptrs:
+            self.L.tg_device_free(self.device, p)
+        self._ptrs = []
+
+
+class BatchDOptimizer(object):
+    """S seeds of the same DSystem, each with its own desired trajectory (xd, ud) and shared weights Q, R, Qf."""
+
+    step_return = namedtuple("batch_step", "done cost0 dcost0 cost1 method armijo")
+
+    def __init__(self, dsys, Xd, Ud, Q, R, Qf=None, device=0, armijo_chunk=None, first_method_iterations=10):
+        self.dsys = dsys
+        ds = dsys
+        Xd = np.asarray(Xd, dtype=float)
+        Ud = np.asarray(Ud, dtype=float)
+        self.S, self.N = Xd.shape[0], Xd.shape[1] - 1
+        self.nX, self.nU = ds.nX, ds.nU
+        if Xd.shape != (self.S, self.N + 1, self.nX) or Ud.shape != (self.S, self.N, self.nU):
+            raise ValueError("Xd must be [S][N+1][nX] and Ud [S][N][nU]")
+        if self.N != ds.kf():
+            raise ValueError("the DSystem's time base has %d steps, the trajectories %d" % (ds.kf(), self.N))
+        steps = np.diff(ds.time)
+        if not np.allclose(steps, steps[0], rtol=1e-9, atol=1e-12):
+            raise NotImplementedError("the batched optimizer needs a uniform time base")
+        self.dt, self.t0 = float(steps[0]), float(ds.time[0])
+        self.armijo_beta = 0.7
+        self.armijo_alpha = 0.00001
+        self.armijo_max_iterations = 30
+        self.descent_tolerance = 1e-6
+        self.first_method_iterations = first_method_iterations
+        self.first_method = "quasi"
+        self.second_method = "newton"
+        self.device = device
+        self.L = _lib.lib()
+        self.pool = pool = _DevicePool(device)
+        S, N, nX, nU = self.S, self.N, self.nX, self.nU
+        sysm = ds.system
+        self._nxh = len(sysm.configs) + len(sysm.dyn_configs)      # leading [Q; p] part of X the curvature covers
+        self._R = self._nxh + nU
+        # engines: horizon batch (one trajectory per (seed, step)) and candidate batch
+        if armijo_chunk is None:   # fill the GPU once (256 CUs x 8 wavefronts) but never more than the search needs
+            armijo_chunk = int(min(self.armijo_max_iterations, max(1, 2048 // S)))
+        self.M = int(armijo_chunk)
+        self.lin = BatchMidpointVI(sysm, S * N, device=device)
+        self.arm = BatchMidpointVI(sysm, S * self.M, device=device)
+        # device state
+        self.Xd, self.Ud = pool.upload(Xd), pool.upload(Ud)
+        self.Q = pool.upload(np.asarray(Q, dtype=float).reshape(nX, nX))
+        self.R = pool.upload(np.asarray(R, dtype=float).reshape(nU, nU))
+        self.Qf = pool.upload(np.asarray(Q if Qf is None else Qf, dtype=float).reshape(nX, nX))
+        self.Ix, self.Iu = pool.upload(np.eye(nX)), pool.upload(np.eye(nU))
+        self.X, self.U = pool.empty((S, N + 1, nX)), pool.empty((S, N, nU))
+        self.A, self.B = pool.empty((S, N, nX, nX)), pool.empty((S, N, nX, nU))
+        self.Kproj, self.K, self.C = pool.empty((S, N, nU, nX)), pool.empty((S, N, nU, nX)), pool.empty((S, N, nU))
+        self.q, self.r = pool.empty((S, N + 1, nX)), pool.empty((S, N, nU))
+        self.dX, self.dU = pool.empty((S, N + 1, nX)), pool.empty((S, N, nU))
+        self.dcost, self.cost = pool.empty((S,)), pool.empty((S,))
+        self.lq_status = pool.empty((S,), np.int32)
+        self.Z = None
+        self.HZ = None
+        self.bX, self.bU = pool.empty((S * self.M, N + 1, nX)), pool.empty((S * self.M, N, nU))
+        self.cX, self.cU = pool.empty((S * self.M, N + 1, nX)), pool.empty((S * self.M, N, nU))
+        self.ccost = pool.empty((S * self.M,))
+        self.lambdas = pool.empty((self.M,))
+        self.x0 = pool.empty((S, nX))
+        self._sel = pool.empty((S,), np.int32)
+        self._rows_a, self._rows_b = pool.empty((S,), np.int32), pool.empty((S,), np.int32)
+        self.iteration = 0
+
+    def close(self):
+        for e in (self.lin, self.arm):
+            if e is not None:
+                e.close()
+        self.lin = self.arm = None
+        self.pool.close()
+
+    # -- trajectories --------------------------------------------------------------------------------------
+    def set_trajectories(self, X, U):
+        self.X.set(X)
+        self.U.set(U)
+
+    def get_trajectories(self):
+        return self.X.get(), self.U.get()
+
+    # -- stages (each one launch or a few; all seeds) ----------------------------------------------------
+    def _check(self, rc):
+        _lib.check(rc)
+
+    def _select(self, seeds):
+        """Device index list for a subset of the seeds (None = all)."""
+        if seeds is None:
+            return None, self.S
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        buf = np.zeros(self.S, dtype=np.int32)
+        buf[:len(seeds)] = seeds
+        self._sel.set(buf)
+        return self._sel.ptr, len(seeds)
+
+    def linearize(self):
+        """A, B about the current (X, U) for every seed and step; leaves the S*N solved steps resident."""
+        self._check(self.L.tg_batch_set_from_trajectories(self.lin._h, self.S, self.N, self.t0, self.dt, self.X.ptr, self.U.ptr, 200))
+        _, status = self.lin.status()
+        if (status != 0).any():
+            bad = np.nonzero(status)[0][:5]
+            raise ConvergenceError("linearisation: DEL solve failed at (seed, k) = %s" % [(int(t // self.N), int(t % self.N)) for t in bad])
+        self._check(self.L.tg_batch_linearize(self.lin._h, self.A.ptr, self.B.ptr))
+
+    def _lq(self, seeds, Q, Qf, R, hz, affine, K, C=None):
+        sel, n = self._select(seeds)
+        if n == 0:
+            return
+        p = _lib.LqProblem()
+        p.n_problems, p.horizon, p.nX, p.nU = n, self.N, self.nX, self.nU
+        p.select_dev = sel
+        p.A_dev, p.B_dev = self.A.ptr, self.B.ptr
+        p.Q_dev, p.Q_seed_stride, p.Q_step_stride = Q.ptr, 0, 0
+        p.Qf_dev, p.Qf_seed_stride = Qf.ptr, 0
+        p.R_dev, p.R_seed_stride, p.R_step_stride = R.ptr, 0, 0
+        p.hz_dev = hz.ptr if hz is not None else None
+        p.hz_R, p.hz_nx = self._R, self._nxh
+        p.q_dev, p.r_dev = (self.q.ptr, self.r.ptr) if affine else (None, None)
+        p.K_dev, p.C_dev = K.ptr, (C.ptr if C is not None else None)
+        p.P0_dev = p.b0_dev = None
+        p.status_dev = self.lq_status.ptr
+        import ctypes
+        self._check(self.L.tg_tv_lq(self.device, ctypes.byref(p)))
+
+    def projection_gain(self):
+        """Kproj = solve_tv_lqr(A, B, I, I) (doptimizer.py:272-287)."""
+        self._lq(None, self.Ix, self.Ix, self.Iu, None, False, self.Kproj)
+
+    def gradients_and_cost(self):
+        S, N, nX, nU = self.S, self.N, self.nX, self.nU
+        self._check(self.L.tg_quadratic_cost_gradients(self.device, S, N, nX, nU, None, self.X.ptr, self.U.ptr, self.Xd.ptr, self.Ud.ptr,
+                                                       self.Q.ptr, self.R.ptr, self.Qf.ptr, self.q.ptr, self.r.ptr))
+        self._check(self.L.tg_quadratic_cost(self.device, S, 1, N, nX, nU, self.X.ptr, self.U.ptr, self.Xd.ptr, self.Ud.ptr,
+                                             self.Q.ptr, self.R.ptr, self.Qf.ptr, self.cost.ptr))
+        return self.cost.get()
+
+    def newton_curvature(self, seeds):
+        """HZ[s][k] = second derivatives of step k contracted with the adjoint z_{k+1} (doptimizer.py:319-345)."""
+        if self.Z is None:
+            self.Z = self.pool.empty((self.S, self.N, self.nX))
+            self.HZ = self.pool.empty((self.S, self.N, self._R, self._R))
+        sel, n = self._select(seeds)
+        self._check(self.L.tg_adjoint_sweep(self.device, n, self.N, self.nX, self.nU, sel, self.A.ptr, self.B.ptr, self.Kproj.ptr,
+                                            self.q.ptr, self.r.ptr, self.Z.ptr))
+        self._check(self.L.tg_batch_deriv2_contract_device(self.lin._h, self.Z.ptr, self.HZ.ptr))
+
+    def descent_direction(self, seeds, method):
+        """K, C from the LQ model of `method`, then dX, dU and the directional derivative for `seeds`."""
+        if method == "steepest":
+            self._lq(seeds, self.Ix, self.Ix, self.Iu, None, True, self.K, self.C)
+        elif method == "quasi":
+            self._lq(seeds, self.Q, self.Qf, self.R, None, True, self.K, self.C)
+        elif method == "newton":
+            self.newton_curvature(seeds)
+            self._lq(seeds, self.Q, self.Qf, self.R, self.HZ, True, self.K, self.C)
+        else:
+            raise ValueError("Invalid descent direction method: %r" % method)
+        sel, n = self._select(seeds)
+        self._check(self.L.tg_tangent_rollout(self.device, n, self.N, self.nX, self.nU, sel, self.A.ptr, self.B.ptr, self.K.ptr, self.C.ptr,
+                                              self.q.ptr, self.r.ptr, self.dX.ptr, self.dU.ptr, self.dcost.ptr))
+
+    def armijo_chunk(self, m0):
+        """Project the candidates lambda = beta^m, m0 <= m < m0 + M, of every seed; returns (costs [S][M], ok [S][M])."""
+        S, N, nX, nU, M = self.S, self.N, self.nX, self.nU, self.M
+        self.lambdas.set(self.armijo_beta ** np.arange(m0, m0 + M, dtype=float))
+        self._check(self.L.tg_armijo_candidates(self.device, S, M, N, nX, nU, None, self.lambdas.ptr, self.X.ptr, self.U.ptr,
+                                                self.dX.ptr, self.dU.ptr, self.bX.ptr, self.bU.ptr))
+        self._check(self.L.tg_batch_initialize_from_state_device(self.arm._h, self.t0, self.bX.ptr, (N + 1) * nX))
+        self._check(self.L.tg_batch_rollout_closed_loop(self.arm._h, N, self.dt, self.Kproj.ptr, M, self.bX.ptr, self.bU.ptr,
+                                                        self.cX.ptr, self.cU.ptr, 200))
+        self._check(self.L.tg_quadratic_cost(self.device, S * M, M, N, nX, nU, self.cX.ptr, self.cU.ptr, self.Xd.ptr, self.Ud.ptr,
+                                             self.Q.ptr, self.R.ptr, self.Qf.ptr, self.ccost.ptr))
+        _, status = self.arm.status()
+        return self.ccost.get().reshape(S, M), (status == 0).reshape(S, M)
+
+    def accept(self, seeds, columns):
+        """X[s], U[s] <- candidate `columns[i]` of the current chunk for s = seeds[i]."""
+        n = len(seeds)
+        if n == 0:
+            return
+        S, N, nX, nU, M = self.S, self.N, self.nX, self.nU, self.M
+        a = np.zeros(S, dtype=np.int32)
+        b = np.zeros(S, dtype=np.int32)
+        a[:n] = seeds
+        b[:n] = np.asarray(seeds) * M + np.asarray(columns)
+        self._rows_a.set(a)
+        self._rows_b.set(b)
+        self._check(self.L.tg_copy_rows(self.device, n, (N + 1) * nX, self._rows_a.ptr, self._rows_b.ptr, self.cX.ptr, self.X.ptr))
+        self._check(self.L.tg_copy_rows(self.device, n, N * nU, self._rows_a.ptr, self._rows_b.ptr, self.cU.ptr, self.U.ptr))
+
+    # -- iteration -----------------------------------------------------------------------------------------
+    def select_method(self, iteration):
+        return self.first_method if iteration < self.first_method_iterations else self.second_method
+
+    @staticmethod
+    def _fallback(method):
+        if method == "newton":
+            return "quasi"
+        if method == "quasi":
+            return "steepest"
+        raise Exception("Derivative of cost is positive for steepest descent.")
+
+    def step(self, method="steepest", active=None):
+        """One DOptimizer.step for every active seed (doptimizer.py:462-506).  `method` is a name or a
+        per-seed list.  Returns arrays over all seeds (inactive seeds: done=True, costs NaN)."""
+        S = self.S
+        active = np.ones(S, dtype=bool) if active is None else np.asarray(active, dtype=bool).copy()
+        methods = np.array([method] * S if isinstance(method, str) else list(method), dtype=object)
+        self.linearize()
+        self.projection_gain()
+        cost0 = self.gradients_and_cost()
+        dcost0 = np.full(S, np.nan)
+        pending = active.copy()
+        while pending.any():
+            for name in METHODS:
+                seeds = np.nonzero(pending & (methods == name))[0]
+                if len(seeds) == 0:
+                    continue
+                self.descent_direction(None if len(seeds) == S else seeds, name)
+                dc = self.dcost.get()
+                dcost0[seeds] = dc[seeds]
+            bad = pending & (dcost0 > 0)
+            pending = bad
+            for s in np.nonzero(bad)[0]:
+                methods[s] = self._fallback(methods[s])
+        done = ~active | (np.abs(dcost0) < self.descent_tolerance)
+        cost1 = np.where(active, cost0, np.nan)
+        armijo = np.full(S, -1)
+        search = active & ~done
+        m0 = 0
+        while search.any() and m0 < self.armijo_max_iterations:
+            costs, ok = self.armijo_chunk(m0)
+            lam = self.armijo_beta ** np.arange(m0, m0 + self.M)
+            acc_seeds, acc_cols = [], []
+            for s in np.nonzero(search)[0]:
+                for j in range(min(self.M, self.armijo_max_iterations - m0)):
+                    if ok[s, j] and costs[s, j] < cost0[s] + self.armijo_alpha * lam[j] * dcost0[s]:
+                        acc_seeds.append(s)
+                        acc_cols.append(j)
+                        cost1[s] = costs[s, j]
+                        armijo[s] = m0 + j
+                        search[s] = False
+                        break
+            self.accept(acc_seeds, acc_cols)
+            m0 += self.M
+        if search.any():
+            raise ConvergenceError("Armijo Failed to Converge for seeds %s" % np.nonzero(search)[0][:8])
+        self.iteration += 1
+        return self.step_return(done, np.where(active, cost0, np.nan), dcost0, cost1, list(methods), armijo)
+
+    def optimize(self, max_steps=50):
+        """Runs every seed until |dcost| < descent_tolerance or max_steps; returns (converged [S], X, U)."""
+        active = np.ones(self.S, dtype=bool)
+        for i in range(max_steps):
+            r = self.step(self.select_method(i), active)
+            active &= ~r.done
+            if not active.any():
+                break
+        X, U = self.get_trajectories()
+        return ~active, X, U
