@@ -4,14 +4,13 @@
 Problem of examples/puppet-optimization.py (reference lines 20-24, 27-105, 127-185): the desired
 trajectory is the puppet simulated with its four limb strings moving sinusoidally; the initial guess is
 the same puppet with the strings held still; cost weights QD=100, QK=1, PD=1, VK=1, RHO=0.1.  One
-"iteration" is one DOptimizer.step: k-parallel linearisation (N DEL solves + deriv1 in one batch),
-TV-LQR, [Newton: adjoint + N z-contracted deriv2 in one batch], TV-LQ, forward tangent rollout,
-m-parallel Armijo (30 closed-loop N-step rollouts in one batch).
+"iteration" is one DOptimizer.step of one seed.  S seeds (perturbed initial poses, SURVEY section 8d
+config 4) are optimised together by BatchDOptimizer, device resident: S*N-way linearisation, S Riccati
+sweeps, [Newton: S adjoint sweeps + S*N z-contracted second derivatives], S LQ sweeps, S*M Armijo
+projections per chunk.  `--sequential` runs the per-seed DOptimizer (host LQR) instead.
 
-Seeds (perturbed initial poses) are processed one after the other in this round; batching the seeds as
-well is the next step.  Prints one JSON line.
-
-  python bench_discopt.py --seeds 4 --horizon 200 --quasi 2 --newton 2
+  python bench_discopt.py --seeds 256 --horizon 1000 --quasi 1 --newton 2
+Prints one JSON line.
 """
 import argparse
 import json
@@ -24,71 +23,129 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-REFERENCE_NEWTON_ITER_S = 35.0   # BASELINE.md §2: reference, puppet, N~1000: >= 35 s per Newton iteration
+REFERENCE_NEWTON_ITER_S = 35.0   # BASELINE.md section 2: reference, puppet, N~1000: >= 35 s per Newton iteration
+
+
+def problem(seeds, N, dt):
+    import trep_amd
+    from trep_amd import systems
+    system = systems.puppet()
+    nd = system.nQd
+    Q0 = systems.puppet_initial_conditions(system, seeds, seed=20250 + 4)
+    K_move = systems.puppet_string_schedule(system, Q0[:, nd:], N, dt)
+    K_still = np.repeat(Q0[:, None, nd:], N, axis=1)
+    sim = trep_amd.BatchMidpointVI(system, seeds)
+    sim.initialize_from_state(0.0, Q0, np.zeros((seeds, nd)))
+    Xd = sim.rollout(N, dt, None, K_move)
+    sim.initialize_from_state(0.0, Q0, np.zeros((seeds, nd)))
+    Xi = sim.rollout(N, dt, None, K_still)
+    sim.close()
+    wq = [100.0] * nd + [1.0] * system.nQk + [1.0] * nd + [1.0] * system.nQk
+    return system, Xd, K_move, Xi, K_still, np.diag(wq), np.diag([0.1] * system.nQk)
+
+
+def run_batched(args):
+    import trep_amd
+    from trep_amd import discopt, _lib
+    dt, N, S = 0.01, args.horizon, args.seeds
+    system, Xd, Ud, Xi, Ui, Qc, Rc = problem(S, N, dt)
+    dsys = discopt.DSystem(trep_amd.MidpointVI(system), dt * np.arange(N + 1))
+    opt = discopt.BatchDOptimizer(dsys, Xd, Ud, Qc, Rc, armijo_chunk=args.armijo_chunk)
+    L = _lib.lib()
+    methods = ["quasi"] * args.quasi + ["newton"] * args.newton
+    opt.set_trajectories(Xi, Ui)
+    opt.step(methods[0])                      # warm-up (allocations, code objects), not timed
+    opt.set_trajectories(Xi, Ui)
+    L.tg_device_synchronize(0)
+    per = {"quasi": [], "newton": []}
+    costs = []
+    n_failed = 0
+    t0 = time.perf_counter()
+    for m in methods:
+        ts = time.perf_counter()
+        r = opt.step(m)
+        L.tg_device_synchronize(0)
+        per[m].append(time.perf_counter() - ts)
+        costs.append([float(np.nanmean(r.cost0)), float(np.nanmean(r.cost1))])
+        n_failed += int(r.failed.sum())
+    elapsed = time.perf_counter() - t0
+    stages = None
+    if args.stages:                            # one more Newton step, synchronising after every stage
+        stages = {}
+
+        def timed(name, fn, *a):
+            ts = time.perf_counter()
+            out = fn(*a)
+            L.tg_device_synchronize(0)
+            stages[name] = stages.get(name, 0.0) + time.perf_counter() - ts
+            return out
+        timed("linearize (S*N DEL solves + deriv1 -> A,B)", opt.linearize)
+        timed("projection gain (Riccati)", opt.projection_gain)
+        timed("cost + gradients", opt.gradients_and_cost)
+        timed("newton curvature (adjoint + S*N deriv2z)", opt.newton_curvature, None)
+        timed("LQ sweep + tangent rollout", lambda: (opt._lq(None, opt.Q, opt.Qf, opt.R, opt.HZ, True, opt.K, opt.C),
+                                                      opt.descent_direction(None, "quasi")))
+        timed("armijo chunk (S*%d projections + costs)" % opt.M, opt.armijo_chunk, 0)
+    iters = S * len(methods)
+    out = {
+        "metric": "discopt iterations/s (puppet ~40-DOF, fp64)", "value": iters / elapsed, "unit": "iters/s",
+        "n_gpus": 1, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "puppet-optimization.py problem, nX=80 nU=18, N=%d, %d seeds batched on the device, %d quasi + %d newton steps each"
+                               % (N, S, args.quasi, args.newton), "armijo_chunk": opt.M},
+        "s_per_batched_quasi_step": float(np.mean(per["quasi"])) if per["quasi"] else None,
+        "s_per_batched_newton_step": float(np.mean(per["newton"])) if per["newton"] else None,
+        "mean_cost_before_after_per_step": costs,
+        "armijo_failures": n_failed,   # seeds where the reference would raise ConvergenceError("Armijo Failed to Converge")
+        "stage_seconds": stages,
+        "reference_s_per_newton_step_N1000_one_seed": REFERENCE_NEWTON_ITER_S,
+    }
+    opt.close()
+    print(json.dumps(out))
+
+
+def run_sequential(args):
+    import trep_amd
+    from trep_amd import discopt
+    dt, N = 0.01, args.horizon
+    system, Xd, Ud, Xi, Ui, Qc, Rc = problem(args.seeds, N, dt)
+    dsys = discopt.DSystem(trep_amd.MidpointVI(system), dt * np.arange(N + 1))
+    methods = ["quasi"] * args.quasi + ["newton"] * args.newton
+    opt = discopt.DOptimizer(dsys, discopt.DCost(Xd[0], Ud[0], Qc, Rc))
+    opt.step(0, Xi[0].copy(), Ui[0].copy(), "quasi")   # warm-up, not timed
+    per = {"quasi": [], "newton": []}
+    iters = 0
+    t0 = time.perf_counter()
+    for s in range(args.seeds):
+        opt.cost = discopt.DCost(Xd[s], Ud[s], Qc, Rc)
+        X, U = Xi[s].copy(), Ui[s].copy()
+        for i, m in enumerate(methods):
+            ts = time.perf_counter()
+            (done, X, U, dcost0, cost1) = opt.step(i, X, U, m)
+            per[m].append(time.perf_counter() - ts)
+            iters += 1
+            if done:
+                break
+    elapsed = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "discopt iterations/s (puppet ~40-DOF, fp64)", "value": iters / elapsed, "unit": "iters/s",
+        "n_gpus": 1, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "puppet-optimization.py problem, nX=80 nU=18, N=%d, %d seeds one after the other (host LQR)" % (N, args.seeds)},
+        "mean_s_per_quasi_step": float(np.mean(per["quasi"])) if per["quasi"] else None,
+        "mean_s_per_newton_step": float(np.mean(per["newton"])) if per["newton"] else None,
+        "reference_s_per_newton_step_N1000_one_seed": REFERENCE_NEWTON_ITER_S}))
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--seeds", type=int, default=4)
+    ap.add_argument("--seeds", type=int, default=32)
     ap.add_argument("--horizon", type=int, default=200, help="number of DEL steps N in the trajectory")
-    ap.add_argument("--quasi", type=int, default=2)
+    ap.add_argument("--quasi", type=int, default=1)
     ap.add_argument("--newton", type=int, default=2)
+    ap.add_argument("--armijo-chunk", type=int, default=None)
+    ap.add_argument("--stages", action="store_true", help="also report per-stage times of one Newton step")
+    ap.add_argument("--sequential", action="store_true")
     args = ap.parse_args()
-
-    import trep_amd
-    from trep_amd import systems, discopt
-
-    dt, N = 0.01, args.horizon
-    system = systems.puppet()
-    nd = system.nQd
-    t = dt * np.arange(N + 1)
-    Q0 = systems.puppet_initial_conditions(system, args.seeds, seed=20250 + 4)
-    K_move = systems.puppet_string_schedule(system, Q0[:, nd:], N, dt)
-    K_still = np.repeat(Q0[:, None, nd:], N, axis=1)
-
-    sim = trep_amd.BatchMidpointVI(system, args.seeds)
-    sim.initialize_from_state(0.0, Q0, np.zeros((args.seeds, nd)))
-    Xd = sim.rollout(N, dt, None, K_move)
-    sim.initialize_from_state(0.0, Q0, np.zeros((args.seeds, nd)))
-    Xi = sim.rollout(N, dt, None, K_still)
-    sim.close()
-
-    dsys = discopt.DSystem(trep_amd.MidpointVI(system), t)
-    wq = [100.0] * nd + [1.0] * system.nQk + [1.0] * nd + [1.0] * system.nQk
-    Qc, Rc = np.diag(wq), np.diag([0.1] * system.nQk)
-
-    results, iters = [], 0
-    methods = ['quasi'] * args.quasi + ['newton'] * args.newton
-    # warm-up (library load, engine allocation) on seed 0, not timed
-    cost = discopt.DCost(Xd[0], K_move[0], Qc, Rc)
-    opt = discopt.DOptimizer(dsys, cost)
-    opt.step(0, Xi[0].copy(), K_still[0].copy(), 'quasi')
-    per_method = {'quasi': [], 'newton': []}
-    t0 = time.perf_counter()
-    for s in range(args.seeds):
-        opt.cost = discopt.DCost(Xd[s], K_move[s], Qc, Rc)
-        X, U = Xi[s].copy(), K_still[s].copy()
-        c0 = opt.calc_cost(X, U)
-        for i, method in enumerate(methods):
-            ts = time.perf_counter()
-            (done, X, U, dcost0, cost1) = opt.step(i, X, U, method)
-            per_method[method].append(time.perf_counter() - ts)
-            iters += 1
-            if done:
-                break
-        results.append((c0, opt.calc_cost(X, U)))
-    elapsed = time.perf_counter() - t0
-    out = {
-        "metric": "discopt iterations/s (puppet ~40-DOF, fp64)", "value": iters / elapsed, "unit": "iters/s",
-        "n_gpus": 1, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "puppet-optimization.py problem, nX=80 nU=18, N=%d, seeds=%d sequential, %d quasi + %d newton steps each"
-                               % (N, args.seeds, args.quasi, args.newton)},
-        "mean_s_per_quasi_step": float(np.mean(per_method['quasi'])) if per_method['quasi'] else None,
-        "mean_s_per_newton_step": float(np.mean(per_method['newton'])) if per_method['newton'] else None,
-        "cost_reduction": [[float(a), float(b)] for a, b in results],
-        "reference_s_per_newton_step_N1000": REFERENCE_NEWTON_ITER_S,
-    }
-    print(json.dumps(out))
+    (run_sequential if args.sequential else run_batched)(args)
 
 
 if __name__ == "__main__":

@@ -216,7 +216,7 @@ def test_batch_optimizer_matches_sequential_cart():
     U0 = np.repeat(g["U0"][None], S, axis=0)
     methods = ["quasi", "quasi", "newton", "newton"]
     ref = _sequential_steps(dsys, Xd, Ud, g["Q"], g["R"], X0, U0, methods)
-    opt = discopt.BatchDOptimizer(dsys, Xd, Ud, g["Q"], g["R"], armijo_chunk=3)
+    opt = discopt.BatchDOptimizer(dsys, Xd, Ud, g["Q"], g["R"], armijo_chunk=2)
     try:
         opt.set_trajectories(X0, U0)
         for i, m in enumerate(methods):
@@ -228,6 +228,22 @@ def test_batch_optimizer_matches_sequential_cart():
                 assert abs(r.dcost0[s] - dc0) < 1e-7 * max(1.0, abs(dc0)), (i, s, r.dcost0[s], dc0)
                 assert abs(r.cost1[s] - c1) < 1e-8 * max(1.0, abs(c1)), (i, s, r.cost1[s], c1)
                 assert relerr(X[s], Xr) < 1e-7 and relerr(U[s], Ur) < 1e-7, (i, s, relerr(X[s], Xr))
+        # a demanding sufficient-decrease constant forces m > 0: exercises the chunked search (2 candidates per launch)
+        from trep_amd import discopt as _d
+        Xs, Us = opt.get_trajectories()
+        opt.armijo_alpha = 0.7
+        r = opt.step("quasi")
+        X, U = opt.get_trajectories()
+        assert (r.armijo > 0).any() and not r.failed.any()
+        for s in range(S):
+            o = _d.DOptimizer(dsys, _d.DCost(Xd[s], Ud[s], g["Q"], g["R"]))
+            o.armijo_alpha = 0.7
+            m_seen = []
+            o.monitor.armijo_evaluation = lambda m, *a: m_seen.append(m)
+            rr = o.step(0, Xs[s], Us[s], "quasi")
+            assert m_seen[-1] == r.armijo[s], (s, m_seen, r.armijo[s])
+            assert abs(rr.cost1 - r.cost1[s]) < 1e-8 * max(1.0, abs(rr.cost1))
+            assert relerr(X[s], rr.nX) < 1e-7
     finally:
         opt.close()
 

@@ -82,7 +82,7 @@ class _DevicePool(object):
 class BatchDOptimizer(object):
     """S seeds of the same DSystem, each with its own desired trajectory (xd, ud) and shared weights Q, R, Qf."""
 
-    step_return = namedtuple("batch_step", "done cost0 dcost0 cost1 method armijo")
+    step_return = namedtuple("batch_step", "done cost0 dcost0 cost1 method armijo failed")
 
     def __init__(self, dsys, Xd, Ud, Q, R, Qf=None, device=0, armijo_chunk=None, first_method_iterations=10):
         self.dsys = dsys
@@ -322,18 +322,22 @@ class BatchDOptimizer(object):
                         break
             self.accept(acc_seeds, acc_cols)
             m0 += self.M
-        if search.any():
-            raise ConvergenceError("Armijo Failed to Converge for seeds %s" % np.nonzero(search)[0][:8])
+        # a seed whose search is exhausted is where the reference raises ConvergenceError("Armijo Failed to
+        # Converge") (doptimizer.py:456-459); here it is flagged and left unchanged, the other seeds carry on
+        failed = search.copy()
         self.iteration += 1
-        return self.step_return(done, np.where(active, cost0, np.nan), dcost0, cost1, list(methods), armijo)
+        return self.step_return(done | failed, np.where(active, cost0, np.nan), dcost0, cost1, list(methods), armijo, failed)
 
     def optimize(self, max_steps=50):
-        """Runs every seed until |dcost| < descent_tolerance or max_steps; returns (converged [S], X, U)."""
+        """Runs every seed until |dcost| < descent_tolerance, an Armijo failure, or max_steps;
+        returns (converged [S], X, U)."""
         active = np.ones(self.S, dtype=bool)
+        failed = np.zeros(self.S, dtype=bool)
         for i in range(max_steps):
             r = self.step(self.select_method(i), active)
             active &= ~r.done
+            failed |= r.failed
             if not active.any():
                 break
         X, U = self.get_trajectories()
-        return ~active, X, U
+        return ~active & ~failed, X, U
