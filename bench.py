@@ -43,6 +43,12 @@ def build_secondary(args, rank):
         Q0 = np.stack([rng.uniform(-1, 1, B), rng.uniform(-np.pi, np.pi, B)], 1)
         U = rng.standard_normal((B, N, 1)) * 2.0
         return system, Q0, U, None, dt
+    if args.system == "puppet-basic":
+        # examples/puppet-basic.py: constraint-consistent poses captured from the reference's satisfy_constraints
+        system = systems.puppet_basic()
+        ics = np.load(os.path.join(ROOT, "tests", "golden", "puppet_basic.npz"))["ic_set"]
+        Q0 = np.tile(np.roll(ics, rank, axis=0), ((B + len(ics) - 1) // len(ics), 1))[:B]
+        return system, Q0, None, None, dt
     system = systems.scissor_lift(4)
     rng = np.random.default_rng(20250 + 5 + 1000 * rank)
     th = rng.uniform(0.03 * np.pi, 0.12 * np.pi, B)
@@ -64,31 +70,68 @@ def build_workload(args, rank):
     return system, Q0, K, dt
 
 
-def cpu_baseline(system, Q0, K, dt, budget_s=12.0):
-    """Oracle (C restatement of the reference, 1 thread) on a bounded sample of the same workload."""
+def host_cores():
+    """CPUs this process may actually use: affinity mask and cgroup CPU quota, not the machine's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
+def cpu_baseline(system, Q0, K, dt, budget_s=12.0, threads=None):
+    """Oracle (C restatement of the reference) on a bounded sample of the same workload: one oracle object per
+    host thread, every thread rolling out its own trajectories of the batch (the C calls release the GIL)."""
+    import threading
     from trep_amd import descriptor
     from oracle.oracle import OracleMVI
-    o = OracleMVI(descriptor.flatten(system))
-    steps = 0
-    t0 = time.perf_counter()
-    b = 0
+    threads = max(1, min(threads or min(host_cores(), 64), len(Q0)))
+    desc = descriptor.flatten(system)
+    oracles = [OracleMVI(desc) for _ in range(threads)]
+    counts = [0] * threads
     chunk = 50
-    while time.perf_counter() - t0 < budget_s and b < len(Q0):
-        o.initialize_from_configs(0.0, Q0[b], dt, Q0[b])
-        k = 0
-        while k < K.shape[1] and time.perf_counter() - t0 < budget_s:
-            n = min(chunk, K.shape[1] - k)
-            o.rollout(n, dt, None, K[b, k:k + n], want_X=False)
-            k += n
-            steps += n
-        b += 1
+    t0 = time.perf_counter()
+
+    def work(i):
+        o, b = oracles[i], i
+        while time.perf_counter() - t0 < budget_s and b < len(Q0):
+            o.initialize_from_configs(0.0, Q0[b], dt, Q0[b])
+            k = 0
+            while k < K.shape[1] and time.perf_counter() - t0 < budget_s:
+                n = min(chunk, K.shape[1] - k)
+                o.rollout(n, dt, None, K[b, k:k + n], want_X=False)
+                k += n
+                counts[i] += n
+            b += threads
+
+    pool = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    for t in pool:
+        t.start()
+    for t in pool:
+        t.join()
     el = time.perf_counter() - t0
-    return {"value": steps / el, "unit": "DEL-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d puppet-40 DEL steps of the same rollouts, oracle/libtreporacle.so single thread, %.1f s" % (steps, el),
+    steps = sum(counts)
+    return {"value": steps / el, "unit": "DEL-steps/s", "cores": threads, "kind": "port",
+            "sample": "%d puppet-40 DEL steps of the same rollouts, oracle/libtreporacle.so on %d host threads (%d usable of %d cores), %.1f s"
+                      % (steps, threads, host_cores(), os.cpu_count() or 1, el),
+            "per_thread_steps_per_s": steps / el / threads,
             "reference_trep_single_core_steps_per_s": REFERENCE_TREP_STEPS_PER_S}
 
 
-def pmc_traffic(batch, rollout_steps):
+def pmc_traffic(batch, rollout_steps, workload_prefix):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json), if one
     exists for exactly this workload; PMC collection needs rocprofv3 around the process, so bench.py
     cannot measure it live (tools/collect_profile.sh + tools/summarize_pmc.py produce the file)."""
@@ -99,7 +142,7 @@ def pmc_traffic(batch, rollout_steps):
             d = json.load(open(path))
         except Exception:
             continue
-        if d.get("global_batch") == batch and d.get("rollout_steps") == rollout_steps:
+        if d.get("global_batch") == batch and d.get("rollout_steps") == rollout_steps and str(d.get("workload", "")).startswith(workload_prefix):
             best = (d["hbm_bytes_per_launch"], os.path.relpath(path, ROOT))
     return best
 
@@ -113,7 +156,7 @@ def main():
     ap.add_argument("--rollout-steps", type=int, default=200, help="DEL steps per trajectory per pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-x", action="store_true", help="do not write the state trajectory X to HBM")
-    ap.add_argument("--system", choices=["puppet", "cart", "scissor"], default="puppet",
+    ap.add_argument("--system", choices=["puppet", "puppet-basic", "cart", "scissor"], default="puppet",
                     help="puppet = the BASELINE metric; cart / scissor = secondary lines")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank (self-test)")
     args = ap.parse_args()
@@ -199,14 +242,15 @@ def main():
         bytes_per_step = 8.0 * (2 * nX + nU + nc)   # read X_k, U_k; write X_k+1, lambda
         algo_bytes = bytes_per_step * B * N
         achieved = algo_bytes / avg_kernel_s / 1e9
-        traffic = pmc_traffic(B, N) if world == 1 else None
+        traffic = pmc_traffic(B, N, "Puppet(string_constraints=True)") if (world == 1 and args.system == "puppet") else None
         out = {
             "metric": "DEL-steps/sec x batch (%s, fp64)" % ("puppet ~40-DOF" if args.system == "puppet" else args.system),
             "value": value, "unit": "DEL-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("Puppet(string_constraints=True) nq=40 nd=22 nk=18 nc=6" if args.system == "puppet" else
-                                    ("pend-on-cart nd=2 nu=1" if args.system == "cart" else "scissor-4 nd=9 nc=8")) +
+                                    {"cart": "pend-on-cart nd=2 nu=1", "scissor": "scissor-4 nd=9 nc=8",
+                                     "puppet-basic": "examples/puppet-basic.py nd=22 nc=6 (fixed-length strings)"}[args.system]) +
                                    ", batch=%d rollouts per GPU x %d DEL steps, dt=0.01" % (B, N),
                        "global_batch": world * B, "rollout_steps": N, "parallelism": "batch-shard x%d" % world,
                        "team": mvi.info()["team"], "lds_bytes_per_trajectory": mvi.info()["lds_bytes_per_trajectory"],

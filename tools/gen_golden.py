@@ -220,6 +220,38 @@ def gen_puppet():
 
 
 
+def gen_puppet_basic():
+    """examples/puppet-basic.py: the starting guess of the script and seeded perturbations of it, each made
+    consistent with the six string constraints by the reference's own System.satisfy_constraints (SLSQP; the
+    build does not re-implement it, the consistent poses are fixture data), then free-running rollouts."""
+    system = systems.puppet_basic(api=trep)
+    rng = np.random.default_rng(20250 + 6)
+    n_ic, N = 16, 200
+    joints = [c.name for c in system.configs if c.name not in ('TorsoX', 'TorsoY', 'TorsoZ')]
+    ics = []
+    for b in range(n_ic):
+        system.q = 0.0
+        system.q = systems.PUPPET_BASIC_POSE
+        if b:
+            for name in joints:
+                c = system.get_config(name)
+                c.q = c.q + rng.uniform(-0.05, 0.05)
+        system.satisfy_constraints()
+        assert max(abs(c.h()) for c in system.constraints) < 1e-8
+        ics.append(system.q.copy())
+    ics = np.array(ics)
+    U = np.zeros((N, 0)); K = np.zeros((N, 0))
+    arrays = dict(dt=DT, ic_set=ics, **topology(system))
+    select = ("q2_dq1dq1", "p2_dq1dp1", "l1_dq1dq1", "q2_dp1dp1", "p2_dp1dp1")
+    for b in range(2):
+        r = rollout(system, ics[b], U, K, N, deriv_steps=(1, 100) if b == 0 else (), deriv2_select=select)
+        for key, val in r.items():
+            arrays["b%d_%s" % (b, key)] = val
+        arrays["b%d_q0" % b] = ics[b]
+    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], U, K, (0, 10, 100), seed=15)
+    save("puppet_basic", **arrays, **ds)
+
+
 def gen_discopt_cart():
     """One DOptimizer trace on the pend-on-cart problem of examples/pend-on-cart-optimization.py:48-116
     (torque input enabled, 5 s horizon): a few quasi-Newton then Newton steps; per step the method,
@@ -277,7 +309,7 @@ def gen_discopt_cart():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "discopt"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "discopt"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -290,5 +322,7 @@ if __name__ == "__main__":
         gen_scissor()
     if "puppet" in which:
         gen_puppet()
+    if "puppet_basic" in which:
+        gen_puppet_basic()
     if "discopt" in which:
         gen_discopt_cart()

@@ -7,6 +7,7 @@ reference example script defines:
   pend_on_cart()       examples/pend-on-cart-optimization.py:48-64
   scissor_lift(n)      examples/scissor.py:53-105        (closed chain, PointToPoint2D)
   puppet()             trep/puppets/puppets.py:220-253   (Puppet(string_constraints=True))
+  puppet_basic()       examples/puppet-basic.py:15-84    (22 dynamic configs, six fixed-length strings)
 
 plus the synthetic initial conditions SURVEY.md §8(d) prescribes for each.
 """
@@ -99,6 +100,65 @@ def scissor_q(system, theta_0, L_link=5.0):
 def puppet(api=None):
     T = _api(api)
     return T.puppets.Puppet(joint_forces=False, string_forces=False, string_constraints=True)
+
+
+def puppet_basic(api=None):
+    """The humanoid marionette of examples/puppet-basic.py:15-84: a 6-DOF torso, two 4-DOF arms, two 4-DOF
+    legs (22 dynamic configs, no kinematic ones), gravity, uniform damping 0.1 and six strings of constant
+    length (Distance constraints) hanging from a fixed frame 14 units up.  Frame and config names are the
+    example's, so configurations can be exchanged by name."""
+    T = _api(api)
+    tx, ty, tz, rx, ry, rz = T.tx, T.ty, T.tz, T.rx, T.ry, T.rz
+
+    def ball(prefix, name, children):
+        # three intersecting revolute axes (z, y, x), the last one carries the limb and its frame name
+        return [rz(prefix + 'Psi'), [ry(prefix + 'Theta'), [rx(prefix + 'Phi', name=name), children]]]
+
+    def arm(side, letter, sx):
+        hand = [tx(0.14 * sx), [ty(-0.173, name=side + ' Finger')]]
+        forearm = [tz(-1, name=side + ' Radius', mass=(4, 1, 1, 1)), tz(-2.001), hand]
+        upper = [tz(-0.95, name=side + ' Humerus', mass=(5, 1, 1, 1)),
+                 tz(-1.9), [rx(letter + 'ElbowTheta', name=side + ' Elbow'), forearm]]
+        return [tx(1.3 * sx), [tz(0.4), ball(letter + 'Shoulder', side + ' Shoulder', upper)]]
+
+    def leg(side, letter, sx, knee_name):
+        shank = [tz(-1.5, name=side + ' Tibia', mass=(4, 1, 1, 1))]
+        thigh = [tz(-1.5, name=side + ' Femur', mass=(5, 1, 1, 1)),
+                 tz(-2.59), [ty(-0.322, name=side + ' Knee Hook')],
+                 tz(-3.0), [rx(letter + 'KneeTheta', name=knee_name), shank]]
+        return [tx(0.5 * sx), [tz(-3.0), ball(letter + 'Hip', side + ' Hip', thigh)]]
+
+    torso = [tz(-1.5, mass=50),
+             tx(-1.011), [tz(0.658, name='Right Torso Hook')],
+             tx(1.011), [tz(0.658, name='Left Torso Hook')],
+             tz(0.9, name='Head'), [tz(0.5, mass=(10, 1, 1, 1))]]
+    torso += arm('Left', 'L', 1) + arm('Right', 'R', -1)
+    torso += leg('Left', 'L', 1, 'Left Knee') + leg('Right', 'R', -1, 'right Knee')
+    body = [tx('TorsoX'), [ty('TorsoY'), [tz('TorsoZ'), [
+        rz('TorsoPsi'), [ry('TorsoTheta'), [rx('TorsoPhi', name='Torso'), torso]]]]]]
+    spindles = [tx(1, name='Left Torso Spindle'), tx(-1, name='Right Torso Spinde'),
+                tx(1), [ty(-1, name='Left Arm Spindle')], tx(-1), [ty(-1, name='Right Arm Spindle')],
+                tx(1), [ty(-2, name='Left Leg Spindle')], tx(-1), [ty(-2, name='Right Leg Spindle')]]
+    system = T.System()
+    system.import_frames(body + [tz(14, name='Frame Plane'), spindles])
+    T.potentials.Gravity(system, (0, 0, -9.8))
+    T.forces.Damping(system, 0.1)
+    for hook, spindle, length in (('Left Torso Hook', 'Left Torso Spindle', 13.4),
+                                  ('Right Torso Hook', 'Right Torso Spinde', 13.4),
+                                  ('Left Finger', 'Left Arm Spindle', 15.4),
+                                  ('Right Finger', 'Right Arm Spindle', 15.5),
+                                  ('Left Knee Hook', 'Left Leg Spindle', 18.6),
+                                  ('Right Knee Hook', 'Right Leg Spindle', 18.6)):
+        T.constraints.Distance(system, hook, spindle, length)
+    return system
+
+
+# Starting guess of examples/puppet-basic.py:87-98 (made consistent by System.satisfy_constraints there; the
+# consistent poses used here come from tests/golden/puppet_basic.npz, captured from the reference).
+PUPPET_BASIC_POSE = {
+    'TorsoX': 1, 'TorsoY': 1, 'LElbowTheta': -1.57, 'RElbowTheta': -1.57, 'LHipTheta': -0.314, 'RHipTheta': 0.314,
+    'LHipPhi': -0.785, 'RHipPhi': -0.785, 'LKneeTheta': 0.785, 'RKneeTheta': 0.785,
+}
 
 
 # Base pose of the reference's puppet-optimization example
