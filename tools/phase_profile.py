@@ -7,9 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import trep_amd
 from trep_amd import systems, _lib
 
-NAMES = ["rates/other", "pose sweep (mid)", "attach+jacobians", "velocities", "residual", "pose sweep (q1/q2)",
+NAMES = ["update+rates+step setup", "pose sweep (mid)", "attach+jacobians", "velocities", "residual", "pose sweep (q1/q2)",
          "attach+constraints", "newton init", "newton pairs", "GJ scales", "GJ pivot+swap", "GJ eliminate",
-         "converged?", "tail", "(sincos part of sweeps)", ""]
+         "converged?", "tail", "Gauss-Jordan (registers)", ""]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 system = systems.puppet()

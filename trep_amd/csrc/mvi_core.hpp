@@ -683,6 +683,9 @@ struct Core {
             // broadcast the pivot row (columns k..N-1 and the rhs)
             const int src = (TEAM == 64) ? __builtin_amdgcn_readfirstlane(piv) : piv;
             auto bcast = [&](double v) -> double {
+#if defined(TG_GJ_BPERMUTE)
+                return __shfl(v, src, TEAM);
+#endif
                 if (TEAM == 64) {
                     const long long b = __double_as_longlong(v);
                     const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFLL), src);
@@ -703,6 +706,19 @@ struct Core {
             for (int j = k + 1; j < N; j++) row[j] = fma(-l, bcast(row[j]), row[j]);
             rhs = fma(-l, prhs, rhs);
             if (go && is_piv) { mycol = k; diag = row[k]; }
+            // Keep the elimination pivot-major: left alone, the instruction selector linearises the fully
+            // unrolled body column by column (fma -> readlane of the same register -> fma ...): one long
+            // dependent chain padded with hazard s_nops.  Passing the updated row through ordered empty asm
+            // statements pins step k before step k+1; inside a step the broadcasts and fmas are independent.
+#pragma unroll
+            for (int j = k + 1; j < N; j += 8) {
+                if (j + 7 < N) asm volatile("" : "+v"(row[j]), "+v"(row[j + 1]), "+v"(row[j + 2]), "+v"(row[j + 3]),
+                                                 "+v"(row[j + 4]), "+v"(row[j + 5]), "+v"(row[j + 6]), "+v"(row[j + 7]));
+                else {
+#pragma unroll
+                    for (int jj = j; jj < N; jj++) asm volatile("" : "+v"(row[jj]));
+                }
+            }
         }
         if (mine && ok && mycol >= 0 && mycol < n) A[mycol * ld + n] = rhs / diag;
         __syncthreads();
@@ -1011,6 +1027,7 @@ struct Core {
 
     // third-order Lagrangian pieces of one body for an ORDERED triple of path items (x, y, o)
     struct Third { double q, dx, dy, dO, eo, ey, ex; };
+    TG_HD static int sym(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }  // packed lower triangle
     TG_HD void sort2(int &a, int &b) const { if (a > b) { const int t_ = a; a = b; b = t_; } }
     TG_HD void vel2(int x, int y, double *out) const {  // d2v/dq_x dq_y = [W_min, J_max]
         sort2(x, y);
@@ -1060,14 +1077,20 @@ struct Core {
 
     TG_HD void deriv2z(bool on, const RunArgs &A, size_t t) {
         const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nf = P.nf;
-        const int ld = P.d_aug_ld, R = P.d_nrhs;
+        const int ld = P.d_aug_ld, R = P.d_nrhs, hl = nq | 1;   // odd row stride of the H tables: no LDS bank conflicts
         double *AUG = S + P.d_o_AUG, *T22 = S + P.d_o_T22;
         double *H11 = S + P.e_o_H11, *H12 = S + P.e_o_H12, *H22 = S + P.e_o_H22, *G1 = S + P.e_o_G1;
         double *w = S + P.e_o_w, *zq = S + P.e_o_zq, *zp = S + P.e_o_zp, *vec = S + P.e_o_vec;
         const int c_p1 = nf + nq, c_ex = nf + R;
         const bool ok = deriv1_solve(on, true);
+#if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        long long d2t[6] = {0, 0, 0, 0, 0, 0};
+        long long d2last = (long long)__builtin_amdgcn_s_memtime();
+#define TG_D2STAMP(i) do { long long t_ = (long long)__builtin_amdgcn_s_memtime(); d2t[i] += t_ - d2last; d2last = t_; } while (0)
+#else
+#define TG_D2STAMP(i) ((void)0)
+#endif
         if (on) {
-            TG_FOR(i, nq * nq) { H11[i] = 0.0; H12[i] = 0.0; H22[i] = 0.0; }
             TG_FOR(i, nq * nc) G1[i] = 0.0;
             TG_FOR(i, nd) { zq[i] = A.z[t * P.nX + i]; zp[i] = A.z[t * P.nX + nq + i]; }
         }
@@ -1077,6 +1100,13 @@ struct Core {
             double r = zq[i];
             for (int o = 0; o < nd; o++) r += T22[i * nd + o] * zp[o];
             vec[i] = r;
+        }
+        TG_SYNC();
+        // the two D.D2L2 tables of the first-derivative solve are dead now; the H tables take their place.
+        // H11 and H22 are symmetric and stored packed (lower triangle); H12 is full with an odd row stride.
+        if (on) {
+            TG_FOR(i, nq * (nq + 1) / 2) { H11[i] = 0.0; H22[i] = 0.0; }
+            TG_FOR(i, nq * hl) H12[i] = 0.0;
         }
         TG_SYNC();
         if (on) TG_FOR(j, nf) {
@@ -1092,112 +1122,126 @@ struct Core {
         if (nc) {
             pose_sweep(on, 1);
             attach_points(on, false, true);
-            for (int c = 0; c < nc; c++) {
-                const int n0 = P.cu_off[c], cnt = P.cu_off[c + 1] - n0;
-                if (on) {
-                    const int cwl = tile_log2<TEAM>(cnt), cw = 1 << cwl, rstep = TEAM >> cwl;
-                    for (int a = lane >> cwl; a < cnt; a += rstep)
-                        for (int bq = lane & (cw - 1); bq < cnt; bq += cw) {
-                            const int na = n0 + a, nb = n0 + bq, ka = P.dh_cfg[na], kb = P.dh_cfg[nb];
-                            double acc = 0.0;
-                            for (int oo = 0; oo < cnt; oo++) {
-                                const int no = n0 + oo, ko = P.dh_cfg[no];
-                                if (ko >= nd) continue;
-                                acc += w[ko] * con_d3(c, na, nb, no);
-                            }
-                            H11[ka * nq + kb] += S[P.o_lam + c] * acc;
-                            if (bq == 0) {  // G1[ka][c] = sum_o w_o h_c,dqdq(ka, o)
-                                double g = 0.0;
-                                for (int oo = 0; oo < cnt; oo++) {
-                                    const int no = n0 + oo, ko = P.dh_cfg[no];
-                                    if (ko < nd) g += w[ko] * con_d2(c, na, no);
-                                }
-                                G1[ka * nc + c] = g;
-                            }
-                        }
+            // one lane per (constraint, a <= b) pair of the flat list; third derivatives are symmetric in (a, b).
+            // Several constraints reach the same entry: LDS atomics (one wavefront, fixed order, deterministic).
+            if (on) TG_FOR(pp, P.n_cpair) {
+                const int *pw = P.cpair4 + 4 * (size_t)pp;
+                const int c = pw[0], na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+                const int n0 = P.cu_off[c], n1 = P.cu_off[c + 1];
+                double acc = 0.0;
+                for (int no = n0; no < n1; no++) {
+                    const int ko = P.dh_cfg[no];
+                    if (ko >= nd) continue;
+                    acc += w[ko] * con_d3(c, na, nb, no);
                 }
-                TG_SYNC();
+                const double val = S[P.o_lam + c] * acc;
+                lds_add(&H11[sym(ka, kb)], val);
             }
+            if (on) TG_FOR(na, P.n_dh) {  // G1[ka][c] = sum_o w_o h_c,dqdq(ka, o)
+                const int c = P.dh_c[na], n0 = P.cu_off[c], n1 = P.cu_off[c + 1];
+                double g = 0.0;
+                for (int no = n0; no < n1; no++) {
+                    const int ko = P.dh_cfg[no];
+                    if (ko < nd) g += w[ko] * con_d2(c, na, no);
+                }
+                G1[P.dh_cfg[na] * nc + c] = g;
+            }
+            TG_SYNC();
             // ---- constraints at q2: H22 -= sum_c w_lambda,c DDh2[c] (calc_h2_deriv2 :1597-1622) -------------
             pose_sweep(on, 2);
             attach_points(on, false, true);
-            for (int c = 0; c < nc; c++) {
-                const int n0 = P.cu_off[c], cnt = P.cu_off[c + 1] - n0;
-                if (on) {
-                    const int cwl = tile_log2<TEAM>(cnt), cw = 1 << cwl, rstep = TEAM >> cwl;
-                    for (int a = lane >> cwl; a < cnt; a += rstep)
-                        for (int bq = lane & (cw - 1); bq < cnt; bq += cw) {
-                            const int na = n0 + a, nb = n0 + bq;
-                            H22[P.dh_cfg[na] * nq + P.dh_cfg[nb]] -= w[nd + c] * con_d2(c, na, nb);
-                        }
-                }
-                TG_SYNC();
-            }
-        }
-        // ---- midpoint: third-order discrete-Lagrangian tables contracted on the fly --------------------------
-        eval_midpoint(on);
-        const double c8 = 0.125 * dt, c2 = 0.5 / dt;
-        for (int b = 0; b < P.n_bodies; b++) {
-            const int i0 = P.b_item_off[b], n = P.b_item_off[b + 1] - i0;
-            if (on) {
-                const int cwl = tile_log2<TEAM>(n), cw = 1 << cwl, rstep = TEAM >> cwl;
-                for (int xi = lane >> cwl; xi < n; xi += rstep)
-                    for (int yi = lane & (cw - 1); yi < n; yi += cw) {
-                        const int x = i0 + xi, y = i0 + yi;
-                        double h11 = 0.0, h12 = 0.0, h22 = 0.0;
-                        for (int oi = 0; oi < n; oi++) {
-                            const int o = i0 + oi, ko = P.it_cfg[o];
-                            if (ko >= nd) continue;
-                            const Third T = third_order(b, x, y, o);
-                            const double q = c8 * T.q, dx = 0.25 * T.dx, dy = 0.25 * T.dy, dO = 0.25 * T.dO;
-                            const double eo = c2 * T.eo, ey = c2 * T.ey, ex = c2 * T.ex;
-                            // T(sa,sb,so) = q + sa dx + sb dy + so dO + sa sb eo + sa so ey + sb so ex  (midpointvi.c:1122-1453)
-                            const double t111 = q - dx - dy - dO + eo + ey + ex, t112 = q - dx - dy + dO + eo - ey - ex;
-                            const double t121 = q - dx + dy - dO - eo + ey - ex, t122 = q - dx + dy + dO - eo - ey + ex;
-                            const double t221 = q + dx + dy - dO + eo - ey - ex, t222 = q + dx + dy + dO + eo + ey + ex;
-                            h11 += -w[ko] * t111 + zp[ko] * t112;
-                            h12 += -w[ko] * t121 + zp[ko] * t122;
-                            h22 += -w[ko] * t221 + zp[ko] * t222;
-                        }
-                        const int kx = P.it_cfg[x], ky = P.it_cfg[y];
-                        H11[kx * nq + ky] += h11; H12[kx * nq + ky] += h12; H22[kx * nq + ky] += h22;
-                    }
+            if (on) TG_FOR(pp, P.n_cpair) {
+                const int *pw = P.cpair4 + 4 * (size_t)pp;
+                const int c = pw[0], na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+                const double val = -w[nd + c] * con_d2(c, na, nb);
+                lds_add(&H22[sym(ka, kb)], val);
             }
             TG_SYNC();
         }
+        TG_D2STAMP(0);
+        // ---- midpoint: third-order discrete-Lagrangian tables contracted on the fly --------------------------
+        eval_midpoint(on);
+        TG_D2STAMP(1);
+        const double c8 = 0.125 * dt, c2 = 0.5 / dt;
+        // one lane per ordered (item x, item y) pair of the flat list over all bodies; the output index o runs over the
+        // body's items.  Bodies share configs, so the accumulation uses LDS atomics like the Newton matrix.
+        if (on) TG_FOR(pp, P.n_tri) {
+            const int *pw = P.tri4 + 4 * (size_t)pp;
+            const int x = pw[0], y = pw[1], kx = pw[2] & 0xFFFF, ky = pw[2] >> 16, b = pw[3];
+            const int i0 = P.b_item_off[b], i1 = P.b_item_off[b + 1];
+            double h11 = 0.0, h12 = 0.0, h22 = 0.0;
+            for (int o = i0; o < i1; o++) {
+                const int ko = P.it_cfg[o];
+                if (ko >= nd) continue;
+                const Third T = third_order(b, x, y, o);
+                const double q = c8 * T.q, dx = 0.25 * T.dx, dy = 0.25 * T.dy, dO = 0.25 * T.dO;
+                const double eo = c2 * T.eo, ey = c2 * T.ey, ex = c2 * T.ex;
+                // T(sa,sb,so) = q + sa dx + sb dy + so dO + sa sb eo + sa so ey + sb so ex  (midpointvi.c:1122-1453)
+                const double t111 = q - dx - dy - dO + eo + ey + ex, t112 = q - dx - dy + dO + eo - ey - ex;
+                const double t121 = q - dx + dy - dO - eo + ey - ex, t122 = q - dx + dy + dO - eo - ey + ex;
+                const double t221 = q + dx + dy - dO + eo - ey - ex, t222 = q + dx + dy + dO + eo + ey + ex;
+                h11 += -w[ko] * t111 + zp[ko] * t112;
+                h12 += -w[ko] * t121 + zp[ko] * t122;
+                h22 += -w[ko] * t221 + zp[ko] * t222;
+            }
+            lds_add(&H12[kx * hl + ky], h12);
+            if (x <= y) { lds_add(&H11[sym(kx, ky)], h11); lds_add(&H22[sym(kx, ky)], h22); }   // (y, x) gives the same value
+        }
+        TG_SYNC();
+        TG_D2STAMP(2);
         // ---- assemble HZ[a][b] column by column ------------------------------------------------------------------
         // tangents: y_b = (x_b, e_i for a k2 variable) with x_b = AUG[0..nd)[nf+b]; l_b = AUG[nd..nf)[nf+b]
-        double *hy = vec, *h12y = vec + nq, *g1l = vec + 2 * nq;
+        // HZ is symmetric; the value computed for (row a, column bcol) is stored at [bcol][a] so that the lanes of
+        // a phase write one contiguous row.  The per-column vectors are double-buffered (second copy in the dead
+        // H-independent scratch `vec2`), so the tangent products of column b+1 share a phase with the rows of
+        // column b: one barrier per column.
         const int first_k2 = nq + nd + nu;
-        for (int bcol = 0; bcol < R; bcol++) {
-            if (on) TG_FOR(j, nq) {
+        auto column_vectors = [&](int bcol, double *buf) {
+            double *hy = buf, *h12y = buf + nq, *g1l = buf + 2 * nq;
+            TG_FOR(j, nq) {
                 double a22 = 0.0, a12 = 0.0, ag = 0.0;
+#pragma unroll 4
                 for (int i2 = 0; i2 < nd; i2++) {
                     const double yb = AUG[i2 * ld + nf + bcol];
-                    a22 += H22[j * nq + i2] * yb; a12 += H12[j * nq + i2] * yb;
+                    a22 += H22[sym(j, i2)] * yb; a12 += H12[j * hl + i2] * yb;
                 }
-                if (bcol >= first_k2) { a22 += H22[j * nq + nd + (bcol - first_k2)]; a12 += H12[j * nq + nd + (bcol - first_k2)]; }
+                if (bcol >= first_k2) { a22 += H22[sym(j, nd + (bcol - first_k2))]; a12 += H12[j * hl + nd + (bcol - first_k2)]; }
+#pragma unroll 2
                 for (int c = 0; c < nc; c++) ag += G1[j * nc + c] * AUG[(nd + c) * ld + nf + bcol];
                 hy[j] = a22; h12y[j] = a12; g1l[j] = ag;
             }
-            TG_SYNC();
+        };
+        double *vec2 = S + P.e_o_vec2;
+        if (on) column_vectors(0, vec);
+        TG_SYNC();
+        for (int bcol = 0; bcol < R; bcol++) {
+            const double *cur = (bcol & 1) ? vec2 : vec;
+            const double *hy = cur, *h12y = cur + nq, *g1l = cur + 2 * nq;
+            if (on && bcol + 1 < R) column_vectors(bcol + 1, (bcol & 1) ? vec : vec2);
             if (on) TG_FOR(a, R) {
                 double acc = 0.0;
+#pragma unroll 4
                 for (int i2 = 0; i2 < nd; i2++) acc += AUG[i2 * ld + nf + a] * hy[i2];
                 if (a >= first_k2) acc += hy[nd + (a - first_k2)];
                 if (a < nq) acc += h12y[a] + g1l[a];
                 if (bcol < nq) {
                     double s12 = 0.0, sg = 0.0;
-                    for (int i2 = 0; i2 < nd; i2++) s12 += H12[bcol * nq + i2] * AUG[i2 * ld + nf + a];
-                    if (a >= first_k2) s12 += H12[bcol * nq + nd + (a - first_k2)];
+#pragma unroll 4
+                    for (int i2 = 0; i2 < nd; i2++) s12 += H12[bcol * hl + i2] * AUG[i2 * ld + nf + a];
+                    if (a >= first_k2) s12 += H12[bcol * hl + nd + (a - first_k2)];
+#pragma unroll 2
                     for (int c = 0; c < nc; c++) sg += G1[bcol * nc + c] * AUG[(nd + c) * ld + nf + a];
                     acc += s12 + sg;
-                    if (a < nq) acc += H11[a * nq + bcol];
+                    if (a < nq) acc += H11[sym(a, bcol)];
                 }
-                A.hz[(t * R + a) * R + bcol] = ok ? acc : NAN;
+                A.hz[(t * R + bcol) * R + a] = ok ? acc : NAN;
             }
             TG_SYNC();
         }
+        TG_D2STAMP(3);
+#if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        if (A.prof_out && t == 0 && lane == 0) for (int i = 0; i < 6; i++) A.prof_out[i] = d2t[i];
+#endif
     }
 
     // team-uniform convergence test (midpointvi.c:672-689)
@@ -1376,6 +1420,9 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
             } else
 #endif
                 ok = core.gauss_jordan(!done, S + P.o_Df, P.nf, 1, P.df_ld, S + P.o_scal);
+#if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+            { long long t_ = (long long)__builtin_amdgcn_s_memtime(); core.prof[14] += t_ - core.prof_last; core.prof_last = t_; }
+#endif
             if (!done && !ok) { done = true; failed = true; status = TG_SINGULAR; }
             if (!done) {
                 TG_FOR(i, nd) S[P.o_q2 + i] -= S[P.o_Df + i * P.df_ld + P.nf];

@@ -45,6 +45,10 @@ struct DevProg {
     const int *pair_b;        // [n_pairs] item index of the config nearer the body (may equal pair_a)
     const int *pair4;         // [n_npairs*4] dynamic-dynamic pairs only: {item a, item b, config a | config b << 16, body}
     int n_npairs;
+    // second-derivative kernel: every ORDERED (item x, item y) pair of every body {x, y, config x | config y << 16, body}
+    // and every (constraint, dh-item a <= dh-item b) pair {c, na, nb, config a | config b << 16}
+    const int *tri4, *cpair4;
+    int n_tri, n_cpair;
     const int *cfg_item_off;  // [nq+1] CSR config -> items
     const int *cfg_items;     // [n_items]
     const int *it_slot;       // [n_items] position of the item in the config-sorted order (inverse of cfg_items)
@@ -68,7 +72,7 @@ struct DevProg {
     // z-contracted second-derivative kernel: contracted Hessians H11/H12/H22 [nq][nq], G1 [nq][nc], vectors
     const int *cu_off;        // [nc+1] dh items of each constraint (its dependent configs)
     const int *tab_i; const double *tab_d; int n_tab_i, n_tab_d;  // the packed table buffers (all pointers above point into them)
-    int e_o_H11, e_o_H12, e_o_H22, e_o_G1, e_o_w, e_o_zq, e_o_zp, e_o_vec, e_lds_per_team;
+    int e_o_H11, e_o_H12, e_o_H22, e_o_G1, e_o_w, e_o_zq, e_o_zp, e_o_vec, e_o_vec2, e_lds_per_team;
 };
 
 struct HostProgram {
@@ -77,7 +81,7 @@ struct HostProgram {
     std::vector<double> j_pre;
     std::vector<int> b_anchor;
     std::vector<double> b_C, b_inertia;
-    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4;
+    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4, tri4, cpair4;
     std::vector<int> e_anchor;
     std::vector<double> e_off;
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
@@ -252,6 +256,12 @@ inline HostProgram build_program(const tg_system_desc *d) {
     }
     H.it_slot.assign(nitems, 0);
     for (int n = 0; n < nitems; n++) H.it_slot[H.cfg_items[n]] = n;
+    for (int b = 0; b < nb; b++)
+        for (int x = H.b_item_off[b]; x < H.b_item_off[b + 1]; x++)
+            for (int y = H.b_item_off[b]; y < H.b_item_off[b + 1]; y++) {
+                H.tri4.push_back(x); H.tri4.push_back(y);
+                H.tri4.push_back(H.it_cfg[x] | (H.it_cfg[y] << 16)); H.tri4.push_back(b);
+            }
     // constraint end points (unique frames) and constraint-Jacobian items
     std::map<int, int> ep_of_frame;
     auto endpoint = [&](int f) {
@@ -286,6 +296,12 @@ inline HostProgram build_program(const tg_system_desc *d) {
     H.cu_off.assign(nc + 1, 0);
     for (size_t n = 0; n < H.dh_c.size(); n++) H.cu_off[H.dh_c[n] + 1] = (int)n + 1;
     for (int c = 0; c < nc; c++) if (H.cu_off[c + 1] < H.cu_off[c]) H.cu_off[c + 1] = H.cu_off[c];
+    for (int c = 0; c < nc; c++)
+        for (int na = H.cu_off[c]; na < H.cu_off[c + 1]; na++)
+            for (int nb2 = na; nb2 < H.cu_off[c + 1]; nb2++) {
+                H.cpair4.push_back(c); H.cpair4.push_back(na); H.cpair4.push_back(nb2);
+                H.cpair4.push_back(H.dh_cfg[na] | (H.dh_cfg[nb2] << 16));
+            }
     // forces / potentials
     H.damp.assign(nd, 0.0);
     for (int i = 0; i < d->n_damping; i++)
@@ -299,6 +315,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.n_endpoints = (int)H.e_anchor.size(); P.n_dh = (int)H.dh_c.size(); P.n_cf = (int)H.cf_cfg.size();
     P.n_cfgitems = (int)H.cfg_items.size();
     P.n_npairs = (int)(H.pair4.size() / 4);
+    P.n_tri = (int)(H.tri4.size() / 4); P.n_cpair = (int)(H.cpair4.size() / 4);
     P.grav[0] = P.grav[1] = P.grav[2] = 0.0;
     for (int i = 0; i < d->n_gravity; i++)
         for (int k = 0; k < 3; k++) P.grav[k] += d->gravity[3 * (size_t)i + k];
@@ -336,9 +353,13 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.d_o_AUG = take(P.nf * P.d_aug_ld);
     P.d_o_T12 = take(nq * nd); P.d_o_T22 = take(nq * nd);
     P.d_lds_per_team = (off + 1) & ~1;
-    // second-derivative (z-contracted) kernel: appended after the deriv1 layout
-    P.e_o_H11 = take(nq * nq); P.e_o_H12 = take(nq * nq); P.e_o_H22 = take(nq * nq); P.e_o_G1 = take(nq * nc);
-    P.e_o_w = take(P.nf); P.e_o_zq = take(nd); P.e_o_zp = take(nd); P.e_o_vec = take(3 * nq);
+    // second-derivative (z-contracted) kernel: starts where the two D.D2L2 tables of the deriv1 layout are (they are
+    // dead once the adjoint's right-hand side is formed); H11 / H22 are symmetric and stored packed.  Puppet-40:
+    // 79.8 KB per trajectory -> two wavefronts per CU.
+    off = P.d_o_T12;
+    P.e_o_H11 = take(nq * (nq + 1) / 2); P.e_o_H22 = take(nq * (nq + 1) / 2); P.e_o_H12 = take(nq * (nq | 1)); P.e_o_G1 = take(nq * nc);
+    P.e_o_w = take(P.nf); P.e_o_zq = take(nd); P.e_o_zp = take(nd); P.e_o_vec = take(3 * nq); P.e_o_vec2 = take(3 * nq);
+    off = std::max(off, P.d_lds_per_team);
     P.e_lds_per_team = (off + 1) & ~1;
     H.pack();
     return H;
@@ -359,7 +380,8 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
 #define TG_INT_TABLES(X)                                                                                     \
     X(level_off) X(j_parent) X(j_kind) X(j_cfg) X(j_pre_ident) X(b_anchor) X(b_item_off) X(b_pair_off) X(it_body) \
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
-    X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4)
+    X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
+    X(tri4) X(cpair4)
 #define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp)
 
 inline void HostProgram::pack() {
