@@ -85,7 +85,7 @@ def run_batched(args):
         timed("newton curvature (adjoint + S*N deriv2z)", opt.newton_curvature, None)
         timed("LQ sweep + tangent rollout", lambda: (opt._lq(None, opt.Q, opt.Qf, opt.R, opt.HZ, True, opt.K, opt.C),
                                                       opt.descent_direction(None, "quasi")))
-        timed("armijo chunk (S*%d projections + costs)" % opt.M, opt.armijo_chunk, 0)
+        timed("armijo round 1 (S*%d projections + costs)" % opt.M, opt.armijo_chunk, 0)
     iters = S * len(methods)
     out = {
         "metric": "discopt iterations/s (puppet ~40-DOF, fp64)", "value": iters / elapsed, "unit": "iters/s",

@@ -223,6 +223,13 @@ int tg_batch_set_from_trajectories(tg_batch *b, int32_t seeds, int32_t horizon, 
 /* initialize_from_state(t, Q, p) (midpointvi.py:145-153) with trajectory b's (Q, p) read from the head of the
  * DSystem state vector X_dev[b*row_stride_doubles ...] = [Q; p; v]; lambda1 <- 0. */
 int tg_batch_initialize_from_state_device(tg_batch *b, double t, const double *X_dev, uint64_t row_stride_doubles);
+/* tg_batch_rollout_closed_loop for the first n_trajectories trajectories of the batch only, with an optional
+ * indirection for the gain schedules: group g (= trajectory / group_size) uses Kproj_dev[group_select_dev[g]].
+ * Used for the later rounds of a batched Armijo search, when only some seeds are still searching. */
+int tg_batch_rollout_closed_loop_subset(tg_batch *b, int32_t n_trajectories, int32_t n_steps, double dt,
+                                        const double *Kproj_dev, int32_t group_size, const int32_t *group_select_dev,
+                                        const double *bX_dev, const double *bU_dev, double *X_dev, double *U_dev,
+                                        int32_t max_iterations);
 /* DSystem.fdx / fdu of every solved step (dsystem.py:284-317): A_dev [batch][nX][nX], B_dev [batch][nX][nU],
  * written directly by the first-derivative kernel (the twelve reference-layout arrays are not produced). */
 int tg_batch_linearize(tg_batch *b, double *A_dev, double *B_dev);
@@ -262,10 +269,10 @@ int tg_tangent_rollout(int32_t device, int32_t n_problems, int32_t horizon, int3
                        const double *C_dev, const double *q_dev, const double *r_dev, double *dX_dev, double *dU_dev,
                        double *dcost_dev);
 /* DCost (trep/discopt/dcost.py:5-118): cost[t] = sum_k 1/2 (x-xd)'Q(x-xd) + 1/2 (u-ud)'R(u-ud) + terminal
- * with Qf, for n_trajectories trajectories of which `group` consecutive ones share the reference of one seed
- * (Xd [n/group][N+1][nX], Ud [n/group][N][nU]). */
-int tg_quadratic_cost(int32_t device, int32_t n_trajectories, int32_t group, int32_t horizon, int32_t nX, int32_t nU,
-                      const double *X_dev, const double *U_dev, const double *Xd_dev, const double *Ud_dev,
+ * with Qf, for n_trajectories trajectories of which `group` consecutive ones share the reference of one seed:
+ * trajectory t is compared with Xd/Ud of seed select_dev[t/group] (or t/group if select_dev is NULL). */
+int tg_quadratic_cost(int32_t device, int32_t n_trajectories, int32_t group, const int32_t *select_dev, int32_t horizon,
+                      int32_t nX, int32_t nU, const double *X_dev, const double *U_dev, const double *Xd_dev, const double *Ud_dev,
                       const double *Q_dev, const double *R_dev, const double *Qf_dev, double *cost_dev);
 /* Its gradients q [S][N+1][nX] (row N = terminal), r [S][N][nU] (dcost.py:62-84). */
 int tg_quadratic_cost_gradients(int32_t device, int32_t n_problems, int32_t horizon, int32_t nX, int32_t nU,

@@ -145,7 +145,7 @@ def test_sweeps_and_cost_match_numpy():
             assert abs(dc[s] - ref) < 1e-10 * max(1.0, abs(ref))
         # cost and gradients (dcost.py)
         dcost, dq2, dr2 = pool.empty((S,)), pool.empty((S, N + 1, nX)), pool.empty((S, N, nU))
-        _lib.check(L.tg_quadratic_cost(0, S, 1, N, nX, nU, d["X"].ptr, d["U"].ptr, d["Xd"].ptr, d["Ud"].ptr, d["Q"].ptr, d["R"].ptr,
+        _lib.check(L.tg_quadratic_cost(0, S, 1, None, N, nX, nU, d["X"].ptr, d["U"].ptr, d["Xd"].ptr, d["Ud"].ptr, d["Q"].ptr, d["R"].ptr,
                                        d["Qf"].ptr, dcost.ptr))
         _lib.check(L.tg_quadratic_cost_gradients(0, S, N, nX, nU, None, d["X"].ptr, d["U"].ptr, d["Xd"].ptr, d["Ud"].ptr, d["Q"].ptr,
                                                  d["R"].ptr, d["Qf"].ptr, dq2.ptr, dr2.ptr))
@@ -163,7 +163,7 @@ def test_sweeps_and_cost_match_numpy():
         assert relerr(bX, X[:, None] + lam[None, :, None, None] * dX[:, None]) < 1e-14   # the device contracts to an fma
         assert relerr(bU, U[:, None] + lam[None, :, None, None] * dU[:, None]) < 1e-14
         dcc = pool.empty((S * M,))
-        _lib.check(L.tg_quadratic_cost(0, S * M, M, N, nX, nU, dbX.ptr, dbU.ptr, d["Xd"].ptr, d["Ud"].ptr, d["Q"].ptr, d["R"].ptr,
+        _lib.check(L.tg_quadratic_cost(0, S * M, M, None, N, nX, nU, dbX.ptr, dbU.ptr, d["Xd"].ptr, d["Ud"].ptr, d["Q"].ptr, d["R"].ptr,
                                        d["Qf"].ptr, dcc.ptr))
         cc = dcc.get().reshape(S, M)
         for s in range(S):

@@ -88,7 +88,8 @@ _SIGNATURES = {
     "tg_tv_lq": (ctypes.c_int, [_i32, ctypes.POINTER(LqProblem)]),
     "tg_adjoint_sweep": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tg_tangent_rollout": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "tg_quadratic_cost": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tg_quadratic_cost": (ctypes.c_int, [_i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tg_batch_rollout_closed_loop_subset": (ctypes.c_int, [_vp, _i32, _i32, _f64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32]),
     "tg_quadratic_cost_gradients": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tg_armijo_candidates": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tg_copy_rows": (ctypes.c_int, [_i32, _i32, ctypes.c_uint64, _vp, _vp, _vp, _vp]),

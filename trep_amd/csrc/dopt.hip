@@ -371,12 +371,12 @@ __global__ __launch_bounds__(SW_T) void k_tangent(int N, int nX, int nU, const i
 // ------------------------------------------------------------------------------------------------------
 constexpr int CT_T = 256;
 
-__global__ __launch_bounds__(CT_T) void k_cost(int N, int nX, int nU, int group, const double *X, const double *U,
+__global__ __launch_bounds__(CT_T) void k_cost(int N, int nX, int nU, int group, const int *sel, const double *X, const double *U,
                                                 const double *Xd, const double *Ud, const double *Q, const double *R,
                                                 const double *Qf, double *cost) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const size_t t = blockIdx.x, s = t / group;
+    const size_t t = blockIdx.x, s = sel ? (size_t)sel[t / group] : t / group;
     double *Qt = lds, *Rt = Qt + nX * nX, *Qft = Rt + nU * nU, *dx = Qft + nX * nX + wave * (nX + nU), *du = dx + nX;
     double *red = Qft + nX * nX + 4 * (nX + nU);
     for (int e = tid; e < nX * nX; e += CT_T) { Qt[(e % nX) * nX + e / nX] = Q[e]; Qft[(e % nX) * nX + e / nX] = Qf[e]; }
@@ -525,8 +525,8 @@ int tg_tangent_rollout(int32_t device, int32_t n_problems, int32_t horizon, int3
     return TG_SUCCESS;
 }
 
-int tg_quadratic_cost(int32_t device, int32_t n_trajectories, int32_t group, int32_t horizon, int32_t nX, int32_t nU,
-                      const double *X_dev, const double *U_dev, const double *Xd_dev, const double *Ud_dev, const double *Q_dev,
+int tg_quadratic_cost(int32_t device, int32_t n_trajectories, int32_t group, const int32_t *select_dev, int32_t horizon,
+                      int32_t nX, int32_t nU, const double *X_dev, const double *U_dev, const double *Xd_dev, const double *Ud_dev, const double *Q_dev,
                       const double *R_dev, const double *Qf_dev, double *cost_dev) {
     if (n_trajectories <= 0 || group <= 0 || horizon <= 0 || !X_dev || !U_dev || !Xd_dev || !Ud_dev || !Q_dev || !R_dev || !Qf_dev || !cost_dev)
         return fail(TG_ERR_INVALID, "bad arguments");
@@ -534,7 +534,7 @@ int tg_quadratic_cost(int32_t device, int32_t n_trajectories, int32_t group, int
     if (lds > 160 * 1024 - 64) return fail(TG_ERR_UNSUPPORTED, "state dimension too large");
     HIP_TRY(hipSetDevice(device));
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_cost, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_cost, dim3(n_trajectories), dim3(CT_T), lds, 0, horizon, nX, nU, group, X_dev, U_dev, Xd_dev, Ud_dev, Q_dev, R_dev,
+    hipLaunchKernelGGL(k_cost, dim3(n_trajectories), dim3(CT_T), lds, 0, horizon, nX, nU, group, select_dev, X_dev, U_dev, Xd_dev, Ud_dev, Q_dev, R_dev,
                        Qf_dev, cost_dev);
     HIP_TRY(hipGetLastError());
     return TG_SUCCESS;

@@ -70,6 +70,7 @@ struct RunArgs {
     const double *Kproj, *bX, *bU;
     double *Uout;
     int group_size;
+    const int *group_map;                  // optional [groups]: gain schedule of group g is Kproj[group_map[g]]
     double *X;                             // [batch][n_steps+1][nX] or null
     double *f_out;                         // MODE_CALC_F: [batch][nf]
     double *d1[12];                        // MODE_DERIV1 outputs q2_d{q1,p1,u1,k2}, p2_d*, l1_d*: [batch][var][out]
@@ -503,19 +504,46 @@ struct Core {
                 const int cw = 1 << cwl, rstep = TEAM >> cwl;
                 const int jc = lane & (cw - 1);
                 const double rinv = 1.0 / A[k * ld + k];
-                for (int i = lane >> cwl; i < n; i += rstep) {
-                    if (i == k) continue;
-                    const double l = A[i * ld + k] * rinv;
-                    for (int j = k + 1 + jc; j < w; j += cw) A[i * ld + j] -= l * A[k * ld + j];
+                // A lane keeps its column(s): the pivot-row entry is loaded once.  Rows are taken four at a time with
+                // all LDS loads issued before the first store: the compiler must assume that a store may alias the
+                // next load, so a load-store-load-store sequence would pay the full LDS latency per row.
+                for (int j = k + 1 + jc; j < w; j += cw) {
+                    const double pk = A[k * ld + j];
+                    const int i0 = lane >> cwl;
+                    int i = i0;
+                    for (; i + 3 * rstep < n; i += 4 * rstep) {
+                        const int r0 = i, r1 = i + rstep, r2 = i + 2 * rstep, r3 = i + 3 * rstep;
+                        const double l0 = A[r0 * ld + k], l1 = A[r1 * ld + k], l2 = A[r2 * ld + k], l3 = A[r3 * ld + k];
+                        const double a0 = A[r0 * ld + j], a1 = A[r1 * ld + j], a2 = A[r2 * ld + j], a3 = A[r3 * ld + j];
+                        if (r0 != k) A[r0 * ld + j] = fma(-(l0 * rinv), pk, a0);
+                        if (r1 != k) A[r1 * ld + j] = fma(-(l1 * rinv), pk, a1);
+                        if (r2 != k) A[r2 * ld + j] = fma(-(l2 * rinv), pk, a2);
+                        if (r3 != k) A[r3 * ld + j] = fma(-(l3 * rinv), pk, a3);
+                    }
+                    for (; i < n; i += rstep) {
+                        const double l = A[i * ld + k] * rinv, a = A[i * ld + j];
+                        if (i != k) A[i * ld + j] = fma(-l, pk, a);
+                    }
                 }
             }
             TG_SYNC();
             TG_STAMP(11);
         }
+        // divide the right-hand sides through by the pivots: reciprocals first (one lane per row), then every lane
+        // scales its column(s) with the loads of four rows in flight
+        if (on && ok) for (int i = lane; i < n; i += TEAM) scal[i] = 1.0 / A[i * ld + i];
+        TG_SYNC();
         if (on && ok) {
-            for (int i = lane; i < n; i += TEAM) {
-                const double dinv = 1.0 / A[i * ld + i];
-                for (int r = 0; r < n_rhs; r++) A[i * ld + n + r] *= dinv;
+            const int cwl = tile_log2<TEAM>(n_rhs), cw = 1 << cwl, rstep = TEAM >> cwl;
+            for (int j = n + (lane & (cw - 1)); j < w; j += cw) {
+                int i = lane >> cwl;
+                for (; i + 3 * rstep < n; i += 4 * rstep) {
+                    const int r0 = i, r1 = i + rstep, r2 = i + 2 * rstep, r3 = i + 3 * rstep;
+                    const double d0 = scal[r0], d1 = scal[r1], d2 = scal[r2], d3 = scal[r3];
+                    const double a0 = A[r0 * ld + j], a1 = A[r1 * ld + j], a2 = A[r2 * ld + j], a3 = A[r3 * ld + j];
+                    A[r0 * ld + j] = a0 * d0; A[r1 * ld + j] = a1 * d1; A[r2 * ld + j] = a2 * d2; A[r3 * ld + j] = a3 * d3;
+                }
+                for (; i < n; i += rstep) A[i * ld + j] *= scal[i];
             }
         }
         TG_SYNC();
@@ -868,6 +896,7 @@ struct Core {
             }
             TG_SYNC();
         }
+        TG_STAMP(8);
         return gauss_jordan(on, AUG, nf, R + (extra ? nc : 0), ld, S + P.o_scal);
     }
 
@@ -876,6 +905,11 @@ struct Core {
         const int ld = P.d_aug_ld, R = P.d_nrhs;
         double *AUG = S + P.d_o_AUG, *T12 = S + P.d_o_T12, *T22 = S + P.d_o_T22;
         const bool ok = deriv1_solve(on, false);
+#if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        struct ProfDump { Core &c; const RunArgs &A; size_t t; int lane;
+            __device__ ~ProfDump() { long long t_ = (long long)__builtin_amdgcn_s_memtime(); c.prof[13] += t_ - c.prof_last;
+                          if (A.prof_out && t == 0 && lane == 0) for (int i = 0; i < 16; i++) A.prof_out[i] = c.prof[i]; } } dump_{*this, A, t, lane};
+#endif
         if (A.A_out) {
             // linearisation of the DSystem state map X_{k+1} = f(X_k, U_k), X = [Q; p; v], U = [u; rho]
             // (dsystem.py:284-317): rows Qd and p hold the transposed derivative blocks, rows Qk / v the
@@ -892,6 +926,7 @@ struct Core {
                         const int i = kind == 0 ? sv : (kind == 3 ? sv - nqd - nu : 0);
                         x = AUG[o * ld + nf + sv];
                         p = kind == 0 ? T12[i * nd + o] : (kind == 3 ? T22[(nd + i) * nd + o] : 0.0);
+#pragma unroll 4
                         for (int i2 = 0; i2 < nd; i2++) p += T22[i2 * nd + o] * AUG[i2 * ld + nf + sv];
                     }
                     if (vv < nX) { Ao[(size_t)o * nX + vv] = x; Ao[(size_t)(nq + o) * nX + vv] = p; }
@@ -922,6 +957,7 @@ struct Core {
                 for (int o = lane & (cw - 1); o < nd; o += cw) {
                     const double x = ok ? AUG[o * ld + nf + vv] : NAN;
                     double p = kind == 0 ? T12[i * nd + o] : (kind == 3 ? T22[(nd + i) * nd + o] : 0.0);
+#pragma unroll 4
                     for (int i2 = 0; i2 < nd; i2++) p += T22[i2 * nd + o] * AUG[i2 * ld + nf + vv];
                     A.d1[kind][(t * rows + i) * nd + o] = x;
                     A.d1[4 + kind][(t * rows + i) * nd + o] = ok ? p : NAN;
@@ -1346,7 +1382,8 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
         if (A.Kproj) {  // feedback inputs from the state entering this step (before the shift: v needs q1)
             const int nU = nu + nk;
             if (on) TG_FOR(j, nU) {
-                const double *Kr = A.Kproj + ((((size_t)(t / A.group_size)) * A.n_steps + step) * nU + j) * nX;
+                const size_t grp = A.group_map ? (size_t)A.group_map[t / A.group_size] : (size_t)(t / A.group_size);
+                const double *Kr = A.Kproj + ((grp * A.n_steps + step) * nU + j) * nX;
                 const double *bx = A.bX + (t * (size_t)(A.n_steps + 1) + step) * nX;
                 const double dtp = step == 0 ? (A.t2 - A.t1) : dt;
                 double acc = A.bU[(t * A.n_steps + step) * nU + j];

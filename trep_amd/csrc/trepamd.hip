@@ -472,6 +472,25 @@ int tg_batch_rollout_closed_loop(tg_batch *b, int32_t n_steps, double dt, const 
     return TG_SUCCESS;
 }
 
+int tg_batch_rollout_closed_loop_subset(tg_batch *b, int32_t n_trajectories, int32_t n_steps, double dt, const double *Kproj_dev,
+                                        int32_t group_size, const int32_t *group_select_dev, const double *bX_dev,
+                                        const double *bU_dev, double *X_dev, double *U_dev, int32_t max_iterations) {
+    if (!b || n_steps <= 0 || dt == 0.0 || !Kproj_dev || !bX_dev || !bU_dev || group_size <= 0 || n_trajectories <= 0 ||
+        n_trajectories > b->batch)
+        return fail(TG_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(b->device));
+    tg::RunArgs A = base_args(b, tg::MODE_ROLLOUT);
+    A.batch = n_trajectories;
+    A.n_steps = n_steps; A.dt = dt; A.max_iterations = max_iterations;
+    A.Kproj = Kproj_dev; A.bX = bX_dev; A.bU = bU_dev; A.Uout = U_dev; A.group_size = group_size; A.X = X_dev;
+    A.group_map = group_select_dev;
+    int rc = launch(b, A);
+    if (rc) return rc;
+    b->t1 = b->t2 + (n_steps - 1) * dt;
+    b->t2 = b->t2 + n_steps * dt;
+    return TG_SUCCESS;
+}
+
 int tg_batch_rollout_stats(tg_batch *b, int64_t *total_iterations, int32_t *n_failed) {
     if (!b) return fail(TG_ERR_INVALID, "null batch");
     std::vector<int> it(b->batch), st(b->batch);

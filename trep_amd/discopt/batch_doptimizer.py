@@ -209,7 +209,7 @@ class BatchDOptimizer(object):
         S, N, nX, nU = self.S, self.N, self.nX, self.nU
         self._check(self.L.tg_quadratic_cost_gradients(self.device, S, N, nX, nU, None, self.X.ptr, self.U.ptr, self.Xd.ptr, self.Ud.ptr,
                                                        self.Q.ptr, self.R.ptr, self.Qf.ptr, self.q.ptr, self.r.ptr))
-        self._check(self.L.tg_quadratic_cost(self.device, S, 1, N, nX, nU, self.X.ptr, self.U.ptr, self.Xd.ptr, self.Ud.ptr,
+        self._check(self.L.tg_quadratic_cost(self.device, S, 1, None, N, nX, nU, self.X.ptr, self.U.ptr, self.Xd.ptr, self.Ud.ptr,
                                              self.Q.ptr, self.R.ptr, self.Qf.ptr, self.cost.ptr))
         return self.cost.get()
 
@@ -238,30 +238,39 @@ class BatchDOptimizer(object):
         self._check(self.L.tg_tangent_rollout(self.device, n, self.N, self.nX, self.nU, sel, self.A.ptr, self.B.ptr, self.K.ptr, self.C.ptr,
                                               self.q.ptr, self.r.ptr, self.dX.ptr, self.dU.ptr, self.dcost.ptr))
 
-    def armijo_chunk(self, m0):
-        """Project the candidates lambda = beta^m, m0 <= m < m0 + M, of every seed; returns (costs [S][M], ok [S][M])."""
-        S, N, nX, nU, M = self.S, self.N, self.nX, self.nU, self.M
-        self.lambdas.set(self.armijo_beta ** np.arange(m0, m0 + M, dtype=float))
-        self._check(self.L.tg_armijo_candidates(self.device, S, M, N, nX, nU, None, self.lambdas.ptr, self.X.ptr, self.U.ptr,
+    def armijo_chunk(self, m0, seeds=None, count=None):
+        """Project the candidates lambda = beta^m, m0 <= m < m0 + count, of `seeds` (default: all seeds, count = M);
+        returns (costs [n][count], ok [n][count]).  Row i*count + j of the candidate buffers belongs to seeds[i]."""
+        S, N, nX, nU = self.S, self.N, self.nX, self.nU
+        sel, n = self._select(seeds)
+        M = self.M if count is None else int(count)
+        assert n * M <= S * self.M
+        if M > self.lambdas.shape[0]:
+            self.lambdas = self.pool.empty((M,))
+        lam = np.zeros(self.lambdas.shape[0])
+        lam[:M] = self.armijo_beta ** np.arange(m0, m0 + M, dtype=float)
+        self.lambdas.set(lam)
+        rows = n * M
+        self._check(self.L.tg_armijo_candidates(self.device, n, M, N, nX, nU, sel, self.lambdas.ptr, self.X.ptr, self.U.ptr,
                                                 self.dX.ptr, self.dU.ptr, self.bX.ptr, self.bU.ptr))
         self._check(self.L.tg_batch_initialize_from_state_device(self.arm._h, self.t0, self.bX.ptr, (N + 1) * nX))
-        self._check(self.L.tg_batch_rollout_closed_loop(self.arm._h, N, self.dt, self.Kproj.ptr, M, self.bX.ptr, self.bU.ptr,
-                                                        self.cX.ptr, self.cU.ptr, 200))
-        self._check(self.L.tg_quadratic_cost(self.device, S * M, M, N, nX, nU, self.cX.ptr, self.cU.ptr, self.Xd.ptr, self.Ud.ptr,
+        self._check(self.L.tg_batch_rollout_closed_loop_subset(self.arm._h, rows, N, self.dt, self.Kproj.ptr, M, sel, self.bX.ptr,
+                                                               self.bU.ptr, self.cX.ptr, self.cU.ptr, 200))
+        self._check(self.L.tg_quadratic_cost(self.device, rows, M, sel, N, nX, nU, self.cX.ptr, self.cU.ptr, self.Xd.ptr, self.Ud.ptr,
                                              self.Q.ptr, self.R.ptr, self.Qf.ptr, self.ccost.ptr))
         _, status = self.arm.status()
-        return self.ccost.get().reshape(S, M), (status == 0).reshape(S, M)
+        return self.ccost.get()[:rows].reshape(n, M), (status[:rows] == 0).reshape(n, M)
 
-    def accept(self, seeds, columns):
-        """X[s], U[s] <- candidate `columns[i]` of the current chunk for s = seeds[i]."""
+    def accept(self, seeds, rows):
+        """X[s], U[s] <- row rows[i] of the candidate buffers for s = seeds[i]."""
         n = len(seeds)
         if n == 0:
             return
-        S, N, nX, nU, M = self.S, self.N, self.nX, self.nU, self.M
+        S, N, nX, nU = self.S, self.N, self.nX, self.nU
         a = np.zeros(S, dtype=np.int32)
         b = np.zeros(S, dtype=np.int32)
         a[:n] = seeds
-        b[:n] = np.asarray(seeds) * M + np.asarray(columns)
+        b[:n] = rows
         self._rows_a.set(a)
         self._rows_b.set(b)
         self._check(self.L.tg_copy_rows(self.device, n, (N + 1) * nX, self._rows_a.ptr, self._rows_b.ptr, self.cX.ptr, self.X.ptr))
@@ -308,20 +317,30 @@ class BatchDOptimizer(object):
         search = active & ~done
         m0 = 0
         while search.any() and m0 < self.armijo_max_iterations:
-            costs, ok = self.armijo_chunk(m0)
-            lam = self.armijo_beta ** np.arange(m0, m0 + self.M)
-            acc_seeds, acc_cols = [], []
-            for s in np.nonzero(search)[0]:
-                for j in range(min(self.M, self.armijo_max_iterations - m0)):
-                    if ok[s, j] and costs[s, j] < cost0[s] + self.armijo_alpha * lam[j] * dcost0[s]:
+            # first round: every seed, M candidates each (one full wave of the GPU); later rounds: only the seeds
+            # still searching, with as many of their remaining candidates as fit into the candidate batch
+            if m0 == 0:
+                seeds, count = np.arange(S), min(self.M, self.armijo_max_iterations)
+                costs, ok = self.armijo_chunk(0)
+            else:
+                seeds = np.nonzero(search)[0]
+                count = int(min(self.armijo_max_iterations - m0, max(1, (S * self.M) // len(seeds))))
+                costs, ok = self.armijo_chunk(m0, seeds, count)
+            lam = self.armijo_beta ** np.arange(m0, m0 + count)
+            acc_seeds, acc_rows = [], []
+            for i, s in enumerate(seeds):
+                if not search[s]:
+                    continue
+                for j in range(count):
+                    if ok[i, j] and costs[i, j] < cost0[s] + self.armijo_alpha * lam[j] * dcost0[s]:
                         acc_seeds.append(s)
-                        acc_cols.append(j)
-                        cost1[s] = costs[s, j]
+                        acc_rows.append(i * costs.shape[1] + j)
+                        cost1[s] = costs[i, j]
                         armijo[s] = m0 + j
                         search[s] = False
                         break
-            self.accept(acc_seeds, acc_cols)
-            m0 += self.M
+            self.accept(acc_seeds, acc_rows)
+            m0 += count
         # a seed whose search is exhausted is where the reference raises ConvergenceError("Armijo Failed to
         # Converge") (doptimizer.py:456-459); here it is flagged and left unchanged, the other seeds carry on
         failed = search.copy()
