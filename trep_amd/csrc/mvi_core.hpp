@@ -182,11 +182,7 @@ struct Core {
         double *sc = S + P.o_sc, *G = S + P.o_G;
         if (on) TG_FOR(j, P.n_joints) {
             const double x = qval(sel, P.j_cfg[j]);
-#ifndef TG_X_NOSINCOS
             if (P.j_kind[j] >= TG_RX) tg_sincos(x, &sc[2 * j], &sc[2 * j + 1]);
-#else
-            if (P.j_kind[j] >= TG_RX) { sc[2 * j] = x; sc[2 * j + 1] = 1.0 - x; }
-#endif
             else { sc[2 * j] = x; sc[2 * j + 1] = 0.0; }
         }
         TG_SYNC();
@@ -435,7 +431,6 @@ struct Core {
         // matrix entry, so the accumulation uses LDS floating-point atomics (ds_add_f64).  One wavefront
         // owns the trajectory and its LDS operations retire in order, so the summation order -- and with
         // it the result -- is the same on every run.
-#ifndef TG_X_NOPAIRS
         if (on) TG_FOR(pp, P.n_npairs) {
             const int *pw = P.pair4 + 4 * (size_t)pp;
             const int ia = pw[0], ib = pw[1], ca = pw[2] & 0xFFFF, cb = pw[2] >> 16, b = pw[3];
@@ -457,7 +452,6 @@ struct Core {
             lds_add(&A[ca * ld + cb], sym + skew);
             if (ia != ib) lds_add(&A[cb * ld + ca], sym - skew);
         }
-#endif
         TG_SYNC();
         TG_STAMP(8);
     }
@@ -551,117 +545,6 @@ struct Core {
     }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-    // ---- Gauss-Jordan on 4x4 REGISTER TILES (full-wave team, n <= 31) -----------------------------------
-    //      The augmented matrix [A | rhs] is cut into 4x4 tiles, one tile per lane (row block rb = lane/8,
-    //      column block cb = lane%8; 7x8 = 56 lanes for the puppet's 28x29).  Per pivot step: the pivot is a
-    //      single 32-bit wave max over (scaled magnitude | row); the lanes that own the pivot ROW publish
-    //      their 4 entries of it, the lanes that own pivot COLUMN k publish their 4 entries of it (two tiny
-    //      LDS vectors); every lane then updates its 16 entries in registers.  Rows never move (in-place
-    //      pivoting, same implicit-scaled rule as math-code.c:337-432).  ~4x fewer instructions per step
-    //      than the row-per-lane variant, which has to broadcast the whole pivot row lane by lane.
-    static __device__ __noinline__ bool gj_tiles(bool on, double *A_generic, int n, int ld, double *scal_generic, int lane) {
-        // the buffers are in LDS: tell the compiler, or a non-inlined function would use slow flat accesses
-        typedef __attribute__((address_space(3))) double lds_double;
-        typedef __attribute__((address_space(3))) int lds_int;
-        lds_double *A = (lds_double *)A_generic;
-        lds_double *scal = (lds_double *)scal_generic;
-        const int rb = lane >> 3, cb = lane & 7;
-        const int nrb = (n + 3) >> 2, ncb = (n + 4) >> 2;   // row blocks, column blocks (rhs = column n)
-        const bool mine = on && rb < nrb && cb < ncb;
-        // implicit scaling factors from the untouched matrix (LDS), one lane per row
-        if (on && lane < n) {
-            double s = -1.0;
-            for (int j = 0; j < n; j++) { const double a = fabs(A[lane * ld + j]); if (a > s) s = a; }
-            scal[lane] = 1.0 / s;
-        }
-        __syncthreads();
-        double t[4][4], sc[4];
-        bool used[4] = {false, false, false, false};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = 4 * rb + i;
-            sc[i] = (mine && row < n) ? scal[row] : 0.0;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int col = 4 * cb + c;
-                t[i][c] = (mine && row < n && col <= n) ? A[row * ld + col] : 0.0;
-            }
-        }
-        __syncthreads();
-        // the matrix now lives in registers: its LDS image becomes scratch
-        lds_double *prow = A, *pcol = A + 32, *diag = A + 64, *rhs = A + 96;
-        lds_int *pivrow = (lds_int *)(A + 128);
-        bool ok = true;
-        for (int kk = 0; kk < nrb; kk++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int k = 4 * kk + r;
-                if (k < n) {
-                    unsigned int key = 0;
-                    if (mine && cb == kk) {
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const int row = 4 * rb + i;
-                            const float cand = (!used[i] && row < n) ? (float)fabs(t[i][r] * sc[i]) : 0.0f;
-                            const unsigned int ki = (__float_as_uint(cand) & ~0x1Fu) | (unsigned int)(31 - row);
-                            key = ki > key ? ki : key;
-                        }
-                    }
-                    key = __ockl_wfred_max_u32(key);
-                    const int piv = __builtin_amdgcn_readfirstlane(31 - (int)(key & 0x1Fu));
-                    const float best = __uint_as_float(key & ~0x1Fu);
-                    if (on && ok && !(best > 1.0e-20f)) ok = false;
-                    const int prb = piv >> 2, pi = piv & 3;
-                    if (mine && rb == prb) {   // publish my 4 entries of the pivot row
-#pragma unroll
-                        for (int c = 0; c < 4; c++)
-                            prow[4 * cb + c] = pi == 0 ? t[0][c] : (pi == 1 ? t[1][c] : (pi == 2 ? t[2][c] : t[3][c]));
-                        used[0] = used[0] || pi == 0; used[1] = used[1] || pi == 1;
-                        used[2] = used[2] || pi == 2; used[3] = used[3] || pi == 3;
-                    }
-                    if (mine && cb == kk) {    // publish my 4 entries of column k
-#pragma unroll
-                        for (int i = 0; i < 4; i++) pcol[4 * rb + i] = t[i][r];
-                    }
-                    __syncthreads();
-                    if (mine && ok) {
-                        const double pkk = prow[k];
-                        double rp = __builtin_amdgcn_rcp(pkk);
-                        rp = fma(rp, fma(-pkk, rp, 1.0), rp);
-                        rp = fma(rp, fma(-pkk, rp, 1.0), rp);
-                        double pr[4], l[4];
-#pragma unroll
-                        for (int c = 0; c < 4; c++) pr[c] = prow[4 * cb + c];
-#pragma unroll
-                        for (int i = 0; i < 4; i++) l[i] = (4 * rb + i == piv) ? 0.0 : pcol[4 * rb + i] * rp;
-#pragma unroll
-                        for (int c = 0; c < 4; c++) {
-                            const bool upd = cb > kk || (cb == kk && c > r);   // only columns right of the pivot
-#pragma unroll
-                            for (int i = 0; i < 4; i++) t[i][c] = upd ? fma(-l[i], pr[c], t[i][c]) : t[i][c];
-                        }
-                        if (lane == 0) { diag[k] = pkk; pivrow[k] = piv; }
-                    }
-                    __syncthreads();
-                }
-            }
-        }
-        // x_k = rhs(pivot row of k) / pivot_k, returned in the caller's layout A[k*ld + n]
-        const int ccb = n >> 2, cc = n & 3;
-        if (mine && cb == ccb) {
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                rhs[4 * rb + i] = cc == 0 ? t[i][0] : (cc == 1 ? t[i][1] : (cc == 2 ? t[i][2] : t[i][3]));
-        }
-        __syncthreads();
-        double x = 0.0;
-        if (on && ok && lane < n) x = rhs[pivrow[lane]] / diag[lane];
-        __syncthreads();
-        if (on && ok && lane < n) A[lane * ld + n] = x;
-        __syncthreads();
-        return ok;
-    }
-
     // ---- Gauss-Jordan with one matrix ROW PER LANE held in registers (n <= N <= TEAM) ---------------------
     //      Same pivot rule as gauss_jordan() but pivoting "in place": rows never move, the lane that owns
     //      the pivot row of step k broadcasts it (v_readlane for a full-wave team, ds_bpermute otherwise)
@@ -711,9 +594,6 @@ struct Core {
             // broadcast the pivot row (columns k..N-1 and the rhs)
             const int src = (TEAM == 64) ? __builtin_amdgcn_readfirstlane(piv) : piv;
             auto bcast = [&](double v) -> double {
-#if defined(TG_GJ_BPERMUTE)
-                return __shfl(v, src, TEAM);
-#endif
                 if (TEAM == 64) {
                     const long long b = __double_as_longlong(v);
                     const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFLL), src);
@@ -1112,7 +992,7 @@ struct Core {
     }
 
     TG_HD void deriv2z(bool on, const RunArgs &A, size_t t) {
-        const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nf = P.nf;
+        const int nq = P.nq, nd = P.nd, nu = P.nu, nc = P.nc, nf = P.nf;
         const int ld = P.d_aug_ld, R = P.d_nrhs, hl = nq | 1;   // odd row stride of the H tables: no LDS bank conflicts
         double *AUG = S + P.d_o_AUG, *T22 = S + P.d_o_T22;
         double *H11 = S + P.e_o_H11, *H12 = S + P.e_o_H12, *H22 = S + P.e_o_H22, *G1 = S + P.e_o_G1;
@@ -1440,7 +1320,7 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
 #endif
             core.newton_matrix(!done);
             bool ok;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_GJROWS)
+#if defined(__HIP_DEVICE_COMPILE__)
             const int nb4 = (P.nf + 3) >> 2;   // matrix size in blocks of 4 rows
             if (TEAM >= 4 && 4 * nb4 <= TEAM && nb4 <= 8) {
                 double *Ad = S + P.o_Df;

@@ -35,27 +35,7 @@ __global__ __launch_bounds__(64, 2) void k_run(const tg::DevProg P, const tg::Ru
     const int team = threadIdx.x / TEAM, lane = threadIdx.x % TEAM;
     const int traj = blockIdx.x * (64 / TEAM) + team;
     const int stride = MODE == tg::MODE_DERIV2Z ? P.e_lds_per_team : (MODE == tg::MODE_DERIV1 ? P.d_lds_per_team : P.lds_per_team);
-#if defined(TG_LDS_TABLES)
-    // EXPERIMENT: stage every schedule table in LDS (per workgroup) to measure the cost of global-table latency
-    tg::DevProg Q = P;
-    double *td = lds + (size_t)(64 / TEAM) * stride;
-    int *ti = (int *)(td + P.n_tab_d);
-    for (int i = threadIdx.x; i < P.n_tab_d; i += 64) td[i] = P.tab_d[i];
-    for (int i = threadIdx.x; i < P.n_tab_i; i += 64) ti[i] = P.tab_i[i];
-    __syncthreads();
-#define RI(f) Q.f = ti + (P.f - P.tab_i)
-#define RD(f) Q.f = td + (P.f - P.tab_d)
-    RI(level_off); RI(j_parent); RI(j_kind); RI(j_cfg); RI(j_pre_ident); RI(b_anchor); RI(b_item_off); RI(b_pair_off);
-    RI(it_body); RI(it_joint); RI(it_cfg); RI(pair_a); RI(pair_b); RI(cfg_item_off); RI(cfg_items); RI(e_anchor);
-    RI(c_type); RI(c_e1); RI(c_e2); RI(c_cfg); RI(c_comp); RI(dh_c); RI(dh_cfg); RI(dh_joint); RI(dh_side);
-    RI(cf_cfg); RI(cf_in); RI(dh_lookup); RI(cu_off); RI(it_slot); RI(pair4);
-    RD(j_pre); RD(jcoef); RD(b_C); RD(b_inertia); RD(e_off); RD(c_dist); RD(c_tol); RD(damp);
-#undef RI
-#undef RD
-    tg::run_trajectory<TEAM, MODE>(Q, A, lds + (size_t)team * stride, lane, traj);
-#else
     tg::run_trajectory<TEAM, MODE>(P, A, lds + (size_t)team * stride, lane, traj);
-#endif
 }
 
 }  // namespace
@@ -164,11 +144,7 @@ int launch(tg_batch *b, tg::RunArgs &A) {
     const int team = b->sys->team, per_block = 64 / team;
     const int grid = (A.batch + per_block - 1) / per_block;
     const int per_team = A.mode == tg::MODE_DERIV2Z ? b->P.e_lds_per_team : (A.mode == tg::MODE_DERIV1 ? b->P.d_lds_per_team : b->P.lds_per_team);
-#if defined(TG_LDS_TABLES)
-    const size_t lds = (size_t)per_block * per_team * sizeof(double) + b->P.n_tab_d * sizeof(double) + b->P.n_tab_i * sizeof(int) + 16;
-#else
     const size_t lds = (size_t)per_block * per_team * sizeof(double);
-#endif
     if (lds > 160 * 1024) return fail(TG_ERR_UNSUPPORTED, "system too large for the LDS-resident kernel");
     hipEvent_t e0, e1;
     if (b->pool.size() >= 2) { e0 = b->pool.back(); b->pool.pop_back(); e1 = b->pool.back(); b->pool.pop_back(); }
