@@ -155,25 +155,28 @@ struct Core {
 
     // ---- world poses of all joints ---------------------------------------------------------------------
     // (1) sin/cos (or the displacement) per joint; (2) every joint's LOCAL transform pre_j * lg(q_j) from
-    // host-made coefficient rows (branch-free: entry = A + B*s1 + C*s0); (3) level by level
-    // G_j = G_parent(j) * local_j in place, one lane per (joint, column): a lane reads only its own
-    // column of the local transform, so there is no intra-joint hazard for any team size.
-    // Level schedule of the sweep in LDS (written once per kernel): for level L and slot s < 16 the packed
-    // word (offset of the slot's joint | offset of its parent << 16), or -1.  Keeps the level loop rolled and
-    // free of global-memory look-ups.
-    bool sweep_fast = false;
+    // host-made coefficient rows (branch-free: entry = A + B*s1 + C*s0), stored where the world pose will be;
+    // (3) world poses G_j = G_parent(j) * local_j in place:
+    //   * device, TEAM >= 4: CHAIN sweep.  Joints are numbered chain by chain (program.hpp); a group of four lanes
+    //     owns a chain, lane r < 3 carries ROW r of the running pose in registers (row r of a product only needs
+    //     row r of the left factor), so the recurrence along a chain is a register-only FMA chain: no cross-lane
+    //     traffic, no barrier; the local transforms are LDS reads that do not depend on it.  One barrier per round
+    //     of chains (puppet: 2) instead of one per tree level (11).
+    //   * otherwise (host emulation, tiny teams): level by level, one lane per (joint, column).
+    // Chain schedule of the sweep in LDS (written once per kernel): for round r and slot s < 16 two words,
+    // (12 * first joint | chain length << 16) and 12 * parent joint (or -1: the world), length 0 for an empty slot.
+    // Keeps global-memory look-ups (and their latency) out of the sweep.
     TG_HD void init_sweep_schedule() {
-        sweep_fast = P.sched_ok != 0;
-        if (!sweep_fast) return;
+        if (!P.sched_ok) return;
         int *sched = (int *)(S + P.o_sched);
-        TG_FOR(idx, 16 * P.n_levels) {
-            const int L = idx >> 4, slot = idx & 15;
-            int w = -1;
-            if (L >= 1) {
-                const int j0 = P.level_off[L], cnt = P.level_off[L + 1] - j0;
-                if (slot < cnt) w = (12 * (j0 + slot)) | ((12 * P.j_parent[j0 + slot]) << 16);
+        TG_FOR(idx, 16 * P.n_rounds) {
+            const int r = idx >> 4, c = P.round_off[r] + (idx & 15);
+            int w0 = 0, w1 = -1;
+            if (c < P.round_off[r + 1]) {
+                w0 = (12 * P.ch_first[c]) | (P.ch_len[c] << 16);
+                w1 = P.ch_parent[c] >= 0 ? 12 * P.ch_parent[c] : -1;
             }
-            sched[idx] = w;
+            sched[2 * idx] = w0; sched[2 * idx + 1] = w1;
         }
         TG_SYNC();
     }
@@ -207,31 +210,57 @@ struct Core {
             }
         }
         TG_SYNC();
-        if (sweep_fast) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (TEAM >= 4) {
             const int *sched = (const int *)(S + P.o_sched);
-            for (int L = 1; L < P.n_levels; L++) {
-                if (on) TG_FOR(idx, 64) {          // 16 slots x 4 columns
-                    const int w = sched[16 * L + (idx >> 2)];
-                    if (w >= 0) {
-                        const int cc = idx & 3;
-                        const double u3 = (cc == 3) ? 1.0 : 0.0;
-                        double *gj = G + (w & 0xFFFF);
-                        const double *gp = G + (w >> 16);
-                        const double m0 = gj[cc], m1 = gj[4 + cc], m2 = gj[8 + cc];
-                        const double v0 = gp[0] * m0 + gp[1] * m1 + gp[2] * m2 + u3 * gp[3];
-                        const double v1 = gp[4] * m0 + gp[5] * m1 + gp[6] * m2 + u3 * gp[7];
-                        const double v2 = gp[8] * m0 + gp[9] * m1 + gp[10] * m2 + u3 * gp[11];
-                        gj[cc] = v0; gj[4 + cc] = v1; gj[8 + cc] = v2;
+            for (int r = 0; r < P.n_rounds; r++) {
+                const int nch = P.sched_ok ? 16 : P.round_off[r + 1] - P.round_off[r];
+                if (on) TG_FOR(idx, 4 * nch) {
+                    const int row = idx & 3;
+                    int o0, len, opar;
+                    if (P.sched_ok) {
+                        const int w0 = sched[2 * (16 * r + (idx >> 2))];
+                        opar = sched[2 * (16 * r + (idx >> 2)) + 1];
+                        o0 = w0 & 0xFFFF; len = w0 >> 16;
+                    } else {
+                        const int ch = P.round_off[r] + (idx >> 2);
+                        o0 = 12 * P.ch_first[ch]; len = P.ch_len[ch]; opar = P.ch_parent[ch] >= 0 ? 12 * P.ch_parent[ch] : -1;
+                    }
+                    if (row < 3 && len > 0) {
+                        double p0, p1, p2, p3;
+                        if (opar >= 0) { const double *gp = G + opar + 4 * row; p0 = gp[0]; p1 = gp[1]; p2 = gp[2]; p3 = gp[3]; }
+                        else { p0 = row == 0 ? 1.0 : 0.0; p1 = row == 1 ? 1.0 : 0.0; p2 = row == 2 ? 1.0 : 0.0; p3 = 0.0; }
+                        double m[12];
+#pragma unroll
+                        for (int e = 0; e < 12; e++) m[e] = G[o0 + e];
+                        for (int s = 0; s < len; s++) {
+                            double *gj = G + o0 + 12 * s;
+                            double n[12];                                // next local transform: loads before this step's stores
+                            const double *gn = s + 1 < len ? gj + 12 : gj;
+#pragma unroll
+                            for (int e = 0; e < 12; e++) n[e] = gn[e];
+                            const double v0 = p0 * m[0] + p1 * m[4] + p2 * m[8];
+                            const double v1 = p0 * m[1] + p1 * m[5] + p2 * m[9];
+                            const double v2 = p0 * m[2] + p1 * m[6] + p2 * m[10];
+                            const double v3 = p0 * m[3] + p1 * m[7] + p2 * m[11] + p3;
+                            double *out = gj + 4 * row;
+                            out[0] = v0; out[1] = v1; out[2] = v2; out[3] = v3;
+                            p0 = v0; p1 = v1; p2 = v2; p3 = v3;
+#pragma unroll
+                            for (int e = 0; e < 12; e++) m[e] = n[e];
+                        }
                     }
                 }
                 TG_SYNC();
             }
             return;
         }
+#endif
         for (int L = 1; L < P.n_levels; L++) {
-            const int j0 = P.level_off[L], cnt = P.level_off[L + 1] - j0;
+            const int l0 = P.level_off[L], cnt = P.level_off[L + 1] - l0;
             if (on) TG_FOR(idx, 4 * cnt) {
-                const int j = j0 + (idx >> 2), cc = idx & 3;
+                const int j = P.lvl_joints[l0 + (idx >> 2)], cc = idx & 3;
+                if (P.j_parent[j] < 0) continue;
                 const double *gp = G + 12 * P.j_parent[j];
                 double *gj = G + 12 * j;
                 const double m0 = gj[cc], m1 = gj[4 + cc], m2 = gj[8 + cc], u3 = (cc == 3) ? 1.0 : 0.0;

@@ -26,7 +26,12 @@ struct DevProg {
     int nq, nd, nk, nu, nc, nf, nX;
     int n_joints, n_levels, n_bodies, n_items, n_pairs, n_endpoints, n_dh, n_cf, n_cfgitems;
     double grav[3];
-    const int *level_off;     // [n_levels+1]
+    const int *level_off;     // [n_levels+1] offsets into lvl_joints
+    const int *lvl_joints;    // joints sorted by level (generic level-by-level sweep)
+    // chain sweep: joints are numbered chain by chain; round r holds the chains round_off[r]..round_off[r+1]-1, every
+    // one of which hangs off a joint of an earlier round (or the world)
+    const int *round_off, *ch_first, *ch_len, *ch_parent;
+    int n_rounds, n_chains;
     const int *j_parent;      // [n_joints] parent joint or -1
     const int *j_kind;        // [n_joints] TG_TX..TG_RZ
     const int *j_cfg;         // [n_joints]
@@ -63,7 +68,7 @@ struct DevProg {
     // LDS layout (offsets in doubles from the team's base)
     int o_q1, o_q2, o_p1, o_lam, o_u, o_dq, o_f, o_sc, o_G, o_gB, o_pE, o_J, o_W, o_vB, o_gam, o_Ldq, o_Lddq,
         o_Dh1, o_Dh2, o_Df, o_scal, o_misc, o_dqi, o_nu, o_sched;
-    int sched_ok;             // 1: every level has <= TEAM/4... (checked on the device) and <= 16 joints: LDS level schedule usable
+    int sched_ok;             // 1: every round has <= 16 chains: the chain schedule is staged in LDS (o_sched)
     int df_ld;
     int dh_ld;                // 0: the step kernel keeps Dh1/Dh2 compact (one value per dh item)
     int lds_per_team;
@@ -77,7 +82,7 @@ struct DevProg {
 
 struct HostProgram {
     DevProg p{};  // sizes + LDS layout filled; pointers left null (set by the owner)
-    std::vector<int> level_off, j_parent, j_kind, j_cfg, j_pre_ident;
+    std::vector<int> level_off, lvl_joints, round_off, ch_first, ch_len, ch_parent, j_parent, j_kind, j_cfg, j_pre_ident;
     std::vector<double> j_pre;
     std::vector<int> b_anchor;
     std::vector<double> b_C, b_inertia;
@@ -153,7 +158,10 @@ inline HostProgram build_program(const tg_system_desc *d) {
         if (d->frame_config[f] >= 0 && (t < TG_TX || t > TG_RZ)) throw std::runtime_error("config on a non-parametric frame");
         if (f > 0 && (d->frame_parent[f] < 0 || d->frame_parent[f] >= f)) throw std::runtime_error("frames must be listed parent-first");
     }
-    // joints = variable frames, sorted by (level, frame index); level = config_gen of the driving config
+    // joints = variable frames.  Numbering: CHAIN ORDER.  A chain is a maximal run of joints in which every joint is
+    // the only joint-child of its predecessor; round 0 holds the chains that hang off the world, round r+1 the chains
+    // that hang off a joint of round r.  The device sweeps one chain per lane group, joint after joint in registers,
+    // with one barrier per ROUND instead of one per tree level (puppet: 2 rounds for 11 levels).
     std::vector<int> jframes;
     int n_levels = 0;
     for (int f = 0; f < nfr; f++)
@@ -162,11 +170,36 @@ inline HostProgram build_program(const tg_system_desc *d) {
             n_levels = std::max(n_levels, d->config_gen[d->frame_config[f]] + 1);
         }
     std::vector<int> order;
-    H.level_off.assign(n_levels + 1, 0);
-    for (int L = 0; L < n_levels; L++) {
-        for (int f : jframes)
-            if (d->config_gen[d->frame_config[f]] == L) order.push_back(f);
-        H.level_off[L + 1] = (int)order.size();
+    {
+        std::vector<int> vparent(nfr, -1);            // nearest variable proper ancestor frame
+        std::vector<int> nearest(nfr, -1);            // nearest variable ancestor-or-self
+        for (int f = 1; f < nfr; f++) {
+            const int p = d->frame_parent[f];
+            vparent[f] = nearest[p];
+            nearest[f] = d->frame_config[f] >= 0 ? f : nearest[p];
+        }
+        std::vector<std::vector<int>> kids(nfr);
+        std::vector<int> roots;
+        for (int f : jframes) { if (vparent[f] < 0) roots.push_back(f); else kids[vparent[f]].push_back(f); }
+        std::vector<int> starts = roots;
+        H.round_off.push_back(0);
+        while (!starts.empty()) {
+            std::vector<int> next;
+            for (int f0 : starts) {
+                H.ch_first.push_back((int)order.size());
+                int f = f0, len = 0;
+                for (;;) {
+                    order.push_back(f); len++;
+                    if (kids[f].size() != 1) break;
+                    f = kids[f][0];
+                }
+                H.ch_len.push_back(len);
+                for (int c : kids[f]) next.push_back(c);
+            }
+            H.round_off.push_back((int)H.ch_first.size());
+            starts.swap(next);
+        }
+        if (order.size() != jframes.size()) throw std::runtime_error("joint tree traversal error");
     }
     std::vector<int> joint_of_frame(nfr, -1), joint_of_cfg(nq, -1);
     for (size_t j = 0; j < order.size(); j++) {
@@ -196,6 +229,13 @@ inline HostProgram build_program(const tg_system_desc *d) {
         H.j_pre_ident[j] = is_ident(offset[p]) ? 1 : 0;
         std::memcpy(&H.j_pre[12 * (size_t)j], offset[p].m, sizeof(offset[p].m));
         if (H.j_parent[j] >= 0 && H.j_parent[j] >= j) throw std::runtime_error("joint ordering error");
+    }
+    for (size_t c = 0; c < H.ch_first.size(); c++) H.ch_parent.push_back(H.j_parent[H.ch_first[c]]);
+    H.level_off.assign(n_levels + 1, 0);
+    for (int L = 0; L < n_levels; L++) {
+        for (int j = 0; j < nj; j++)
+            if (d->config_gen[H.j_cfg[j]] == L) H.lvl_joints.push_back(j);
+        H.level_off[L + 1] = (int)H.lvl_joints.size();
     }
     // local transform of joint j as a function of its coordinate: entry e (row l, column c) of
     // pre_j * lg(q) = A + B*s1 + C*s0 with (s0, s1) = (sin q, cos q) for a rotary joint and (q, 0) for a
@@ -330,9 +370,11 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.o_Ldq = take(nd); P.o_Lddq = take(nd); P.o_Dh1 = take(P.n_dh); P.o_Dh2 = take(P.n_dh);  // compact: one value per (constraint, dependent config) item
     P.o_scal = take(P.nf); P.o_misc = take(2); P.o_nu = take(P.nu + P.nk);
     // level schedule of the pose sweep: 16 packed words (own offset | parent offset << 16) per level, as ints
+    P.n_chains = (int)H.ch_first.size(); P.n_rounds = (int)H.round_off.size() - 1;
     P.sched_ok = (12 * nj < 65536) ? 1 : 0;
-    for (int L = 1; L < n_levels; L++) if (H.level_off[L + 1] - H.level_off[L] > 16) P.sched_ok = 0;
-    P.o_sched = take(P.sched_ok ? (16 * n_levels + 1) / 2 : 0);
+    for (int r = 0; r < P.n_rounds; r++) if (H.round_off[r + 1] - H.round_off[r] > 16) P.sched_ok = 0;
+    for (int c : H.ch_len) if (c >= 32768) P.sched_ok = 0;
+    P.o_sched = take(P.sched_ok ? 16 * P.n_rounds : 0);   // two ints per (round, slot)
     P.df_ld = (P.nf + 1) | 1;  // augmented with the right-hand side; odd stride avoids LDS bank conflicts
     const int shared0 = off;
     P.o_Df = take(P.nf * P.df_ld);
@@ -378,7 +420,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
 }  // namespace detail
 
 #define TG_INT_TABLES(X)                                                                                     \
-    X(level_off) X(j_parent) X(j_kind) X(j_cfg) X(j_pre_ident) X(b_anchor) X(b_item_off) X(b_pair_off) X(it_body) \
+    X(level_off) X(lvl_joints) X(round_off) X(ch_first) X(ch_len) X(ch_parent) X(j_parent) X(j_kind) X(j_cfg) X(j_pre_ident) X(b_anchor) X(b_item_off) X(b_pair_off) X(it_body) \
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
     X(tri4) X(cpair4)
