@@ -157,17 +157,18 @@ struct Core {
     // (1) sin/cos (or the displacement) per joint; (2) every joint's LOCAL transform pre_j * lg(q_j) from
     // host-made coefficient rows (branch-free: entry = A + B*s1 + C*s0), stored where the world pose will be;
     // (3) world poses G_j = G_parent(j) * local_j in place:
-    //   * device, TEAM >= 4: CHAIN sweep.  Joints are numbered chain by chain (program.hpp); a group of four lanes
+    //   * device, full-wave teams: CHAIN sweep.  Joints are numbered chain by chain (program.hpp); a group of four lanes
     //     owns a chain, lane r < 3 carries ROW r of the running pose in registers (row r of a product only needs
     //     row r of the left factor), so the recurrence along a chain is a register-only FMA chain: no cross-lane
     //     traffic, no barrier; the local transforms are LDS reads that do not depend on it.  One barrier per round
     //     of chains (puppet: 2) instead of one per tree level (11).
-    //   * otherwise (host emulation, tiny teams): level by level, one lane per (joint, column).
+    //   * otherwise (host emulation, small systems with several trajectories per wave): level by level, one lane
+    //     per (joint, column).
     // Chain schedule of the sweep in LDS (written once per kernel): for round r and slot s < 16 two words,
     // (12 * first joint | chain length << 16) and 12 * parent joint (or -1: the world), length 0 for an empty slot.
     // Keeps global-memory look-ups (and their latency) out of the sweep.
     TG_HD void init_sweep_schedule() {
-        if (!P.sched_ok) return;
+        if (!P.sched_ok || TEAM != 64) return;
         int *sched = (int *)(S + P.o_sched);
         TG_FOR(idx, 16 * P.n_rounds) {
             const int r = idx >> 4, c = P.round_off[r] + (idx & 15);
@@ -211,7 +212,7 @@ struct Core {
         }
         TG_SYNC();
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (TEAM >= 4) {
+        if (TEAM == 64) {
             const int *sched = (const int *)(S + P.o_sched);
             for (int r = 0; r < P.n_rounds; r++) {
                 const int nch = P.sched_ok ? 16 : P.round_off[r + 1] - P.round_off[r];
