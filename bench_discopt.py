@@ -10,7 +10,9 @@ sweeps, [Newton: S adjoint sweeps + S*N z-contracted second derivatives], S LQ s
 projections per chunk.  `--sequential` runs the per-seed DOptimizer (host LQR) instead.
 
   python bench_discopt.py --seeds 256 --horizon 1000 --quasi 1 --newton 2
-Prints one JSON line.
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench_discopt.py --seeds 256 ...        # seeds sharded over N GPUs, costs all-gathered
+Prints one JSON line (rank 0).
 """
 import argparse
 import json
@@ -26,7 +28,13 @@ sys.path.insert(0, ROOT)
 REFERENCE_NEWTON_ITER_S = 35.0   # reference, puppet, N~1000: >= 35 s per Newton iteration
 
 
-def problem(seeds, N, dt):
+def sum_over_ranks(value, dist, torch):
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def problem(seeds, N, dt, device=0):
     import trep_amd
     from trep_amd import systems
     system = systems.puppet()
@@ -34,7 +42,7 @@ def problem(seeds, N, dt):
     Q0 = systems.puppet_initial_conditions(system, seeds, seed=20250 + 4)
     K_move = systems.puppet_string_schedule(system, Q0[:, nd:], N, dt)
     K_still = np.repeat(Q0[:, None, nd:], N, axis=1)
-    sim = trep_amd.BatchMidpointVI(system, seeds)
+    sim = trep_amd.BatchMidpointVI(system, seeds, device=device)
     sim.initialize_from_state(0.0, Q0, np.zeros((seeds, nd)))
     Xd = sim.rollout(N, dt, None, K_move)
     sim.initialize_from_state(0.0, Q0, np.zeros((seeds, nd)))
@@ -45,18 +53,34 @@ def problem(seeds, N, dt):
 
 
 def run_batched(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = torch = None
+    if world > 1:   # torch first: one HIP runtime in the process
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     import trep_amd
-    from trep_amd import discopt, _lib
-    dt, N, S = 0.01, args.horizon, args.seeds
-    system, Xd, Ud, Xi, Ui, Qc, Rc = problem(S, N, dt)
-    dsys = discopt.DSystem(trep_amd.MidpointVI(system), dt * np.arange(N + 1))
-    opt = discopt.BatchDOptimizer(dsys, Xd, Ud, Qc, Rc, armijo_chunk=args.armijo_chunk)
+    from trep_amd import discopt, _lib, distributed
+    dt, N = 0.01, args.horizon
+    system, Xd, Ud, Xi, Ui, Qc, Rc = problem(args.seeds, N, dt, device=local_rank)
+    lo, hi = distributed.shard_bounds(args.seeds, rank, world)     # this rank's seeds
+    Xd, Ud, Xi, Ui = Xd[lo:hi], Ud[lo:hi], Xi[lo:hi], Ui[lo:hi]
+    S = hi - lo
+    dsys = discopt.DSystem(trep_amd.MidpointVI(system, device=local_rank), dt * np.arange(N + 1))
+    opt = discopt.BatchDOptimizer(dsys, Xd, Ud, Qc, Rc, device=local_rank, armijo_chunk=args.armijo_chunk)
     L = _lib.lib()
     methods = ["quasi"] * args.quasi + ["newton"] * args.newton
     opt.set_trajectories(Xi, Ui)
     opt.step(methods[0])                      # warm-up (allocations, code objects), not timed
     opt.set_trajectories(Xi, Ui)
-    L.tg_device_synchronize(0)
+    L.tg_device_synchronize(local_rank)
+    if dist is not None:
+        dist.barrier()
     per = {"quasi": [], "newton": []}
     costs = []
     n_failed = 0
@@ -64,19 +88,25 @@ def run_batched(args):
     for m in methods:
         ts = time.perf_counter()
         r = opt.step(m)
-        L.tg_device_synchronize(0)
+        L.tg_device_synchronize(local_rank)
         per[m].append(time.perf_counter() - ts)
         costs.append([float(np.nanmean(r.cost0)), float(np.nanmean(r.cost1))])
         n_failed += int(r.failed.sum())
     elapsed = time.perf_counter() - t0
+    final_cost = r.cost1
+    if dist is not None:                      # every rank sees every seed's cost (what a supervisor would act on)
+        dist.barrier()
+        elapsed = distributed.max_over_ranks(elapsed, device="cuda")
+        final_cost = distributed.all_gather_rows(torch.from_numpy(np.nan_to_num(r.cost1)[:, None]).cuda()).cpu().numpy()[:, 0]
+        n_failed = int(sum_over_ranks(n_failed, dist, torch))
     stages = None
-    if args.stages:                            # one more Newton step, synchronising after every stage
+    if args.stages and world == 1:             # one more Newton step, synchronising after every stage
         stages = {}
 
         def timed(name, fn, *a):
             ts = time.perf_counter()
             out = fn(*a)
-            L.tg_device_synchronize(0)
+            L.tg_device_synchronize(local_rank)
             stages[name] = stages.get(name, 0.0) + time.perf_counter() - ts
             return out
         timed("linearize (S*N DEL solves + deriv1 -> A,B)", opt.linearize)
@@ -86,12 +116,13 @@ def run_batched(args):
         timed("LQ sweep + tangent rollout", lambda: (opt._lq(None, opt.Q, opt.Qf, opt.R, opt.HZ, True, opt.K, opt.C),
                                                       opt.descent_direction(None, "quasi")))
         timed("armijo round 1 (S*%d projections + costs)" % opt.M, opt.armijo_chunk, 0)
-    iters = S * len(methods)
+    iters = args.seeds * len(methods)
     out = {
         "metric": "discopt iterations/s (puppet ~40-DOF, fp64)", "value": iters / elapsed, "unit": "iters/s",
-        "n_gpus": 1, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "puppet-optimization.py problem, nX=80 nU=18, N=%d, %d seeds batched on the device, %d quasi + %d newton steps each"
-                               % (N, S, args.quasi, args.newton), "armijo_chunk": opt.M},
+        "n_gpus": world, "dtype": "f64", "data": "synthetic", "scaling": "strong",
+        "config": {"workload": "puppet-optimization.py problem, nX=80 nU=18, N=%d, %d seeds batched on the device (%d per GPU), %d quasi + %d newton steps each"
+                               % (N, args.seeds, S, args.quasi, args.newton), "armijo_chunk": opt.M},
+        "mean_final_cost_all_seeds": float(np.mean(final_cost)),
         "s_per_batched_quasi_step": float(np.mean(per["quasi"])) if per["quasi"] else None,
         "s_per_batched_newton_step": float(np.mean(per["newton"])) if per["newton"] else None,
         "mean_cost_before_after_per_step": costs,
@@ -100,7 +131,11 @@ def run_batched(args):
         "reference_s_per_newton_step_N1000_one_seed": REFERENCE_NEWTON_ITER_S,
     }
     opt.close()
-    print(json.dumps(out))
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def run_sequential(args):

@@ -242,7 +242,8 @@ int tg_batch_deriv2_contract_device(tg_batch *b, const double *z_dev, double *hz
  * dynamics HZ [S][N][hz_R][hz_R] (variables ordered x-part[hz_nx], u-part[nU]) is added on the fly:
  * Q_k += HZ[:hz_nx,:hz_nx], S_k = HZ[:hz_nx, hz_nx:], R_k += HZ[hz_nx:, hz_nx:]  (the Newton model of
  * doptimizer.py:319-345).  Outputs: K [S][N][nU][nX], C [S][N][nU] (affine only), P0 [S][nX][nX], b0 [S][nX],
- * status [S] (TG_OK / TG_SINGULAR). */
+ * status [S] (TG_OK / TG_SINGULAR).  Q_k and Qf must be symmetric (every P_k then is: the recursion symmetrises
+ * it like the reference does). */
 typedef struct tg_lq_problem {
     int32_t n_problems, horizon, nX, nU;
     const int32_t *select_dev;

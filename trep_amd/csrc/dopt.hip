@@ -115,7 +115,7 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
             for (int m = 0; m < nX; m++) {
                 double pv[TS], av[TS];
 #pragma unroll
-                for (int i = 0; i < TS; i++) pv[i] = Pm[(i0 + i) * ldx + m];
+                for (int i = 0; i < TS; i++) pv[i] = Pm[m * ldx + i0 + i];   // P is symmetric: row m instead of column m (contiguous, no bank conflicts)
 #pragma unroll
                 for (int j = 0; j < TS; j++) av[j] = Am[m * ldx + j0 + j];
 #pragma unroll
