@@ -191,7 +191,9 @@ struct Core {
     // (12 * first joint | chain length << 16) and 12 * parent joint (or -1: the world), length 0 for an empty slot.
     // Keeps global-memory look-ups (and their latency) out of the sweep.
     TG_HD void init_sweep_schedule() {
-        if (!P.sched_ok || TEAM != 64) return;
+        TG_FOR(i, 4 * P.n_bodies) S[P.o_I + i] = P.b_inertia[i];   // body inertias: LDS copy for the whole kernel
+        TG_FOR(c, P.nc) S[P.o_ctol + c] = P.c_tol[c];
+        if (!P.sched_ok || TEAM != 64) { TG_SYNC(); return; }
         int *sched = (int *)(S + P.o_sched);
         TG_FOR(idx, 16 * P.n_rounds) {
             const int r = idx >> 4, c = P.round_off[r] + (idx & 15);
@@ -329,8 +331,9 @@ struct Core {
     TG_HD void jacobians(bool on) {
         const double *G = S + P.o_G;
         if (on) TG_FOR(it, P.n_items) {
-            const int b = P.it_body[it], j = P.it_joint[it], kind = P.j_kind[j];
-            const double *gb = S + P.o_gB + 12 * b, *gj = G + 12 * j;
+            const int *rec = P.it_pack + 4 * (size_t)it;
+            const int b = rec[0], oj = rec[1], kind = rec[2], cfg = rec[3] & 0xFFFF;
+            const double *gb = S + P.o_gB + 12 * b, *gj = G + oj;
             double *J = S + P.o_J + 6 * it;
             double lin[3], ang[3];
             if (kind <= TG_TZ) {
@@ -347,7 +350,7 @@ struct Core {
                 J[r] = gb[r] * lin[0] + gb[4 + r] * lin[1] + gb[8 + r] * lin[2];
                 J[3 + r] = gb[r] * ang[0] + gb[4 + r] * ang[1] + gb[8 + r] * ang[2];
             }
-            S[P.o_dqi + it] = S[P.o_dq + P.it_cfg[it]];  // rate of the item's config, for the prefix sums
+            S[P.o_dqi + it] = S[P.o_dq + cfg];  // rate of the item's config, for the prefix sums
         }
         if (on) TG_FOR(idx, 3 * P.n_bodies) {
             const int b = idx / 3, r = idx % 3;
@@ -388,8 +391,8 @@ struct Core {
         // pose area, then one contiguous sum per dynamic config
         double *terms = S + P.o_G;
         if (on) TG_FOR(it, P.n_items) {
-            const int b = P.it_body[it], slot = P.it_slot[it];
-            const double *I = P.b_inertia + 4 * b, *v = S + P.o_vB + 6 * b;
+            const int b = P.it_pack[4 * (size_t)it], slot = P.it_pack[4 * (size_t)it + 3] >> 16;
+            const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b;
             const double *J = S + P.o_J + 6 * it, *W = S + P.o_W + 6 * it, *gam = S + P.o_gam + 3 * b;
             terms[2 * slot] = inner6(I, J, v);
             terms[2 * slot + 1] = inner6(I, W, v) + I[0] * (gam[0] * J[0] + gam[1] * J[1] + gam[2] * J[2]);
@@ -426,6 +429,19 @@ struct Core {
         }
     }
 
+    // same with the joint given by its pose offset and kind, the end point by its offset (packed dh records)
+    TG_HD void dpos_rec(int oe, int oj, int kind, double *d) const {
+        const double *gj = S + P.o_G + oj;
+        if (kind <= TG_TZ) { const int a = kind - TG_TX; d[0] = gj[a]; d[1] = gj[4 + a]; d[2] = gj[8 + a]; }
+        else {
+            const int a = kind - TG_RX;
+            const double wx = gj[a], wy = gj[4 + a], wz = gj[8 + a];
+            const double *pe = S + P.o_pE + oe;
+            const double dx = pe[0] - gj[3], dy = pe[1] - gj[7], dz = pe[2] - gj[11];
+            d[0] = wy * dz - wz * dy; d[1] = wz * dx - wx * dz; d[2] = wx * dy - wy * dx;
+        }
+    }
+
     // ---- constraint values (into f[nd..]) and Jacobian Dh (into dest) at the swept state -------------
     // distance.c:16-63, point.c:16-38.  `sel` picks the config vector for the length configs.
     TG_HD void constraints(bool on, int sel, bool want_h, double *Dh, int ld) {
@@ -441,15 +457,17 @@ struct Core {
             S[P.o_f + P.nd + c] = h;
         }
         if (on) TG_FOR(n, P.n_dh) {
-            const int c = P.dh_c[n], k = P.dh_cfg[n], j = P.dh_joint[n], side = P.dh_side[n];
+            const int *rec = P.dh_pack + 8 * (size_t)n;   // one record instead of chained table look-ups
+            const int c = rec[0], k = rec[1], oj = rec[2], w = rec[3], oe1 = rec[4], oe2 = rec[5];
+            const int side = w & 0xFF, kind = (w >> 8) & 0xFF, type = (w >> 16) & 0xFF, comp = w >> 24;
             double d1[3] = {0, 0, 0}, d2[3] = {0, 0, 0};
-            if (side & 1) dpos(P.c_e1[c], j, d1);
-            if (side & 2) dpos(P.c_e2[c], j, d2);
+            if (side & 1) dpos_rec(oe1, oj, kind, d1);
+            if (side & 2) dpos_rec(oe2, oj, kind, d2);
             const double dx = d1[0] - d2[0], dy = d1[1] - d2[1], dz = d1[2] - d2[2];
             double val;
-            if (P.c_type[c] == TG_CONSTRAINT_POINT) val = P.c_comp[c] == 0 ? dx : (P.c_comp[c] == 1 ? dy : dz);
+            if (type == TG_CONSTRAINT_POINT) val = comp == 0 ? dx : (comp == 1 ? dy : dz);
             else {
-                const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
+                const double *a = S + P.o_pE + oe1, *b = S + P.o_pE + oe2;
                 val = (a[0] - b[0]) * dx + (a[1] - b[1]) * dy + (a[2] - b[2]) * dz;
                 if (side & 4) val -= qval(sel, k);
                 val *= 2.0;
@@ -473,7 +491,7 @@ struct Core {
                 if (r < nd) A[r * ld + r] = -P.damp[r];
             }
             TG_FOR(n, P.n_dh) {
-                const int k = P.dh_cfg[n], c = P.dh_c[n];
+                const int c = P.dh_pack[8 * (size_t)n], k = P.dh_pack[8 * (size_t)n + 1];
                 if (k < nd) { A[k * ld + nd + c] = -S[P.o_Dh1 + n]; A[(nd + c) * ld + k] = S[P.o_Dh2 + n]; }
             }
         }
@@ -487,7 +505,7 @@ struct Core {
         if (on) TG_FOR(pp, P.n_npairs) {
             const int *pw = P.pair4 + 4 * (size_t)pp;
             const int ia = pw[0], ib = pw[1], ca = pw[2] & 0xFFFF, cb = pw[2] >> 16, b = pw[3];
-            const double *I = P.b_inertia + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
+            const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
             const double *Ja = S + P.o_J + 6 * ia, *Jb = S + P.o_J + 6 * ib;
             const double *Wa = S + P.o_W + 6 * ia, *Wb = S + P.o_W + 6 * ib;
             double t[6];
@@ -795,7 +813,7 @@ struct Core {
         const double qdt = 0.25 * dt, rdt = 1.0 / dt;
         for (int b = 0; b < P.n_bodies; b++) {
             const int p0 = P.b_pair_off[b], np = P.b_pair_off[b + 1] - p0;
-            const double *I = P.b_inertia + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
+            const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
             if (on) TG_FOR(pp, np) {
                 const int ia = P.pair_a[p0 + pp], ib = P.pair_b[p0 + pp];
                 const int ca = P.it_cfg[ia], cb = P.it_cfg[ib];
@@ -1025,7 +1043,7 @@ struct Core {
         return acc;
     }
     TG_HD Third third_order(int b, int x, int y, int o) const {
-        const double *I = P.b_inertia + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
+        const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
         double vxy[6], vxo[6], vyo[6], t1[6], t2[6];
         vel2(x, y, vxy); vel2(x, o, vxo); vel2(y, o, vyo);
         int a = x, bb = y, c = o;
@@ -1218,7 +1236,7 @@ struct Core {
         double norm = 0.0;
         for (int i = 0; i < P.nd; i++) norm += S[P.o_f + i] * S[P.o_f + i];
         if (sqrt(norm) > tolerance) return false;
-        for (int c = 0; c < P.nc; c++) if (fabs(S[P.o_f + P.nd + c]) > P.c_tol[c]) return false;
+        for (int c = 0; c < P.nc; c++) if (fabs(S[P.o_f + P.nd + c]) > S[P.o_ctol + c]) return false;
         return true;
     }
 

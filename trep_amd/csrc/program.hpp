@@ -53,6 +53,11 @@ struct DevProg {
     // second-derivative kernel: every ORDERED (item x, item y) pair of every body {x, y, config x | config y << 16, body}
     // and every (constraint, dh-item a <= dh-item b) pair {c, na, nb, config a | config b << 16}
     const int *tri4, *cpair4;
+    // packed records (one 16-byte load instead of chained look-ups):
+    //   it_pack[it]  = {body, 12*joint, joint kind, config | residual slot << 16}
+    //   dh_pack[2n]  = {constraint, config, 12*joint (or -1), side | joint kind << 8 | constraint type << 16 | component << 24}
+    //   dh_pack[2n+1]= {3*end point 1, 3*end point 2, length config (or -1), 0}
+    const int *it_pack, *dh_pack;
     int n_tri, n_cpair;
     const int *cfg_item_off;  // [nq+1] CSR config -> items
     const int *cfg_items;     // [n_items]
@@ -67,7 +72,7 @@ struct DevProg {
     const int *cf_cfg, *cf_in;
     // LDS layout (offsets in doubles from the team's base)
     int o_q1, o_q2, o_p1, o_lam, o_u, o_dq, o_f, o_sc, o_G, o_gB, o_pE, o_J, o_W, o_vB, o_gam, o_Ldq, o_Lddq,
-        o_Dh1, o_Dh2, o_Df, o_scal, o_misc, o_dqi, o_nu, o_sched;
+        o_Dh1, o_Dh2, o_Df, o_scal, o_misc, o_dqi, o_nu, o_sched, o_I, o_ctol;
     int sched_ok;             // 1: every round has <= 16 chains: the chain schedule is staged in LDS (o_sched)
     int df_ld;
     int dh_ld;                // 0: the step kernel keeps Dh1/Dh2 compact (one value per dh item)
@@ -86,7 +91,7 @@ struct HostProgram {
     std::vector<double> j_pre;
     std::vector<int> b_anchor;
     std::vector<double> b_C, b_inertia;
-    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4, tri4, cpair4;
+    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4, tri4, cpair4, it_pack, dh_pack;
     std::vector<int> e_anchor;
     std::vector<double> e_off;
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
@@ -296,6 +301,11 @@ inline HostProgram build_program(const tg_system_desc *d) {
     }
     H.it_slot.assign(nitems, 0);
     for (int n = 0; n < nitems; n++) H.it_slot[H.cfg_items[n]] = n;
+    for (int n = 0; n < nitems; n++) {
+        if (H.it_cfg[n] >= 65536 || H.it_slot[n] >= 32768) throw std::runtime_error("too many items for the packed item table");
+        H.it_pack.push_back(H.it_body[n]); H.it_pack.push_back(12 * H.it_joint[n]);
+        H.it_pack.push_back(H.j_kind[H.it_joint[n]]); H.it_pack.push_back(H.it_cfg[n] | (H.it_slot[n] << 16));
+    }
     for (int b = 0; b < nb; b++)
         for (int x = H.b_item_off[b]; x < H.b_item_off[b + 1]; x++)
             for (int y = H.b_item_off[b]; y < H.b_item_off[b + 1]; y++) {
@@ -336,6 +346,12 @@ inline HostProgram build_program(const tg_system_desc *d) {
     H.cu_off.assign(nc + 1, 0);
     for (size_t n = 0; n < H.dh_c.size(); n++) H.cu_off[H.dh_c[n] + 1] = (int)n + 1;
     for (int c = 0; c < nc; c++) if (H.cu_off[c + 1] < H.cu_off[c]) H.cu_off[c + 1] = H.cu_off[c];
+    for (size_t n = 0; n < H.dh_c.size(); n++) {
+        const int c = H.dh_c[n], j = H.dh_joint[n];
+        H.dh_pack.push_back(c); H.dh_pack.push_back(H.dh_cfg[n]); H.dh_pack.push_back(j >= 0 ? 12 * j : -1);
+        H.dh_pack.push_back(H.dh_side[n] | ((j >= 0 ? H.j_kind[j] : 0) << 8) | (H.c_type[c] << 16) | ((H.c_comp[c] & 0xFF) << 24));
+        H.dh_pack.push_back(3 * H.c_e1[c]); H.dh_pack.push_back(3 * H.c_e2[c]); H.dh_pack.push_back(H.c_cfg[c]); H.dh_pack.push_back(0);
+    }
     for (int c = 0; c < nc; c++)
         for (int na = H.cu_off[c]; na < H.cu_off[c + 1]; na++)
             for (int nb2 = na; nb2 < H.cu_off[c + 1]; nb2++) {
@@ -369,6 +385,8 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.o_J = take(6 * nitems); P.o_W = take(6 * nitems); P.o_vB = take(6 * nb); P.o_gam = take(3 * nb);
     P.o_Ldq = take(nd); P.o_Lddq = take(nd); P.o_Dh1 = take(P.n_dh); P.o_Dh2 = take(P.n_dh);  // compact: one value per (constraint, dependent config) item
     P.o_scal = take(P.nf); P.o_misc = take(2); P.o_nu = take(P.nu + P.nk);
+    P.o_I = take(4 * nb);   // mass and principal inertias of every body (copied from the table once per kernel)
+    P.o_ctol = take(nc);    // constraint tolerances, likewise
     // level schedule of the pose sweep: 16 packed words (own offset | parent offset << 16) per level, as ints
     P.n_chains = (int)H.ch_first.size(); P.n_rounds = (int)H.round_off.size() - 1;
     P.sched_ok = (12 * nj < 65536) ? 1 : 0;
@@ -423,7 +441,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(level_off) X(lvl_joints) X(round_off) X(ch_first) X(ch_len) X(ch_parent) X(j_parent) X(j_kind) X(j_cfg) X(j_pre_ident) X(b_anchor) X(b_item_off) X(b_pair_off) X(it_body) \
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
-    X(tri4) X(cpair4)
+    X(tri4) X(cpair4) X(it_pack) X(dh_pack)
 #define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp)
 
 inline void HostProgram::pack() {
