@@ -868,20 +868,36 @@ struct Core {
             if (on) {
                 const int nX = P.nX, nU = nu + nk, nqd = nq + nd;
                 double *Ao = A.A_out + t * (size_t)nX * nX, *Bo = A.B_out + t * (size_t)nX * nU;
-                for (int o = 0; o < nd; o++) TG_FOR(vv, nX + nU) {
-                    double x = NAN, p = NAN;
-                    if (vv >= nqd && vv < nX) { x = 0.0; p = 0.0; }       // columns of the v part of X
-                    else if (ok) {
+                // p2 derivative = T12 / T22 row + T22' x: four output rows per pass share the loads of x
+                for (int o0 = 0; o0 < nd; o0 += 4) TG_FOR(vv, nX + nU) {
+                    double x[4] = {NAN, NAN, NAN, NAN}, p[4] = {NAN, NAN, NAN, NAN};
+                    if (vv >= nqd && vv < nX) {                           // columns of the v part of X
+                        for (int j = 0; j < 4; j++) { x[j] = 0.0; p[j] = 0.0; }
+                    } else if (ok) {
                         const int sv = vv < nqd ? vv : vv - nk;           // index among (q1, p1, u1, k2)
                         const int kind = sv < nq ? 0 : (sv < nqd ? 1 : (sv < nqd + nu ? 2 : 3));
                         const int i = kind == 0 ? sv : (kind == 3 ? sv - nqd - nu : 0);
-                        x = AUG[o * ld + nf + sv];
-                        p = kind == 0 ? T12[i * nd + o] : (kind == 3 ? T22[(nd + i) * nd + o] : 0.0);
-#pragma unroll 4
-                        for (int i2 = 0; i2 < nd; i2++) p += T22[i2 * nd + o] * AUG[i2 * ld + nf + sv];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int o = o0 + j < nd ? o0 + j : nd - 1;
+                            x[j] = AUG[o * ld + nf + sv];
+                            p[j] = kind == 0 ? T12[i * nd + o] : (kind == 3 ? T22[(nd + i) * nd + o] : 0.0);
+                        }
+#pragma unroll 2
+                        for (int i2 = 0; i2 < nd; i2++) {
+                            const double a = AUG[i2 * ld + nf + sv];
+                            const double *tr = T22 + i2 * nd;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) p[j] += tr[o0 + j < nd ? o0 + j : nd - 1] * a;
+                        }
                     }
-                    if (vv < nX) { Ao[(size_t)o * nX + vv] = x; Ao[(size_t)(nq + o) * nX + vv] = p; }
-                    else { Bo[(size_t)o * nU + vv - nX] = x; Bo[(size_t)(nq + o) * nU + vv - nX] = p; }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int o = o0 + j;
+                        if (o >= nd) break;
+                        if (vv < nX) { Ao[(size_t)o * nX + vv] = x[j]; Ao[(size_t)(nq + o) * nX + vv] = p[j]; }
+                        else { Bo[(size_t)o * nU + vv - nX] = x[j]; Bo[(size_t)(nq + o) * nU + vv - nX] = p[j]; }
+                    }
                 }
                 const double rdt = 1.0 / dt;
                 for (int i = 0; i < nk; i++) TG_FOR(vv, nX + nU) {        // Qk_{k+1} = rho_k, v_{k+1} = (rho_k - Qk_k)/dt
