@@ -20,6 +20,8 @@
 namespace tg_detail {
 int fail(int code, const std::string &msg);
 }
+// ROCm device-library wavefront reduction (DPP based)
+extern "C" __device__ __attribute__((const)) unsigned int __ockl_wfred_max_u32(unsigned int);
 
 namespace {
 
@@ -31,6 +33,14 @@ using tg_detail::fail;
     } while (0)
 
 constexpr int LQ_T = 256;  // threads per workgroup of the sweep kernels
+
+// Diagnostic build only (-DTG_PROFILE): cycles per phase of the LQ sweep, workgroup 0 thread 0, read by tg_lq_profile.
+#if defined(TG_PROFILE)
+__device__ long long g_lq_prof[8];
+#define LQ_STAMP(i) do { if (blockIdx.x == 0 && tid == 0) { long long t_ = (long long)__builtin_amdgcn_s_memtime(); lq_acc[i] += t_ - lq_last; lq_last = t_; } } while (0)
+#else
+#define LQ_STAMP(i) ((void)0)
+#endif
 
 __host__ __device__ inline int round_up(int n, int m) { return (n + m - 1) / m * m; }
 
@@ -50,7 +60,7 @@ __host__ __device__ inline int round_up(int n, int m) { return (n + m - 1) / m *
 template <int TS, int RI, int CI, int PB>
 __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
     extern __shared__ double lds[];
-    __shared__ int s_piv, s_sing;
+    __shared__ int s_sing, s_rowof[64];
     const int tid = threadIdx.x;
     const int s = a.select_dev ? a.select_dev[blockIdx.x] : blockIdx.x;
     const int nX = a.nX, nU = a.nU, N = a.horizon;
@@ -105,6 +115,9 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
     const bool has_tile = tid < ntiles;
     const int i0 = TS * (tid / nT), j0 = TS * (tid % nT);
     double acc[TS * TS];
+#if defined(TG_PROFILE)
+    long long lq_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lq_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
     for (int k = N - 1; k >= 0; k--) {
         if (k > 0) prefetch(k - 1);
         const double *hz = a.hz_dev ? a.hz_dev + (sN + k) * (size_t)hzR * hzR : nullptr;
@@ -144,6 +157,7 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
             rv[tid] = a.r_dev[(sN + k) * nU + tid];
         }
         __syncthreads();
+        LQ_STAMP(0);
         // ---- phase 2: PA -> LDS (over P), gamma, Kpart = (B'P) A + S' ------------------------------------
         if (has_tile) {
 #pragma unroll
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
             for (int j = 0; j < nX; j++) g += BtP[u * ldx + j] * Bm[j * nU + v];
             G[u * ldw + v] = g;
         }
-        if (tid < nU) G[tid * ldw + nU] = affine ? wv[tid] + rv[tid] : 0.0;
+        if (tid < nU) { const double rw = affine ? wv[tid] + rv[tid] : 0.0; rv[tid] = rw; G[tid * ldw + nU] = rw; }   // r_k + B'b
         for (int o = tid; o < nU * nT; o += LQ_T) {
             const int u = o / nT, c0 = TS * (o % nT);
             double c[TS];
@@ -173,35 +187,64 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
             for (int j = 0; j < TS; j++) { Kp[u * ldx + c0 + j] = c[j]; G[u * ldw + nU + 1 + c0 + j] = c[j]; }
         }
         __syncthreads();
-        // ---- phase 3: [C | K] = gamma^-1 [.|.]: Gauss-Jordan with partial pivoting (LAPACK getrf pivot rule) ---
-        for (int p = 0; p < nU; p++) {
-            if (tid == 0) {
-                int best = p; double bm = fabs(G[p * ldw + p]);
-                for (int i = p + 1; i < nU; i++) { const double m = fabs(G[i * ldw + p]); if (m > bm) { bm = m; best = i; } }
-                s_piv = best;
-                if (!(bm > 0.0)) s_sing = 1;
+        LQ_STAMP(1);
+        // ---- phase 3: [C | K] = gamma^-1 [.|.]: Gauss-Jordan with partial pivoting, rows never move ------------
+        // Per pivot ONE phase: every wavefront finds the pivot of column p itself (lane i holds |G[i][p]| of the
+        // rows not used yet -- the rows LAPACK's getrf searches -- and a wave max picks the row), then thread
+        // (half h, column c) eliminates column p+1+c in its half of the rows with all loads ahead of the stores.
+        // Rows are normalised and put in variable order at the end (into the dead B'P buffer and `wv`).
+        {
+            const int lane = tid & 63, half = tid >> 7, col = tid & 127;
+            const int h0 = half ? (nU + 1) / 2 : 0, h1 = half ? nU : (nU + 1) / 2;
+            unsigned long long used = 0ull;
+            for (int p = 0; p < nU; p++) {
+                // the magnitude only ranks candidates: single precision with the lane in the low mantissa bits, one
+                // 32-bit wave max (DPP) instead of a shuffle butterfly
+                float mf = 0.0f;
+                if (lane < nU && !((used >> lane) & 1ull)) mf = (float)fabs(G[lane * ldw + p]);
+                const unsigned int key = __ockl_wfred_max_u32((__float_as_uint(mf) & ~0x3Fu) | (unsigned int)(63 - lane));
+                const int r = 63 - (int)(key & 0x3Fu);
+                if (!(__uint_as_float(key & ~0x3Fu) > 0.0f)) { if (tid == 0) s_sing = 1; }
+                used |= 1ull << r;
+                if (tid == 0) s_rowof[p] = r;
+                const double piv = G[r * ldw + p];
+                double inv = __builtin_amdgcn_rcp(piv);           // hardware seed + two Newton steps: the multipliers
+                inv = fma(inv, fma(-piv, inv, 1.0), inv);         // need not be correctly rounded
+                inv = fma(inv, fma(-piv, inv, 1.0), inv);
+                for (int c = p + 1 + col; c < ldw; c += 128) {
+                    const double pk = G[r * ldw + c];
+                    for (int i0 = h0; i0 < h1; i0 += 4) {
+                        double l[4], a4[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int i = i0 + q < h1 ? i0 + q : h1 - 1;
+                            l[q] = G[i * ldw + p]; a4[q] = G[i * ldw + c];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int i = i0 + q;
+                            if (i < h1 && i != r) G[i * ldw + c] = fma(-(l[q] * inv), pk, a4[q]);
+                        }
+                    }
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            const int pr = s_piv;
-            if (pr != p) for (int c = p + tid; c < ldw; c += LQ_T) { const double t_ = G[p * ldw + c]; G[p * ldw + c] = G[pr * ldw + c]; G[pr * ldw + c] = t_; }
-            __syncthreads();
-            const double inv = 1.0 / G[p * ldw + p];
-            if (tid < nU) fac[tid] = G[tid * ldw + p];
-            __syncthreads();
-            for (int c = p + 1 + tid; c < ldw; c += LQ_T) G[p * ldw + c] *= inv;
-            __syncthreads();
-            const int wcols = ldw - p - 1;
-            for (int o = tid; o < nU * wcols; o += LQ_T) {
-                const int i = o / wcols, c = p + 1 + o % wcols;
-                if (i != p) G[i * ldw + c] -= fac[i] * G[p * ldw + c];
-            }
-            __syncthreads();
         }
+        if (tid < nU) fac[tid] = 1.0 / G[s_rowof[tid] * ldw + tid];
+        __syncthreads();
+        double *Ks = BtP, *Cs = wv;   // K_k [nU][ldx], C_k [nU]
+        for (int o = tid; o < nU * ldx; o += LQ_T) {
+            const int u = o / ldx, j = o % ldx;
+            Ks[o] = G[s_rowof[u] * ldw + nU + 1 + j] * fac[u];
+        }
+        if (tid < nU) Cs[tid] = G[s_rowof[tid] * ldw + nU] * fac[tid];
+        __syncthreads();
+        LQ_STAMP(2);
         // ---- phase 4: outputs K_k, C_k; new P tile (registers), new b ----------------------------------------
         {
             double *Ko = a.K_dev + (sN + k) * (size_t)nU * nX;
-            for (int o = tid; o < nU * nX; o += LQ_T) Ko[o] = G[(o / nX) * ldw + nU + 1 + o % nX];
-            if (a.C_dev && tid < nU) a.C_dev[(sN + k) * nU + tid] = G[tid * ldw + nU];
+            for (int o = tid; o < nU * nX; o += LQ_T) Ko[o] = Ks[(o / nX) * ldx + o % nX];
+            if (a.C_dev && tid < nU) a.C_dev[(sN + k) * nU + tid] = Cs[tid];
         }
         if (has_tile) {
             const double *Qk = a.Q_dev + (size_t)s * a.Q_seed_stride + (size_t)k * a.Q_step_stride;
@@ -230,7 +273,7 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
 #pragma unroll
                 for (int i = 0; i < TS; i++) kv[i] = Kp[u * ldx + i0 + i];
 #pragma unroll
-                for (int j = 0; j < TS; j++) gv[j] = G[u * ldw + nU + 1 + j0 + j];
+                for (int j = 0; j < TS; j++) gv[j] = Ks[u * ldx + j0 + j];
 #pragma unroll
                 for (int i = 0; i < TS; i++)
 #pragma unroll
@@ -240,10 +283,11 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
         if (affine) for (int i = tid; i < nX; i += LQ_T) {
             double v = a.q_dev[(sN + s + k) * nX + i];
             for (int m = 0; m < nX; m++) v += Am[m * ldx + i] * bv[m];
-            for (int u = 0; u < nU; u++) v -= G[u * ldw + nU + 1 + i] * (rv[u] + wv[u]);
+            for (int u = 0; u < nU; u++) v -= Ks[u * ldx + i] * rv[u];
             bn[i] = v;
         }
         __syncthreads();
+        LQ_STAMP(3);
         // ---- phase 5: P <- new tile, b <- new b, next A, B into LDS ---------------------------------------------
         if (has_tile) {
 #pragma unroll
@@ -254,6 +298,7 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
         if (affine) for (int i = tid; i < nX; i += LQ_T) bv[i] = bn[i];
         if (k > 0) commit();
         __syncthreads();
+        LQ_STAMP(4);
         // ---- phase 6: P <- (P + P')/2, one thread per unordered pair --------------------------------------------
         for (int e = tid; e < nX * nX; e += LQ_T) {
             const int i = e / nX, j = e % nX;
@@ -263,7 +308,11 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
             }
         }
         __syncthreads();
+        LQ_STAMP(5);
     }
+#if defined(TG_PROFILE)
+    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 8; i++) g_lq_prof[i] = lq_acc[i];
+#endif
     if (a.P0_dev) for (int e = tid; e < nX * nX; e += LQ_T) a.P0_dev[(size_t)s * nX * nX + e] = Pm[(e / nX) * ldx + e % nX];
     if (a.b0_dev && affine) for (int i = tid; i < nX; i += LQ_T) a.b0_dev[(size_t)s * nX + i] = bv[i];
     if (a.status_dev && tid == 0) a.status_dev[s] = s_sing ? TG_SINGULAR : TG_OK;
@@ -475,6 +524,7 @@ int tg_tv_lq(int32_t device, const tg_lq_problem *p) {
     if (!p->A_dev || !p->B_dev || !p->Q_dev || !p->Qf_dev || !p->R_dev || !p->K_dev) return fail(TG_ERR_INVALID, "null LQ buffer");
     if ((p->q_dev == nullptr) != (p->r_dev == nullptr)) return fail(TG_ERR_INVALID, "q and r must be given together");
     if (p->hz_dev && (p->hz_R < p->hz_nx + p->nU || p->hz_nx > p->nX)) return fail(TG_ERR_INVALID, "bad curvature block sizes");
+    if (p->nU > 64) return fail(TG_ERR_UNSUPPORTED, "more than 64 inputs");
     // size class: tile size TS with nX <= 16*TS (one tile per thread), prefetch registers RI*CI >= nX*ceil(nX/32)/8
     const int nX = p->nX, nXU = p->nX * p->nU;
     const int cls = (nX <= 32 && nXU <= 2 * LQ_T) ? 0 : ((nX <= 64 && nXU <= 6 * LQ_T) ? 1 : ((nX <= 80 && nXU <= 8 * LQ_T) ? 2 : ((nX <= 96 && nXU <= 12 * LQ_T) ? 3 : -1)));
@@ -575,6 +625,15 @@ int tg_copy_rows(int32_t device, int32_t n_rows, uint64_t row_doubles, const int
     HIP_TRY(hipGetLastError());
     return TG_SUCCESS;
 }
+
+#if defined(TG_PROFILE)
+int tg_lq_profile(int32_t device, int64_t out[8]) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lq_prof), 8 * sizeof(long long)));
+    return TG_SUCCESS;
+}
+#endif
 
 int tg_device_synchronize(int32_t device) {
     HIP_TRY(hipSetDevice(device));
