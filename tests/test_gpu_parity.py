@@ -165,6 +165,38 @@ def test_random_batch_matches_oracle(name, B, N):
     mvi.close()
 
 
+@pytest.mark.parametrize("links,B,N", [(20, 5, 30), (36, 3, 20)])
+def test_long_chain_matches_oracle(links, B, N):
+    """Size edge: an n-link pendulum is one chain of n joints with n(n+1)/2 (body, config) items.  20 links use
+    the 20-row register Gauss-Jordan, 36 links (nf > 32) the LDS Gauss-Jordan inside the rollout, and the
+    per-trajectory LDS slice grows to ~80 KB (one wavefront per CU).  Includes first derivatives."""
+    from oracle.oracle import OracleMVI
+    from trep_amd import systems, descriptor
+    system = systems.pendulum(links)
+    d = descriptor.flatten(system)
+    rng = np.random.default_rng(links)
+    Q0 = rng.uniform(-0.6, 0.6, (B, links))
+    mvi = _batch(system, B)
+    mvi.initialize_from_configs(0.0, Q0, DT, Q0)
+    X = mvi.rollout(N, DT, np.zeros((B, N, 0)), np.zeros((B, N, 0)))
+    iters, status = mvi.status()
+    assert (status == 0).all()
+    mvi.calc_deriv1()
+    o = OracleMVI(d)
+    for b in range(B):
+        o.initialize_from_configs(0.0, Q0[b], DT, Q0[b])
+        Xo, tot = o.rollout(N, DT, np.zeros((N, 0)), np.zeros((N, 0)))
+        assert relerr(X[b], Xo) < TOL, (links, b, relerr(X[b], Xo))
+        # with this many links the rounding floor of the residual sits near the 1e-10 stopping tolerance, so the
+        # last Newton iteration of a step is decided by rounding: counts may differ by up to one per step
+        assert abs(tot - iters[b]) <= (1 if links <= 20 else N)
+        o.calc_deriv1()
+        for n in ("q2_dq1", "q2_dp1", "p2_dq1", "p2_dp1"):
+            # derivatives are taken at the converged state, which itself agrees to ~1e-10 (sensitivity ~1e3 here)
+            assert relerr(mvi.deriv1(n)[b], o.deriv1(n)) < (1e-8 if links <= 20 else 1e-6), (links, b, n)
+    mvi.close()
+
+
 def test_full_size_properties_puppet():
     """BASELINE puppet size (B=8192, N=200): every trajectory converges, the DEL residual of the final
     state vanishes, and results do not depend on batch composition (bit-identical sub-batch)."""

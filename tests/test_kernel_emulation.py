@@ -129,3 +129,22 @@ def test_emulated_contracted_second_derivatives_match_oracle(name):
     HZ = e.deriv2z(z[None, :])[0]
     ref = oracle_hz(o, d, z)
     assert relerr(HZ, ref) < 1e-8, name
+
+
+@pytest.mark.parametrize("links", [12, 34])
+def test_emulated_long_chain_matches_oracle(links):
+    """n-link pendulum (one chain of n joints, n(n+1)/2 items; 34 links exceed the 32-row register solver's range)."""
+    from oracle.oracle import OracleMVI
+    from trep_amd import systems, descriptor
+    system = systems.pendulum(links)
+    d = descriptor.flatten(system)
+    rng = np.random.default_rng(links)
+    q0 = rng.uniform(-0.6, 0.6, links)
+    N = 10
+    e = EmuBatch(d, 1)
+    e.initialize_from_configs(0.0, q0[None], DT, q0[None])
+    X = e.rollout(N, DT, np.zeros((1, N, 0)), np.zeros((1, N, 0)))
+    o = OracleMVI(d)
+    o.initialize_from_configs(0.0, q0, DT, q0)
+    Xo, _ = o.rollout(N, DT, np.zeros((N, 0)), np.zeros((N, 0)))
+    assert relerr(X[0], Xo) < 1e-10
