@@ -24,7 +24,15 @@
 
 #if defined(__HIPCC__)
 #define TG_HD __host__ __device__ __forceinline__
-#define TG_SYNC() __syncthreads()
+// Phase boundary.  Lanes of a team exchange data through LDS only, so the fence is restricted to the LDS address
+// space: a plain __syncthreads() also waits for every outstanding GLOBAL store (s_waitcnt vmcnt(0)), which puts
+// the HBM write latency of the result rows on the critical path of the next phase.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TG_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
+                       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
+#else
+#define TG_SYNC() ((void)0)
+#endif
 #else
 #define TG_HD inline
 #define TG_SYNC() ((void)0)
@@ -1192,52 +1200,65 @@ struct Core {
         }
         TG_SYNC();
         TG_D2STAMP(2);
-        // ---- assemble HZ[a][b] column by column ------------------------------------------------------------------
-        // tangents: y_b = (x_b, e_i for a k2 variable) with x_b = AUG[0..nd)[nf+b]; l_b = AUG[nd..nf)[nf+b]
-        // HZ is symmetric; the value computed for (row a, column bcol) is stored at [bcol][a] so that the lanes of
-        // a phase write one contiguous row.  The per-column vectors are double-buffered (second copy in the dead
-        // H-independent scratch `vec2`), so the tangent products of column b+1 share a phase with the rows of
-        // column b: one barrier per column.
+        // ---- assemble HZ, four columns per pass --------------------------------------------------------------
+        // tangents: y_b = (x_b, e_i for a k2 variable) with x_b = AUG[0..nd)[nf+b]; l_b = AUG[nd..nf)[nf+b].
+        // HZ is symmetric; the value computed for (row a, column b) is stored at [b][a] so that the lanes of a phase
+        // write contiguous rows.  Four columns share every load of H22 / H12 (tangent products) and of the
+        // tangent matrix (row products): the loops are bound by LDS latency, not arithmetic.
         const int first_k2 = nq + nd + nu;
-        auto column_vectors = [&](int bcol, double *buf) {
-            double *hy = buf, *h12y = buf + nq, *g1l = buf + 2 * nq;
-            TG_FOR(j, nq) {
-                double a22 = 0.0, a12 = 0.0, ag = 0.0;
-#pragma unroll 4
+        double *hy = vec, *h12y = vec + 4 * nq, *g1l = vec + 8 * nq;     // [4][nq] each (vec and vec2 are adjacent)
+        for (int b0 = 0; b0 < R; b0 += 4) {
+            const int nb = R - b0 < 4 ? R - b0 : 4;
+            if (on) TG_FOR(j, nq) {
+                double a22[4] = {0, 0, 0, 0}, a12[4] = {0, 0, 0, 0}, ag[4] = {0, 0, 0, 0};
+#pragma unroll 2
                 for (int i2 = 0; i2 < nd; i2++) {
-                    const double yb = AUG[i2 * ld + nf + bcol];
-                    a22 += H22[sym(j, i2)] * yb; a12 += H12[j * hl + i2] * yb;
+                    const double h22 = H22[sym(j, i2)], h12 = H12[j * hl + i2];
+                    const double *yr = AUG + i2 * ld + nf + b0;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { const double yb = yr[c < nb ? c : 0]; a22[c] += h22 * yb; a12[c] += h12 * yb; }
                 }
-                if (bcol >= first_k2) { a22 += H22[sym(j, nd + (bcol - first_k2))]; a12 += H12[j * hl + nd + (bcol - first_k2)]; }
-#pragma unroll 2
-                for (int c = 0; c < nc; c++) ag += G1[j * nc + c] * AUG[(nd + c) * ld + nf + bcol];
-                hy[j] = a22; h12y[j] = a12; g1l[j] = ag;
+#pragma unroll
+                for (int c = 0; c < 4; c++) if (c < nb && b0 + c >= first_k2) {
+                    a22[c] += H22[sym(j, nd + (b0 + c - first_k2))]; a12[c] += H12[j * hl + nd + (b0 + c - first_k2)];
+                }
+                for (int cc = 0; cc < nc; cc++) {
+                    const double g = G1[j * nc + cc];
+                    const double *lr = AUG + (nd + cc) * ld + nf + b0;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) ag[c] += g * lr[c < nb ? c : 0];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) { hy[c * nq + j] = a22[c]; h12y[c * nq + j] = a12[c]; g1l[c * nq + j] = ag[c]; }
             }
-        };
-        double *vec2 = S + P.e_o_vec2;
-        if (on) column_vectors(0, vec);
-        TG_SYNC();
-        for (int bcol = 0; bcol < R; bcol++) {
-            const double *cur = (bcol & 1) ? vec2 : vec;
-            const double *hy = cur, *h12y = cur + nq, *g1l = cur + 2 * nq;
-            if (on && bcol + 1 < R) column_vectors(bcol + 1, (bcol & 1) ? vec : vec2);
+            TG_SYNC();
             if (on) TG_FOR(a, R) {
-                double acc = 0.0;
-#pragma unroll 4
-                for (int i2 = 0; i2 < nd; i2++) acc += AUG[i2 * ld + nf + a] * hy[i2];
-                if (a >= first_k2) acc += hy[nd + (a - first_k2)];
-                if (a < nq) acc += h12y[a] + g1l[a];
-                if (bcol < nq) {
-                    double s12 = 0.0, sg = 0.0;
-#pragma unroll 4
-                    for (int i2 = 0; i2 < nd; i2++) s12 += H12[bcol * hl + i2] * AUG[i2 * ld + nf + a];
-                    if (a >= first_k2) s12 += H12[bcol * hl + nd + (a - first_k2)];
+                double acc[4] = {0, 0, 0, 0}, s12[4] = {0, 0, 0, 0};
 #pragma unroll 2
-                    for (int c = 0; c < nc; c++) sg += G1[bcol * nc + c] * AUG[(nd + c) * ld + nf + a];
-                    acc += s12 + sg;
-                    if (a < nq) acc += H11[sym(a, bcol)];
+                for (int i2 = 0; i2 < nd; i2++) {
+                    const double x = AUG[i2 * ld + nf + a];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        acc[c] += x * hy[c * nq + i2];
+                        if (c < nb && b0 + c < nq) s12[c] += H12[(b0 + c) * hl + i2] * x;
+                    }
                 }
-                A.hz[(t * R + bcol) * R + a] = ok ? acc : NAN;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int bcol = b0 + c;
+                    if (c >= nb) break;
+                    double v = acc[c];
+                    if (a >= first_k2) v += hy[c * nq + nd + (a - first_k2)];
+                    if (a < nq) v += h12y[c * nq + a] + g1l[c * nq + a];
+                    if (bcol < nq) {
+                        double sg = 0.0;
+                        if (a >= first_k2) s12[c] += H12[bcol * hl + nd + (a - first_k2)];
+                        for (int cc = 0; cc < nc; cc++) sg += G1[bcol * nc + cc] * AUG[(nd + cc) * ld + nf + a];
+                        v += s12[c] + sg;
+                        if (a < nq) v += H11[sym(a, bcol)];
+                    }
+                    A.hz[(t * R + bcol) * R + a] = ok ? v : NAN;
+                }
             }
             TG_SYNC();
         }

@@ -418,7 +418,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     // 79.8 KB per trajectory -> two wavefronts per CU.
     off = P.d_o_T12;
     P.e_o_H11 = take(nq * (nq + 1) / 2); P.e_o_H22 = take(nq * (nq + 1) / 2); P.e_o_H12 = take(nq * (nq | 1)); P.e_o_G1 = take(nq * nc);
-    P.e_o_w = take(P.nf); P.e_o_zq = take(nd); P.e_o_zp = take(nd); P.e_o_vec = take(3 * nq); P.e_o_vec2 = take(3 * nq);
+    P.e_o_w = take(P.nf); P.e_o_zq = take(nd); P.e_o_zp = take(nd); P.e_o_vec = take(12 * nq); P.e_o_vec2 = P.e_o_vec;   // tangent products of four columns: [3][4][nq]
     off = std::max(off, P.d_lds_per_team);
     P.e_lds_per_team = (off + 1) & ~1;
     H.pack();
