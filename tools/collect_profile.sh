@@ -20,3 +20,12 @@ cp $(find $out/pmc_write -name "*counter_collection.csv" | head -1) $out/pmc_wri
 if [ -f trep_amd/libtrepamd_prof.so ]; then TREPAMD_LIB=trep_amd/libtrepamd_prof.so python tools/phase_profile.py 8192 50 > $out/phase_profile.txt 2>&1; fi
 rm -rf $out/trace $out/pmc_fetch $out/pmc_write
 ls -la $out; cat $out/bench.json; cat $out/kernel_stats.csv; head -5 $out/pmc_fetch.csv; head -5 $out/pmc_write.csv
+# kernel-level view of one batched discopt run (all kernels of the device-resident optimiser)
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_discopt -- python3 $GRAFT_REPO_ROOT/bench_discopt.py --seeds 64 --horizon 400 --quasi 1 --newton 1 > $out/bench_discopt_under_trace.json 2> $out/trace_discopt.err; echo "discopt trace rc=$?"
+cd $GRAFT_REPO_ROOT
+cp $(find $out/trace_discopt -name "*kernel_stats.csv" | head -1) $out/kernel_stats_discopt.csv 2>/dev/null
+rm -rf $out/trace_discopt
+timeout 900 python bench_discopt.py --seeds 256 --horizon 1000 --quasi 2 --newton 2 --stages > $out/bench_discopt.json 2> $out/bench_discopt.err
+python tools/bench_derivs.py --batch 65536 > $out/bench_derivs.json 2>&1
+cat $out/kernel_stats_discopt.csv | head -20; cat $out/bench_discopt.json | cut -c1-300
