@@ -147,6 +147,20 @@ def pmc_traffic(batch, rollout_steps, workload_prefix):
     return best
 
 
+def pmc_fp64(batch, rollout_steps, workload_prefix):
+    """fp64 flop per launch estimated from the committed SQ instruction counters (profiles/*_fp64.json)."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fp64.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("global_batch") == batch and d.get("rollout_steps") == rollout_steps and str(d.get("workload", "")).startswith(workload_prefix):
+            best = (d["estimated_fp64_flop_per_launch"], d["valu_f64_wave_instructions_per_launch"], os.path.relpath(path, ROOT))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,6 +278,11 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "path is fp64-VALU/LDS-latency bound, not HBM bound (SURVEY.md §8d)"},
         }
+        fp64 = pmc_fp64(B, N, "Puppet(string_constraints=True)") if (world == 1 and args.system == "puppet") else None
+        if fp64:   # secondary figure: the path is compute/latency bound, so also say how far from the fp64 peak
+            out["fp64"] = {"estimated_tflops": fp64[0] / avg_kernel_s / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                           "frac": fp64[0] / avg_kernel_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                           "flop_per_del_step": fp64[0] / (B * N), "f64_wave_instructions_per_del_step": fp64[1] / (B * N), "source": fp64[2]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(system, Q0, K, dt)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
