@@ -713,6 +713,94 @@ struct Core {
     }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+    // ---- Gauss-Jordan with two matrix COLUMNS PER LANE in registers: few rows, many right-hand sides --------------
+    //      (the derivative solves: n <= NR <= 32 rows, up to 128 columns [A | rhs]).  Lane c holds columns c and
+    //      c + 64 of every row.  Per pivot column k: lane k publishes its column in LDS (NR doubles); lane i < NR
+    //      scales entry i and one 32-bit wave max picks the pivot row r; every lane reads the multipliers back with
+    //      uniform (broadcast) LDS reads.  Rows never move and r is only known at run time, so a lane picks its
+    //      pivot-row entries with a 0/1-weighted FMA sum over its rows instead of an indexed register read.  The
+    //      matrix itself never touches LDS during the elimination.  Leaves x_i in A[i*ld + n + rhs] like
+    //      gauss_jordan().  `scal` is 4*NR doubles of scratch (scale factors, pivot reciprocals, row -> variable
+    //      map, current column).
+    template <int NR>
+    static __device__ __noinline__ bool gj_cols(bool on, double *A_generic, int n, int w, int ld, double *scal_generic, int lane) {
+        typedef __attribute__((address_space(3))) double lds_double;
+        lds_double *A = (lds_double *)A_generic, *scal = (lds_double *)scal_generic;
+        lds_double *dinv = scal + NR;                      // pivot reciprocal of physical row i
+        double a0[NR], a1[NR];
+        const bool c0 = on && lane < w, c1 = on && lane + 64 < w;
+        // implicit scaling factors 1 / max_j |a_ij| over the matrix columns: lane i < n owns row i
+        if (on && lane < NR) {
+            double s = -1.0;
+            if (lane < n) for (int j = 0; j < n; j++) { const double v = fabs(A[lane * ld + j]); s = v > s ? v : s; }
+            scal[lane] = lane < n ? 1.0 / s : 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+            a0[i] = (c0 && i < n) ? A[i * ld + lane] : 0.0;
+            a1[i] = (c1 && i < n) ? A[i * ld + lane + 64] : 0.0;
+        }
+        bool ok = true;
+        unsigned int used = 0u;
+        lds_double *colbuf = scal + 3 * NR;                // column k of the current step, published by its lane
+        for (int k = 0; k < n; k++) {
+            if (lane == k) {
+#pragma unroll
+                for (int i = 0; i < NR; i++) colbuf[i] = a0[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            // scaled pivot search, one row per lane: the magnitude only ranks candidates, so single precision with the
+            // lane in the low mantissa bits and one 32-bit wave max (scal is 0 for padding rows)
+            float mf = 0.0f;
+            if (lane < NR && !((used >> lane) & 1u)) mf = (float)(fabs(colbuf[lane]) * scal[lane]);
+            const unsigned int key = __ockl_wfred_max_u32((__float_as_uint(mf) & ~0x3Fu) | (unsigned int)(63 - lane));
+            const int r = __builtin_amdgcn_readfirstlane(63 - (int)(key & 0x3Fu));
+            if (on && ok && !(__uint_as_float(key & ~0x3Fu) > 1.0e-20f)) ok = false;
+            used |= 1u << r;
+            // this lane's pivot-row entries: 0/1-weighted sums (r is uniform but not a compile-time index)
+            double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NR; i++) {
+                const double e = (i == r) ? 1.0 : 0.0;
+                p0 = fma(e, a0[i], p0); p1 = fma(e, a1[i], p1);
+            }
+            const double piv = colbuf[r];
+            double inv = __builtin_amdgcn_rcp(piv);
+            inv = fma(inv, fma(-piv, inv, 1.0), inv);
+            inv = fma(inv, fma(-piv, inv, 1.0), inv);
+            if (lane == 0 && on) { ((__attribute__((address_space(3))) int *)(scal + 2 * NR))[r] = k; dinv[r] = 1.0 / piv; }
+            const double ginv = (on && ok) ? inv : 0.0;
+#pragma unroll
+            for (int i = 0; i < NR; i++) {
+                const double l = (i == r) ? 0.0 : colbuf[i] * ginv;     // uniform address: one LDS broadcast read
+                a0[i] = fma(-l, p0, a0[i]); a1[i] = fma(-l, p1, a1[i]);
+            }
+            // the next step overwrites colbuf: its reads above are ordered before those writes (same wavefront, in-order LDS)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        // physical row i solved variable var_i; write x = a / pivot into the row of the variable (right-hand sides only)
+        if (on && ok) {
+            const __attribute__((address_space(3))) int *var = (const __attribute__((address_space(3))) int *)(scal + 2 * NR);
+#pragma unroll
+            for (int i = 0; i < NR; i++) {
+                if (i < n) {
+                    const int v = var[i];
+                    const double d = dinv[i];
+                    if (c0 && lane >= n) A[v * ld + lane] = a0[i] * d;
+                    if (c1) A[v * ld + lane + 64] = a1[i] * d;
+                }
+            }
+        }
+        TG_SYNC();
+        return ok;
+    }
+#endif
+
     // =====================================================================================================
     // First derivatives of the step map (reference MidpointVI_calc_deriv1, midpointvi.c:749-1120).
     // The reference factors M2 and the projected matrix -Dh2 M2^-1 Dh1T separately and solves each
@@ -856,6 +944,24 @@ struct Core {
             TG_SYNC();
         }
         TG_STAMP(8);
+#if defined(__HIP_DEVICE_COMPILE__)
+        {   // small KKT matrix, many right-hand sides: register-resident column elimination (whole wavefront)
+            const int w = nf + R + (extra ? nc : 0), nb4 = (nf + 3) >> 2;
+            if (TEAM == 64 && w <= 128 && nb4 <= 8 && P.gjc_ok) {
+                double *sc = S + P.o_G;   // the joint poses are dead during the solve
+                switch (nb4) {
+                case 1: return Core<TEAM>::template gj_cols<4>(on, AUG, nf, w, ld, sc, lane);
+                case 2: return Core<TEAM>::template gj_cols<8>(on, AUG, nf, w, ld, sc, lane);
+                case 3: return Core<TEAM>::template gj_cols<12>(on, AUG, nf, w, ld, sc, lane);
+                case 4: return Core<TEAM>::template gj_cols<16>(on, AUG, nf, w, ld, sc, lane);
+                case 5: return Core<TEAM>::template gj_cols<20>(on, AUG, nf, w, ld, sc, lane);
+                case 6: return Core<TEAM>::template gj_cols<24>(on, AUG, nf, w, ld, sc, lane);
+                case 7: return Core<TEAM>::template gj_cols<28>(on, AUG, nf, w, ld, sc, lane);
+                default: return Core<TEAM>::template gj_cols<32>(on, AUG, nf, w, ld, sc, lane);
+                }
+            }
+        }
+#endif
         return gauss_jordan(on, AUG, nf, R + (extra ? nc : 0), ld, S + P.o_scal);
     }
 

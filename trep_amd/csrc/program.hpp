@@ -72,7 +72,7 @@ struct DevProg {
     const int *cf_cfg, *cf_in;
     // LDS layout (offsets in doubles from the team's base)
     int o_q1, o_q2, o_p1, o_lam, o_u, o_dq, o_f, o_sc, o_G, o_gB, o_pE, o_J, o_W, o_vB, o_gam, o_Ldq, o_Lddq,
-        o_Dh1, o_Dh2, o_Df, o_scal, o_misc, o_dqi, o_nu, o_sched, o_I, o_ctol;
+        o_Dh1, o_Dh2, o_Df, o_scal, o_misc, o_dqi, o_nu, o_sched, o_I, o_ctol, gjc_ok;
     int sched_ok;             // 1: every round has <= 16 chains: the chain schedule is staged in LDS (o_sched)
     int df_ld;
     int dh_ld;                // 0: the step kernel keeps Dh1/Dh2 compact (one value per dh item)
@@ -411,6 +411,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.d_o_Dh1 = take(nc * nq); P.d_o_Dh2 = take(nc * nq);
     P.d_aug_ld = (P.nf + P.d_nrhs + nc) | 1;  // + nc unit columns used by the second-derivative adjoint
     P.d_o_AUG = take(P.nf * P.d_aug_ld);
+    P.gjc_ok = (std::max(12 * nj, 2 * nitems) >= 4 * 32) ? 1 : 0;   // gj_cols scratch (128 doubles) lives in the dead pose area
     P.d_o_T12 = take(nq * nd); P.d_o_T22 = take(nq * nd);
     P.d_lds_per_team = (off + 1) & ~1;
     // second-derivative (z-contracted) kernel: starts where the two D.D2L2 tables of the deriv1 layout are (they are
