@@ -811,54 +811,15 @@ struct Core {
     // sum_c lambda_c h_c,dqdq(q_i, q_o) added to the q1 right-hand sides (calc_h1_deriv1 :864-889 and
     // the DDh1T term of calc_deriv1 :964-966); state q1 must be swept, pE valid.
     TG_HD void constraint_hessian_rhs(bool on, double *AUG, int ld) {
-        const int nq = P.nq, nd = P.nd, nf = P.nf;
-        if (on) {
-            const int cwl = tile_log2<TEAM>(nd), cw = 1 << cwl, rstep = TEAM >> cwl;
-            for (int i = lane >> cwl; i < nq; i += rstep)
-                for (int o = lane & (cw - 1); o < nd; o += cw) {
-                    double acc = 0.0;
-                    for (int c = 0; c < P.nc; c++) {
-                        const int ni = P.dh_lookup[c * nq + i], no = P.dh_lookup[c * nq + o];
-                        if (ni < 0 || no < 0) continue;
-                        const int si = P.dh_side[ni], so = P.dh_side[no], ji = P.dh_joint[ni], jo = P.dh_joint[no];
-                        double hqq = 0.0;
-                        if (ji >= 0 && jo >= 0) {
-                            const int e1 = P.c_e1[c], e2 = P.c_e2[c];
-                            double di1[3] = {0, 0, 0}, do1[3] = {0, 0, 0}, di2[3] = {0, 0, 0}, do2[3] = {0, 0, 0};
-                            if (si & 1) dpos(e1, ji, di1);
-                            if (so & 1) dpos(e1, jo, do1);
-                            if (si & 2) dpos(e2, ji, di2);
-                            if (so & 2) dpos(e2, jo, do2);
-                            // second derivative of each end point: w_a x d_b with a the joint nearer the root
-                            const int ja = ji < jo ? ji : jo;
-                            double dd[3] = {0, 0, 0};
-                            if (P.j_kind[ja] >= TG_RX) {
-                                const double *ga = S + P.o_G + 12 * ja;
-                                const int ax = P.j_kind[ja] - TG_RX;
-                                const double wx = ga[ax], wy = ga[4 + ax], wz = ga[8 + ax];
-                                if ((si & 1) && (so & 1)) {
-                                    const double *db = ji < jo ? do1 : di1;
-                                    dd[0] += wy * db[2] - wz * db[1]; dd[1] += wz * db[0] - wx * db[2]; dd[2] += wx * db[1] - wy * db[0];
-                                }
-                                if ((si & 2) && (so & 2)) {
-                                    const double *db = ji < jo ? do2 : di2;
-                                    dd[0] -= wy * db[2] - wz * db[1]; dd[1] -= wz * db[0] - wx * db[2]; dd[2] -= wx * db[1] - wy * db[0];
-                                }
-                            }
-                            if (P.c_type[c] == TG_CONSTRAINT_POINT) hqq = dd[P.c_comp[c]];
-                            else {
-                                const double *a = S + P.o_pE + 3 * e1, *b = S + P.o_pE + 3 * e2;
-                                const double vx = a[0] - b[0], vy = a[1] - b[1], vz = a[2] - b[2];
-                                hqq = 2.0 * ((di1[0] - di2[0]) * (do1[0] - do2[0]) + (di1[1] - di2[1]) * (do1[1] - do2[1]) +
-                                             (di1[2] - di2[2]) * (do1[2] - do2[2]) + vx * dd[0] + vy * dd[1] + vz * dd[2]);
-                            }
-                        } else if ((si & 4) && (so & 4) && i == o) {
-                            hqq = -2.0;  // distance.c:90-93: both are the string-length config
-                        }
-                        acc += hqq * S[P.o_lam + c];
-                    }
-                    AUG[o * ld + nf + i] += acc;
-                }
+        const int nd = P.nd, nf = P.nf;
+        // one lane per (constraint, a <= b) pair of the flat list (second derivatives are symmetric); several
+        // constraints reach the same entry, hence LDS atomics (one wavefront: deterministic order)
+        if (on) TG_FOR(pp, P.n_cpair) {
+            const int *pw = P.cpair4 + 4 * (size_t)pp;
+            const int c = pw[0], na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+            const double h = S[P.o_lam + c] * con_d2(c, na, nb);
+            if (kb < nd) lds_add(&AUG[kb * ld + nf + ka], h);
+            if (na != nb && ka < nd) lds_add(&AUG[ka * ld + nf + kb], h);
         }
         TG_SYNC();
     }
