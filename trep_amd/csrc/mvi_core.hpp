@@ -1200,31 +1200,137 @@ struct Core {
         if (nc) {
             pose_sweep(on, 1);
             attach_points(on, false, true);
+            if (P.o_cps >= 0) {
+                // The sums over the output index o are pushed into prefix / suffix sums along each end point's joint
+                // path, which makes the w-contracted third derivative of a constraint O(1) per (a, b) pair instead
+                // of a loop over o.  With D_t = d p_E / d q_t, Om_t = world axis of joint t (0 if prismatic) and t
+                // ordered root-first:  d2 p(x<=y) = Om_x x D_y,  d3 p(x<=y<=z) = Om_x x (Om_y x D_z), so for x <= y
+                //   sum_o w_o d2p(x,o)   = Om_x x SD_x + PW_x x D_x
+                //   sum_o w_o d3p(x,y,o) = Om_x x (Om_y x SD_y) + Om_x x ((PW_y - PW_x) x D_y) + PW_x x (Om_x x D_y)
+                // with SD_t = sum_{u >= t} w_u D_u and PW_t = sum_{u < t} w_u Om_u (w_u = 0 for kinematic configs).
+                double *cps = S + P.o_cps;
+                auto item = [&](int n, int E, double *D, double *Om, double &wt) {   // D, Om, weight of dh item n for end point E
+                    const int *rec = P.dh_pack + 8 * (size_t)n;
+                    const int k = rec[1], oj = rec[2], kind = (rec[3] >> 8) & 0xFF;
+                    dpos_rec(rec[4 + E], oj, kind, D);
+                    if (kind >= TG_RX) { const double *gj = S + P.o_G + oj; const int ax = kind - TG_RX; Om[0] = gj[ax]; Om[1] = gj[4 + ax]; Om[2] = gj[8 + ax]; }
+                    else { Om[0] = Om[1] = Om[2] = 0.0; }
+                    wt = k < nd ? w[k] : 0.0;
+                };
+                auto cross = [](const double *a, const double *b, double *r) {
+                    r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0];
+                };
+                if (on) TG_FOR(ce, 2 * nc) {
+                    const int t0 = P.cpath_off[ce], t1 = P.cpath_off[ce + 1], E = ce & 1;
+                    double pw[3] = {0, 0, 0}, sd[3] = {0, 0, 0}, D[3], Om[3], wt;
+                    for (int t = t0; t < t1; t++) {
+                        item(P.cpath_items[t], E, D, Om, wt);
+                        cps[6 * t + 3] = pw[0]; cps[6 * t + 4] = pw[1]; cps[6 * t + 5] = pw[2];
+                        pw[0] += wt * Om[0]; pw[1] += wt * Om[1]; pw[2] += wt * Om[2];
+                    }
+                    for (int t = t1 - 1; t >= t0; t--) {
+                        item(P.cpath_items[t], E, D, Om, wt);
+                        sd[0] += wt * D[0]; sd[1] += wt * D[1]; sd[2] += wt * D[2];
+                        cps[6 * t] = sd[0]; cps[6 * t + 1] = sd[1]; cps[6 * t + 2] = sd[2];
+                    }
+                    double *vw = cps + 6 * P.n_cpath + 3 * ce;       // sum_o w_o D_o over the whole path
+                    vw[0] = sd[0]; vw[1] = sd[1]; vw[2] = sd[2];
+                }
+                TG_SYNC();
+                // per dh item a: v_a, V2w_a (differences end point 1 - end point 2); returns false if a has no joint
+                auto first_second = [&](int c, int n, double *va, double *V2) {
+                    va[0] = va[1] = va[2] = V2[0] = V2[1] = V2[2] = 0.0;
+                    for (int E = 0; E < 2; E++) {
+                        const int t = P.dh_pos[2 * n + E];
+                        if (t < 0) continue;
+                        const double *q = cps + 6 * (P.cpath_off[2 * c + E] + t);
+                        double D[3], Om[3], wt, x1[3], x2[3];
+                        item(n, E, D, Om, wt);
+                        cross(Om, q, x1); cross(q + 3, D, x2);
+                        const double sg = E ? -1.0 : 1.0;
+                        for (int m = 0; m < 3; m++) { va[m] += sg * D[m]; V2[m] += sg * (x1[m] + x2[m]); }
+                    }
+                };
+                if (on) TG_FOR(pp, P.n_cpair) {
+                    const int *pw4 = P.cpair4 + 4 * (size_t)pp;
+                    const int c = pw4[0], na = pw4[1], nb = pw4[2], ka = pw4[3] & 0xFFFF, kb = pw4[3] >> 16;
+                    const int *rc = P.dh_pack + 8 * (size_t)na;
+                    const int type = (rc[3] >> 16) & 0xFF, comp = rc[3] >> 24;
+                    double va[3], vb[3], V2a[3], V2b[3], vab[3] = {0, 0, 0}, V3[3] = {0, 0, 0}, Vw[3] = {0, 0, 0};
+                    first_second(c, na, va, V2a);
+                    first_second(c, nb, vb, V2b);
+                    for (int E = 0; E < 2; E++) {
+                        const double sg = E ? -1.0 : 1.0;
+                        const double *vw = cps + 6 * P.n_cpath + 3 * (2 * c + E);
+                        for (int m = 0; m < 3; m++) Vw[m] += sg * vw[m];
+                        const int ta = P.dh_pos[2 * na + E], tb = P.dh_pos[2 * nb + E];
+                        if (ta < 0 || tb < 0) continue;
+                        const int nx = ta <= tb ? na : nb, ny = ta <= tb ? nb : na;
+                        const int base = P.cpath_off[2 * c + E];
+                        const double *qx = cps + 6 * (base + (ta <= tb ? ta : tb)), *qy = cps + 6 * (base + (ta <= tb ? tb : ta));
+                        double Dx[3], Ox[3], Dy[3], Oy[3], wt, d2[3], t1[3], t2[3], t3[3], dpw[3];
+                        item(nx, E, Dx, Ox, wt); item(ny, E, Dy, Oy, wt);
+                        cross(Ox, Dy, d2);                                   // d2 p(x, y)
+                        cross(Oy, qy, t1); cross(Ox, t1, t2);                // Om_x x (Om_y x SD_y)
+                        for (int m = 0; m < 3; m++) dpw[m] = qy[3 + m] - qx[3 + m];
+                        cross(dpw, Dy, t1); cross(Ox, t1, t3);               // Om_x x ((PW_y - PW_x) x D_y)
+                        double t4[3];
+                        cross(qx + 3, d2, t4);                               // PW_x x (Om_x x D_y)
+                        for (int m = 0; m < 3; m++) { vab[m] += sg * d2[m]; V3[m] += sg * (t2[m] + t3[m] + t4[m]); }
+                    }
+                    double acc;
+                    if (type == TG_CONSTRAINT_POINT) acc = V3[comp];
+                    else {
+                        const double *pa = S + P.o_pE + rc[4], *pb = S + P.o_pE + rc[5];
+                        const double d0 = pa[0] - pb[0], d1 = pa[1] - pb[1], d2_ = pa[2] - pb[2];
+                        acc = 2.0 * (va[0] * V2b[0] + va[1] * V2b[1] + va[2] * V2b[2] + vb[0] * V2a[0] + vb[1] * V2a[1] + vb[2] * V2a[2] +
+                                     Vw[0] * vab[0] + Vw[1] * vab[1] + Vw[2] * vab[2] + d0 * V3[0] + d1 * V3[1] + d2_ * V3[2]);
+                    }
+                    lds_add(&H11[sym(ka, kb)], S[P.o_lam + c] * acc);
+                }
+                if (on) TG_FOR(na, P.n_dh) {  // G1[ka][c] = sum_o w_o h_c,dqdq(ka, o) = 2 (v_a . Vw + d . V2w_a)
+                    const int *rc = P.dh_pack + 8 * (size_t)na;
+                    const int c = rc[0], type = (rc[3] >> 16) & 0xFF, comp = rc[3] >> 24;
+                    double va[3], V2a[3], Vw[3];
+                    first_second(c, na, va, V2a);
+                    const double *v1 = cps + 6 * P.n_cpath + 3 * (2 * c), *v2 = v1 + 3;
+                    for (int m = 0; m < 3; m++) Vw[m] = v1[m] - v2[m];
+                    double g;
+                    if (type == TG_CONSTRAINT_POINT) g = V2a[comp];
+                    else {
+                        const double *pa = S + P.o_pE + rc[4], *pb = S + P.o_pE + rc[5];
+                        g = 2.0 * (va[0] * Vw[0] + va[1] * Vw[1] + va[2] * Vw[2] + (pa[0] - pb[0]) * V2a[0] + (pa[1] - pb[1]) * V2a[1] + (pa[2] - pb[2]) * V2a[2]);
+                    }
+                    G1[rc[1] * nc + c] = g;
+                }
+                TG_SYNC();
+            } else {
             // one lane per (constraint, a <= b) pair of the flat list; third derivatives are symmetric in (a, b).
-            // Several constraints reach the same entry: LDS atomics (one wavefront, fixed order, deterministic).
-            if (on) TG_FOR(pp, P.n_cpair) {
-                const int *pw = P.cpair4 + 4 * (size_t)pp;
-                const int c = pw[0], na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
-                const int n0 = P.cu_off[c], n1 = P.cu_off[c + 1];
-                double acc = 0.0;
-                for (int no = n0; no < n1; no++) {
-                    const int ko = P.dh_cfg[no];
-                    if (ko >= nd) continue;
-                    acc += w[ko] * con_d3(c, na, nb, no);
+                // Several constraints reach the same entry: LDS atomics (one wavefront, fixed order, deterministic).
+                if (on) TG_FOR(pp, P.n_cpair) {
+                    const int *pw = P.cpair4 + 4 * (size_t)pp;
+                    const int c = pw[0], na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+                    const int n0 = P.cu_off[c], n1 = P.cu_off[c + 1];
+                    double acc = 0.0;
+                    for (int no = n0; no < n1; no++) {
+                        const int ko = P.dh_cfg[no];
+                        if (ko >= nd) continue;
+                        acc += w[ko] * con_d3(c, na, nb, no);
+                    }
+                    const double val = S[P.o_lam + c] * acc;
+                    lds_add(&H11[sym(ka, kb)], val);
                 }
-                const double val = S[P.o_lam + c] * acc;
-                lds_add(&H11[sym(ka, kb)], val);
-            }
-            if (on) TG_FOR(na, P.n_dh) {  // G1[ka][c] = sum_o w_o h_c,dqdq(ka, o)
-                const int c = P.dh_c[na], n0 = P.cu_off[c], n1 = P.cu_off[c + 1];
-                double g = 0.0;
-                for (int no = n0; no < n1; no++) {
-                    const int ko = P.dh_cfg[no];
-                    if (ko < nd) g += w[ko] * con_d2(c, na, no);
+                if (on) TG_FOR(na, P.n_dh) {  // G1[ka][c] = sum_o w_o h_c,dqdq(ka, o)
+                    const int c = P.dh_c[na], n0 = P.cu_off[c], n1 = P.cu_off[c + 1];
+                    double g = 0.0;
+                    for (int no = n0; no < n1; no++) {
+                        const int ko = P.dh_cfg[no];
+                        if (ko < nd) g += w[ko] * con_d2(c, na, no);
+                    }
+                    G1[P.dh_cfg[na] * nc + c] = g;
                 }
-                G1[P.dh_cfg[na] * nc + c] = g;
+                TG_SYNC();
             }
-            TG_SYNC();
             // ---- constraints at q2: H22 -= sum_c w_lambda,c DDh2[c] (calc_h2_deriv2 :1597-1622) -------------
             pose_sweep(on, 2);
             attach_points(on, false, true);

@@ -11,6 +11,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -58,6 +59,11 @@ struct DevProg {
     //   dh_pack[2n]  = {constraint, config, 12*joint (or -1), side | joint kind << 8 | constraint type << 16 | component << 24}
     //   dh_pack[2n+1]= {3*end point 1, 3*end point 2, length config (or -1), 0}
     const int *it_pack, *dh_pack;
+    // second-derivative kernel, constraint part: for constraint c and end point E (0/1) the dh items whose joint lies on
+    // the end point's path, sorted root-first: cpath_items[cpath_off[2c+E] .. cpath_off[2c+E+1]); dh_pos[2n+E] = position
+    // of dh item n in that list or -1.  o_cps: LDS scratch (6 doubles per listed item), aliased with the dead J/W area.
+    const int *cpath_off, *cpath_items, *dh_pos;
+    int n_cpath, o_cps;
     int n_tri, n_cpair;
     const int *cfg_item_off;  // [nq+1] CSR config -> items
     const int *cfg_items;     // [n_items]
@@ -91,7 +97,7 @@ struct HostProgram {
     std::vector<double> j_pre;
     std::vector<int> b_anchor;
     std::vector<double> b_C, b_inertia;
-    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4, tri4, cpair4, it_pack, dh_pack;
+    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4, tri4, cpair4, it_pack, dh_pack, cpath_off, cpath_items, dh_pos;
     std::vector<int> e_anchor;
     std::vector<double> e_off;
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
@@ -346,6 +352,17 @@ inline HostProgram build_program(const tg_system_desc *d) {
     H.cu_off.assign(nc + 1, 0);
     for (size_t n = 0; n < H.dh_c.size(); n++) H.cu_off[H.dh_c[n] + 1] = (int)n + 1;
     for (int c = 0; c < nc; c++) if (H.cu_off[c + 1] < H.cu_off[c]) H.cu_off[c + 1] = H.cu_off[c];
+    H.cpath_off.assign(2 * nc + 1, 0);
+    H.dh_pos.assign(2 * H.dh_c.size(), -1);
+    for (int c = 0; c < nc; c++)
+        for (int E = 0; E < 2; E++) {
+            std::vector<std::pair<int, int>> on;   // (joint, dh item)
+            for (int n = H.cu_off[c]; n < H.cu_off[c + 1]; n++)
+                if (H.dh_joint[n] >= 0 && (H.dh_side[n] & (1 << E))) on.push_back({H.dh_joint[n], n});
+            std::sort(on.begin(), on.end());
+            for (size_t t = 0; t < on.size(); t++) { H.dh_pos[2 * on[t].second + E] = (int)t; H.cpath_items.push_back(on[t].second); }
+            H.cpath_off[2 * c + E + 1] = (int)H.cpath_items.size();
+        }
     for (size_t n = 0; n < H.dh_c.size(); n++) {
         const int c = H.dh_c[n], j = H.dh_joint[n];
         H.dh_pack.push_back(c); H.dh_pack.push_back(H.dh_cfg[n]); H.dh_pack.push_back(j >= 0 ? 12 * j : -1);
@@ -372,6 +389,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.n_cfgitems = (int)H.cfg_items.size();
     P.n_npairs = (int)(H.pair4.size() / 4);
     P.n_tri = (int)(H.tri4.size() / 4); P.n_cpair = (int)(H.cpair4.size() / 4);
+    P.n_cpath = (int)H.cpath_items.size();
     P.grav[0] = P.grav[1] = P.grav[2] = 0.0;
     for (int i = 0; i < d->n_gravity; i++)
         for (int k = 0; k < 3; k++) P.grav[k] += d->gravity[3 * (size_t)i + k];
@@ -411,6 +429,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.d_o_Dh1 = take(nc * nq); P.d_o_Dh2 = take(nc * nq);
     P.d_aug_ld = (P.nf + P.d_nrhs + nc) | 1;  // + nc unit columns used by the second-derivative adjoint
     P.d_o_AUG = take(P.nf * P.d_aug_ld);
+    P.o_cps = (6 * P.n_cpath + 6 * nc <= 12 * nitems) ? P.o_J : -1;   // prefix / suffix sums of the constraint paths + per-constraint sums
     P.gjc_ok = (std::max(12 * nj, 2 * nitems) >= 4 * 32) ? 1 : 0;   // gj_cols scratch (128 doubles) lives in the dead pose area
     P.d_o_T12 = take(nq * nd); P.d_o_T22 = take(nq * nd);
     P.d_lds_per_team = (off + 1) & ~1;
@@ -442,7 +461,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(level_off) X(lvl_joints) X(round_off) X(ch_first) X(ch_len) X(ch_parent) X(j_parent) X(j_kind) X(j_cfg) X(j_pre_ident) X(b_anchor) X(b_item_off) X(b_pair_off) X(it_body) \
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
-    X(tri4) X(cpair4) X(it_pack) X(dh_pack)
+    X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos)
 #define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp)
 
 inline void HostProgram::pack() {
