@@ -1347,31 +1347,142 @@ struct Core {
         eval_midpoint(on);
         TG_D2STAMP(1);
         const double c8 = 0.125 * dt, c2 = 0.5 / dt;
-        // one lane per ordered (item x, item y) pair of the flat list over all bodies; the output index o runs over the
-        // body's items.  Bodies share configs, so the accumulation uses LDS atomics like the Newton matrix.
-        if (on) TG_FOR(pp, P.n_tri) {
-            const int *pw = P.tri4 + 4 * (size_t)pp;
-            const int x = pw[0], y = pw[1], kx = pw[2] & 0xFFFF, ky = pw[2] >> 16, b = pw[3];
-            const int i0 = P.b_item_off[b], i1 = P.b_item_off[b + 1];
-            double h11 = 0.0, h12 = 0.0, h22 = 0.0;
-            for (int o = i0; o < i1; o++) {
-                const int ko = P.it_cfg[o];
-                if (ko >= nd) continue;
-                const Third T = third_order(b, x, y, o);
-                const double q = c8 * T.q, dx = 0.25 * T.dx, dy = 0.25 * T.dy, dO = 0.25 * T.dO;
-                const double eo = c2 * T.eo, ey = c2 * T.ey, ex = c2 * T.ex;
-                // T(sa,sb,so) = q + sa dx + sb dy + so dO + sa sb eo + sa so ey + sb so ex  (midpointvi.c:1122-1453)
-                const double t111 = q - dx - dy - dO + eo + ey + ex, t112 = q - dx - dy + dO + eo - ey - ex;
-                const double t121 = q - dx + dy - dO - eo + ey - ex, t122 = q - dx + dy + dO - eo - ey + ex;
-                const double t221 = q + dx + dy - dO + eo - ey - ex, t222 = q + dx + dy + dO + eo + ey + ex;
-                h11 += -w[ko] * t111 + zp[ko] * t112;
-                h12 += -w[ko] * t121 + zp[ko] * t122;
-                h22 += -w[ko] * t221 + zp[ko] * t222;
+        if (P.n_tchunk > 0) {
+            // The sums over the output item o are pushed into prefix / suffix sums along every body's item path, so
+            // the (w, z_p)-contracted third-order terms cost O(1) per (x, y) pair instead of a loop over o.
+            // Contracting T(sa,sb,so) = q + sa dx + sb dy + sa sb eo + so (dO + sa ey + sb ex) with -w_o at so = -1 and
+            // z_p,o at so = +1 leaves two weights per item, alpha_o = z_p,o - w_o on the so-free terms and
+            // beta_o = z_p,o + w_o on the others (0 for kinematic configs).  Per item t (root-first):
+            //   SJa_t = sum_{o >= t} alpha_o J_o,  PWa_t = sum_{o < t} alpha_o W_o,  PJb_t = sum_{o < t} beta_o J_o
+            // and per body TWa, TJa, TJb.  Every term of system.c:204-530 is linear in the slot that o occupies; which
+            // slot that is depends on the position of o relative to x and y, which is what the three ranges
+            // (o >= hi, lo <= o < hi, o < lo) below are.
+            double *tps = S + P.o_tps;
+            for (int ci = 0; ci < P.n_tchunk; ci++) {
+                const int b0 = P.tchunk[ci], b1 = P.tchunk[ci + 1];
+                const int it0 = P.b_item_off[b0], nit = P.b_item_off[b1] - it0;
+                if (on) TG_FOR(idx, 6 * (b1 - b0)) {
+                    const int b = b0 + idx / 6, m = idx % 6;
+                    const int first = P.b_item_off[b], last = P.b_item_off[b + 1];
+                    double pwa = 0.0, pjb = 0.0, sja = 0.0;
+                    for (int k = first; k < last; k++) {
+                        const int cfg = P.it_pack[4 * (size_t)k + 3] & 0xFFFF;
+                        const double al = cfg < nd ? zp[cfg] - w[cfg] : 0.0, be = cfg < nd ? zp[cfg] + w[cfg] : 0.0;
+                        double *q = tps + 18 * (k - it0);
+                        q[6 + m] = pwa; q[12 + m] = pjb;
+                        pwa += al * S[P.o_W + 6 * k + m]; pjb += be * S[P.o_J + 6 * k + m];
+                    }
+                    for (int k = last - 1; k >= first; k--) {
+                        const int cfg = P.it_pack[4 * (size_t)k + 3] & 0xFFFF;
+                        const double al = cfg < nd ? zp[cfg] - w[cfg] : 0.0;
+                        sja += al * S[P.o_J + 6 * k + m];
+                        tps[18 * (k - it0) + m] = sja;
+                    }
+                    double *tb = tps + 18 * nit + 18 * (b - b0);
+                    tb[m] = pwa; tb[6 + m] = sja; tb[12 + m] = pjb;      // TWa, TJa, TJb
+                }
+                TG_SYNC();
+                if (on) for (int pp = P.tri_off[b0] + tg_opaque(lane); pp < P.tri_off[b1]; pp += TEAM) {
+                    const int *pw = P.tri4 + 4 * (size_t)pp;
+                    const int x = pw[0], y = pw[1], kx = pw[2] & 0xFFFF, ky = pw[2] >> 16, b = pw[3];
+                    const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
+                    const int lo = x < y ? x : y, hi = x < y ? y : x;
+                    const double *Jx = S + P.o_J + 6 * x, *Jy = S + P.o_J + 6 * y, *Wx = S + P.o_W + 6 * x, *Wy = S + P.o_W + 6 * y;
+                    const double *Jlo = S + P.o_J + 6 * lo, *Jhi = S + P.o_J + 6 * hi, *Wlo = S + P.o_W + 6 * lo;
+                    const double *qx = tps + 18 * (x - it0), *qy = tps + 18 * (y - it0);
+                    const double *qlo = tps + 18 * (lo - it0), *qhi = tps + 18 * (hi - it0);
+                    const double *TWa = tps + 18 * nit + 18 * (b - b0), *TJa = TWa + 6, *TJb = TWa + 12;
+                    double t1[6], t2[6], t3[6];
+                    // V2a_t = sum_o alpha_o d2v(t, o) = [W_t, SJa_t] + [PWa_t, J_t]
+                    double V2x[6], V2y[6];
+                    bracket(Wx, qx, V2x); bracket(qx + 6, Jx, t1);
+                    for (int m = 0; m < 6; m++) V2x[m] += t1[m];
+                    bracket(Wy, qy, V2y); bracket(qy + 6, Jy, t1);
+                    for (int m = 0; m < 6; m++) V2y[m] += t1[m];
+                    double v2xy[6];
+                    bracket(Wlo, Jhi, v2xy);                                   // d2v(x, y)
+                    // ---- q: L_dqdqdq (system.c:204-268) ----
+                    double dS[6];
+                    for (int m = 0; m < 6; m++) dS[m] = qlo[m] - qhi[m];        // sum over lo <= o < hi of alpha_o J_o
+                    bracket(v2xy, qhi, t1);                                    // o >= hi
+                    bracket(Wlo, dS, t2); bracket(t2, Jhi, t3);                // lo <= o < hi
+                    for (int m = 0; m < 6; m++) t1[m] += t3[m];
+                    bracket(qlo + 6, Jlo, t2); bracket(t2, Jhi, t3);           // o < lo
+                    for (int m = 0; m < 6; m++) t1[m] += t3[m];
+                    double Q = inner6(I, Wx, V2y) + inner6(I, Wy, V2x) + inner6(I, TWa, v2xy) + inner6(I, v, t1);
+                    {   // gravity: m gam . sum_o alpha_o w_a x (w_b x lin_c), (a, b, c) = sorted (x, y, o)
+                        auto cross = [](const double *p, const double *q_, double *r) {
+                            r[0] = p[1] * q_[2] - p[2] * q_[1]; r[1] = p[2] * q_[0] - p[0] * q_[2]; r[2] = p[0] * q_[1] - p[1] * q_[0];
+                        };
+                        double u[3], g[3], gs[3] = {0, 0, 0}, pa[3];
+                        cross(Jhi + 3, qhi, u); cross(Jlo + 3, u, g);          // o >= hi: w_lo x (w_hi x lin(SJa_hi))
+                        for (int m = 0; m < 3; m++) gs[m] += g[m];
+                        cross(dS + 3, Jhi, u); cross(Jlo + 3, u, g);           // lo <= o < hi: w_lo x (w_o x lin_hi)
+                        for (int m = 0; m < 3; m++) gs[m] += g[m];
+                        for (int m = 0; m < 3; m++) pa[m] = TJa[3 + m] - qlo[3 + m];   // sum over o < lo of alpha_o w_o
+                        cross(Jlo + 3, Jhi, u); cross(pa, u, g);               // o < lo: w_o x (w_lo x lin_hi)
+                        for (int m = 0; m < 3; m++) gs[m] += g[m];
+                        Q += I[0] * (gam[0] * gs[0] + gam[1] * gs[1] + gam[2] * gs[2]);
+                    }
+                    // ---- dx, dy: L_ddqdqdq with the dq slot on x resp. y (system.c:336-393), alpha-weighted ----
+                    double JxSx[6], JySy[6], Jxy[6];
+                    bracket(Jx, qx, JxSx); bracket(Jy, qy, JySy);             // [J_t, SJa_t] = sum_{o > t} alpha_o [J_t, J_o]
+                    double Dx = inner6(I, Jx, V2y) + inner6(I, JxSx, Wy), Dy = inner6(I, Jy, V2x) + inner6(I, JySy, Wx);
+                    if (x < y) {
+                        bracket(Jx, Jy, Jxy);
+                        bracket(Jxy, qy, t1); bracket(Jx, dS, t2); bracket(t2, Jy, t3);     // (lo, hi) = (x, y): dS = SJa_x - SJa_y
+                        for (int m = 0; m < 6; m++) t1[m] += t3[m];
+                        Dx += inner6(I, Jxy, TWa) + inner6(I, t1, v);
+                    } else if (y < x) {
+                        bracket(Jy, Jx, Jxy);
+                        bracket(Jxy, qx, t1); bracket(Jy, dS, t2); bracket(t2, Jx, t3);     // (lo, hi) = (y, x): dS = SJa_y - SJa_x
+                        for (int m = 0; m < 6; m++) t1[m] += t3[m];
+                        Dy += inner6(I, Jxy, TWa) + inner6(I, t1, v);
+                    }
+                    // ---- eo: L_ddqddqdq(dq x, dq y; q o), alpha-weighted (system.c:491-530) ----
+                    const double Eo = inner6(I, JxSx, Jy) + inner6(I, Jx, JySy);
+                    // ---- dO, ey, ex: o in a dq slot, beta-weighted ----
+                    double PxJx[6], PyJy[6];
+                    bracket(qx + 12, Jx, PxJx); bracket(qy + 12, Jy, PyJy);    // [PJb_t, J_t] = sum_{o < t} beta_o [J_o, J_t]
+                    bracket(x < y ? PxJx : PyJy, Jhi, t1);                     // [[PJb_lo, J_lo], J_hi]
+                    const double DO = inner6(I, TJb, v2xy) + inner6(I, PxJx, Wy) + inner6(I, PyJy, Wx) + inner6(I, t1, v);
+                    double Ey = inner6(I, Jx, PyJy), Ex = inner6(I, Jy, PxJx);
+                    if (x < y) Ey += inner6(I, Jxy, TJb);
+                    else if (y < x) Ex += inner6(I, Jxy, TJb);
+                    const double q_ = c8 * Q, dx = 0.25 * Dx, dy = 0.25 * Dy, eo = c2 * Eo, dO = 0.25 * DO, ey = c2 * Ey, ex = c2 * Ex;
+                    const double h11 = q_ - dx - dy + eo + dO - ey - ex, h12 = q_ - dx + dy - eo + dO - ey + ex, h22 = q_ + dx + dy + eo + dO + ey + ex;
+                    lds_add(&H12[kx * hl + ky], h12);
+                    if (x <= y) { lds_add(&H11[sym(kx, ky)], h11); lds_add(&H22[sym(kx, ky)], h22); }   // (y, x) gives the same value
+                }
+                TG_SYNC();
             }
-            lds_add(&H12[kx * hl + ky], h12);
-            if (x <= y) { lds_add(&H11[sym(kx, ky)], h11); lds_add(&H22[sym(kx, ky)], h22); }   // (y, x) gives the same value
+        } else {
+            // one lane per ordered (item x, item y) pair of the flat list over all bodies; the output index o runs over the
+            // body's items.  Bodies share configs, so the accumulation uses LDS atomics like the Newton matrix.
+            if (on) TG_FOR(pp, P.n_tri) {
+                const int *pw = P.tri4 + 4 * (size_t)pp;
+                const int x = pw[0], y = pw[1], kx = pw[2] & 0xFFFF, ky = pw[2] >> 16, b = pw[3];
+                const int i0 = P.b_item_off[b], i1 = P.b_item_off[b + 1];
+                double h11 = 0.0, h12 = 0.0, h22 = 0.0;
+                for (int o = i0; o < i1; o++) {
+                    const int ko = P.it_cfg[o];
+                    if (ko >= nd) continue;
+                    const Third T = third_order(b, x, y, o);
+                    const double q = c8 * T.q, dx = 0.25 * T.dx, dy = 0.25 * T.dy, dO = 0.25 * T.dO;
+                    const double eo = c2 * T.eo, ey = c2 * T.ey, ex = c2 * T.ex;
+                    // T(sa,sb,so) = q + sa dx + sb dy + so dO + sa sb eo + sa so ey + sb so ex  (midpointvi.c:1122-1453)
+                    const double t111 = q - dx - dy - dO + eo + ey + ex, t112 = q - dx - dy + dO + eo - ey - ex;
+                    const double t121 = q - dx + dy - dO - eo + ey - ex, t122 = q - dx + dy + dO - eo - ey + ex;
+                    const double t221 = q + dx + dy - dO + eo - ey - ex, t222 = q + dx + dy + dO + eo + ey + ex;
+                    h11 += -w[ko] * t111 + zp[ko] * t112;
+                    h12 += -w[ko] * t121 + zp[ko] * t122;
+                    h22 += -w[ko] * t221 + zp[ko] * t222;
+                }
+                lds_add(&H12[kx * hl + ky], h12);
+                if (x <= y) { lds_add(&H11[sym(kx, ky)], h11); lds_add(&H22[sym(kx, ky)], h22); }   // (y, x) gives the same value
+            }
+            TG_SYNC();
         }
-        TG_SYNC();
         TG_D2STAMP(2);
         // ---- assemble HZ, four columns per pass --------------------------------------------------------------
         // tangents: y_b = (x_b, e_i for a k2 variable) with x_b = AUG[0..nd)[nf+b]; l_b = AUG[nd..nf)[nf+b].

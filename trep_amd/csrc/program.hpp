@@ -64,6 +64,11 @@ struct DevProg {
     // of dh item n in that list or -1.  o_cps: LDS scratch (6 doubles per listed item), aliased with the dead J/W area.
     const int *cpath_off, *cpath_items, *dh_pos;
     int n_cpath, o_cps;
+    // body part: bodies are taken in chunks whose per-item prefix / suffix sums (18 doubles per item + 18 per body) fit
+    // the dead pose area (o_tps, tps_cap doubles): chunk ci = bodies tchunk[ci] .. tchunk[ci+1]-1; tri_off[b] = first
+    // entry of body b in tri4.  n_tchunk = 0: fall back to the direct triple loop.
+    const int *tchunk, *tri_off;
+    int n_tchunk, o_tps;
     int n_tri, n_cpair;
     const int *cfg_item_off;  // [nq+1] CSR config -> items
     const int *cfg_items;     // [n_items]
@@ -97,7 +102,7 @@ struct HostProgram {
     std::vector<double> j_pre;
     std::vector<int> b_anchor;
     std::vector<double> b_C, b_inertia;
-    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4, tri4, cpair4, it_pack, dh_pack, cpath_off, cpath_items, dh_pos;
+    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4, tri4, cpair4, it_pack, dh_pack, cpath_off, cpath_items, dh_pos, tchunk, tri_off;
     std::vector<int> e_anchor;
     std::vector<double> e_off;
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
@@ -312,6 +317,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
         H.it_pack.push_back(H.it_body[n]); H.it_pack.push_back(12 * H.it_joint[n]);
         H.it_pack.push_back(H.j_kind[H.it_joint[n]]); H.it_pack.push_back(H.it_cfg[n] | (H.it_slot[n] << 16));
     }
+    for (int b = 0; b <= nb; b++) { const int n0 = b ? H.b_item_off[b] - H.b_item_off[b - 1] : 0; H.tri_off.push_back(b ? H.tri_off[b - 1] + n0 * n0 : 0); }
     for (int b = 0; b < nb; b++)
         for (int x = H.b_item_off[b]; x < H.b_item_off[b + 1]; x++)
             for (int y = H.b_item_off[b]; y < H.b_item_off[b + 1]; y++) {
@@ -429,7 +435,25 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.d_o_Dh1 = take(nc * nq); P.d_o_Dh2 = take(nc * nq);
     P.d_aug_ld = (P.nf + P.d_nrhs + nc) | 1;  // + nc unit columns used by the second-derivative adjoint
     P.d_o_AUG = take(P.nf * P.d_aug_ld);
-    P.o_cps = (6 * P.n_cpath + 6 * nc <= 12 * nitems) ? P.o_J : -1;   // prefix / suffix sums of the constraint paths + per-constraint sums
+    {   // chunks of bodies for the prefix-sum form of the third-order body terms; scratch = the dead pose union
+        P.o_tps = P.o_sc;
+        const int cap = (P.o_dqi + nitems) - P.o_sc;
+        H.tchunk.clear();
+        H.tchunk.push_back(0);
+        int b = 0;
+        bool fits = true;
+        while (b < nb && fits) {
+            int b1 = b, items = 0;
+            while (b1 < nb && 18 * (items + (H.b_item_off[b1 + 1] - H.b_item_off[b1]) + (b1 - b + 1)) <= cap) {
+                items += H.b_item_off[b1 + 1] - H.b_item_off[b1];
+                b1++;
+            }
+            if (b1 == b) fits = false; else { H.tchunk.push_back(b1); b = b1; }
+        }
+        if (!fits) { H.tchunk.clear(); H.tchunk.push_back(0); }
+        P.n_tchunk = (int)H.tchunk.size() - 1;
+    }
+    P.o_cps = (6 * P.n_cpath + 6 * nc <= (P.o_gam + 3 * nb) - P.o_J) ? P.o_J : -1;   // J, W, vB, gam are dead there (recomputed afterwards)   // prefix / suffix sums of the constraint paths + per-constraint sums
     P.gjc_ok = (std::max(12 * nj, 2 * nitems) >= 4 * 32) ? 1 : 0;   // gj_cols scratch (128 doubles) lives in the dead pose area
     P.d_o_T12 = take(nq * nd); P.d_o_T22 = take(nq * nd);
     P.d_lds_per_team = (off + 1) & ~1;
@@ -461,7 +485,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(level_off) X(lvl_joints) X(round_off) X(ch_first) X(ch_len) X(ch_parent) X(j_parent) X(j_kind) X(j_cfg) X(j_pre_ident) X(b_anchor) X(b_item_off) X(b_pair_off) X(it_body) \
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
-    X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos)
+    X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off)
 #define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp)
 
 inline void HostProgram::pack() {
