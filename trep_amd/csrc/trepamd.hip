@@ -29,8 +29,10 @@ int fail(int code, const std::string &msg) {
         if (e_ != hipSuccess) return fail(TG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// The derivative modes keep 60-80 KB of LDS per trajectory, i.e. at most two wavefronts per CU: they may use the whole
+// register file of a SIMD (no spills, deeper unrolling); the rollout modes run two wavefronts per SIMD.
 template <int TEAM, int MODE>
-__global__ __launch_bounds__(64, 2) void k_run(const tg::DevProg P, const tg::RunArgs A) {
+__global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z) ? 1 : 2) void k_run(const tg::DevProg P, const tg::RunArgs A) {
     extern __shared__ double lds[];
     const int team = threadIdx.x / TEAM, lane = threadIdx.x % TEAM;
     const int traj = blockIdx.x * (64 / TEAM) + team;
