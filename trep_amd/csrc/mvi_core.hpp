@@ -1506,11 +1506,16 @@ struct Core {
                 for (int c = 0; c < 4; c++) if (c < nb && b0 + c >= first_k2) {
                     a22[c] += H22[sym(j, nd + (b0 + c - first_k2))]; a12[c] += H12[j * hl + nd + (b0 + c - first_k2)];
                 }
-                for (int cc = 0; cc < nc; cc++) {
-                    const double g = G1[j * nc + cc];
-                    const double *lr = AUG + (nd + cc) * ld + nf + b0;
+                for (int c0 = 0; c0 < nc; c0 += 4) {       // multiplier tangents, four constraints at a time: loads first
+                    double g[4];
 #pragma unroll
-                    for (int c = 0; c < 4; c++) ag[c] += g * lr[c < nb ? c : 0];
+                    for (int q = 0; q < 4; q++) g[q] = c0 + q < nc ? G1[j * nc + c0 + q] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const double *lr = AUG + (nd + (c0 + q < nc ? c0 + q : 0)) * ld + nf + b0;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) ag[c] += g[q] * lr[c < nb ? c : 0];
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < 4; c++) { hy[c * nq + j] = a22[c]; h12y[c * nq + j] = a12[c]; g1l[c * nq + j] = ag[c]; }
@@ -1518,28 +1523,39 @@ struct Core {
             TG_SYNC();
             if (on) TG_FOR(a, R) {
                 double acc[4] = {0, 0, 0, 0}, s12[4] = {0, 0, 0, 0};
-#pragma unroll 2
+                // straight-line loop body (clamped row for the columns without an H12 term, weighted out below): a
+                // branch per column would split the body into basic blocks, each waiting for its own LDS reads
+                int hrow[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) hrow[c] = (c < nb && b0 + c < nq) ? (b0 + c) * hl : 0;
+#pragma unroll 4
                 for (int i2 = 0; i2 < nd; i2++) {
                     const double x = AUG[i2 * ld + nf + a];
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
                         acc[c] += x * hy[c * nq + i2];
-                        if (c < nb && b0 + c < nq) s12[c] += H12[(b0 + c) * hl + i2] * x;
+                        s12[c] += H12[hrow[c] + i2] * x;
                     }
                 }
+                // row-dependent extras without divergent branches: clamped indices and 0/1 weights, so that all the LDS
+                // reads of the epilogue can be in flight together
+                const bool k2row = a >= first_k2, qrow = a < nq;
+                const int ak = k2row ? nd + (a - first_k2) : 0, aq = qrow ? a : 0;
+                const double wk = k2row ? 1.0 : 0.0, wq = qrow ? 1.0 : 0.0;
+                double xl[8];                                  // multiplier tangents of this row (constraints in groups of 8)
+#pragma unroll
+                for (int q = 0; q < 8; q++) xl[q] = q < nc ? AUG[(nd + q) * ld + nf + a] : 0.0;
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const int bcol = b0 + c;
                     if (c >= nb) break;
-                    double v = acc[c];
-                    if (a >= first_k2) v += hy[c * nq + nd + (a - first_k2)];
-                    if (a < nq) v += h12y[c * nq + a] + g1l[c * nq + a];
-                    if (bcol < nq) {
+                    double v = acc[c] + wk * hy[c * nq + ak] + wq * (h12y[c * nq + aq] + g1l[c * nq + aq]);
+                    if (bcol < nq) {                           // uniform over the wavefront
                         double sg = 0.0;
-                        if (a >= first_k2) s12[c] += H12[bcol * hl + nd + (a - first_k2)];
-                        for (int cc = 0; cc < nc; cc++) sg += G1[bcol * nc + cc] * AUG[(nd + cc) * ld + nf + a];
-                        v += s12[c] + sg;
-                        if (a < nq) v += H11[sym(a, bcol)];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) sg += (q < nc ? G1[bcol * nc + q] : 0.0) * xl[q];
+                        for (int cc = 8; cc < nc; cc++) sg += G1[bcol * nc + cc] * AUG[(nd + cc) * ld + nf + a];
+                        v += s12[c] + wk * H12[bcol * hl + ak] + sg + wq * H11[sym(aq, bcol)];
                     }
                     A.hz[(t * R + bcol) * R + a] = ok ? v : NAN;
                 }
