@@ -310,27 +310,26 @@ struct Core {
     // ---- poses of the massive frames and positions of the constraint end points --------------------
     TG_HD void attach_points(bool on, bool bodies, bool endpoints) {
         const double *G = S + P.o_G;
+        // Branch-free: an unanchored frame (anchor < 0: fixed to the world) reads joint 0 and weights it out.  A branch
+        // would split the loop body into basic blocks that each wait for their own loads.
         if (on && bodies) TG_FOR(idx, 12 * P.n_bodies) {
             const int b = idx / 12, e = idx % 12, r = e >> 2, c = e & 3;
             const double *C = P.b_C + 12 * b;
             const int anchor = P.b_anchor[b];
-            double val;
-            if (anchor < 0) val = C[e];
-            else {
-                const double *g = G + 12 * anchor + 4 * r;
-                val = g[0] * C[c] + g[1] * C[4 + c] + g[2] * C[8 + c];
-                if (c == 3) val += g[3];
-            }
-            S[P.o_gB + idx] = val;
+            const double ce = C[e], c0 = C[c], c1 = C[4 + c], c2 = C[8 + c];
+            const double *g = G + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
+            const double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+            const double val = g0 * c0 + g1 * c1 + g2 * c2 + (c == 3 ? g3 : 0.0);
+            S[P.o_gB + idx] = anchor < 0 ? ce : val;
         }
         if (on && endpoints) TG_FOR(idx, 3 * P.n_endpoints) {
             const int e = idx / 3, r = idx % 3;
             const double *o = P.e_off + 3 * e;
             const int anchor = P.e_anchor[e];
-            double val;
-            if (anchor < 0) val = o[r];
-            else { const double *g = G + 12 * anchor + 4 * r; val = g[0] * o[0] + g[1] * o[1] + g[2] * o[2] + g[3]; }
-            S[P.o_pE + idx] = val;
+            const double o0 = o[0], o1 = o[1], o2 = o[2], orr = o[r];
+            const double *g = G + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
+            const double val = g[0] * o0 + g[1] * o1 + g[2] * o2 + g[3];
+            S[P.o_pE + idx] = anchor < 0 ? orr : val;
         }
         TG_SYNC();
     }
@@ -343,17 +342,16 @@ struct Core {
             const int b = rec[0], oj = rec[1], kind = rec[2], cfg = rec[3] & 0xFFFF;
             const double *gb = S + P.o_gB + 12 * b, *gj = G + oj;
             double *J = S + P.o_J + 6 * it;
+            // branch-free: the joint axis column is read either way (column kind-TX or kind-RX of the joint pose)
+            const bool prismatic = kind <= TG_TZ;
+            const int ax = prismatic ? kind - TG_TX : kind - TG_RX;
+            const double a0 = gj[ax], a1 = gj[4 + ax], a2 = gj[8 + ax];
+            const double dx = gb[3] - gj[3], dy = gb[7] - gj[7], dz = gb[11] - gj[11];
             double lin[3], ang[3];
-            if (kind <= TG_TZ) {
-                const int a = kind - TG_TX;
-                lin[0] = gj[a]; lin[1] = gj[4 + a]; lin[2] = gj[8 + a];
-                ang[0] = ang[1] = ang[2] = 0.0;
-            } else {
-                const int a = kind - TG_RX;
-                ang[0] = gj[a]; ang[1] = gj[4 + a]; ang[2] = gj[8 + a];
-                const double dx = gb[3] - gj[3], dy = gb[7] - gj[7], dz = gb[11] - gj[11];
-                lin[0] = ang[1] * dz - ang[2] * dy; lin[1] = ang[2] * dx - ang[0] * dz; lin[2] = ang[0] * dy - ang[1] * dx;
-            }
+            ang[0] = prismatic ? 0.0 : a0; ang[1] = prismatic ? 0.0 : a1; ang[2] = prismatic ? 0.0 : a2;
+            lin[0] = prismatic ? a0 : a1 * dz - a2 * dy;
+            lin[1] = prismatic ? a1 : a2 * dx - a0 * dz;
+            lin[2] = prismatic ? a2 : a0 * dy - a1 * dx;
             for (int r = 0; r < 3; r++) {  // R_F^T applied to both parts
                 J[r] = gb[r] * lin[0] + gb[4 + r] * lin[1] + gb[8 + r] * lin[2];
                 J[3 + r] = gb[r] * ang[0] + gb[4 + r] * ang[1] + gb[8 + r] * ang[2];
@@ -414,9 +412,9 @@ struct Core {
             double force = -P.damp[i] * S[P.o_dq + i];
             for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
             double f = S[P.o_p1 + i] + (0.5 * dt * ldq - lddq) + dt * force;
-            for (int c = 0; c < P.nc; c++) {
+            for (int c = 0; c < P.nc; c++) {                 // branch-free: a missing entry reads item 0 with weight 0
                 const int n = P.dh_lookup[c * P.nq + i];
-                if (n >= 0) f -= S[P.o_Dh1 + n] * S[P.o_lam + c];
+                f -= (n >= 0 ? S[P.o_lam + c] : 0.0) * S[P.o_Dh1 + (n >= 0 ? n : 0)];
             }
             S[P.o_f + i] = f;
         }
@@ -439,15 +437,14 @@ struct Core {
 
     // same with the joint given by its pose offset and kind, the end point by its offset (packed dh records)
     TG_HD void dpos_rec(int oe, int oj, int kind, double *d) const {
-        const double *gj = S + P.o_G + oj;
-        if (kind <= TG_TZ) { const int a = kind - TG_TX; d[0] = gj[a]; d[1] = gj[4 + a]; d[2] = gj[8 + a]; }
-        else {
-            const int a = kind - TG_RX;
-            const double wx = gj[a], wy = gj[4 + a], wz = gj[8 + a];
-            const double *pe = S + P.o_pE + oe;
-            const double dx = pe[0] - gj[3], dy = pe[1] - gj[7], dz = pe[2] - gj[11];
-            d[0] = wy * dz - wz * dy; d[1] = wz * dx - wx * dz; d[2] = wx * dy - wy * dx;
-        }
+        const double *gj = S + P.o_G + oj, *pe = S + P.o_pE + oe;
+        const bool prismatic = kind <= TG_TZ;
+        const int a = prismatic ? kind - TG_TX : kind - TG_RX;
+        const double wx = gj[a], wy = gj[4 + a], wz = gj[8 + a];
+        const double dx = pe[0] - gj[3], dy = pe[1] - gj[7], dz = pe[2] - gj[11];
+        d[0] = prismatic ? wx : wy * dz - wz * dy;
+        d[1] = prismatic ? wy : wz * dx - wx * dz;
+        d[2] = prismatic ? wz : wx * dy - wy * dx;
     }
 
     // ---- constraint values (into f[nd..]) and Jacobian Dh (into dest) at the swept state -------------
@@ -468,10 +465,12 @@ struct Core {
             const int *rec = P.dh_pack + 8 * (size_t)n;   // one record instead of chained table look-ups
             const int c = rec[0], k = rec[1], oj = rec[2], w = rec[3], oe1 = rec[4], oe2 = rec[5];
             const int side = w & 0xFF, kind = (w >> 8) & 0xFF, type = (w >> 16) & 0xFF, comp = w >> 24;
-            double d1[3] = {0, 0, 0}, d2[3] = {0, 0, 0};
-            if (side & 1) dpos_rec(oe1, oj, kind, d1);
-            if (side & 2) dpos_rec(oe2, oj, kind, d2);
-            const double dx = d1[0] - d2[0], dy = d1[1] - d2[1], dz = d1[2] - d2[2];
+            double d1[3], d2[3];
+            const int ojc = oj < 0 ? 0 : oj;                 // the length config drives no joint: both sides weighted out
+            dpos_rec(oe1, ojc, kind, d1);
+            dpos_rec(oe2, ojc, kind, d2);
+            const double s1 = (side & 1) ? 1.0 : 0.0, s2 = (side & 2) ? 1.0 : 0.0;
+            const double dx = s1 * d1[0] - s2 * d2[0], dy = s1 * d1[1] - s2 * d2[1], dz = s1 * d1[2] - s2 * d2[2];
             double val;
             if (type == TG_CONSTRAINT_POINT) val = comp == 0 ? dx : (comp == 1 ? dy : dz);
             else {
