@@ -178,6 +178,21 @@ struct Core {
 
     TG_HD Core(const DevProg &p, double *s, int l, double dt_) : P(p), S(s), lane(l), dt(dt_) {}
 
+    // Phase loop over n independent items, two per lane and trip: compute(i) only READS and returns its results,
+    // store(i, r) writes them.  Both items' loads are issued before either item's stores -- the compiler cannot
+    // reorder an LDS load over an earlier LDS store, so a plain two-trip loop waits out the full latency twice.
+    template <class Compute, class Store>
+    TG_HD void for_pairs(int n, Compute compute, Store store) {
+        for (int i0 = tg_opaque(lane); i0 < n; i0 += 2 * TEAM) {
+            const int i1 = i0 + TEAM;
+            const bool two = i1 < n;
+            const auto r0 = compute(i0);
+            const auto r1 = compute(two ? i1 : i0);
+            store(i0, r0);
+            if (two) store(i1, r1);
+        }
+    }
+
     // configuration value at the evaluation point: 0 midpoint, 1 q1, 2 q2 (midpointvi.c:401-457)
     TG_HD double qval(int sel, int c) const {
         double a = S[P.o_q1 + c], b = S[P.o_q2 + c];
@@ -337,11 +352,11 @@ struct Core {
     // ---- body Jacobian columns J_{F,k} and gravity in body coordinates ------------------------------
     TG_HD void jacobians(bool on) {
         const double *G = S + P.o_G;
-        if (on) TG_FOR(it, P.n_items) {
+        struct JacOut { double J[6], dq; };
+        if (on) for_pairs(P.n_items, [&](int it) {
             const int *rec = P.it_pack + 4 * (size_t)it;
             const int b = rec[0], oj = rec[1], kind = rec[2], cfg = rec[3] & 0xFFFF;
             const double *gb = S + P.o_gB + 12 * b, *gj = G + oj;
-            double *J = S + P.o_J + 6 * it;
             // branch-free: the joint axis column is read either way (column kind-TX or kind-RX of the joint pose)
             const bool prismatic = kind <= TG_TZ;
             const int ax = prismatic ? kind - TG_TX : kind - TG_RX;
@@ -352,12 +367,18 @@ struct Core {
             lin[0] = prismatic ? a0 : a1 * dz - a2 * dy;
             lin[1] = prismatic ? a1 : a2 * dx - a0 * dz;
             lin[2] = prismatic ? a2 : a0 * dy - a1 * dx;
+            JacOut o;
             for (int r = 0; r < 3; r++) {  // R_F^T applied to both parts
-                J[r] = gb[r] * lin[0] + gb[4 + r] * lin[1] + gb[8 + r] * lin[2];
-                J[3 + r] = gb[r] * ang[0] + gb[4 + r] * ang[1] + gb[8 + r] * ang[2];
+                o.J[r] = gb[r] * lin[0] + gb[4 + r] * lin[1] + gb[8 + r] * lin[2];
+                o.J[3 + r] = gb[r] * ang[0] + gb[4 + r] * ang[1] + gb[8 + r] * ang[2];
             }
-            S[P.o_dqi + it] = S[P.o_dq + cfg];  // rate of the item's config, for the prefix sums
-        }
+            o.dq = S[P.o_dq + cfg];  // rate of the item's config, for the prefix sums
+            return o;
+        }, [&](int it, const JacOut &o) {
+            double *J = S + P.o_J + 6 * it;
+            for (int r = 0; r < 6; r++) J[r] = o.J[r];
+            S[P.o_dqi + it] = o.dq;
+        });
         if (on) TG_FOR(idx, 3 * P.n_bodies) {
             const int b = idx / 3, r = idx % 3;
             const double *gb = S + P.o_gB + 12 * b;
@@ -396,13 +417,17 @@ struct Core {
         // per-item terms <J,v> and <W,v> + m gam.Jv, stored in config-sorted order in the (now dead) joint
         // pose area, then one contiguous sum per dynamic config
         double *terms = S + P.o_G;
-        if (on) TG_FOR(it, P.n_items) {
+        struct TermOut { double a, b; int slot; };
+        if (on) for_pairs(P.n_items, [&](int it) {
             const int b = P.it_pack[4 * (size_t)it], slot = P.it_pack[4 * (size_t)it + 3] >> 16;
             const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b;
             const double *J = S + P.o_J + 6 * it, *W = S + P.o_W + 6 * it, *gam = S + P.o_gam + 3 * b;
-            terms[2 * slot] = inner6(I, J, v);
-            terms[2 * slot + 1] = inner6(I, W, v) + I[0] * (gam[0] * J[0] + gam[1] * J[1] + gam[2] * J[2]);
-        }
+            TermOut o;
+            o.a = inner6(I, J, v);
+            o.b = inner6(I, W, v) + I[0] * (gam[0] * J[0] + gam[1] * J[1] + gam[2] * J[2]);
+            o.slot = slot;
+            return o;
+        }, [&](int, const TermOut &o) { terms[2 * o.slot] = o.a; terms[2 * o.slot + 1] = o.b; });
         TG_SYNC();
         if (on) TG_FOR(i, P.nd) {
             double ldq = 0.0, lddq = 0.0;
