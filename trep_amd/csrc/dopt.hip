@@ -125,6 +125,7 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
         if (has_tile) {
 #pragma unroll
             for (int e = 0; e < TS * TS; e++) acc[e] = 0.0;
+#pragma unroll 2
             for (int m = 0; m < nX; m++) {
                 double pv[TS], av[TS];
 #pragma unroll
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
             double c[TS];
 #pragma unroll
             for (int j = 0; j < TS; j++) c[j] = 0.0;
+#pragma unroll 4
             for (int i = 0; i < nX; i++) {
                 const double bb = Bm[i * nU + u];
 #pragma unroll
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
             const int u = o / nU, v = o % nU;
             double g = a.R_dev[(size_t)s * a.R_seed_stride + (size_t)k * a.R_step_stride + o];
             if (hz) g += hz[(size_t)(nxh + u) * hzR + nxh + v];
+#pragma unroll 4
             for (int j = 0; j < nX; j++) g += BtP[u * ldx + j] * Bm[j * nU + v];
             G[u * ldw + v] = g;
         }
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
             double c[TS];
 #pragma unroll
             for (int j = 0; j < TS; j++) c[j] = (hz && c0 + j < nxh) ? hz[(size_t)(c0 + j) * hzR + nxh + u] : 0.0;
+#pragma unroll 4
             for (int i = 0; i < nX; i++) {
                 const double bp = BtP[u * ldx + i];
 #pragma unroll
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
                     if (hz && r < nxh && c < nxh) q0 += hz[(size_t)r * hzR + c];
                     acc[TS * i + j] = q0;
                 }
+#pragma unroll 2
             for (int m = 0; m < nX; m++) {  // + A' (PA)
                 double av[TS], pv[TS];
 #pragma unroll
