@@ -197,6 +197,31 @@ def test_long_chain_matches_oracle(links, B, N):
     mvi.close()
 
 
+def test_many_chains_matches_oracle():
+    """Shape edge: 20 two-link chains hanging off the world -- more chains in a sweep round than the LDS chain
+    schedule holds (16), so the sweep reads its schedule from the global tables; 40 bodies, nd = 40 > 32 (LDS
+    Gauss-Jordan in the rollout)."""
+    from oracle.oracle import OracleMVI
+    from trep_amd import descriptor
+    from test_kernel_emulation import _star
+    system = _star(20, 2)
+    d = descriptor.flatten(system)
+    B, N = 5, 15
+    rng = np.random.default_rng(8)
+    Q0 = rng.uniform(-0.5, 0.5, (B, d.n_configs))
+    mvi = _batch(system, B)
+    mvi.initialize_from_configs(0.0, Q0, DT, Q0)
+    X = mvi.rollout(N, DT, np.zeros((B, N, 0)), np.zeros((B, N, 0)))
+    iters, status = mvi.status()
+    assert (status == 0).all()
+    o = OracleMVI(d)
+    for b in range(B):
+        o.initialize_from_configs(0.0, Q0[b], DT, Q0[b])
+        Xo, tot = o.rollout(N, DT, np.zeros((N, 0)), np.zeros((N, 0)))
+        assert relerr(X[b], Xo) < TOL, (b, relerr(X[b], Xo))
+    mvi.close()
+
+
 def test_full_size_properties_puppet():
     """BASELINE puppet size (B=8192, N=200): every trajectory converges, the DEL residual of the final
     state vanishes, and results do not depend on batch composition (bit-identical sub-batch)."""

@@ -148,3 +148,34 @@ def test_emulated_long_chain_matches_oracle(links):
     o.initialize_from_configs(0.0, q0, DT, q0)
     Xo, _ = o.rollout(N, DT, np.zeros((N, 0)), np.zeros((N, 0)))
     assert relerr(X[0], Xo) < 1e-10
+
+
+def _star(n_arms, links_per_arm):
+    """n_arms independent pendulum chains hanging off the world: many chains in one sweep round."""
+    import trep_amd as T
+    system = T.System()
+    T.potentials.Gravity(system, name="Gravity")
+    for a in range(n_arms):
+        parent = system.world_frame
+        for l in range(links_per_arm):
+            joint = T.Frame(parent, T.RX if (a + l) % 2 == 0 else T.RY, "q%d_%d" % (a, l), "j%d_%d" % (a, l))
+            parent = T.Frame(joint, T.TZ, -1.0 - 0.1 * a)
+            parent.set_mass(1.0 + 0.05 * l, 0.1, 0.2, 0.3)
+    return system
+
+
+def test_emulated_star_matches_oracle():
+    from oracle.oracle import OracleMVI
+    from trep_amd import descriptor
+    system = _star(20, 2)
+    d = descriptor.flatten(system)
+    rng = np.random.default_rng(8)
+    q0 = rng.uniform(-0.5, 0.5, d.n_configs)
+    N = 8
+    e = EmuBatch(d, 1)
+    e.initialize_from_configs(0.0, q0[None], DT, q0[None])
+    X = e.rollout(N, DT, np.zeros((1, N, 0)), np.zeros((1, N, 0)))
+    o = OracleMVI(d)
+    o.initialize_from_configs(0.0, q0, DT, q0)
+    Xo, _ = o.rollout(N, DT, np.zeros((N, 0)), np.zeros((N, 0)))
+    assert relerr(X[0], Xo) < 1e-10
