@@ -333,10 +333,40 @@ size_t lq_lds_bytes(int nX, int nU, int ts) {
 // ------------------------------------------------------------------------------------------------------
 constexpr int SW_T = 256;
 
-__device__ inline void stage_ab(const double *Ak, const double *Bk, double *Am, double *Bm, int nX, int nU, int lda, int tid) {
-    for (int e = tid; e < nX * nX; e += SW_T) Am[(e / nX) * lda + e % nX] = Ak[e];
-    for (int e = tid; e < nX * nU; e += SW_T) Bm[e] = Bk[e];
-}
+// A_k (nX x nX, row stride lda in LDS), B_k and a third nU x nX block (K_k) travel global -> registers -> LDS: the
+// loads of step k+1 are issued while step k computes (2-D mapping, 256-byte row segments, no integer division).
+struct SweepStage {
+    static constexpr int RI = 12, CI = 3, PB = 12;   // nX <= 96, nX * nU <= 12 * 256
+    double a[RI * CI], b[PB], c[PB];
+    __device__ void load(const double *Ak, const double *Bk, const double *Ck, int nX, int nU, int tid) {
+        const int r0 = tid >> 5, c0 = tid & 31;
+#pragma unroll
+        for (int ri = 0; ri < RI; ri++)
+#pragma unroll
+            for (int ci = 0; ci < CI; ci++) {
+                const int r = r0 + 8 * ri, cc = c0 + 32 * ci;
+                if (r < nX && cc < nX) a[ri * CI + ci] = Ak[r * nX + cc];
+            }
+#pragma unroll
+        for (int i = 0; i < PB; i++) { const int e = tid + i * SW_T; if (e < nX * nU) { b[i] = Bk[e]; c[i] = Ck[e]; } }
+    }
+    // A -> Am[r * lda + c]; B -> Bm (row-major nX x nU); C (nU x nX) -> Cm[(e / nX) * ldc + e % nX] when ldc != nX
+    __device__ void store(double *Am, double *Bm, double *Cm, int nX, int nU, int lda, int ldc, int tid) const {
+        const int r0 = tid >> 5, c0 = tid & 31;
+#pragma unroll
+        for (int ri = 0; ri < RI; ri++)
+#pragma unroll
+            for (int ci = 0; ci < CI; ci++) {
+                const int r = r0 + 8 * ri, cc = c0 + 32 * ci;
+                if (r < nX && cc < nX) Am[r * lda + cc] = a[ri * CI + ci];
+            }
+#pragma unroll
+        for (int i = 0; i < PB; i++) {
+            const int e = tid + i * SW_T;
+            if (e < nX * nU) { Bm[e] = b[i]; Cm[ldc == nX ? e : (e / nX) * ldc + e % nX] = c[i]; }
+        }
+    }
+};
 
 // Backward adjoint of doptimizer.py:319-345: Z_k = z_{k+1} (the vector the second derivatives of step k are
 // contracted with), z_k = q_k - K_k' r_k + (A_k - B_k K_k)' z_{k+1}, z_N = q_N.
@@ -348,21 +378,34 @@ __global__ __launch_bounds__(SW_T) void k_adjoint(int N, int nX, int nU, const i
     double *Am = lds, *Bm = Am + nX * lda, *Km = Bm + nX * nU, *z = Km + nU * nX, *zn = z + nX, *w = zn + nX;
     const size_t sN = (size_t)s * N;
     for (int i = tid; i < nX; i += SW_T) z[i] = q[(sN + s + N) * nX + i];
+    SweepStage st;
+    st.load(A + (sN + N - 1) * (size_t)nX * nX, B + (sN + N - 1) * (size_t)nX * nU, K + (sN + N - 1) * (size_t)nU * nX, nX, nU, tid);
     __syncthreads();
     for (int k = N - 1; k >= 0; k--) {
-        stage_ab(A + (sN + k) * (size_t)nX * nX, B + (sN + k) * (size_t)nX * nU, Am, Bm, nX, nU, lda, tid);
-        for (int e = tid; e < nU * nX; e += SW_T) Km[e] = K[(sN + k) * (size_t)nU * nX + e];
+        st.store(Am, Bm, Km, nX, nU, lda, nX, tid);
+        if (k > 0) st.load(A + (sN + k - 1) * (size_t)nX * nX, B + (sN + k - 1) * (size_t)nX * nU, K + (sN + k - 1) * (size_t)nU * nX, nX, nU, tid);
         for (int i = tid; i < nX; i += SW_T) Z[(sN + k) * nX + i] = z[i];
         __syncthreads();
         if (tid < nU) {  // w = r_k + B' z
-            double v = r[(sN + k) * nU + tid];
-            for (int i = 0; i < nX; i++) v += Bm[i * nU + tid] * z[i];
-            w[tid] = v;
+            double v0 = r[(sN + k) * nU + tid], v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            int i = 0;
+            for (; i + 3 < nX; i += 4) {
+                v0 += Bm[i * nU + tid] * z[i]; v1 += Bm[(i + 1) * nU + tid] * z[i + 1];
+                v2 += Bm[(i + 2) * nU + tid] * z[i + 2]; v3 += Bm[(i + 3) * nU + tid] * z[i + 3];
+            }
+            for (; i < nX; i++) v0 += Bm[i * nU + tid] * z[i];
+            w[tid] = (v0 + v1) + (v2 + v3);
         }
         __syncthreads();
         for (int i = tid; i < nX; i += SW_T) {
-            double v = q[(sN + s + k) * nX + i];
-            for (int m = 0; m < nX; m++) v += Am[m * lda + i] * z[m];
+            double v0 = q[(sN + s + k) * nX + i], v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            int m = 0;
+            for (; m + 3 < nX; m += 4) {
+                v0 += Am[m * lda + i] * z[m]; v1 += Am[(m + 1) * lda + i] * z[m + 1];
+                v2 += Am[(m + 2) * lda + i] * z[m + 2]; v3 += Am[(m + 3) * lda + i] * z[m + 3];
+            }
+            for (; m < nX; m++) v0 += Am[m * lda + i] * z[m];
+            double v = (v0 + v1) + (v2 + v3);
             for (int u = 0; u < nU; u++) v -= Km[u * nX + i] * w[u];
             zn[i] = v;
         }
@@ -384,14 +427,22 @@ __global__ __launch_bounds__(SW_T) void k_tangent(int N, int nX, int nU, const i
     const size_t sN = (size_t)s * N;
     for (int i = tid; i < nX; i += SW_T) { x[i] = 0.0; dX[(sN + s) * nX + i] = 0.0; }
     double part = 0.0;
+    SweepStage st;
+    st.load(A + sN * (size_t)nX * nX, B + sN * (size_t)nX * nU, K + sN * (size_t)nU * nX, nX, nU, tid);
     __syncthreads();
     for (int k = 0; k < N; k++) {
-        stage_ab(A + (sN + k) * (size_t)nX * nX, B + (sN + k) * (size_t)nX * nU, Am, Bm, nX, nU, lda, tid);
-        for (int e = tid; e < nU * nX; e += SW_T) Km[(e / nX) * lda + e % nX] = K[(sN + k) * (size_t)nU * nX + e];
+        st.store(Am, Bm, Km, nX, nU, lda, lda, tid);
+        if (k + 1 < N) st.load(A + (sN + k + 1) * (size_t)nX * nX, B + (sN + k + 1) * (size_t)nX * nU, K + (sN + k + 1) * (size_t)nU * nX, nX, nU, tid);
         __syncthreads();
         if (tid < nU) {
-            double v = -C[(sN + k) * nU + tid];
-            for (int m = 0; m < nX; m++) v -= Km[tid * lda + m] * x[m];
+            double v0 = -C[(sN + k) * nU + tid], v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            int m = 0;
+            for (; m + 3 < nX; m += 4) {
+                v0 -= Km[tid * lda + m] * x[m]; v1 -= Km[tid * lda + m + 1] * x[m + 1];
+                v2 -= Km[tid * lda + m + 2] * x[m + 2]; v3 -= Km[tid * lda + m + 3] * x[m + 3];
+            }
+            for (; m < nX; m++) v0 -= Km[tid * lda + m] * x[m];
+            const double v = (v0 + v1) + (v2 + v3);
             u[tid] = v;
             dU[(sN + k) * nU + tid] = v;
             part += r[(sN + k) * nU + tid] * v;
@@ -399,8 +450,14 @@ __global__ __launch_bounds__(SW_T) void k_tangent(int N, int nX, int nU, const i
         for (int i = tid; i < nX; i += SW_T) part += q[(sN + s + k) * nX + i] * x[i];
         __syncthreads();
         for (int i = tid; i < nX; i += SW_T) {
-            double v = 0.0;
-            for (int m = 0; m < nX; m++) v += Am[i * lda + m] * x[m];
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            int m = 0;
+            for (; m + 3 < nX; m += 4) {
+                v0 += Am[i * lda + m] * x[m]; v1 += Am[i * lda + m + 1] * x[m + 1];
+                v2 += Am[i * lda + m + 2] * x[m + 2]; v3 += Am[i * lda + m + 3] * x[m + 3];
+            }
+            for (; m < nX; m++) v0 += Am[i * lda + m] * x[m];
+            double v = (v0 + v1) + (v2 + v3);
             for (int c = 0; c < nU; c++) v += Bm[i * nU + c] * u[c];
             xn[i] = v;
             dX[(sN + s + k + 1) * nX + i] = v;
@@ -556,7 +613,7 @@ int tg_adjoint_sweep(int32_t device, int32_t n_problems, int32_t horizon, int32_
                      double *Z_dev) {
     if (n_problems <= 0 || horizon <= 0 || !A_dev || !B_dev || !K_dev || !q_dev || !r_dev || !Z_dev) return fail(TG_ERR_INVALID, "bad arguments");
     const size_t lds = sizeof(double) * ((size_t)nX * (nX | 1) + (size_t)nX * nU + (size_t)nU * nX + 2 * nX + nU);
-    if (lds > 160 * 1024 - 64) return fail(TG_ERR_UNSUPPORTED, "state dimension too large");
+    if (lds > 160 * 1024 - 64 || nX > 96 || nX * nU > 12 * SW_T) return fail(TG_ERR_UNSUPPORTED, "state dimension too large");
     HIP_TRY(hipSetDevice(device));
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_adjoint, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_adjoint, dim3(n_problems), dim3(SW_T), lds, 0, horizon, nX, nU, select_dev, A_dev, B_dev, K_dev, q_dev, r_dev, Z_dev);
@@ -571,7 +628,7 @@ int tg_tangent_rollout(int32_t device, int32_t n_problems, int32_t horizon, int3
         return fail(TG_ERR_INVALID, "bad arguments");
     const int lda = nX | 1;
     const size_t lds = sizeof(double) * ((size_t)nX * lda + (size_t)nX * nU + (size_t)nU * lda + 2 * nX + nU + SW_T);
-    if (lds > 160 * 1024 - 64) return fail(TG_ERR_UNSUPPORTED, "state dimension too large");
+    if (lds > 160 * 1024 - 64 || nX > 96 || nX * nU > 12 * SW_T) return fail(TG_ERR_UNSUPPORTED, "state dimension too large");
     HIP_TRY(hipSetDevice(device));
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_tangent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_tangent, dim3(n_problems), dim3(SW_T), lds, 0, horizon, nX, nU, select_dev, A_dev, B_dev, K_dev, C_dev, q_dev,
