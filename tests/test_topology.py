@@ -38,3 +38,32 @@ def test_uses_config_and_lookup():
     assert len(system.get_config("torso_tx").masses) == 10
     assert len(knee.masses) == 1
     assert system.get_config("left_arm_string-length").config_gen == system.nQ
+
+
+def test_satisfy_constraints_matches_reference():
+    """System.satisfy_constraints (host-side setup, examples/puppet-basic.py:101, scissor.py:104): the consistent pose
+    found from the script's starting guess equals the one the reference's own satisfy_constraints produced
+    (tests/golden/puppet_basic.npz, ic_set[0]); constraint gradients are checked by finite differences."""
+    import numpy as np
+    from trep_amd import systems
+    from common import golden
+    s = systems.puppet_basic()
+    s.q = 0.0
+    s.q = systems.PUPPET_BASIC_POSE
+    assert max(abs(c.h()) for c in s.constraints) > 1.0
+    for c in s.constraints[:3]:
+        for name in ("TorsoPhi", "LShoulderTheta", "LKneeTheta", "TorsoZ"):
+            cfg = s.get_config(name)
+            h0, g = c.h(), c.h_dq(cfg)
+            cfg.q += 1e-6
+            fd = (c.h() - h0) / 1e-6
+            cfg.q -= 1e-6
+            assert abs(fd - g) < 1e-4 * max(1.0, abs(g))
+    q = s.satisfy_constraints()
+    assert max(abs(c.h()) for c in s.constraints) < 1e-9
+    assert np.abs(q - golden("puppet_basic")["ic_set"][0]).max() < 1e-9
+    kept = systems.scissor_lift(4)
+    kept.get_config("L01").q += 0.05
+    slider = kept.get_config("SLIDER").q
+    kept.satisfy_constraints(constant_q_list=["SLIDER"])
+    assert max(abs(c.h()) for c in kept.constraints) < 1e-9 and kept.get_config("SLIDER").q == slider

@@ -163,6 +163,18 @@ class Distance(Constraint):
     frame1 = property(lambda self: self._frame1)
     frame2 = property(lambda self: self._frame2)
 
+    def h(self):
+        """Constraint value at the system's current configuration (host, setup only; distance.c:16-33)."""
+        d = self.frame1.p()[:3] - self.frame2.p()[:3]
+        return float(d.dot(d) - self.distance ** 2)
+
+    def h_dq(self, config):
+        d = self.frame1.p()[:3] - self.frame2.p()[:3]
+        val = 2.0 * d.dot(self.frame1.p_dq(config)[:3] - self.frame2.p_dq(config)[:3])
+        if self._config is not None and config is self._config:
+            val -= 2.0 * self.distance
+        return float(val)
+
     @property
     def distance(self):
         return self._config.q if self._config else self._distance
@@ -194,6 +206,13 @@ class PointToPoint1D(Constraint):
     frame1 = property(lambda self: self._frame1)
     frame2 = property(lambda self: self._frame2)
     component = property(lambda self: self._component)
+
+    def h(self):
+        """Constraint value at the system's current configuration (host, setup only; point.c:16-27)."""
+        return float((self.frame1.p() - self.frame2.p())[self._component])
+
+    def h_dq(self, config):
+        return float((self.frame1.p_dq(config) - self.frame2.p_dq(config))[self._component])
 
 
 class _PointGroup(object):

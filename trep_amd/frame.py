@@ -258,3 +258,21 @@ class Frame(object):
 
     def p(self):
         return self.g()[:, 3].copy()
+
+    def p_dq(self, config):
+        """d p / d q (host, setup only): axis x (p - p_joint) for a rotary joint on the path from the world to
+        this frame, the joint axis for a prismatic one, zero if the frame does not depend on `config`."""
+        f = self
+        while f is not None and f._config is not config:
+            f = f._parent
+        if f is None or config is None:
+            return np.zeros(4)
+        gj = f.g()
+        kind = f._transform
+        out = np.zeros(4)
+        if kind in (TX, TY, TZ):
+            out[:3] = gj[:3, (TX, TY, TZ).index(kind)]
+        else:
+            axis = gj[:3, (RX, RY, RZ).index(kind)]
+            out[:3] = np.cross(axis, self.p()[:3] - gj[:3, 3])
+        return out

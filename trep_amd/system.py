@@ -248,6 +248,41 @@ class System(object):
     u = _state_prop("inputs", "u", "get_input")
     del _state_prop
 
+    def satisfy_constraints(self, tolerance=1e-10, verbose=False, keep_kinematic=False, constant_q_list=None):
+        """Move the configuration to the nearest one (least squares) that satisfies the holonomic constraints
+        (host-side setup, same approach and arguments as trep/system.py:158-214: SLSQP on |q - q0|^2 subject to
+        h(q) = 0 with analytic constraint gradients).  Velocities are set to zero.  Returns the new configuration."""
+        import scipy.optimize
+        self.dq = 0
+        if constant_q_list:
+            fixed = set(self.get_config(c).name for c in constant_q_list)
+            free = [c for c in self.configs if c.name not in fixed]
+        elif keep_kinematic:
+            free = list(self.dyn_configs)
+        else:
+            free = list(self.configs)
+        q0 = np.array([c.q for c in free], dtype=float)
+
+        def put(q):
+            for c, v in zip(free, q):
+                c.q = v
+
+        def f_eqcons(q):
+            put(q)
+            return np.array([c.h() for c in self.constraints])
+
+        def fprime_eqcons(q):
+            put(q)
+            return np.array([[c.h_dq(cfg) for cfg in free] for c in self.constraints])
+
+        (q_opt, fx, its, imode, smode) = scipy.optimize.fmin_slsqp(
+            lambda q: float((q - q0).dot(q - q0)), q0, f_eqcons=f_eqcons, fprime=lambda q: 2.0 * (q - q0),
+            fprime_eqcons=fprime_eqcons, acc=tolerance, iter=100 * self.nQ, iprint=1 if verbose else 0, full_output=True)
+        if imode != 0:
+            raise Exception("Minimization failed: %s" % smode)
+        put(q_opt)
+        return self.q
+
     def set_state(self, q=None, dq=None, u=None, ddqk=None, t=None):
         if q is not None:
             self.q = q
