@@ -192,6 +192,10 @@ int tg_batch_deriv1(tg_batch *b);
  * The full [A][B][out] tensors are never materialised.
  */
 int tg_batch_deriv2_contract(tg_batch *b, const double *z_host, double *hz_host);
+/* Same with an additional weight vector on the multiplier outputs (either vector may be NULL = zeros):
+ *   hz[b][A][B] += sum_c zlambda[b][c] * l1_dAdB[A][B][c]      (the reference's _l1_dAdB tensors, trep.h:439-473;
+ * in the implicit-function solve this is a seed on the constraint rows of the adjoint vector). */
+int tg_batch_deriv2_contract_lambda(tg_batch *b, const double *z_host, const double *zlambda_host, double *hz_host);
 
 /* Device memory helpers so a host language without a HIP binding can stage inputs. */
 void *tg_device_alloc(int32_t device, uint64_t bytes);

@@ -21,7 +21,7 @@ class RunArgs(ctypes.Structure):
                 ("tolerance", ctypes.c_double),
                 ("q1", _D), ("q2", _D), ("p1", _D), ("p2", _D), ("lam", _D), ("u1", _D),
                 ("U", _D), ("K", _D), ("q2_hint", _D), ("lam_hint", _D), ("Kproj", _D), ("bX", _D), ("bU", _D), ("Uout", _D), ("group_size", ctypes.c_int), ("group_map", _I), ("X", _D), ("f_out", _D),
-                ("d1", _D * 12), ("A_out", _D), ("B_out", _D), ("z", _D), ("hz", _D), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p)]
+                ("d1", _D * 12), ("A_out", _D), ("B_out", _D), ("z", _D), ("zl", _D), ("hz", _D), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p)]
 
 
 def lib():
@@ -131,13 +131,17 @@ class EmuBatch(object):
         self.t1, self.t2 = self.t2 + (n_steps - 1) * dt, self.t2 + n_steps * dt
         return X, Uo
 
-    def deriv2z(self, Z):
-        """HZ [B][R][R]: second derivatives of the step map contracted with z = Z[b] (nX)."""
+    def deriv2z(self, Z, ZL=None):
+        """HZ [B][R][R]: second derivatives of the step map contracted with z = Z[b] (nX) and, optionally, of
+        lambda1 contracted with ZL[b] (nc)."""
         R = self.nq + self.nd + self.nu + self.nk
         Z = np.ascontiguousarray(Z, dtype=float)
         HZ = np.zeros((self.B, R, R))
         a = self._args(4)
         a.z, a.hz = _p(Z), _p(HZ)
+        if ZL is not None:
+            ZL = np.ascontiguousarray(ZL, dtype=float)
+            a.zl = _p(ZL)
         self.L.emu_run(self.h, ctypes.byref(a))
         return HZ
 

@@ -129,6 +129,22 @@ def test_emulated_contracted_second_derivatives_match_oracle(name):
     HZ = e.deriv2z(z[None, :])[0]
     ref = oracle_hz(o, d, z)
     assert relerr(HZ, ref) < 1e-8, name
+    if d.n_constraints:   # multiplier second derivatives: seed on the lambda rows (the reference's _l1_dAdB tensors)
+        zl = rng.standard_normal(d.n_constraints)
+        HL = e.deriv2z(np.zeros((1, e.nX)), zl[None, :])[0]
+        nq, nd, nk, nu = d.n_configs, d.n_dyn, d.n_kin, d.n_inputs
+        cnt = {"dq1": nq, "dp1": nd, "du1": nu, "dk2": nk}
+        off = {"dq1": 0, "dp1": nq, "du1": nq + nd, "dk2": nq + nd + nu}
+        names = ["dq1", "dp1", "du1", "dk2"]
+        refl = np.zeros_like(HL)
+        for ia, a in enumerate(names):
+            for b in names[ia:]:
+                if cnt[a] == 0 or cnt[b] == 0:
+                    continue
+                blk = o.deriv2("l1_" + a + b) @ zl
+                refl[off[a]:off[a] + cnt[a], off[b]:off[b] + cnt[b]] = blk
+                refl[off[b]:off[b] + cnt[b], off[a]:off[a] + cnt[a]] = blk.T
+        assert relerr(HL, refl) < 1e-7, (name, relerr(HL, refl))
 
 
 @pytest.mark.parametrize("links", [12, 34])

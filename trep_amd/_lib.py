@@ -71,6 +71,7 @@ _SIGNATURES = {
     "tg_batch_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tg_batch_deriv1": (ctypes.c_int, [ctypes.c_void_p]),
     "tg_batch_deriv2_contract": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "tg_batch_deriv2_contract_lambda": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tg_batch_snapshot": (ctypes.c_int, [ctypes.c_void_p]),
     "tg_batch_restore": (ctypes.c_int, [ctypes.c_void_p]),
     "tg_device_alloc": (ctypes.c_void_p, [ctypes.c_int32, ctypes.c_uint64]),

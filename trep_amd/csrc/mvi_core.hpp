@@ -85,6 +85,7 @@ struct RunArgs {
     double *A_out, *B_out;                 // MODE_DERIV1, if A_out != null: write DSystem.fdx / fdu instead
                                            // (dsystem.py:284-317): A [batch][nX][nX], B [batch][nX][nU]
     const double *z;                       // MODE_DERIV2Z: [batch][nX] contraction vector
+    const double *zl;                      // MODE_DERIV2Z, optional: [batch][nc] weights of the lambda1 second derivatives
     double *hz;                            // MODE_DERIV2Z: [batch][R][R], R = nq+nd+nu+nk
     int *iters, *status;                   // [batch]
     long long *prof_out;                   // diagnostic build: [16] cycle counters of trajectory 0
@@ -1197,12 +1198,13 @@ struct Core {
             TG_FOR(i, nd) { zq[i] = A.z[t * P.nX + i]; zp[i] = A.z[t * P.nX + nq + i]; }
         }
         TG_SYNC();
-        // r = z_Qd + D2D2L2[:nd] z_p  (kept in vec[0..nd)), then w = Kinv^T [r; 0]
+        // r = z_Qd + D2D2L2[:nd] z_p  (kept in vec[0..nd)), then w = Kinv^T [r; z_lambda]
         if (on) TG_FOR(i, nd) {
             double r = zq[i];
             for (int o = 0; o < nd; o++) r += T22[i * nd + o] * zp[o];
             vec[i] = r;
         }
+        if (on) TG_FOR(c, nc) vec[nd + c] = A.zl ? A.zl[t * nc + c] : 0.0;   // seed on the multiplier rows: lambda1'' (trep.h:439-473)
         TG_SYNC();
         // the two D.D2L2 tables of the first-derivative solve are dead now; the H tables take their place.
         // H11 and H22 are symmetric and stored packed (lower triangle); H12 is full with an odd row stride.
@@ -1213,7 +1215,7 @@ struct Core {
         TG_SYNC();
         if (on) TG_FOR(j, nf) {
             double acc = 0.0;
-            for (int i = 0; i < nd; i++) {
+            for (int i = 0; i < nf; i++) {
                 const double kinv = j < nd ? -AUG[i * ld + c_p1 + j] : AUG[i * ld + c_ex + (j - nd)];
                 acc += vec[i] * kinv;
             }

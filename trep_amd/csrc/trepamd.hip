@@ -56,7 +56,7 @@ struct tg_batch {
     double *q1 = nullptr, *q2 = nullptr, *p1 = nullptr, *p2 = nullptr, *lam = nullptr, *u1 = nullptr;
     double *stage_u = nullptr, *stage_k = nullptr, *stage_qh = nullptr, *stage_lh = nullptr, *f_out = nullptr;
     int *iters = nullptr, *status = nullptr;
-    double *z_dev = nullptr, *hz_dev = nullptr;
+    double *z_dev = nullptr, *hz_dev = nullptr, *zl_dev = nullptr;
     double *d1[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool have_d1 = false;
     long long *prof = nullptr; // diagnostic build only (TG_PROFILE)
@@ -177,7 +177,7 @@ int ensure_deriv_buffers(tg_batch *b, bool first, bool second) {
         const size_t rows = var == 0 ? P.nq : (var == 1 ? P.nd : (var == 2 ? P.nu : P.nk));
         ok = dalloc(&b->d1[k], B * rows * (out == 2 ? P.nc : P.nd));
     }
-    if (second && ok) ok = dalloc(&b->z_dev, B * P.nX) && dalloc(&b->hz_dev, B * (size_t)P.d_nrhs * P.d_nrhs);
+    if (second && ok) ok = dalloc(&b->z_dev, B * P.nX) && dalloc(&b->zl_dev, B * P.nc) && dalloc(&b->hz_dev, B * (size_t)P.d_nrhs * P.d_nrhs);
     return ok ? TG_SUCCESS : fail(TG_ERR_HIP, "device allocation failed");
 }
 
@@ -316,7 +316,7 @@ void tg_batch_destroy(tg_batch *b) {
     for (auto &e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : b->pool) hipEventDestroy(e);
     void *ptrs[] = {b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
-                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev,
+                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev, b->zl_dev,
                     b->d1[0], b->d1[1], b->d1[2], b->d1[3], b->d1[4], b->d1[5], b->d1[6], b->d1[7], b->d1[8], b->d1[9], b->d1[10], b->d1[11]};
     for (void *p : ptrs) if (p) hipFree(p);
     if (b->stream && b->own_stream) hipStreamDestroy(b->stream);
@@ -544,6 +544,24 @@ int tg_batch_deriv2_contract(tg_batch *b, const double *z_host, double *hz_host)
     if (int rc0 = ensure_deriv_buffers(b, false, true)) return rc0;
     HIP_TRY(hipMemcpyAsync(b->z_dev, z_host, B * b->P.nX * sizeof(double), hipMemcpyHostToDevice, b->stream));
     tg::RunArgs A = base_args(b, tg::MODE_DERIV2Z);
+    int rc = launch(b, A);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(hz_host, b->hz_dev, B * R * R * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return TG_SUCCESS;
+}
+
+int tg_batch_deriv2_contract_lambda(tg_batch *b, const double *z_host, const double *zlambda_host, double *hz_host) {
+    if (!b || !hz_host || (!z_host && !zlambda_host)) return fail(TG_ERR_INVALID, "null argument");
+    if (b->t2 == b->t1) return fail(TG_ERR_STATE, "Integrator has not solved the next time step yet.");
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t B = (size_t)b->batch, R = (size_t)b->P.d_nrhs;
+    if (int rc0 = ensure_deriv_buffers(b, false, true)) return rc0;
+    if (z_host) HIP_TRY(hipMemcpyAsync(b->z_dev, z_host, B * b->P.nX * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    else HIP_TRY(hipMemsetAsync(b->z_dev, 0, B * b->P.nX * sizeof(double), b->stream));
+    if (zlambda_host && b->P.nc) HIP_TRY(hipMemcpyAsync(b->zl_dev, zlambda_host, B * b->P.nc * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    tg::RunArgs A = base_args(b, tg::MODE_DERIV2Z);
+    A.zl = (zlambda_host && b->P.nc) ? b->zl_dev : nullptr;
     int rc = launch(b, A);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(hz_host, b->hz_dev, B * R * R * sizeof(double), hipMemcpyDeviceToHost, b->stream));

@@ -166,14 +166,18 @@ class BatchMidpointVI(object):
             _lib.check(self._L.tg_batch_get(self._h, _lib.F_D1_BASE + k, out.ctypes.data))
         return out
 
-    def deriv2_contract(self, Z):
+    def deriv2_contract(self, Z, ZL=None):
         """Second derivatives contracted with Z [B][nX] over the output index: HZ [B][R][R] with the
         derivative variables ordered (q1[nq], p1[nd], u1[nu], k2[nk]).  HZ[b][A][B] =
         sum_o Z[b][o] q2_dAdB[A][B][o] + Z[b][nq+o] p2_dAdB[A][B][o] (what DSystem.fdxdx/fdxdu/fdudu use)."""
         R = self.nq + self.nd + self.nu + self.nk
         Z = _lib.as_f64(np.broadcast_to(np.asarray(Z, dtype=float), (self._batch, self.nX)), (self._batch, self.nX))
         HZ = np.zeros((self._batch, R, R))
-        _lib.check(self._L.tg_batch_deriv2_contract(self._h, Z.ctypes.data, HZ.ctypes.data))
+        if ZL is None:
+            _lib.check(self._L.tg_batch_deriv2_contract(self._h, Z.ctypes.data, HZ.ctypes.data))
+        else:   # additionally sum_c ZL[b][c] * lambda1_dAdB[A][B][c]
+            ZL = _lib.as_f64(np.broadcast_to(np.asarray(ZL, dtype=float), (self._batch, self.nc)), (self._batch, self.nc))
+            _lib.check(self._L.tg_batch_deriv2_contract_lambda(self._h, Z.ctypes.data, _lib.ptr(ZL), HZ.ctypes.data))
         return HZ
 
     def step(self, t2, u1=None, k2=None, max_iterations=200, q2_hint=None, lambda1_hint=None):
@@ -401,17 +405,21 @@ class MidpointVI(object):
             raise Exception("Integrator has not solved of the next time step yet.")
         b = self._batch()
         nd, nq, nu, nk = b.nd, b.nq, b.nu, b.nk
+        nc = b.nc
         if getattr(self, "_b2", None) is None or self._b2_version != self._system._structure_version:
-            self._b2 = BatchMidpointVI(self._system, max(2 * nd, 1), self._tolerance, self._device)
+            self._b2 = BatchMidpointVI(self._system, max(2 * nd + nc, 1), self._tolerance, self._device)
             self._b2_version = self._system._structure_version
         h = self._b2
         h.set_times(*b.times())
         for name in ("q1", "q2", "p1", "p2", "u1", "lambda1"):
             setattr(h, name, getattr(b, name)[0])
-        Z = np.zeros((2 * nd, b.nX))
+        # one unit contraction per output: nd for q2, nd for p2, nc for lambda1
+        Z = np.zeros((2 * nd + nc, b.nX))
+        ZL = np.zeros((2 * nd + nc, nc))
         Z[np.arange(nd), np.arange(nd)] = 1.0
         Z[nd + np.arange(nd), nq + np.arange(nd)] = 1.0
-        HZ = h.deriv2_contract(Z)
+        ZL[2 * nd + np.arange(nc), np.arange(nc)] = 1.0
+        HZ = h.deriv2_contract(Z, ZL if nc else None)
         off = {"dq1": (0, nq), "dp1": (nq, nd), "du1": (nq + nd, nu), "dk2": (nq + nd + nu, nk)}
         self._d2 = {}
         names = ["dq1", "dp1", "du1", "dk2"]
@@ -420,17 +428,19 @@ class MidpointVI(object):
                 (oa, na), (ob, nb) = off[a], off[bname]
                 blk = HZ[:, oa:oa + na, ob:ob + nb]
                 self._d2["q2_" + a + bname] = np.ascontiguousarray(np.moveaxis(blk[:nd], 0, 2))
-                self._d2["p2_" + a + bname] = np.ascontiguousarray(np.moveaxis(blk[nd:], 0, 2))
+                self._d2["p2_" + a + bname] = np.ascontiguousarray(np.moveaxis(blk[nd:2 * nd], 0, 2))
+                self._d2["lambda1_" + a + bname] = np.ascontiguousarray(np.moveaxis(blk[2 * nd:], 0, 2))
         self._cache |= 4
 
     def _d2_accessor(name, kinds):
         def accessor(self, out=None, var1=None, var2=None):
             self._calc_deriv2()
-            return self._d2[name][self._index(var1, kinds[0]), self._index(var2, kinds[1]), self._index(out, "d")].copy()
+            out_kind = "c" if name.startswith("lambda1") else "d"
+            return self._d2[name][self._index(var1, kinds[0]), self._index(var2, kinds[1]), self._index(out, out_kind)].copy()
         accessor.__name__ = name
         return accessor
 
-    for _pre in ("q2", "p2"):
+    for _pre in ("q2", "p2", "lambda1"):
         for _pair, _kinds in (("dq1dq1", "qq"), ("dq1dp1", "qd"), ("dq1du1", "qu"), ("dq1dk2", "qk"), ("dp1dp1", "dd"),
                               ("dp1du1", "du"), ("dp1dk2", "dk"), ("du1du1", "uu"), ("du1dk2", "uk"), ("dk2dk2", "kk")):
             locals()["%s_%s" % (_pre, _pair)] = _d2_accessor("%s_%s" % (_pre, _pair), _kinds)
