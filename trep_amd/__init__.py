@@ -11,13 +11,13 @@ done by ``libtrepamd.so`` (hand-written HIP for gfx950) through a ctypes C ABI
 from .frame import (Frame, FrameDef, WORLD, TX, TY, TZ, RX, RY, RZ, CONST_SE3,
                     tx, ty, tz, rx, ry, rz, const_se3, const_txyz)
 from .config import Config, Input
-from .system import System
+from .system import System, save_trajectory, load_trajectory
 from .dynamics import Potential, Force, Constraint
 from . import potentials, forces, constraints, puppets, systems
 from .errors import ConvergenceError
 from .midpointvi import MidpointVI, BatchMidpointVI
 from . import discopt
 
-__all__ = ["System", "Frame", "Config", "Input", "Potential", "Force", "Constraint", "MidpointVI",
+__all__ = ["System", "save_trajectory", "load_trajectory", "Frame", "Config", "Input", "Potential", "Force", "Constraint", "MidpointVI",
            "BatchMidpointVI", "ConvergenceError", "tx", "ty", "tz", "rx", "ry", "rz", "const_se3",
            "const_txyz", "WORLD", "TX", "TY", "TZ", "RX", "RY", "RZ", "CONST_SE3"]

@@ -38,6 +38,9 @@ class _Packing(object):
         self.split_input_return = namedtuple('split_input', 'u rho')
         self.split_trajectory_return = namedtuple('split_trajectory', 'Q p v u rho')
         self.linearization_return = namedtuple('linearization', 'A B')
+        self.tangent_trajectory_return = namedtuple('tangent_trajectory', 'dX dU')
+        self.feedback_return = namedtuple('feedback', 'Kproj A B')
+        self.error_return = namedtuple('error', 'error exact_norm approx_norm')
 
     nX = property(lambda self: self._nX)
     nU = property(lambda self: self._nU)
@@ -232,6 +235,143 @@ class DSystem(_Packing):
         hz = self.varint.deriv2_contract(Z)
         parts = [self._split_hz(hz[b]) for b in range(self.varint.batch)]
         return tuple(np.array([p[i] for p in parts]) for i in range(3))
+
+    # -- trajectory files (dsystem.py:389-403) -------------------------------------------------------
+    def save_state_trajectory(self, filename, X=None, U=None):
+        from ..system import save_trajectory
+        (Q, p, v, u, rho) = self.split_trajectory(X, U)
+        save_trajectory(filename, self.system, self._time, Q, p, v, u, rho)
+
+    def load_state_trajectory(self, filename):
+        from ..system import load_trajectory
+        (t, Q, p, v, u, rho) = load_trajectory(filename, self.system)
+        self.time = t
+        return self.build_trajectory(Q, p, v, u, rho)
+
+    # -- projection onto the trajectory manifold (dsystem.py:426-494) ----------------------------------
+    def project(self, bX, bU, Kproj=None):
+        """X[0] = bX[0]; U[k] = bU[k] - Kproj[k] (X[k] - bX[k]); X[k+1] = f(X[k], U[k], k).
+        The N dependent steps run as one closed-loop device rollout when the time base is uniform."""
+        bX, bU = np.asarray(bX, dtype=float), np.asarray(bU, dtype=float)
+        if Kproj is None:
+            Kproj = self.calc_feedback_controller(bX, bU)
+        steps = np.diff(self._time)
+        N = len(bX) - 1
+        if N > 0 and np.allclose(steps, steps[0], rtol=1e-9, atol=1e-12):
+            eng = self._projection_engine()
+            Q0, p0, _ = self.split_state(bX[0])
+            eng.initialize_from_state(self._time[0], Q0[None], p0[None])
+            nX, nU = eng.rollout_closed_loop(N, float(steps[0]), np.asarray(Kproj)[None], bX[None], bU[None])
+            _, status = eng.status()
+            if status[0] != 0:
+                from ..errors import ConvergenceError
+                raise ConvergenceError("project: DEL solve failed")
+            nX[0, 0, :] = bX[0]
+            return self.trajectory_return(nX[0], nU[0])
+        nX, nU = np.zeros(bX.shape), np.zeros(bU.shape)
+        nX[0] = bX[0]
+        for k in range(N):
+            nU[k] = bU[k] - np.dot(Kproj[k], nX[k] - bX[k])
+            if k == 0:
+                self.set(nX[k], nU[k], k, xk_hint=bX[k + 1])
+            else:
+                self.step(nU[k], xk_hint=bX[k + 1])
+            nX[k + 1] = self.f()
+        return self.trajectory_return(nX, nU)
+
+    def _projection_engine(self):
+        if getattr(self, "_proj", None) is None:
+            self._proj = BatchMidpointVI(self.system, 1, tolerance=self.varint.tolerance, device=self.varint._device)
+        return self._proj
+
+    def dproject(self, A, B, bdX, bdU, K):
+        dX, dU = np.zeros(np.shape(bdX)), np.zeros(np.shape(bdU))
+        dX[0] = bdX[0]
+        for k in range(len(bdX) - 1):
+            dU[k] = bdU[k] - np.dot(K[k], dX[k] - bdX[k])
+            dX[k + 1] = np.dot(A[k], dX[k]) + np.dot(B[k], dU[k])
+        return self.tangent_trajectory_return(dX, dU)
+
+    def calc_feedback_controller(self, X, U, Q=None, R=None, return_linearization=False):
+        from . import dlqr
+        (A, B) = self.linearize_trajectory(X, U)
+        if Q is None:
+            eyeX = np.eye(self.nX)
+            Q = lambda k: eyeX      # noqa: E731
+        if R is None:
+            eyeU = np.eye(self.nU)
+            R = lambda k: eyeU      # noqa: E731
+        Kproj = dlqr.solve_tv_lqr(A, B, Q, R)[0]
+        return self.feedback_return(Kproj, A, B) if return_linearization else Kproj
+
+    def convert_trajectory(self, dsys_a, X, U):
+        """Map a trajectory of dsys_a onto this system by config / input names (dsystem.py:497-535)."""
+        (qa, pa, va, ua, ra) = dsys_a.split_trajectory(X, U)
+        qb, pb, vb = np.zeros((len(X), self._nQ)), np.zeros((len(X), self._np)), np.zeros((len(X), self._nv))
+        ub, rb = np.zeros((len(U), self._nu)), np.zeros((len(U), self._nrho))
+
+        def matches(list_a, list_b):
+            names = [item.name for item in list_a]
+            pairs = [(i, names.index(item.name)) for i, item in enumerate(list_b) if item.name in names]
+            return [i for i, _ in pairs], [j for _, j in pairs]
+        sa, sb = dsys_a.system, self.system
+        for dst, src, (ib, ia) in ((qb, qa, matches(sa.configs, sb.configs)), (pb, pa, matches(sa.dyn_configs, sb.dyn_configs)),
+                                   (ub, ua, matches(sa.inputs, sb.inputs)), (vb, va, matches(sa.kin_configs, sb.kin_configs)),
+                                   (rb, ra, matches(sa.kin_configs, sb.kin_configs))):
+            if ib:
+                dst[:, ib] = src[:, ia]
+        return self.build_trajectory(qb, pb, vb, ub, rb)
+
+    # -- finite-difference validators (dsystem.py:538-704): every perturbation is one lane of a batch ------
+    def _fd_batch(self, xk, uk, k, delta, wrt):
+        n = self.nX if wrt == "x" else self.nU
+        bd = BatchDSystem(self.system, self._time, 2 * n, device=self.varint._device, tolerance=self.varint.tolerance)
+        Xp, Up = np.tile(np.asarray(xk, dtype=float), (2 * n, 1)), np.tile(np.asarray(uk, dtype=float), (2 * n, 1))
+        tgt = Xp if wrt == "x" else Up
+        tgt[np.arange(n), np.arange(n)] += delta
+        tgt[n + np.arange(n), np.arange(n)] -= delta
+        _, status = bd.set(Xp, Up, k)
+        if (status != 0).any():
+            from ..errors import ConvergenceError
+            raise ConvergenceError("finite-difference check: DEL solve failed")
+        return bd, n
+
+    def _fd_report(self, exact, approx):
+        return self.error_return(np.linalg.norm(exact - approx), np.linalg.norm(exact), np.linalg.norm(approx))
+
+    def _check_first(self, xk, uk, k, delta, wrt):
+        self.set(xk, uk, k)
+        exact = self.fdx() if wrt == "x" else self.fdu()
+        bd, n = self._fd_batch(xk, uk, k, delta, wrt)
+        F = bd.f()
+        bd.varint.close()
+        return self._fd_report(exact, ((F[:n] - F[n:]) / (2 * delta)).T)
+
+    def check_fdx(self, xk, uk, k, delta=1e-5):
+        return self._check_first(xk, uk, k, delta, "x")
+
+    def check_fdu(self, xk, uk, k, delta=1e-5):
+        return self._check_first(xk, uk, k, delta, "u")
+
+    def _check_second(self, xk, uk, k, delta, which):
+        self.set(xk, uk, k)
+        idx = {"xx": 0, "xu": 1, "uu": 2}[which]
+        exact = np.array([self._second_order(z)[idx] for z in np.eye(self.nX)])       # [out][a][b]
+        bd, n = self._fd_batch(xk, uk, k, delta, "u" if which[1] == "u" else "x")
+        A, B = bd.linearize()
+        bd.varint.close()
+        J = A if which[0] == "x" else B                                                     # d f_out / d a
+        approx = np.moveaxis((J[:n] - J[n:]) / (2 * delta), 0, 2)                           # [out][a][b]
+        return self._fd_report(exact, approx)
+
+    def check_fdxdx(self, xk, uk, k, delta=1e-5):
+        return self._check_second(xk, uk, k, delta, "xx")
+
+    def check_fdxdu(self, xk, uk, k, delta=1e-5):
+        return self._check_second(xk, uk, k, delta, "xu")
+
+    def check_fdudu(self, xk, uk, k, delta=1e-5):
+        return self._check_second(xk, uk, k, delta, "uu")
 
 
 class BatchDSystem(_Packing):

@@ -294,3 +294,51 @@ class System(object):
             self.ddqk = ddqk
         if t is not None:
             self.t = t
+
+
+def save_trajectory(filename, system, t, Q=None, p=None, v=None, u=None, rho=None):
+    """Write a trajectory to a MATLAB file, same variables as the reference (system.py:1209-1230):
+    ``time``, the given arrays of ``Q p v u rho``, and ``*_index`` cell arrays with the config / input names."""
+    import scipy.io
+    data = {"time": np.array(t)}
+    for key, value in (("Q", Q), ("p", p), ("v", v), ("u", u), ("rho", rho)):
+        if value is not None:
+            data[key] = np.array(value)
+
+    def cells(items):
+        return np.array([item.name for item in items], dtype=object)
+    data["Q_index"] = cells(system.configs)
+    data["p_index"] = cells(system.dyn_configs)
+    data["v_index"] = cells(system.kin_configs)
+    data["u_index"] = cells(system.inputs)
+    data["rho_index"] = cells(system.kin_configs)
+    scipy.io.savemat(filename, data)
+
+
+def load_trajectory(filename, system=None):
+    """Read a file written by save_trajectory (system.py:1233-1304).  Without ``system``: the raw arrays with
+    their name lists, ``(t, (Q_index, Q), (p_index, p), ...)``; with it: ``(t, Q, p, v, u, rho)`` re-ordered by
+    name into the system's layout, unknown columns zero."""
+    import scipy.io
+    data = scipy.io.loadmat(filename)
+    t = data["time"].squeeze()
+    keys = ("Q", "p", "v", "u", "rho")
+    arrays = dict((key, data.get(key, None)) for key in keys)
+    names = dict((key, [str(c[0]).strip() for c in data[key + "_index"].ravel()]) for key in keys)
+    if system is None:
+        return (t,) + tuple((names[key], arrays[key]) for key in keys)
+    layout = {"Q": (system.configs, len(t), lambda c: c.index), "p": (system.dyn_configs, len(t), lambda c: c.index),
+              "v": (system.kin_configs, len(t), lambda c: c.k_index), "u": (system.inputs, len(t) - 1, lambda c: c.index),
+              "rho": (system.kin_configs, len(t) - 1, lambda c: c.k_index)}
+    out = []
+    for key in keys:
+        if arrays[key] is None:
+            out.append(None)
+            continue
+        items, rows, col = layout[key]
+        full = np.zeros((rows, len(items)))
+        for item in items:
+            if item.name in names[key]:
+                full[:, col(item)] = arrays[key][:, names[key].index(item.name)]
+        out.append(full)
+    return (t,) + tuple(out)
