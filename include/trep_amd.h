@@ -218,6 +218,18 @@ int tg_batch_timing(tg_batch *b, int32_t reset, int32_t *n_launches, double *tot
  * `select_dev` (optional, int32 [n_problems]) restricts a call to a subset of the seeds.
  * ------------------------------------------------------------------------------------------------------ */
 
+/* ---- continuous dynamics -------------------------------------------------------------
+ * Replaces calc_dynamics (system.c:749-893) behind System.f() / System.lambda_() (system.py:951-959, 1018-1024),
+ * for every trajectory of the batch at once: accelerations of the dynamic configs and constraint forces at the state
+ * (q [B][nq], dq [B][nq], u [B][nu], ddq of the kinematic configs [B][nk]).  Outputs ddq [B][nd], lambda [B][nc],
+ * status [B] (TG_OK or TG_SINGULAR; may be NULL).  Arrays of zero width may be NULL.  The integrator state of the
+ * batch (q1, q2, p, lambda1, caches) is not touched.  The _device variant takes device pointers, launches on the
+ * batch's stream and does not synchronise. */
+int tg_batch_dynamics(tg_batch *b, const double *q_host, const double *dq_host, const double *u_host,
+                      const double *ddqk_host, double *ddq_host, double *lambda_host, int32_t *status_host);
+int tg_batch_dynamics_device(tg_batch *b, const double *q_dev, const double *dq_dev, const double *u_dev,
+                             const double *ddqk_dev, double *ddq_dev, double *lambda_dev, int32_t *status_dev);
+
 /* DSystem.set(X[s][k], U[s][k], k, xk_hint = X[s][k+1]) for every (s, k) at once (reference
  * trep/discopt/dsystem.py:229-251 as used by linearize_trajectory, :406-423, and calc_newton_model,
  * doptimizer.py:333-335): the batch must hold seeds*horizon trajectories, trajectory t = s*horizon + k;

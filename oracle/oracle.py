@@ -43,6 +43,7 @@ def lib():
         L.to_rollout.restype = ctypes.c_int64
         L.to_rollout.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
                                  ctypes.c_void_p, ctypes.c_int]
+        L.to_dynamics.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6
         _LIB = L
     return _LIB
 
@@ -176,6 +177,18 @@ class OracleMVI(object):
         cnt = {"dq1": self.nq, "dp1": self.nd, "du1": self.nu, "dk2": self.nk}
         a, b = name[3:6], name[6:9]
         return self.arr(name, (cnt[a], cnt[b], out)).copy()
+
+    def dynamics(self, q, dq, u=None, ddqk=None):
+        """Continuous dynamics (system.c:749-893): returns (ddq [nd], lambda [nc])."""
+        q = np.ascontiguousarray(q, dtype=float)
+        dq = np.ascontiguousarray(dq, dtype=float)
+        u = np.zeros(max(self.nu, 1)) if u is None else np.ascontiguousarray(np.append(u, 0.0), dtype=float)
+        ddqk = np.zeros(max(self.nk, 1)) if ddqk is None else np.ascontiguousarray(np.append(ddqk, 0.0), dtype=float)
+        f, lam = np.zeros(max(self.nd, 1)), np.zeros(max(self.nc, 1))
+        if self._L.to_dynamics(self._h, q.ctypes.data, dq.ctypes.data, u.ctypes.data, ddqk.ctypes.data,
+                               f.ctypes.data, lam.ctypes.data):
+            raise OracleError("singular")
+        return f[:self.nd], lam[:self.nc]
 
     def rollout(self, n_steps, dt, U=None, K=None, want_X=True, max_iterations=200):
         nX = self.nq + self.nd + self.nk

@@ -48,6 +48,7 @@ void emu_run(void *h, const tg::RunArgs *args) {
         case tg::MODE_CALC_P2: tg::run_trajectory<1, tg::MODE_CALC_P2>(e->P, *args, lds.data(), 0, t); break;
         case tg::MODE_CALC_F: tg::run_trajectory<1, tg::MODE_CALC_F>(e->P, *args, lds.data(), 0, t); break;
         case tg::MODE_DERIV1: tg::run_trajectory<1, tg::MODE_DERIV1>(e->P, *args, lds.data(), 0, t); break;
+        case tg::MODE_DYNAMICS: tg::run_trajectory<1, tg::MODE_DYNAMICS>(e->P, *args, lds.data(), 0, t); break;
         default: tg::run_trajectory<1, tg::MODE_DERIV2Z>(e->P, *args, lds.data(), 0, t); break;
         }
     }

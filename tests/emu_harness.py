@@ -21,7 +21,7 @@ class RunArgs(ctypes.Structure):
                 ("tolerance", ctypes.c_double),
                 ("q1", _D), ("q2", _D), ("p1", _D), ("p2", _D), ("lam", _D), ("u1", _D),
                 ("U", _D), ("K", _D), ("q2_hint", _D), ("lam_hint", _D), ("Kproj", _D), ("bX", _D), ("bU", _D), ("Uout", _D), ("group_size", ctypes.c_int), ("group_map", _I), ("X", _D), ("f_out", _D),
-                ("d1", _D * 12), ("A_out", _D), ("B_out", _D), ("z", _D), ("zl", _D), ("hz", _D), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p)]
+                ("d1", _D * 12), ("A_out", _D), ("B_out", _D), ("z", _D), ("zl", _D), ("hz", _D), ("dq_in", _D), ("ddqk_in", _D), ("ddq_out", _D), ("lam_out", _D), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p)]
 
 
 def lib():
@@ -130,6 +130,20 @@ class EmuBatch(object):
         self.L.emu_run(self.h, ctypes.byref(a))
         self.t1, self.t2 = self.t2 + (n_steps - 1) * dt, self.t2 + n_steps * dt
         return X, Uo
+
+    def dynamics(self, Q, dQ, U=None, ddK=None):
+        """Continuous dynamics of every trajectory: returns (ddq [B][nd], lambda [B][nc], status [B])."""
+        Q = np.ascontiguousarray(Q, dtype=float)
+        dQ = np.ascontiguousarray(dQ, dtype=float)
+        U = np.zeros((self.B, self.nu)) if U is None else np.ascontiguousarray(U, dtype=float)
+        ddK = np.zeros((self.B, self.nk)) if ddK is None else np.ascontiguousarray(ddK, dtype=float)
+        ddq, lam = np.zeros((self.B, self.nd)), np.zeros((self.B, self.nc))
+        a = self._args(5)
+        a.q1 = a.q2 = _p(Q)
+        a.u1 = _p(U)
+        a.dq_in, a.ddqk_in, a.ddq_out, a.lam_out = _p(dQ), _p(ddK), _p(ddq), _p(lam)
+        self.L.emu_run(self.h, ctypes.byref(a))
+        return ddq, lam, self.status.copy()
 
     def deriv2z(self, Z, ZL=None):
         """HZ [B][R][R]: second derivatives of the step map contracted with z = Z[b] (nX) and, optionally, of

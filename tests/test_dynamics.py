@@ -1,0 +1,76 @@
+"""Continuous dynamics ddq = f(q, dq, u, ddq_k), lambda (system.c:749-893).
+Golden data: tools/gen_dynamics_golden.py (System.f() / System.lambda_() of the real reference)."""
+import os
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, build, relerr
+
+NAMES = ["pendulum5", "pend_on_cart", "scissor4", "puppet40", "puppet_basic"]
+
+
+def golden():
+    return dict(np.load(os.path.join(GOLDEN, "dynamics.npz")))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_dynamics_match_reference(name):
+    from oracle.oracle import OracleMVI
+    g = golden()
+    _, d = build(name)
+    o = OracleMVI(d)
+    for s in range(len(g[name + "_q"])):
+        f, lam = o.dynamics(g[name + "_q"][s], g[name + "_dq"][s], g[name + "_u"][s], g[name + "_ddqk"][s])
+        assert relerr(f, g[name + "_f"][s]) < 1e-11, (name, s)
+        assert relerr(lam, g[name + "_lam"][s]) < 1e-11, (name, s)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_emulated_kernel_dynamics_match_reference(name):
+    """The device code of MODE_DYNAMICS compiled for the host (one lane) against the reference's f / lambda."""
+    from emu_harness import EmuBatch
+    g = golden()
+    _, d = build(name)
+    n = len(g[name + "_q"])
+    e = EmuBatch(d, n)
+    ddq, lam, status = e.dynamics(g[name + "_q"], g[name + "_dq"], g[name + "_u"], g[name + "_ddqk"])
+    assert (status == 0).all()
+    assert relerr(ddq, g[name + "_f"]) < 1e-10, name
+    assert relerr(lam, g[name + "_lam"]) < 1e-10, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_dynamics_match_reference_and_oracle(name):
+    """tg_batch_dynamics through the C ABI: golden states of the reference, then 256 random states against the oracle."""
+    import trep_amd
+    from oracle.oracle import OracleMVI
+    g = golden()
+    system, d = build(name)
+    n = len(g[name + "_q"])
+    eng = trep_amd.BatchMidpointVI(system, n)
+    ddq, lam, status = eng.dynamics(g[name + "_q"], g[name + "_dq"], g[name + "_u"], g[name + "_ddqk"])
+    assert (status == 0).all()
+    assert relerr(ddq, g[name + "_f"]) < 1e-10 and relerr(lam, g[name + "_lam"]) < 1e-10
+    eng.close()
+    # the drop-in single-state API
+    system.q, system.dq, system.u, system.ddqk = g[name + "_q"][1], g[name + "_dq"][1], g[name + "_u"][1], g[name + "_ddqk"][1]
+    assert relerr(system.f(), g[name + "_f"][1]) < 1e-10
+    assert relerr(system.lambda_(), g[name + "_lam"][1]) < 1e-10
+    assert np.array_equal(system.ddqd, system.f())
+    cfg = system.dyn_configs[-1]
+    assert system.f(cfg) == system.f()[cfg.index]
+    # a bigger batch of random states (off the constraint manifold as well: f is defined everywhere)
+    rng = np.random.default_rng(9)
+    B = 256
+    Q = g[name + "_q"][rng.integers(0, n, B)] + 0.05 * rng.standard_normal((B, system.nQ))
+    dQ = rng.standard_normal((B, system.nQ))
+    U = rng.standard_normal((B, system.nu))
+    ddK = rng.standard_normal((B, system.nQk))
+    eng = trep_amd.BatchMidpointVI(system, B)
+    ddq, lam, status = eng.dynamics(Q, dQ, U, ddK)
+    o = OracleMVI(d)
+    for b in range(0, B, 16):
+        f_o, lam_o = o.dynamics(Q[b], dQ[b], U[b], ddK[b])
+        assert relerr(ddq[b], f_o) < 1e-9 and relerr(lam[b], lam_o) < 1e-9, (name, b)

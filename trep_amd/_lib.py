@@ -71,6 +71,8 @@ _SIGNATURES = {
     "tg_batch_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tg_batch_deriv1": (ctypes.c_int, [ctypes.c_void_p]),
     "tg_batch_deriv2_contract": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "tg_batch_dynamics": (ctypes.c_int, [ctypes.c_void_p] * 8),
+    "tg_batch_dynamics_device": (ctypes.c_int, [ctypes.c_void_p] * 8),
     "tg_batch_deriv2_contract_lambda": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tg_batch_snapshot": (ctypes.c_int, [ctypes.c_void_p]),
     "tg_batch_restore": (ctypes.c_int, [ctypes.c_void_p]),

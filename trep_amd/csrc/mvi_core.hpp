@@ -64,7 +64,7 @@ extern "C" __device__ __attribute__((const)) unsigned int __ockl_wfred_max_u32(u
 
 namespace tg {
 
-enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3, MODE_DERIV2Z = 4 };
+enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3, MODE_DERIV2Z = 4, MODE_DYNAMICS = 5 };
 
 struct RunArgs {
     int batch, n_steps, max_iterations, mode, first_is_init;
@@ -87,6 +87,8 @@ struct RunArgs {
     const double *z;                       // MODE_DERIV2Z: [batch][nX] contraction vector
     const double *zl;                      // MODE_DERIV2Z, optional: [batch][nc] weights of the lambda1 second derivatives
     double *hz;                            // MODE_DERIV2Z: [batch][R][R], R = nq+nd+nu+nk
+    const double *dq_in, *ddqk_in;         // MODE_DYNAMICS: rates [batch][nq] and kinematic accelerations [batch][nk] (q in q1 = q2, u in u1)
+    double *ddq_out, *lam_out;             // MODE_DYNAMICS: accelerations of the dynamic configs [batch][nd], constraint forces [batch][nc]
     int *iters, *status;                   // [batch]
     long long *prof_out;                   // diagnostic build: [16] cycle counters of trajectory 0
 };
@@ -1603,6 +1605,123 @@ struct Core {
         return true;
     }
 
+    // [Df | f] -> [.. | Df^-1 f]: the register-resident row-per-lane solver when the matrix fits the team
+    TG_HD bool solve_kkt(bool on) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int nb4 = (P.nf + 3) >> 2;   // matrix size in blocks of 4 rows
+        if (TEAM >= 4 && 4 * nb4 <= TEAM && nb4 <= 8) {
+            double *Ad = S + P.o_Df;
+            switch (nb4) {
+            case 1: return Core<TEAM>::template gj_rows<4>(on, Ad, P.nf, P.df_ld, lane);
+            case 2: return Core<TEAM>::template gj_rows<(TEAM >= 8 ? 8 : 4)>(on, Ad, P.nf, P.df_ld, lane);
+            case 3: return Core<TEAM>::template gj_rows<(TEAM >= 12 ? 12 : 4)>(on, Ad, P.nf, P.df_ld, lane);
+            case 4: return Core<TEAM>::template gj_rows<(TEAM >= 16 ? 16 : 4)>(on, Ad, P.nf, P.df_ld, lane);
+            case 5: return Core<TEAM>::template gj_rows<(TEAM >= 20 ? 20 : 4)>(on, Ad, P.nf, P.df_ld, lane);
+            case 6: return Core<TEAM>::template gj_rows<(TEAM >= 24 ? 24 : 4)>(on, Ad, P.nf, P.df_ld, lane);
+            case 7: return Core<TEAM>::template gj_rows<(TEAM >= 28 ? 28 : 4)>(on, Ad, P.nf, P.df_ld, lane);
+            default: return Core<TEAM>::template gj_rows<(TEAM >= 32 ? 32 : 4)>(on, Ad, P.nf, P.df_ld, lane);
+            }
+        }
+#endif
+        return gauss_jordan(on, S + P.o_Df, P.nf, 1, P.df_ld, S + P.o_scal);
+    }
+
+    // =====================================================================================================
+    // Continuous dynamics (reference calc_dynamics, system.c:749-893): accelerations of the dynamic configs and the
+    // constraint forces at a state (q, dq, u, ddq_k).  The reference factors M, forms A_proj = -Ad M^-1 Ad^T and back-
+    // substitutes; here the same equations are one KKT solve
+    //     [ M   -Ad^T ] [ddq_d ]   [ D                                   ]
+    //     [ Ad    0   ] [lambda] = [ -(Ak ddq_k + sum_ij h_dqdq dq_i dq_j) ]
+    // and the bias D = L_dq - L_ddqdq dq - M_dk ddq_k + F is summed per (body, joint) item without forming the nq^2
+    // Coriolis table: with W_k = dv/dq_k and S_F = sum_k (W_k dq_k + J_k ddq_k [k kinematic]) of body F,
+    //     D_i = sum_{items a of config i} ( m gam.J_a - <J_a, S_F> - <[J_a, v_F], v_F> ) + F_i
+    // (the <W_a, v> parts of L_dq and L_ddqdq dq cancel).  q must be loaded in both q1 and q2.
+    // =====================================================================================================
+    TG_HD bool dynamics(bool on, const RunArgs &A, size_t t) {
+        const int nq = P.nq, nd = P.nd, nk = P.nk, nc = P.nc, nf = P.nf, ld = P.df_ld;
+        // The KKT matrix shares its storage with the poses (program.hpp, LDS layout): the right-hand side is
+        // accumulated in f while the poses are alive, the matrix is assembled afterwards from J and the Dh items.
+        double *K = S + P.o_Df, *rhs = S + P.o_f, *ddk = S + P.o_nu + P.nu;
+        if (on) {
+            TG_FOR(i, nq) S[P.o_dq + i] = A.dq_in[t * nq + i];
+            TG_FOR(i, nk) ddk[i] = A.ddqk_in[t * nk + i];
+            TG_FOR(i, nf) rhs[i] = 0.0;
+        }
+        TG_SYNC();
+        pose_sweep(on, 2);
+        attach_points(on, true, true);
+        if (nc) {
+            constraints(on, 2, false, S + P.o_Dh2, 0);
+            if (on) {
+                TG_FOR(n, P.n_dh) {
+                    const int c = P.dh_pack[8 * (size_t)n], k = P.dh_pack[8 * (size_t)n + 1];
+                    if (k >= nd) lds_add(&rhs[nd + c], -S[P.o_Dh2 + n] * ddk[k - nd]);
+                }
+                TG_FOR(pp, P.n_cpair) {
+                    const int *pw = P.cpair4 + 4 * (size_t)pp;
+                    const int c = pw[0], na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+                    const double h = con_d2(c, na, nb) * S[P.o_dq + ka] * S[P.o_dq + kb];
+                    lds_add(&rhs[nd + c], na != nb ? -2.0 * h : -h);
+                }
+            }
+            TG_SYNC();
+        }
+        jacobians(on);
+        velocities(on);
+        // S_F per body, in the (now dead) joint pose area
+        double *SF = S + P.o_G;
+        if (on) TG_FOR(idx, 6 * P.n_bodies) {
+            const int b = idx / 6, m = idx % 6;
+            double acc = 0.0;
+            for (int k = P.b_item_off[b]; k < P.b_item_off[b + 1]; k++) {
+                const int cfg = P.it_pack[4 * (size_t)k + 3] & 0xFFFF;
+                acc += S[P.o_W + 6 * k + m] * S[P.o_dq + cfg] + (cfg >= nd ? S[P.o_J + 6 * k + m] * ddk[cfg - nd] : 0.0);
+            }
+            SF[idx] = acc;
+        }
+        TG_SYNC();
+        if (on) {
+            TG_FOR(it, P.n_items) {
+                const int b = P.it_pack[4 * (size_t)it], cfg = P.it_pack[4 * (size_t)it + 3] & 0xFFFF;
+                const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
+                const double *J = S + P.o_J + 6 * it;
+                double jv[6];
+                bracket(J, v, jv);
+                const double term = I[0] * (gam[0] * J[0] + gam[1] * J[1] + gam[2] * J[2]) - inner6(I, J, SF + 6 * b) - inner6(I, jv, v);
+                if (cfg < nd) lds_add(&rhs[cfg], term);
+            }
+            TG_FOR(i, nd) {
+                double force = -P.damp[i] * S[P.o_dq + i];
+                for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
+                lds_add(&rhs[i], force);
+            }
+        }
+        TG_SYNC();
+        if (on) TG_FOR(i, nf * ld) K[i] = 0.0;
+        TG_SYNC();
+        if (on) {
+            TG_FOR(r, nf) K[r * ld + nf] = rhs[r];
+            TG_FOR(n, P.n_dh) {
+                const int c = P.dh_pack[8 * (size_t)n], k = P.dh_pack[8 * (size_t)n + 1];
+                if (k < nd) { K[k * ld + nd + c] = -S[P.o_Dh2 + n]; K[(nd + c) * ld + k] = S[P.o_Dh2 + n]; }
+            }
+            TG_FOR(pp, P.n_npairs) {   // M = [L_ddqddq] (system.c:459-489)
+                const int *pw = P.pair4 + 4 * (size_t)pp;
+                const int ia = pw[0], ib = pw[1], ca = pw[2] & 0xFFFF, cb = pw[2] >> 16, b = pw[3];
+                const double mab = inner6(S + P.o_I + 4 * b, S + P.o_J + 6 * ia, S + P.o_J + 6 * ib);
+                lds_add(&K[ca * ld + cb], mab);
+                if (ia != ib) lds_add(&K[cb * ld + ca], mab);
+            }
+        }
+        TG_SYNC();
+        const bool ok = solve_kkt(on);
+        if (on && ok) {
+            TG_FOR(i, nd) A.ddq_out[t * nd + i] = K[i * ld + nf];
+            TG_FOR(c, nc) A.lam_out[t * nc + c] = K[(nd + c) * ld + nf];
+        }
+        return ok;
+    }
+
     // midpoint evaluation shared by every mode: rates, poses, Jacobians, velocities, residual
     TG_HD void eval_midpoint(bool on) {
         if (on) TG_FOR(i, P.nq) S[P.o_dq + i] = (S[P.o_q2 + i] - S[P.o_q1 + i]) / dt;
@@ -1666,6 +1785,11 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
     }
     if constexpr (MODE == MODE_DERIV2Z) {
         core.deriv2z(live, A, t);
+        return;
+    }
+    if constexpr (MODE == MODE_DYNAMICS) {
+        const bool ok = core.dynamics(live, A, t);
+        if (live && lane == 0) { A.iters[t] = 0; A.status[t] = ok ? TG_OK : TG_SINGULAR; }
         return;
     }
     if constexpr (MODE == MODE_CALC_F) {  // MidpointVI.calc_f: midpointvi.c:567-575
@@ -1753,24 +1877,7 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
             if (done) break;
 #endif
             core.newton_matrix(!done);
-            bool ok;
-#if defined(__HIP_DEVICE_COMPILE__)
-            const int nb4 = (P.nf + 3) >> 2;   // matrix size in blocks of 4 rows
-            if (TEAM >= 4 && 4 * nb4 <= TEAM && nb4 <= 8) {
-                double *Ad = S + P.o_Df;
-                switch (nb4) {
-                case 1: ok = Core<TEAM>::template gj_rows<4>(!done, Ad, P.nf, P.df_ld, lane); break;
-                case 2: ok = Core<TEAM>::template gj_rows<(TEAM >= 8 ? 8 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
-                case 3: ok = Core<TEAM>::template gj_rows<(TEAM >= 12 ? 12 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
-                case 4: ok = Core<TEAM>::template gj_rows<(TEAM >= 16 ? 16 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
-                case 5: ok = Core<TEAM>::template gj_rows<(TEAM >= 20 ? 20 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
-                case 6: ok = Core<TEAM>::template gj_rows<(TEAM >= 24 ? 24 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
-                case 7: ok = Core<TEAM>::template gj_rows<(TEAM >= 28 ? 28 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
-                default: ok = Core<TEAM>::template gj_rows<(TEAM >= 32 ? 32 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
-                }
-            } else
-#endif
-                ok = core.gauss_jordan(!done, S + P.o_Df, P.nf, 1, P.df_ld, S + P.o_scal);
+            const bool ok = core.solve_kkt(!done);
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
             { long long t_ = (long long)__builtin_amdgcn_s_memtime(); core.prof[14] += t_ - core.prof_last; core.prof_last = t_; }
 #endif

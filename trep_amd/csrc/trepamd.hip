@@ -57,6 +57,8 @@ struct tg_batch {
     double *stage_u = nullptr, *stage_k = nullptr, *stage_qh = nullptr, *stage_lh = nullptr, *f_out = nullptr;
     int *iters = nullptr, *status = nullptr;
     double *z_dev = nullptr, *hz_dev = nullptr, *zl_dev = nullptr;
+    double *dyn = nullptr;     // staging of the host-facing continuous-dynamics call: q, dq, u, ddq_k, ddq, lambda
+    int *dyn_ints = nullptr;   // its status / iteration words (the integrator's own stay untouched)
     double *d1[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool have_d1 = false;
     long long *prof = nullptr; // diagnostic build only (TG_PROFILE)
@@ -138,6 +140,7 @@ int launch_team(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
     case tg::MODE_CALC_F: return launch_one<TEAM, tg::MODE_CALC_F>(b, A, grid, lds);
     case tg::MODE_DERIV1: return launch_one<TEAM, tg::MODE_DERIV1>(b, A, grid, lds);
     case tg::MODE_DERIV2Z: return launch_one<TEAM, tg::MODE_DERIV2Z>(b, A, grid, lds);
+    case tg::MODE_DYNAMICS: return launch_one<TEAM, tg::MODE_DYNAMICS>(b, A, grid, lds);
     default: return fail(TG_ERR_INVALID, "unknown kernel mode");
     }
 }
@@ -316,7 +319,7 @@ void tg_batch_destroy(tg_batch *b) {
     for (auto &e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : b->pool) hipEventDestroy(e);
     void *ptrs[] = {b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
-                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev, b->zl_dev,
+                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev, b->zl_dev, b->dyn, b->dyn_ints,
                     b->d1[0], b->d1[1], b->d1[2], b->d1[3], b->d1[4], b->d1[5], b->d1[6], b->d1[7], b->d1[8], b->d1[9], b->d1[10], b->d1[11]};
     for (void *p : ptrs) if (p) hipFree(p);
     if (b->stream && b->own_stream) hipStreamDestroy(b->stream);
@@ -565,6 +568,44 @@ int tg_batch_deriv2_contract_lambda(tg_batch *b, const double *z_host, const dou
     int rc = launch(b, A);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(hz_host, b->hz_dev, B * R * R * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return TG_SUCCESS;
+}
+
+int tg_batch_dynamics_device(tg_batch *b, const double *q_dev, const double *dq_dev, const double *u_dev, const double *ddqk_dev,
+                             double *ddq_dev, double *lambda_dev, int32_t *status_dev) {
+    if (!b || !q_dev || !dq_dev || !ddq_dev) return fail(TG_ERR_INVALID, "null argument");
+    const tg::DevProg &P = b->P;
+    if ((P.nu && !u_dev) || (P.nk && !ddqk_dev) || (P.nc && !lambda_dev)) return fail(TG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(b->device));
+    if (!b->dyn_ints) HIP_TRY(hipMalloc(&b->dyn_ints, 2 * (size_t)b->batch * sizeof(int)));
+    tg::RunArgs A = base_args(b, tg::MODE_DYNAMICS);
+    // the state is an argument of this call: nothing of the integrator (q1, q2, p, lambda1, status) is touched
+    A.q1 = A.q2 = const_cast<double *>(q_dev);
+    A.u1 = const_cast<double *>(u_dev ? u_dev : b->u1);
+    A.dq_in = dq_dev; A.ddqk_in = ddqk_dev; A.ddq_out = ddq_dev; A.lam_out = lambda_dev;
+    A.iters = b->dyn_ints; A.status = status_dev ? status_dev : b->dyn_ints + b->batch;
+    return launch(b, A);
+}
+
+int tg_batch_dynamics(tg_batch *b, const double *q_host, const double *dq_host, const double *u_host, const double *ddqk_host,
+                      double *ddq_host, double *lambda_host, int32_t *status_host) {
+    if (!b || !q_host || !dq_host || !ddq_host) return fail(TG_ERR_INVALID, "null argument");
+    const tg::DevProg &P = b->P;
+    if ((P.nu && !u_host) || (P.nk && !ddqk_host) || (P.nc && !lambda_host)) return fail(TG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t B = (size_t)b->batch, nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc;
+    const size_t total = B * (2 * nq + nu + nk + nd + nc);
+    if (!b->dyn) HIP_TRY(hipMalloc(&b->dyn, (total ? total : 1) * sizeof(double)));
+    double *q = b->dyn, *dq = q + B * nq, *u = dq + B * nq, *ddk = u + B * nu, *ddq = ddk + B * nk, *lam = ddq + B * nd;
+    HIP_TRY(hipMemcpyAsync(q, q_host, B * nq * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(dq, dq_host, B * nq * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    if (nu) HIP_TRY(hipMemcpyAsync(u, u_host, B * nu * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    if (nk) HIP_TRY(hipMemcpyAsync(ddk, ddqk_host, B * nk * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    if (int rc = tg_batch_dynamics_device(b, q, dq, nu ? u : nullptr, nk ? ddk : nullptr, ddq, lam, nullptr)) return rc;
+    HIP_TRY(hipMemcpyAsync(ddq_host, ddq, B * nd * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    if (nc) HIP_TRY(hipMemcpyAsync(lambda_host, lam, B * nc * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    if (status_host) HIP_TRY(hipMemcpyAsync(status_host, b->dyn_ints + B, B * sizeof(int), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return TG_SUCCESS;
 }

@@ -260,6 +260,21 @@ class BatchMidpointVI(object):
             self._owned_dev.remove(p)
         return X, U
 
+    def dynamics(self, Q, dQ, U=None, ddQk=None):
+        """Continuous dynamics of B states at once (the reference's System.f() / System.lambda_(), system.py:951-1024):
+        Q, dQ [B][nq]; U [B][nu]; ddQk [B][nk] accelerations of the kinematic configs (zeros when omitted).
+        Returns (ddq [B][nd], lambda [B][nc], status [B]).  The integrator state is left alone."""
+        B = self._batch
+        Q = _lib.as_f64(np.broadcast_to(np.asarray(Q, dtype=float), (B, self.nq)), (B, self.nq))
+        dQ = _lib.as_f64(np.broadcast_to(np.asarray(dQ, dtype=float), (B, self.nq)), (B, self.nq))
+        U = np.zeros((B, self.nu)) if U is None else _lib.as_f64(np.broadcast_to(np.asarray(U, dtype=float), (B, self.nu)), (B, self.nu))
+        K = np.zeros((B, self.nk)) if ddQk is None else _lib.as_f64(np.broadcast_to(np.asarray(ddQk, dtype=float), (B, self.nk)), (B, self.nk))
+        ddq, lam = np.zeros((B, self.nd)), np.zeros((B, self.nc))
+        status = np.zeros(B, dtype=np.int32)
+        _lib.check(self._L.tg_batch_dynamics(self._h, _lib.ptr(Q), _lib.ptr(dQ), _lib.ptr(U), _lib.ptr(K),
+                                             _lib.ptr(ddq), _lib.ptr(lam), status.ctypes.data))
+        return ddq, lam, status
+
     def snapshot(self):
         """Save the integrator state on the device (replayed by restore())."""
         _lib.check(self._L.tg_batch_snapshot(self._h))

@@ -283,6 +283,35 @@ class System(object):
         put(q_opt)
         return self.q
 
+    # -- continuous dynamics (system.py:951-959, 1018-1024 of the reference; calc_dynamics system.c:749-893) --------
+    def _dynamics(self):
+        """Accelerations and constraint forces at the current (q, dq, u, ddqk): one launch of the dynamics kernel
+        on a batch of one.  Like the reference, the result is also stored in the dynamic configs' ddq."""
+        from .midpointvi import BatchMidpointVI
+        eng = getattr(self, "_dyn_engine", None)
+        if eng is None or self._dyn_engine_version != self._structure_version:
+            if eng is not None:
+                eng.close()
+            eng = self._dyn_engine = BatchMidpointVI(self, 1)
+            self._dyn_engine_version = self._structure_version
+        ddq, lam, status = eng.dynamics(self.q[None], self.dq[None], self.u[None], self.ddqk[None])
+        if status[0] != 0:
+            raise ValueError("singular inertia or constraint matrix")   # LU_decomp failure in the reference
+        self.ddqd = ddq[0]
+        return ddq[0], lam[0]
+
+    def f(self, q=None):
+        """ddq of the dynamic configs (all of them, or of config ``q``)."""
+        ddq = self._dynamics()[0]
+        if q is None:
+            return ddq
+        assert not q.kinematic
+        return float(ddq[q.index])
+
+    def lambda_(self, constraint=None):
+        lam = self._dynamics()[1]
+        return lam if constraint is None else float(lam[constraint.index])
+
     def set_state(self, q=None, dq=None, u=None, ddqk=None, t=None):
         if q is not None:
             self.q = q
