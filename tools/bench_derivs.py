@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the derivative kernels (SURVEY section 8 rows a-12 .. a-14) on the puppet: teacher-forced DEL
 solve, first derivatives written as A/B (tg_batch_linearize), z-contracted second derivatives
-(tg_batch_deriv2_contract_device).  Kernel times from the library's HIP events.  Prints one JSON line.
+(tg_batch_deriv2_contract_device), and of the continuous dynamics (tg_batch_dynamics_device, section 8f rank 2).  Kernel times from the library's HIP events.  Prints one JSON line.
 
   python tools/bench_derivs.py --batch 65536
 """
@@ -41,6 +41,9 @@ def main():
     dZ, dHZ = pool.upload(np.random.default_rng(0).standard_normal((B, nX))), pool.empty((B, R, R))
     out = {"batch": B, "system": "Puppet(string_constraints=True) nq=40 nd=22 nk=18 nc=6"}
     res = {}
+    rng = np.random.default_rng(1)
+    dQ, ddQ = pool.upload(Q0), pool.upload(rng.standard_normal((B, mvi.nq)))       # continuous dynamics inputs
+    ddK, dACC, dLAM = pool.upload(rng.standard_normal((B, mvi.nk))), pool.empty((B, mvi.nd)), pool.empty((B, mvi.nc))
     for rep in range(args.reps + 1):
         mvi.timing()
         _lib.check(L.tg_batch_set_from_trajectories(mvi._h, B, 1, 0.0, dt, dX.ptr, dU.ptr, 200))
@@ -49,12 +52,15 @@ def main():
         n, ms_d1 = mvi.timing()
         _lib.check(L.tg_batch_deriv2_contract_device(mvi._h, dZ.ptr, dHZ.ptr))
         n, ms_d2 = mvi.timing()
+        _lib.check(L.tg_batch_dynamics_device(mvi._h, dQ.ptr, ddQ.ptr, None, ddK.ptr, dACC.ptr, dLAM.ptr, None))
+        n, ms_dyn = mvi.timing()
         if rep:   # first pass = warm-up
-            for k, v in (("step", ms_step), ("deriv1_AB", ms_d1), ("deriv2z", ms_d2)):
+            for k, v in (("step", ms_step), ("deriv1_AB", ms_d1), ("deriv2z", ms_d2), ("dynamics", ms_dyn)):
                 res.setdefault(k, []).append(v)
     iters, status = mvi.status()
     assert (status == 0).all()
-    bytes_per = {"step": 8 * (2 * nX + nU + mvi.nc), "deriv1_AB": 8 * (nX * nX + nX * nU), "deriv2z": 8 * (nX + R * R)}
+    bytes_per = {"step": 8 * (2 * nX + nU + mvi.nc), "deriv1_AB": 8 * (nX * nX + nX * nU), "deriv2z": 8 * (nX + R * R),
+                 "dynamics": 8 * (2 * mvi.nq + mvi.nu + mvi.nk + mvi.nd + mvi.nc)}
     for k, v in res.items():
         ms = float(np.mean(v))
         out[k] = {"kernel_ms": ms, "per_s": B / ms * 1e3, "algorithmic_bytes_per_unit": bytes_per[k],
