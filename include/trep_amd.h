@@ -67,6 +67,11 @@ typedef struct tg_system_desc {
     const int32_t *constraint_component; /* [n_constraints] point: 0,1,2 */
     const double  *constraint_distance;  /* [n_constraints] distance: constant length if no config */
     const double  *constraint_tolerance; /* [n_constraints] */
+    /* potentials on single configs: V = 1/2 k (q - q0)^2 (potentials/configspring.c:15-45) */
+    int32_t n_config_springs;
+    const int32_t *config_spring_config; /* [n_config_springs] config index */
+    const double  *config_spring_k;      /* [n_config_springs] */
+    const double  *config_spring_q0;     /* [n_config_springs] */
 } tg_system_desc;
 
 /* Per-trajectory status written by every solve (reference: ConvergenceError / ValueError("singular")

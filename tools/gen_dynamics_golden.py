@@ -25,6 +25,7 @@ BUILDERS = {
     "scissor4": lambda: systems.scissor_lift(4, api=trep),
     "puppet40": lambda: systems.puppet(api=trep),
     "puppet_basic": lambda: systems.puppet_basic(api=trep),
+    "spring_arm": lambda: systems.spring_arm(api=trep),
 }
 N_STATES = 4
 

@@ -252,6 +252,27 @@ def gen_puppet_basic():
     save("puppet_basic", **arrays, **ds)
 
 
+def gen_spring_arm():
+    """Synthetic system with ConfigSpring potentials: free-running rollouts under a
+    random torque and a moving base, full derivative tensors, DSystem captures."""
+    system = systems.spring_arm(api=trep)
+    rng = np.random.default_rng(20250 + 7)
+    B, N = 2, 200
+    arrays = dict(dt=DT, **topology(system))
+    for b in range(B):
+        q0 = np.concatenate([rng.uniform(-0.8, 0.8, size=3), [0.2 * b]])
+        U = rng.standard_normal((N, 1))
+        K = (0.2 * b + 0.3 * np.sin(2.0 * DT * np.arange(1, N + 1)))[:, None]
+        r = rollout(system, q0, U, K, N, deriv_steps=(1, 50, N) if b == 0 else (), deriv2_full=True)
+        for key, val in r.items():
+            arrays["b%d_%s" % (b, key)] = val
+        arrays["b%d_q0" % b] = q0
+        arrays["b%d_U" % b] = U
+        arrays["b%d_K" % b] = K
+    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], arrays["b0_U"], arrays["b0_K"], (0, 10, 100), seed=16)
+    save("spring_arm", **arrays, **ds)
+
+
 def gen_discopt_cart():
     """One DOptimizer trace on the pend-on-cart problem of examples/pend-on-cart-optimization.py:48-116
     (torque input enabled, 5 s horizon): a few quasi-Newton then Newton steps; per step the method,
@@ -309,7 +330,7 @@ def gen_discopt_cart():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "discopt"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "discopt"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -324,5 +345,7 @@ if __name__ == "__main__":
         gen_puppet()
     if "puppet_basic" in which:
         gen_puppet_basic()
+    if "spring_arm" in which:
+        gen_spring_arm()
     if "discopt" in which:
         gen_discopt_cart()

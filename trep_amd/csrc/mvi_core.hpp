@@ -436,6 +436,7 @@ struct Core {
             double ldq = 0.0, lddq = 0.0;
             const int n1 = P.cfg_item_off[i + 1];
             for (int n = P.cfg_item_off[i]; n < n1; n++) { lddq += terms[2 * n]; ldq += terms[2 * n + 1]; }
+            if (P.has_cs) ldq -= P.cs_k[i] * qval(0, i) - P.cs_kq0[i];   // config springs (configspring.c:22-31)
             S[P.o_Ldq + i] = ldq; S[P.o_Lddq + i] = lddq;
             double force = -P.damp[i] * S[P.o_dq + i];
             for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
@@ -523,7 +524,7 @@ struct Core {
         if (on) {
             TG_FOR(r, nf) {
                 A[r * ld + nf] = S[P.o_f + r];
-                if (r < nd) A[r * ld + r] = -P.damp[r];
+                if (r < nd) A[r * ld + r] = -P.damp[r] - (P.has_cs ? 0.25 * dt * P.cs_k[r] : 0.0);   // + dt/4 (-V_dqdq)
             }
             TG_FOR(n, P.n_dh) {
                 const int c = P.dh_pack[8 * (size_t)n], k = P.dh_pack[8 * (size_t)n + 1];
@@ -881,6 +882,11 @@ struct Core {
                 AUG[o * ld + o] -= P.damp[o];              // D2D1L2_D2fm2: + dF_o/d(dq_o)
                 AUG[o * ld + c_q1 + o] -= P.damp[o];       // -(D1D1L2_D1fm2): -( - dF_o/d(dq_o) )
                 AUG[o * ld + c_p1 + o] = -1.0;
+                if (P.has_cs) {   // a = dt/4 (-V_dqdq) on the diagonal of all four second-order tables
+                    const double a_ = -0.25 * dt * P.cs_k[o];
+                    AUG[o * ld + c_q1 + o] -= a_; AUG[o * ld + o] += a_;
+                    T12[o * nd + o] += a_; T22[o * nd + o] += a_;
+                }
                 for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == o) AUG[o * ld + c_u1 + P.cf_in[k]] -= dt;
                 for (int c = 0; c < nc; c++) AUG[o * ld + nd + c] = -Dh1[c * nq + o];
             }
@@ -1693,6 +1699,7 @@ struct Core {
             TG_FOR(i, nd) {
                 double force = -P.damp[i] * S[P.o_dq + i];
                 for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
+                if (P.has_cs) force -= P.cs_k[i] * S[P.o_q2 + i] - P.cs_kq0[i];
                 lds_add(&rhs[i], force);
             }
         }

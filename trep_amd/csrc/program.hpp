@@ -80,6 +80,8 @@ struct DevProg {
     const int *dh_lookup;     // [nc*nq] index into the dh items of (constraint, config), -1 if independent
     const int *dh_c, *dh_cfg, *dh_joint, *dh_side; // side: bit0 on e1's path, bit1 on e2's path, bit2 length config
     const double *damp;       // [nd] summed damping coefficients
+    const double *cs_k, *cs_kq0;  // [nq] config springs: sum k and sum k q0 per config (V_dq = cs_k q - cs_kq0)
+    int has_cs;
     const int *cf_cfg, *cf_in;
     // LDS layout (offsets in doubles from the team's base)
     int o_q1, o_q2, o_p1, o_lam, o_u, o_dq, o_f, o_sc, o_G, o_gB, o_pE, o_J, o_W, o_vB, o_gam, o_Ldq, o_Lddq,
@@ -108,7 +110,7 @@ struct HostProgram {
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
     std::vector<double> c_dist, c_tol;
     std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
-    std::vector<double> damp;
+    std::vector<double> damp, cs_k, cs_kq0;
     std::vector<int> cf_cfg, cf_in;
     std::vector<double> jcoef;      // [n_joints*16*4] local-transform coefficients (see pose_sweep)
     int max_depth = 0;
@@ -385,6 +387,12 @@ inline HostProgram build_program(const tg_system_desc *d) {
     H.damp.assign(nd, 0.0);
     for (int i = 0; i < d->n_damping; i++)
         for (int k = 0; k < nd; k++) H.damp[k] += d->damping[(size_t)i * nd + k];
+    H.cs_k.assign(nq, 0.0); H.cs_kq0.assign(nq, 0.0);
+    for (int i = 0; i < d->n_config_springs; i++) {
+        const int c = d->config_spring_config[i];
+        if (c < 0 || c >= nq) throw std::runtime_error("config spring: bad config index");
+        H.cs_k[c] += d->config_spring_k[i]; H.cs_kq0[c] += d->config_spring_k[i] * d->config_spring_q0[i];
+    }
     for (int i = 0; i < d->n_config_forces; i++) {
         H.cf_cfg.push_back(d->config_force_config[i]); H.cf_in.push_back(d->config_force_input[i]);
     }
@@ -395,6 +403,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.n_cfgitems = (int)H.cfg_items.size();
     P.n_npairs = (int)(H.pair4.size() / 4);
     P.n_tri = (int)(H.tri4.size() / 4); P.n_cpair = (int)(H.cpair4.size() / 4);
+    P.has_cs = d->n_config_springs > 0 ? 1 : 0;
     P.n_cpath = (int)H.cpath_items.size();
     P.grav[0] = P.grav[1] = P.grav[2] = 0.0;
     for (int i = 0; i < d->n_gravity; i++)
@@ -486,7 +495,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
     X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off)
-#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp)
+#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0)
 
 inline void HostProgram::pack() {
     ipool.clear(); dpool.clear(); ioff.clear(); doff.clear();

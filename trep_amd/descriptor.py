@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 
 from . import frame as _frame
-from .dynamics import Gravity, Damping, ConfigForce, Distance, PointToPoint1D
+from .dynamics import Gravity, ConfigSpring, Damping, ConfigForce, Distance, PointToPoint1D
 
 _I32 = ctypes.POINTER(ctypes.c_int32)
 _F64 = ctypes.POINTER(ctypes.c_double)
@@ -32,8 +32,13 @@ _ARRAYS = [
 ]
 
 
+_TAIL_SCALARS = ["n_config_springs"]
+_TAIL_ARRAYS = [("config_spring_config", _I32), ("config_spring_k", _F64), ("config_spring_q0", _F64)]
+
+
 class SystemDescStruct(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in _INT_SCALARS] + _ARRAYS
+    _fields_ = ([(n, ctypes.c_int32) for n in _INT_SCALARS] + _ARRAYS +
+                [(n, ctypes.c_int32) for n in _TAIL_SCALARS] + _TAIL_ARRAYS)
 
 
 class SystemDesc(object):
@@ -42,9 +47,9 @@ class SystemDesc(object):
     def __init__(self, tables):
         self.tables = tables
         self.struct = SystemDescStruct()
-        for n in _INT_SCALARS:
+        for n in _INT_SCALARS + _TAIL_SCALARS:
             setattr(self.struct, n, int(tables[n]))
-        for n, ptype in _ARRAYS:
+        for n, ptype in _ARRAYS + _TAIL_ARRAYS:
             arr = tables[n]
             want = np.int32 if ptype is _I32 else np.float64
             assert arr.dtype == want and arr.flags["C_CONTIGUOUS"], n
@@ -113,9 +118,14 @@ def flatten(system):
     t["masses"] = np.array([fidx[id(f)] for f in system.masses], dtype=np.int32)
 
     grav, damp, cf_c, cf_u = [], [], [], []
+    cs_c, cs_k, cs_q0 = [], [], []
     for pot in system.potentials:
         if isinstance(pot, Gravity):
             grav.append(list(pot._gravity))
+        elif isinstance(pot, ConfigSpring):
+            cs_c.append(cidx[id(pot.config)])
+            cs_k.append(pot.k)
+            cs_q0.append(pot.q0)
         else:
             raise NotImplementedError("potential %r is outside the device path's scope" % (pot,))
     for force in system.forces:
@@ -133,6 +143,10 @@ def flatten(system):
     t["damping"] = np.array(damp, dtype=np.float64).reshape(-1)
     t["config_force_config"] = np.array(cf_c, dtype=np.int32)
     t["config_force_input"] = np.array(cf_u, dtype=np.int32)
+    t["n_config_springs"] = len(cs_c)
+    t["config_spring_config"] = np.array(cs_c, dtype=np.int32)
+    t["config_spring_k"] = np.array(cs_k, dtype=np.float64)
+    t["config_spring_q0"] = np.array(cs_q0, dtype=np.float64)
 
     ctype, cf1, cf2, ccfg, ccomp, cdist, ctol = [], [], [], [], [], [], []
     for con in system.constraints:

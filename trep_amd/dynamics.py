@@ -50,6 +50,45 @@ class Gravity(Potential):
         self._system._structure_changed()
 
 
+class ConfigSpring(Potential):
+    """V = 1/2 k (q - q0)^2 on one configuration variable (potentials/configspring.py:15-54)."""
+
+    def __init__(self, system, config, k, q0=0.0, name=None):
+        Potential.__init__(self, system, name)
+        if not system.get_config(config):
+            raise ValueError("Could not find config %r" % config)
+        self._config = system.get_config(config)
+        self._k = float(k)
+        self._q0 = float(q0)
+        system._structure_changed()
+
+    def __repr__(self):
+        return "<ConfigSpring %r k=%f q0=%f>" % (self._config.name, self._k, self._q0)
+
+    config = property(lambda self: self._config)
+
+    @property
+    def k(self):
+        return self._k
+
+    @k.setter
+    def k(self, value):
+        self._k = float(value)
+        self._system._structure_changed()
+
+    @property
+    def q0(self):
+        return self._q0
+
+    @q0.setter
+    def q0(self, value):
+        self._q0 = float(value)
+        self._system._structure_changed()
+
+    def V(self):
+        return 0.5 * self._k * (self._config.q - self._q0) ** 2
+
+
 class Force(object):
     def __init__(self, system, name=None):
         self._system = system

@@ -53,6 +53,31 @@ def pend_on_cart(torque_force=False, api=None):
     return system
 
 
+def spring_arm(api=None):
+    """A 3-D three-joint arm on a sliding base with springs on its configs: exercises the ConfigSpring
+    potential (several springs on one config, a spring on a kinematic config) next to gravity, damping and
+    an input force.  Synthetic test system (no reference example of this shape)."""
+    T = _api(api)
+    system = T.System()
+    system.import_frames([
+        T.tx('slide', name='Base', kinematic=True), [
+            T.rz('a', name='Shoulder'), [
+                T.tx(1.0, name='Upper', mass=2.0), [
+                    T.ry('b', name='Elbow'), [
+                        T.tx(0.8, name='Fore', mass=(1.0, 0.1, 0.2, 0.3)), [
+                            T.rx('c', name='Wrist'), [
+                                T.tz(-0.5, name='Hand', mass=0.5)]]]]]]])
+    T.potentials.Gravity(system, (0.3, 0, -9.8))
+    T.potentials.ConfigSpring(system, 'a', k=20.0, q0=0.3)
+    T.potentials.ConfigSpring(system, 'b', k=5.0)
+    T.potentials.ConfigSpring(system, 'c', k=2.0, q0=-0.2)
+    T.potentials.ConfigSpring(system, 'c', k=1.0, q0=0.1)
+    T.potentials.ConfigSpring(system, 'slide', k=3.0, q0=0.5)
+    T.forces.Damping(system, 0.1)
+    T.forces.ConfigForce(system, 'a', 'a-torque')
+    return system
+
+
 def scissor_lift(segments=4, theta_0=0.05 * math.pi, m_link=1.0, I_link=1.0, L_link=5.0, m_slider=1.0,
                  api=None):
     """Scissor lift at its analytic closed configuration (no constraint solver needed)."""
