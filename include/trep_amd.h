@@ -72,6 +72,14 @@ typedef struct tg_system_desc {
     const int32_t *config_spring_config; /* [n_config_springs] config index */
     const double  *config_spring_k;      /* [n_config_springs] */
     const double  *config_spring_q0;     /* [n_config_springs] */
+    /* springs between the origins of two frames: V = 1/2 k (|p1 - p2| - x0)^2 (potentials/linearspring.c:16-78).
+     * Like the reference, which defines V, V_dq and V_dqdq only, systems with such springs have no second
+     * derivatives of the step map (tg_batch_deriv2_* return TG_ERR_UNSUPPORTED). */
+    int32_t n_linear_springs;
+    const int32_t *linear_spring_frame1; /* [n_linear_springs] */
+    const int32_t *linear_spring_frame2; /* [n_linear_springs] */
+    const double  *linear_spring_k;      /* [n_linear_springs] */
+    const double  *linear_spring_x0;     /* [n_linear_springs] */
 } tg_system_desc;
 
 /* Per-trajectory status written by every solve (reference: ConvergenceError / ValueError("singular")

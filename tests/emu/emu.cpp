@@ -44,12 +44,12 @@ void emu_run(void *h, const tg::RunArgs *args) {
     for (int t = 0; t < args->batch; t++) {
         std::fill(lds.begin(), lds.end(), 0.0);
         switch (args->mode) {
-        case tg::MODE_ROLLOUT: tg::run_trajectory<1, tg::MODE_ROLLOUT>(e->P, *args, lds.data(), 0, t); break;
-        case tg::MODE_CALC_P2: tg::run_trajectory<1, tg::MODE_CALC_P2>(e->P, *args, lds.data(), 0, t); break;
-        case tg::MODE_CALC_F: tg::run_trajectory<1, tg::MODE_CALC_F>(e->P, *args, lds.data(), 0, t); break;
-        case tg::MODE_DERIV1: tg::run_trajectory<1, tg::MODE_DERIV1>(e->P, *args, lds.data(), 0, t); break;
-        case tg::MODE_DYNAMICS: tg::run_trajectory<1, tg::MODE_DYNAMICS>(e->P, *args, lds.data(), 0, t); break;
-        default: tg::run_trajectory<1, tg::MODE_DERIV2Z>(e->P, *args, lds.data(), 0, t); break;
+        case tg::MODE_ROLLOUT: tg::run_trajectory<1, tg::MODE_ROLLOUT, true>(e->P, *args, lds.data(), 0, t); break;
+        case tg::MODE_CALC_P2: tg::run_trajectory<1, tg::MODE_CALC_P2, true>(e->P, *args, lds.data(), 0, t); break;
+        case tg::MODE_CALC_F: tg::run_trajectory<1, tg::MODE_CALC_F, true>(e->P, *args, lds.data(), 0, t); break;
+        case tg::MODE_DERIV1: tg::run_trajectory<1, tg::MODE_DERIV1, true>(e->P, *args, lds.data(), 0, t); break;
+        case tg::MODE_DYNAMICS: tg::run_trajectory<1, tg::MODE_DYNAMICS, true>(e->P, *args, lds.data(), 0, t); break;
+        default: tg::run_trajectory<1, tg::MODE_DERIV2Z, true>(e->P, *args, lds.data(), 0, t); break;
         }
     }
 }

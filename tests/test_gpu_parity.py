@@ -393,3 +393,18 @@ def test_full_second_derivative_tensors_match_reference(name):
         checked += 1
         n_lambda += nm.startswith("lambda1")
     assert checked >= 4 and (n_lambda > 0 or system.nc == 0)
+
+
+def test_second_derivatives_undefined_with_linear_springs():
+    """LinearSpring defines no V_dqdqdq in the reference (linearspring.c:86-88): _calc_deriv2 raises there; here the
+    contraction entry points report TG_ERR_UNSUPPORTED and the drop-in accessor raises."""
+    import trep_amd
+    g = golden("spring_link")
+    system, d = build("spring_link")
+    mvi = trep_amd.MidpointVI(system)
+    mvi.initialize_from_state(DT, g["b0_Q"][0], g["b0_P"][0], g["b0_LAM"][0])
+    mvi.step(2 * DT, (), g["b0_K"][0])
+    assert relerr(mvi.q2, g["b0_Q"][1]) < 1e-10
+    assert relerr(mvi.q2_dq1(), g["b0_d1_1_q2_dq1"].T) < 1e-9
+    with pytest.raises(Exception, match="LinearSpring"):
+        mvi.q2_dq1dq1()

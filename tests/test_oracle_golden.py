@@ -2,8 +2,8 @@
 import numpy as np
 import pytest
 
-from common import BUILDERS, D1, PAIRS, build, golden, trajectories, relerr
-from oracle.oracle import OracleMVI
+from common import BUILDERS, D1, NO_SECOND_ORDER, PAIRS, build, golden, trajectories, relerr
+from oracle.oracle import OracleMVI, OracleError
 
 TOL = 1e-10   # BASELINE.json north_star: fp64 state within 1e-10
 DT = 0.01
@@ -80,7 +80,12 @@ def test_derivatives(name):
         k = s - 1
         o.initialize_from_state(k * DT + DT, Q[k], P[k], LAM[k])
         o.step((k + 2) * DT, U[k], K[k])
-        o.calc_deriv2()
+        if name in NO_SECOND_ORDER:
+            with pytest.raises(OracleError):
+                o.calc_deriv2()
+            o.calc_deriv1()
+        else:
+            o.calc_deriv2()
         for n in D1:
             assert relerr(o.deriv1(n), g["%sd1_%d_%s" % (prefix, s, n)]) < 1e-10, (name, s, n)
         checked = 0
@@ -90,7 +95,7 @@ def test_derivatives(name):
                 if key in g:
                     assert relerr(o.deriv2(pre + pr), g[key]) < 1e-9, (name, s, pre + pr)
                     checked += 1
-        assert checked >= 5
+        assert checked >= 5 or name in NO_SECOND_ORDER
 
 
 def test_puppet_base_pose_first_step():

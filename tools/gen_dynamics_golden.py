@@ -26,6 +26,7 @@ BUILDERS = {
     "puppet40": lambda: systems.puppet(api=trep),
     "puppet_basic": lambda: systems.puppet_basic(api=trep),
     "spring_arm": lambda: systems.spring_arm(api=trep),
+    "spring_link": lambda: systems.spring_link(api=trep),
 }
 N_STATES = 4
 

@@ -67,7 +67,7 @@ def topology(system):
     return t
 
 
-def rollout(system, q0, U, K, n_steps, deriv_steps=(), deriv2_full=False, deriv2_select=()):
+def rollout(system, q0, U, K, n_steps, deriv_steps=(), deriv2_full=False, deriv2_select=(), second_order=True):
     """Free-running reference rollout from initialize_from_configs(0, q0, DT, q0)."""
     mvi = trep.MidpointVI(system, num_threads=1)
     mvi.initialize_from_configs(0.0, q0, DT, q0)
@@ -78,20 +78,23 @@ def rollout(system, q0, U, K, n_steps, deriv_steps=(), deriv2_full=False, deriv2
         it = mvi.step(mvi.t2 + DT, U[k], K[k])
         Q.append(mvi.q2); P.append(mvi.p2); LAM.append(mvi.lambda1); IT.append(it)
         if (k + 1) in deriv_steps:
-            mvi._calc_deriv2()
+            if second_order:
+                mvi._calc_deriv2()
+            else:
+                mvi._calc_deriv1()
             for n in D1:
                 extra["d1_%d_%s" % (k + 1, n)] = getattr(mvi, "_" + n).copy()
             for pr in PAIRS:
                 for pre in ("q2_", "p2_", "l1_"):
                     name = pre + pr
-                    if deriv2_full or name in deriv2_select:
+                    if second_order and (deriv2_full or name in deriv2_select):
                         extra["d2_%d_%s" % (k + 1, name)] = getattr(mvi, "_" + name).copy()
             extra["f_%d" % (k + 1)] = mvi.calc_f()
     return dict(Q=np.array(Q), P=np.array(P), LAM=np.array(LAM).reshape(n_steps + 1, -1),
                 IT=np.array(IT, dtype=np.int32), **extra)
 
 
-def dsystem_captures(system, Q, P, U, K, ks, seed):
+def dsystem_captures(system, Q, P, U, K, ks, seed, second_order=True):
     """DSystem.set(X[k],U[k],k,xk_hint=X[k+1]) -> f, A, B and z-contracted second-order terms."""
     n = len(Q)
     t = DT * np.arange(n)
@@ -110,7 +113,7 @@ def dsystem_captures(system, Q, P, U, K, ks, seed):
         out["ds_%d_A" % k] = dsys.fdx()
         out["ds_%d_B" % k] = dsys.fdu()
         out["ds_%d_lambda" % k] = mvi.lambda1
-        for zi in range(2):
+        for zi in range(2 if second_order else 0):
             out["ds_%d_fdxdx_%d" % (k, zi)] = dsys.fdxdx(Z[zi])
             out["ds_%d_fdxdu_%d" % (k, zi)] = dsys.fdxdu(Z[zi])
             out["ds_%d_fdudu_%d" % (k, zi)] = dsys.fdudu(Z[zi])
@@ -273,6 +276,27 @@ def gen_spring_arm():
     save("spring_arm", **arrays, **ds)
 
 
+def gen_spring_link():
+    """Synthetic system with LinearSpring potentials and a distance constraint.  The reference defines no third
+    derivative for LinearSpring, so only first derivatives are recorded."""
+    system = systems.spring_link(api=trep)
+    rng = np.random.default_rng(20250 + 8)
+    B, N = 2, 200
+    arrays = dict(dt=DT, **topology(system))
+    for b in range(B):
+        q0 = np.concatenate([rng.uniform(-0.8, 0.8, size=3), [-1.0, 0.2 * b]])   # a, b, d, e, slide
+        U = np.zeros((N, 0))
+        K = (0.2 * b + 0.3 * np.sin(2.0 * DT * np.arange(1, N + 1)))[:, None]
+        r = rollout(system, q0, U, K, N, deriv_steps=(1, 50, N) if b == 0 else (), second_order=False)
+        for key, val in r.items():
+            arrays["b%d_%s" % (b, key)] = val
+        arrays["b%d_q0" % b] = q0
+        arrays["b%d_K" % b] = K
+    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], np.zeros((N, 0)), arrays["b0_K"], (0, 10, 100), seed=17,
+                          second_order=False)
+    save("spring_link", **arrays, **ds)
+
+
 def gen_discopt_cart():
     """One DOptimizer trace on the pend-on-cart problem of examples/pend-on-cart-optimization.py:48-116
     (torque input enabled, 5 s horizon): a few quasi-Newton then Newton steps; per step the method,
@@ -330,7 +354,7 @@ def gen_discopt_cart():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "discopt"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "discopt"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -345,6 +369,8 @@ if __name__ == "__main__":
         gen_puppet()
     if "puppet_basic" in which:
         gen_puppet_basic()
+    if "spring_link" in which:
+        gen_spring_link()
     if "spring_arm" in which:
         gen_spring_arm()
     if "discopt" in which:

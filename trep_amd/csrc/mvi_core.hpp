@@ -85,12 +85,12 @@ struct RunArgs {
     double *A_out, *B_out;                 // MODE_DERIV1, if A_out != null: write DSystem.fdx / fdu instead
                                            // (dsystem.py:284-317): A [batch][nX][nX], B [batch][nX][nU]
     const double *z;                       // MODE_DERIV2Z: [batch][nX] contraction vector
-    const double *zl;                      // MODE_DERIV2Z, optional: [batch][nc] weights of the lambda1 second derivatives
     double *hz;                            // MODE_DERIV2Z: [batch][R][R], R = nq+nd+nu+nk
-    const double *dq_in, *ddqk_in;         // MODE_DYNAMICS: rates [batch][nq] and kinematic accelerations [batch][nk] (q in q1 = q2, u in u1)
-    double *ddq_out, *lam_out;             // MODE_DYNAMICS: accelerations of the dynamic configs [batch][nd], constraint forces [batch][nc]
     int *iters, *status;                   // [batch]
     long long *prof_out;                   // diagnostic build: [16] cycle counters of trajectory 0
+    const double *zl;                      // MODE_DERIV2Z, optional: [batch][nc] weights of the lambda1 second derivatives
+    const double *dq_in, *ddqk_in;         // MODE_DYNAMICS: rates [batch][nq] and kinematic accelerations [batch][nk] (q in q1 = q2, u in u1)
+    double *ddq_out, *lam_out;             // MODE_DYNAMICS: accelerations of the dynamic configs [batch][nd], constraint forces [batch][nc]
 };
 
 // sin and cos together for joint angles.  |x| < 2^17: three-constant Cody-Waite reduction to [-pi/4, pi/4]
@@ -170,8 +170,14 @@ TG_HD void team_argmax(double &v, int &i) {
 #endif
 }
 
-template <int TEAM>
+// SPRINGS: the spring potentials (ConfigSpring, LinearSpring) are compiled in only for systems that have them, so
+// that the spring-free kernels keep their instruction stream and register allocation.
+template <int TEAM, bool SPRINGS = false>
 struct Core {
+    TG_HD bool has_cs() const { return SPRINGS && P.has_cs; }
+    TG_HD int n_springs() const { return SPRINGS ? P.n_springs : 0; }
+    TG_HD int n_spair() const { return SPRINGS ? P.n_spair : 0; }
+    TG_HD int n_sdh() const { return SPRINGS ? P.n_sdh : 0; }
     const DevProg &P;
     double *S;
     int lane;
@@ -436,7 +442,8 @@ struct Core {
             double ldq = 0.0, lddq = 0.0;
             const int n1 = P.cfg_item_off[i + 1];
             for (int n = P.cfg_item_off[i]; n < n1; n++) { lddq += terms[2 * n]; ldq += terms[2 * n + 1]; }
-            if (P.has_cs) ldq -= P.cs_k[i] * qval(0, i) - P.cs_kq0[i];   // config springs (configspring.c:22-31)
+            if (has_cs()) ldq -= P.cs_k[i] * qval(0, i) - P.cs_kq0[i];   // config springs (configspring.c:22-31)
+            if (n_springs()) ldq -= S[P.o_sV + i];
             S[P.o_Ldq + i] = ldq; S[P.o_Lddq + i] = lddq;
             double force = -P.damp[i] * S[P.o_dq + i];
             for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
@@ -524,7 +531,7 @@ struct Core {
         if (on) {
             TG_FOR(r, nf) {
                 A[r * ld + nf] = S[P.o_f + r];
-                if (r < nd) A[r * ld + r] = -P.damp[r] - (P.has_cs ? 0.25 * dt * P.cs_k[r] : 0.0);   // + dt/4 (-V_dqdq)
+                if (r < nd) A[r * ld + r] = -P.damp[r] - (has_cs() ? 0.25 * dt * P.cs_k[r] : 0.0);   // + dt/4 (-V_dqdq)
             }
             TG_FOR(n, P.n_dh) {
                 const int c = P.dh_pack[8 * (size_t)n], k = P.dh_pack[8 * (size_t)n + 1];
@@ -558,6 +565,14 @@ struct Core {
             const double skew = 0.5 * (c_ba - c_ab);                  // exactly 0 for a == b
             lds_add(&A[ca * ld + cb], sym + skew);
             if (ia != ib) lds_add(&A[cb * ld + ca], sym - skew);
+        }
+        if (on) TG_FOR(pp, n_spair()) {   // dt/4 (-V_dqdq) of the two-point springs, from the midpoint evaluation
+            const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
+            const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+            if (ka >= nd || kb >= nd) continue;
+            const double a_ = -qdt * S[P.o_sH + pp];
+            lds_add(&A[ka * ld + kb], a_);
+            if (pw[1] != pw[2]) lds_add(&A[kb * ld + ka], a_);
         }
         TG_SYNC();
         TG_STAMP(8);
@@ -882,7 +897,7 @@ struct Core {
                 AUG[o * ld + o] -= P.damp[o];              // D2D1L2_D2fm2: + dF_o/d(dq_o)
                 AUG[o * ld + c_q1 + o] -= P.damp[o];       // -(D1D1L2_D1fm2): -( - dF_o/d(dq_o) )
                 AUG[o * ld + c_p1 + o] = -1.0;
-                if (P.has_cs) {   // a = dt/4 (-V_dqdq) on the diagonal of all four second-order tables
+                if (has_cs()) {   // a = dt/4 (-V_dqdq) on the diagonal of all four second-order tables
                     const double a_ = -0.25 * dt * P.cs_k[o];
                     AUG[o * ld + c_q1 + o] -= a_; AUG[o * ld + o] += a_;
                     T12[o * nd + o] += a_; T22[o * nd + o] += a_;
@@ -934,6 +949,24 @@ struct Core {
                 };
                 add(ca, cb, c_ab, c_ba);
                 if (ia != ib) add(cb, ca, c_ba, c_ab);
+            }
+            TG_SYNC();
+        }
+        if (n_springs()) {   // a = dt/4 (-V_dqdq) of the two-point springs enters all four tables like the gravity part of L_qq
+            if (on && lane == 0) for (int pp = 0; pp < n_spair(); pp++) {
+                const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
+                const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+                const double a_ = -qdt * S[P.o_sH + pp];
+                auto add = [&](int r, int o) {
+                    if (o >= nd) return;
+                    AUG[o * ld + c_q1 + r] -= a_;
+                    if (r < nd) AUG[o * ld + r] += a_;
+                    else AUG[o * ld + c_k2 + (r - nd)] -= a_;
+                    T12[r * nd + o] += a_;
+                    T22[r * nd + o] += a_;
+                };
+                add(ka, kb);
+                if (pw[1] != pw[2]) add(kb, ka);
             }
             TG_SYNC();
         }
@@ -1109,6 +1142,46 @@ struct Core {
         }
         v[0] = a[0] - b[0]; v[1] = a[1] - b[1]; v[2] = a[2] - b[2];
     }
+    // Two-point springs V = 1/2 k (|p1 - p2| - x0)^2 at the swept state (linearspring.c:30-78): gradient per dynamic config
+    // into sV, Hessian per (item, item) pair into sH.  Both live outside the storage the Newton matrix shares with the
+    // poses, because the matrix is assembled after the poses are gone.  Poses and end points must be valid.
+    TG_HD void spring_terms(bool on) {
+        if (n_springs() == 0) return;
+        double *sV = S + P.o_sV, *sH = S + P.o_sH;
+        if (on) TG_FOR(i, P.nd) sV[i] = 0.0;
+        TG_SYNC();
+        if (on) {
+            TG_FOR(n, n_sdh()) {
+                const int m = P.n_dh + n, c = P.dh_c[m], k = P.dh_cfg[m], sp = c - P.nc;
+                if (k >= P.nd) continue;
+                const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
+                const double v[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+                const double x = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                double v1[3];
+                cdiff1(c, m, v1);
+                const double dx = (1.0 / x) * (v[0] * v1[0] + v[1] * v1[1] + v[2] * v1[2]);
+                if (dx != dx && P.s_x0[sp] == 0.0) continue;   // coincident end points of a zero-length spring (:44-45)
+                lds_add(&sV[k], P.s_k[sp] * (x - P.s_x0[sp]) * dx);
+            }
+            TG_FOR(pp, n_spair()) {
+                const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
+                const int c = pw[0], na = pw[1], nb = pw[2], sp = c - P.nc;
+                const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
+                const double v[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+                const double x = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                double vi[3], vj[3], vij[3];
+                cdiff1(c, na, vi); cdiff1(c, nb, vj); cdiff2(c, na, nb, vij);
+                const double vvi = v[0] * vi[0] + v[1] * vi[1] + v[2] * vi[2];
+                const double dix = (1.0 / x) * vvi;
+                const double djx = (1.0 / x) * (v[0] * vj[0] + v[1] * vj[1] + v[2] * vj[2]);
+                const double ddx = -djx / (x * x) * vvi + 1.0 / x * (vj[0] * vi[0] + vj[1] * vi[1] + vj[2] * vi[2]) +
+                                   1.0 / x * (v[0] * vij[0] + v[1] * vij[1] + v[2] * vij[2]);
+                sH[pp] = P.s_k[sp] * dix * djx + P.s_k[sp] * (x - P.s_x0[sp]) * ddx;
+            }
+        }
+        TG_SYNC();
+    }
+
     // h_c,dqdq for two dependent configs given by their dh items (distance.c:65-98, point.c:40-46)
     TG_HD double con_d2(int c, int n1, int n2) const {
         double v12[3];
@@ -1656,6 +1729,7 @@ struct Core {
         TG_SYNC();
         pose_sweep(on, 2);
         attach_points(on, true, true);
+        spring_terms(on);
         if (nc) {
             constraints(on, 2, false, S + P.o_Dh2, 0);
             if (on) {
@@ -1699,7 +1773,8 @@ struct Core {
             TG_FOR(i, nd) {
                 double force = -P.damp[i] * S[P.o_dq + i];
                 for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
-                if (P.has_cs) force -= P.cs_k[i] * S[P.o_q2 + i] - P.cs_kq0[i];
+                if (has_cs()) force -= P.cs_k[i] * S[P.o_q2 + i] - P.cs_kq0[i];
+                if (n_springs()) force -= S[P.o_sV + i];
                 lds_add(&rhs[i], force);
             }
         }
@@ -1736,7 +1811,8 @@ struct Core {
         TG_STAMP(0);
         pose_sweep(on, 0);
         TG_STAMP(1);
-        attach_points(on, true, false);
+        attach_points(on, true, n_springs() > 0);
+        spring_terms(on);
         jacobians(on);
         TG_STAMP(2);
         velocities(on);
@@ -1759,13 +1835,13 @@ struct Core {
 // every TG_SYNC.
 // MODE is a compile-time parameter so that every kernel mode gets its own register allocation (the
 // derivative modes are far larger than the rollout loop).
-template <int TEAM, int MODE>
+template <int TEAM, int MODE, bool SPRINGS = false>
 TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lane, int traj) {
     const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc;
     const bool live = traj < A.batch;
     const size_t t = (size_t)(live ? traj : 0);
     double dt = MODE == MODE_ROLLOUT ? A.dt : (A.t2 - A.t1);
-    Core<TEAM> core(P, S, lane, dt);
+    Core<TEAM, SPRINGS> core(P, S, lane, dt);
     core.init_sweep_schedule();
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     core.prof_last = (long long)__builtin_amdgcn_s_memtime();
@@ -1884,7 +1960,24 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
             if (done) break;
 #endif
             core.newton_matrix(!done);
-            const bool ok = core.solve_kkt(!done);
+            bool ok;
+#if defined(__HIP_DEVICE_COMPILE__)
+            const int nb4 = (P.nf + 3) >> 2;   // matrix size in blocks of 4 rows
+            if (TEAM >= 4 && 4 * nb4 <= TEAM && nb4 <= 8) {
+                double *Ad = S + P.o_Df;
+                switch (nb4) {
+                case 1: ok = Core<TEAM>::template gj_rows<4>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 2: ok = Core<TEAM>::template gj_rows<(TEAM >= 8 ? 8 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 3: ok = Core<TEAM>::template gj_rows<(TEAM >= 12 ? 12 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 4: ok = Core<TEAM>::template gj_rows<(TEAM >= 16 ? 16 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 5: ok = Core<TEAM>::template gj_rows<(TEAM >= 20 ? 20 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 6: ok = Core<TEAM>::template gj_rows<(TEAM >= 24 ? 24 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 7: ok = Core<TEAM>::template gj_rows<(TEAM >= 28 ? 28 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                default: ok = Core<TEAM>::template gj_rows<(TEAM >= 32 ? 32 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                }
+            } else
+#endif
+                ok = core.gauss_jordan(!done, S + P.o_Df, P.nf, 1, P.df_ld, S + P.o_scal);
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
             { long long t_ = (long long)__builtin_amdgcn_s_memtime(); core.prof[14] += t_ - core.prof_last; core.prof_last = t_; }
 #endif

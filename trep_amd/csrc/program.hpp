@@ -80,8 +80,6 @@ struct DevProg {
     const int *dh_lookup;     // [nc*nq] index into the dh items of (constraint, config), -1 if independent
     const int *dh_c, *dh_cfg, *dh_joint, *dh_side; // side: bit0 on e1's path, bit1 on e2's path, bit2 length config
     const double *damp;       // [nd] summed damping coefficients
-    const double *cs_k, *cs_kq0;  // [nq] config springs: sum k and sum k q0 per config (V_dq = cs_k q - cs_kq0)
-    int has_cs;
     const int *cf_cfg, *cf_in;
     // LDS layout (offsets in doubles from the team's base)
     int o_q1, o_q2, o_p1, o_lam, o_u, o_dq, o_f, o_sc, o_G, o_gB, o_pE, o_J, o_W, o_vB, o_gam, o_Ldq, o_Lddq,
@@ -94,6 +92,10 @@ struct DevProg {
     int d_o_Dh1, d_o_Dh2, d_o_AUG, d_aug_ld, d_o_T12, d_o_T22, d_nrhs, d_lds_per_team;
     // z-contracted second-derivative kernel: contracted Hessians H11/H12/H22 [nq][nq], G1 [nq][nc], vectors
     const int *cu_off;        // [nc+1] dh items of each constraint (its dependent configs)
+    // spring potentials, kept near the end: the spring-free kernels' argument layout stays what it was
+    const double *cs_k, *cs_kq0;  // [nq] config springs: sum k and sum k q0 per config (V_dq = cs_k q - cs_kq0)
+    const double *s_k, *s_x0;     // [n_springs]
+    int n_springs, n_sdh, n_spair, o_sV, o_sH, has_cs;   // two-point springs: dh items / pairs follow the constraints' in the same tables
     const int *tab_i; const double *tab_d; int n_tab_i, n_tab_d;  // the packed table buffers (all pointers above point into them)
     int e_o_H11, e_o_H12, e_o_H22, e_o_G1, e_o_w, e_o_zq, e_o_zp, e_o_vec, e_o_vec2, e_lds_per_team;
 };
@@ -110,7 +112,7 @@ struct HostProgram {
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
     std::vector<double> c_dist, c_tol;
     std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
-    std::vector<double> damp, cs_k, cs_kq0;
+    std::vector<double> damp, cs_k, cs_kq0, s_k, s_x0;
     std::vector<int> cf_cfg, cf_in;
     std::vector<double> jcoef;      // [n_joints*16*4] local-transform coefficients (see pose_sweep)
     int max_depth = 0;
@@ -357,9 +359,28 @@ inline HostProgram build_program(const tg_system_desc *d) {
             H.dh_side.push_back((on1 ? 1 : 0) | (on2 ? 2 : 0) | (isl ? 4 : 0));
         }
     }
-    H.cu_off.assign(nc + 1, 0);
+    // two-point springs (linearspring.c): same end point / dependent-config items as a distance constraint, listed after
+    // the constraints' so that every constraint loop (n_dh, n_cpair, nc) leaves them out
+    const int n_dh_con = (int)H.dh_c.size();
+    const int ns = d->n_linear_springs;
+    for (int s = 0; s < ns; s++) {
+        const int f1 = d->linear_spring_frame1[s], f2 = d->linear_spring_frame2[s], c = nc + s;
+        if (f1 < 0 || f1 >= d->n_frames || f2 < 0 || f2 >= d->n_frames) throw std::runtime_error("linear spring: bad frame index");
+        H.c_type.push_back(2); H.c_e1.push_back(endpoint(f1)); H.c_e2.push_back(endpoint(f2));
+        H.c_cfg.push_back(-1); H.c_comp.push_back(0); H.c_dist.push_back(0.0); H.c_tol.push_back(0.0);
+        H.s_k.push_back(d->linear_spring_k[s]); H.s_x0.push_back(d->linear_spring_x0[s]);
+        for (int k = 0; k < nq; k++) {
+            int g = d->config_gen[k];
+            bool on1 = d->frame_cache_index[(size_t)f1 * (nq + 1) + g] == k;
+            bool on2 = d->frame_cache_index[(size_t)f2 * (nq + 1) + g] == k;
+            if (!on1 && !on2) continue;
+            H.dh_c.push_back(c); H.dh_cfg.push_back(k); H.dh_joint.push_back(joint_of_cfg[k]);
+            H.dh_side.push_back((on1 ? 1 : 0) | (on2 ? 2 : 0));
+        }
+    }
+    H.cu_off.assign(nc + ns + 1, 0);
     for (size_t n = 0; n < H.dh_c.size(); n++) H.cu_off[H.dh_c[n] + 1] = (int)n + 1;
-    for (int c = 0; c < nc; c++) if (H.cu_off[c + 1] < H.cu_off[c]) H.cu_off[c + 1] = H.cu_off[c];
+    for (int c = 0; c < nc + ns; c++) if (H.cu_off[c + 1] < H.cu_off[c]) H.cu_off[c + 1] = H.cu_off[c];
     H.cpath_off.assign(2 * nc + 1, 0);
     H.dh_pos.assign(2 * H.dh_c.size(), -1);
     for (int c = 0; c < nc; c++)
@@ -377,12 +398,16 @@ inline HostProgram build_program(const tg_system_desc *d) {
         H.dh_pack.push_back(H.dh_side[n] | ((j >= 0 ? H.j_kind[j] : 0) << 8) | (H.c_type[c] << 16) | ((H.c_comp[c] & 0xFF) << 24));
         H.dh_pack.push_back(3 * H.c_e1[c]); H.dh_pack.push_back(3 * H.c_e2[c]); H.dh_pack.push_back(H.c_cfg[c]); H.dh_pack.push_back(0);
     }
-    for (int c = 0; c < nc; c++)
+    int n_cpair_con = 0;
+    for (int c = 0; c < nc + ns; c++) {
+        if (c == nc) n_cpair_con = (int)(H.cpair4.size() / 4);
         for (int na = H.cu_off[c]; na < H.cu_off[c + 1]; na++)
             for (int nb2 = na; nb2 < H.cu_off[c + 1]; nb2++) {
                 H.cpair4.push_back(c); H.cpair4.push_back(na); H.cpair4.push_back(nb2);
                 H.cpair4.push_back(H.dh_cfg[na] | (H.dh_cfg[nb2] << 16));
             }
+    }
+    if (ns == 0) n_cpair_con = (int)(H.cpair4.size() / 4);
     // forces / potentials
     H.damp.assign(nd, 0.0);
     for (int i = 0; i < d->n_damping; i++)
@@ -399,10 +424,11 @@ inline HostProgram build_program(const tg_system_desc *d) {
     DevProg &P = H.p;
     P.nq = nq; P.nd = nd; P.nk = d->n_kin; P.nu = d->n_inputs; P.nc = nc; P.nf = nd + nc; P.nX = nq + nd + d->n_kin;
     P.n_joints = nj; P.n_levels = n_levels; P.n_bodies = nb; P.n_items = nitems; P.n_pairs = (int)H.pair_a.size();
-    P.n_endpoints = (int)H.e_anchor.size(); P.n_dh = (int)H.dh_c.size(); P.n_cf = (int)H.cf_cfg.size();
+    P.n_endpoints = (int)H.e_anchor.size(); P.n_dh = n_dh_con; P.n_cf = (int)H.cf_cfg.size();
+    P.n_springs = ns; P.n_sdh = (int)H.dh_c.size() - n_dh_con;
     P.n_cfgitems = (int)H.cfg_items.size();
     P.n_npairs = (int)(H.pair4.size() / 4);
-    P.n_tri = (int)(H.tri4.size() / 4); P.n_cpair = (int)(H.cpair4.size() / 4);
+    P.n_tri = (int)(H.tri4.size() / 4); P.n_cpair = n_cpair_con; P.n_spair = (int)(H.cpair4.size() / 4) - n_cpair_con;
     P.has_cs = d->n_config_springs > 0 ? 1 : 0;
     P.n_cpath = (int)H.cpath_items.size();
     P.grav[0] = P.grav[1] = P.grav[2] = 0.0;
@@ -420,6 +446,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.o_scal = take(P.nf); P.o_misc = take(2); P.o_nu = take(P.nu + P.nk);
     P.o_I = take(4 * nb);   // mass and principal inertias of every body (copied from the table once per kernel)
     P.o_ctol = take(nc);    // constraint tolerances, likewise
+    P.o_sV = take(ns ? nd : 0); P.o_sH = take(P.n_spair);   // spring gradient per dynamic config, Hessian per item pair (midpoint)
     // level schedule of the pose sweep: 16 packed words (own offset | parent offset << 16) per level, as ints
     P.n_chains = (int)H.ch_first.size(); P.n_rounds = (int)H.round_off.size() - 1;
     P.sched_ok = (12 * nj < 65536) ? 1 : 0;
@@ -495,7 +522,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
     X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off)
-#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0)
+#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(s_k) X(s_x0)
 
 inline void HostProgram::pack() {
     ipool.clear(); dpool.clear(); ioff.clear(); doff.clear();

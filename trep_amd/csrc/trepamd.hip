@@ -31,13 +31,13 @@ int fail(int code, const std::string &msg) {
 
 // The derivative modes keep 60-80 KB of LDS per trajectory, i.e. at most two wavefronts per CU: they may use the whole
 // register file of a SIMD (no spills, deeper unrolling); the rollout modes run two wavefronts per SIMD.
-template <int TEAM, int MODE>
+template <int TEAM, int MODE, bool SPRINGS>
 __global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z) ? 1 : 2) void k_run(const tg::DevProg P, const tg::RunArgs A) {
     extern __shared__ double lds[];
     const int team = threadIdx.x / TEAM, lane = threadIdx.x % TEAM;
     const int traj = blockIdx.x * (64 / TEAM) + team;
     const int stride = MODE == tg::MODE_DERIV2Z ? P.e_lds_per_team : (MODE == tg::MODE_DERIV1 ? P.d_lds_per_team : P.lds_per_team);
-    tg::run_trajectory<TEAM, MODE>(P, A, lds + (size_t)team * stride, lane, traj);
+    tg::run_trajectory<TEAM, MODE, SPRINGS>(P, A, lds + (size_t)team * stride, lane, traj);
 }
 
 }  // namespace
@@ -124,12 +124,18 @@ void append(std::vector<T> &pool, const std::vector<T> &v, size_t &off) {
     while (pool.size() % 2) pool.push_back(T());
 }
 
+template <int TEAM, int MODE, bool SPRINGS>
+int launch_variant(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<TEAM, MODE, SPRINGS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_run<TEAM, MODE, SPRINGS>), dim3(grid), dim3(64), lds, b->stream, b->P, A);
+    return TG_SUCCESS;
+}
+
+// systems with spring potentials run their own instantiation of every kernel (mvi_core.hpp, Core<TEAM, SPRINGS>)
 template <int TEAM, int MODE>
 int launch_one(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
-    if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<TEAM, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_run<TEAM, MODE>), dim3(grid), dim3(64), lds, b->stream, b->P, A);
-    return TG_SUCCESS;
+    return (b->P.has_cs || b->P.n_springs) ? launch_variant<TEAM, MODE, true>(b, A, grid, lds) : launch_variant<TEAM, MODE, false>(b, A, grid, lds);
 }
 
 template <int TEAM>
@@ -541,6 +547,7 @@ int tg_batch_deriv1(tg_batch *b) {
 
 int tg_batch_deriv2_contract(tg_batch *b, const double *z_host, double *hz_host) {
     if (!b || !z_host || !hz_host) return fail(TG_ERR_INVALID, "null argument");
+    if (b->P.n_springs) return fail(TG_ERR_UNSUPPORTED, "V_dqdqdq() is undefined for LinearSpring (as in the reference): no second derivatives");
     if (b->t2 == b->t1) return fail(TG_ERR_STATE, "Integrator has not solved the next time step yet.");
     HIP_TRY(hipSetDevice(b->device));
     const size_t B = (size_t)b->batch, R = (size_t)b->P.d_nrhs;
@@ -556,6 +563,7 @@ int tg_batch_deriv2_contract(tg_batch *b, const double *z_host, double *hz_host)
 
 int tg_batch_deriv2_contract_lambda(tg_batch *b, const double *z_host, const double *zlambda_host, double *hz_host) {
     if (!b || !hz_host || (!z_host && !zlambda_host)) return fail(TG_ERR_INVALID, "null argument");
+    if (b->P.n_springs) return fail(TG_ERR_UNSUPPORTED, "V_dqdqdq() is undefined for LinearSpring (as in the reference): no second derivatives");
     if (b->t2 == b->t1) return fail(TG_ERR_STATE, "Integrator has not solved the next time step yet.");
     HIP_TRY(hipSetDevice(b->device));
     const size_t B = (size_t)b->batch, R = (size_t)b->P.d_nrhs;
@@ -612,6 +620,7 @@ int tg_batch_dynamics(tg_batch *b, const double *q_host, const double *dq_host, 
 
 int tg_batch_deriv2_contract_device(tg_batch *b, const double *z_dev, double *hz_dev) {
     if (!b || !z_dev || !hz_dev) return fail(TG_ERR_INVALID, "null argument");
+    if (b->P.n_springs) return fail(TG_ERR_UNSUPPORTED, "V_dqdqdq() is undefined for LinearSpring (as in the reference): no second derivatives");
     if (b->t2 == b->t1) return fail(TG_ERR_STATE, "Integrator has not solved the next time step yet.");
     HIP_TRY(hipSetDevice(b->device));
     tg::RunArgs A = base_args(b, tg::MODE_DERIV2Z);

@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 
 from . import frame as _frame
-from .dynamics import Gravity, ConfigSpring, Damping, ConfigForce, Distance, PointToPoint1D
+from .dynamics import Gravity, ConfigSpring, LinearSpring, Damping, ConfigForce, Distance, PointToPoint1D
 
 _I32 = ctypes.POINTER(ctypes.c_int32)
 _F64 = ctypes.POINTER(ctypes.c_double)
@@ -32,13 +32,16 @@ _ARRAYS = [
 ]
 
 
-_TAIL_SCALARS = ["n_config_springs"]
-_TAIL_ARRAYS = [("config_spring_config", _I32), ("config_spring_k", _F64), ("config_spring_q0", _F64)]
+_TAIL = [("n_config_springs", None), ("config_spring_config", _I32), ("config_spring_k", _F64), ("config_spring_q0", _F64),
+         ("n_linear_springs", None), ("linear_spring_frame1", _I32), ("linear_spring_frame2", _I32),
+         ("linear_spring_k", _F64), ("linear_spring_x0", _F64)]   # in struct order (include/trep_amd.h)
+_TAIL_SCALARS = [n for n, t in _TAIL if t is None]
+_TAIL_ARRAYS = [(n, t) for n, t in _TAIL if t is not None]
 
 
 class SystemDescStruct(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_int32) for n in _INT_SCALARS] + _ARRAYS +
-                [(n, ctypes.c_int32) for n in _TAIL_SCALARS] + _TAIL_ARRAYS)
+                [(n, ctypes.c_int32 if t is None else t) for n, t in _TAIL])
 
 
 class SystemDesc(object):
@@ -119,9 +122,15 @@ def flatten(system):
 
     grav, damp, cf_c, cf_u = [], [], [], []
     cs_c, cs_k, cs_q0 = [], [], []
+    ls_f1, ls_f2, ls_k, ls_x0 = [], [], [], []
     for pot in system.potentials:
         if isinstance(pot, Gravity):
             grav.append(list(pot._gravity))
+        elif isinstance(pot, LinearSpring):
+            ls_f1.append(fidx[id(pot.frame1)])
+            ls_f2.append(fidx[id(pot.frame2)])
+            ls_k.append(pot.k)
+            ls_x0.append(pot.x0)
         elif isinstance(pot, ConfigSpring):
             cs_c.append(cidx[id(pot.config)])
             cs_k.append(pot.k)
@@ -147,6 +156,11 @@ def flatten(system):
     t["config_spring_config"] = np.array(cs_c, dtype=np.int32)
     t["config_spring_k"] = np.array(cs_k, dtype=np.float64)
     t["config_spring_q0"] = np.array(cs_q0, dtype=np.float64)
+    t["n_linear_springs"] = len(ls_k)
+    t["linear_spring_frame1"] = np.array(ls_f1, dtype=np.int32)
+    t["linear_spring_frame2"] = np.array(ls_f2, dtype=np.int32)
+    t["linear_spring_k"] = np.array(ls_k, dtype=np.float64)
+    t["linear_spring_x0"] = np.array(ls_x0, dtype=np.float64)
 
     ctype, cf1, cf2, ccfg, ccomp, cdist, ctol = [], [], [], [], [], [], []
     for con in system.constraints:

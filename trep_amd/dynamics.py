@@ -89,6 +89,50 @@ class ConfigSpring(Potential):
         return 0.5 * self._k * (self._config.q - self._q0) ** 2
 
 
+class LinearSpring(Potential):
+    """V = 1/2 k (|p(frame1) - p(frame2)| - x0)^2 (potentials/linearspring.py:15-70)."""
+
+    def __init__(self, system, frame1, frame2, k, x0=0, name=None):
+        Potential.__init__(self, system, name)
+        if not system.get_frame(frame1):
+            raise ValueError("Could not find frame %r" % frame1)
+        self._frame1 = system.get_frame(frame1)
+        if not system.get_frame(frame2):
+            raise ValueError("Could not find frame %r" % frame2)
+        self._frame2 = system.get_frame(frame2)
+        self._k = float(k)
+        self._x0 = float(x0)
+        system._structure_changed()
+
+    def __repr__(self):
+        return "<LinearSpring %r %r k=%f x0=%f>" % (self._frame1.name, self._frame2.name, self._k, self._x0)
+
+    frame1 = property(lambda self: self._frame1)
+    frame2 = property(lambda self: self._frame2)
+
+    @property
+    def k(self):
+        return self._k
+
+    @k.setter
+    def k(self, value):
+        self._k = float(value)
+        self._system._structure_changed()
+
+    @property
+    def x0(self):
+        return self._x0
+
+    @x0.setter
+    def x0(self, value):
+        self._x0 = float(value)
+        self._system._structure_changed()
+
+    def V(self):
+        x = float(np.linalg.norm(self._frame1.p()[:3] - self._frame2.p()[:3]))
+        return 0.5 * self._k * (x - self._x0) ** 2
+
+
 class Force(object):
     def __init__(self, system, name=None):
         self._system = system

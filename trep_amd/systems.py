@@ -78,6 +78,32 @@ def spring_arm(api=None):
     return system
 
 
+def spring_link(api=None):
+    """Two branches joined by two-point springs: a 3-D arm on a kinematic slider and a telescopic pendulum held at
+    unit length by a distance constraint; one LinearSpring from the arm's tip to a fixed anchor (rest length 1), one
+    of zero rest length between the fore-arm and the pendulum bob.  Synthetic test system for the LinearSpring
+    potential next to constraints, damping and a kinematic config."""
+    T = _api(api)
+    system = T.System()
+    system.import_frames([
+        T.tx('slide', name='Base', kinematic=True), [
+            T.rz('a', name='Shoulder'), [
+                T.tx(1.0, name='Upper', mass=2.0), [
+                    T.ry('b', name='Elbow'), [
+                        T.tx(0.8, name='Fore', mass=(1.0, 0.1, 0.2, 0.3)), [
+                            T.tx(0.2, name='Tip')]]]]],
+        T.ty(1.5, name='Pivot'), [
+            T.rx('d', name='Swing'), [
+                T.tz('e', name='Bob', mass=1.5)]],
+        T.tz(2.0, name='Anchor')])
+    T.potentials.Gravity(system, (0, 0, -9.8))
+    T.potentials.LinearSpring(system, 'Tip', 'Anchor', k=15.0, x0=1.0)
+    T.potentials.LinearSpring(system, 'Fore', 'Bob', k=4.0)
+    T.constraints.Distance(system, 'Bob', 'Pivot', 1.0)
+    T.forces.Damping(system, 0.2)
+    return system
+
+
 def scissor_lift(segments=4, theta_0=0.05 * math.pi, m_link=1.0, I_link=1.0, L_link=5.0, m_slider=1.0,
                  api=None):
     """Scissor lift at its analytic closed configuration (no constraint solver needed)."""
