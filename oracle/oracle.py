@@ -44,6 +44,7 @@ def lib():
         L.to_rollout.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
                                  ctypes.c_void_p, ctypes.c_int]
         L.to_dynamics.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6
+        L.to_dynamics_deriv1.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 12
         _LIB = L
     return _LIB
 
@@ -189,6 +190,28 @@ class OracleMVI(object):
                                f.ctypes.data, lam.ctypes.data):
             raise OracleError("singular")
         return f[:self.nd], lam[:self.nc]
+
+    def dynamics_deriv1(self, q, dq, u=None, ddqk=None):
+        """First derivatives of the continuous dynamics (system.c:912-1299) in the layout of the reference's accessors
+        System.f_dq() ... lambda_du(): dict of [output][derivative variable] arrays."""
+        q = np.ascontiguousarray(q, dtype=float)
+        dq = np.ascontiguousarray(dq, dtype=float)
+        u = np.zeros(max(self.nu, 1)) if u is None else np.ascontiguousarray(np.append(u, 0.0), dtype=float)
+        ddqk = np.zeros(max(self.nk, 1)) if ddqk is None else np.ascontiguousarray(np.append(ddqk, 0.0), dtype=float)
+        rows = {"dq": self.nq, "ddq": self.nq, "dk": self.nk, "du": self.nu}
+        arrs = {}
+        for pre, width in (("f", self.nd), ("l", self.nc)):
+            for var in ("dq", "ddq", "dk", "du"):
+                arrs[pre + "_" + var] = np.zeros((rows[var], width)) if rows[var] * width else np.zeros((max(rows[var], 1), max(width, 1)))
+        order = ["f_dq", "f_ddq", "f_dk", "f_du", "l_dq", "l_ddq", "l_dk", "l_du"]
+        if self._L.to_dynamics_deriv1(self._h, q.ctypes.data, dq.ctypes.data, u.ctypes.data, ddqk.ctypes.data,
+                                      *[arrs[n].ctypes.data for n in order]):
+            raise OracleError("singular")
+        out = {}
+        for pre, width, name in (("f", self.nd, "f"), ("l", self.nc, "lam")):
+            for var, key in (("dq", "dq"), ("ddq", "ddq"), ("dk", "dddk"), ("du", "du")):
+                out["%s_%s" % (name, key)] = arrs[pre + "_" + var][:rows[var], :width].T.copy()
+        return out
 
     def rollout(self, n_steps, dt, U=None, K=None, want_X=True, max_iterations=200):
         nX = self.nq + self.nd + self.nk

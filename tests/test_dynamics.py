@@ -74,3 +74,18 @@ def test_gpu_dynamics_match_reference_and_oracle(name):
     for b in range(0, B, 16):
         f_o, lam_o = o.dynamics(Q[b], dQ[b], U[b], ddK[b])
         assert relerr(ddq[b], f_o) < 1e-9 and relerr(lam[b], lam_o) < 1e-9, (name, b)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_dynamics_first_derivatives_match_reference(name):
+    """to_dynamics_deriv1 (restating calc_dynamics_deriv1, system.c:912-1299) against System.f_dq() ... lambda_du()."""
+    from oracle.oracle import OracleMVI
+    g = golden()
+    _, d = build(name)
+    o = OracleMVI(d)
+    for s in range(len(g[name + "_q"])):
+        got = o.dynamics_deriv1(g[name + "_q"][s], g[name + "_dq"][s], g[name + "_u"][s], g[name + "_ddqk"][s])
+        for key in ("f_dq", "f_ddq", "f_dddk", "f_du", "lam_dq", "lam_ddq", "lam_dddk", "lam_du"):
+            ref = g["%s_%s" % (name, key)][s]
+            assert got[key].shape == ref.shape, (name, key, got[key].shape, ref.shape)
+            assert relerr(got[key], ref) < 1e-9, (name, s, key)
