@@ -18,11 +18,11 @@ def mean_counter(path, kernel_substr):
     return sum(vals) / len(vals), len(vals)
 
 
-fetch_kb, nf = mean_counter(src + "/pmc_fetch.csv", "k_run<64, 0>")
-write_kb, nw = mean_counter(src + "/pmc_write.csv", "k_run<64, 0>")
+fetch_kb, nf = mean_counter(src + "/pmc_fetch.csv", "k_run<64, 0")
+write_kb, nw = mean_counter(src + "/pmc_write.csv", "k_run<64, 0")
 bench = json.load(open(src + "/bench.json"))
 out = {
-    "kernel": "k_run<64, 0> (rollout)",
+    "kernel": "k_run<64, 0, false> (rollout)",
     "workload": bench["config"]["workload"],
     "global_batch": bench["config"]["global_batch"], "rollout_steps": bench["config"]["rollout_steps"],
     "FETCH_SIZE_kB_raw": fetch_kb, "WRITE_SIZE_kB": write_kb, "dispatches_averaged": [nf, nw],
