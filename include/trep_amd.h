@@ -242,6 +242,17 @@ int tg_batch_dynamics(tg_batch *b, const double *q_host, const double *dq_host, 
                       const double *ddqk_host, double *ddq_host, double *lambda_host, int32_t *status_host);
 int tg_batch_dynamics_device(tg_batch *b, const double *q_dev, const double *dq_dev, const double *u_dev,
                              const double *ddqk_dev, double *ddq_dev, double *lambda_dev, int32_t *status_dev);
+/* First derivatives of the same map: calc_dynamics_deriv1 (system.c:912-1299) behind System.f_dq(), f_ddq(), f_dddk(),
+ * f_du(), lambda_dq(), lambda_ddq(), lambda_dddk(), lambda_du() (system.py:961-980, 1026-1044).  Arrays are laid out
+ * like the reference's internal ones, derivative variable first: f_dq, f_ddq [B][nq][nd]; f_dddk [B][nk][nd];
+ * f_du [B][nu][nd]; lambda_* the same with nc outputs.  Any output may be NULL (not wanted).  The _device variant takes
+ * the eight device pointers in that order. */
+int tg_batch_dynamics_deriv1(tg_batch *b, const double *q_host, const double *dq_host, const double *u_host,
+                             const double *ddqk_host, double *f_dq, double *f_ddq, double *f_dddk, double *f_du,
+                             double *lambda_dq, double *lambda_ddq, double *lambda_dddk, double *lambda_du,
+                             int32_t *status_host);
+int tg_batch_dynamics_deriv1_device(tg_batch *b, const double *q_dev, const double *dq_dev, const double *u_dev,
+                                    const double *ddqk_dev, double *const out_dev[8], int32_t *status_dev);
 
 /* DSystem.set(X[s][k], U[s][k], k, xk_hint = X[s][k+1]) for every (s, k) at once (reference
  * trep/discopt/dsystem.py:229-251 as used by linearize_trajectory, :406-423, and calc_newton_model,

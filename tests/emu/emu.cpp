@@ -40,7 +40,7 @@ int emu_lds_doubles(void *h) { return ((Emu *)h)->P.lds_per_team; }
 // Runs every trajectory of the batch through the kernel body, one after the other.
 void emu_run(void *h, const tg::RunArgs *args) {
     Emu *e = (Emu *)h;
-    std::vector<double> lds((size_t)std::max(std::max(e->P.lds_per_team, e->P.d_lds_per_team), e->P.e_lds_per_team));
+    std::vector<double> lds((size_t)std::max(std::max(std::max(e->P.lds_per_team, e->P.d_lds_per_team), e->P.e_lds_per_team), e->P.g_lds_per_team));
     for (int t = 0; t < args->batch; t++) {
         std::fill(lds.begin(), lds.end(), 0.0);
         switch (args->mode) {
@@ -49,6 +49,7 @@ void emu_run(void *h, const tg::RunArgs *args) {
         case tg::MODE_CALC_F: tg::run_trajectory<1, tg::MODE_CALC_F, true>(e->P, *args, lds.data(), 0, t); break;
         case tg::MODE_DERIV1: tg::run_trajectory<1, tg::MODE_DERIV1, true>(e->P, *args, lds.data(), 0, t); break;
         case tg::MODE_DYNAMICS: tg::run_trajectory<1, tg::MODE_DYNAMICS, true>(e->P, *args, lds.data(), 0, t); break;
+        case tg::MODE_DYN_DERIV1: tg::run_trajectory<1, tg::MODE_DYN_DERIV1, true>(e->P, *args, lds.data(), 0, t); break;
         default: tg::run_trajectory<1, tg::MODE_DERIV2Z, true>(e->P, *args, lds.data(), 0, t); break;
         }
     }

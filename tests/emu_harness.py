@@ -22,7 +22,7 @@ class RunArgs(ctypes.Structure):
                 ("q1", _D), ("q2", _D), ("p1", _D), ("p2", _D), ("lam", _D), ("u1", _D),
                 ("U", _D), ("K", _D), ("q2_hint", _D), ("lam_hint", _D), ("Kproj", _D), ("bX", _D), ("bU", _D), ("Uout", _D), ("group_size", ctypes.c_int), ("group_map", _I), ("X", _D), ("f_out", _D),
                 ("d1", _D * 12), ("A_out", _D), ("B_out", _D), ("z", _D), ("hz", _D), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p),
-                ("zl", _D), ("dq_in", _D), ("ddqk_in", _D), ("ddq_out", _D), ("lam_out", _D)]
+                ("zl", _D), ("dq_in", _D), ("ddqk_in", _D), ("ddq_out", _D), ("lam_out", _D), ("g1", _D * 8)]
 
 
 def lib():
@@ -145,6 +145,28 @@ class EmuBatch(object):
         a.dq_in, a.ddqk_in, a.ddq_out, a.lam_out = _p(dQ), _p(ddK), _p(ddq), _p(lam)
         self.L.emu_run(self.h, ctypes.byref(a))
         return ddq, lam, self.status.copy()
+
+    def dynamics_deriv1(self, Q, dQ, U=None, ddK=None):
+        """First derivatives of the continuous dynamics, in the layout of the reference's accessors
+        (System.f_dq() ...): dict of [B][output][derivative variable] arrays."""
+        Q = np.ascontiguousarray(Q, dtype=float)
+        dQ = np.ascontiguousarray(dQ, dtype=float)
+        U = np.zeros((self.B, self.nu)) if U is None else np.ascontiguousarray(U, dtype=float)
+        ddK = np.zeros((self.B, self.nk)) if ddK is None else np.ascontiguousarray(ddK, dtype=float)
+        rows = [self.nq, self.nq, self.nk, self.nu]
+        names = ["dq", "ddq", "dddk", "du"]
+        a = self._args(6)
+        a.q1 = a.q2 = _p(Q)
+        a.u1 = _p(U)
+        a.dq_in, a.ddqk_in = _p(dQ), _p(ddK)
+        arrs = {}
+        for g in range(8):
+            width = self.nd if g < 4 else self.nc
+            arr = np.zeros((self.B, rows[g & 3], width))
+            arrs[("f_" if g < 4 else "lam_") + names[g & 3]] = arr
+            a.g1[g] = arr.ctypes.data_as(_D) if arr.size else ctypes.cast(0, _D)
+        self.L.emu_run(self.h, ctypes.byref(a))
+        return dict((k, np.swapaxes(v, 1, 2)) for k, v in arrs.items()), self.status.copy()
 
     def deriv2z(self, Z, ZL=None):
         """HZ [B][R][R]: second derivatives of the step map contracted with z = Z[b] (nX) and, optionally, of

@@ -44,6 +44,11 @@ def main():
     rng = np.random.default_rng(1)
     dQ, ddQ = pool.upload(Q0), pool.upload(rng.standard_normal((B, mvi.nq)))       # continuous dynamics inputs
     ddK, dACC, dLAM = pool.upload(rng.standard_normal((B, mvi.nk))), pool.empty((B, mvi.nd)), pool.empty((B, mvi.nc))
+    import ctypes
+    rows = (mvi.nq, mvi.nq, mvi.nk, mvi.nu)
+    g1_bufs = [pool.empty((B, max(rows[g & 3], 1), mvi.nd if g < 4 else mvi.nc)) for g in range(8)]
+    g1 = (ctypes.c_void_p * 8)(*[buf.ptr if rows[g & 3] else None for g, buf in enumerate(g1_bufs)])
+    n_g1 = sum(rows[g & 3] * (mvi.nd if g < 4 else mvi.nc) for g in range(8))
     for rep in range(args.reps + 1):
         mvi.timing()
         _lib.check(L.tg_batch_set_from_trajectories(mvi._h, B, 1, 0.0, dt, dX.ptr, dU.ptr, 200))
@@ -54,13 +59,16 @@ def main():
         n, ms_d2 = mvi.timing()
         _lib.check(L.tg_batch_dynamics_device(mvi._h, dQ.ptr, ddQ.ptr, None, ddK.ptr, dACC.ptr, dLAM.ptr, None))
         n, ms_dyn = mvi.timing()
+        _lib.check(L.tg_batch_dynamics_deriv1_device(mvi._h, dQ.ptr, ddQ.ptr, None, ddK.ptr, g1, None))
+        n, ms_dyn1 = mvi.timing()
         if rep:   # first pass = warm-up
-            for k, v in (("step", ms_step), ("deriv1_AB", ms_d1), ("deriv2z", ms_d2), ("dynamics", ms_dyn)):
+            for k, v in (("step", ms_step), ("deriv1_AB", ms_d1), ("deriv2z", ms_d2), ("dynamics", ms_dyn), ("dynamics_deriv1", ms_dyn1)):
                 res.setdefault(k, []).append(v)
     iters, status = mvi.status()
     assert (status == 0).all()
     bytes_per = {"step": 8 * (2 * nX + nU + mvi.nc), "deriv1_AB": 8 * (nX * nX + nX * nU), "deriv2z": 8 * (nX + R * R),
-                 "dynamics": 8 * (2 * mvi.nq + mvi.nu + mvi.nk + mvi.nd + mvi.nc)}
+                 "dynamics": 8 * (2 * mvi.nq + mvi.nu + mvi.nk + mvi.nd + mvi.nc),
+                 "dynamics_deriv1": 8 * (2 * mvi.nq + mvi.nu + mvi.nk + n_g1)}
     for k, v in res.items():
         ms = float(np.mean(v))
         out[k] = {"kernel_ms": ms, "per_s": B / ms * 1e3, "algorithmic_bytes_per_unit": bytes_per[k],

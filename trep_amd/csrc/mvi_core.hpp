@@ -64,7 +64,7 @@ extern "C" __device__ __attribute__((const)) unsigned int __ockl_wfred_max_u32(u
 
 namespace tg {
 
-enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3, MODE_DERIV2Z = 4, MODE_DYNAMICS = 5 };
+enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3, MODE_DERIV2Z = 4, MODE_DYNAMICS = 5, MODE_DYN_DERIV1 = 6 };
 
 struct RunArgs {
     int batch, n_steps, max_iterations, mode, first_is_init;
@@ -91,6 +91,8 @@ struct RunArgs {
     const double *zl;                      // MODE_DERIV2Z, optional: [batch][nc] weights of the lambda1 second derivatives
     const double *dq_in, *ddqk_in;         // MODE_DYNAMICS: rates [batch][nq] and kinematic accelerations [batch][nk] (q in q1 = q2, u in u1)
     double *ddq_out, *lam_out;             // MODE_DYNAMICS: accelerations of the dynamic configs [batch][nd], constraint forces [batch][nc]
+    double *g1[8];                         // MODE_DYN_DERIV1: f_dq, f_ddq [batch][nq][nd], f_dk [batch][nk][nd], f_du [batch][nu][nd], then the
+                                           // same four for lambda ([..][nc]); derivative variable first, like the reference's arrays
 };
 
 // sin and cos together for joint angles.  |x| < 2^17: three-constant Cody-Waite reduction to [-pi/4, pi/4]
@@ -1797,11 +1799,171 @@ struct Core {
         }
         TG_SYNC();
         const bool ok = solve_kkt(on);
-        if (on && ok) {
-            TG_FOR(i, nd) A.ddq_out[t * nd + i] = K[i * ld + nf];
-            TG_FOR(c, nc) A.lam_out[t * nc + c] = K[(nd + c) * ld + nf];
-        }
+        if (on && ok && A.ddq_out) TG_FOR(i, nd) A.ddq_out[t * nd + i] = K[i * ld + nf];
+        if (on && ok && A.lam_out) TG_FOR(c, nc) A.lam_out[t * nc + c] = K[(nd + c) * ld + nf];
         return ok;
+    }
+
+    // =====================================================================================================
+    // First derivatives of the continuous dynamics (reference calc_dynamics_deriv1, system.c:912-1299): d(ddq_d, lambda)
+    // / d(q, dq, ddq_k, u).  With r = D - M ddq_d + Ad^T lambda = 0 and g = A ddq + dq^T H dq = 0 solved by `dynamics`,
+    // the implicit-function theorem gives, with the SAME KKT matrix, one right-hand side per derivative variable:
+    //     [ M  -Ad^T ] [d ddq_d ]   [  dr/dtheta ]
+    //     [ Ad   0   ] [d lambda] = [ -dg/dtheta ]      (partials at fixed ddq_d, lambda)
+    // and all columns are eliminated together.  The reference's O(nq^3) tables (M_dq, L_ddqdqdq dq, ...) never appear:
+    // per (body, joint) item k the derivative of the body's acceleration-like vector a_F = sum_j (W_j dq_j + J_j ddq_j),
+    //     da_F/dq_k  = [PX_k, J_k] + [W_k, v - P_k]      (PX_k, P_k: prefix sums of W_j dq_j + J_j ddq_j and of J_j dq_j)
+    //     da_F/ddq_k = 2 W_k + [J_k, v]
+    // is O(1), and the torque tau_a = m gam.J_a - <J_a, a_F> - <[J_a, v], v> of item a is differentiated pair by pair.
+    // =====================================================================================================
+    TG_HD bool dyn_deriv1(bool on, const RunArgs &A, size_t t) {
+        const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nf = P.nf, ld = P.g_ld;
+        double *AUG = S + P.g_o_AUG, *PR = S + P.g_o_P, *X = S + P.g_o_X, *aF = S + P.g_o_aF, *xs = S + P.g_o_x, *acc = xs + nf;
+        const double *dq = S + P.o_dq;
+        const int c_q = nf, c_dq = nf + nq, c_k = nf + 2 * nq, c_u = c_k + nk;
+        const bool ok0 = dynamics(on, A, t);
+        if (on) TG_FOR(r, nf) xs[r] = S[P.o_Df + r * P.df_ld + nf];
+        TG_SYNC();
+        if (on) {
+            TG_FOR(i, nq) acc[i] = i < nd ? xs[i] : S[P.o_nu + nu + (i - nd)];   // ddq of every config
+            TG_FOR(i, nf * ld) AUG[i] = 0.0;
+        }
+        TG_SYNC();
+        // the poses again (the solve above overwrote them); J, W, v, gam of `dynamics` are still valid
+        pose_sweep(on, 2);
+        attach_points(on, true, true);
+        if (nc && on) {
+            TG_FOR(n, P.n_dh) {
+                const int c = P.dh_pack[8 * (size_t)n], k = P.dh_pack[8 * (size_t)n + 1];
+                const double a = S[P.o_Dh2 + n];
+                if (k < nd) { AUG[k * ld + nd + c] = -a; AUG[(nd + c) * ld + k] = a; }
+                else AUG[(nd + c) * ld + c_k + (k - nd)] = -a;                       // -dg/d(ddq_k)
+            }
+            TG_FOR(pp, P.n_cpair) {
+                const int *pw = P.cpair4 + 4 * (size_t)pp;
+                const int c = pw[0], na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+                const double h2 = con_d2(c, na, nb), lam = xs[nd + c];
+                const int row = (nd + c) * ld;
+                if (ka < nd) lds_add(&AUG[ka * ld + c_q + kb], lam * h2);           // d(Ad^T lambda)/dq
+                lds_add(&AUG[row + c_q + kb], -h2 * acc[ka]);                        // -d(A ddq)/dq
+                lds_add(&AUG[row + c_dq + ka], -2.0 * h2 * dq[kb]);                  // -d(dq^T H dq)/d(dq)
+                if (na != nb) {
+                    if (kb < nd) lds_add(&AUG[kb * ld + c_q + ka], lam * h2);
+                    lds_add(&AUG[row + c_q + ka], -h2 * acc[kb]);
+                    lds_add(&AUG[row + c_dq + kb], -2.0 * h2 * dq[ka]);
+                }
+            }
+            TG_FOR(n, P.n_dh) {                                                      // -d(dq^T H dq)/dq: third derivatives
+                const int c = P.dh_c[n], k = P.dh_cfg[n];
+                double sum = 0.0;
+                for (int ni = P.cu_off[c]; ni < P.cu_off[c + 1]; ni++)
+                    for (int nj = P.cu_off[c]; nj < P.cu_off[c + 1]; nj++)
+                        sum += con_d3(c, ni, nj, n) * dq[P.dh_cfg[ni]] * dq[P.dh_cfg[nj]];
+                lds_add(&AUG[(nd + c) * ld + c_q + k], -sum);
+            }
+        }
+        TG_SYNC();
+        // prefix sums along every body's path: P_k = sum_{j<k} J_j dq_j, PX_k = sum_{j<k} (W_j dq_j + J_j ddq_j)
+        if (on) TG_FOR(idx, 6 * P.n_bodies) {
+            const int b = idx / 6, m = idx % 6;
+            double ap = 0.0, ax = 0.0;
+            for (int k = P.b_item_off[b]; k < P.b_item_off[b + 1]; k++) {
+                const int cfg = P.it_pack[4 * (size_t)k + 3] & 0xFFFF;
+                PR[6 * k + m] = ap; X[6 * k + m] = ax;
+                ap += S[P.o_J + 6 * k + m] * dq[cfg];
+                ax += S[P.o_W + 6 * k + m] * dq[cfg] + S[P.o_J + 6 * k + m] * acc[cfg];
+            }
+            aF[idx] = ax;
+        }
+        TG_SYNC();
+        if (on) TG_FOR(it, P.n_items) {   // X_k <- da_F/dq_k
+            const int b = P.it_pack[4 * (size_t)it];
+            const double *v = S + P.o_vB + 6 * b, *J = S + P.o_J + 6 * it, *W = S + P.o_W + 6 * it;
+            double px[6], vm[6], t1[6], t2[6];
+            for (int m = 0; m < 6; m++) { px[m] = X[6 * it + m]; vm[m] = v[m] - PR[6 * it + m]; }
+            bracket(px, J, t1);
+            bracket(W, vm, t2);
+            for (int m = 0; m < 6; m++) X[6 * it + m] = t1[m] + t2[m];
+        }
+        TG_SYNC();
+        if (on) {
+            TG_FOR(pp, P.n_pairs) {
+                const int x = P.pair_a[pp], y = P.pair_b[pp];   // x at or before y on the path
+                const int b = P.it_pack[4 * (size_t)x];
+                const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b, *aFb = aF + 6 * b;
+                const double *Jx = S + P.o_J + 6 * x, *Jy = S + P.o_J + 6 * y;
+                // gravity: d(m gam.J_a)/dq_k = m gam.(w_x x v_y), symmetric in (a, k)
+                const double g2 = I[0] * (gam[0] * (Jx[4] * Jy[2] - Jx[5] * Jy[1]) + gam[1] * (Jx[5] * Jy[0] - Jx[3] * Jy[2]) +
+                                          gam[2] * (Jx[3] * Jy[1] - Jx[4] * Jy[0]));
+                auto emit = [&](int a, int k, bool k_later) {
+                    const int ca = P.it_pack[4 * (size_t)a + 3] & 0xFFFF, ck = P.it_pack[4 * (size_t)k + 3] & 0xFFFF;
+                    if (ca >= nd) return;
+                    const double *Ja = S + P.o_J + 6 * a, *Jk = S + P.o_J + 6 * k, *Wk = S + P.o_W + 6 * k, *dAk = X + 6 * k;
+                    double br[6], jav[6], jaw[6], jkv[6];
+                    bracket(Ja, Jk, br); bracket(Ja, v, jav); bracket(Ja, Wk, jaw); bracket(Jk, v, jkv);
+                    double tq = g2 - inner6(I, Ja, dAk) - inner6(I, jaw, v) - inner6(I, jav, Wk);
+                    if (k_later) {   // dJ_a/dq_k = [J_a, J_k] only for joints after a
+                        double djv[6];
+                        bracket(br, v, djv);
+                        tq -= inner6(I, br, aFb) + inner6(I, djv, v);
+                    }
+                    const double td = -(2.0 * inner6(I, Ja, Wk) + inner6(I, Ja, jkv)) - inner6(I, br, v) - inner6(I, jav, Jk);
+                    const double mak = inner6(I, Ja, Jk);
+                    lds_add(&AUG[ca * ld + c_q + ck], tq);
+                    lds_add(&AUG[ca * ld + c_dq + ck], td);
+                    if (ck < nd) lds_add(&AUG[ca * ld + ck], mak);
+                    else lds_add(&AUG[ca * ld + c_k + (ck - nd)], -mak);
+                };
+                emit(x, y, y != x);
+                if (x != y) emit(y, x, false);
+            }
+            TG_FOR(i, nd) {
+                lds_add(&AUG[i * ld + c_dq + i], -P.damp[i]);
+                for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) lds_add(&AUG[i * ld + c_u + P.cf_in[k]], 1.0);
+                if (has_cs()) lds_add(&AUG[i * ld + c_q + i], -P.cs_k[i]);
+            }
+            TG_FOR(pp, n_spair()) {
+                const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
+                const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+                const double h = S[P.o_sH + pp];
+                if (ka < nd) lds_add(&AUG[ka * ld + c_q + kb], -h);
+                if (pw[1] != pw[2] && kb < nd) lds_add(&AUG[kb * ld + c_q + ka], -h);
+            }
+        }
+        TG_SYNC();
+        bool ok;
+        const int R = P.g_nrhs;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int w = nf + R, nb4 = (nf + 3) >> 2;
+        if (TEAM == 64 && w <= 128 && nb4 <= 8 && P.gjc_ok) {
+            double *sc = S + P.o_G;   // the joint poses are dead during the solve
+            switch (nb4) {
+            case 1: ok = Core<TEAM>::template gj_cols<4>(on, AUG, nf, w, ld, sc, lane); break;
+            case 2: ok = Core<TEAM>::template gj_cols<8>(on, AUG, nf, w, ld, sc, lane); break;
+            case 3: ok = Core<TEAM>::template gj_cols<12>(on, AUG, nf, w, ld, sc, lane); break;
+            case 4: ok = Core<TEAM>::template gj_cols<16>(on, AUG, nf, w, ld, sc, lane); break;
+            case 5: ok = Core<TEAM>::template gj_cols<20>(on, AUG, nf, w, ld, sc, lane); break;
+            case 6: ok = Core<TEAM>::template gj_cols<24>(on, AUG, nf, w, ld, sc, lane); break;
+            case 7: ok = Core<TEAM>::template gj_cols<28>(on, AUG, nf, w, ld, sc, lane); break;
+            default: ok = Core<TEAM>::template gj_cols<32>(on, AUG, nf, w, ld, sc, lane); break;
+            }
+        } else
+#endif
+            ok = gauss_jordan(on, AUG, nf, R, ld, S + P.o_scal);
+        if (on && ok0 && ok) {
+            const int col0[4] = {c_q, c_dq, c_k, c_u}, rows[4] = {nq, nq, nk, nu};
+            for (int g = 0; g < 8; g++) {
+                double *dst = A.g1[g];
+                if (!dst) continue;
+                const int v = g & 3, width = g < 4 ? nd : nc, r0 = g < 4 ? 0 : nd;
+                dst += t * (size_t)rows[v] * width;
+                TG_FOR(idx, rows[v] * width) {
+                    const int k = idx / width, o = idx % width;
+                    dst[idx] = AUG[(r0 + o) * ld + col0[v] + k];
+                }
+            }
+        }
+        return ok0 && ok;
     }
 
     // midpoint evaluation shared by every mode: rates, poses, Jacobians, velocities, residual
@@ -1868,6 +2030,11 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
     }
     if constexpr (MODE == MODE_DERIV2Z) {
         core.deriv2z(live, A, t);
+        return;
+    }
+    if constexpr (MODE == MODE_DYN_DERIV1) {
+        const bool ok = core.dyn_deriv1(live, A, t);
+        if (live && lane == 0) { A.iters[t] = 0; A.status[t] = ok ? TG_OK : TG_SINGULAR; }
         return;
     }
     if constexpr (MODE == MODE_DYNAMICS) {

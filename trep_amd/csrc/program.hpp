@@ -96,6 +96,8 @@ struct DevProg {
     const double *cs_k, *cs_kq0;  // [nq] config springs: sum k and sum k q0 per config (V_dq = cs_k q - cs_kq0)
     const double *s_k, *s_x0;     // [n_springs]
     int n_springs, n_sdh, n_spair, o_sV, o_sH, has_cs;   // two-point springs: dh items / pairs follow the constraints' in the same tables
+    // continuous-dynamics derivative kernel (MODE_DYN_DERIV1): KKT matrix + one column per derivative variable, prefix vectors
+    int g_nrhs, g_ld, g_o_AUG, g_o_P, g_o_X, g_o_aF, g_o_x, g_lds_per_team;
     const int *tab_i; const double *tab_d; int n_tab_i, n_tab_d;  // the packed table buffers (all pointers above point into them)
     int e_o_H11, e_o_H12, e_o_H22, e_o_G1, e_o_w, e_o_zq, e_o_zp, e_o_vec, e_o_vec2, e_lds_per_team;
 };
@@ -490,6 +492,15 @@ inline HostProgram build_program(const tg_system_desc *d) {
         P.n_tchunk = (int)H.tchunk.size() - 1;
     }
     P.o_cps = (6 * P.n_cpath + 6 * nc <= (P.o_gam + 3 * nb) - P.o_J) ? P.o_J : -1;   // J, W, vB, gam are dead there (recomputed afterwards)   // prefix / suffix sums of the constraint paths + per-constraint sums
+    {   // MODE_DYN_DERIV1 layout on top of the base region
+        int goff = P.lds_per_team;
+        auto gtake = [&](int n) { int o = goff; goff += (n > 0 ? n : 0); return o; };
+        P.g_nrhs = 2 * nq + P.nk + P.nu;
+        P.g_ld = (P.nf + P.g_nrhs) | 1;
+        P.g_o_AUG = gtake(P.nf * P.g_ld);
+        P.g_o_P = gtake(6 * nitems); P.g_o_X = gtake(6 * nitems); P.g_o_aF = gtake(6 * nb); P.g_o_x = gtake(P.nf + nq);
+        P.g_lds_per_team = (goff + 1) & ~1;
+    }
     P.gjc_ok = (std::max(12 * nj, 2 * nitems) >= 4 * 32) ? 1 : 0;   // gj_cols scratch (128 doubles) lives in the dead pose area
     P.d_o_T12 = take(nq * nd); P.d_o_T22 = take(nq * nd);
     P.d_lds_per_team = (off + 1) & ~1;

@@ -32,11 +32,11 @@ int fail(int code, const std::string &msg) {
 // The derivative modes keep 60-80 KB of LDS per trajectory, i.e. at most two wavefronts per CU: they may use the whole
 // register file of a SIMD (no spills, deeper unrolling); the rollout modes run two wavefronts per SIMD.
 template <int TEAM, int MODE, bool SPRINGS>
-__global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z) ? 1 : 2) void k_run(const tg::DevProg P, const tg::RunArgs A) {
+__global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z || MODE == tg::MODE_DYN_DERIV1) ? 1 : 2) void k_run(const tg::DevProg P, const tg::RunArgs A) {
     extern __shared__ double lds[];
     const int team = threadIdx.x / TEAM, lane = threadIdx.x % TEAM;
     const int traj = blockIdx.x * (64 / TEAM) + team;
-    const int stride = MODE == tg::MODE_DERIV2Z ? P.e_lds_per_team : (MODE == tg::MODE_DERIV1 ? P.d_lds_per_team : P.lds_per_team);
+    const int stride = MODE == tg::MODE_DERIV2Z ? P.e_lds_per_team : (MODE == tg::MODE_DERIV1 ? P.d_lds_per_team : (MODE == tg::MODE_DYN_DERIV1 ? P.g_lds_per_team : P.lds_per_team));
     tg::run_trajectory<TEAM, MODE, SPRINGS>(P, A, lds + (size_t)team * stride, lane, traj);
 }
 
@@ -58,6 +58,7 @@ struct tg_batch {
     int *iters = nullptr, *status = nullptr;
     double *z_dev = nullptr, *hz_dev = nullptr, *zl_dev = nullptr;
     double *dyn = nullptr;     // staging of the host-facing continuous-dynamics call: q, dq, u, ddq_k, ddq, lambda
+    double *dyn_d1 = nullptr;  // ... and of its eight first-derivative arrays
     int *dyn_ints = nullptr;   // its status / iteration words (the integrator's own stay untouched)
     double *d1[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool have_d1 = false;
@@ -147,6 +148,7 @@ int launch_team(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
     case tg::MODE_DERIV1: return launch_one<TEAM, tg::MODE_DERIV1>(b, A, grid, lds);
     case tg::MODE_DERIV2Z: return launch_one<TEAM, tg::MODE_DERIV2Z>(b, A, grid, lds);
     case tg::MODE_DYNAMICS: return launch_one<TEAM, tg::MODE_DYNAMICS>(b, A, grid, lds);
+    case tg::MODE_DYN_DERIV1: return launch_one<TEAM, tg::MODE_DYN_DERIV1>(b, A, grid, lds);
     default: return fail(TG_ERR_INVALID, "unknown kernel mode");
     }
 }
@@ -154,7 +156,7 @@ int launch_team(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
 int launch(tg_batch *b, tg::RunArgs &A) {
     const int team = b->sys->team, per_block = 64 / team;
     const int grid = (A.batch + per_block - 1) / per_block;
-    const int per_team = A.mode == tg::MODE_DERIV2Z ? b->P.e_lds_per_team : (A.mode == tg::MODE_DERIV1 ? b->P.d_lds_per_team : b->P.lds_per_team);
+    const int per_team = A.mode == tg::MODE_DERIV2Z ? b->P.e_lds_per_team : (A.mode == tg::MODE_DERIV1 ? b->P.d_lds_per_team : (A.mode == tg::MODE_DYN_DERIV1 ? b->P.g_lds_per_team : b->P.lds_per_team));
     const size_t lds = (size_t)per_block * per_team * sizeof(double);
     if (lds > 160 * 1024) return fail(TG_ERR_UNSUPPORTED, "system too large for the LDS-resident kernel");
     hipEvent_t e0, e1;
@@ -325,7 +327,7 @@ void tg_batch_destroy(tg_batch *b) {
     for (auto &e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : b->pool) hipEventDestroy(e);
     void *ptrs[] = {b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
-                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev, b->zl_dev, b->dyn, b->dyn_ints,
+                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev, b->zl_dev, b->dyn, b->dyn_ints, b->dyn_d1,
                     b->d1[0], b->d1[1], b->d1[2], b->d1[3], b->d1[4], b->d1[5], b->d1[6], b->d1[7], b->d1[8], b->d1[9], b->d1[10], b->d1[11]};
     for (void *p : ptrs) if (p) hipFree(p);
     if (b->stream && b->own_stream) hipStreamDestroy(b->stream);
@@ -594,6 +596,57 @@ int tg_batch_dynamics_device(tg_batch *b, const double *q_dev, const double *dq_
     A.dq_in = dq_dev; A.ddqk_in = ddqk_dev; A.ddq_out = ddq_dev; A.lam_out = lambda_dev;
     A.iters = b->dyn_ints; A.status = status_dev ? status_dev : b->dyn_ints + b->batch;
     return launch(b, A);
+}
+
+int tg_batch_dynamics_deriv1_device(tg_batch *b, const double *q_dev, const double *dq_dev, const double *u_dev, const double *ddqk_dev,
+                                    double *const out_dev[8], int32_t *status_dev) {
+    if (!b || !q_dev || !dq_dev || !out_dev) return fail(TG_ERR_INVALID, "null argument");
+    const tg::DevProg &P = b->P;
+    if ((P.nu && !u_dev) || (P.nk && !ddqk_dev)) return fail(TG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(b->device));
+    if (!b->dyn_ints) HIP_TRY(hipMalloc(&b->dyn_ints, 2 * (size_t)b->batch * sizeof(int)));
+    tg::RunArgs A = base_args(b, tg::MODE_DYN_DERIV1);
+    A.q1 = A.q2 = const_cast<double *>(q_dev);
+    A.u1 = const_cast<double *>(u_dev ? u_dev : b->u1);
+    A.dq_in = dq_dev; A.ddqk_in = ddqk_dev; A.ddq_out = nullptr; A.lam_out = nullptr;
+    for (int g = 0; g < 8; g++) A.g1[g] = out_dev[g];
+    A.iters = b->dyn_ints; A.status = status_dev ? status_dev : b->dyn_ints + b->batch;
+    return launch(b, A);
+}
+
+int tg_batch_dynamics_deriv1(tg_batch *b, const double *q_host, const double *dq_host, const double *u_host, const double *ddqk_host,
+                             double *f_dq, double *f_ddq, double *f_dddk, double *f_du,
+                             double *lambda_dq, double *lambda_ddq, double *lambda_dddk, double *lambda_du, int32_t *status_host) {
+    if (!b || !q_host || !dq_host) return fail(TG_ERR_INVALID, "null argument");
+    const tg::DevProg &P = b->P;
+    if ((P.nu && !u_host) || (P.nk && !ddqk_host)) return fail(TG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t B = (size_t)b->batch, nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc;
+    const size_t in_total = B * (2 * nq + nu + nk + nd + nc);
+    if (!b->dyn) HIP_TRY(hipMalloc(&b->dyn, (in_total ? in_total : 1) * sizeof(double)));
+    const size_t rows[4] = {nq, nq, nk, nu};
+    size_t out_total = 0;
+    for (int g = 0; g < 8; g++) out_total += B * rows[g & 3] * (g < 4 ? nd : nc);
+    if (!b->dyn_d1) HIP_TRY(hipMalloc(&b->dyn_d1, (out_total ? out_total : 1) * sizeof(double)));
+    double *q = b->dyn, *dq = q + B * nq, *u = dq + B * nq, *ddk = u + B * nu;
+    HIP_TRY(hipMemcpyAsync(q, q_host, B * nq * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(dq, dq_host, B * nq * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    if (nu) HIP_TRY(hipMemcpyAsync(u, u_host, B * nu * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    if (nk) HIP_TRY(hipMemcpyAsync(ddk, ddqk_host, B * nk * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    double *host[8] = {f_dq, f_ddq, f_dddk, f_du, lambda_dq, lambda_ddq, lambda_dddk, lambda_du};
+    double *dev[8];
+    size_t off = 0, cnt[8];
+    for (int g = 0; g < 8; g++) {
+        cnt[g] = B * rows[g & 3] * (g < 4 ? nd : nc);
+        dev[g] = (host[g] && cnt[g]) ? b->dyn_d1 + off : nullptr;
+        off += cnt[g];
+    }
+    if (int rc = tg_batch_dynamics_deriv1_device(b, q, dq, nu ? u : nullptr, nk ? ddk : nullptr, dev, nullptr)) return rc;
+    for (int g = 0; g < 8; g++)
+        if (dev[g]) HIP_TRY(hipMemcpyAsync(host[g], dev[g], cnt[g] * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    if (status_host) HIP_TRY(hipMemcpyAsync(status_host, b->dyn_ints + B, B * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return TG_SUCCESS;
 }
 
 int tg_batch_dynamics(tg_batch *b, const double *q_host, const double *dq_host, const double *u_host, const double *ddqk_host,

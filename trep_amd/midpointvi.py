@@ -275,6 +275,23 @@ class BatchMidpointVI(object):
                                              _lib.ptr(ddq), _lib.ptr(lam), status.ctypes.data))
         return ddq, lam, status
 
+    DYN_D1_NAMES = ("f_dq", "f_ddq", "f_dddk", "f_du", "lambda_dq", "lambda_ddq", "lambda_dddk", "lambda_du")
+
+    def dynamics_deriv1(self, Q, dQ, U=None, ddQk=None):
+        """First derivatives of the continuous dynamics of B states at once (System.f_dq() ... lambda_du() of the
+        reference, system.py:961-1044).  Returns ({name: [B][output][derivative variable]}, status [B])."""
+        B = self._batch
+        Q = _lib.as_f64(np.broadcast_to(np.asarray(Q, dtype=float), (B, self.nq)), (B, self.nq))
+        dQ = _lib.as_f64(np.broadcast_to(np.asarray(dQ, dtype=float), (B, self.nq)), (B, self.nq))
+        U = np.zeros((B, self.nu)) if U is None else _lib.as_f64(np.broadcast_to(np.asarray(U, dtype=float), (B, self.nu)), (B, self.nu))
+        K = np.zeros((B, self.nk)) if ddQk is None else _lib.as_f64(np.broadcast_to(np.asarray(ddQk, dtype=float), (B, self.nk)), (B, self.nk))
+        rows = (self.nq, self.nq, self.nk, self.nu)
+        outs = [np.zeros((B, rows[g & 3], self.nd if g < 4 else self.nc)) for g in range(8)]
+        status = np.zeros(B, dtype=np.int32)
+        _lib.check(self._L.tg_batch_dynamics_deriv1(self._h, _lib.ptr(Q), _lib.ptr(dQ), _lib.ptr(U), _lib.ptr(K),
+                                                    *([_lib.ptr(o) for o in outs] + [status.ctypes.data])))
+        return dict((n, np.swapaxes(o, 1, 2)) for n, o in zip(self.DYN_D1_NAMES, outs)), status
+
     def snapshot(self):
         """Save the integrator state on the device (replayed by restore())."""
         _lib.check(self._L.tg_batch_snapshot(self._h))

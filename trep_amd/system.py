@@ -312,6 +312,37 @@ class System(object):
         lam = self._dynamics()[1]
         return lam if constraint is None else float(lam[constraint.index])
 
+    def _dynamics_deriv1(self):
+        self._dynamics()                      # engine + the reference's side effect on Config.ddq
+        d, status = self._dyn_engine.dynamics_deriv1(self.q[None], self.dq[None], self.u[None], self.ddqk[None])
+        if status[0] != 0:
+            raise ValueError("singular inertia or constraint matrix")
+        return dict((k, v[0]) for k, v in d.items())
+
+    def _dyn_d1_accessor(name, out_kind, var_kind):
+        def pick(obj, kind):
+            if obj is None:
+                return slice(None)
+            if kind == "d":
+                assert not obj.kinematic
+                return obj.index
+            return obj.k_index if kind == "k" else obj.index
+        def accessor(self, out=None, var=None):
+            """[output][derivative variable] like the reference (system.py:961-980, 1026-1044); objects select entries."""
+            return np.array(self._dynamics_deriv1()[name][pick(out, out_kind), pick(var, var_kind)])
+        accessor.__name__ = name
+        return accessor
+
+    f_dq = _dyn_d1_accessor("f_dq", "d", "q")
+    f_ddq = _dyn_d1_accessor("f_ddq", "d", "q")
+    f_dddk = _dyn_d1_accessor("f_dddk", "d", "k")
+    f_du = _dyn_d1_accessor("f_du", "d", "u")
+    lambda_dq = _dyn_d1_accessor("lambda_dq", "c", "q")
+    lambda_ddq = _dyn_d1_accessor("lambda_ddq", "c", "q")
+    lambda_dddk = _dyn_d1_accessor("lambda_dddk", "c", "k")
+    lambda_du = _dyn_d1_accessor("lambda_du", "c", "u")
+    del _dyn_d1_accessor
+
     def set_state(self, q=None, dq=None, u=None, ddqk=None, t=None):
         if q is not None:
             self.q = q
