@@ -1818,7 +1818,7 @@ struct Core {
     // =====================================================================================================
     TG_HD bool dyn_deriv1(bool on, const RunArgs &A, size_t t) {
         const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nf = P.nf, ld = P.g_ld;
-        double *AUG = S + P.g_o_AUG, *PR = S + P.g_o_P, *X = S + P.g_o_X, *aF = S + P.g_o_aF, *xs = S + P.g_o_x, *acc = xs + nf;
+        double *AUG = S + P.g_o_AUG, *X = S + P.g_o_X, *aF = S + P.g_o_aF, *xs = S + P.g_o_x, *acc = xs + nf;
         const double *dq = S + P.o_dq;
         const int c_q = nf, c_dq = nf + nq, c_k = nf + 2 * nq, c_u = c_k + nk;
         const bool ok0 = dynamics(on, A, t);
@@ -1853,37 +1853,39 @@ struct Core {
                     lds_add(&AUG[row + c_dq + kb], -2.0 * h2 * dq[ka]);
                 }
             }
-            TG_FOR(n, P.n_dh) {                                                      // -d(dq^T H dq)/dq: third derivatives
-                const int c = P.dh_c[n], k = P.dh_cfg[n];
+            TG_FOR(idx, P.n_dh * P.g_max_cu) {                                       // -d(dq^T H dq)/dq: third derivatives,
+                const int n = idx / P.g_max_cu, c = P.dh_c[n], k = P.dh_cfg[n];         // one lane per (item k, item i), j >= i
+                const int ni = P.cu_off[c] + idx % P.g_max_cu;
+                if (ni >= P.cu_off[c + 1]) continue;
+                const double dqi = dq[P.dh_cfg[ni]];
                 double sum = 0.0;
-                for (int ni = P.cu_off[c]; ni < P.cu_off[c + 1]; ni++)
-                    for (int nj = P.cu_off[c]; nj < P.cu_off[c + 1]; nj++)
-                        sum += con_d3(c, ni, nj, n) * dq[P.dh_cfg[ni]] * dq[P.dh_cfg[nj]];
-                lds_add(&AUG[(nd + c) * ld + c_q + k], -sum);
+                for (int nj = ni; nj < P.cu_off[c + 1]; nj++)
+                    sum += (nj == ni ? 1.0 : 2.0) * con_d3(c, ni, nj, n) * dq[P.dh_cfg[nj]];
+                lds_add(&AUG[(nd + c) * ld + c_q + k], -sum * dqi);
             }
         }
         TG_SYNC();
-        // prefix sums along every body's path: P_k = sum_{j<k} J_j dq_j, PX_k = sum_{j<k} (W_j dq_j + J_j ddq_j)
-        if (on) TG_FOR(idx, 6 * P.n_bodies) {
-            const int b = idx / 6, m = idx % 6;
-            double ap = 0.0, ax = 0.0;
+        // One lane per body walks its path with the two running prefixes P_k = sum_{j<k} J_j dq_j and
+        // PX_k = sum_{j<k} (W_j dq_j + J_j ddq_j) in registers and leaves X_k = da_F/dq_k = [PX_k, J_k] + [W_k, v - P_k]
+        // (only X is stored: 6 doubles per item instead of 18 keeps the kernel at two wavefronts per CU)
+        if (on) TG_FOR(b, P.n_bodies) {
+            const double *v = S + P.o_vB + 6 * b;
+            double pr[6] = {0, 0, 0, 0, 0, 0}, px[6] = {0, 0, 0, 0, 0, 0};
             for (int k = P.b_item_off[b]; k < P.b_item_off[b + 1]; k++) {
                 const int cfg = P.it_pack[4 * (size_t)k + 3] & 0xFFFF;
-                PR[6 * k + m] = ap; X[6 * k + m] = ax;
-                ap += S[P.o_J + 6 * k + m] * dq[cfg];
-                ax += S[P.o_W + 6 * k + m] * dq[cfg] + S[P.o_J + 6 * k + m] * acc[cfg];
+                const double *J = S + P.o_J + 6 * k, *W = S + P.o_W + 6 * k;
+                const double dqk = dq[cfg], ak = acc[cfg];
+                double vm[6], t1[6], t2[6];
+                for (int m = 0; m < 6; m++) vm[m] = v[m] - pr[m];
+                bracket(px, J, t1);
+                bracket(W, vm, t2);
+                for (int m = 0; m < 6; m++) {
+                    X[6 * k + m] = t1[m] + t2[m];
+                    pr[m] += J[m] * dqk;
+                    px[m] += W[m] * dqk + J[m] * ak;
+                }
             }
-            aF[idx] = ax;
-        }
-        TG_SYNC();
-        if (on) TG_FOR(it, P.n_items) {   // X_k <- da_F/dq_k
-            const int b = P.it_pack[4 * (size_t)it];
-            const double *v = S + P.o_vB + 6 * b, *J = S + P.o_J + 6 * it, *W = S + P.o_W + 6 * it;
-            double px[6], vm[6], t1[6], t2[6];
-            for (int m = 0; m < 6; m++) { px[m] = X[6 * it + m]; vm[m] = v[m] - PR[6 * it + m]; }
-            bracket(px, J, t1);
-            bracket(W, vm, t2);
-            for (int m = 0; m < 6; m++) X[6 * it + m] = t1[m] + t2[m];
+            for (int m = 0; m < 6; m++) aF[6 * b + m] = px[m];
         }
         TG_SYNC();
         if (on) {

@@ -97,7 +97,7 @@ struct DevProg {
     const double *s_k, *s_x0;     // [n_springs]
     int n_springs, n_sdh, n_spair, o_sV, o_sH, has_cs;   // two-point springs: dh items / pairs follow the constraints' in the same tables
     // continuous-dynamics derivative kernel (MODE_DYN_DERIV1): KKT matrix + one column per derivative variable, prefix vectors
-    int g_nrhs, g_ld, g_o_AUG, g_o_P, g_o_X, g_o_aF, g_o_x, g_lds_per_team;
+    int g_nrhs, g_ld, g_o_AUG, g_o_P, g_o_X, g_o_aF, g_o_x, g_lds_per_team, g_max_cu;
     const int *tab_i; const double *tab_d; int n_tab_i, n_tab_d;  // the packed table buffers (all pointers above point into them)
     int e_o_H11, e_o_H12, e_o_H22, e_o_G1, e_o_w, e_o_zq, e_o_zp, e_o_vec, e_o_vec2, e_lds_per_team;
 };
@@ -498,8 +498,10 @@ inline HostProgram build_program(const tg_system_desc *d) {
         P.g_nrhs = 2 * nq + P.nk + P.nu;
         P.g_ld = (P.nf + P.g_nrhs) | 1;
         P.g_o_AUG = gtake(P.nf * P.g_ld);
-        P.g_o_P = gtake(6 * nitems); P.g_o_X = gtake(6 * nitems); P.g_o_aF = gtake(6 * nb); P.g_o_x = gtake(P.nf + nq);
+        P.g_o_P = 0; P.g_o_X = gtake(6 * nitems); P.g_o_aF = gtake(6 * nb); P.g_o_x = gtake(P.nf + nq);
         P.g_lds_per_team = (goff + 1) & ~1;
+        P.g_max_cu = 0;
+        for (int c = 0; c < nc; c++) P.g_max_cu = std::max(P.g_max_cu, H.cu_off[c + 1] - H.cu_off[c]);
     }
     P.gjc_ok = (std::max(12 * nj, 2 * nitems) >= 4 * 32) ? 1 : 0;   // gj_cols scratch (128 doubles) lives in the dead pose area
     P.d_o_T12 = take(nq * nd); P.d_o_T22 = take(nq * nd);
