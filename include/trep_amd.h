@@ -26,7 +26,7 @@ extern "C" {
 /* Frame transform kinds (reference trep/_trep/trep.h:160-167 TREP_WORLD..TREP_CONST_SE3). */
 enum { TG_WORLD = 0, TG_TX = 1, TG_TY = 2, TG_TZ = 3, TG_RX = 4, TG_RY = 5, TG_RZ = 6, TG_CONST_SE3 = 7 };
 /* Constraint kinds (reference constraints/distance.c, constraints/point.c). */
-enum { TG_CONSTRAINT_DISTANCE = 0, TG_CONSTRAINT_POINT = 1 };
+enum { TG_CONSTRAINT_DISTANCE = 0, TG_CONSTRAINT_POINT = 1, TG_CONSTRAINT_PLANE = 2 };
 
 /*
  * Flattened mechanical system: the integer topology tables the reference keeps in
@@ -80,6 +80,9 @@ typedef struct tg_system_desc {
     const int32_t *linear_spring_frame2; /* [n_linear_springs] */
     const double  *linear_spring_k;      /* [n_linear_springs] */
     const double  *linear_spring_x0;     /* [n_linear_springs] */
+    /* TG_CONSTRAINT_PLANE: h = (R(frame1) n) . (p(frame1) - p(frame2)), frame1 = plane frame, frame2 = point frame
+     * (constraints/plane.c:13-26) */
+    const double  *constraint_normal;    /* [n_constraints*3] plane normal n in plane-frame coordinates (others: zeros) */
 } tg_system_desc;
 
 /* Per-trajectory status written by every solve (reference: ConvergenceError / ValueError("singular")

@@ -16,6 +16,7 @@ BUILDERS = {
     "puppet_basic": lambda: systems.puppet_basic(),
     "spring_arm": lambda: systems.spring_arm(),
     "spring_link": lambda: systems.spring_link(),
+    "plane_link": lambda: systems.plane_link(),
 }
 D1 = ["q2_dq1", "q2_dp1", "q2_du1", "q2_dk2", "p2_dq1", "p2_dp1", "p2_du1", "p2_dk2",
       "l1_dq1", "l1_dp1", "l1_du1", "l1_dk2"]

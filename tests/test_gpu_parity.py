@@ -314,7 +314,7 @@ def test_deriv1_accessors_dropin():
     assert mvi.q2_dk2().shape == (2, 0)
 
 
-@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "pendulum5", "spring_arm"])
+@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "pendulum5", "spring_arm", "plane_link"])
 def test_dsystem_linearization_matches_reference(name):
     """DSystem.set(X[k],U[k],k,xk_hint=X[k+1]) -> f, fdx (A_k), fdu (B_k) vs the reference's DSystem."""
     import trep_amd
@@ -343,7 +343,7 @@ def test_dsystem_linearization_matches_reference(name):
     assert lin.A.shape == (3, one.nX, one.nX) and lin.B.shape == (3, one.nX, one.nU)
 
 
-@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "pendulum5", "spring_arm"])
+@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "pendulum5", "spring_arm", "plane_link"])
 def test_dsystem_second_order_matches_reference(name):
     """fdxdx(z), fdxdu(z), fdudu(z) vs the reference DSystem (dsystem.py:320-386) for two z."""
     import trep_amd
@@ -367,7 +367,7 @@ def test_dsystem_second_order_matches_reference(name):
     assert np.array_equal(xx[0], xx[2])
 
 
-@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "puppet_basic", "spring_arm"])
+@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "puppet_basic", "spring_arm", "plane_link"])
 def test_full_second_derivative_tensors_match_reference(name):
     """MidpointVI.q2_dq1dq1() ... p2_dk2dk2(), lambda1_dq1dq1() ... accessors vs the reference's [A][B][out] tensors."""
     import trep_amd

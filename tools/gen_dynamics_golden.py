@@ -27,6 +27,7 @@ BUILDERS = {
     "puppet_basic": lambda: systems.puppet_basic(api=trep),
     "spring_arm": lambda: systems.spring_arm(api=trep),
     "spring_link": lambda: systems.spring_link(api=trep),
+    "plane_link": lambda: systems.plane_link(api=trep),
 }
 N_STATES = 4
 

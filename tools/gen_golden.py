@@ -297,6 +297,24 @@ def gen_spring_link():
     save("spring_link", **arrays, **ds)
 
 
+def gen_plane_link():
+    """Synthetic closed chain with PointOnPlane constraints on moving plane frames; starts at the zero configuration
+    (both constraints satisfied) with seeded initial velocities made consistent by the first DEL step."""
+    system = systems.plane_link(api=trep)
+    B, N = 2, 200
+    arrays = dict(dt=DT, **topology(system))
+    U = np.zeros((N, 0)); K = np.zeros((N, 0))
+    for b in range(B):
+        q0 = np.zeros(system.nQ)
+        r = rollout(system, q0, U, K, N, deriv_steps=(1, 50, N) if b == 0 else (), deriv2_full=True)
+        for key, val in r.items():
+            arrays["b%d_%s" % (b, key)] = val
+        arrays["b%d_q0" % b] = q0
+        system.get_potential(0) if False else None
+    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], U, K, (0, 10, 100), seed=18)
+    save("plane_link", **arrays, **ds)
+
+
 def gen_discopt_cart():
     """One DOptimizer trace on the pend-on-cart problem of examples/pend-on-cart-optimization.py:48-116
     (torque input enabled, 5 s horizon): a few quasi-Newton then Newton steps; per step the method,
@@ -354,7 +372,7 @@ def gen_discopt_cart():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "discopt"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "discopt"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -369,6 +387,8 @@ if __name__ == "__main__":
         gen_puppet()
     if "puppet_basic" in which:
         gen_puppet_basic()
+    if "plane_link" in which:
+        gen_plane_link()
     if "spring_link" in which:
         gen_spring_link()
     if "spring_arm" in which:

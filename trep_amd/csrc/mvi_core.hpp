@@ -172,7 +172,7 @@ TG_HD void team_argmax(double &v, int &i) {
 #endif
 }
 
-// SPRINGS: the spring potentials (ConfigSpring, LinearSpring) are compiled in only for systems that have them, so
+// SPRINGS: the spring potentials (ConfigSpring, LinearSpring) and the plane constraints are compiled in only for systems that have them, so
 // that the spring-free kernels keep their instruction stream and register allocation.
 template <int TEAM, bool SPRINGS = false>
 struct Core {
@@ -180,6 +180,7 @@ struct Core {
     TG_HD int n_springs() const { return SPRINGS ? P.n_springs : 0; }
     TG_HD int n_spair() const { return SPRINGS ? P.n_spair : 0; }
     TG_HD int n_sdh() const { return SPRINGS ? P.n_sdh : 0; }
+    TG_HD bool has_plane() const { return SPRINGS && P.has_plane; }   // plane constraints ride on the same switch
     const DevProg &P;
     double *S;
     int lane;
@@ -357,6 +358,14 @@ struct Core {
             const double val = g[0] * o0 + g[1] * o1 + g[2] * o2 + g[3];
             S[P.o_pE + idx] = anchor < 0 ? orr : val;
         }
+        if (on && endpoints && has_plane()) TG_FOR(idx, 3 * P.nc) {   // world normal of every plane constraint
+            const int c = idx / 3, r = idx % 3;
+            const double *nl = P.c_nloc + 3 * c;
+            const int anchor = P.e_anchor[P.c_e1[c]];
+            const double *g = G + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
+            const double val = g[0] * nl[0] + g[1] * nl[1] + g[2] * nl[2];
+            S[P.o_nE + idx] = anchor < 0 ? nl[r] : val;
+        }
         TG_SYNC();
     }
 
@@ -492,7 +501,8 @@ struct Core {
             const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
             const double vx = a[0] - b[0], vy = a[1] - b[1], vz = a[2] - b[2];
             double h;
-            if (P.c_type[c] == TG_CONSTRAINT_POINT) h = P.c_comp[c] == 0 ? vx : (P.c_comp[c] == 1 ? vy : vz);
+            if (has_plane() && P.c_type[c] == TG_CONSTRAINT_PLANE) { const double *nw = S + P.o_nE + 3 * c; h = nw[0] * vx + nw[1] * vy + nw[2] * vz; }
+            else if (P.c_type[c] == TG_CONSTRAINT_POINT) h = P.c_comp[c] == 0 ? vx : (P.c_comp[c] == 1 ? vy : vz);
             else {
                 const double len = P.c_cfg[c] >= 0 ? qval(sel, P.c_cfg[c]) : P.c_dist[c];
                 h = (vx * vx + vy * vy + vz * vz) - len * len;
@@ -510,7 +520,15 @@ struct Core {
             const double s1 = (side & 1) ? 1.0 : 0.0, s2 = (side & 2) ? 1.0 : 0.0;
             const double dx = s1 * d1[0] - s2 * d2[0], dy = s1 * d1[1] - s2 * d2[1], dz = s1 * d1[2] - s2 * d2[2];
             double val;
-            if (type == TG_CONSTRAINT_POINT) val = comp == 0 ? dx : (comp == 1 ? dy : dz);
+            if (has_plane() && type == TG_CONSTRAINT_PLANE) {   // plane.c:28-45: (dR n) . (p1 - p2) + (R n) . d(p1 - p2)
+                const double *nw = S + P.o_nE + 3 * c, *a = S + P.o_pE + oe1, *b = S + P.o_pE + oe2, *gj = S + P.o_G + ojc;
+                const bool turns = kind >= TG_RX && (side & 1);
+                const int ax = kind >= TG_RX ? kind - TG_RX : 0;
+                const double wx = turns ? gj[ax] : 0.0, wy = turns ? gj[4 + ax] : 0.0, wz = turns ? gj[8 + ax] : 0.0;
+                const double n1x = wy * nw[2] - wz * nw[1], n1y = wz * nw[0] - wx * nw[2], n1z = wx * nw[1] - wy * nw[0];
+                val = n1x * (a[0] - b[0]) + n1y * (a[1] - b[1]) + n1z * (a[2] - b[2]) + nw[0] * dx + nw[1] * dy + nw[2] * dz;
+            }
+            else if (type == TG_CONSTRAINT_POINT) val = comp == 0 ? dx : (comp == 1 ? dy : dz);
             else {
                 const double *a = S + P.o_pE + oe1, *b = S + P.o_pE + oe2;
                 val = (a[0] - b[0]) * dx + (a[1] - b[1]) * dy + (a[2] - b[2]) * dz;
@@ -1184,8 +1202,60 @@ struct Core {
         TG_SYNC();
     }
 
+    // ---- plane constraints: derivatives of the world normal n = R_plane n_local w.r.t. the joints of the plane frame's
+    //      path: d n/dq_a = w_a x n, d2 n/dq_a dq_b = w_a x (w_b x n) (a at or before b), ... (w: world axis of a rotary
+    //      joint; prismatic joints and joints that only move the point frame contribute nothing)
+    TG_HD void plane_axis(int n, double *w) const {
+        const int j = P.dh_joint[n];
+        w[0] = w[1] = w[2] = 0.0;
+        if (j < 0 || !(P.dh_side[n] & 1) || P.j_kind[j] < TG_RX) return;
+        const double *gj = S + P.o_G + 12 * j;
+        const int ax = P.j_kind[j] - TG_RX;
+        w[0] = gj[ax]; w[1] = gj[4 + ax]; w[2] = gj[8 + ax];
+    }
+    TG_HD static void cross3(const double *a, const double *b, double *r) {
+        r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0];
+    }
+    TG_HD static double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+    // k-th derivative of the normal w.r.t. the dh items n[0..k-1] (any order)
+    TG_HD void plane_dn(int c, int k, const int *n, double *out) const {
+        int o[3] = {k > 0 ? n[0] : 0, k > 1 ? n[1] : 0, k > 2 ? n[2] : 0};
+        auto later = [&](int x, int y) { return P.dh_joint[x] > P.dh_joint[y]; };
+        if (k > 1 && later(o[0], o[1])) { const int t_ = o[0]; o[0] = o[1]; o[1] = t_; }
+        if (k > 2 && later(o[1], o[2])) { const int t_ = o[1]; o[1] = o[2]; o[2] = t_; }
+        if (k > 1 && later(o[0], o[1])) { const int t_ = o[0]; o[0] = o[1]; o[1] = t_; }
+        const double *nw = S + P.o_nE + 3 * c;
+        double cur[3] = {nw[0], nw[1], nw[2]};
+        for (int i = k - 1; i >= 0; i--) {   // innermost cross product belongs to the joint farthest down the path
+            double w[3], nxt[3];
+            plane_axis(o[i], w);
+            cross3(w, cur, nxt);
+            cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
+        }
+        out[0] = cur[0]; out[1] = cur[1]; out[2] = cur[2];
+    }
+    // Leibniz expansion of d^k (n . D) over the dh items n[0..k-1], D = p_plane - p_point (plane.c:28-167)
+    TG_HD double plane_dk(int c, int k, const int *n) const {
+        double acc = 0.0;
+        for (int mask = 0; mask < (1 << k); mask++) {
+            int a[3], b[3], na = 0, nb = 0;
+            for (int i = 0; i < k; i++) { if (mask & (1 << i)) a[na++] = n[i]; else b[nb++] = n[i]; }
+            double dn[3], dd[3];
+            plane_dn(c, na, a, dn);
+            if (nb == 0) {
+                const double *pa = S + P.o_pE + 3 * P.c_e1[c], *pb = S + P.o_pE + 3 * P.c_e2[c];
+                dd[0] = pa[0] - pb[0]; dd[1] = pa[1] - pb[1]; dd[2] = pa[2] - pb[2];
+            } else if (nb == 1) cdiff1(c, b[0], dd);
+            else if (nb == 2) cdiff2(c, b[0], b[1], dd);
+            else cdiff3(c, b[0], b[1], b[2], dd);
+            acc += dot3(dn, dd);
+        }
+        return acc;
+    }
+
     // h_c,dqdq for two dependent configs given by their dh items (distance.c:65-98, point.c:40-46)
     TG_HD double con_d2(int c, int n1, int n2) const {
+        if (has_plane() && P.c_type[c] == TG_CONSTRAINT_PLANE) { const int n[2] = {n1, n2}; return plane_dk(c, 2, n); }
         double v12[3];
         cdiff2(c, n1, n2, v12);
         if (P.c_type[c] == TG_CONSTRAINT_POINT) return v12[P.c_comp[c]];
@@ -1199,6 +1269,7 @@ struct Core {
     // h_c,dqdqdq (distance.c:100-133, point.c:48-54); zero when any argument is the string-length config
     TG_HD double con_d3(int c, int n1, int n2, int n3) const {
         if (P.dh_joint[n1] < 0 || P.dh_joint[n2] < 0 || P.dh_joint[n3] < 0) return 0.0;
+        if (has_plane() && P.c_type[c] == TG_CONSTRAINT_PLANE) { const int n[3] = {n1, n2, n3}; return plane_dk(c, 3, n); }
         double v123[3];
         cdiff3(c, n1, n2, n3, v123);
         if (P.c_type[c] == TG_CONSTRAINT_POINT) return v123[P.c_comp[c]];

@@ -98,6 +98,9 @@ struct DevProg {
     int n_springs, n_sdh, n_spair, o_sV, o_sH, has_cs;   // two-point springs: dh items / pairs follow the constraints' in the same tables
     // continuous-dynamics derivative kernel (MODE_DYN_DERIV1): KKT matrix + one column per derivative variable, prefix vectors
     int g_nrhs, g_ld, g_o_AUG, g_o_P, g_o_X, g_o_aF, g_o_x, g_lds_per_team, g_max_cu;
+    // plane constraints (TG_CONSTRAINT_PLANE): normal in the coordinates of the plane frame's anchor joint; world normal in LDS
+    const double *c_nloc;   // [3 * (nc + n_springs)]
+    int has_plane, o_nE;
     const int *tab_i; const double *tab_d; int n_tab_i, n_tab_d;  // the packed table buffers (all pointers above point into them)
     int e_o_H11, e_o_H12, e_o_H22, e_o_G1, e_o_w, e_o_zq, e_o_zp, e_o_vec, e_o_vec2, e_lds_per_team;
 };
@@ -114,7 +117,7 @@ struct HostProgram {
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
     std::vector<double> c_dist, c_tol;
     std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
-    std::vector<double> damp, cs_k, cs_kq0, s_k, s_x0;
+    std::vector<double> damp, cs_k, cs_kq0, s_k, s_x0, c_nloc;
     std::vector<int> cf_cfg, cf_in;
     std::vector<double> jcoef;      // [n_joints*16*4] local-transform coefficients (see pose_sweep)
     int max_depth = 0;
@@ -342,14 +345,24 @@ inline HostProgram build_program(const tg_system_desc *d) {
         return e;
     };
     H.dh_lookup.assign((size_t)nc * nq, -1);
+    bool has_plane = false;
     for (int c = 0; c < nc; c++) {
         int t = d->constraint_type[c];
-        if (t != TG_CONSTRAINT_DISTANCE && t != TG_CONSTRAINT_POINT) throw std::runtime_error("unknown constraint type");
+        if (t != TG_CONSTRAINT_DISTANCE && t != TG_CONSTRAINT_POINT && t != TG_CONSTRAINT_PLANE) throw std::runtime_error("unknown constraint type");
         int f1 = d->constraint_frame1[c], f2 = d->constraint_frame2[c];
         H.c_type.push_back(t); H.c_e1.push_back(endpoint(f1)); H.c_e2.push_back(endpoint(f2));
         int lc = (t == TG_CONSTRAINT_DISTANCE) ? d->constraint_config[c] : -1;
         H.c_cfg.push_back(lc); H.c_comp.push_back(d->constraint_component[c]);
         H.c_dist.push_back(d->constraint_distance[c]); H.c_tol.push_back(d->constraint_tolerance[c]);
+        {   // plane normal carried into the coordinates of the plane frame's anchor joint (constant rotation)
+            double nl[3] = {0, 0, 0};
+            if (t == TG_CONSTRAINT_PLANE) {
+                const double *n = d->constraint_normal + 3 * (size_t)c;
+                for (int r = 0; r < 3; r++) nl[r] = offset[f1].m[4 * r] * n[0] + offset[f1].m[4 * r + 1] * n[1] + offset[f1].m[4 * r + 2] * n[2];
+                has_plane = true;
+            }
+            H.c_nloc.push_back(nl[0]); H.c_nloc.push_back(nl[1]); H.c_nloc.push_back(nl[2]);
+        }
         for (int k = 0; k < nq; k++) {
             int g = d->config_gen[k];
             bool on1 = d->frame_cache_index[(size_t)f1 * (nq + 1) + g] == k;
@@ -368,7 +381,8 @@ inline HostProgram build_program(const tg_system_desc *d) {
     for (int s = 0; s < ns; s++) {
         const int f1 = d->linear_spring_frame1[s], f2 = d->linear_spring_frame2[s], c = nc + s;
         if (f1 < 0 || f1 >= d->n_frames || f2 < 0 || f2 >= d->n_frames) throw std::runtime_error("linear spring: bad frame index");
-        H.c_type.push_back(2); H.c_e1.push_back(endpoint(f1)); H.c_e2.push_back(endpoint(f2));
+        H.c_type.push_back(9); H.c_e1.push_back(endpoint(f1)); H.c_e2.push_back(endpoint(f2));   // 9: not a constraint type
+        H.c_nloc.push_back(0.0); H.c_nloc.push_back(0.0); H.c_nloc.push_back(0.0);
         H.c_cfg.push_back(-1); H.c_comp.push_back(0); H.c_dist.push_back(0.0); H.c_tol.push_back(0.0);
         H.s_k.push_back(d->linear_spring_k[s]); H.s_x0.push_back(d->linear_spring_x0[s]);
         for (int k = 0; k < nq; k++) {
@@ -463,6 +477,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.o_sc = take(2 * nj);
     P.o_G = take(std::max(12 * nj, 2 * nitems));  // also holds the per-item residual terms
     P.o_gB = take(12 * nb); P.o_pE = take(3 * P.n_endpoints);
+    P.has_plane = has_plane ? 1 : 0; P.o_nE = take(has_plane ? 3 * nc : 0);   // world normals of the plane constraints
     P.o_dqi = take(nitems);  // per-item rates: alive only while the poses are (Jacobians -> prefix sums)
     off = std::max(off, end_df);
     P.lds_per_team = (off + 1) & ~1;
@@ -491,7 +506,8 @@ inline HostProgram build_program(const tg_system_desc *d) {
         if (!fits) { H.tchunk.clear(); H.tchunk.push_back(0); }
         P.n_tchunk = (int)H.tchunk.size() - 1;
     }
-    P.o_cps = (6 * P.n_cpath + 6 * nc <= (P.o_gam + 3 * nb) - P.o_J) ? P.o_J : -1;   // J, W, vB, gam are dead there (recomputed afterwards)   // prefix / suffix sums of the constraint paths + per-constraint sums
+    P.o_cps = (!has_plane && 6 * P.n_cpath + 6 * nc <= (P.o_gam + 3 * nb) - P.o_J) ? P.o_J : -1;   // (plane constraints: generic path)
+    //   // J, W, vB, gam are dead there (recomputed afterwards)   // prefix / suffix sums of the constraint paths + per-constraint sums
     {   // MODE_DYN_DERIV1 layout on top of the base region
         int goff = P.lds_per_team;
         auto gtake = [&](int n) { int o = goff; goff += (n > 0 ? n : 0); return o; };
@@ -535,7 +551,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
     X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off)
-#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(s_k) X(s_x0)
+#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(s_k) X(s_x0) X(c_nloc)
 
 inline void HostProgram::pack() {
     ipool.clear(); dpool.clear(); ioff.clear(); doff.clear();

@@ -136,7 +136,7 @@ int launch_variant(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
 // systems with spring potentials run their own instantiation of every kernel (mvi_core.hpp, Core<TEAM, SPRINGS>)
 template <int TEAM, int MODE>
 int launch_one(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
-    return (b->P.has_cs || b->P.n_springs) ? launch_variant<TEAM, MODE, true>(b, A, grid, lds) : launch_variant<TEAM, MODE, false>(b, A, grid, lds);
+    return (b->P.has_cs || b->P.n_springs || b->P.has_plane) ? launch_variant<TEAM, MODE, true>(b, A, grid, lds) : launch_variant<TEAM, MODE, false>(b, A, grid, lds);
 }
 
 template <int TEAM>

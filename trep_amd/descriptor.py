@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 
 from . import frame as _frame
-from .dynamics import Gravity, ConfigSpring, LinearSpring, Damping, ConfigForce, Distance, PointToPoint1D
+from .dynamics import Gravity, ConfigSpring, LinearSpring, Damping, ConfigForce, Distance, PointToPoint1D, PointOnPlane
 
 _I32 = ctypes.POINTER(ctypes.c_int32)
 _F64 = ctypes.POINTER(ctypes.c_double)
@@ -34,7 +34,7 @@ _ARRAYS = [
 
 _TAIL = [("n_config_springs", None), ("config_spring_config", _I32), ("config_spring_k", _F64), ("config_spring_q0", _F64),
          ("n_linear_springs", None), ("linear_spring_frame1", _I32), ("linear_spring_frame2", _I32),
-         ("linear_spring_k", _F64), ("linear_spring_x0", _F64)]   # in struct order (include/trep_amd.h)
+         ("linear_spring_k", _F64), ("linear_spring_x0", _F64), ("constraint_normal", _F64)]   # in struct order (include/trep_amd.h)
 _TAIL_SCALARS = [n for n, t in _TAIL if t is None]
 _TAIL_ARRAYS = [(n, t) for n, t in _TAIL if t is not None]
 
@@ -163,12 +163,20 @@ def flatten(system):
     t["linear_spring_x0"] = np.array(ls_x0, dtype=np.float64)
 
     ctype, cf1, cf2, ccfg, ccomp, cdist, ctol = [], [], [], [], [], [], []
+    cnormal = []
     for con in system.constraints:
+        cnormal.append([0.0, 0.0, 0.0])
         if isinstance(con, Distance):
             ctype.append(0)
             ccfg.append(-1 if con.config is None else cidx[id(con.config)])
             ccomp.append(0)
             cdist.append(con._distance)
+        elif isinstance(con, PointOnPlane):
+            ctype.append(2)
+            ccfg.append(-1)
+            ccomp.append(0)
+            cdist.append(0.0)
+            cnormal[-1] = [float(x) for x in con.normal]
         elif isinstance(con, PointToPoint1D):
             ctype.append(1)
             ccfg.append(-1)
@@ -186,4 +194,5 @@ def flatten(system):
     t["constraint_component"] = np.array(ccomp, dtype=np.int32)
     t["constraint_distance"] = np.array(cdist, dtype=np.float64)
     t["constraint_tolerance"] = np.array(ctol, dtype=np.float64)
+    t["constraint_normal"] = np.array(cnormal, dtype=np.float64).reshape(-1)
     return SystemDesc(t)

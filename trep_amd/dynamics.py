@@ -298,6 +298,39 @@ class PointToPoint1D(Constraint):
         return float((self.frame1.p_dq(config) - self.frame2.p_dq(config))[self._component])
 
 
+class PointOnPlane(Constraint):
+    """h = (R_plane n) . (p_plane - p_point): a point held in a plane that moves with another frame
+    (constraints/plane.py:7-37, plane.c:13-26)."""
+
+    def __init__(self, system, plane_frame, plane_normal, point_frame, name=None):
+        Constraint.__init__(self, system, name)
+        self._plane_frame = system.get_frame(plane_frame)
+        self._point_frame = system.get_frame(point_frame)
+        self.normal = plane_normal
+
+    def __repr__(self):
+        return "<PointOnPlane plane_frame='%s' normal=(%f %f %f) point_frame='%s'>" % (
+            (self._plane_frame.name,) + tuple(self._normal) + (self._point_frame.name,))
+
+    plane_frame = property(lambda self: self._plane_frame)
+    point_frame = property(lambda self: self._point_frame)
+    frame1 = property(lambda self: self._plane_frame)      # descriptor order: frame1 = plane, frame2 = point
+    frame2 = property(lambda self: self._point_frame)
+
+    @property
+    def normal(self):
+        return np.array(self._normal)
+
+    @normal.setter
+    def normal(self, normal):
+        self._normal = (float(normal[0]), float(normal[1]), float(normal[2]))
+        self._system._structure_changed()
+
+    def h(self):
+        g = self._plane_frame.g()
+        return float(np.dot(g[:3, :3].dot(self._normal), (self._plane_frame.p() - self._point_frame.p())[:3]))
+
+
 class _PointGroup(object):
     """PointToPoint2D/3D are not constraints themselves: they add 1-D ones."""
 

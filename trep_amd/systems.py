@@ -104,6 +104,28 @@ def spring_link(api=None):
     return system
 
 
+def plane_link(api=None):
+    """Closed chain held together by PointOnPlane constraints whose plane frames move: a pendulum carries the plane
+    (its own y = 0 plane, and a second one with an oblique normal on its bob), a 3-D two-link arm on another pivot
+    keeps its tip in them.  At the zero configuration the tip lies in both planes.  Synthetic test system."""
+    T = _api(api)
+    system = T.System()
+    system.import_frames([
+        T.rx('a', name='PlaneBody'), [
+            T.tz(-1.0, name='PlaneBob', mass=2.0)],
+        T.ty(1.0, name='Pivot2'), [
+            T.rx('b', name='Arm1'), [
+                T.tz(-1.0, name='Arm1Mass', mass=1.0), [
+                    T.ry('c', name='Arm2'), [
+                        T.rx('d', name='Arm3'), [
+                            T.ty(-1.0, name='Tip', mass=(0.5, 0.05, 0.06, 0.07))]]]]]])
+    T.potentials.Gravity(system, (0.5, 0.3, -9.8))
+    T.constraints.PointOnPlane(system, 'PlaneBody', (0, 1, 0), 'Tip')
+    T.constraints.PointOnPlane(system, 'PlaneBob', (1, 0, 0.5), 'Tip')
+    T.forces.Damping(system, 0.05)
+    return system
+
+
 def scissor_lift(segments=4, theta_0=0.05 * math.pi, m_link=1.0, I_link=1.0, L_link=5.0, m_slider=1.0,
                  api=None):
     """Scissor lift at its analytic closed configuration (no constraint solver needed)."""
