@@ -408,3 +408,18 @@ def test_second_derivatives_undefined_with_linear_springs():
     assert relerr(mvi.q2_dq1(), g["b0_d1_1_q2_dq1"].T) < 1e-9
     with pytest.raises(Exception, match="LinearSpring"):
         mvi.q2_dq1dq1()
+
+
+def test_second_derivatives_not_implemented_with_hybrid_wrench():
+    """The force second derivatives of HybridWrench (f_dqdq, f_dudq) are not implemented: the entry points say so."""
+    import trep_amd
+    g = golden("wrench_arm")
+    system, d = build("wrench_arm")
+    assert [u.name for u in system.inputs] == [str(n) for n in g["input_names"]]
+    mvi = trep_amd.MidpointVI(system)
+    mvi.initialize_from_state(DT, g["b0_Q"][0], g["b0_P"][0], g["b0_LAM"][0])
+    mvi.step(2 * DT, g["b0_U"][0], g["b0_K"][0])
+    assert relerr(mvi.q2, g["b0_Q"][1]) < 1e-10
+    assert relerr(mvi.q2_du1(), g["b0_d1_1_q2_du1"].T) < 1e-9
+    with pytest.raises(Exception, match="HybridWrench"):
+        mvi.q2_dq1dq1()

@@ -28,6 +28,7 @@ BUILDERS = {
     "spring_arm": lambda: systems.spring_arm(api=trep),
     "spring_link": lambda: systems.spring_link(api=trep),
     "plane_link": lambda: systems.plane_link(api=trep),
+    "wrench_arm": lambda: systems.wrench_arm(api=trep),
 }
 N_STATES = 4
 

@@ -315,6 +315,29 @@ def gen_plane_link():
     save("plane_link", **arrays, **ds)
 
 
+def gen_wrench_arm():
+    """Synthetic system with HybridWrench forces.  First derivatives only: the build does not implement the force
+    second derivatives (f_dqdq, f_dudq)."""
+    system = systems.wrench_arm(api=trep)
+    rng = np.random.default_rng(20250 + 9)
+    B, N = 2, 200
+    arrays = dict(dt=DT, **topology(system))
+    arrays["input_names"] = np.array([str(u.name) for u in system.inputs])
+    for b in range(B):
+        q0 = np.concatenate([rng.uniform(-0.8, 0.8, size=3), [0.2 * b]])
+        U = rng.standard_normal((N, system.nu))
+        K = (0.2 * b + 0.3 * np.sin(2.0 * DT * np.arange(1, N + 1)))[:, None]
+        r = rollout(system, q0, U, K, N, deriv_steps=(1, 50, N) if b == 0 else (), second_order=False)
+        for key, val in r.items():
+            arrays["b%d_%s" % (b, key)] = val
+        arrays["b%d_q0" % b] = q0
+        arrays["b%d_U" % b] = U
+        arrays["b%d_K" % b] = K
+    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], arrays["b0_U"], arrays["b0_K"], (0, 10, 100), seed=19,
+                          second_order=False)
+    save("wrench_arm", **arrays, **ds)
+
+
 def gen_discopt_cart():
     """One DOptimizer trace on the pend-on-cart problem of examples/pend-on-cart-optimization.py:48-116
     (torque input enabled, 5 s horizon): a few quasi-Newton then Newton steps; per step the method,
@@ -372,7 +395,7 @@ def gen_discopt_cart():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "discopt"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "discopt"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -387,6 +410,8 @@ if __name__ == "__main__":
         gen_puppet()
     if "puppet_basic" in which:
         gen_puppet_basic()
+    if "wrench_arm" in which:
+        gen_wrench_arm()
     if "plane_link" in which:
         gen_plane_link()
     if "spring_link" in which:

@@ -181,6 +181,9 @@ struct Core {
     TG_HD int n_spair() const { return SPRINGS ? P.n_spair : 0; }
     TG_HD int n_sdh() const { return SPRINGS ? P.n_sdh : 0; }
     TG_HD bool has_plane() const { return SPRINGS && P.has_plane; }   // plane constraints ride on the same switch
+    TG_HD int n_wrenches() const { return SPRINGS ? P.n_wrenches : 0; } // ... and the point forces
+    TG_HD int n_wdh() const { return SPRINGS ? P.n_wdh : 0; }
+    TG_HD int n_wpair() const { return SPRINGS ? P.n_wpair : 0; }
     const DevProg &P;
     double *S;
     int lane;
@@ -458,6 +461,7 @@ struct Core {
             S[P.o_Ldq + i] = ldq; S[P.o_Lddq + i] = lddq;
             double force = -P.damp[i] * S[P.o_dq + i];
             for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
+            if (n_wrenches()) force += S[P.o_wF + i];
             double f = S[P.o_p1 + i] + (0.5 * dt * ldq - lddq) + dt * force;
             for (int c = 0; c < P.nc; c++) {                 // branch-free: a missing entry reads item 0 with weight 0
                 const int n = P.dh_lookup[c * P.nq + i];
@@ -585,6 +589,14 @@ struct Core {
             const double skew = 0.5 * (c_ba - c_ab);                  // exactly 0 for a == b
             lds_add(&A[ca * ld + cb], sym + skew);
             if (ia != ib) lds_add(&A[cb * ld + ca], sym - skew);
+        }
+        if (on) TG_FOR(pp, n_wpair()) {   // D2 fm2 = dt/2 F_dq of the point forces (midpointvi.c:593-600)
+            const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + n_spair() + pp);
+            const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+            if (ka >= nd || kb >= nd) continue;
+            const double a_ = 0.5 * dt * S[P.o_wH + pp];
+            lds_add(&A[ka * ld + kb], a_);
+            if (pw[1] != pw[2]) lds_add(&A[kb * ld + ka], a_);
         }
         if (on) TG_FOR(pp, n_spair()) {   // dt/4 (-V_dqdq) of the two-point springs, from the midpoint evaluation
             const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
@@ -972,6 +984,33 @@ struct Core {
             }
             TG_SYNC();
         }
+        if (n_wrenches()) {   // D1 fm2 = D2 fm2 = dt/2 F_dq into the q1 columns and M2 / the k2 columns; D3 fm2 = dt F_du
+            if (on && lane == 0) {
+                const int m0 = P.n_dh + n_sdh(), p0 = P.n_cpair + n_spair(), c0 = nc + n_springs();
+                for (int pp = 0; pp < n_wpair(); pp++) {
+                    const int *pw = P.cpair4 + 4 * (size_t)(p0 + pp);
+                    const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+                    const double a_ = 0.5 * dt * S[P.o_wH + pp];
+                    auto add = [&](int r, int o) {
+                        if (o >= nd) return;
+                        AUG[o * ld + c_q1 + r] -= a_;
+                        if (r < nd) AUG[o * ld + r] += a_;
+                        else AUG[o * ld + c_k2 + (r - nd)] -= a_;
+                    };
+                    add(ka, kb);
+                    if (pw[1] != pw[2]) add(kb, ka);
+                }
+                for (int n = 0; n < n_wdh(); n++) {
+                    const int m = m0 + n, o = P.dh_cfg[m], w = P.dh_c[m] - c0;
+                    if (o >= nd) continue;
+                    for (int s3 = 0; s3 < 3; s3++) {
+                        const int in = P.wr_in[3 * w + s3];
+                        if (in >= 0) AUG[o * ld + c_u1 + in] -= dt * S[P.o_wD + 3 * n + s3];
+                    }
+                }
+            }
+            TG_SYNC();
+        }
         if (n_springs()) {   // a = dt/4 (-V_dqdq) of the two-point springs enters all four tables like the gravity part of L_qq
             if (on && lane == 0) for (int pp = 0; pp < n_spair(); pp++) {
                 const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
@@ -1197,6 +1236,34 @@ struct Core {
                 const double ddx = -djx / (x * x) * vvi + 1.0 / x * (vj[0] * vi[0] + vj[1] * vi[1] + vj[2] * vi[2]) +
                                    1.0 / x * (v[0] * vij[0] + v[1] * vij[1] + v[2] * vij[2]);
                 sH[pp] = P.s_k[sp] * dix * djx + P.s_k[sp] * (x - P.s_x0[sp]) * ddx;
+            }
+        }
+        TG_SYNC();
+    }
+
+    // Point forces (hybridwrench.c:17-82, force part) at the swept state: generalized force F . dp/dq per dynamic config
+    // into wF, dp/dq per item into wD (the input columns of the derivatives), F . d2p/dq dq per item pair into wH.
+    TG_HD void wrench_terms(bool on) {
+        if (n_wrenches() == 0) return;
+        double *wF = S + P.o_wF, *wH = S + P.o_wH, *wD = S + P.o_wD;
+        const int m0 = P.n_dh + n_sdh(), p0 = P.n_cpair + n_spair(), c0 = P.nc + n_springs();
+        if (on) TG_FOR(i, P.nd) wF[i] = 0.0;
+        TG_SYNC();
+        auto component = [&](int w, int s3) { const int in = P.wr_in[3 * w + s3]; return in >= 0 ? S[P.o_u + in] : P.wr_const[3 * w + s3]; };
+        if (on) {
+            TG_FOR(n, n_wdh()) {
+                const int m = m0 + n, c = P.dh_c[m], k = P.dh_cfg[m], w = c - c0;
+                double dp[3];
+                cdiff1(c, m, dp);
+                wD[3 * n] = dp[0]; wD[3 * n + 1] = dp[1]; wD[3 * n + 2] = dp[2];
+                if (k < P.nd) lds_add(&wF[k], component(w, 0) * dp[0] + component(w, 1) * dp[1] + component(w, 2) * dp[2]);
+            }
+            TG_FOR(pp, n_wpair()) {
+                const int *pw = P.cpair4 + 4 * (size_t)(p0 + pp);
+                const int c = pw[0], w = c - c0;
+                double d2[3];
+                cdiff2(c, pw[1], pw[2], d2);
+                wH[pp] = component(w, 0) * d2[0] + component(w, 1) * d2[1] + component(w, 2) * d2[2];
             }
         }
         TG_SYNC();
@@ -1803,6 +1870,7 @@ struct Core {
         pose_sweep(on, 2);
         attach_points(on, true, true);
         spring_terms(on);
+        wrench_terms(on);
         if (nc) {
             constraints(on, 2, false, S + P.o_Dh2, 0);
             if (on) {
@@ -1848,6 +1916,7 @@ struct Core {
                 for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
                 if (has_cs()) force -= P.cs_k[i] * S[P.o_q2 + i] - P.cs_kq0[i];
                 if (n_springs()) force -= S[P.o_sV + i];
+                if (n_wrenches()) force += S[P.o_wF + i];
                 lds_add(&rhs[i], force);
             }
         }
@@ -1995,6 +2064,21 @@ struct Core {
                 for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) lds_add(&AUG[i * ld + c_u + P.cf_in[k]], 1.0);
                 if (has_cs()) lds_add(&AUG[i * ld + c_q + i], -P.cs_k[i]);
             }
+            TG_FOR(pp, n_wpair()) {
+                const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + n_spair() + pp);
+                const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+                const double h = S[P.o_wH + pp];
+                if (ka < nd) lds_add(&AUG[ka * ld + c_q + kb], h);
+                if (pw[1] != pw[2] && kb < nd) lds_add(&AUG[kb * ld + c_q + ka], h);
+            }
+            TG_FOR(n, n_wdh()) {
+                const int m = P.n_dh + n_sdh() + n, o = P.dh_cfg[m], w = P.dh_c[m] - (nc + n_springs());
+                if (o >= nd) continue;
+                for (int s3 = 0; s3 < 3; s3++) {
+                    const int in = P.wr_in[3 * w + s3];
+                    if (in >= 0) lds_add(&AUG[o * ld + c_u + in], S[P.o_wD + 3 * n + s3]);
+                }
+            }
             TG_FOR(pp, n_spair()) {
                 const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
                 const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
@@ -2046,8 +2130,9 @@ struct Core {
         TG_STAMP(0);
         pose_sweep(on, 0);
         TG_STAMP(1);
-        attach_points(on, true, n_springs() > 0);
+        attach_points(on, true, n_springs() > 0 || n_wrenches() > 0);
         spring_terms(on);
+        wrench_terms(on);
         jacobians(on);
         TG_STAMP(2);
         velocities(on);

@@ -99,8 +99,11 @@ struct DevProg {
     // continuous-dynamics derivative kernel (MODE_DYN_DERIV1): KKT matrix + one column per derivative variable, prefix vectors
     int g_nrhs, g_ld, g_o_AUG, g_o_P, g_o_X, g_o_aF, g_o_x, g_lds_per_team, g_max_cu;
     // plane constraints (TG_CONSTRAINT_PLANE): normal in the coordinates of the plane frame's anchor joint; world normal in LDS
-    const double *c_nloc;   // [3 * (nc + n_springs)]
+    const double *c_nloc;   // [3 * (nc + n_springs + n_wrenches)]
     int has_plane, o_nE;
+    // point forces (HybridWrench, force part): items / pairs follow the springs' in the dh / cpair tables
+    const int *wr_in; const double *wr_const;   // [3 * n_wrenches] input index or -1, constant component
+    int n_wrenches, n_wdh, n_wpair, o_wF, o_wH, o_wD;
     const int *tab_i; const double *tab_d; int n_tab_i, n_tab_d;  // the packed table buffers (all pointers above point into them)
     int e_o_H11, e_o_H12, e_o_H22, e_o_G1, e_o_w, e_o_zq, e_o_zp, e_o_vec, e_o_vec2, e_lds_per_team;
 };
@@ -117,7 +120,8 @@ struct HostProgram {
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
     std::vector<double> c_dist, c_tol;
     std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
-    std::vector<double> damp, cs_k, cs_kq0, s_k, s_x0, c_nloc;
+    std::vector<double> damp, cs_k, cs_kq0, s_k, s_x0, c_nloc, wr_const;
+    std::vector<int> wr_in;
     std::vector<int> cf_cfg, cf_in;
     std::vector<double> jcoef;      // [n_joints*16*4] local-transform coefficients (see pose_sweep)
     int max_depth = 0;
@@ -394,9 +398,29 @@ inline HostProgram build_program(const tg_system_desc *d) {
             H.dh_side.push_back((on1 ? 1 : 0) | (on2 ? 2 : 0));
         }
     }
-    H.cu_off.assign(nc + ns + 1, 0);
+    // point forces (hybridwrench.c, force part): one-ended elements listed after the springs
+    const int n_dh_spr = (int)H.dh_c.size();
+    const int nw = d->n_hybrid_wrenches;
+    for (int w = 0; w < nw; w++) {
+        const int f1 = d->hybrid_wrench_frame[w], c = nc + ns + w;
+        if (f1 < 0 || f1 >= d->n_frames) throw std::runtime_error("hybrid wrench: bad frame index");
+        H.c_type.push_back(9); H.c_e1.push_back(endpoint(f1)); H.c_e2.push_back(endpoint(f1));
+        H.c_nloc.push_back(0.0); H.c_nloc.push_back(0.0); H.c_nloc.push_back(0.0);
+        H.c_cfg.push_back(-1); H.c_comp.push_back(0); H.c_dist.push_back(0.0); H.c_tol.push_back(0.0);
+        for (int s3 = 0; s3 < 3; s3++) {
+            const int in = d->hybrid_wrench_input[3 * w + s3];
+            if (in >= d->n_inputs) throw std::runtime_error("hybrid wrench: bad input index");
+            H.wr_in.push_back(in); H.wr_const.push_back(d->hybrid_wrench_const[3 * w + s3]);
+        }
+        for (int k = 0; k < nq; k++) {
+            if (d->frame_cache_index[(size_t)f1 * (nq + 1) + d->config_gen[k]] != k) continue;
+            H.dh_c.push_back(c); H.dh_cfg.push_back(k); H.dh_joint.push_back(joint_of_cfg[k]); H.dh_side.push_back(1);
+        }
+    }
+    const int nel = nc + ns + nw;
+    H.cu_off.assign(nel + 1, 0);
     for (size_t n = 0; n < H.dh_c.size(); n++) H.cu_off[H.dh_c[n] + 1] = (int)n + 1;
-    for (int c = 0; c < nc + ns; c++) if (H.cu_off[c + 1] < H.cu_off[c]) H.cu_off[c + 1] = H.cu_off[c];
+    for (int c = 0; c < nel; c++) if (H.cu_off[c + 1] < H.cu_off[c]) H.cu_off[c + 1] = H.cu_off[c];
     H.cpath_off.assign(2 * nc + 1, 0);
     H.dh_pos.assign(2 * H.dh_c.size(), -1);
     for (int c = 0; c < nc; c++)
@@ -414,16 +438,17 @@ inline HostProgram build_program(const tg_system_desc *d) {
         H.dh_pack.push_back(H.dh_side[n] | ((j >= 0 ? H.j_kind[j] : 0) << 8) | (H.c_type[c] << 16) | ((H.c_comp[c] & 0xFF) << 24));
         H.dh_pack.push_back(3 * H.c_e1[c]); H.dh_pack.push_back(3 * H.c_e2[c]); H.dh_pack.push_back(H.c_cfg[c]); H.dh_pack.push_back(0);
     }
-    int n_cpair_con = 0;
-    for (int c = 0; c < nc + ns; c++) {
+    int n_cpair_con = 0, n_cpair_spr = 0;
+    for (int c = 0; c <= nel; c++) {
         if (c == nc) n_cpair_con = (int)(H.cpair4.size() / 4);
+        if (c == nc + ns) n_cpair_spr = (int)(H.cpair4.size() / 4);
+        if (c == nel) break;
         for (int na = H.cu_off[c]; na < H.cu_off[c + 1]; na++)
             for (int nb2 = na; nb2 < H.cu_off[c + 1]; nb2++) {
                 H.cpair4.push_back(c); H.cpair4.push_back(na); H.cpair4.push_back(nb2);
                 H.cpair4.push_back(H.dh_cfg[na] | (H.dh_cfg[nb2] << 16));
             }
     }
-    if (ns == 0) n_cpair_con = (int)(H.cpair4.size() / 4);
     // forces / potentials
     H.damp.assign(nd, 0.0);
     for (int i = 0; i < d->n_damping; i++)
@@ -441,10 +466,11 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.nq = nq; P.nd = nd; P.nk = d->n_kin; P.nu = d->n_inputs; P.nc = nc; P.nf = nd + nc; P.nX = nq + nd + d->n_kin;
     P.n_joints = nj; P.n_levels = n_levels; P.n_bodies = nb; P.n_items = nitems; P.n_pairs = (int)H.pair_a.size();
     P.n_endpoints = (int)H.e_anchor.size(); P.n_dh = n_dh_con; P.n_cf = (int)H.cf_cfg.size();
-    P.n_springs = ns; P.n_sdh = (int)H.dh_c.size() - n_dh_con;
+    P.n_springs = ns; P.n_sdh = n_dh_spr - n_dh_con;
+    P.n_wrenches = nw; P.n_wdh = (int)H.dh_c.size() - n_dh_spr;
     P.n_cfgitems = (int)H.cfg_items.size();
     P.n_npairs = (int)(H.pair4.size() / 4);
-    P.n_tri = (int)(H.tri4.size() / 4); P.n_cpair = n_cpair_con; P.n_spair = (int)(H.cpair4.size() / 4) - n_cpair_con;
+    P.n_tri = (int)(H.tri4.size() / 4); P.n_cpair = n_cpair_con; P.n_spair = n_cpair_spr - n_cpair_con; P.n_wpair = (int)(H.cpair4.size() / 4) - n_cpair_spr;
     P.has_cs = d->n_config_springs > 0 ? 1 : 0;
     P.n_cpath = (int)H.cpath_items.size();
     P.grav[0] = P.grav[1] = P.grav[2] = 0.0;
@@ -463,6 +489,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.o_I = take(4 * nb);   // mass and principal inertias of every body (copied from the table once per kernel)
     P.o_ctol = take(nc);    // constraint tolerances, likewise
     P.o_sV = take(ns ? nd : 0); P.o_sH = take(P.n_spair);   // spring gradient per dynamic config, Hessian per item pair (midpoint)
+    P.o_wF = take(nw ? nd : 0); P.o_wH = take(P.n_wpair); P.o_wD = take(3 * P.n_wdh);   // point forces: generalized force, its q-Hessian, dp/dq per item
     // level schedule of the pose sweep: 16 packed words (own offset | parent offset << 16) per level, as ints
     P.n_chains = (int)H.ch_first.size(); P.n_rounds = (int)H.round_off.size() - 1;
     P.sched_ok = (12 * nj < 65536) ? 1 : 0;
@@ -550,8 +577,8 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(level_off) X(lvl_joints) X(round_off) X(ch_first) X(ch_len) X(ch_parent) X(j_parent) X(j_kind) X(j_cfg) X(j_pre_ident) X(b_anchor) X(b_item_off) X(b_pair_off) X(it_body) \
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
-    X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off)
-#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(s_k) X(s_x0) X(c_nloc)
+    X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in)
+#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(s_k) X(s_x0) X(c_nloc) X(wr_const)
 
 inline void HostProgram::pack() {
     ipool.clear(); dpool.clear(); ioff.clear(); doff.clear();

@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 
 from . import frame as _frame
-from .dynamics import Gravity, ConfigSpring, LinearSpring, Damping, ConfigForce, Distance, PointToPoint1D, PointOnPlane
+from .dynamics import Gravity, ConfigSpring, LinearSpring, Damping, ConfigForce, HybridWrench, Distance, PointToPoint1D, PointOnPlane
 
 _I32 = ctypes.POINTER(ctypes.c_int32)
 _F64 = ctypes.POINTER(ctypes.c_double)
@@ -34,7 +34,8 @@ _ARRAYS = [
 
 _TAIL = [("n_config_springs", None), ("config_spring_config", _I32), ("config_spring_k", _F64), ("config_spring_q0", _F64),
          ("n_linear_springs", None), ("linear_spring_frame1", _I32), ("linear_spring_frame2", _I32),
-         ("linear_spring_k", _F64), ("linear_spring_x0", _F64), ("constraint_normal", _F64)]   # in struct order (include/trep_amd.h)
+         ("linear_spring_k", _F64), ("linear_spring_x0", _F64), ("constraint_normal", _F64),
+         ("n_hybrid_wrenches", None), ("hybrid_wrench_frame", _I32), ("hybrid_wrench_input", _I32), ("hybrid_wrench_const", _F64)]   # in struct order (include/trep_amd.h)
 _TAIL_SCALARS = [n for n, t in _TAIL if t is None]
 _TAIL_ARRAYS = [(n, t) for n, t in _TAIL if t is not None]
 
@@ -123,6 +124,7 @@ def flatten(system):
     grav, damp, cf_c, cf_u = [], [], [], []
     cs_c, cs_k, cs_q0 = [], [], []
     ls_f1, ls_f2, ls_k, ls_x0 = [], [], [], []
+    hw_f, hw_in, hw_c = [], [], []
     for pot in system.potentials:
         if isinstance(pot, Gravity):
             grav.append(list(pot._gravity))
@@ -140,6 +142,12 @@ def flatten(system):
     for force in system.forces:
         if isinstance(force, Damping):
             damp.append(force.coefficient_array())
+        elif isinstance(force, HybridWrench):
+            if any(v is not None for v in force._wrench_vars[3:]) or any(c != 0.0 for c in force._wrench_cons[3:]):
+                raise NotImplementedError("HybridWrench torque components are outside the device path's scope")
+            hw_f.append(fidx[id(force.frame)])
+            hw_in += [-1 if v is None else v._index for v in force._wrench_vars[:3]]
+            hw_c += [float(c) for c in force._wrench_cons[:3]]
         elif isinstance(force, ConfigForce):
             cf_c.append(cidx[id(force.config)])
             cf_u.append(force.finput._index)
@@ -161,6 +169,10 @@ def flatten(system):
     t["linear_spring_frame2"] = np.array(ls_f2, dtype=np.int32)
     t["linear_spring_k"] = np.array(ls_k, dtype=np.float64)
     t["linear_spring_x0"] = np.array(ls_x0, dtype=np.float64)
+    t["n_hybrid_wrenches"] = len(hw_f)
+    t["hybrid_wrench_frame"] = np.array(hw_f, dtype=np.int32)
+    t["hybrid_wrench_input"] = np.array(hw_in, dtype=np.int32)
+    t["hybrid_wrench_const"] = np.array(hw_c, dtype=np.float64)
 
     ctype, cf1, cf2, ccfg, ccomp, cdist, ctol = [], [], [], [], [], [], []
     cnormal = []

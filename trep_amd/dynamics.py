@@ -201,6 +201,41 @@ class ConfigForce(Force):
     config = property(lambda self: self._config)
 
 
+class HybridWrench(Force):
+    """A wrench applied at a frame, force in world coordinates and torque in body coordinates; every component is a
+    constant or a new input (forces/hybridwrench.py:15-33).  The device path implements the force part."""
+
+    def __init__(self, system, frame, wrench=tuple(), name=None):
+        Force.__init__(self, system, name)
+        if not system.get_frame(frame):
+            raise ValueError("Could not find frame %r" % frame)
+        self._frame = system.get_frame(frame)
+        wrench = (list(wrench) + [0.0] * 6)[:6]
+        self._wrench_vars = [None] * 6
+        self._wrench_cons = [0.0] * 6
+        for i in range(6):
+            if isinstance(wrench[i], str):
+                self._wrench_vars[i] = self._create_input(wrench[i])
+            else:
+                self._wrench_cons[i] = float(wrench[i])
+        system._structure_changed()
+
+    frame = property(lambda self: self._frame)
+
+    @property
+    def wrench_val(self):
+        return [v.u if v is not None else c for (v, c) in zip(self._wrench_vars, self._wrench_cons)]
+
+    @wrench_val.setter
+    def wrench_val(self, wrench):
+        for i, value in enumerate(wrench[:6]):
+            if self._wrench_vars[i] is not None:
+                self._wrench_vars[i].u = value
+            else:
+                self._wrench_cons[i] = float(value)
+        self._system._structure_changed()
+
+
 class Constraint(object):
     def __init__(self, system, name=None, tolerance=1e-10):
         self._system = system

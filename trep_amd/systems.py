@@ -126,6 +126,28 @@ def plane_link(api=None):
     return system
 
 
+def wrench_arm(api=None):
+    """A 3-D arm on a kinematic slider pushed around by HybridWrench forces (world-frame force at a frame's origin):
+    one with two input components and a constant one at the hand, a constant one at the fore-arm; plus damping and a
+    ConfigForce.  Synthetic test system."""
+    T = _api(api)
+    system = T.System()
+    system.import_frames([
+        T.tx('slide', name='Base', kinematic=True), [
+            T.rz('a', name='Shoulder'), [
+                T.tx(1.0, name='Upper', mass=2.0), [
+                    T.ry('b', name='Elbow'), [
+                        T.tx(0.8, name='Fore', mass=(1.0, 0.1, 0.2, 0.3)), [
+                            T.rx('c', name='Wrist'), [
+                                T.tz(-0.5, name='Hand', mass=0.5)]]]]]]])
+    T.potentials.Gravity(system, (0, 0, -9.8))
+    T.forces.HybridWrench(system, 'Hand', ('hand-fx', 2.0, 'hand-fz', 0, 0, 0), name='hand')
+    T.forces.HybridWrench(system, 'Fore', (0, 1.0, -1.0), name='fore')
+    T.forces.ConfigForce(system, 'a', 'a-torque')
+    T.forces.Damping(system, 0.1)
+    return system
+
+
 def scissor_lift(segments=4, theta_0=0.05 * math.pi, m_link=1.0, I_link=1.0, L_link=5.0, m_slider=1.0,
                  api=None):
     """Scissor lift at its analytic closed configuration (no constraint solver needed)."""
