@@ -338,6 +338,27 @@ def gen_wrench_arm():
     save("wrench_arm", **arrays, **ds)
 
 
+def gen_puppet_forces():
+    """Puppet(string_forces=True) under seeded random string forces: rollout and first derivatives."""
+    system = systems.puppet_forces(api=trep)
+    rng = np.random.default_rng(20250 + 10)
+    N = 100
+    arrays = dict(dt=DT, **topology(system))
+    arrays["input_names"] = np.array([str(u.name) for u in system.inputs])
+    system.q = 0.0
+    system.q = systems.PUPPET_BASE_POSE
+    q0 = system.q
+    U = 0.5 * rng.standard_normal((N, system.nu))
+    U[:, 2::3] += 3.0          # some lift on every hook
+    K = np.zeros((N, 0))
+    r = rollout(system, q0, U, K, N, deriv_steps=(1, 50), second_order=False)
+    for key, val in r.items():
+        arrays["b0_" + key] = val
+    arrays["b0_q0"] = q0
+    arrays["b0_U"] = U
+    save("puppet_forces", **arrays)
+
+
 def gen_discopt_cart():
     """One DOptimizer trace on the pend-on-cart problem of examples/pend-on-cart-optimization.py:48-116
     (torque input enabled, 5 s horizon): a few quasi-Newton then Newton steps; per step the method,
@@ -395,7 +416,7 @@ def gen_discopt_cart():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "discopt"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "discopt"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -410,6 +431,8 @@ if __name__ == "__main__":
         gen_puppet()
     if "puppet_basic" in which:
         gen_puppet_basic()
+    if "puppet_forces" in which:
+        gen_puppet_forces()
     if "wrench_arm" in which:
         gen_wrench_arm()
     if "plane_link" in which:

@@ -11,7 +11,7 @@ nc=6, 86 frames, 10 masses.
 """
 from .system import System
 from .frame import rx, ry, rz, tx, ty, tz, const_txyz
-from .dynamics import Gravity, Damping, ConfigForce, Distance
+from .dynamics import Gravity, Damping, ConfigForce, HybridWrench, Distance
 
 # Lengths from motion-capture data; inertia entries are [M, Ixx, Iyy, Izz].
 DEFAULT_DIMENSIONS = {
@@ -147,7 +147,7 @@ class Puppet(System):
         if joint_forces:
             self.make_joint_forces()
         if string_forces:
-            raise NotImplementedError("string_forces needs HybridWrench, which is outside the hot-path scope")
+            self.make_string_forces()
         if string_constraints:
             self.make_string_constraints()
         Gravity(self, (0, 0, -9.8))
@@ -164,6 +164,13 @@ class Puppet(System):
     def make_joint_forces(self):
         for config in self.dyn_configs:
             self.joint_forces[config.name] = ConfigForce(self, config, config.name, config.name)
+
+    def make_string_forces(self):
+        """A world-frame force with three inputs at every string hook (puppets.py:276-288)."""
+        for name, hook in self.string_hooks.items():
+            force = {'name': name, 'x': name + '-x', 'y': name + '-y', 'z': name + '-z', 'hook': hook}
+            HybridWrench(self, hook, (force['x'], force['y'], force['z'], 0, 0, 0), name=name)
+            self.string_forces[name] = force
 
     def make_string_constraints(self):
         for name, hook in self.string_hooks.items():

@@ -148,6 +148,13 @@ def wrench_arm(api=None):
     return system
 
 
+def puppet_forces(api=None):
+    """Puppet(string_forces=True): the marionette driven by a world-frame force with three inputs at each of its six
+    string hooks instead of kinematic strings (22 dynamic configs, 18 inputs, no constraints)."""
+    T = _api(api)
+    return T.puppets.Puppet(joint_forces=False, string_forces=True, string_constraints=False)
+
+
 def scissor_lift(segments=4, theta_0=0.05 * math.pi, m_link=1.0, I_link=1.0, L_link=5.0, m_slider=1.0,
                  api=None):
     """Scissor lift at its analytic closed configuration (no constraint solver needed)."""
