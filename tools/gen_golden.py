@@ -359,6 +359,20 @@ def gen_puppet_forces():
     save("puppet_forces", **arrays)
 
 
+def gen_extensor_tendon():
+    """examples/extensor-tendon-model.py run as the script does (tf = 10, dt = 0.01), plus first derivatives."""
+    system = systems.extensor_tendon(api=trep)
+    N = 1000
+    arrays = dict(dt=DT, **topology(system))
+    q0 = system.q
+    U = np.zeros((N, 0)); K = np.zeros((N, 0))
+    r = rollout(system, q0, U, K, N, deriv_steps=(1, 500), second_order=False)
+    for key, val in r.items():
+        arrays["b0_" + key] = val
+    arrays["b0_q0"] = q0
+    save("extensor_tendon", **arrays)
+
+
 def gen_discopt_cart():
     """One DOptimizer trace on the pend-on-cart problem of examples/pend-on-cart-optimization.py:48-116
     (torque input enabled, 5 s horizon): a few quasi-Newton then Newton steps; per step the method,
@@ -416,7 +430,7 @@ def gen_discopt_cart():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "discopt"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "discopt"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -433,6 +447,8 @@ if __name__ == "__main__":
         gen_puppet_basic()
     if "puppet_forces" in which:
         gen_puppet_forces()
+    if "extensor_tendon" in which:
+        gen_extensor_tendon()
     if "wrench_arm" in which:
         gen_wrench_arm()
     if "plane_link" in which:

@@ -155,6 +155,46 @@ def puppet_forces(api=None):
     return T.puppets.Puppet(joint_forces=False, string_forces=True, string_constraints=False)
 
 
+EXTENSOR_TENDON_POSE = {
+    "theta-1": 0.5, "theta-2": 0.0, "theta-3": -0.5, "theta-4": -1.0, "theta-5": 0.5, "theta-6": -0.5, "theta-8": 0.0,
+    "theta-9": 0.5, "x-1": -1.0, "x-2": -1.0, "x-3": -1.0, "x-4": -1.0, "x-5": -1.0, "x-6": -1.0, "x-8": -1.0, "x-9": -1.0,
+}
+
+
+def extensor_tendon(api=None):
+    """examples/extensor-tendon-model.py:15-56: a planar network of nine linear springs (the tendon) pulled by three
+    constant muscle forces (HybridWrench), heavy damping, no gravity; it settles into a steady state."""
+    T = _api(api)
+    tz, rx = T.tz, T.rx
+    system = T.System()
+    system.import_frames([
+        rx('theta-1'), [
+            tz('x-1', name='A', mass=1), [
+                rx('theta-2'), [
+                    tz('x-2', name='B', mass=1), [
+                        rx('theta-3'), [
+                            tz('x-3', name='C', mass=1)]]],
+                rx('theta-4'), [
+                    tz('x-4', name='D', mass=1), [
+                        rx('theta-5'), [
+                            tz('x-5', name='E', mass=1)]]]]],
+        rx('theta-6'), [
+            tz('x-6', name='F', mass=1), [
+                rx('theta-8'), [
+                    tz('x-8', name='H', mass=1), [
+                        rx('theta-9'), [
+                            tz('x-9', name='I', mass=1)]]]]]])
+    for a, b in (("World", "A"), ("A", "B"), ("B", "C"), ("A", "D"), ("D", "E"), ("World", "F"), ("F", "D"), ("F", "H"),
+                 ("H", "I")):
+        T.potentials.LinearSpring(system, a, b, 10.0, 1.0)
+    T.forces.Damping(system, 4.0)
+    T.forces.HybridWrench(system, 'C', (0, 1, -1))
+    T.forces.HybridWrench(system, 'E', (0, 0, -1.414))
+    T.forces.HybridWrench(system, 'I', (0, -1, -1))
+    system.q = EXTENSOR_TENDON_POSE
+    return system
+
+
 def scissor_lift(segments=4, theta_0=0.05 * math.pi, m_link=1.0, I_link=1.0, L_link=5.0, m_slider=1.0,
                  api=None):
     """Scissor lift at its analytic closed configuration (no constraint solver needed)."""
