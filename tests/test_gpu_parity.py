@@ -131,7 +131,9 @@ def test_residual_matches_oracle():
         assert relerr(f[b], o.calc_f()) < 1e-12
 
 
-@pytest.mark.parametrize("name,B,N", [("puppet40", 48, 40), ("scissor4", 33, 60), ("pend_on_cart", 67, 100)])
+@pytest.mark.parametrize("name,B,N", [("puppet40", 48, 40), ("scissor4", 33, 60), ("pend_on_cart", 67, 100),
+                                      ("spring_arm", 37, 80), ("spring_link", 29, 60), ("wrench_arm", 41, 80),
+                                      ("extensor_tendon", 21, 100)])
 def test_random_batch_matches_oracle(name, B, N):
     """Seeded random initial conditions / inputs, HIP vs oracle, ragged batch sizes."""
     from oracle.oracle import OracleMVI
@@ -147,10 +149,16 @@ def test_random_batch_matches_oracle(name, B, N):
         th = rng.uniform(0.03 * np.pi, 0.12 * np.pi, B)
         Q0 = np.array([systems.scissor_q(system, t) for t in th])
         K = np.zeros((B, N, 0)); U = np.zeros((B, N, 0))
-    else:
+    elif name == "pend_on_cart":
         Q0 = np.stack([rng.uniform(-1, 1, B), rng.uniform(-np.pi, np.pi, B)], 1)
         U = rng.standard_normal((B, N, 1)) * 2.0
         K = np.zeros((B, N, 0))
+    else:   # the synthetic systems of the spring / wrench types: random poses around the builder's, random inputs
+        Q0 = system.q[None] + 0.3 * rng.standard_normal((B, nq))
+        if name == "spring_link":
+            Q0[:, system.get_config('e').index] = -1.0        # on the distance constraint
+        U = rng.standard_normal((B, N, nu))
+        K = Q0[:, None, nd:] + 0.2 * np.sin(3.0 * DT * np.arange(1, N + 1))[None, :, None] * np.ones((1, 1, nk))
     mvi = _batch(system, B)
     mvi.initialize_from_configs(0.0, Q0, DT, Q0)
     X = mvi.rollout(N, DT, U, K)
