@@ -84,8 +84,7 @@ typedef struct tg_system_desc {
      * (constraints/plane.c:13-26) */
     const double  *constraint_normal;    /* [n_constraints*3] plane normal n in plane-frame coordinates (others: zeros) */
     /* forces/hybridwrench.c, force part: a force with world-frame components applied at the origin of a frame; each
-     * component is an input or a constant.  (Torque components are not supported: the host layer rejects them.)
-     * Second derivatives of the step map are not available for systems with such forces (TG_ERR_UNSUPPORTED). */
+     * component is an input or a constant.  (Torque components are not supported: the host layer rejects them.) */
     int32_t n_hybrid_wrenches;
     const int32_t *hybrid_wrench_frame;  /* [n_hybrid_wrenches] */
     const int32_t *hybrid_wrench_input;  /* [n_hybrid_wrenches*3] input index of fx, fy, fz, or -1 for a constant */

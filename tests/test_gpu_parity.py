@@ -322,7 +322,7 @@ def test_deriv1_accessors_dropin():
     assert mvi.q2_dk2().shape == (2, 0)
 
 
-@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "pendulum5", "spring_arm", "plane_link"])
+@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "pendulum5", "spring_arm", "plane_link", "wrench_arm", "puppet_forces"])
 def test_dsystem_linearization_matches_reference(name):
     """DSystem.set(X[k],U[k],k,xk_hint=X[k+1]) -> f, fdx (A_k), fdu (B_k) vs the reference's DSystem."""
     import trep_amd
@@ -351,7 +351,7 @@ def test_dsystem_linearization_matches_reference(name):
     assert lin.A.shape == (3, one.nX, one.nX) and lin.B.shape == (3, one.nX, one.nU)
 
 
-@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "pendulum5", "spring_arm", "plane_link"])
+@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "pendulum5", "spring_arm", "plane_link", "wrench_arm", "puppet_forces"])
 def test_dsystem_second_order_matches_reference(name):
     """fdxdx(z), fdxdu(z), fdudu(z) vs the reference DSystem (dsystem.py:320-386) for two z."""
     import trep_amd
@@ -375,7 +375,7 @@ def test_dsystem_second_order_matches_reference(name):
     assert np.array_equal(xx[0], xx[2])
 
 
-@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "puppet_basic", "spring_arm", "plane_link"])
+@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "puppet_basic", "spring_arm", "plane_link", "wrench_arm", "puppet_forces"])
 def test_full_second_derivative_tensors_match_reference(name):
     """MidpointVI.q2_dq1dq1() ... p2_dk2dk2(), lambda1_dq1dq1() ... accessors vs the reference's [A][B][out] tensors."""
     import trep_amd
@@ -418,8 +418,9 @@ def test_second_derivatives_undefined_with_linear_springs():
         mvi.q2_dq1dq1()
 
 
-def test_second_derivatives_not_implemented_with_hybrid_wrench():
-    """The force second derivatives of HybridWrench (f_dqdq, f_dudq) are not implemented: the entry points say so."""
+def test_hybrid_wrench_inputs_and_second_derivatives():
+    """HybridWrench: input ordering, the configuration-dependent input columns and the input blocks of the second
+    derivatives (D1D3fm2 / D2D3fm2) through the drop-in accessors."""
     import trep_amd
     g = golden("wrench_arm")
     system, d = build("wrench_arm")
@@ -429,5 +430,5 @@ def test_second_derivatives_not_implemented_with_hybrid_wrench():
     mvi.step(2 * DT, g["b0_U"][0], g["b0_K"][0])
     assert relerr(mvi.q2, g["b0_Q"][1]) < 1e-10
     assert relerr(mvi.q2_du1(), g["b0_d1_1_q2_du1"].T) < 1e-9
-    with pytest.raises(Exception, match="HybridWrench"):
-        mvi.q2_dq1dq1()
+    for nm in ("q2_dq1du1", "p2_dq1du1", "q2_du1du1", "p2_du1dk2", "q2_dp1du1", "q2_dq1dq1"):
+        assert relerr(getattr(mvi, nm)(), g["b0_d2_1_" + nm]) < 1e-8, nm

@@ -316,8 +316,7 @@ def gen_plane_link():
 
 
 def gen_wrench_arm():
-    """Synthetic system with HybridWrench forces.  First derivatives only: the build does not implement the force
-    second derivatives (f_dqdq, f_dudq)."""
+    """Synthetic system with HybridWrench forces: rollouts, first and full second derivative tensors, DSystem captures."""
     system = systems.wrench_arm(api=trep)
     rng = np.random.default_rng(20250 + 9)
     B, N = 2, 200
@@ -327,14 +326,13 @@ def gen_wrench_arm():
         q0 = np.concatenate([rng.uniform(-0.8, 0.8, size=3), [0.2 * b]])
         U = rng.standard_normal((N, system.nu))
         K = (0.2 * b + 0.3 * np.sin(2.0 * DT * np.arange(1, N + 1)))[:, None]
-        r = rollout(system, q0, U, K, N, deriv_steps=(1, 50, N) if b == 0 else (), second_order=False)
+        r = rollout(system, q0, U, K, N, deriv_steps=(1, 50, N) if b == 0 else (), deriv2_full=True)
         for key, val in r.items():
             arrays["b%d_%s" % (b, key)] = val
         arrays["b%d_q0" % b] = q0
         arrays["b%d_U" % b] = U
         arrays["b%d_K" % b] = K
-    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], arrays["b0_U"], arrays["b0_K"], (0, 10, 100), seed=19,
-                          second_order=False)
+    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], arrays["b0_U"], arrays["b0_K"], (0, 10, 100), seed=19)
     save("wrench_arm", **arrays, **ds)
 
 
@@ -351,12 +349,13 @@ def gen_puppet_forces():
     U = 0.5 * rng.standard_normal((N, system.nu))
     U[:, 2::3] += 3.0          # some lift on every hook
     K = np.zeros((N, 0))
-    r = rollout(system, q0, U, K, N, deriv_steps=(1, 50), second_order=False)
+    r = rollout(system, q0, U, K, N, deriv_steps=(1, 50), deriv2_select=("q2_dq1dq1", "p2_dq1du1", "q2_du1du1", "q2_dp1du1", "p2_dq1dq1"))
     for key, val in r.items():
         arrays["b0_" + key] = val
     arrays["b0_q0"] = q0
     arrays["b0_U"] = U
-    save("puppet_forces", **arrays)
+    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], U, K, (0, 10, 50), seed=20)
+    save("puppet_forces", **arrays, **ds)
 
 
 def gen_extensor_tendon():

@@ -184,6 +184,7 @@ struct Core {
     TG_HD int n_wrenches() const { return SPRINGS ? P.n_wrenches : 0; } // ... and the point forces
     TG_HD int n_wdh() const { return SPRINGS ? P.n_wdh : 0; }
     TG_HD int n_wpair() const { return SPRINGS ? P.n_wpair : 0; }
+    const double *d2w = nullptr;   // adjoint weights while the second-derivative kernel evaluates the midpoint, else null
     const DevProg &P;
     double *S;
     int lane;
@@ -1264,6 +1265,25 @@ struct Core {
                 double d2[3];
                 cdiff2(c, pw[1], pw[2], d2);
                 wH[pp] = component(w, 0) * d2[0] + component(w, 1) * d2[1] + component(w, 2) * d2[2];
+                if (d2w) {   // second-derivative kernel: sum_o w_o F_dqdq(o; a, b) and -dt/2 sum_o w_o F_dudq(o, u; a)
+                    const int na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+                    double acc = 0.0;
+                    for (int no = P.cu_off[c]; no < P.cu_off[c + 1]; no++) {
+                        const int ko = P.dh_cfg[no];
+                        if (ko >= P.nd) continue;
+                        double d3[3];
+                        cdiff3(c, na, nb, no, d3);
+                        acc += d2w[ko] * (component(w, 0) * d3[0] + component(w, 1) * d3[1] + component(w, 2) * d3[2]);
+                    }
+                    S[P.e_o_wT + pp] = acc;
+                    double *Hu = S + P.e_o_Hu;
+                    for (int s3 = 0; s3 < 3; s3++) {
+                        const int in = P.wr_in[3 * w + s3];
+                        if (in < 0) continue;
+                        if (kb < P.nd) lds_add(&Hu[ka * P.nu + in], -0.5 * dt * d2w[kb] * d2[s3]);
+                        if (na != nb && ka < P.nd) lds_add(&Hu[kb * P.nu + in], -0.5 * dt * d2w[ka] * d2[s3]);
+                    }
+                }
             }
         }
         TG_SYNC();
@@ -1591,7 +1611,23 @@ struct Core {
         }
         TG_D2STAMP(0);
         // ---- midpoint: third-order discrete-Lagrangian tables contracted on the fly --------------------------
+        if (n_wrenches()) {   // the point forces' second derivatives are contracted while the midpoint poses are alive
+            if (on) TG_FOR(i, nq * nu) S[P.e_o_Hu + i] = 0.0;
+            TG_SYNC();
+            d2w = w;
+        }
         eval_midpoint(on);
+        d2w = nullptr;
+        if (on) TG_FOR(pp, n_wpair()) {   // D_a D_b fm2 = dt/4 F_dqdq in all three slot combinations (midpointvi.c:1473-1497)
+            const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + n_spair() + pp);
+            const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+            const double val = -0.25 * dt * S[P.e_o_wT + pp];
+            lds_add(&H12[ka * hl + kb], val);
+            if (pw[1] != pw[2]) lds_add(&H12[kb * hl + ka], val);
+            lds_add(&H11[sym(ka, kb)], val);
+            lds_add(&H22[sym(ka, kb)], val);
+        }
+        TG_SYNC();
         TG_D2STAMP(1);
         const double c8 = 0.125 * dt, c2 = 0.5 / dt;
         if (P.n_tchunk > 0) {
@@ -1808,6 +1844,32 @@ struct Core {
                 }
             }
             TG_SYNC();
+        }
+        if (n_wrenches() && nu > 0) {
+            // input blocks of the point forces: D1D3fm2 = D2D3fm2 = dt/2 F_dudq (midpointvi.c:1500-1512) couple an input
+            // column with the total configuration tangent of the other variable:  HZ[a][u] += sum_i (dq1_i/da + dq2_i/da) Hu[i][u]
+            // and symmetrically.  Added to the finished matrix (rare path: read-modify-write of this trajectory's HZ).
+#if defined(__HIP_DEVICE_COMPILE__)
+            __threadfence();
+            __syncthreads();
+#endif
+            const double *Hu = S + P.e_o_Hu;
+            const int c_u = nq + nd;
+            if (on && ok) TG_FOR(idx, R * nu) {
+                const int a = idx / nu, m = idx % nu;
+                double corr = 0.0;
+                for (int i = 0; i < nd; i++) corr += AUG[i * ld + nf + a] * Hu[i * nu + m];
+                if (a < nq) corr += Hu[a * nu + m];
+                if (a >= first_k2) corr += Hu[(nd + (a - first_k2)) * nu + m];
+                double *hz = A.hz + t * (size_t)R * R;
+#if defined(__HIP_DEVICE_COMPILE__)
+                atomicAdd(&hz[(size_t)a * R + (c_u + m)], corr);
+                atomicAdd(&hz[(size_t)(c_u + m) * R + a], corr);
+#else
+                hz[(size_t)a * R + (c_u + m)] += corr;
+                hz[(size_t)(c_u + m) * R + a] += corr;
+#endif
+            }
         }
         TG_D2STAMP(3);
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)

@@ -103,7 +103,7 @@ struct DevProg {
     int has_plane, o_nE;
     // point forces (HybridWrench, force part): items / pairs follow the springs' in the dh / cpair tables
     const int *wr_in; const double *wr_const;   // [3 * n_wrenches] input index or -1, constant component
-    int n_wrenches, n_wdh, n_wpair, o_wF, o_wH, o_wD;
+    int n_wrenches, n_wdh, n_wpair, o_wF, o_wH, o_wD, e_o_wT, e_o_Hu;
     const int *tab_i; const double *tab_d; int n_tab_i, n_tab_d;  // the packed table buffers (all pointers above point into them)
     int e_o_H11, e_o_H12, e_o_H22, e_o_G1, e_o_w, e_o_zq, e_o_zp, e_o_vec, e_o_vec2, e_lds_per_team;
 };
@@ -555,6 +555,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     off = P.d_o_T12;
     P.e_o_H11 = take(nq * (nq + 1) / 2); P.e_o_H22 = take(nq * (nq + 1) / 2); P.e_o_H12 = take(nq * (nq | 1)); P.e_o_G1 = take(nq * nc);
     P.e_o_w = take(P.nf); P.e_o_zq = take(nd); P.e_o_zp = take(nd); P.e_o_vec = take(12 * nq); P.e_o_vec2 = P.e_o_vec;   // tangent products of four columns: [3][4][nq]
+    P.e_o_wT = take(P.n_wpair); P.e_o_Hu = take(nw ? nq * P.nu : 0);   // point forces: w-contracted F.d3p per pair, -dt/2 w.F_dudq [nq][nu]
     off = std::max(off, P.d_lds_per_team);
     P.e_lds_per_team = (off + 1) & ~1;
     H.pack();
