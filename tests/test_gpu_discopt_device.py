@@ -283,3 +283,46 @@ def test_batch_optimizer_matches_sequential_puppet():
                 assert relerr(X[s], Xr) < 1e-7 and relerr(U[s], Ur) < 1e-7, (i, s, relerr(X[s], Xr))
     finally:
         opt.close()
+
+
+def test_batch_optimizer_matches_sequential_wrench_arm():
+    """Inputs that enter through HybridWrench forces and a kinematic config: the Newton steps exercise the input blocks
+    of the contracted second derivatives (D1D3fm2 / D2D3fm2) inside the device-resident optimiser."""
+    import trep_amd
+    from trep_amd import discopt, systems
+    from common import golden as gold
+    g = gold("wrench_arm")
+    system = systems.wrench_arm()
+    N, S, dt = 60, 3, 0.01
+    t = dt * np.arange(N + 1)
+    dsys = discopt.DSystem(trep_amd.MidpointVI(system), t)
+    X_all, U_all = g["ds_X"], g["ds_U"]                      # a true trajectory of the reference rollout
+    rng = np.random.default_rng(4)
+    Xd = np.repeat(X_all[None, :N + 1], S, axis=0)
+    Ud = np.repeat(U_all[None, :N], S, axis=0)
+    X0, U0 = [], []
+    for s in range(S):                                        # initial guesses: projections of perturbed copies
+        bX = Xd[s] + 0.02 * rng.standard_normal(Xd[s].shape)
+        bU = Ud[s] + 0.2 * rng.standard_normal(Ud[s].shape)
+        bX[0] = Xd[s][0]
+        pX, pU = dsys.project(bX, bU)
+        X0.append(pX); U0.append(pU)
+    X0, U0 = np.array(X0), np.array(U0)
+    Q = np.diag(rng.uniform(0.5, 2.0, dsys.nX))
+    R = np.diag(rng.uniform(0.05, 0.2, dsys.nU))
+    methods = ["quasi", "newton", "newton"]
+    ref = _sequential_steps(dsys, Xd, Ud, Q, R, X0, U0, methods)
+    opt = discopt.BatchDOptimizer(dsys, Xd, Ud, Q, R, armijo_chunk=4)
+    try:
+        opt.set_trajectories(X0, U0)
+        for i, m in enumerate(methods):
+            r = opt.step(m)
+            X, U = opt.get_trajectories()
+            for s in range(S):
+                c0, dc0, c1, Xr, Ur = ref[s][i]
+                assert abs(r.cost0[s] - c0) < 1e-9 * max(1.0, abs(c0)), (i, s)
+                assert abs(r.dcost0[s] - dc0) < 1e-6 * max(1.0, abs(dc0)), (i, s, r.dcost0[s], dc0)
+                assert abs(r.cost1[s] - c1) < 1e-7 * max(1.0, abs(c1)), (i, s, r.cost1[s], c1)
+                assert relerr(X[s], Xr) < 1e-6 and relerr(U[s], Ur) < 1e-6, (i, s, relerr(X[s], Xr))
+    finally:
+        opt.close()
