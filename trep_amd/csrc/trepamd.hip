@@ -136,7 +136,13 @@ int launch_variant(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
 // systems with spring potentials run their own instantiation of every kernel (mvi_core.hpp, Core<TEAM, SPRINGS>)
 template <int TEAM, int MODE>
 int launch_one(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
+#if defined(TG_PROFILE)   // the diagnostic build only instruments the plain kernels of full-wave teams (fewer instantiations)
+    if (TEAM != 64 || b->P.has_cs || b->P.n_springs || b->P.has_plane || b->P.n_wrenches)
+        return fail(TG_ERR_UNSUPPORTED, "the profiling build covers full-wave teams without spring / plane / wrench features");
+    return launch_variant<64, MODE, false>(b, A, grid, lds);
+#else
     return (b->P.has_cs || b->P.n_springs || b->P.has_plane || b->P.n_wrenches) ? launch_variant<TEAM, MODE, true>(b, A, grid, lds) : launch_variant<TEAM, MODE, false>(b, A, grid, lds);
+#endif
 }
 
 template <int TEAM>
@@ -147,8 +153,10 @@ int launch_team(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
     case tg::MODE_CALC_F: return launch_one<TEAM, tg::MODE_CALC_F>(b, A, grid, lds);
     case tg::MODE_DERIV1: return launch_one<TEAM, tg::MODE_DERIV1>(b, A, grid, lds);
     case tg::MODE_DERIV2Z: return launch_one<TEAM, tg::MODE_DERIV2Z>(b, A, grid, lds);
+#if !defined(TG_PROFILE)   // the continuous-dynamics modes are not instrumented (and not instantiated) in the diagnostic build
     case tg::MODE_DYNAMICS: return launch_one<TEAM, tg::MODE_DYNAMICS>(b, A, grid, lds);
     case tg::MODE_DYN_DERIV1: return launch_one<TEAM, tg::MODE_DYN_DERIV1>(b, A, grid, lds);
+#endif
     default: return fail(TG_ERR_INVALID, "unknown kernel mode");
     }
 }
