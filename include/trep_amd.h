@@ -262,6 +262,10 @@ int tg_batch_dynamics_deriv1(tg_batch *b, const double *q_host, const double *dq
                              int32_t *status_host);
 int tg_batch_dynamics_deriv1_device(tg_batch *b, const double *q_dev, const double *dq_dev, const double *u_dev,
                                     const double *ddqk_dev, double *const out_dev[8], int32_t *status_dev);
+/* Kinetic and potential energy of every state of the batch: energy[b] = {T, V} with T = sum over the massive frames of
+ * 1/2 <v_b, I v_b> and V the sum of the potentials, so that System.L() = T - V and System.total_energy() = T + V
+ * (System_L / System_total_energy, system.c:78-127).  q, dq [B][nq]; energy [B][2]. */
+int tg_batch_energy(tg_batch *b, const double *q_host, const double *dq_host, double *energy_host);
 
 /* DSystem.set(X[s][k], U[s][k], k, xk_hint = X[s][k+1]) for every (s, k) at once (reference
  * trep/discopt/dsystem.py:229-251 as used by linearize_trajectory, :406-423, and calc_newton_model,

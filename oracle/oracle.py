@@ -44,6 +44,7 @@ def lib():
         L.to_rollout.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
                                  ctypes.c_void_p, ctypes.c_int]
         L.to_dynamics.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6
+        L.to_energy.argtypes = [ctypes.c_void_p] * 4
         L.to_dynamics_deriv1.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 12
         _LIB = L
     return _LIB
@@ -190,6 +191,14 @@ class OracleMVI(object):
                                f.ctypes.data, lam.ctypes.data):
             raise OracleError("singular")
         return f[:self.nd], lam[:self.nc]
+
+    def energy(self, q, dq):
+        """(kinetic, potential) energy at (q, dq) (system.c:78-127)."""
+        q = np.ascontiguousarray(q, dtype=float)
+        dq = np.ascontiguousarray(dq, dtype=float)
+        out = np.zeros(2)
+        self._L.to_energy(self._h, q.ctypes.data, dq.ctypes.data, out.ctypes.data)
+        return float(out[0]), float(out[1])
 
     def dynamics_deriv1(self, q, dq, u=None, ddqk=None):
         """First derivatives of the continuous dynamics (system.c:912-1299) in the layout of the reference's accessors

@@ -22,7 +22,7 @@ class RunArgs(ctypes.Structure):
                 ("q1", _D), ("q2", _D), ("p1", _D), ("p2", _D), ("lam", _D), ("u1", _D),
                 ("U", _D), ("K", _D), ("q2_hint", _D), ("lam_hint", _D), ("Kproj", _D), ("bX", _D), ("bU", _D), ("Uout", _D), ("group_size", ctypes.c_int), ("group_map", _I), ("X", _D), ("f_out", _D),
                 ("d1", _D * 12), ("A_out", _D), ("B_out", _D), ("z", _D), ("hz", _D), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p),
-                ("zl", _D), ("dq_in", _D), ("ddqk_in", _D), ("ddq_out", _D), ("lam_out", _D), ("g1", _D * 8)]
+                ("zl", _D), ("dq_in", _D), ("ddqk_in", _D), ("ddq_out", _D), ("lam_out", _D), ("g1", _D * 8), ("energy_out", _D)]
 
 
 def lib():
@@ -145,6 +145,17 @@ class EmuBatch(object):
         a.dq_in, a.ddqk_in, a.ddq_out, a.lam_out = _p(dQ), _p(ddK), _p(ddq), _p(lam)
         self.L.emu_run(self.h, ctypes.byref(a))
         return ddq, lam, self.status.copy()
+
+    def energy(self, Q, dQ):
+        """[B][2]: kinetic and potential energy of every state."""
+        Q = np.ascontiguousarray(Q, dtype=float)
+        dQ = np.ascontiguousarray(dQ, dtype=float)
+        out = np.zeros((self.B, 2))
+        a = self._args(7)
+        a.q1 = a.q2 = _p(Q)
+        a.dq_in, a.energy_out = _p(dQ), _p(out)
+        self.L.emu_run(self.h, ctypes.byref(a))
+        return out
 
     def dynamics_deriv1(self, Q, dQ, U=None, ddK=None):
         """First derivatives of the continuous dynamics, in the layout of the reference's accessors

@@ -137,3 +137,41 @@ def test_gpu_dynamics_first_derivatives_match_reference(name):
     ddq, lam, st = eng.dynamics(Qp, g[name + "_dq"][s], g[name + "_u"][s], g[name + "_ddqk"][s])
     fd = (ddq[0] - ddq[1]) / (2 * h)
     assert relerr(fd, g[name + "_f_dq"][s][:, 0]) < 1e-5
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_energies_match_reference(name):
+    from oracle.oracle import OracleMVI
+    g = golden()
+    _, d = build(name)
+    o = OracleMVI(d)
+    for s in range(len(g[name + "_q"])):
+        T, V = o.energy(g[name + "_q"][s], g[name + "_dq"][s])
+        assert abs((T + V) - g[name + "_E"][s]) < 1e-11 * max(1.0, abs(g[name + "_E"][s])), (name, s)
+        assert abs((T - V) - g[name + "_L"][s]) < 1e-11 * max(1.0, abs(g[name + "_L"][s])), (name, s)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_emulated_kernel_energies_match_reference(name):
+    from emu_harness import EmuBatch
+    g = golden()
+    _, d = build(name)
+    e = EmuBatch(d, len(g[name + "_q"]))
+    TV = e.energy(g[name + "_q"], g[name + "_dq"])
+    assert relerr(TV[:, 0] + TV[:, 1], g[name + "_E"]) < 1e-11 and relerr(TV[:, 0] - TV[:, 1], g[name + "_L"]) < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_energies_match_reference(name):
+    import trep_amd
+    g = golden()
+    system, d = build(name)
+    n = len(g[name + "_q"])
+    eng = trep_amd.BatchMidpointVI(system, n)
+    TV = eng.energy(g[name + "_q"], g[name + "_dq"])
+    assert relerr(TV[:, 0] + TV[:, 1], g[name + "_E"]) < 1e-11 and relerr(TV[:, 0] - TV[:, 1], g[name + "_L"]) < 1e-11
+    eng.close()
+    system.q, system.dq = g[name + "_q"][3], g[name + "_dq"][3]
+    assert abs(system.total_energy() - g[name + "_E"][3]) < 1e-10 * max(1.0, abs(g[name + "_E"][3]))
+    assert abs(system.L() - g[name + "_L"][3]) < 1e-10 * max(1.0, abs(g[name + "_L"][3]))

@@ -44,7 +44,7 @@ def main():
         picks = np.linspace(1, len(Q) - 1, N_STATES).astype(int)
         nq, nd, nk, nu, nc = system.nQ, system.nQd, system.nQk, system.nu, system.nc
         qs, dqs, us, ddks = [], [], [], []
-        for key in ("f", "lam", "f_dq", "f_ddq", "f_dddk", "f_du", "lam_dq", "lam_ddq", "lam_dddk", "lam_du"):
+        for key in ("E", "L", "f", "lam", "f_dq", "f_ddq", "f_dddk", "f_du", "lam_dq", "lam_ddq", "lam_dddk", "lam_du"):
             out["%s_%s" % (name, key)] = []
         for k in picks:
             q = Q[k][:nq]
@@ -53,6 +53,8 @@ def main():
             ddk = rng.standard_normal(nk)
             system.q, system.dq, system.u, system.ddqk = q, dq, u, ddk
             qs.append(q); dqs.append(dq); us.append(u); ddks.append(ddk)
+            out[name + "_E"].append(system.total_energy())
+            out[name + "_L"].append(system.L())
             out[name + "_f"].append(system.f())
             out[name + "_lam"].append(system.lambda_())
             out[name + "_f_dq"].append(system.f_dq())

@@ -64,7 +64,7 @@ extern "C" __device__ __attribute__((const)) unsigned int __ockl_wfred_max_u32(u
 
 namespace tg {
 
-enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3, MODE_DERIV2Z = 4, MODE_DYNAMICS = 5, MODE_DYN_DERIV1 = 6 };
+enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3, MODE_DERIV2Z = 4, MODE_DYNAMICS = 5, MODE_DYN_DERIV1 = 6, MODE_ENERGY = 7 };
 
 struct RunArgs {
     int batch, n_steps, max_iterations, mode, first_is_init;
@@ -93,6 +93,7 @@ struct RunArgs {
     double *ddq_out, *lam_out;             // MODE_DYNAMICS: accelerations of the dynamic configs [batch][nd], constraint forces [batch][nc]
     double *g1[8];                         // MODE_DYN_DERIV1: f_dq, f_ddq [batch][nq][nd], f_dk [batch][nk][nd], f_du [batch][nu][nd], then the
                                            // same four for lambda ([..][nc]); derivative variable first, like the reference's arrays
+    double *energy_out;                    // MODE_ENERGY: [batch][2] kinetic and potential energy at (q, dq_in)
 };
 
 // sin and cos together for joint angles.  |x| < 2^17: three-constant Cody-Waite reduction to [-pi/4, pi/4]
@@ -2006,6 +2007,40 @@ struct Core {
         return ok;
     }
 
+    // Kinetic and potential energy at (q, dq) (System_total_energy / System_L, system.c:78-127): T = sum 1/2 <v_F, I v_F>,
+    // V = -sum m g.p_F + config springs + two-point springs.  One lane per term, summed through an LDS atomic.
+    TG_HD void energy(bool on, const RunArgs &A, size_t t) {
+        double *acc = S + P.o_f;   // [0] = T, [1] = V
+        if (on) {
+            TG_FOR(i, P.nq) S[P.o_dq + i] = A.dq_in[t * P.nq + i];
+            if (lane == 0) { acc[0] = 0.0; acc[1] = 0.0; }
+        }
+        TG_SYNC();
+        pose_sweep(on, 2);
+        attach_points(on, true, n_springs() > 0);
+        jacobians(on);
+        velocities(on);
+        if (on) {
+            TG_FOR(b, P.n_bodies) {
+                const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gb = S + P.o_gB + 12 * b;
+                lds_add(&acc[0], 0.5 * inner6(I, v, v));
+                lds_add(&acc[1], -I[0] * (P.grav[0] * gb[3] + P.grav[1] * gb[7] + P.grav[2] * gb[11]));
+            }
+            if (has_cs()) TG_FOR(i, P.nq) {
+                const double q = S[P.o_q2 + i];
+                lds_add(&acc[1], 0.5 * P.cs_k[i] * q * q - P.cs_kq0[i] * q + P.cs_c0[i]);
+            }
+            TG_FOR(sp, n_springs()) {
+                const int c = P.nc + sp;
+                const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
+                const double x = sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
+                lds_add(&acc[1], 0.5 * P.s_k[sp] * (x - P.s_x0[sp]) * (x - P.s_x0[sp]));
+            }
+        }
+        TG_SYNC();
+        if (on && lane == 0) { A.energy_out[2 * t] = acc[0]; A.energy_out[2 * t + 1] = acc[1]; }
+    }
+
     // =====================================================================================================
     // First derivatives of the continuous dynamics (reference calc_dynamics_deriv1, system.c:912-1299): d(ddq_d, lambda)
     // / d(q, dq, ddq_k, u).  With r = D - M ddq_d + Ad^T lambda = 0 and g = A ddq + dq^T H dq = 0 solved by `dynamics`,
@@ -2250,6 +2285,10 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
     }
     if constexpr (MODE == MODE_DERIV2Z) {
         core.deriv2z(live, A, t);
+        return;
+    }
+    if constexpr (MODE == MODE_ENERGY) {
+        core.energy(live, A, t);
         return;
     }
     if constexpr (MODE == MODE_DYN_DERIV1) {

@@ -94,6 +94,7 @@ struct DevProg {
     const int *cu_off;        // [nc+1] dh items of each constraint (its dependent configs)
     // spring potentials, kept near the end: the spring-free kernels' argument layout stays what it was
     const double *cs_k, *cs_kq0;  // [nq] config springs: sum k and sum k q0 per config (V_dq = cs_k q - cs_kq0)
+    const double *cs_c0;          // [nq] 1/2 sum k q0^2 (constant part of V)
     const double *s_k, *s_x0;     // [n_springs]
     int n_springs, n_sdh, n_spair, o_sV, o_sH, has_cs;   // two-point springs: dh items / pairs follow the constraints' in the same tables
     // continuous-dynamics derivative kernel (MODE_DYN_DERIV1): KKT matrix + one column per derivative variable, prefix vectors
@@ -120,7 +121,7 @@ struct HostProgram {
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
     std::vector<double> c_dist, c_tol;
     std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
-    std::vector<double> damp, cs_k, cs_kq0, s_k, s_x0, c_nloc, wr_const;
+    std::vector<double> damp, cs_k, cs_kq0, cs_c0, s_k, s_x0, c_nloc, wr_const;
     std::vector<int> wr_in;
     std::vector<int> cf_cfg, cf_in;
     std::vector<double> jcoef;      // [n_joints*16*4] local-transform coefficients (see pose_sweep)
@@ -453,11 +454,12 @@ inline HostProgram build_program(const tg_system_desc *d) {
     H.damp.assign(nd, 0.0);
     for (int i = 0; i < d->n_damping; i++)
         for (int k = 0; k < nd; k++) H.damp[k] += d->damping[(size_t)i * nd + k];
-    H.cs_k.assign(nq, 0.0); H.cs_kq0.assign(nq, 0.0);
+    H.cs_k.assign(nq, 0.0); H.cs_kq0.assign(nq, 0.0); H.cs_c0.assign(nq, 0.0);
     for (int i = 0; i < d->n_config_springs; i++) {
         const int c = d->config_spring_config[i];
         if (c < 0 || c >= nq) throw std::runtime_error("config spring: bad config index");
         H.cs_k[c] += d->config_spring_k[i]; H.cs_kq0[c] += d->config_spring_k[i] * d->config_spring_q0[i];
+        H.cs_c0[c] += 0.5 * d->config_spring_k[i] * d->config_spring_q0[i] * d->config_spring_q0[i];
     }
     for (int i = 0; i < d->n_config_forces; i++) {
         H.cf_cfg.push_back(d->config_force_config[i]); H.cf_in.push_back(d->config_force_input[i]);
@@ -579,7 +581,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
     X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in)
-#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(s_k) X(s_x0) X(c_nloc) X(wr_const)
+#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const)
 
 inline void HostProgram::pack() {
     ipool.clear(); dpool.clear(); ioff.clear(); doff.clear();

@@ -59,6 +59,7 @@ struct tg_batch {
     double *z_dev = nullptr, *hz_dev = nullptr, *zl_dev = nullptr;
     double *dyn = nullptr;     // staging of the host-facing continuous-dynamics call: q, dq, u, ddq_k, ddq, lambda
     double *dyn_d1 = nullptr;  // ... and of its eight first-derivative arrays
+    double *energy = nullptr;  // [batch][2] output of tg_batch_energy
     int *dyn_ints = nullptr;   // its status / iteration words (the integrator's own stay untouched)
     double *d1[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool have_d1 = false;
@@ -156,6 +157,7 @@ int launch_team(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
 #if !defined(TG_PROFILE)   // the continuous-dynamics modes are not instrumented (and not instantiated) in the diagnostic build
     case tg::MODE_DYNAMICS: return launch_one<TEAM, tg::MODE_DYNAMICS>(b, A, grid, lds);
     case tg::MODE_DYN_DERIV1: return launch_one<TEAM, tg::MODE_DYN_DERIV1>(b, A, grid, lds);
+    case tg::MODE_ENERGY: return launch_one<TEAM, tg::MODE_ENERGY>(b, A, grid, lds);
 #endif
     default: return fail(TG_ERR_INVALID, "unknown kernel mode");
     }
@@ -335,7 +337,7 @@ void tg_batch_destroy(tg_batch *b) {
     for (auto &e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : b->pool) hipEventDestroy(e);
     void *ptrs[] = {b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
-                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev, b->zl_dev, b->dyn, b->dyn_ints, b->dyn_d1,
+                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev, b->zl_dev, b->dyn, b->dyn_ints, b->dyn_d1, b->energy,
                     b->d1[0], b->d1[1], b->d1[2], b->d1[3], b->d1[4], b->d1[5], b->d1[6], b->d1[7], b->d1[8], b->d1[9], b->d1[10], b->d1[11]};
     for (void *p : ptrs) if (p) hipFree(p);
     if (b->stream && b->own_stream) hipStreamDestroy(b->stream);
@@ -604,6 +606,27 @@ int tg_batch_dynamics_device(tg_batch *b, const double *q_dev, const double *dq_
     A.dq_in = dq_dev; A.ddqk_in = ddqk_dev; A.ddq_out = ddq_dev; A.lam_out = lambda_dev;
     A.iters = b->dyn_ints; A.status = status_dev ? status_dev : b->dyn_ints + b->batch;
     return launch(b, A);
+}
+
+int tg_batch_energy(tg_batch *b, const double *q_host, const double *dq_host, double *energy_host) {
+    if (!b || !q_host || !dq_host || !energy_host) return fail(TG_ERR_INVALID, "null argument");
+    const tg::DevProg &P = b->P;
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t B = (size_t)b->batch, nq = P.nq;
+    const size_t in_total = B * (2 * nq + P.nu + P.nk + P.nd + P.nc);   // the staging block of the dynamics calls (>= 2 B nq + 2 B)
+    if (!b->dyn) HIP_TRY(hipMalloc(&b->dyn, (in_total ? in_total : 1) * sizeof(double)));
+    if (!b->dyn_ints) HIP_TRY(hipMalloc(&b->dyn_ints, 2 * B * sizeof(int)));
+    if (!b->energy) HIP_TRY(hipMalloc(&b->energy, 2 * B * sizeof(double)));
+    double *q = b->dyn, *dq = q + B * nq;
+    HIP_TRY(hipMemcpyAsync(q, q_host, B * nq * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(dq, dq_host, B * nq * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    tg::RunArgs A = base_args(b, tg::MODE_ENERGY);
+    A.q1 = A.q2 = q; A.dq_in = dq; A.energy_out = b->energy;
+    A.iters = b->dyn_ints; A.status = b->dyn_ints + b->batch;
+    if (int rc = launch(b, A)) return rc;
+    HIP_TRY(hipMemcpyAsync(energy_host, b->energy, 2 * B * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return TG_SUCCESS;
 }
 
 int tg_batch_dynamics_deriv1_device(tg_batch *b, const double *q_dev, const double *dq_dev, const double *u_dev, const double *ddqk_dev,

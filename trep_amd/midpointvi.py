@@ -275,6 +275,16 @@ class BatchMidpointVI(object):
                                              _lib.ptr(ddq), _lib.ptr(lam), status.ctypes.data))
         return ddq, lam, status
 
+    def energy(self, Q, dQ):
+        """Kinetic and potential energy of B states: [B][2] = (T, V); the reference's System.L() is T - V and
+        System.total_energy() T + V (system.py:844-850)."""
+        B = self._batch
+        Q = _lib.as_f64(np.broadcast_to(np.asarray(Q, dtype=float), (B, self.nq)), (B, self.nq))
+        dQ = _lib.as_f64(np.broadcast_to(np.asarray(dQ, dtype=float), (B, self.nq)), (B, self.nq))
+        out = np.zeros((B, 2))
+        _lib.check(self._L.tg_batch_energy(self._h, _lib.ptr(Q), _lib.ptr(dQ), _lib.ptr(out)))
+        return out
+
     DYN_D1_NAMES = ("f_dq", "f_ddq", "f_dddk", "f_du", "lambda_dq", "lambda_ddq", "lambda_dddk", "lambda_du")
 
     def dynamics_deriv1(self, Q, dQ, U=None, ddQk=None):

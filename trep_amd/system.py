@@ -284,9 +284,7 @@ class System(object):
         return self.q
 
     # -- continuous dynamics (system.py:951-959, 1018-1024 of the reference; calc_dynamics system.c:749-893) --------
-    def _dynamics(self):
-        """Accelerations and constraint forces at the current (q, dq, u, ddqk): one launch of the dynamics kernel
-        on a batch of one.  Like the reference, the result is also stored in the dynamic configs' ddq."""
+    def _dynamics_engine(self):
         from .midpointvi import BatchMidpointVI
         eng = getattr(self, "_dyn_engine", None)
         if eng is None or self._dyn_engine_version != self._structure_version:
@@ -294,6 +292,12 @@ class System(object):
                 eng.close()
             eng = self._dyn_engine = BatchMidpointVI(self, 1)
             self._dyn_engine_version = self._structure_version
+        return eng
+
+    def _dynamics(self):
+        """Accelerations and constraint forces at the current (q, dq, u, ddqk): one launch of the dynamics kernel
+        on a batch of one.  Like the reference, the result is also stored in the dynamic configs' ddq."""
+        eng = self._dynamics_engine()
         ddq, lam, status = eng.dynamics(self.q[None], self.dq[None], self.u[None], self.ddqk[None])
         if status[0] != 0:
             raise ValueError("singular inertia or constraint matrix")   # LU_decomp failure in the reference
@@ -311,6 +315,20 @@ class System(object):
     def lambda_(self, constraint=None):
         lam = self._dynamics()[1]
         return lam if constraint is None else float(lam[constraint.index])
+
+    def _energies(self):
+        self._dynamics_engine()
+        return self._dyn_engine.energy(self.q[None], self.dq[None])[0]
+
+    def total_energy(self):
+        """Kinetic plus potential energy at the current state (system.py:844-846)."""
+        T, V = self._energies()
+        return float(T + V)
+
+    def L(self):
+        """The Lagrangian at the current state (system.py:848-850)."""
+        T, V = self._energies()
+        return float(T - V)
 
     def _dynamics_deriv1(self):
         self._dynamics()                      # engine + the reference's side effect on Config.ddq
