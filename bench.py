@@ -172,6 +172,9 @@ def main():
     ap.add_argument("--no-x", action="store_true", help="do not write the state trajectory X to HBM")
     ap.add_argument("--system", choices=["puppet", "puppet-basic", "cart", "scissor"], default="puppet",
                     help="puppet = the BASELINE metric; cart / scissor = secondary lines")
+    ap.add_argument("--predictor", choices=["reference", "extrapolate"], default="reference",
+                    help="Newton initial guess of the rollout; 'reference' (default) keeps the reference's semantics and "
+                         "iteration counts, 'extrapolate' is an opt-in warm start (reported separately, not the headline)")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank (self-test)")
     args = ap.parse_args()
 
@@ -199,6 +202,7 @@ def main():
         args.no_cpu_baseline = True
     B, N = args.batch, args.rollout_steps
     mvi = trep_amd.BatchMidpointVI(system, B, device=local_rank)
+    mvi.predictor = args.predictor
     nX, nU, nc = mvi.nX, mvi.nU, mvi.nc
     K_dev = mvi.device_array(K) if K is not None else None
     U_dev = mvi.device_array(U) if U is not None else None
@@ -269,7 +273,7 @@ def main():
                        "global_batch": world * B, "rollout_steps": N, "parallelism": "batch-shard x%d" % world,
                        "team": mvi.info()["team"], "lds_bytes_per_trajectory": mvi.info()["lds_bytes_per_trajectory"],
                        "newton_iterations_per_step": total_iters / float(B * N), "failed_trajectories": n_failed,
-                       "writes_X": not args.no_x},
+                       "writes_X": not args.no_x, "newton_initial_guess": args.predictor},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,

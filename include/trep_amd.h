@@ -262,6 +262,12 @@ int tg_batch_dynamics_deriv1(tg_batch *b, const double *q_host, const double *dq
                              int32_t *status_host);
 int tg_batch_dynamics_deriv1_device(tg_batch *b, const double *q_dev, const double *dq_dev, const double *u_dev,
                                     const double *ddqk_dev, double *const out_dev[8], int32_t *status_dev);
+/* Initial guess of the Newton iteration in the device-resident rollouts.  0 (default): the reference's, q2 <- the previous
+ * q2 (midpointvi.py:188-197) -- iteration counts then match the reference's.  1: constant-velocity extrapolation
+ * q2 + (q2 - q1); same root to within the solver tolerance, about one Newton iteration fewer per step.  An opt-in
+ * that departs from the reference's iteration-by-iteration behaviour; the headline benchmark uses 0. */
+int tg_batch_set_predictor(tg_batch *b, int32_t mode);
+
 /* Kinetic and potential energy of every state of the batch: energy[b] = {T, V} with T = sum over the massive frames of
  * 1/2 <v_b, I v_b> and V the sum of the potentials, so that System.L() = T - V and System.total_energy() = T + V
  * (System_L / System_total_energy, system.c:78-127).  q, dq [B][nq]; energy [B][2]. */

@@ -16,7 +16,7 @@ _I = ctypes.POINTER(ctypes.c_int)
 
 class RunArgs(ctypes.Structure):
     _fields_ = [("batch", ctypes.c_int), ("n_steps", ctypes.c_int), ("max_iterations", ctypes.c_int),
-                ("mode", ctypes.c_int), ("first_is_init", ctypes.c_int),
+                ("mode", ctypes.c_int), ("predictor", ctypes.c_int),
                 ("dt", ctypes.c_double), ("t1", ctypes.c_double), ("t2", ctypes.c_double),
                 ("tolerance", ctypes.c_double),
                 ("q1", _D), ("q2", _D), ("p1", _D), ("p2", _D), ("lam", _D), ("u1", _D),

@@ -432,3 +432,29 @@ def test_hybrid_wrench_inputs_and_second_derivatives():
     assert relerr(mvi.q2_du1(), g["b0_d1_1_q2_du1"].T) < 1e-9
     for nm in ("q2_dq1du1", "p2_dq1du1", "q2_du1du1", "p2_du1dk2", "q2_dp1du1", "q2_dq1dq1"):
         assert relerr(getattr(mvi, nm)(), g["b0_d2_1_" + nm]) < 1e-8, nm
+
+
+def test_extrapolating_predictor_same_trajectory_fewer_iterations():
+    """The opt-in warm start q2 + (q2 - q1) reaches the same root: trajectories agree with the reference-semantics
+    rollout to solver tolerance, Newton iterations per step drop."""
+    from trep_amd import systems
+    system, d = build("puppet40")
+    B, N = 64, 100
+    nd = d.n_dyn
+    Q0 = systems.puppet_initial_conditions(system, B, seed=3)
+    K = systems.puppet_string_schedule(system, Q0[:, nd:], N, DT)
+    out = {}
+    for mode in ("reference", "extrapolate"):
+        mvi = _batch(system, B)
+        mvi.predictor = mode
+        assert mvi.predictor == mode
+        mvi.initialize_from_configs(0.0, Q0, DT, Q0)
+        X = mvi.rollout(N, DT, None, K)
+        iters, status = mvi.status()
+        assert (status == 0).all()
+        out[mode] = (X, iters.mean() / N)
+        mvi.close()
+    assert relerr(out["extrapolate"][0], out["reference"][0]) < 1e-9
+    assert out["extrapolate"][1] < out["reference"][1] - 0.3
+    with pytest.raises(ValueError):
+        _batch(system, 1).predictor = "nonsense"

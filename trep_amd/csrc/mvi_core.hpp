@@ -67,7 +67,8 @@ namespace tg {
 enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3, MODE_DERIV2Z = 4, MODE_DYNAMICS = 5, MODE_DYN_DERIV1 = 6, MODE_ENERGY = 7 };
 
 struct RunArgs {
-    int batch, n_steps, max_iterations, mode, first_is_init;
+    int batch, n_steps, max_iterations, mode;
+    int predictor;                         // rollout: 0 = the reference's initial guess q2 <- previous q2 (midpointvi.py:188-197), 1 = q2 + (q2 - q1)
     double dt, t1, t2, tolerance;
     double *q1, *q2, *p1, *p2, *lam, *u1;  // batch state, row-major [batch][width]
     const double *U, *K;                   // [batch][n_steps][nu], [batch][n_steps][nk]
@@ -2350,7 +2351,11 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
         }
         // advance: q1 <- q2, (p1 already holds p2), inputs, kinematic targets, hints (midpointvi.py:188-197)
         if (on) {
-            TG_FOR(i, nq) S[P.o_q1 + i] = S[P.o_q2 + i];
+            TG_FOR(i, nq) {
+                const double prev = S[P.o_q1 + i], cur = S[P.o_q2 + i];
+                S[P.o_q1 + i] = cur;
+                if (A.predictor && i < nd) S[P.o_q2 + i] = 2.0 * cur - prev;   // opt-in warm start: constant-velocity extrapolation
+            }
             TG_FOR(i, nu) S[P.o_u + i] = A.Kproj ? S[P.o_nu + i] : A.U[(t * A.n_steps + step) * nu + i];
             // the momentum entering the last step is the state's p1 afterwards (midpointvi.py:189)
             if (step == A.n_steps - 1) TG_FOR(i, nd) A.p1[t * nd + i] = S[P.o_p1 + i];

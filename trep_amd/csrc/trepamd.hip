@@ -68,6 +68,7 @@ struct tg_batch {
     double snap_t1 = 0.0, snap_t2 = 0.0;
     long long total_iters = 0;
     double t1 = 0.0, t2 = 0.0, tolerance = 1.0e-10;
+    int predictor = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -205,7 +206,7 @@ int ensure_deriv_buffers(tg_batch *b, bool first, bool second) {
 tg::RunArgs base_args(tg_batch *b, int mode) {
     tg::RunArgs A{};
     A.batch = b->batch; A.mode = mode; A.max_iterations = 200;
-    A.t1 = b->t1; A.t2 = b->t2; A.tolerance = b->tolerance;
+    A.t1 = b->t1; A.t2 = b->t2; A.tolerance = b->tolerance; A.predictor = b->predictor;
     A.q1 = b->q1; A.q2 = b->q2; A.p1 = b->p1; A.p2 = b->p2; A.lam = b->lam; A.u1 = b->u1;
     A.iters = b->iters; A.status = b->status; A.f_out = b->f_out;
     A.prof_out = b->prof;
@@ -606,6 +607,12 @@ int tg_batch_dynamics_device(tg_batch *b, const double *q_dev, const double *dq_
     A.dq_in = dq_dev; A.ddqk_in = ddqk_dev; A.ddq_out = ddq_dev; A.lam_out = lambda_dev;
     A.iters = b->dyn_ints; A.status = status_dev ? status_dev : b->dyn_ints + b->batch;
     return launch(b, A);
+}
+
+int tg_batch_set_predictor(tg_batch *b, int32_t mode) {
+    if (!b || mode < 0 || mode > 1) return fail(TG_ERR_INVALID, "predictor mode must be 0 or 1");
+    b->predictor = mode;
+    return TG_SUCCESS;
 }
 
 int tg_batch_energy(tg_batch *b, const double *q_host, const double *dq_host, double *energy_host) {

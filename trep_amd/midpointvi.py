@@ -275,6 +275,20 @@ class BatchMidpointVI(object):
                                              _lib.ptr(ddq), _lib.ptr(lam), status.ctypes.data))
         return ddq, lam, status
 
+    @property
+    def predictor(self):
+        """Initial guess of the rollouts' Newton iteration: "reference" (q2 <- previous q2, the reference's semantics
+        and iteration counts) or "extrapolate" (q2 + (q2 - q1): same trajectory to solver tolerance, fewer iterations)."""
+        return getattr(self, "_predictor", "reference")
+
+    @predictor.setter
+    def predictor(self, mode):
+        modes = {"reference": 0, "extrapolate": 1}
+        if mode not in modes:
+            raise ValueError("predictor must be one of %r" % sorted(modes))
+        _lib.check(self._L.tg_batch_set_predictor(self._h, modes[mode]))
+        self._predictor = mode
+
     def energy(self, Q, dQ):
         """Kinetic and potential energy of B states: [B][2] = (T, V); the reference's System.L() is T - V and
         System.total_energy() T + V (system.py:844-850)."""
