@@ -72,7 +72,8 @@ def run_batched(args):
     Xd, Ud, Xi, Ui = Xd[lo:hi], Ud[lo:hi], Xi[lo:hi], Ui[lo:hi]
     S = hi - lo
     dsys = discopt.DSystem(trep_amd.MidpointVI(system, device=local_rank), dt * np.arange(N + 1))
-    opt = discopt.BatchDOptimizer(dsys, Xd, Ud, Qc, Rc, device=local_rank, armijo_chunk=args.armijo_chunk)
+    opt = discopt.BatchDOptimizer(dsys, Xd, Ud, Qc, Rc, device=local_rank, armijo_chunk=args.armijo_chunk,
+                                  predictor=args.predictor)
     L = _lib.lib()
     methods = ["quasi"] * args.quasi + ["newton"] * args.newton
     opt.set_trajectories(Xi, Ui)
@@ -121,7 +122,8 @@ def run_batched(args):
         "metric": "discopt iterations/s (puppet ~40-DOF, fp64)", "value": iters / elapsed, "unit": "iters/s",
         "n_gpus": world, "dtype": "f64", "data": "synthetic", "scaling": "strong",
         "config": {"workload": "puppet-optimization.py problem, nX=80 nU=18, N=%d, %d seeds batched on the device (%d per GPU), %d quasi + %d newton steps each"
-                               % (N, args.seeds, S, args.quasi, args.newton), "armijo_chunk": opt.M},
+                               % (N, args.seeds, S, args.quasi, args.newton), "armijo_chunk": opt.M,
+                   "newton_initial_guess": args.predictor},
         "mean_final_cost_all_seeds": float(np.mean(final_cost)),
         "s_per_batched_quasi_step": float(np.mean(per["quasi"])) if per["quasi"] else None,
         "s_per_batched_newton_step": float(np.mean(per["newton"])) if per["newton"] else None,
@@ -178,6 +180,8 @@ def main():
     ap.add_argument("--newton", type=int, default=2)
     ap.add_argument("--armijo-chunk", type=int, default=None)
     ap.add_argument("--stages", action="store_true", help="also report per-stage times of one Newton step")
+    ap.add_argument("--predictor", choices=["reference", "extrapolate"], default="reference",
+                    help="Newton initial guess of the Armijo projections (default: the reference's)")
     ap.add_argument("--sequential", action="store_true")
     args = ap.parse_args()
     (run_sequential if args.sequential else run_batched)(args)

@@ -84,7 +84,8 @@ class BatchDOptimizer(object):
 
     step_return = namedtuple("batch_step", "done cost0 dcost0 cost1 method armijo failed")
 
-    def __init__(self, dsys, Xd, Ud, Q, R, Qf=None, device=0, armijo_chunk=None, first_method_iterations=10):
+    def __init__(self, dsys, Xd, Ud, Q, R, Qf=None, device=0, armijo_chunk=None, first_method_iterations=10,
+                 predictor="reference"):
         self.dsys = dsys
         ds = dsys
         Xd = np.asarray(Xd, dtype=float)
@@ -119,6 +120,7 @@ class BatchDOptimizer(object):
         self.M = int(armijo_chunk)
         self.lin = BatchMidpointVI(sysm, S * N, device=device)
         self.arm = BatchMidpointVI(sysm, S * self.M, device=device)
+        self.arm.predictor = predictor    # Newton start of the Armijo projections ("extrapolate": opt-in warm start)
         # device state
         self.Xd, self.Ud = pool.upload(Xd), pool.upload(Ud)
         self.Q = pool.upload(np.asarray(Q, dtype=float).reshape(nX, nX))
