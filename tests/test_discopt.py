@@ -122,3 +122,26 @@ def test_closed_loop_rollout_equals_host_feedback_loop():
         x = one.f()
         assert relerr(nU[1, k], u) < 1e-9
         assert relerr(nX[0, k + 1], x) < 1e-9
+
+
+@pytest.mark.gpu
+def test_descent_model_validators_and_monitors(capsys):
+    """check_dcost / check_ddcost (doptimizer.py:621-674), armijo_simulate and the monitor helpers on the pend-on-cart
+    problem: the first and second directional derivatives of the cost agree with finite differences of projections."""
+    import trep_amd
+    from trep_amd import discopt
+    g, system, cost = _problem()
+    dsys = discopt.DSystem(trep_amd.MidpointVI(system), g["t"])
+    opt = discopt.DOptimizer(dsys, cost, monitor=discopt.DOptimizerVerboseMonitor())
+    X, U = g["X0"].copy(), g["U0"].copy()
+    for method in ("quasi", "newton"):
+        r = opt.check_dcost(X, U, method, delta=1e-5, tolerance=1e-4 * abs(opt.calc_dcost(X, U, *opt.calc_descent_direction(X, U, method)[1:3])))
+        assert r.result, (method, r)
+    r = opt.check_ddcost(X, U, "newton", delta=1e-5, tolerance=1e-3 * abs(g["it0_dcost0"][0]))
+    assert abs(r.error) <= 1e-3 * abs(r.exact_ddcost), r
+    Kproj = opt.calc_descent_direction(X, U, "quasi").Kproj
+    ok = opt.armijo_simulate(X, U, Kproj)
+    assert ok.success and relerr(ok.nX, X) < 1e-9
+    (done, X1, U1, dcost0, cost1) = opt.step(0, X, U, "quasi")
+    assert opt.monitor.get_costs()[-1] > cost1 and opt.monitor.get_dcosts()[-1] == dcost0
+    assert "Armijo evaluation" in capsys.readouterr().out

@@ -60,6 +60,43 @@ class DOptimizerDefaultMonitor(DOptimizerMonitor):
         self.cost_history[self.iteration] = cost
         self.dcost_history[self.iteration] = dcost
 
+    def get_costs(self):
+        return [self.cost_history[i] for i in sorted(self.cost_history)]
+
+    def get_dcosts(self):
+        return [self.dcost_history[i] for i in sorted(self.dcost_history)]
+
+    def msg(self, text):
+        import datetime
+        print("%s %3d: %s" % (datetime.datetime.now().strftime('[%H:%M:%S]'), self.iteration, text))
+
+
+class DOptimizerVerboseMonitor(DOptimizerDefaultMonitor):
+    """Prints what the optimiser does (doptimizer.py:180-246)."""
+
+    def optimize_begin(self, X, U):
+        self.msg("Optimization starting")
+
+    def optimize_end(self, converged, X, U, cost):
+        self.msg("Optimization completed%s, cost %f" % ("" if converged else " (not converged)", cost))
+
+    def step_info(self, method, cost, dcost, X, U, dX, dU, Kproj):
+        self.msg("Current Trajectory cost: %f, dcost: %f, method=%s" % (cost, dcost, method))
+        DOptimizerDefaultMonitor.step_info(self, method, cost, dcost, X, U, dX, dU, Kproj)
+
+    def step_method_failure(self, method, cost, dcost, fallback_method):
+        self.msg("Descent method %r failed (dcost %f), falling back to %r" % (method, dcost, fallback_method))
+
+    def step_termination(self, cost, dcost):
+        self.msg("Optimization terminated: cost %f, dcost %f" % (cost, dcost))
+
+    def armijo_evaluation(self, armijo_iteration, nX, nU, bX, bU, cost, max_cost):
+        verdict = "is too expensive" if cost >= max_cost else "is acceptable"
+        self.msg("  Armijo evaluation (%d) %s (%f vs %f)" % (armijo_iteration, verdict, cost, max_cost))
+
+    def armijo_simulation_failure(self, armijo_iteration, nX, nU, bX, bU):
+        self.msg("  Armijo simulation (%d) failed" % armijo_iteration)
+
 
 class DOptimizer(object):
     def __init__(self, dsys, cost, first_method_iterations=10, monitor=None, device=0):
@@ -83,6 +120,9 @@ class DOptimizer(object):
         self.model_return = namedtuple('descent_model', 'Q R S')
         self.descent_return = namedtuple('calc_descent_direction', 'Kproj dX dU Q R S')
         self.armijo_search_return = namedtuple('armijo_search', 'nX nU cost1')
+        self.armijo_simulate_return = namedtuple('armijo_simulate', 'success nX nU')
+        self.check_dcost_return = namedtuple('check_dcost', 'result error cost1 cost0 approx_dcost exact_dcost')
+        self.check_ddcost_return = namedtuple('check_ddcost', 'result error cost1 cost0 approx_ddcost exact_ddcost')
         self._device = device
         self._lin = None      # batch over the horizon (k-parallel linearisation, deriv2 contraction)
         self._arm = None      # batch over the Armijo candidates
@@ -270,6 +310,46 @@ class DOptimizer(object):
         (X, U, cost1) = self.armijo_search(X, U, Kproj, dX, dU)
         self.monitor.step_completed(method, cost1, X, U)
         return self.step_return(False, X, U, dcost0, cost1)
+
+    def armijo_simulate(self, bX, bU, Kproj):
+        """Project (bX, bU) like DSystem.project; reports failure instead of raising (doptimizer.py:405-428).  The
+        projection is one closed-loop device rollout, so a failed one yields no partial trajectory."""
+        try:
+            nX, nU = self.dsys.project(np.asarray(bX, dtype=float), np.asarray(bU, dtype=float), Kproj)
+        except ConvergenceError:
+            return self.armijo_simulate_return(False, np.zeros((0,) + np.shape(bX)[1:]), np.zeros((0,) + np.shape(bU)[1:]))
+        return self.armijo_simulate_return(True, nX, nU)
+
+    # -- finite-difference validators of the descent model (doptimizer.py:621-674): both probes in one batch ------
+    def _probe(self, X, U, Kproj, dX, dU, delta):
+        nX, nU, ok = self.project_candidates(X, U, Kproj, dX, dU, [-delta, delta])
+        if not ok.all():
+            raise ConvergenceError("finite-difference check: projection failed")
+        return nX, nU
+
+    def check_dcost(self, X, U, method='steepest', delta=1e-6, tolerance=1e-5):
+        (Kproj, dX, dU, Q, R, S) = self.calc_descent_direction(X, U, method)
+        exact = self.calc_dcost(X, U, dX, dU)
+        nX, nU = self._probe(X, U, Kproj, dX, dU, delta)
+        cost0, cost1 = self.calc_cost(nX[0], nU[0]), self.calc_cost(nX[1], nU[1])
+        approx = (cost1 - cost0) / (2 * delta)
+        error = approx - exact
+        return self.check_dcost_return(abs(error) <= tolerance, error, cost1, cost0, approx, exact)
+
+    def check_ddcost(self, X, U, method='steepest', delta=1e-6, tolerance=1e-5):
+        (Kproj, dX, dU, Q, R, S) = self.calc_descent_direction(X, U, method)
+        if method != 'newton':
+            (Q, R, S) = self.calc_descent_direction(X, U, 'newton')[-3:]
+        exact = self.calc_ddcost(X, U, dX, dU, Q, R, S)
+        nX, nU = self._probe(X, U, Kproj, dX, dU, delta)
+        dcosts = []
+        for i in range(2):
+            (A, B) = self.linearize(nX[i], nU[i])
+            (ndX, ndU) = self.dsys.dproject(A, B, dX, dU, Kproj)
+            dcosts.append(self.calc_dcost(nX[i], nU[i], ndX, ndU))
+        approx = (dcosts[1] - dcosts[0]) / (2 * delta)
+        error = approx - exact
+        return self.check_ddcost_return(abs(error) <= tolerance, error, dcosts[1], dcosts[0], approx, exact)
 
     def select_method(self, iteration):
         return self.first_method if iteration < self.first_method_iterations else self.second_method
