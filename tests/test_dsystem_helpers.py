@@ -101,3 +101,16 @@ def test_finite_difference_validators_match_reference():
         assert abs(exact - ref[1]) <= 1e-9 * max(1.0, ref[1]), name
         assert abs(approx - ref[2]) <= 1e-5 * max(1.0, ref[2]), name
         assert err <= max(10 * ref[0], 1e-6), (name, err, ref[0])
+
+
+@pytest.mark.gpu
+def test_minimize_potential_energy_matches_reference():
+    """System.minimize_potential_energy (system.py:215-272) on the spring_link system: same equilibrium and energy as the
+    reference's SLSQP run from the same pose (V and its finite-difference gradient come from the energy kernel)."""
+    g = extras()
+    system = systems.spring_link()
+    system.q = g["minpot_q0"]
+    q = system.minimize_potential_energy(keep_kinematic=True)
+    assert abs(-system.L() - g["minpot_V"][0]) < 1e-7
+    assert np.allclose(np.cos(q - g["minpot_q"]), 1.0, atol=1e-8) or relerr(q, g["minpot_q"]) < 1e-4
+    assert max(abs(c.h()) for c in system.constraints) < 1e-8 and np.all(system.dq == 0)

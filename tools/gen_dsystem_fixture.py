@@ -77,6 +77,12 @@ def main():
     Ua = rng.standard_normal((5, da.nU))
     (Xb, Ub) = db.convert_trajectory(da, Xa, Ua)
     out["conv_Xa"], out["conv_Ua"], out["conv_Xb"], out["conv_Ub"] = Xa, Ua, Xb, Ub
+    # System.minimize_potential_energy (system.py:215-272) on the spring_link system, from its builder pose
+    sl = systems.spring_link(api=trep)
+    sl.q = {'a': 0.3, 'b': -0.2, 'd': 0.4, 'e': -1.0, 'slide': 0.1}
+    out["minpot_q0"] = sl.q
+    out["minpot_q"] = sl.minimize_potential_energy(keep_kinematic=True)
+    out["minpot_V"] = np.array([-sl.L()])
     np.savez_compressed(os.path.join(OUT, "dsystem_extras.npz"), **out)
     print("wrote", sorted(out))
 

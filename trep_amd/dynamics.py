@@ -361,6 +361,16 @@ class PointOnPlane(Constraint):
         self._normal = (float(normal[0]), float(normal[1]), float(normal[2]))
         self._system._structure_changed()
 
+    def h_dq(self, config):
+        """dh/dq by central differences (host, setup only: satisfy_constraints / minimize_potential_energy)."""
+        q, d = config.q, 1e-7
+        config.q = q + d
+        hp = self.h()
+        config.q = q - d
+        hm = self.h()
+        config.q = q
+        return (hp - hm) / (2 * d)
+
     def h(self):
         g = self._plane_frame.g()
         return float(np.dot(g[:3, :3].dot(self._normal), (self._plane_frame.p() - self._point_frame.p())[:3]))

@@ -283,6 +283,63 @@ class System(object):
         put(q_opt)
         return self.q
 
+    def minimize_potential_energy(self, tolerance=1e-10, verbose=False, keep_kinematic=False, constant_q_list=None):
+        """Move to a nearby configuration that minimises the potential energy subject to the holonomic constraints
+        (equilibrium search; same approach and arguments as trep/system.py:215-272: SLSQP on V(q) with h(q) = 0).
+        V comes from the energy kernel; its gradient from central differences evaluated as ONE batch of 2n states
+        (the reference uses -L_dq).  Velocities are set to zero.  Returns the new configuration."""
+        import scipy.optimize
+        from .midpointvi import BatchMidpointVI
+        self.dq = 0
+        if constant_q_list:
+            fixed = set(self.get_config(c).name for c in constant_q_list)
+            free = [c for c in self.configs if c.name not in fixed]
+        elif keep_kinematic:
+            free = list(self.dyn_configs)
+        else:
+            free = list(self.configs)
+        q0 = np.array([c.q for c in free], dtype=float)
+        idx = np.array([c.index for c in free], dtype=int)
+        n = len(free)
+        grad_engine = BatchMidpointVI(self, 2 * n)
+        delta = 1e-6
+
+        def put(q):
+            for c, v in zip(free, q):
+                c.q = v
+
+        def func(q):
+            put(q)
+            return float(self._energies()[1])
+
+        def fprime(q):
+            put(q)
+            Q = np.tile(self.q, (2 * n, 1))
+            Q[np.arange(n), idx] += delta
+            Q[n + np.arange(n), idx] -= delta
+            V = grad_engine.energy(Q, np.zeros_like(Q))[:, 1]
+            return (V[:n] - V[n:]) / (2 * delta)
+
+        def f_eqcons(q):
+            put(q)
+            return np.array([c.h() for c in self.constraints])
+
+        def fprime_eqcons(q):
+            put(q)
+            return np.array([[c.h_dq(cfg) for cfg in free] for c in self.constraints]).reshape(len(self.constraints), n)
+
+        try:
+            (q_opt, fx, its, imode, smode) = scipy.optimize.fmin_slsqp(
+                func, q0, f_eqcons=f_eqcons if self.constraints else None, fprime=fprime,
+                fprime_eqcons=fprime_eqcons if self.constraints else None, acc=tolerance, iter=100 * self.nQ,
+                iprint=1 if verbose else 0, full_output=True)
+        finally:
+            grad_engine.close()
+        if imode != 0:
+            raise Exception("Minimization failed: %s" % smode)
+        put(q_opt)
+        return self.q
+
     # -- continuous dynamics (system.py:951-959, 1018-1024 of the reference; calc_dynamics system.c:749-893) --------
     def _dynamics_engine(self):
         from .midpointvi import BatchMidpointVI
