@@ -175,3 +175,16 @@ def test_gpu_energies_match_reference(name):
     system.q, system.dq = g[name + "_q"][3], g[name + "_dq"][3]
     assert abs(system.total_energy() - g[name + "_E"][3]) < 1e-10 * max(1.0, abs(g[name + "_E"][3]))
     assert abs(system.L() - g[name + "_L"][3]) < 1e-10 * max(1.0, abs(g[name + "_L"][3]))
+
+
+@pytest.mark.gpu
+def test_system_derivative_validators():
+    """System.test_derivative_dq / _ddq (system.py:1080-1203) applied to the continuous dynamics, the way the reference's
+    own scripts validate f_dq / f_ddq."""
+    g = golden()
+    system, d = build("spring_link")
+    system.q, system.dq, system.ddqk = g["spring_link_q"][1], g["spring_link_dq"][1], g["spring_link_ddqk"][1]
+    assert system.test_derivative_dq(system.f, lambda q: system.f_dq(None, q), delta=1e-6, tolerance=1e-5)
+    assert system.test_derivative_ddq(system.f, lambda q: system.f_ddq(None, q), delta=1e-6, tolerance=1e-6)
+    assert system.test_derivative_dq(system.lambda_, lambda q: system.lambda_dq(None, q), delta=1e-6, tolerance=1e-5)
+    assert not system.test_derivative_dq(system.f, lambda q: 2.0 * system.f_dq(None, q), delta=1e-6, tolerance=1e-5)

@@ -418,6 +418,39 @@ class System(object):
     lambda_du = _dyn_d1_accessor("lambda_du", "c", "u")
     del _dyn_d1_accessor
 
+    # -- numeric validators (system.py:1080-1203): func() -> float or array, func_d(config) -> its derivative -------
+    def _test_derivative(self, attr, func, func_d, delta, tolerance, verbose, test_name):
+        x0 = getattr(self, attr)
+        failed = total = 0
+        for q in self.configs:
+            setattr(self, attr, x0)
+            exact = func_d(q)
+            x = x0.copy(); x[q.index] -= delta
+            setattr(self, attr, x)
+            y0 = func()
+            x = x0.copy(); x[q.index] += delta
+            setattr(self, attr, x)
+            y1 = func()
+            approx = (y1 - y0) / (2 * delta)
+            error = np.linalg.norm(exact - approx)
+            total += 1
+            if not (error <= tolerance):
+                failed += 1
+                if verbose:
+                    print("Test '%s' failed for the %s derivative of %r: error %g > %g" % (test_name, attr, q, error, tolerance))
+        if verbose:
+            print("%d tests passing." % total if not failed else "%d/%d tests FAILED." % (failed, total))
+        setattr(self, attr, x0)
+        return not failed
+
+    def test_derivative_dq(self, func, func_dq, delta=1e-6, tolerance=1e-7, verbose=False, test_name='<unnamed>'):
+        """Central-difference check of a derivative w.r.t. the configuration values."""
+        return self._test_derivative("q", func, func_dq, delta, tolerance, verbose, test_name)
+
+    def test_derivative_ddq(self, func, func_ddq, delta=1e-6, tolerance=1e-7, verbose=False, test_name='<unnamed>'):
+        """Central-difference check of a derivative w.r.t. the configuration velocities."""
+        return self._test_derivative("dq", func, func_ddq, delta, tolerance, verbose, test_name)
+
     def set_state(self, q=None, dq=None, u=None, ddqk=None, t=None):
         if q is not None:
             self.q = q
