@@ -83,12 +83,12 @@ typedef struct tg_system_desc {
     /* TG_CONSTRAINT_PLANE: h = (R(frame1) n) . (p(frame1) - p(frame2)), frame1 = plane frame, frame2 = point frame
      * (constraints/plane.c:13-26) */
     const double  *constraint_normal;    /* [n_constraints*3] plane normal n in plane-frame coordinates (others: zeros) */
-    /* forces/hybridwrench.c, force part: a force with world-frame components applied at the origin of a frame; each
-     * component is an input or a constant.  (Torque components are not supported: the host layer rejects them.) */
+    /* forces/hybridwrench.c: a wrench applied at the origin of a frame, force and torque both given by their world-frame
+     * components; each of the six components (fx, fy, fz, tx, ty, tz) is an input or a constant. */
     int32_t n_hybrid_wrenches;
     const int32_t *hybrid_wrench_frame;  /* [n_hybrid_wrenches] */
-    const int32_t *hybrid_wrench_input;  /* [n_hybrid_wrenches*3] input index of fx, fy, fz, or -1 for a constant */
-    const double  *hybrid_wrench_const;  /* [n_hybrid_wrenches*3] the constant components */
+    const int32_t *hybrid_wrench_input;  /* [n_hybrid_wrenches*6] input index of each component, or -1 for a constant */
+    const double  *hybrid_wrench_const;  /* [n_hybrid_wrenches*6] the constant components */
 } tg_system_desc;
 
 /* Per-trajectory status written by every solve (reference: ConvergenceError / ValueError("singular")

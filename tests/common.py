@@ -18,6 +18,7 @@ BUILDERS = {
     "spring_link": lambda: systems.spring_link(),
     "plane_link": lambda: systems.plane_link(),
     "wrench_arm": lambda: systems.wrench_arm(),
+    "wrench_torque": lambda: systems.wrench_torque(),
     "puppet_forces": lambda: systems.puppet_forces(),
     "extensor_tendon": lambda: systems.extensor_tendon(),
 }

@@ -29,6 +29,7 @@ BUILDERS = {
     "spring_link": lambda: systems.spring_link(api=trep),
     "plane_link": lambda: systems.plane_link(api=trep),
     "wrench_arm": lambda: systems.wrench_arm(api=trep),
+    "wrench_torque": lambda: systems.wrench_torque(api=trep),
 }
 N_STATES = 4
 

@@ -336,6 +336,27 @@ def gen_wrench_arm():
     save("wrench_arm", **arrays, **ds)
 
 
+def gen_wrench_torque():
+    """HybridWrench with torque components: rollouts, first and full second derivative tensors, DSystem captures."""
+    system = systems.wrench_torque(api=trep)
+    rng = np.random.default_rng(20250 + 11)
+    B, N = 2, 200
+    arrays = dict(dt=DT, **topology(system))
+    arrays["input_names"] = np.array([str(u.name) for u in system.inputs])
+    for b in range(B):
+        q0 = np.concatenate([rng.uniform(-0.8, 0.8, size=3), [0.2 * b]])
+        U = rng.standard_normal((N, system.nu))
+        K = (0.2 * b + 0.3 * np.sin(2.0 * DT * np.arange(1, N + 1)))[:, None]
+        r = rollout(system, q0, U, K, N, deriv_steps=(1, 50, N) if b == 0 else (), deriv2_full=True)
+        for key, val in r.items():
+            arrays["b%d_%s" % (b, key)] = val
+        arrays["b%d_q0" % b] = q0
+        arrays["b%d_U" % b] = U
+        arrays["b%d_K" % b] = K
+    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], arrays["b0_U"], arrays["b0_K"], (0, 10, 100), seed=21)
+    save("wrench_torque", **arrays, **ds)
+
+
 def gen_puppet_forces():
     """Puppet(string_forces=True) under seeded random string forces: rollout and first derivatives."""
     system = systems.puppet_forces(api=trep)
@@ -429,7 +450,7 @@ def gen_discopt_cart():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "discopt"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "wrench_torque", "discopt"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -448,6 +469,8 @@ if __name__ == "__main__":
         gen_puppet_forces()
     if "extensor_tendon" in which:
         gen_extensor_tendon()
+    if "wrench_torque" in which:
+        gen_wrench_torque()
     if "wrench_arm" in which:
         gen_wrench_arm()
     if "plane_link" in which:

@@ -597,9 +597,8 @@ struct Core {
             const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + n_spair() + pp);
             const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
             if (ka >= nd || kb >= nd) continue;
-            const double a_ = 0.5 * dt * S[P.o_wH + pp];
-            lds_add(&A[ka * ld + kb], a_);
-            if (pw[1] != pw[2]) lds_add(&A[kb * ld + ka], a_);
+            lds_add(&A[ka * ld + kb], 0.5 * dt * S[P.o_wH + 2 * pp]);
+            if (pw[1] != pw[2]) lds_add(&A[kb * ld + ka], 0.5 * dt * S[P.o_wH + 2 * pp + 1]);
         }
         if (on) TG_FOR(pp, n_spair()) {   // dt/4 (-V_dqdq) of the two-point springs, from the midpoint evaluation
             const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
@@ -993,22 +992,21 @@ struct Core {
                 for (int pp = 0; pp < n_wpair(); pp++) {
                     const int *pw = P.cpair4 + 4 * (size_t)(p0 + pp);
                     const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
-                    const double a_ = 0.5 * dt * S[P.o_wH + pp];
-                    auto add = [&](int r, int o) {
+                    auto add = [&](int r, int o, double a_) {   // a_ = dt/2 F_dq(o; r): force on config o, derivative variable r
                         if (o >= nd) return;
                         AUG[o * ld + c_q1 + r] -= a_;
                         if (r < nd) AUG[o * ld + r] += a_;
                         else AUG[o * ld + c_k2 + (r - nd)] -= a_;
                     };
-                    add(ka, kb);
-                    if (pw[1] != pw[2]) add(kb, ka);
+                    add(kb, ka, 0.5 * dt * S[P.o_wH + 2 * pp]);
+                    if (pw[1] != pw[2]) add(ka, kb, 0.5 * dt * S[P.o_wH + 2 * pp + 1]);
                 }
                 for (int n = 0; n < n_wdh(); n++) {
                     const int m = m0 + n, o = P.dh_cfg[m], w = P.dh_c[m] - c0;
                     if (o >= nd) continue;
-                    for (int s3 = 0; s3 < 3; s3++) {
-                        const int in = P.wr_in[3 * w + s3];
-                        if (in >= 0) AUG[o * ld + c_u1 + in] -= dt * S[P.o_wD + 3 * n + s3];
+                    for (int s6 = 0; s6 < 6; s6++) {
+                        const int in = P.wr_in[6 * w + s6];
+                        if (in >= 0) AUG[o * ld + c_u1 + in] -= dt * S[P.o_wD + 6 * n + s6];
                     }
                 }
             }
@@ -1244,46 +1242,69 @@ struct Core {
         TG_SYNC();
     }
 
-    // Point forces (hybridwrench.c:17-82, force part) at the swept state: generalized force F . dp/dq per dynamic config
-    // into wF, dp/dq per item into wD (the input columns of the derivatives), F . d2p/dq dq per item pair into wH.
+    // Wrenches (hybridwrench.c:17-205) at the swept state.  With dp_n = d p/dq_n and om_n = the world axis of joint n (zero
+    // for a prismatic one) the generalized force is F . dp_n + tau . om_n (into wF per dynamic config); wD keeps (dp_n, om_n)
+    // per item (the input columns of the derivatives); per item pair, F_dq is F . d2p (symmetric) plus tau . (om_b x om_a)
+    // when joint b comes before joint a on the path -- not symmetric, so wH holds F_dq(a; b) and F_dq(b; a).
     TG_HD void wrench_terms(bool on) {
         if (n_wrenches() == 0) return;
         double *wF = S + P.o_wF, *wH = S + P.o_wH, *wD = S + P.o_wD;
         const int m0 = P.n_dh + n_sdh(), p0 = P.n_cpair + n_spair(), c0 = P.nc + n_springs();
         if (on) TG_FOR(i, P.nd) wF[i] = 0.0;
         TG_SYNC();
-        auto component = [&](int w, int s3) { const int in = P.wr_in[3 * w + s3]; return in >= 0 ? S[P.o_u + in] : P.wr_const[3 * w + s3]; };
+        auto component = [&](int w, int s6) { const int in = P.wr_in[6 * w + s6]; return in >= 0 ? S[P.o_u + in] : P.wr_const[6 * w + s6]; };
         if (on) {
             TG_FOR(n, n_wdh()) {
                 const int m = m0 + n, c = P.dh_c[m], k = P.dh_cfg[m], w = c - c0;
-                double dp[3];
+                double dp[3], om[3];
                 cdiff1(c, m, dp);
-                wD[3 * n] = dp[0]; wD[3 * n + 1] = dp[1]; wD[3 * n + 2] = dp[2];
-                if (k < P.nd) lds_add(&wF[k], component(w, 0) * dp[0] + component(w, 1) * dp[1] + component(w, 2) * dp[2]);
+                plane_axis(m, om);
+                for (int r = 0; r < 3; r++) { wD[6 * n + r] = dp[r]; wD[6 * n + 3 + r] = om[r]; }
+                if (k < P.nd) lds_add(&wF[k], component(w, 0) * dp[0] + component(w, 1) * dp[1] + component(w, 2) * dp[2] +
+                                               component(w, 3) * om[0] + component(w, 4) * om[1] + component(w, 5) * om[2]);
             }
             TG_FOR(pp, n_wpair()) {
                 const int *pw = P.cpair4 + 4 * (size_t)(p0 + pp);
-                const int c = pw[0], w = c - c0;
-                double d2[3];
-                cdiff2(c, pw[1], pw[2], d2);
-                wH[pp] = component(w, 0) * d2[0] + component(w, 1) * d2[1] + component(w, 2) * d2[2];
-                if (d2w) {   // second-derivative kernel: sum_o w_o F_dqdq(o; a, b) and -dt/2 sum_o w_o F_dudq(o, u; a)
-                    const int na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+                const int c = pw[0], w = c - c0, na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+                const int ja = P.dh_joint[na], jb = P.dh_joint[nb];
+                const double F[3] = {component(w, 0), component(w, 1), component(w, 2)};
+                const double tq[3] = {component(w, 3), component(w, 4), component(w, 5)};
+                double d2[3], oa[3], ob[3], x_ab[3];
+                cdiff2(c, na, nb, d2);
+                plane_axis(na, oa); plane_axis(nb, ob);
+                cross3(oa, ob, x_ab);                                   // om_a x om_b
+                const double hs = dot3(F, d2), t_ab = dot3(tq, x_ab);
+                wH[2 * pp] = hs + (jb < ja ? -t_ab : 0.0);             // F_dq(a; b): tau . (om_b x om_a), b before a
+                wH[2 * pp + 1] = hs + (ja < jb ? t_ab : 0.0);          // F_dq(b; a): tau . (om_a x om_b), a before b
+                if (d2w) {   // second-derivative kernel: sum_o w_o F_dqdq(o; a, b) and -dt/2 sum_o w_o F_dudq(o, u; .)
                     double acc = 0.0;
+                    const int n1 = ja <= jb ? na : nb, n2 = ja <= jb ? nb : na, j2 = ja <= jb ? jb : ja;   // n1 at or before n2
+                    double o1[3], o2[3];
+                    plane_axis(n1, o1); plane_axis(n2, o2);
                     for (int no = P.cu_off[c]; no < P.cu_off[c + 1]; no++) {
                         const int ko = P.dh_cfg[no];
                         if (ko >= P.nd) continue;
                         double d3[3];
                         cdiff3(c, na, nb, no, d3);
-                        acc += d2w[ko] * (component(w, 0) * d3[0] + component(w, 1) * d3[1] + component(w, 2) * d3[2]);
+                        double term = dot3(F, d3);
+                        if (j2 < P.dh_joint[no]) {                       // both before o: d2 om_o = om_1 x (om_2 x om_o)
+                            double oo[3], u1[3], u2[3];
+                            plane_axis(no, oo);
+                            cross3(o2, oo, u1); cross3(o1, u1, u2);
+                            term += dot3(tq, u2);
+                        }
+                        acc += d2w[ko] * term;
                     }
                     S[P.e_o_wT + pp] = acc;
                     double *Hu = S + P.e_o_Hu;
-                    for (int s3 = 0; s3 < 3; s3++) {
-                        const int in = P.wr_in[3 * w + s3];
+                    for (int s6 = 0; s6 < 6; s6++) {
+                        const int in = P.wr_in[6 * w + s6];
                         if (in < 0) continue;
-                        if (kb < P.nd) lds_add(&Hu[ka * P.nu + in], -0.5 * dt * d2w[kb] * d2[s3]);
-                        if (na != nb && ka < P.nd) lds_add(&Hu[kb * P.nu + in], -0.5 * dt * d2w[ka] * d2[s3]);
+                        // F_dudq(o = b, u; a) and F_dudq(o = a, u; b): d2p component (symmetric) or the axis derivative
+                        const double to_b = s6 < 3 ? d2[s6] : (ja < jb ? x_ab[s6 - 3] : 0.0);
+                        const double to_a = s6 < 3 ? d2[s6] : (jb < ja ? -x_ab[s6 - 3] : 0.0);
+                        if (kb < P.nd) lds_add(&Hu[ka * P.nu + in], -0.5 * dt * d2w[kb] * to_b);
+                        if (na != nb && ka < P.nd) lds_add(&Hu[kb * P.nu + in], -0.5 * dt * d2w[ka] * to_a);
                     }
                 }
             }
@@ -2165,16 +2186,15 @@ struct Core {
             TG_FOR(pp, n_wpair()) {
                 const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + n_spair() + pp);
                 const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
-                const double h = S[P.o_wH + pp];
-                if (ka < nd) lds_add(&AUG[ka * ld + c_q + kb], h);
-                if (pw[1] != pw[2] && kb < nd) lds_add(&AUG[kb * ld + c_q + ka], h);
+                if (ka < nd) lds_add(&AUG[ka * ld + c_q + kb], S[P.o_wH + 2 * pp]);
+                if (pw[1] != pw[2] && kb < nd) lds_add(&AUG[kb * ld + c_q + ka], S[P.o_wH + 2 * pp + 1]);
             }
             TG_FOR(n, n_wdh()) {
                 const int m = P.n_dh + n_sdh() + n, o = P.dh_cfg[m], w = P.dh_c[m] - (nc + n_springs());
                 if (o >= nd) continue;
-                for (int s3 = 0; s3 < 3; s3++) {
-                    const int in = P.wr_in[3 * w + s3];
-                    if (in >= 0) lds_add(&AUG[o * ld + c_u + in], S[P.o_wD + 3 * n + s3]);
+                for (int s6 = 0; s6 < 6; s6++) {
+                    const int in = P.wr_in[6 * w + s6];
+                    if (in >= 0) lds_add(&AUG[o * ld + c_u + in], S[P.o_wD + 6 * n + s6]);
                 }
             }
             TG_FOR(pp, n_spair()) {

@@ -103,7 +103,7 @@ struct DevProg {
     const double *c_nloc;   // [3 * (nc + n_springs + n_wrenches)]
     int has_plane, o_nE;
     // point forces (HybridWrench, force part): items / pairs follow the springs' in the dh / cpair tables
-    const int *wr_in; const double *wr_const;   // [3 * n_wrenches] input index or -1, constant component
+    const int *wr_in; const double *wr_const;   // [6 * n_wrenches] input index or -1, constant component (fx fy fz tx ty tz)
     int n_wrenches, n_wdh, n_wpair, o_wF, o_wH, o_wD, e_o_wT, e_o_Hu;
     const int *tab_i; const double *tab_d; int n_tab_i, n_tab_d;  // the packed table buffers (all pointers above point into them)
     int e_o_H11, e_o_H12, e_o_H22, e_o_G1, e_o_w, e_o_zq, e_o_zp, e_o_vec, e_o_vec2, e_lds_per_team;
@@ -408,10 +408,10 @@ inline HostProgram build_program(const tg_system_desc *d) {
         H.c_type.push_back(9); H.c_e1.push_back(endpoint(f1)); H.c_e2.push_back(endpoint(f1));
         H.c_nloc.push_back(0.0); H.c_nloc.push_back(0.0); H.c_nloc.push_back(0.0);
         H.c_cfg.push_back(-1); H.c_comp.push_back(0); H.c_dist.push_back(0.0); H.c_tol.push_back(0.0);
-        for (int s3 = 0; s3 < 3; s3++) {
-            const int in = d->hybrid_wrench_input[3 * w + s3];
+        for (int s6 = 0; s6 < 6; s6++) {
+            const int in = d->hybrid_wrench_input[6 * w + s6];
             if (in >= d->n_inputs) throw std::runtime_error("hybrid wrench: bad input index");
-            H.wr_in.push_back(in); H.wr_const.push_back(d->hybrid_wrench_const[3 * w + s3]);
+            H.wr_in.push_back(in); H.wr_const.push_back(d->hybrid_wrench_const[6 * w + s6]);
         }
         for (int k = 0; k < nq; k++) {
             if (d->frame_cache_index[(size_t)f1 * (nq + 1) + d->config_gen[k]] != k) continue;
@@ -491,7 +491,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.o_I = take(4 * nb);   // mass and principal inertias of every body (copied from the table once per kernel)
     P.o_ctol = take(nc);    // constraint tolerances, likewise
     P.o_sV = take(ns ? nd : 0); P.o_sH = take(P.n_spair);   // spring gradient per dynamic config, Hessian per item pair (midpoint)
-    P.o_wF = take(nw ? nd : 0); P.o_wH = take(P.n_wpair); P.o_wD = take(3 * P.n_wdh);   // point forces: generalized force, its q-Hessian, dp/dq per item
+    P.o_wF = take(nw ? nd : 0); P.o_wH = take(2 * P.n_wpair); P.o_wD = take(6 * P.n_wdh);   // wrenches: generalized force, F_dq(a;b) and F_dq(b;a) per pair, (dp/dq, axis) per item
     // level schedule of the pose sweep: 16 packed words (own offset | parent offset << 16) per level, as ints
     P.n_chains = (int)H.ch_first.size(); P.n_rounds = (int)H.round_off.size() - 1;
     P.sched_ok = (12 * nj < 65536) ? 1 : 0;

@@ -143,11 +143,9 @@ def flatten(system):
         if isinstance(force, Damping):
             damp.append(force.coefficient_array())
         elif isinstance(force, HybridWrench):
-            if any(v is not None for v in force._wrench_vars[3:]) or any(c != 0.0 for c in force._wrench_cons[3:]):
-                raise NotImplementedError("HybridWrench torque components are outside the device path's scope")
             hw_f.append(fidx[id(force.frame)])
-            hw_in += [-1 if v is None else v._index for v in force._wrench_vars[:3]]
-            hw_c += [float(c) for c in force._wrench_cons[:3]]
+            hw_in += [-1 if v is None else v._index for v in force._wrench_vars]
+            hw_c += [float(c) for c in force._wrench_cons]
         elif isinstance(force, ConfigForce):
             cf_c.append(cidx[id(force.config)])
             cf_u.append(force.finput._index)

@@ -148,6 +148,26 @@ def wrench_arm(api=None):
     return system
 
 
+def wrench_torque(api=None):
+    """The arm of wrench_arm with HybridWrench torque components: a wrench with force and torque inputs at the hand and a
+    constant torque on the fore-arm.  Synthetic test system."""
+    T = _api(api)
+    system = T.System()
+    system.import_frames([
+        T.tx('slide', name='Base', kinematic=True), [
+            T.rz('a', name='Shoulder'), [
+                T.tx(1.0, name='Upper', mass=2.0), [
+                    T.ry('b', name='Elbow'), [
+                        T.tx(0.8, name='Fore', mass=(1.0, 0.1, 0.2, 0.3)), [
+                            T.rx('c', name='Wrist'), [
+                                T.tz(-0.5, name='Hand', mass=0.5)]]]]]]])
+    T.potentials.Gravity(system, (0, 0, -9.8))
+    T.forces.HybridWrench(system, 'Hand', ('hand-fx', 0.5, 0, 'hand-tx', 0.3, 'hand-tz'), name='hand')
+    T.forces.HybridWrench(system, 'Fore', (0, 0, 0, 0, 1.0, -0.5), name='fore')
+    T.forces.Damping(system, 0.1)
+    return system
+
+
 def puppet_forces(api=None):
     """Puppet(string_forces=True): the marionette driven by a world-frame force with three inputs at each of its six
     string hooks instead of kinematic strings (22 dynamic configs, 18 inputs, no constraints)."""
