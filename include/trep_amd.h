@@ -262,6 +262,12 @@ int tg_batch_dynamics_deriv1(tg_batch *b, const double *q_host, const double *dq
                              int32_t *status_host);
 int tg_batch_dynamics_deriv1_device(tg_batch *b, const double *q_dev, const double *dq_dev, const double *u_dev,
                                     const double *ddqk_dev, double *const out_dev[8], int32_t *status_dev);
+/* First and second derivatives of the Lagrangian of every state of the batch, for every config / pair of configs
+ * (System_L_dq, L_ddq, L_dqdq, L_ddqdq, L_ddqddq, system.c:129-489 behind System.L_dq() ... System.L_ddqddq(),
+ * system.py:852-925).  first [B][2][nq] = (L_dq, L_ddq); second [B][3][nq][nq] = (L_dqdq, L_ddqdq with the velocity
+ * config as the row and the configuration config as the column, L_ddqddq). */
+int tg_batch_lagrangian(tg_batch *b, const double *q_host, const double *dq_host, double *first_host, double *second_host);
+
 /* Initial guess of the Newton iteration in the device-resident rollouts.  0 (default): the reference's, q2 <- the previous
  * q2 (midpointvi.py:188-197) -- iteration counts then match the reference's.  1: constant-velocity extrapolation
  * q2 + (q2 - q1); same root to within the solver tolerance, about one Newton iteration fewer per step.  An opt-in

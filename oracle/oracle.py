@@ -45,6 +45,7 @@ def lib():
                                  ctypes.c_void_p, ctypes.c_int]
         L.to_dynamics.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6
         L.to_energy.argtypes = [ctypes.c_void_p] * 4
+        L.to_lagrangian.argtypes = [ctypes.c_void_p] * 5
         L.to_dynamics_deriv1.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 12
         _LIB = L
     return _LIB
@@ -199,6 +200,14 @@ class OracleMVI(object):
         out = np.zeros(2)
         self._L.to_energy(self._h, q.ctypes.data, dq.ctypes.data, out.ctypes.data)
         return float(out[0]), float(out[1])
+
+    def lagrangian(self, q, dq):
+        """(L_dq [nq], L_ddq [nq], L_dqdq, L_ddqdq (dq row, q column), L_ddqddq [nq][nq]) at (q, dq)."""
+        q = np.ascontiguousarray(q, dtype=float)
+        dq = np.ascontiguousarray(dq, dtype=float)
+        o1, o2 = np.zeros((2, self.nq)), np.zeros((3, self.nq, self.nq))
+        self._L.to_lagrangian(self._h, q.ctypes.data, dq.ctypes.data, o1.ctypes.data, o2.ctypes.data)
+        return o1[0], o1[1], o2[0], o2[1], o2[2]
 
     def dynamics_deriv1(self, q, dq, u=None, ddqk=None):
         """First derivatives of the continuous dynamics (system.c:912-1299) in the layout of the reference's accessors

@@ -51,6 +51,7 @@ void emu_run(void *h, const tg::RunArgs *args) {
         case tg::MODE_DYNAMICS: tg::run_trajectory<1, tg::MODE_DYNAMICS, true>(e->P, *args, lds.data(), 0, t); break;
         case tg::MODE_DYN_DERIV1: tg::run_trajectory<1, tg::MODE_DYN_DERIV1, true>(e->P, *args, lds.data(), 0, t); break;
         case tg::MODE_ENERGY: tg::run_trajectory<1, tg::MODE_ENERGY, true>(e->P, *args, lds.data(), 0, t); break;
+        case tg::MODE_LAGRANGIAN: tg::run_trajectory<1, tg::MODE_LAGRANGIAN, true>(e->P, *args, lds.data(), 0, t); break;
         default: tg::run_trajectory<1, tg::MODE_DERIV2Z, true>(e->P, *args, lds.data(), 0, t); break;
         }
     }

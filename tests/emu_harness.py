@@ -22,7 +22,7 @@ class RunArgs(ctypes.Structure):
                 ("q1", _D), ("q2", _D), ("p1", _D), ("p2", _D), ("lam", _D), ("u1", _D),
                 ("U", _D), ("K", _D), ("q2_hint", _D), ("lam_hint", _D), ("Kproj", _D), ("bX", _D), ("bU", _D), ("Uout", _D), ("group_size", ctypes.c_int), ("group_map", _I), ("X", _D), ("f_out", _D),
                 ("d1", _D * 12), ("A_out", _D), ("B_out", _D), ("z", _D), ("hz", _D), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p),
-                ("zl", _D), ("dq_in", _D), ("ddqk_in", _D), ("ddq_out", _D), ("lam_out", _D), ("g1", _D * 8), ("energy_out", _D)]
+                ("zl", _D), ("dq_in", _D), ("ddqk_in", _D), ("ddq_out", _D), ("lam_out", _D), ("g1", _D * 8), ("energy_out", _D), ("lag1_out", _D), ("lag2_out", _D)]
 
 
 def lib():
@@ -156,6 +156,17 @@ class EmuBatch(object):
         a.dq_in, a.energy_out = _p(dQ), _p(out)
         self.L.emu_run(self.h, ctypes.byref(a))
         return out
+
+    def lagrangian(self, Q, dQ):
+        """(L1 [B][2][nq], L2 [B][3][nq][nq]): first and second derivatives of the Lagrangian of every state."""
+        Q = np.ascontiguousarray(Q, dtype=float)
+        dQ = np.ascontiguousarray(dQ, dtype=float)
+        o1, o2 = np.zeros((self.B, 2, self.nq)), np.zeros((self.B, 3, self.nq, self.nq))
+        a = self._args(8)
+        a.q1 = a.q2 = _p(Q)
+        a.dq_in, a.lag1_out, a.lag2_out = _p(dQ), _p(o1), _p(o2)
+        self.L.emu_run(self.h, ctypes.byref(a))
+        return o1, o2
 
     def dynamics_deriv1(self, Q, dQ, U=None, ddK=None):
         """First derivatives of the continuous dynamics, in the layout of the reference's accessors

@@ -188,3 +188,50 @@ def test_system_derivative_validators():
     assert system.test_derivative_ddq(system.f, lambda q: system.f_ddq(None, q), delta=1e-6, tolerance=1e-6)
     assert system.test_derivative_dq(system.lambda_, lambda q: system.lambda_dq(None, q), delta=1e-6, tolerance=1e-5)
     assert not system.test_derivative_dq(system.f, lambda q: 2.0 * system.f_dq(None, q), delta=1e-6, tolerance=1e-5)
+
+
+LAGRANGIAN_KEYS = ("L_dq", "L_ddq", "L_dqdq", "L_ddqdq", "L_ddqddq")
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_lagrangian_derivatives_match_reference(name):
+    from oracle.oracle import OracleMVI
+    g = golden()
+    _, d = build(name)
+    o = OracleMVI(d)
+    for s in range(len(g[name + "_q"])):
+        got = o.lagrangian(g[name + "_q"][s], g[name + "_dq"][s])
+        for key, val in zip(LAGRANGIAN_KEYS, got):
+            assert relerr(val, g["%s_%s" % (name, key)][s]) < 1e-11, (name, s, key)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_emulated_kernel_lagrangian_derivatives_match_reference(name):
+    from emu_harness import EmuBatch
+    g = golden()
+    _, d = build(name)
+    e = EmuBatch(d, len(g[name + "_q"]))
+    o1, o2 = e.lagrangian(g[name + "_q"], g[name + "_dq"])
+    got = (o1[:, 0], o1[:, 1], o2[:, 0], o2[:, 1], o2[:, 2])
+    for key, val in zip(LAGRANGIAN_KEYS, got):
+        assert relerr(val, g["%s_%s" % (name, key)]) < 1e-11, (name, key)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_lagrangian_derivatives_match_reference(name):
+    import trep_amd
+    g = golden()
+    system, d = build(name)
+    n = len(g[name + "_q"])
+    eng = trep_amd.BatchMidpointVI(system, n)
+    got = eng.lagrangian(g[name + "_q"], g[name + "_dq"])
+    for key in LAGRANGIAN_KEYS:
+        assert relerr(got[key], g["%s_%s" % (name, key)]) < 1e-11, (name, key)
+    eng.close()
+    system.q, system.dq = g[name + "_q"][2], g[name + "_dq"][2]
+    a, b = system.configs[0], system.configs[-1]
+    ref = g[name + "_L_ddqdq"][2]
+    assert abs(system.L_ddqdq(a, b) - ref[a.index, b.index]) < 1e-10 * max(1.0, np.abs(ref).max())
+    assert abs(system.L_dq(b) - g[name + "_L_dq"][2][b.index]) < 1e-10 * max(1.0, np.abs(g[name + "_L_dq"][2]).max())
+    assert abs(system.L_ddqddq(a, a) - g[name + "_L_ddqddq"][2][a.index, a.index]) < 1e-10 * max(1.0, np.abs(g[name + "_L_ddqddq"][2]).max())

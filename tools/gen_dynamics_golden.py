@@ -45,7 +45,7 @@ def main():
         picks = np.linspace(1, len(Q) - 1, N_STATES).astype(int)
         nq, nd, nk, nu, nc = system.nQ, system.nQd, system.nQk, system.nu, system.nc
         qs, dqs, us, ddks = [], [], [], []
-        for key in ("E", "L", "f", "lam", "f_dq", "f_ddq", "f_dddk", "f_du", "lam_dq", "lam_ddq", "lam_dddk", "lam_du"):
+        for key in ("L_dq", "L_ddq", "L_dqdq", "L_ddqdq", "L_ddqddq", "E", "L", "f", "lam", "f_dq", "f_ddq", "f_dddk", "f_du", "lam_dq", "lam_ddq", "lam_dddk", "lam_du"):
             out["%s_%s" % (name, key)] = []
         for k in picks:
             q = Q[k][:nq]
@@ -54,6 +54,12 @@ def main():
             ddk = rng.standard_normal(nk)
             system.q, system.dq, system.u, system.ddqk = q, dq, u, ddk
             qs.append(q); dqs.append(dq); us.append(u); ddks.append(ddk)
+            C = system.configs
+            out[name + "_L_dq"].append([system.L_dq(a) for a in C])
+            out[name + "_L_ddq"].append([system.L_ddq(a) for a in C])
+            out[name + "_L_dqdq"].append([[system.L_dqdq(a, b) for b in C] for a in C])
+            out[name + "_L_ddqdq"].append([[system.L_ddqdq(a, b) for b in C] for a in C])
+            out[name + "_L_ddqddq"].append([[system.L_ddqddq(a, b) for b in C] for a in C])
             out[name + "_E"].append(system.total_energy())
             out[name + "_L"].append(system.L())
             out[name + "_f"].append(system.f())

@@ -64,7 +64,7 @@ extern "C" __device__ __attribute__((const)) unsigned int __ockl_wfred_max_u32(u
 
 namespace tg {
 
-enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3, MODE_DERIV2Z = 4, MODE_DYNAMICS = 5, MODE_DYN_DERIV1 = 6, MODE_ENERGY = 7 };
+enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3, MODE_DERIV2Z = 4, MODE_DYNAMICS = 5, MODE_DYN_DERIV1 = 6, MODE_ENERGY = 7, MODE_LAGRANGIAN = 8 };
 
 struct RunArgs {
     int batch, n_steps, max_iterations, mode;
@@ -95,6 +95,7 @@ struct RunArgs {
     double *g1[8];                         // MODE_DYN_DERIV1: f_dq, f_ddq [batch][nq][nd], f_dk [batch][nk][nd], f_du [batch][nu][nd], then the
                                            // same four for lambda ([..][nc]); derivative variable first, like the reference's arrays
     double *energy_out;                    // MODE_ENERGY: [batch][2] kinetic and potential energy at (q, dq_in)
+    double *lag1_out, *lag2_out;           // MODE_LAGRANGIAN: [batch][2][nq] (L_dq, L_ddq) and [batch][3][nq][nq] (L_dqdq, L_ddqdq, L_ddqddq), zeroed by the caller
 };
 
 // sin and cos together for joint angles.  |x| < 2^17: three-constant Cody-Waite reduction to [-pi/4, pi/4]
@@ -142,6 +143,14 @@ TG_HD void bracket(const double *a, const double *b, double *r) {
 TG_HD void lds_add(double *p, double v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    *p += v;
+#endif
+}
+// accumulate into a global output from several lanes / bodies
+TG_HD void gl_add(double *p, double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(p, v);
 #else
     *p += v;
 #endif
@@ -1202,18 +1211,17 @@ struct Core {
         }
         v[0] = a[0] - b[0]; v[1] = a[1] - b[1]; v[2] = a[2] - b[2];
     }
-    // Two-point springs V = 1/2 k (|p1 - p2| - x0)^2 at the swept state (linearspring.c:30-78): gradient per dynamic config
+    // Two-point springs V = 1/2 k (|p1 - p2| - x0)^2 at the swept state (linearspring.c:30-78): gradient per config
     // into sV, Hessian per (item, item) pair into sH.  Both live outside the storage the Newton matrix shares with the
     // poses, because the matrix is assembled after the poses are gone.  Poses and end points must be valid.
     TG_HD void spring_terms(bool on) {
         if (n_springs() == 0) return;
         double *sV = S + P.o_sV, *sH = S + P.o_sH;
-        if (on) TG_FOR(i, P.nd) sV[i] = 0.0;
+        if (on) TG_FOR(i, P.nq) sV[i] = 0.0;
         TG_SYNC();
         if (on) {
             TG_FOR(n, n_sdh()) {
                 const int m = P.n_dh + n, c = P.dh_c[m], k = P.dh_cfg[m], sp = c - P.nc;
-                if (k >= P.nd) continue;
                 const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
                 const double v[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
                 const double x = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
@@ -2063,6 +2071,63 @@ struct Core {
         if (on && lane == 0) { A.energy_out[2 * t] = acc[0]; A.energy_out[2 * t + 1] = acc[1]; }
     }
 
+    // First and second derivatives of the Lagrangian for every config / pair of configs at (q, dq) (System_L_dq ...
+    // System_L_ddqddq, system.c:129-489): the per-item and per-pair quantities of the integrator, summed into the caller's
+    // (zeroed) output arrays.  lag1 = [L_dq | L_ddq], lag2 = [L_dqdq | L_ddqdq (dq row, q column) | L_ddqddq].
+    TG_HD void lagrangian(bool on, const RunArgs &A, size_t t) {
+        const int nq = P.nq;
+        if (on) TG_FOR(i, nq) S[P.o_dq + i] = A.dq_in[t * nq + i];
+        TG_SYNC();
+        pose_sweep(on, 2);
+        attach_points(on, true, n_springs() > 0);
+        spring_terms(on);
+        jacobians(on);
+        velocities(on);
+        double *o1 = A.lag1_out + t * 2 * (size_t)nq, *o2 = A.lag2_out + t * 3 * (size_t)nq * nq;
+        if (on) {
+            TG_FOR(it, P.n_items) {
+                const int b = P.it_pack[4 * (size_t)it], cfg = P.it_pack[4 * (size_t)it + 3] & 0xFFFF;
+                const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
+                const double *J = S + P.o_J + 6 * it, *W = S + P.o_W + 6 * it;
+                gl_add(&o1[cfg], inner6(I, W, v) + I[0] * (gam[0] * J[0] + gam[1] * J[1] + gam[2] * J[2]));
+                gl_add(&o1[nq + cfg], inner6(I, J, v));
+            }
+            TG_FOR(pp, P.n_pairs) {
+                const int ia = P.pair_a[pp], ib = P.pair_b[pp];
+                const int b = P.it_pack[4 * (size_t)ia], ca = P.it_pack[4 * (size_t)ia + 3] & 0xFFFF, cb = P.it_pack[4 * (size_t)ib + 3] & 0xFFFF;
+                const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
+                const double *Ja = S + P.o_J + 6 * ia, *Jb = S + P.o_J + 6 * ib, *Wa = S + P.o_W + 6 * ia, *Wb = S + P.o_W + 6 * ib;
+                double tb[6];
+                bracket(Wa, Jb, tb);
+                const double lqq = inner6(I, tb, v) + inner6(I, Wa, Wb) +
+                                   I[0] * (gam[0] * (Ja[4] * Jb[2] - Ja[5] * Jb[1]) + gam[1] * (Ja[5] * Jb[0] - Ja[3] * Jb[2]) +
+                                           gam[2] * (Ja[3] * Jb[1] - Ja[4] * Jb[0]));
+                const double mab = inner6(I, Ja, Jb);
+                bracket(Ja, Jb, tb);
+                const double c_ab = inner6(I, tb, v) + inner6(I, Ja, Wb), c_ba = inner6(I, Jb, Wa);
+                gl_add(&o2[(size_t)ca * nq + cb], lqq);
+                gl_add(&o2[((size_t)nq + ca) * nq + cb], c_ab);
+                gl_add(&o2[((size_t)2 * nq + ca) * nq + cb], mab);
+                if (ia != ib) {
+                    gl_add(&o2[(size_t)cb * nq + ca], lqq);
+                    gl_add(&o2[((size_t)nq + cb) * nq + ca], c_ba);
+                    gl_add(&o2[((size_t)2 * nq + cb) * nq + ca], mab);
+                }
+            }
+            if (has_cs()) TG_FOR(i, nq) {
+                gl_add(&o1[i], -(P.cs_k[i] * S[P.o_q2 + i] - P.cs_kq0[i]));
+                gl_add(&o2[(size_t)i * nq + i], -P.cs_k[i]);
+            }
+            if (n_springs()) TG_FOR(i, nq) gl_add(&o1[i], -S[P.o_sV + i]);
+            TG_FOR(pp, n_spair()) {
+                const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
+                const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+                gl_add(&o2[(size_t)ka * nq + kb], -S[P.o_sH + pp]);
+                if (pw[1] != pw[2]) gl_add(&o2[(size_t)kb * nq + ka], -S[P.o_sH + pp]);
+            }
+        }
+    }
+
     // =====================================================================================================
     // First derivatives of the continuous dynamics (reference calc_dynamics_deriv1, system.c:912-1299): d(ddq_d, lambda)
     // / d(q, dq, ddq_k, u).  With r = D - M ddq_d + Ad^T lambda = 0 and g = A ddq + dq^T H dq = 0 solved by `dynamics`,
@@ -2308,6 +2373,10 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
         core.deriv2z(live, A, t);
         return;
     }
+    if constexpr (MODE == MODE_LAGRANGIAN) {
+        core.lagrangian(live, A, t);
+        return;
+    }
     if constexpr (MODE == MODE_ENERGY) {
         core.energy(live, A, t);
         return;
@@ -2371,10 +2440,14 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
         }
         // advance: q1 <- q2, (p1 already holds p2), inputs, kinematic targets, hints (midpointvi.py:188-197)
         if (on) {
-            TG_FOR(i, nq) {
-                const double prev = S[P.o_q1 + i], cur = S[P.o_q2 + i];
-                S[P.o_q1 + i] = cur;
-                if (A.predictor && i < nd) S[P.o_q2 + i] = 2.0 * cur - prev;   // opt-in warm start: constant-velocity extrapolation
+            if (A.predictor) {   // opt-in warm start: constant-velocity extrapolation of the dynamic configs
+                TG_FOR(i, nq) {
+                    const double prev = S[P.o_q1 + i], cur = S[P.o_q2 + i];
+                    S[P.o_q1 + i] = cur;
+                    if (i < nd) S[P.o_q2 + i] = 2.0 * cur - prev;
+                }
+            } else {
+                TG_FOR(i, nq) S[P.o_q1 + i] = S[P.o_q2 + i];
             }
             TG_FOR(i, nu) S[P.o_u + i] = A.Kproj ? S[P.o_nu + i] : A.U[(t * A.n_steps + step) * nu + i];
             // the momentum entering the last step is the state's p1 afterwards (midpointvi.py:189)

@@ -94,7 +94,6 @@ struct DevProg {
     const int *cu_off;        // [nc+1] dh items of each constraint (its dependent configs)
     // spring potentials, kept near the end: the spring-free kernels' argument layout stays what it was
     const double *cs_k, *cs_kq0;  // [nq] config springs: sum k and sum k q0 per config (V_dq = cs_k q - cs_kq0)
-    const double *cs_c0;          // [nq] 1/2 sum k q0^2 (constant part of V)
     const double *s_k, *s_x0;     // [n_springs]
     int n_springs, n_sdh, n_spair, o_sV, o_sH, has_cs;   // two-point springs: dh items / pairs follow the constraints' in the same tables
     // continuous-dynamics derivative kernel (MODE_DYN_DERIV1): KKT matrix + one column per derivative variable, prefix vectors
@@ -107,6 +106,7 @@ struct DevProg {
     int n_wrenches, n_wdh, n_wpair, o_wF, o_wH, o_wD, e_o_wT, e_o_Hu;
     const int *tab_i; const double *tab_d; int n_tab_i, n_tab_d;  // the packed table buffers (all pointers above point into them)
     int e_o_H11, e_o_H12, e_o_H22, e_o_G1, e_o_w, e_o_zq, e_o_zp, e_o_vec, e_o_vec2, e_lds_per_team;
+    const double *cs_c0;          // [nq] 1/2 sum k q0^2 (constant part of V)
 };
 
 struct HostProgram {
@@ -490,7 +490,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.o_scal = take(P.nf); P.o_misc = take(2); P.o_nu = take(P.nu + P.nk);
     P.o_I = take(4 * nb);   // mass and principal inertias of every body (copied from the table once per kernel)
     P.o_ctol = take(nc);    // constraint tolerances, likewise
-    P.o_sV = take(ns ? nd : 0); P.o_sH = take(P.n_spair);   // spring gradient per dynamic config, Hessian per item pair (midpoint)
+    P.o_sV = take(ns ? nq : 0); P.o_sH = take(P.n_spair);   // spring gradient per dynamic config, Hessian per item pair (midpoint)
     P.o_wF = take(nw ? nd : 0); P.o_wH = take(2 * P.n_wpair); P.o_wD = take(6 * P.n_wdh);   // wrenches: generalized force, F_dq(a;b) and F_dq(b;a) per pair, (dp/dq, axis) per item
     // level schedule of the pose sweep: 16 packed words (own offset | parent offset << 16) per level, as ints
     P.n_chains = (int)H.ch_first.size(); P.n_rounds = (int)H.round_off.size() - 1;

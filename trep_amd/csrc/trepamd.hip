@@ -60,6 +60,7 @@ struct tg_batch {
     double *dyn = nullptr;     // staging of the host-facing continuous-dynamics call: q, dq, u, ddq_k, ddq, lambda
     double *dyn_d1 = nullptr;  // ... and of its eight first-derivative arrays
     double *energy = nullptr;  // [batch][2] output of tg_batch_energy
+    double *lag = nullptr;     // outputs of tg_batch_lagrangian
     int *dyn_ints = nullptr;   // its status / iteration words (the integrator's own stay untouched)
     double *d1[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool have_d1 = false;
@@ -159,6 +160,7 @@ int launch_team(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
     case tg::MODE_DYNAMICS: return launch_one<TEAM, tg::MODE_DYNAMICS>(b, A, grid, lds);
     case tg::MODE_DYN_DERIV1: return launch_one<TEAM, tg::MODE_DYN_DERIV1>(b, A, grid, lds);
     case tg::MODE_ENERGY: return launch_one<TEAM, tg::MODE_ENERGY>(b, A, grid, lds);
+    case tg::MODE_LAGRANGIAN: return launch_one<TEAM, tg::MODE_LAGRANGIAN>(b, A, grid, lds);
 #endif
     default: return fail(TG_ERR_INVALID, "unknown kernel mode");
     }
@@ -338,7 +340,7 @@ void tg_batch_destroy(tg_batch *b) {
     for (auto &e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : b->pool) hipEventDestroy(e);
     void *ptrs[] = {b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
-                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev, b->zl_dev, b->dyn, b->dyn_ints, b->dyn_d1, b->energy,
+                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev, b->zl_dev, b->dyn, b->dyn_ints, b->dyn_d1, b->energy, b->lag,
                     b->d1[0], b->d1[1], b->d1[2], b->d1[3], b->d1[4], b->d1[5], b->d1[6], b->d1[7], b->d1[8], b->d1[9], b->d1[10], b->d1[11]};
     for (void *p : ptrs) if (p) hipFree(p);
     if (b->stream && b->own_stream) hipStreamDestroy(b->stream);
@@ -607,6 +609,29 @@ int tg_batch_dynamics_device(tg_batch *b, const double *q_dev, const double *dq_
     A.dq_in = dq_dev; A.ddqk_in = ddqk_dev; A.ddq_out = ddq_dev; A.lam_out = lambda_dev;
     A.iters = b->dyn_ints; A.status = status_dev ? status_dev : b->dyn_ints + b->batch;
     return launch(b, A);
+}
+
+int tg_batch_lagrangian(tg_batch *b, const double *q_host, const double *dq_host, double *first_host, double *second_host) {
+    if (!b || !q_host || !dq_host || !first_host || !second_host) return fail(TG_ERR_INVALID, "null argument");
+    const tg::DevProg &P = b->P;
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t B = (size_t)b->batch, nq = P.nq;
+    const size_t in_total = B * (2 * nq + P.nu + P.nk + P.nd + P.nc), out_total = B * nq * (2 + 3 * nq);
+    if (!b->dyn) HIP_TRY(hipMalloc(&b->dyn, (in_total ? in_total : 1) * sizeof(double)));
+    if (!b->dyn_ints) HIP_TRY(hipMalloc(&b->dyn_ints, 2 * B * sizeof(int)));
+    if (!b->lag) HIP_TRY(hipMalloc(&b->lag, (out_total ? out_total : 1) * sizeof(double)));
+    double *q = b->dyn, *dq = q + B * nq, *o1 = b->lag, *o2 = o1 + 2 * B * nq;
+    HIP_TRY(hipMemcpyAsync(q, q_host, B * nq * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(dq, dq_host, B * nq * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemsetAsync(b->lag, 0, out_total * sizeof(double), b->stream));     // the kernel accumulates
+    tg::RunArgs A = base_args(b, tg::MODE_LAGRANGIAN);
+    A.q1 = A.q2 = q; A.dq_in = dq; A.lag1_out = o1; A.lag2_out = o2;
+    A.iters = b->dyn_ints; A.status = b->dyn_ints + b->batch;
+    if (int rc = launch(b, A)) return rc;
+    HIP_TRY(hipMemcpyAsync(first_host, o1, 2 * B * nq * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(second_host, o2, 3 * B * nq * nq * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return TG_SUCCESS;
 }
 
 int tg_batch_set_predictor(tg_batch *b, int32_t mode) {

@@ -275,6 +275,16 @@ class BatchMidpointVI(object):
                                              _lib.ptr(ddq), _lib.ptr(lam), status.ctypes.data))
         return ddq, lam, status
 
+    def lagrangian(self, Q, dQ):
+        """First and second derivatives of the Lagrangian of B states: dict with L_dq, L_ddq [B][nq] and L_dqdq,
+        L_ddqdq (velocity config = row), L_ddqddq [B][nq][nq] (System.L_dq() ... L_ddqddq(), system.py:852-925)."""
+        B = self._batch
+        Q = _lib.as_f64(np.broadcast_to(np.asarray(Q, dtype=float), (B, self.nq)), (B, self.nq))
+        dQ = _lib.as_f64(np.broadcast_to(np.asarray(dQ, dtype=float), (B, self.nq)), (B, self.nq))
+        o1, o2 = np.zeros((B, 2, self.nq)), np.zeros((B, 3, self.nq, self.nq))
+        _lib.check(self._L.tg_batch_lagrangian(self._h, _lib.ptr(Q), _lib.ptr(dQ), _lib.ptr(o1), _lib.ptr(o2)))
+        return {"L_dq": o1[:, 0], "L_ddq": o1[:, 1], "L_dqdq": o2[:, 0], "L_ddqdq": o2[:, 1], "L_ddqddq": o2[:, 2]}
+
     @property
     def predictor(self):
         """Initial guess of the rollouts' Newton iteration: "reference" (q2 <- previous q2, the reference's semantics

@@ -387,6 +387,26 @@ class System(object):
         T, V = self._energies()
         return float(T - V)
 
+    def _lagrangian(self):
+        d = self._dynamics_engine().lagrangian(self.q[None], self.dq[None])
+        return dict((k, v[0]) for k, v in d.items())
+
+    def L_dq(self, q1):
+        """dL/dq1 at the current state (system.py:852-858)."""
+        return float(self._lagrangian()["L_dq"][q1.index])
+
+    def L_ddq(self, dq1):
+        return float(self._lagrangian()["L_ddq"][dq1.index])
+
+    def L_dqdq(self, q1, q2):
+        return float(self._lagrangian()["L_dqdq"][q1.index, q2.index])
+
+    def L_ddqdq(self, dq1, q2):
+        return float(self._lagrangian()["L_ddqdq"][dq1.index, q2.index])
+
+    def L_ddqddq(self, dq1, dq2):
+        return float(self._lagrangian()["L_ddqddq"][dq1.index, dq2.index])
+
     def _dynamics_deriv1(self):
         self._dynamics()                      # engine + the reference's side effect on Config.ddq
         d, status = self._dyn_engine.dynamics_deriv1(self.q[None], self.dq[None], self.u[None], self.ddqk[None])
