@@ -67,3 +67,22 @@ def test_satisfy_constraints_matches_reference():
     slider = kept.get_config("SLIDER").q
     kept.satisfy_constraints(constant_q_list=["SLIDER"])
     assert max(abs(c.h()) for c in kept.constraints) < 1e-9 and kept.get_config("SLIDER").q == slider
+
+
+def test_export_frames_round_trip():
+    """System.export_frames() text rebuilds the same topology tables through import_frames."""
+    import trep_amd
+    from trep_amd import systems, descriptor
+    for build_system in (systems.puppet, systems.spring_link, systems.scissor_lift):
+        a = build_system()
+        text = a.export_frames().replace("from trep import", "from trep_amd import")
+        scope = {"system": trep_amd.System()}
+        exec(text, scope)
+        b = scope["system"]
+        da, db = descriptor.flatten(a), descriptor.flatten(b)
+        for key in ("frame_transform", "frame_parent", "frame_value", "frame_lg", "frame_inertia", "frame_cache_size"):
+            assert np.array_equal(da.tables[key], db.tables[key]), (build_system.__name__, key)
+        assert [f.name for f in a.frames] == [f.name for f in b.frames]
+        # configs of the frames by name (configs that constraints create, e.g. string lengths, are not part of the tree)
+        describe = lambda s: [(None if f.config is None else (f.config.name, f.config.kinematic)) for f in s.frames]
+        assert describe(a) == describe(b)

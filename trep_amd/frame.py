@@ -242,6 +242,34 @@ class Frame(object):
     del _inertia_prop
 
     # -- host forward kinematics (setup only) --------------------------------
+    def export_frames(self, tabs=0, tab_size=4):
+        """This frame and its children as source text in the nested-list form that import_frames reads
+        (frame.py:223-262 of the reference)."""
+        names = {TX: 'tx', TY: 'ty', TZ: 'tz', RX: 'rx', RY: 'ry', RZ: 'rz', CONST_SE3: 'const_se3'}
+        params = []
+        if self._transform is CONST_SE3:
+            mat = self.lg()
+            cols = ['[' + ', '.join('%s' % x for x in mat[:3, j]) + ']' for j in range(4)]
+            params.append('[%s, %s, %s, %s]' % tuple(cols))
+        elif self.config is None:
+            params.append('%s' % self.transform_value)
+        else:
+            params.append("'%s'" % self.config.name)
+            if self.config.kinematic:
+                params.append('kinematic=True')
+        if self.name:
+            params.append("name='%s'" % self.name)
+        if self.mass:
+            if self.Ixx or self.Iyy or self.Izz:
+                params.append('mass=[%s, %s, %s, %s]' % (self.mass, self.Ixx, self.Iyy, self.Izz))
+            else:
+                params.append('mass=%s' % self.mass)
+        txt = ' ' * tab_size * tabs + '%s(%s)' % (names[self._transform], ', '.join(params))
+        if self._children:
+            txt += ', [\n' + ',\n'.join(c.export_frames(tabs + 1, tab_size) for c in self._children)
+            txt += '\n' + ' ' * (tab_size * tabs + tab_size) + ']'
+        return txt
+
     def lg(self):
         return local_transform(self._transform, self.transform_value, self._lg_const)
 

@@ -215,6 +215,17 @@ class System(object):
     def import_frames(self, children):
         self._world_frame.import_frames(children)
 
+    def export_frames(self, system_name='system', frames_name='frames', tab_size=4):
+        """Python source that rebuilds this system's frame tree (system.py:292-305)."""
+        txt = '#' * 80 + '\n# Frame tree definition generated by System.export_frames()\n\n'
+        txt += 'from trep import const_se3, rx, ry, rz, tx, ty, tz\n'
+        txt += '%s = [\n' % frames_name
+        txt += ',\n'.join(child.export_frames(1, tab_size) for child in self._world_frame.children) + '\n'
+        txt += ' ' * tab_size + ']\n'
+        txt += '%s.import_frames(%s)\n' % (system_name, frames_name)
+        return txt + '#' * 80 + '\n'
+
+
     # -- state vectors ---------------------------------------------------------------
     @staticmethod
     def _assign(items, attr, value, lookup):
