@@ -89,6 +89,13 @@ typedef struct tg_system_desc {
     const int32_t *hybrid_wrench_frame;  /* [n_hybrid_wrenches] */
     const int32_t *hybrid_wrench_input;  /* [n_hybrid_wrenches*6] input index of each component, or -1 for a constant */
     const double  *hybrid_wrench_const;  /* [n_hybrid_wrenches*6] the constant components */
+    /* forces/lineardamper.c: f = -c (d/dt |p1 - p2|) d|p1 - p2|/dq between the origins of two frames.  DEL solve, first
+     * derivatives and continuous dynamics; second derivatives of the step map are not implemented for systems with
+     * such dampers (TG_ERR_UNSUPPORTED; the reference has them). */
+    int32_t n_linear_dampers;
+    const int32_t *linear_damper_frame1; /* [n_linear_dampers] */
+    const int32_t *linear_damper_frame2; /* [n_linear_dampers] */
+    const double  *linear_damper_c;      /* [n_linear_dampers] */
 } tg_system_desc;
 
 /* Per-trajectory status written by every solve (reference: ConvergenceError / ValueError("singular")

@@ -19,13 +19,14 @@ BUILDERS = {
     "plane_link": lambda: systems.plane_link(),
     "wrench_arm": lambda: systems.wrench_arm(),
     "wrench_torque": lambda: systems.wrench_torque(),
+    "dual_pendulums": lambda: systems.dual_pendulums(),
     "puppet_forces": lambda: systems.puppet_forces(),
     "extensor_tendon": lambda: systems.extensor_tendon(),
 }
 D1 = ["q2_dq1", "q2_dp1", "q2_du1", "q2_dk2", "p2_dq1", "p2_dp1", "p2_du1", "p2_dk2",
       "l1_dq1", "l1_dp1", "l1_du1", "l1_dk2"]
 PAIRS = ["dq1dq1", "dq1dp1", "dq1du1", "dq1dk2", "dp1dp1", "dp1du1", "dp1dk2", "du1du1", "du1dk2", "dk2dk2"]
-NO_SECOND_ORDER = {"spring_link", "extensor_tendon"}   # LinearSpring has no third derivative in the reference: deriv2 raises there too
+NO_SECOND_ORDER = {"spring_link", "extensor_tendon", "dual_pendulums"}   # LinearSpring has no third derivative in the reference: deriv2 raises there too
 _cache = {}
 
 

@@ -133,7 +133,7 @@ def test_residual_matches_oracle():
 
 @pytest.mark.parametrize("name,B,N", [("puppet40", 48, 40), ("scissor4", 33, 60), ("pend_on_cart", 67, 100),
                                       ("spring_arm", 37, 80), ("spring_link", 29, 60), ("wrench_arm", 41, 80), ("wrench_torque", 23, 60),
-                                      ("extensor_tendon", 21, 100)])
+                                      ("extensor_tendon", 21, 100), ("dual_pendulums", 35, 120)])
 def test_random_batch_matches_oracle(name, B, N):
     """Seeded random initial conditions / inputs, HIP vs oracle, ragged batch sizes."""
     from oracle.oracle import OracleMVI
@@ -458,3 +458,15 @@ def test_extrapolating_predictor_same_trajectory_fewer_iterations():
     assert out["extrapolate"][1] < out["reference"][1] - 0.3
     with pytest.raises(ValueError):
         _batch(system, 1).predictor = "nonsense"
+
+
+def test_second_derivatives_not_implemented_with_linear_damper():
+    import trep_amd
+    g = golden("dual_pendulums")
+    system, d = build("dual_pendulums")
+    mvi = trep_amd.MidpointVI(system)
+    mvi.initialize_from_state(DT, g["b0_Q"][0], g["b0_P"][0], g["b0_LAM"][0])
+    mvi.step(2 * DT)
+    assert relerr(mvi.q2, g["b0_Q"][1]) < 1e-10 and relerr(mvi.p2_dq1(), g["b0_d1_1_p2_dq1"].T) < 1e-9
+    with pytest.raises(Exception, match="LinearDamper"):
+        mvi.q2_dq1dq1()

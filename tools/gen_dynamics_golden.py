@@ -30,6 +30,7 @@ BUILDERS = {
     "plane_link": lambda: systems.plane_link(api=trep),
     "wrench_arm": lambda: systems.wrench_arm(api=trep),
     "wrench_torque": lambda: systems.wrench_torque(api=trep),
+    "dual_pendulums": lambda: systems.dual_pendulums(api=trep),
 }
 N_STATES = 4
 

@@ -357,6 +357,22 @@ def gen_wrench_torque():
     save("wrench_torque", **arrays, **ds)
 
 
+def gen_dual_pendulums():
+    """examples/dual_pendulums.py run as the script does (tf = 10, dt = 0.01) plus first derivatives (the build has no
+    second derivatives for LinearDamper)."""
+    system = systems.dual_pendulums(api=trep)
+    N = 1000
+    arrays = dict(dt=DT, **topology(system))
+    q0 = system.q
+    U = np.zeros((N, 0)); K = np.zeros((N, 0))
+    r = rollout(system, q0, U, K, N, deriv_steps=(1, 500), second_order=False)
+    for key, val in r.items():
+        arrays["b0_" + key] = val
+    arrays["b0_q0"] = q0
+    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], U, K, (0, 10, 100), seed=22, second_order=False)
+    save("dual_pendulums", **arrays, **ds)
+
+
 def gen_puppet_forces():
     """Puppet(string_forces=True) under seeded random string forces: rollout and first derivatives."""
     system = systems.puppet_forces(api=trep)
@@ -450,7 +466,7 @@ def gen_discopt_cart():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "wrench_torque", "discopt"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "wrench_torque", "dual_pendulums", "discopt"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -469,6 +485,8 @@ if __name__ == "__main__":
         gen_puppet_forces()
     if "extensor_tendon" in which:
         gen_extensor_tendon()
+    if "dual_pendulums" in which:
+        gen_dual_pendulums()
     if "wrench_torque" in which:
         gen_wrench_torque()
     if "wrench_arm" in which:

@@ -193,6 +193,7 @@ struct Core {
     TG_HD int n_sdh() const { return SPRINGS ? P.n_sdh : 0; }
     TG_HD bool has_plane() const { return SPRINGS && P.has_plane; }   // plane constraints ride on the same switch
     TG_HD int n_wrenches() const { return SPRINGS ? P.n_wrenches : 0; } // ... and the point forces
+    TG_HD bool has_damper() const { return SPRINGS && P.has_damper; }     // ... and the linear dampers
     TG_HD int n_wdh() const { return SPRINGS ? P.n_wdh : 0; }
     TG_HD int n_wpair() const { return SPRINGS ? P.n_wpair : 0; }
     const double *d2w = nullptr;   // adjoint weights while the second-derivative kernel evaluates the midpoint, else null
@@ -474,6 +475,7 @@ struct Core {
             double force = -P.damp[i] * S[P.o_dq + i];
             for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
             if (n_wrenches()) force += S[P.o_wF + i];
+            if (has_damper()) force += S[P.o_sF + i];
             double f = S[P.o_p1 + i] + (0.5 * dt * ldq - lddq) + dt * force;
             for (int c = 0; c < P.nc; c++) {                 // branch-free: a missing entry reads item 0 with weight 0
                 const int n = P.dh_lookup[c * P.nq + i];
@@ -613,9 +615,14 @@ struct Core {
             const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
             const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
             if (ka >= nd || kb >= nd) continue;
-            const double a_ = -qdt * S[P.o_sH + pp];
+            double a_ = -qdt * S[P.o_sH + pp], b_ = a_;
+            if (has_damper()) {   // D2 fm2 = dt/2 F_dq + F_ddq
+                double fab, fba, fdd;
+                damper_pair(pp, fab, fba, fdd);
+                a_ += 0.5 * dt * fab + fdd; b_ += 0.5 * dt * fba + fdd;
+            }
             lds_add(&A[ka * ld + kb], a_);
-            if (pw[1] != pw[2]) lds_add(&A[kb * ld + ka], a_);
+            if (pw[1] != pw[2]) lds_add(&A[kb * ld + ka], b_);
         }
         TG_SYNC();
         TG_STAMP(8);
@@ -1036,6 +1043,19 @@ struct Core {
                 };
                 add(ka, kb);
                 if (pw[1] != pw[2]) add(kb, ka);
+                if (has_damper()) {   // D1 fm2 = dt/2 F_dq - F_ddq (q1 columns), D2 fm2 = dt/2 F_dq + F_ddq (M2 / k2 columns)
+                    double fab, fba, fdd;
+                    damper_pair(pp, fab, fba, fdd);
+                    auto addf = [&](int r, int o, double fq) {   // force on config o, derivative variable r
+                        if (o >= nd) return;
+                        const double d1 = 0.5 * dt * fq - fdd, d2 = 0.5 * dt * fq + fdd;
+                        AUG[o * ld + c_q1 + r] -= d1;
+                        if (r < nd) AUG[o * ld + r] += d2;
+                        else AUG[o * ld + c_k2 + (r - nd)] -= d2;
+                    };
+                    addf(kb, ka, fab);
+                    if (pw[1] != pw[2]) addf(ka, kb, fba);
+                }
             }
             TG_SYNC();
         }
@@ -1228,6 +1248,7 @@ struct Core {
                 double v1[3];
                 cdiff1(c, m, v1);
                 const double dx = (1.0 / x) * (v[0] * v1[0] + v[1] * v1[1] + v[2] * v1[2]);
+                if (has_damper()) S[P.o_sX + n] = dx == dx ? dx : 0.0;
                 if (dx != dx && P.s_x0[sp] == 0.0) continue;   // coincident end points of a zero-length spring (:44-45)
                 lds_add(&sV[k], P.s_k[sp] * (x - P.s_x0[sp]) * dx);
             }
@@ -1245,9 +1266,48 @@ struct Core {
                 const double ddx = -djx / (x * x) * vvi + 1.0 / x * (vj[0] * vi[0] + vj[1] * vi[1] + vj[2] * vi[2]) +
                                    1.0 / x * (v[0] * vij[0] + v[1] * vij[1] + v[2] * vij[2]);
                 sH[pp] = P.s_k[sp] * dix * djx + P.s_k[sp] * (x - P.s_x0[sp]) * ddx;
+                if (has_damper()) S[P.o_sXX + pp] = ddx;
             }
         }
         TG_SYNC();
+        if (has_damper()) {   // lineardamper.c:12-45: rate of every element, d(rate)/dq per item, generalized force
+            const double *dqv = S + P.o_dq;
+            if (on) {
+                TG_FOR(i, n_springs()) S[P.o_svel + i] = 0.0;
+                TG_FOR(i, n_sdh()) S[P.o_sVq + i] = 0.0;
+                TG_FOR(i, P.nd) S[P.o_sF + i] = 0.0;
+            }
+            TG_SYNC();
+            if (on) {
+                TG_FOR(n, n_sdh()) {
+                    const int m = P.n_dh + n;
+                    lds_add(&S[P.o_svel + (P.dh_c[m] - P.nc)], S[P.o_sX + n] * dqv[P.dh_cfg[m]]);
+                }
+                TG_FOR(pp, n_spair()) {
+                    const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
+                    const int na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+                    const double xab = S[P.o_sXX + pp];
+                    lds_add(&S[P.o_sVq + (na - P.n_dh)], xab * dqv[kb]);
+                    if (na != nb) lds_add(&S[P.o_sVq + (nb - P.n_dh)], xab * dqv[ka]);
+                }
+            }
+            TG_SYNC();
+            if (on) TG_FOR(n, n_sdh()) {
+                const int m = P.n_dh + n, sp = P.dh_c[m] - P.nc, k = P.dh_cfg[m];
+                if (k < P.nd) lds_add(&S[P.o_sF + k], -P.s_c[sp] * S[P.o_svel + sp] * S[P.o_sX + n]);
+            }
+            TG_SYNC();
+        }
+    }
+
+    // derivatives of the damper force of the element pair pp = (na, nb): F_dq(a; b), F_dq(b; a) and F_ddq (symmetric)
+    TG_HD void damper_pair(int pp, double &fq_ab, double &fq_ba, double &fdd) const {
+        const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
+        const int sp = pw[0] - P.nc, ia = pw[1] - P.n_dh, ib = pw[2] - P.n_dh;
+        const double c = P.s_c[sp], vel = S[P.o_svel + sp], xa = S[P.o_sX + ia], xb = S[P.o_sX + ib], xab = S[P.o_sXX + pp];
+        fq_ab = -c * (S[P.o_sVq + ib] * xa + vel * xab);
+        fq_ba = -c * (S[P.o_sVq + ia] * xb + vel * xab);
+        fdd = -c * xa * xb;
     }
 
     // Wrenches (hybridwrench.c:17-205) at the swept state.  With dp_n = d p/dq_n and om_n = the world axis of joint n (zero
@@ -2010,6 +2070,7 @@ struct Core {
                 if (has_cs()) force -= P.cs_k[i] * S[P.o_q2 + i] - P.cs_kq0[i];
                 if (n_springs()) force -= S[P.o_sV + i];
                 if (n_wrenches()) force += S[P.o_wF + i];
+                if (has_damper()) force += S[P.o_sF + i];
                 lds_add(&rhs[i], force);
             }
         }
@@ -2268,6 +2329,12 @@ struct Core {
                 const double h = S[P.o_sH + pp];
                 if (ka < nd) lds_add(&AUG[ka * ld + c_q + kb], -h);
                 if (pw[1] != pw[2] && kb < nd) lds_add(&AUG[kb * ld + c_q + ka], -h);
+                if (has_damper()) {
+                    double fab, fba, fdd;
+                    damper_pair(pp, fab, fba, fdd);
+                    if (ka < nd) { lds_add(&AUG[ka * ld + c_q + kb], fab); lds_add(&AUG[ka * ld + c_dq + kb], fdd); }
+                    if (pw[1] != pw[2] && kb < nd) { lds_add(&AUG[kb * ld + c_q + ka], fba); lds_add(&AUG[kb * ld + c_dq + ka], fdd); }
+                }
             }
         }
         TG_SYNC();

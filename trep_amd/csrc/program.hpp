@@ -104,6 +104,8 @@ struct DevProg {
     // point forces (HybridWrench, force part): items / pairs follow the springs' in the dh / cpair tables
     const int *wr_in; const double *wr_const;   // [6 * n_wrenches] input index or -1, constant component (fx fy fz tx ty tz)
     int n_wrenches, n_wdh, n_wpair, o_wF, o_wH, o_wD, e_o_wT, e_o_Hu;
+    // linear dampers (spring elements with a coefficient c): d|p1-p2|/dq per item, its q-derivative per pair, rate per element
+    const double *s_c; int has_damper, o_sX, o_sVq, o_sXX, o_svel, o_sF;
     const int *tab_i; const double *tab_d; int n_tab_i, n_tab_d;  // the packed table buffers (all pointers above point into them)
     int e_o_H11, e_o_H12, e_o_H22, e_o_G1, e_o_w, e_o_zq, e_o_zp, e_o_vec, e_o_vec2, e_lds_per_team;
     const double *cs_c0;          // [nq] 1/2 sum k q0^2 (constant part of V)
@@ -121,7 +123,7 @@ struct HostProgram {
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
     std::vector<double> c_dist, c_tol;
     std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
-    std::vector<double> damp, cs_k, cs_kq0, cs_c0, s_k, s_x0, c_nloc, wr_const;
+    std::vector<double> damp, cs_k, cs_kq0, cs_c0, s_k, s_x0, s_c, c_nloc, wr_const;
     std::vector<int> wr_in;
     std::vector<int> cf_cfg, cf_in;
     std::vector<double> jcoef;      // [n_joints*16*4] local-transform coefficients (see pose_sweep)
@@ -382,14 +384,18 @@ inline HostProgram build_program(const tg_system_desc *d) {
     // two-point springs (linearspring.c): same end point / dependent-config items as a distance constraint, listed after
     // the constraints' so that every constraint loop (n_dh, n_cpair, nc) leaves them out
     const int n_dh_con = (int)H.dh_c.size();
-    const int ns = d->n_linear_springs;
+    const int n_true_springs = d->n_linear_springs;
+    const int ns = n_true_springs + d->n_linear_dampers;   // dampers are spring elements with k = 0 and a coefficient c
     for (int s = 0; s < ns; s++) {
-        const int f1 = d->linear_spring_frame1[s], f2 = d->linear_spring_frame2[s], c = nc + s;
+        const bool damper = s >= n_true_springs;
+        const int f1 = damper ? d->linear_damper_frame1[s - n_true_springs] : d->linear_spring_frame1[s];
+        const int f2 = damper ? d->linear_damper_frame2[s - n_true_springs] : d->linear_spring_frame2[s], c = nc + s;
         if (f1 < 0 || f1 >= d->n_frames || f2 < 0 || f2 >= d->n_frames) throw std::runtime_error("linear spring: bad frame index");
         H.c_type.push_back(9); H.c_e1.push_back(endpoint(f1)); H.c_e2.push_back(endpoint(f2));   // 9: not a constraint type
         H.c_nloc.push_back(0.0); H.c_nloc.push_back(0.0); H.c_nloc.push_back(0.0);
         H.c_cfg.push_back(-1); H.c_comp.push_back(0); H.c_dist.push_back(0.0); H.c_tol.push_back(0.0);
-        H.s_k.push_back(d->linear_spring_k[s]); H.s_x0.push_back(d->linear_spring_x0[s]);
+        H.s_k.push_back(damper ? 0.0 : d->linear_spring_k[s]); H.s_x0.push_back(damper ? 0.0 : d->linear_spring_x0[s]);
+        H.s_c.push_back(damper ? d->linear_damper_c[s - n_true_springs] : 0.0);
         for (int k = 0; k < nq; k++) {
             int g = d->config_gen[k];
             bool on1 = d->frame_cache_index[(size_t)f1 * (nq + 1) + g] == k;
@@ -491,6 +497,9 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.o_I = take(4 * nb);   // mass and principal inertias of every body (copied from the table once per kernel)
     P.o_ctol = take(nc);    // constraint tolerances, likewise
     P.o_sV = take(ns ? nq : 0); P.o_sH = take(P.n_spair);   // spring gradient per dynamic config, Hessian per item pair (midpoint)
+    P.has_damper = d->n_linear_dampers > 0 ? 1 : 0;
+    P.o_sX = take(P.has_damper ? P.n_sdh : 0); P.o_sVq = take(P.has_damper ? P.n_sdh : 0); P.o_sXX = take(P.has_damper ? P.n_spair : 0);
+    P.o_svel = take(P.has_damper ? ns : 0); P.o_sF = take(P.has_damper ? nd : 0);
     P.o_wF = take(nw ? nd : 0); P.o_wH = take(2 * P.n_wpair); P.o_wD = take(6 * P.n_wdh);   // wrenches: generalized force, F_dq(a;b) and F_dq(b;a) per pair, (dp/dq, axis) per item
     // level schedule of the pose sweep: 16 packed words (own offset | parent offset << 16) per level, as ints
     P.n_chains = (int)H.ch_first.size(); P.n_rounds = (int)H.round_off.size() - 1;
@@ -581,7 +590,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
     X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in)
-#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const)
+#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c)
 
 inline void HostProgram::pack() {
     ipool.clear(); dpool.clear(); ioff.clear(); doff.clear();

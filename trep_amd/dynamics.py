@@ -236,6 +236,34 @@ class HybridWrench(Force):
         self._system._structure_changed()
 
 
+class LinearDamper(Force):
+    """A viscous damper between the origins of two frames: force -c d|p1 - p2|/dt along the line between them
+    (forces/lineardamper.py:14-60, lineardamper.c:12-45)."""
+
+    def __init__(self, system, frame1, frame2, c, name=None):
+        Force.__init__(self, system, name)
+        if not system.get_frame(frame1):
+            raise ValueError("Could not find frame %r" % frame1)
+        self._frame1 = system.get_frame(frame1)
+        if not system.get_frame(frame2):
+            raise ValueError("Could not find frame %r" % frame2)
+        self._frame2 = system.get_frame(frame2)
+        self._c = float(c)
+        system._structure_changed()
+
+    frame1 = property(lambda self: self._frame1)
+    frame2 = property(lambda self: self._frame2)
+
+    @property
+    def c(self):
+        return self._c
+
+    @c.setter
+    def c(self, value):
+        self._c = float(value)
+        self._system._structure_changed()
+
+
 class Constraint(object):
     def __init__(self, system, name=None, tolerance=1e-10):
         self._system = system

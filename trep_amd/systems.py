@@ -148,6 +148,24 @@ def wrench_arm(api=None):
     return system
 
 
+def dual_pendulums(api=None):
+    """examples/dual_pendulums.py:28-44: two pendulums on neighbouring pivots joined by a linear spring and a linear
+    damper, under gravity."""
+    T = _api(api)
+    system = T.System()
+    system.import_frames([
+        T.rx('theta1'), [
+            T.tz(2, mass=1, name='pend1')],
+        T.ty(1), [
+            T.rx('theta2'), [
+                T.tz(2, mass=1, name='pend2')]]])
+    T.potentials.LinearSpring(system, 'pend1', 'pend2', k=20, x0=1)
+    T.forces.LinearDamper(system, 'pend1', 'pend2', c=1)
+    T.potentials.Gravity(system, name="Gravity")
+    system.q = [3, -3]
+    return system
+
+
 def wrench_torque(api=None):
     """The arm of wrench_arm with HybridWrench torque components: a wrench with force and torque inputs at the hand and a
     constant torque on the fore-arm.  Synthetic test system."""
