@@ -604,14 +604,15 @@ struct Core {
             lds_add(&A[ca * ld + cb], sym + skew);
             if (ia != ib) lds_add(&A[cb * ld + ca], sym - skew);
         }
-        if (on) TG_FOR(pp, n_wpair()) {   // D2 fm2 = dt/2 F_dq of the point forces (midpointvi.c:593-600)
+        // (`SPRINGS &&`: the laundered lane index keeps a loop with a compile-time-zero bound alive, so compile it out here)
+        if (SPRINGS && on) TG_FOR(pp, n_wpair()) {   // D2 fm2 = dt/2 F_dq of the point forces (midpointvi.c:593-600)
             const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + n_spair() + pp);
             const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
             if (ka >= nd || kb >= nd) continue;
             lds_add(&A[ka * ld + kb], 0.5 * dt * S[P.o_wH + 2 * pp]);
             if (pw[1] != pw[2]) lds_add(&A[kb * ld + ka], 0.5 * dt * S[P.o_wH + 2 * pp + 1]);
         }
-        if (on) TG_FOR(pp, n_spair()) {   // dt/4 (-V_dqdq) of the two-point springs, from the midpoint evaluation
+        if (SPRINGS && on) TG_FOR(pp, n_spair()) {   // dt/4 (-V_dqdq) of the two-point springs, from the midpoint evaluation
             const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
             const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
             if (ka >= nd || kb >= nd) continue;
