@@ -20,6 +20,7 @@ BUILDERS = {
     "wrench_arm": lambda: systems.wrench_arm(),
     "wrench_torque": lambda: systems.wrench_torque(),
     "dual_pendulums": lambda: systems.dual_pendulums(),
+    "wrench_spatial": lambda: systems.wrench_spatial(),
     "puppet_forces": lambda: systems.puppet_forces(),
     "extensor_tendon": lambda: systems.extensor_tendon(),
 }

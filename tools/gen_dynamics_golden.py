@@ -31,6 +31,7 @@ BUILDERS = {
     "wrench_arm": lambda: systems.wrench_arm(api=trep),
     "wrench_torque": lambda: systems.wrench_torque(api=trep),
     "dual_pendulums": lambda: systems.dual_pendulums(api=trep),
+    "wrench_spatial": lambda: systems.wrench_spatial(api=trep),
 }
 N_STATES = 4
 

@@ -336,10 +336,11 @@ def gen_wrench_arm():
     save("wrench_arm", **arrays, **ds)
 
 
-def gen_wrench_torque():
-    """HybridWrench with torque components: rollouts, first and full second derivative tensors, DSystem captures."""
-    system = systems.wrench_torque(api=trep)
-    rng = np.random.default_rng(20250 + 11)
+def gen_wrench_torque(name="wrench_torque", seed=11):
+    """HybridWrench with torque components / SpatialWrench: rollouts, first and full second derivative tensors, DSystem
+    captures."""
+    system = getattr(systems, name)(api=trep)
+    rng = np.random.default_rng(20250 + seed)
     B, N = 2, 200
     arrays = dict(dt=DT, **topology(system))
     arrays["input_names"] = np.array([str(u.name) for u in system.inputs])
@@ -353,8 +354,8 @@ def gen_wrench_torque():
         arrays["b%d_q0" % b] = q0
         arrays["b%d_U" % b] = U
         arrays["b%d_K" % b] = K
-    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], arrays["b0_U"], arrays["b0_K"], (0, 10, 100), seed=21)
-    save("wrench_torque", **arrays, **ds)
+    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], arrays["b0_U"], arrays["b0_K"], (0, 10, 100), seed=10 + seed)
+    save(name, **arrays, **ds)
 
 
 def gen_dual_pendulums():
@@ -466,7 +467,7 @@ def gen_discopt_cart():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "wrench_torque", "dual_pendulums", "discopt"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "wrench_torque", "dual_pendulums", "wrench_spatial", "discopt"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -489,6 +490,8 @@ if __name__ == "__main__":
         gen_dual_pendulums()
     if "wrench_torque" in which:
         gen_wrench_torque()
+    if "wrench_spatial" in which:
+        gen_wrench_torque("wrench_spatial", seed=12)
     if "wrench_arm" in which:
         gen_wrench_arm()
     if "plane_link" in which:

@@ -1315,6 +1315,18 @@ struct Core {
     // for a prismatic one) the generalized force is F . dp_n + tau . om_n (into wF per dynamic config); wD keeps (dp_n, om_n)
     // per item (the input columns of the derivatives); per item pair, F_dq is F . d2p (symmetric) plus tau . (om_b x om_a)
     // when joint b comes before joint a on the path -- not symmetric, so wH holds F_dq(a; b) and F_dq(b; a).
+    // the six coefficients of wrench element c for its dh item n: (dp/dq, axis) for a HybridWrench, the joint's spatial
+    // twist (dp/dq - axis x p, axis) for a SpatialWrench (spatialwrench.c:16-38: unhat(g_dq g^-1))
+    TG_HD void wrench_coeff(int c, int n, bool spatial, double *xi) const {
+        cdiff1(c, n, xi);
+        plane_axis(n, xi + 3);
+        if (spatial) {
+            const double *p = S + P.o_pE + 3 * P.c_e1[c];
+            double t_[3];
+            cross3(xi + 3, p, t_);
+            xi[0] -= t_[0]; xi[1] -= t_[1]; xi[2] -= t_[2];
+        }
+    }
     TG_HD void wrench_terms(bool on) {
         if (n_wrenches() == 0) return;
         double *wF = S + P.o_wF, *wH = S + P.o_wH, *wD = S + P.o_wD;
@@ -1325,17 +1337,49 @@ struct Core {
         if (on) {
             TG_FOR(n, n_wdh()) {
                 const int m = m0 + n, c = P.dh_c[m], k = P.dh_cfg[m], w = c - c0;
-                double dp[3], om[3];
-                cdiff1(c, m, dp);
-                plane_axis(m, om);
-                for (int r = 0; r < 3; r++) { wD[6 * n + r] = dp[r]; wD[6 * n + 3 + r] = om[r]; }
-                if (k < P.nd) lds_add(&wF[k], component(w, 0) * dp[0] + component(w, 1) * dp[1] + component(w, 2) * dp[2] +
-                                               component(w, 3) * om[0] + component(w, 4) * om[1] + component(w, 5) * om[2]);
+                double xi[6], f = 0.0;
+                wrench_coeff(c, m, P.wr_kind[w] == 1, xi);
+                for (int r = 0; r < 6; r++) { wD[6 * n + r] = xi[r]; f += component(w, r) * xi[r]; }
+                if (k < P.nd) lds_add(&wF[k], f);
             }
             TG_FOR(pp, n_wpair()) {
                 const int *pw = P.cpair4 + 4 * (size_t)(p0 + pp);
                 const int c = pw[0], w = c - c0, na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
                 const int ja = P.dh_joint[na], jb = P.dh_joint[nb];
+                if (P.wr_kind[w] == 1) {   // SpatialWrench: d xi_a/dq_b = [xi_b, xi_a] for b before a; nothing symmetric
+                    double Wv[6], xa[6], xb[6], br[6];
+                    for (int r = 0; r < 6; r++) Wv[r] = component(w, r);
+                    wrench_coeff(c, na, true, xa); wrench_coeff(c, nb, true, xb);
+                    bracket(xa, xb, br);                                      // [xi_a, xi_b]
+                    double t_ab = 0.0;
+                    for (int r = 0; r < 6; r++) t_ab += Wv[r] * br[r];
+                    wH[2 * pp] = jb < ja ? -t_ab : 0.0;                      // F_dq(a; b) = W . [xi_b, xi_a]
+                    wH[2 * pp + 1] = ja < jb ? t_ab : 0.0;                   // F_dq(b; a) = W . [xi_a, xi_b]
+                    if (d2w) {
+                        double acc = 0.0;
+                        const int n1 = ja <= jb ? na : nb, n2 = ja <= jb ? nb : na, j2 = ja <= jb ? jb : ja;
+                        double x1[6], x2[6];
+                        wrench_coeff(c, n1, true, x1); wrench_coeff(c, n2, true, x2);
+                        for (int no = P.cu_off[c]; no < P.cu_off[c + 1]; no++) {
+                            const int ko = P.dh_cfg[no];
+                            if (ko >= P.nd || !(j2 < P.dh_joint[no])) continue;
+                            double xo[6], u1[6], u2[6], term = 0.0;
+                            wrench_coeff(c, no, true, xo);
+                            bracket(x2, xo, u1); bracket(x1, u1, u2);        // [xi_1, [xi_2, xi_o]]
+                            for (int r = 0; r < 6; r++) term += Wv[r] * u2[r];
+                            acc += d2w[ko] * term;
+                        }
+                        S[P.e_o_wT + pp] = acc;
+                        double *Hu = S + P.e_o_Hu;
+                        for (int s6 = 0; s6 < 6; s6++) {
+                            const int in = P.wr_in[6 * w + s6];
+                            if (in < 0) continue;
+                            if (kb < P.nd && ja < jb) lds_add(&Hu[ka * P.nu + in], -0.5 * dt * d2w[kb] * br[s6]);
+                            if (na != nb && ka < P.nd && jb < ja) lds_add(&Hu[kb * P.nu + in], 0.5 * dt * d2w[ka] * br[s6]);
+                        }
+                    }
+                    continue;
+                }
                 const double F[3] = {component(w, 0), component(w, 1), component(w, 2)};
                 const double tq[3] = {component(w, 3), component(w, 4), component(w, 5)};
                 double d2[3], oa[3], ob[3], x_ab[3];

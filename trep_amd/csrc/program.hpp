@@ -103,6 +103,7 @@ struct DevProg {
     int has_plane, o_nE;
     // point forces (HybridWrench, force part): items / pairs follow the springs' in the dh / cpair tables
     const int *wr_in; const double *wr_const;   // [6 * n_wrenches] input index or -1, constant component (fx fy fz tx ty tz)
+    const int *wr_kind;                         // [n_wrenches] 0 hybrid, 1 spatial
     int n_wrenches, n_wdh, n_wpair, o_wF, o_wH, o_wD, e_o_wT, e_o_Hu;
     // linear dampers (spring elements with a coefficient c): d|p1-p2|/dq per item, its q-derivative per pair, rate per element
     const double *s_c; int has_damper, o_sX, o_sVq, o_sXX, o_svel, o_sF;
@@ -124,7 +125,7 @@ struct HostProgram {
     std::vector<double> c_dist, c_tol;
     std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
     std::vector<double> damp, cs_k, cs_kq0, cs_c0, s_k, s_x0, s_c, c_nloc, wr_const;
-    std::vector<int> wr_in;
+    std::vector<int> wr_in, wr_kind;
     std::vector<int> cf_cfg, cf_in;
     std::vector<double> jcoef;      // [n_joints*16*4] local-transform coefficients (see pose_sweep)
     int max_depth = 0;
@@ -414,6 +415,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
         H.c_type.push_back(9); H.c_e1.push_back(endpoint(f1)); H.c_e2.push_back(endpoint(f1));
         H.c_nloc.push_back(0.0); H.c_nloc.push_back(0.0); H.c_nloc.push_back(0.0);
         H.c_cfg.push_back(-1); H.c_comp.push_back(0); H.c_dist.push_back(0.0); H.c_tol.push_back(0.0);
+        H.wr_kind.push_back(d->hybrid_wrench_kind[w]);
         for (int s6 = 0; s6 < 6; s6++) {
             const int in = d->hybrid_wrench_input[6 * w + s6];
             if (in >= d->n_inputs) throw std::runtime_error("hybrid wrench: bad input index");
@@ -589,7 +591,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(level_off) X(lvl_joints) X(round_off) X(ch_first) X(ch_len) X(ch_parent) X(j_parent) X(j_kind) X(j_cfg) X(j_pre_ident) X(b_anchor) X(b_item_off) X(b_pair_off) X(it_body) \
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
-    X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in)
+    X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in) X(wr_kind)
 #define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c)
 
 inline void HostProgram::pack() {

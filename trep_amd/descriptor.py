@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 
 from . import frame as _frame
-from .dynamics import Gravity, ConfigSpring, LinearSpring, Damping, ConfigForce, HybridWrench, LinearDamper, Distance, PointToPoint1D, PointOnPlane
+from .dynamics import Gravity, ConfigSpring, LinearSpring, Damping, ConfigForce, HybridWrench, SpatialWrench, LinearDamper, Distance, PointToPoint1D, PointOnPlane
 
 _I32 = ctypes.POINTER(ctypes.c_int32)
 _F64 = ctypes.POINTER(ctypes.c_double)
@@ -35,7 +35,7 @@ _ARRAYS = [
 _TAIL = [("n_config_springs", None), ("config_spring_config", _I32), ("config_spring_k", _F64), ("config_spring_q0", _F64),
          ("n_linear_springs", None), ("linear_spring_frame1", _I32), ("linear_spring_frame2", _I32),
          ("linear_spring_k", _F64), ("linear_spring_x0", _F64), ("constraint_normal", _F64),
-         ("n_hybrid_wrenches", None), ("hybrid_wrench_frame", _I32), ("hybrid_wrench_input", _I32), ("hybrid_wrench_const", _F64),
+         ("n_hybrid_wrenches", None), ("hybrid_wrench_frame", _I32), ("hybrid_wrench_input", _I32), ("hybrid_wrench_const", _F64), ("hybrid_wrench_kind", _I32),
          ("n_linear_dampers", None), ("linear_damper_frame1", _I32), ("linear_damper_frame2", _I32), ("linear_damper_c", _F64)]   # in struct order (include/trep_amd.h)
 _TAIL_SCALARS = [n for n, t in _TAIL if t is None]
 _TAIL_ARRAYS = [(n, t) for n, t in _TAIL if t is not None]
@@ -125,7 +125,7 @@ def flatten(system):
     grav, damp, cf_c, cf_u = [], [], [], []
     cs_c, cs_k, cs_q0 = [], [], []
     ls_f1, ls_f2, ls_k, ls_x0 = [], [], [], []
-    hw_f, hw_in, hw_c = [], [], []
+    hw_f, hw_in, hw_c, hw_kind = [], [], [], []
     ld_f1, ld_f2, ld_c = [], [], []
     for pot in system.potentials:
         if isinstance(pot, Gravity):
@@ -144,7 +144,8 @@ def flatten(system):
     for force in system.forces:
         if isinstance(force, Damping):
             damp.append(force.coefficient_array())
-        elif isinstance(force, HybridWrench):
+        elif isinstance(force, (HybridWrench, SpatialWrench)):
+            hw_kind.append(1 if isinstance(force, SpatialWrench) else 0)
             hw_f.append(fidx[id(force.frame)])
             hw_in += [-1 if v is None else v._index for v in force._wrench_vars]
             hw_c += [float(c) for c in force._wrench_cons]
@@ -177,6 +178,7 @@ def flatten(system):
     t["hybrid_wrench_frame"] = np.array(hw_f, dtype=np.int32)
     t["hybrid_wrench_input"] = np.array(hw_in, dtype=np.int32)
     t["hybrid_wrench_const"] = np.array(hw_c, dtype=np.float64)
+    t["hybrid_wrench_kind"] = np.array(hw_kind, dtype=np.int32)
     t["n_linear_dampers"] = len(ld_c)
     t["linear_damper_frame1"] = np.array(ld_f1, dtype=np.int32)
     t["linear_damper_frame2"] = np.array(ld_f2, dtype=np.int32)

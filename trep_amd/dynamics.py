@@ -236,6 +236,12 @@ class HybridWrench(Force):
         self._system._structure_changed()
 
 
+class SpatialWrench(HybridWrench):
+    """A wrench given in spatial (world) coordinates: its six components multiply the spatial twist of each joint of the
+    frame's path, i.e. the force acts at the point of the frame that coincides with the world origin
+    (forces/spatialwrench.py:14-37, spatialwrench.c:16-38)."""
+
+
 class LinearDamper(Force):
     """A viscous damper between the origins of two frames: force -c d|p1 - p2|/dt along the line between them
     (forces/lineardamper.py:14-60, lineardamper.c:12-45)."""
