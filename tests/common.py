@@ -21,6 +21,7 @@ BUILDERS = {
     "wrench_torque": lambda: systems.wrench_torque(),
     "dual_pendulums": lambda: systems.dual_pendulums(),
     "wrench_spatial": lambda: systems.wrench_spatial(),
+    "wrench_body": lambda: systems.wrench_body(),
     "puppet_forces": lambda: systems.puppet_forces(),
     "extensor_tendon": lambda: systems.extensor_tendon(),
 }

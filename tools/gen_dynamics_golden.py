@@ -32,6 +32,7 @@ BUILDERS = {
     "wrench_torque": lambda: systems.wrench_torque(api=trep),
     "dual_pendulums": lambda: systems.dual_pendulums(api=trep),
     "wrench_spatial": lambda: systems.wrench_spatial(api=trep),
+    "wrench_body": lambda: systems.wrench_body(api=trep),
 }
 N_STATES = 4
 

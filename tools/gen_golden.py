@@ -467,7 +467,7 @@ def gen_discopt_cart():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "wrench_torque", "dual_pendulums", "wrench_spatial", "discopt"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "wrench_torque", "dual_pendulums", "wrench_spatial", "wrench_body", "discopt"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -492,6 +492,8 @@ if __name__ == "__main__":
         gen_wrench_torque()
     if "wrench_spatial" in which:
         gen_wrench_torque("wrench_spatial", seed=12)
+    if "wrench_body" in which:
+        gen_wrench_torque("wrench_body", seed=13)
     if "wrench_arm" in which:
         gen_wrench_arm()
     if "plane_link" in which:

@@ -374,6 +374,14 @@ struct Core {
             const double val = g[0] * o0 + g[1] * o1 + g[2] * o2 + g[3];
             S[P.o_pE + idx] = anchor < 0 ? orr : val;
         }
+        if (on && endpoints && n_wrenches()) TG_FOR(idx, 9 * P.n_wrenches) {   // world rotation of every wrench frame
+            const int w = idx / 9, r = (idx % 9) / 3, cc = idx % 3;
+            const double *Rl = P.wr_Rloc + 9 * w;
+            const int anchor = P.e_anchor[P.c_e1[P.nc + n_springs() + w]];
+            const double *g = G + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
+            const double val = g[0] * Rl[cc] + g[1] * Rl[3 + cc] + g[2] * Rl[6 + cc];
+            S[P.o_wR + idx] = anchor < 0 ? Rl[3 * r + cc] : val;
+        }
         if (on && endpoints && has_plane()) TG_FOR(idx, 3 * P.nc) {   // world normal of every plane constraint
             const int c = idx / 3, r = idx % 3;
             const double *nl = P.c_nloc + 3 * c;
@@ -1317,14 +1325,21 @@ struct Core {
     // when joint b comes before joint a on the path -- not symmetric, so wH holds F_dq(a; b) and F_dq(b; a).
     // the six coefficients of wrench element c for its dh item n: (dp/dq, axis) for a HybridWrench, the joint's spatial
     // twist (dp/dq - axis x p, axis) for a SpatialWrench (spatialwrench.c:16-38: unhat(g_dq g^-1))
-    TG_HD void wrench_coeff(int c, int n, bool spatial, double *xi) const {
+    TG_HD void wrench_coeff(int c, int n, int kind, double *xi) const {
         cdiff1(c, n, xi);
         plane_axis(n, xi + 3);
-        if (spatial) {
+        if (kind == 1) {
             const double *p = S + P.o_pE + 3 * P.c_e1[c];
             double t_[3];
             cross3(xi + 3, p, t_);
             xi[0] -= t_[0]; xi[1] -= t_[1]; xi[2] -= t_[2];
+        } else if (kind == 2) {   // BodyWrench (bodywrench.c:16-38, unhat(g^-1 g_dq)): the same two vectors in the frame's axes
+            const double *R = S + P.o_wR + 9 * (c - P.nc - n_springs());
+            const double a[6] = {xi[0], xi[1], xi[2], xi[3], xi[4], xi[5]};
+            for (int i = 0; i < 3; i++) {
+                xi[i] = R[i] * a[0] + R[3 + i] * a[1] + R[6 + i] * a[2];
+                xi[3 + i] = R[i] * a[3] + R[3 + i] * a[4] + R[6 + i] * a[5];
+            }
         }
     }
     TG_HD void wrench_terms(bool on) {
@@ -1338,7 +1353,7 @@ struct Core {
             TG_FOR(n, n_wdh()) {
                 const int m = m0 + n, c = P.dh_c[m], k = P.dh_cfg[m], w = c - c0;
                 double xi[6], f = 0.0;
-                wrench_coeff(c, m, P.wr_kind[w] == 1, xi);
+                wrench_coeff(c, m, P.wr_kind[w], xi);
                 for (int r = 0; r < 6; r++) { wD[6 * n + r] = xi[r]; f += component(w, r) * xi[r]; }
                 if (k < P.nd) lds_add(&wF[k], f);
             }
@@ -1346,26 +1361,34 @@ struct Core {
                 const int *pw = P.cpair4 + 4 * (size_t)(p0 + pp);
                 const int c = pw[0], w = c - c0, na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
                 const int ja = P.dh_joint[na], jb = P.dh_joint[nb];
-                if (P.wr_kind[w] == 1) {   // SpatialWrench: d xi_a/dq_b = [xi_b, xi_a] for b before a; nothing symmetric
+                if (P.wr_kind[w] != 0) {
+                    // SpatialWrench: d xi_a/dq_b = [xi_b, xi_a] for b before a;  BodyWrench: d xi_a/dq_b = [xi_a, xi_b] for b
+                    // after a.  Nothing symmetric.  With br = [xi_a, xi_b]:
+                    const int kind = P.wr_kind[w];
+                    const bool body = kind == 2;
                     double Wv[6], xa[6], xb[6], br[6];
                     for (int r = 0; r < 6; r++) Wv[r] = component(w, r);
-                    wrench_coeff(c, na, true, xa); wrench_coeff(c, nb, true, xb);
-                    bracket(xa, xb, br);                                      // [xi_a, xi_b]
+                    wrench_coeff(c, na, kind, xa); wrench_coeff(c, nb, kind, xb);
+                    bracket(xa, xb, br);
                     double t_ab = 0.0;
                     for (int r = 0; r < 6; r++) t_ab += Wv[r] * br[r];
-                    wH[2 * pp] = jb < ja ? -t_ab : 0.0;                      // F_dq(a; b) = W . [xi_b, xi_a]
-                    wH[2 * pp + 1] = ja < jb ? t_ab : 0.0;                   // F_dq(b; a) = W . [xi_a, xi_b]
+                    const bool d_ab = body ? ja < jb : jb < ja;   // does coefficient a depend on joint b?
+                    const bool d_ba = body ? jb < ja : ja < jb;   // does coefficient b depend on joint a?
+                    const double sg = body ? 1.0 : -1.0;          // d xi_a/dq_b = sg br,  d xi_b/dq_a = -sg br
+                    wH[2 * pp] = d_ab ? sg * t_ab : 0.0;
+                    wH[2 * pp + 1] = d_ba ? -sg * t_ab : 0.0;
                     if (d2w) {
                         double acc = 0.0;
-                        const int n1 = ja <= jb ? na : nb, n2 = ja <= jb ? nb : na, j2 = ja <= jb ? jb : ja;
+                        const int n1 = ja <= jb ? na : nb, n2 = ja <= jb ? nb : na, j1 = ja <= jb ? ja : jb, j2 = ja <= jb ? jb : ja;
                         double x1[6], x2[6];
-                        wrench_coeff(c, n1, true, x1); wrench_coeff(c, n2, true, x2);
+                        wrench_coeff(c, n1, kind, x1); wrench_coeff(c, n2, kind, x2);
                         for (int no = P.cu_off[c]; no < P.cu_off[c + 1]; no++) {
-                            const int ko = P.dh_cfg[no];
-                            if (ko >= P.nd || !(j2 < P.dh_joint[no])) continue;
+                            const int ko = P.dh_cfg[no], jo = P.dh_joint[no];
+                            if (ko >= P.nd || !(body ? jo < j1 : j2 < jo)) continue;
                             double xo[6], u1[6], u2[6], term = 0.0;
-                            wrench_coeff(c, no, true, xo);
-                            bracket(x2, xo, u1); bracket(x1, u1, u2);        // [xi_1, [xi_2, xi_o]]
+                            wrench_coeff(c, no, kind, xo);
+                            if (body) { bracket(xo, x1, u1); bracket(u1, x2, u2); }     // [[xi_o, xi_1], xi_2]
+                            else { bracket(x2, xo, u1); bracket(x1, u1, u2); }          // [xi_1, [xi_2, xi_o]]
                             for (int r = 0; r < 6; r++) term += Wv[r] * u2[r];
                             acc += d2w[ko] * term;
                         }
@@ -1374,8 +1397,9 @@ struct Core {
                         for (int s6 = 0; s6 < 6; s6++) {
                             const int in = P.wr_in[6 * w + s6];
                             if (in < 0) continue;
-                            if (kb < P.nd && ja < jb) lds_add(&Hu[ka * P.nu + in], -0.5 * dt * d2w[kb] * br[s6]);
-                            if (na != nb && ka < P.nd && jb < ja) lds_add(&Hu[kb * P.nu + in], 0.5 * dt * d2w[ka] * br[s6]);
+                            // F_dudq(o = b, u; a) = d xi_b/dq_a and F_dudq(o = a, u; b) = d xi_a/dq_b, component s6
+                            if (kb < P.nd && d_ba) lds_add(&Hu[ka * P.nu + in], -0.5 * dt * d2w[kb] * (-sg * br[s6]));
+                            if (na != nb && ka < P.nd && d_ab) lds_add(&Hu[kb * P.nu + in], -0.5 * dt * d2w[ka] * (sg * br[s6]));
                         }
                     }
                     continue;

@@ -103,7 +103,8 @@ struct DevProg {
     int has_plane, o_nE;
     // point forces (HybridWrench, force part): items / pairs follow the springs' in the dh / cpair tables
     const int *wr_in; const double *wr_const;   // [6 * n_wrenches] input index or -1, constant component (fx fy fz tx ty tz)
-    const int *wr_kind;                         // [n_wrenches] 0 hybrid, 1 spatial
+    const int *wr_kind;                         // [n_wrenches] 0 hybrid, 1 spatial, 2 body
+    const double *wr_Rloc; int o_wR;            // [9 * n_wrenches] frame rotation relative to its anchor joint; world rotation in LDS
     int n_wrenches, n_wdh, n_wpair, o_wF, o_wH, o_wD, e_o_wT, e_o_Hu;
     // linear dampers (spring elements with a coefficient c): d|p1-p2|/dq per item, its q-derivative per pair, rate per element
     const double *s_c; int has_damper, o_sX, o_sVq, o_sXX, o_svel, o_sF;
@@ -124,7 +125,7 @@ struct HostProgram {
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
     std::vector<double> c_dist, c_tol;
     std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
-    std::vector<double> damp, cs_k, cs_kq0, cs_c0, s_k, s_x0, s_c, c_nloc, wr_const;
+    std::vector<double> damp, cs_k, cs_kq0, cs_c0, s_k, s_x0, s_c, c_nloc, wr_const, wr_Rloc;
     std::vector<int> wr_in, wr_kind;
     std::vector<int> cf_cfg, cf_in;
     std::vector<double> jcoef;      // [n_joints*16*4] local-transform coefficients (see pose_sweep)
@@ -416,6 +417,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
         H.c_nloc.push_back(0.0); H.c_nloc.push_back(0.0); H.c_nloc.push_back(0.0);
         H.c_cfg.push_back(-1); H.c_comp.push_back(0); H.c_dist.push_back(0.0); H.c_tol.push_back(0.0);
         H.wr_kind.push_back(d->hybrid_wrench_kind[w]);
+        for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) H.wr_Rloc.push_back(offset[f1].m[4 * r + cc]);
         for (int s6 = 0; s6 < 6; s6++) {
             const int in = d->hybrid_wrench_input[6 * w + s6];
             if (in >= d->n_inputs) throw std::runtime_error("hybrid wrench: bad input index");
@@ -518,6 +520,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.o_G = take(std::max(12 * nj, 2 * nitems));  // also holds the per-item residual terms
     P.o_gB = take(12 * nb); P.o_pE = take(3 * P.n_endpoints);
     P.has_plane = has_plane ? 1 : 0; P.o_nE = take(has_plane ? 3 * nc : 0);   // world normals of the plane constraints
+    P.o_wR = take(9 * d->n_hybrid_wrenches);   // world rotations of the wrench frames (body wrenches)
     P.o_dqi = take(nitems);  // per-item rates: alive only while the poses are (Jacobians -> prefix sums)
     off = std::max(off, end_df);
     P.lds_per_team = (off + 1) & ~1;
@@ -592,7 +595,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
     X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in) X(wr_kind)
-#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c)
+#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c) X(wr_Rloc)
 
 inline void HostProgram::pack() {
     ipool.clear(); dpool.clear(); ioff.clear(); doff.clear();

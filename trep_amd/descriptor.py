@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 
 from . import frame as _frame
-from .dynamics import Gravity, ConfigSpring, LinearSpring, Damping, ConfigForce, HybridWrench, SpatialWrench, LinearDamper, Distance, PointToPoint1D, PointOnPlane
+from .dynamics import Gravity, ConfigSpring, LinearSpring, Damping, ConfigForce, HybridWrench, SpatialWrench, BodyWrench, LinearDamper, Distance, PointToPoint1D, PointOnPlane
 
 _I32 = ctypes.POINTER(ctypes.c_int32)
 _F64 = ctypes.POINTER(ctypes.c_double)
@@ -144,8 +144,8 @@ def flatten(system):
     for force in system.forces:
         if isinstance(force, Damping):
             damp.append(force.coefficient_array())
-        elif isinstance(force, (HybridWrench, SpatialWrench)):
-            hw_kind.append(1 if isinstance(force, SpatialWrench) else 0)
+        elif isinstance(force, HybridWrench):   # and its subclasses SpatialWrench, BodyWrench
+            hw_kind.append(2 if isinstance(force, BodyWrench) else (1 if isinstance(force, SpatialWrench) else 0))
             hw_f.append(fidx[id(force.frame)])
             hw_in += [-1 if v is None else v._index for v in force._wrench_vars]
             hw_c += [float(c) for c in force._wrench_cons]

@@ -242,6 +242,11 @@ class SpatialWrench(HybridWrench):
     (forces/spatialwrench.py:14-37, spatialwrench.c:16-38)."""
 
 
+class BodyWrench(HybridWrench):
+    """A wrench given in the coordinates of the frame it is applied to: its six components multiply the body twist of each
+    joint of the frame's path (forces/bodywrench.py, bodywrench.c:16-38)."""
+
+
 class LinearDamper(Force):
     """A viscous damper between the origins of two frames: force -c d|p1 - p2|/dt along the line between them
     (forces/lineardamper.py:14-60, lineardamper.c:12-45)."""

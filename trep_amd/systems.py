@@ -169,6 +169,27 @@ def wrench_spatial(api=None):
     return system
 
 
+def wrench_body(api=None):
+    """The arm of wrench_arm driven by BodyWrench forces (components in the coordinates of the frame they act on), one on a
+    frame with a constant offset rotation.  Synthetic test system."""
+    T = _api(api)
+    system = T.System()
+    system.import_frames([
+        T.tx('slide', name='Base', kinematic=True), [
+            T.rz('a', name='Shoulder'), [
+                T.tx(1.0, name='Upper', mass=2.0), [
+                    T.ry('b', name='Elbow'), [
+                        T.tx(0.8, name='Fore', mass=(1.0, 0.1, 0.2, 0.3)), [
+                            T.rx('c', name='Wrist'), [
+                                T.tz(-0.5, name='Hand', mass=0.5), [
+                                    T.ry(0.7), [T.tx(0.1, name='Tool')]]]]]]]]])
+    T.potentials.Gravity(system, (0, 0, -9.8))
+    T.forces.BodyWrench(system, 'Tool', ('tool-fx', 0.5, -0.3, 'tool-tx', 0.3, 'tool-tz'), name='tool')
+    T.forces.BodyWrench(system, 'Fore', (0.2, 0, 0.4, 0, 1.0, -0.5), name='fore')
+    T.forces.Damping(system, 0.1)
+    return system
+
+
 def dual_pendulums(api=None):
     """examples/dual_pendulums.py:28-44: two pendulums on neighbouring pivots joined by a linear spring and a linear
     damper, under gravity."""
