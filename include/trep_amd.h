@@ -92,9 +92,7 @@ typedef struct tg_system_desc {
     const int32_t *hybrid_wrench_kind;   /* [n_hybrid_wrenches] 0: HybridWrench; 1: SpatialWrench (forces/spatialwrench.c: all six
                                           * coefficients from g_dq g^-1, the joint's spatial twist); 2: BodyWrench
                                           * (forces/bodywrench.c: from g^-1 g_dq, the body twist) */
-    /* forces/lineardamper.c: f = -c (d/dt |p1 - p2|) d|p1 - p2|/dq between the origins of two frames.  DEL solve, first
-     * derivatives and continuous dynamics; second derivatives of the step map are not implemented for systems with
-     * such dampers (TG_ERR_UNSUPPORTED; the reference has them). */
+    /* forces/lineardamper.c: f = -c (d/dt |p1 - p2|) d|p1 - p2|/dq between the origins of two frames. */
     int32_t n_linear_dampers;
     const int32_t *linear_damper_frame1; /* [n_linear_dampers] */
     const int32_t *linear_damper_frame2; /* [n_linear_dampers] */

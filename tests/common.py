@@ -22,6 +22,7 @@ BUILDERS = {
     "dual_pendulums": lambda: systems.dual_pendulums(),
     "wrench_spatial": lambda: systems.wrench_spatial(),
     "wrench_body": lambda: systems.wrench_body(),
+    "damper_link": lambda: systems.damper_link(),
     "puppet_forces": lambda: systems.puppet_forces(),
     "extensor_tendon": lambda: systems.extensor_tendon(),
 }

@@ -33,6 +33,7 @@ BUILDERS = {
     "dual_pendulums": lambda: systems.dual_pendulums(api=trep),
     "wrench_spatial": lambda: systems.wrench_spatial(api=trep),
     "wrench_body": lambda: systems.wrench_body(api=trep),
+    "damper_link": lambda: systems.damper_link(api=trep),
 }
 N_STATES = 4
 

@@ -358,6 +358,21 @@ def gen_wrench_torque(name="wrench_torque", seed=11):
     save(name, **arrays, **ds)
 
 
+def gen_damper_link():
+    """LinearDamper without LinearSpring: rollout, first and full second derivative tensors, DSystem captures."""
+    system = systems.damper_link(api=trep)
+    N = 200
+    arrays = dict(dt=DT, **topology(system))
+    q0 = system.q
+    U = np.zeros((N, 0)); K = np.zeros((N, 0))
+    r = rollout(system, q0, U, K, N, deriv_steps=(1, 50, N), deriv2_full=True)
+    for key, val in r.items():
+        arrays["b0_" + key] = val
+    arrays["b0_q0"] = q0
+    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], U, K, (0, 10, 100), seed=23)
+    save("damper_link", **arrays, **ds)
+
+
 def gen_dual_pendulums():
     """examples/dual_pendulums.py run as the script does (tf = 10, dt = 0.01) plus first derivatives (the build has no
     second derivatives for LinearDamper)."""
@@ -467,7 +482,7 @@ def gen_discopt_cart():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "wrench_torque", "dual_pendulums", "wrench_spatial", "wrench_body", "discopt"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "wrench_torque", "dual_pendulums", "wrench_spatial", "wrench_body", "damper_link", "discopt"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -486,6 +501,8 @@ if __name__ == "__main__":
         gen_puppet_forces()
     if "extensor_tendon" in which:
         gen_extensor_tendon()
+    if "damper_link" in which:
+        gen_damper_link()
     if "dual_pendulums" in which:
         gen_dual_pendulums()
     if "wrench_torque" in which:

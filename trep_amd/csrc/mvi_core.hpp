@@ -1306,7 +1306,65 @@ struct Core {
                 if (k < P.nd) lds_add(&S[P.o_sF + k], -P.s_c[sp] * S[P.o_svel + sp] * S[P.o_sX + n]);
             }
             TG_SYNC();
+            if (d2w) damper_second(on);
         }
+    }
+
+    // d3|p1 - p2| / dq_a dq_b dq_c of spring element c for three of its dh items (tapemeasure.c:98-168); poses alive
+    TG_HD double length_d3(int c, int na, int nb, int nc_) const {
+        const double *pa = S + P.o_pE + 3 * P.c_e1[c], *pb = S + P.o_pE + 3 * P.c_e2[c];
+        const double v[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+        double a[3], b[3], cc[3], ab[3], ac[3], bc[3], abc[3];
+        cdiff1(c, na, a); cdiff1(c, nb, b); cdiff1(c, nc_, cc);
+        cdiff2(c, na, nb, ab); cdiff2(c, na, nc_, ac); cdiff2(c, nb, nc_, bc);
+        cdiff3(c, na, nb, nc_, abc);
+        const double x = sqrt(dot3(v, v));
+        const double xa = dot3(v, a) / x, xb = dot3(v, b) / x, xc = dot3(v, cc) / x;
+        const double xab = (dot3(a, b) + dot3(v, ab) - xa * xb) / x, xac = (dot3(a, cc) + dot3(v, ac) - xa * xc) / x;
+        const double xbc = (dot3(b, cc) + dot3(v, bc) - xb * xc) / x;
+        return (dot3(ac, b) + dot3(a, bc) + dot3(cc, ab) + dot3(v, abc) - xac * xb - xa * xbc - xab * xc) / x;
+    }
+    // Second-derivative kernel, dampers (lineardamper.c:47-92 contracted with the adjoint weights w): per element pair
+    //   P = sum_o w_o f_dqdq(o; a, b),  R = sum_o w_o f_ddqdq(o; dq a, q b)
+    // (R is symmetric in (a, b) because the reference's f_ddqdq uses length_dq(q2) where length_dqdq(q, q2) is meant,
+    // :88 -- reproduced).  Needs the poses and the first-order damper quantities.
+    TG_HD void damper_second(bool on) {
+        double *sT = S + P.e_o_sT, *WX = S + P.e_o_sWX, *WXq = S + P.e_o_sWXq;
+        const double *dqv = S + P.o_dq;
+        if (on) {
+            TG_FOR(i, 2 * n_springs()) WX[i] = 0.0;
+            TG_FOR(i, n_sdh()) WXq[i] = 0.0;
+        }
+        TG_SYNC();
+        if (on) {
+            TG_FOR(n, n_sdh()) {
+                const int m = P.n_dh + n, sp = P.dh_c[m] - P.nc, k = P.dh_cfg[m];
+                if (k < P.nd) { lds_add(&WX[2 * sp], d2w[k] * S[P.o_sX + n]); lds_add(&WX[2 * sp + 1], d2w[k]); }
+            }
+            TG_FOR(pp, n_spair()) {
+                const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
+                const int na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+                const double xab = S[P.o_sXX + pp];
+                if (kb < P.nd) lds_add(&WXq[na - P.n_dh], d2w[kb] * xab);
+                if (na != nb && ka < P.nd) lds_add(&WXq[nb - P.n_dh], d2w[ka] * xab);
+            }
+        }
+        TG_SYNC();
+        if (on) TG_FOR(pp, n_spair()) {
+            const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
+            const int c = pw[0], sp = c - P.nc, na = pw[1], nb = pw[2], ia = na - P.n_dh, ib = nb - P.n_dh;
+            const double cc = P.s_c[sp], vel = S[P.o_svel + sp], xa = S[P.o_sX + ia], xb = S[P.o_sX + ib], xab = S[P.o_sXX + pp];
+            double vab = 0.0, wxab = 0.0;
+            for (int no = P.cu_off[c]; no < P.cu_off[c + 1]; no++) {
+                const int ko = P.dh_cfg[no];
+                const double x3 = length_d3(c, no, na, nb);
+                vab += x3 * dqv[ko];
+                if (ko < P.nd) wxab += d2w[ko] * x3;
+            }
+            sT[2 * pp] = -cc * (vab * WX[2 * sp] + S[P.o_sVq + ia] * WXq[ib] + S[P.o_sVq + ib] * WXq[ia] + vel * wxab);
+            sT[2 * pp + 1] = -cc * (xab * WX[2 * sp] + xa * xb * WX[2 * sp + 1]);
+        }
+        TG_SYNC();
     }
 
     // derivatives of the damper force of the element pair pp = (na, nb): F_dq(a; b), F_dq(b; a) and F_ddq (symmetric)
@@ -1776,8 +1834,18 @@ struct Core {
             TG_SYNC();
             d2w = w;
         }
+        if (has_damper()) d2w = w;
         eval_midpoint(on);
         d2w = nullptr;
+        if (has_damper() && on) TG_FOR(pp, n_spair()) {   // dampers: dt/4 F_dqdq + sa/2 F_ddqdq(.; a, b) + sb/2 F_ddqdq(.; b, a)
+            const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
+            const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
+            const double Pq = 0.25 * dt * S[P.e_o_sT + 2 * pp], R = S[P.e_o_sT + 2 * pp + 1];
+            lds_add(&H12[ka * hl + kb], -Pq);                    // slots (1, 2): -R/2 + R/2
+            if (pw[1] != pw[2]) lds_add(&H12[kb * hl + ka], -Pq);
+            lds_add(&H11[sym(ka, kb)], -(Pq - R));               // slots (1, 1): -R/2 - R/2
+            lds_add(&H22[sym(ka, kb)], -(Pq + R));               // slots (2, 2)
+        }
         if (on) TG_FOR(pp, n_wpair()) {   // D_a D_b fm2 = dt/4 F_dqdq in all three slot combinations (midpointvi.c:1473-1497)
             const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + n_spair() + pp);
             const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;

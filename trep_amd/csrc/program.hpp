@@ -108,6 +108,7 @@ struct DevProg {
     int n_wrenches, n_wdh, n_wpair, o_wF, o_wH, o_wD, e_o_wT, e_o_Hu;
     // linear dampers (spring elements with a coefficient c): d|p1-p2|/dq per item, its q-derivative per pair, rate per element
     const double *s_c; int has_damper, o_sX, o_sVq, o_sXX, o_svel, o_sF;
+    int n_true_springs, e_o_sT, e_o_sWX, e_o_sWXq;   // second derivatives: per pair (P, R), per element (sum w x, sum w), per item sum_o w_o x_ob
     const int *tab_i; const double *tab_d; int n_tab_i, n_tab_d;  // the packed table buffers (all pointers above point into them)
     int e_o_H11, e_o_H12, e_o_H22, e_o_G1, e_o_w, e_o_zq, e_o_zp, e_o_vec, e_o_vec2, e_lds_per_team;
     const double *cs_c0;          // [nq] 1/2 sum k q0^2 (constant part of V)
@@ -501,7 +502,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.o_I = take(4 * nb);   // mass and principal inertias of every body (copied from the table once per kernel)
     P.o_ctol = take(nc);    // constraint tolerances, likewise
     P.o_sV = take(ns ? nq : 0); P.o_sH = take(P.n_spair);   // spring gradient per dynamic config, Hessian per item pair (midpoint)
-    P.has_damper = d->n_linear_dampers > 0 ? 1 : 0;
+    P.has_damper = d->n_linear_dampers > 0 ? 1 : 0; P.n_true_springs = n_true_springs;
     P.o_sX = take(P.has_damper ? P.n_sdh : 0); P.o_sVq = take(P.has_damper ? P.n_sdh : 0); P.o_sXX = take(P.has_damper ? P.n_spair : 0);
     P.o_svel = take(P.has_damper ? ns : 0); P.o_sF = take(P.has_damper ? nd : 0);
     P.o_wF = take(nw ? nd : 0); P.o_wH = take(2 * P.n_wpair); P.o_wD = take(6 * P.n_wdh);   // wrenches: generalized force, F_dq(a;b) and F_dq(b;a) per pair, (dp/dq, axis) per item
@@ -571,6 +572,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     off = P.d_o_T12;
     P.e_o_H11 = take(nq * (nq + 1) / 2); P.e_o_H22 = take(nq * (nq + 1) / 2); P.e_o_H12 = take(nq * (nq | 1)); P.e_o_G1 = take(nq * nc);
     P.e_o_w = take(P.nf); P.e_o_zq = take(nd); P.e_o_zp = take(nd); P.e_o_vec = take(12 * nq); P.e_o_vec2 = P.e_o_vec;   // tangent products of four columns: [3][4][nq]
+    P.e_o_sT = take(P.has_damper ? 2 * P.n_spair : 0); P.e_o_sWX = take(P.has_damper ? 2 * ns : 0); P.e_o_sWXq = take(P.has_damper ? P.n_sdh : 0);
     P.e_o_wT = take(P.n_wpair); P.e_o_Hu = take(nw ? nq * P.nu : 0);   // point forces: w-contracted F.d3p per pair, -dt/2 w.F_dudq [nq][nu]
     off = std::max(off, P.d_lds_per_team);
     P.e_lds_per_team = (off + 1) & ~1;

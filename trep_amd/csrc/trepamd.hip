@@ -562,7 +562,7 @@ int tg_batch_deriv1(tg_batch *b) {
 
 int tg_batch_deriv2_contract(tg_batch *b, const double *z_host, double *hz_host) {
     if (!b || !z_host || !hz_host) return fail(TG_ERR_INVALID, "null argument");
-    if (b->P.n_springs) return fail(TG_ERR_UNSUPPORTED, b->P.has_damper ? "second derivatives with LinearDamper forces (f_dqdq, f_ddqdq) are not implemented" : "V_dqdqdq() is undefined for LinearSpring (as in the reference): no second derivatives");
+    if (b->P.n_true_springs) return fail(TG_ERR_UNSUPPORTED, "V_dqdqdq() is undefined for LinearSpring (as in the reference): no second derivatives");
     if (b->t2 == b->t1) return fail(TG_ERR_STATE, "Integrator has not solved the next time step yet.");
     HIP_TRY(hipSetDevice(b->device));
     const size_t B = (size_t)b->batch, R = (size_t)b->P.d_nrhs;
@@ -578,7 +578,7 @@ int tg_batch_deriv2_contract(tg_batch *b, const double *z_host, double *hz_host)
 
 int tg_batch_deriv2_contract_lambda(tg_batch *b, const double *z_host, const double *zlambda_host, double *hz_host) {
     if (!b || !hz_host || (!z_host && !zlambda_host)) return fail(TG_ERR_INVALID, "null argument");
-    if (b->P.n_springs) return fail(TG_ERR_UNSUPPORTED, b->P.has_damper ? "second derivatives with LinearDamper forces (f_dqdq, f_ddqdq) are not implemented" : "V_dqdqdq() is undefined for LinearSpring (as in the reference): no second derivatives");
+    if (b->P.n_true_springs) return fail(TG_ERR_UNSUPPORTED, "V_dqdqdq() is undefined for LinearSpring (as in the reference): no second derivatives");
     if (b->t2 == b->t1) return fail(TG_ERR_STATE, "Integrator has not solved the next time step yet.");
     HIP_TRY(hipSetDevice(b->device));
     const size_t B = (size_t)b->batch, R = (size_t)b->P.d_nrhs;
@@ -736,7 +736,7 @@ int tg_batch_dynamics(tg_batch *b, const double *q_host, const double *dq_host, 
 
 int tg_batch_deriv2_contract_device(tg_batch *b, const double *z_dev, double *hz_dev) {
     if (!b || !z_dev || !hz_dev) return fail(TG_ERR_INVALID, "null argument");
-    if (b->P.n_springs) return fail(TG_ERR_UNSUPPORTED, b->P.has_damper ? "second derivatives with LinearDamper forces (f_dqdq, f_ddqdq) are not implemented" : "V_dqdqdq() is undefined for LinearSpring (as in the reference): no second derivatives");
+    if (b->P.n_true_springs) return fail(TG_ERR_UNSUPPORTED, "V_dqdqdq() is undefined for LinearSpring (as in the reference): no second derivatives");
     if (b->t2 == b->t1) return fail(TG_ERR_STATE, "Integrator has not solved the next time step yet.");
     HIP_TRY(hipSetDevice(b->device));
     tg::RunArgs A = base_args(b, tg::MODE_DERIV2Z);

@@ -148,6 +148,27 @@ def wrench_arm(api=None):
     return system
 
 
+def damper_link(api=None):
+    """Two pendulums and a 3-D arm joined by LinearDamper forces only (no LinearSpring, so the reference has second
+    derivatives for it), config springs for stiffness.  Synthetic test system."""
+    T = _api(api)
+    system = T.System()
+    system.import_frames([
+        T.rx('theta1'), [
+            T.tz(2, mass=1, name='pend1')],
+        T.ty(1), [
+            T.rx('theta2'), [
+                T.tz(2, mass=1, name='pend2'), [
+                    T.ry('phi'), [T.tx(0.7, mass=0.5, name='tip')]]]]])
+    T.forces.LinearDamper(system, 'pend1', 'pend2', c=1.0)
+    T.forces.LinearDamper(system, 'pend1', 'tip', c=0.6)
+    T.potentials.ConfigSpring(system, 'theta1', k=3.0, q0=0.2)
+    T.potentials.ConfigSpring(system, 'phi', k=2.0)
+    T.potentials.Gravity(system, name="Gravity")
+    system.q = [2.5, -2.0, 0.4]
+    return system
+
+
 def wrench_spatial(api=None):
     """The arm of wrench_arm driven by SpatialWrench forces (components in spatial coordinates): one with inputs and
     constants at the hand, a constant one on the fore-arm.  Synthetic test system."""
