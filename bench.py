@@ -11,10 +11,12 @@ ranks / wall time between barriers.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: the batch shards trivially (weak scaling: 8192 trajectories per GPU), no data-path
-collective; after each rollout the ranks all-gather the terminal states [B_local][nX] over
-RCCL/xGMI (what a discopt line-search consumes).  torch is used only for that (process group,
-barrier, the gather buffer); the product path itself is libtrepamd.so through ctypes.
+Multi-GPU: the batch shards trivially, no data-path collective; after each rollout the ranks all-gather the
+terminal states [B_local][nX] over RCCL/xGMI (what a discopt line-search consumes).  The ranks never import
+torch: the launcher only provides RANK / LOCAL_RANK / WORLD_SIZE, the communicator is RCCL behind the C ABI
+(include/trep_amd.h tg_comm_*, trep_amd/rccl.py).  The headline value is WEAK scaling (8192 trajectories per GPU);
+the same run also measures BASELINE config 3 as written -- 8192 trajectories in total, B/N per GPU -- and reports
+it as the "strong_scaling" object, and config 4 (discopt on 256 puppet seeds, N = 1000) as the "discopt" object.
 """
 import argparse
 import json
@@ -61,11 +63,9 @@ def build_workload(args, rank):
     system = systems.puppet()
     B, N, dt = args.batch, args.rollout_steps, 0.01
     nd = system.nQd
-    # 256 distinct seeded initial conditions, tiled over the batch (building 8192 host-side FK poses
-    # in Python would dominate start-up); each rank takes its own seed so shards differ.
-    distinct = min(B, 256)
-    base = systems.puppet_initial_conditions(system, distinct, seed=20250 + 3 + 1000 * rank)
-    Q0 = np.tile(base, ((B + distinct - 1) // distinct, 1))[:B]
+    # every trajectory of the batch gets its own seeded initial condition (about 5 s of host
+    # forward kinematics for 8192 poses); each rank takes its own seed so shards differ.
+    Q0 = systems.puppet_initial_conditions(system, B, seed=20250 + 3 + 1000 * rank)
     K = systems.puppet_string_schedule(system, Q0[:, nd:], N, dt)
     return system, Q0, K, dt
 
@@ -161,80 +161,42 @@ def pmc_fp64(batch, rollout_steps, workload_prefix):
     return best
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8192, help="trajectories per GPU")
-    ap.add_argument("--rollout-steps", type=int, default=200, help="DEL steps per trajectory per pass")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-x", action="store_true", help="do not write the state trajectory X to HBM")
-    ap.add_argument("--system", choices=["puppet", "puppet-basic", "cart", "scissor"], default="puppet",
-                    help="puppet = the BASELINE metric; cart / scissor = secondary lines")
-    ap.add_argument("--predictor", choices=["reference", "extrapolate"], default="reference",
-                    help="Newton initial guess of the rollout; 'reference' (default) keeps the reference's semantics and "
-                         "iteration counts, 'extrapolate' is an opt-in warm start (reported separately, not the headline)")
-    ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank (self-test)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    torch = None
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        # torch first: its bundled HIP runtime (same SONAME) is then the single runtime of the process
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+def measure_rollouts(args, system, Q0, U, K, dt, B, N, device, comm, gather_rows):
+    """W warm-up + K timed passes of B trajectories x N steps on this rank; returns timing and status figures."""
     import trep_amd
-
-    U = None
-    if args.system == "puppet":
-        system, Q0, K, dt = build_workload(args, rank)
-    else:
-        system, Q0, U, K, dt = build_secondary(args, rank)
-        args.no_cpu_baseline = True
-    B, N = args.batch, args.rollout_steps
-    mvi = trep_amd.BatchMidpointVI(system, B, device=local_rank)
+    from trep_amd import _lib
+    L = _lib.lib()
+    mvi = trep_amd.BatchMidpointVI(system, B, device=device)
     mvi.predictor = args.predictor
-    nX, nU, nc = mvi.nX, mvi.nU, mvi.nc
+    nX = mvi.nX
     K_dev = mvi.device_array(K) if K is not None else None
     U_dev = mvi.device_array(U) if U is not None else None
-    gather = None
-    if use_dist:
-        X_t = None if args.no_x else torch.empty((B, N + 1, nX), dtype=torch.float64, device="cuda")
-        X_dev = None if X_t is None else X_t.data_ptr()
-        gather = torch.empty((world * B, nX), dtype=torch.float64, device="cuda")
-        term = torch.empty((B, nX), dtype=torch.float64, device="cuda")
-    else:
-        X_dev = None if args.no_x else mvi.device_empty(B * (N + 1) * nX)
-
-    def reset():
-        mvi.initialize_from_configs(0.0, Q0, dt, Q0)
+    X_dev = None if args.no_x else mvi.device_empty(B * (N + 1) * nX)
+    term = gather = rows = None
+    if comm is not None:
+        term = mvi.device_empty(gather_rows * nX)            # this rank's terminal states, padded to the largest shard
+        gather = mvi.device_empty(comm.world * gather_rows * nX)
+        if X_dev is not None:
+            idx = (np.arange(B, dtype=np.int64) * (N + 1) + N).astype(np.int32)
+            rows = L.tg_device_alloc(device, max(idx.nbytes, 8))
+            mvi._owned_dev.append(rows)
+            _lib.check(L.tg_memcpy_h2d(device, rows, idx.ctypes.data, idx.nbytes))
 
     def one_pass():
-        mvi.restore()   # device-to-device: every pass integrates the same 200-step window
+        mvi.restore()   # device-to-device: every pass integrates the same N-step window
         mvi.rollout_device(N, dt, U_dev, K_dev, X_dev)
-        if use_dist:
-            mvi.synchronize()
-            if X_t is not None:
-                term.copy_(X_t[:, N, :])
-            dist.all_gather_into_tensor(gather, term)
+        if comm is not None:
+            if rows is not None:   # term[b] = X[b][N] (default stream: ordered after the rollout, before the collective)
+                _lib.check(L.tg_copy_rows(device, B, nX, None, rows, X_dev, term))
+            comm.all_gather_device(term, gather, gather_rows * nX * 8, synchronize=False)
 
     def sync():
         mvi.synchronize()
-        if use_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        if comm is not None:
+            _lib.check(L.tg_comm_synchronize(comm._h))
+            comm.barrier()
 
-    reset()
+    mvi.initialize_from_configs(0.0, Q0, dt, Q0)
     mvi.snapshot()
     for _ in range(args.warmup):
         one_pass()
@@ -245,58 +207,142 @@ def main():
         one_pass()
     sync()
     elapsed = time.perf_counter() - t0
-    if use_dist:
-        from trep_amd import distributed
-        elapsed = distributed.max_over_ranks(elapsed, device="cuda")
+    if comm is not None:
+        elapsed = comm.max(elapsed)
     n_launch, kernel_ms = mvi.timing(reset=True)
     iters, status = mvi.status()
-    total_iters = int(iters.sum())
-    n_failed = int((status != 0).sum())
+    res = {"elapsed": elapsed, "launches": n_launch, "kernel_ms": kernel_ms, "newton_iterations": int(iters.sum()),
+           "failed": int((status != 0).sum()), "info": mvi.info(), "nX": mvi.nX, "nU": mvi.nU, "nc": mvi.nc}
+    mvi.close()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8192, help="trajectories per GPU (weak scaling) / in total (strong scaling)")
+    ap.add_argument("--rollout-steps", type=int, default=200, help="DEL steps per trajectory per pass")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="headline line: weak = --batch per GPU (default), strong = --batch in total (BASELINE config 3 as written); "
+                         "with more than one rank the other mode is measured too and reported next to it")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-discopt", action="store_true", help="skip the discopt iterations/s measurement (BASELINE config 4)")
+    ap.add_argument("--discopt-seeds", type=int, default=256)
+    ap.add_argument("--discopt-horizon", type=int, default=1000)
+    ap.add_argument("--no-x", action="store_true", help="do not write the state trajectory X to HBM")
+    ap.add_argument("--system", choices=["puppet", "puppet-basic", "cart", "scissor"], default="puppet",
+                    help="puppet = the BASELINE metric; cart / scissor = secondary lines")
+    ap.add_argument("--predictor", choices=["reference", "extrapolate"], default="reference",
+                    help="Newton initial guess of the rollout; 'reference' (default) keeps the reference's semantics and "
+                         "iteration counts, 'extrapolate' is an opt-in warm start (reported separately, not the headline)")
+    ap.add_argument("--force-dist", action="store_true", help="take the RCCL path even with one rank (self-test)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    want_cpu = not args.no_cpu_baseline and world == 1 and args.system == "puppet"
+    if want_cpu:      # compile the checker (a `make` child process) BEFORE this process touches the GPU
+        from oracle import oracle as _oracle
+        _oracle.build()
+    comm = None
+    if world > 1 or args.force_dist:
+        from trep_amd import rccl
+        comm = rccl.Communicator.from_env()
+    import trep_amd  # noqa: F401
+
+    from trep_amd.distributed import shard_bounds
+    N = args.rollout_steps
+    U = None
+    if args.system == "puppet":
+        system, Q0, K, dt = build_workload(args, rank)
+    else:
+        system, Q0, U, K, dt = build_secondary(args, rank)
+    B = args.batch
+
+    def shard_of_global():    # this rank's slice of ONE global batch of --batch trajectories (strong scaling)
+        lo, hi = shard_bounds(B, rank, world)
+        return (Q0[lo:hi], None if U is None else U[lo:hi], None if K is None else K[lo:hi], hi - lo,
+                shard_bounds(B, 0, world)[1])
+
+    modes = [args.scaling] + ([("strong" if args.scaling == "weak" else "weak")] if world > 1 else [])
+    results = {}
+    for mode in modes:
+        if mode == "weak":
+            results[mode] = (measure_rollouts(args, system, Q0, U, K, dt, B, N, local_rank, comm, B), world * B, B)
+        else:
+            q, u, k, b_local, b_max = shard_of_global()
+            results[mode] = (measure_rollouts(args, system, q, u, k, dt, b_local, N, local_rank, comm, b_max), B, b_local)
+
+    discopt = None
+    if not args.no_discopt and args.system == "puppet":
+        import bench_discopt
+        d = bench_discopt.measure(args.discopt_seeds, args.discopt_horizon, quasi=1, newton=1, comm=comm, device=local_rank)
+        discopt = {k: d[k] for k in ("iters_per_s", "seeds", "horizon", "n_gpus", "seed_iterations_counted", "elapsed_s",
+                                     "s_per_batched_quasi_step", "s_per_batched_newton_step", "armijo_failures",
+                                     "mean_cost_before_after_per_step", "mean_final_cost_successful_seeds")}
+        discopt["unit"] = "DOptimizer.step equivalents (seed-iterations) per second: 1 quasi-Newton + 1 Newton step of every seed, after one untimed warm-up step"
+        discopt["scaling"] = "strong (seeds sharded over the ranks)"
+        discopt["reference_s_per_newton_step_one_seed"] = d["reference_s_per_newton_step_N1000_one_seed"]
 
     if rank == 0:
-        del_steps = float(world) * B * N * args.steps
+        r, global_batch, b_local = results[args.scaling]
+        nX, nU, nc = r["nX"], r["nU"], r["nc"]
+        elapsed = r["elapsed"]
+        del_steps = float(global_batch) * N * args.steps
         value = del_steps / elapsed
-        avg_kernel_s = kernel_ms / 1e3 / max(n_launch, 1)
+        avg_kernel_s = r["kernel_ms"] / 1e3 / max(r["launches"], 1)
         bytes_per_step = 8.0 * (2 * nX + nU + nc)   # read X_k, U_k; write X_k+1, lambda
-        algo_bytes = bytes_per_step * B * N
+        algo_bytes = bytes_per_step * b_local * N
         achieved = algo_bytes / avg_kernel_s / 1e9
-        traffic = pmc_traffic(B, N, "Puppet(string_constraints=True)") if (world == 1 and args.system == "puppet") else None
+        traffic = pmc_traffic(b_local, N, "Puppet(string_constraints=True)") if (world == 1 and args.system == "puppet") else None
         out = {
             "metric": "DEL-steps/sec x batch (%s, fp64)" % ("puppet ~40-DOF" if args.system == "puppet" else args.system),
             "value": value, "unit": "DEL-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("Puppet(string_constraints=True) nq=40 nd=22 nk=18 nc=6" if args.system == "puppet" else
                                     {"cart": "pend-on-cart nd=2 nu=1", "scissor": "scissor-4 nd=9 nc=8",
                                      "puppet-basic": "examples/puppet-basic.py nd=22 nc=6 (fixed-length strings)"}[args.system]) +
-                                   ", batch=%d rollouts per GPU x %d DEL steps, dt=0.01" % (B, N),
-                       "global_batch": world * B, "rollout_steps": N, "parallelism": "batch-shard x%d" % world,
-                       "team": mvi.info()["team"], "lds_bytes_per_trajectory": mvi.info()["lds_bytes_per_trajectory"],
-                       "newton_iterations_per_step": total_iters / float(B * N), "failed_trajectories": n_failed,
+                                   ", batch=%d rollouts %s x %d DEL steps, dt=0.01" % (B, "per GPU" if args.scaling == "weak" else "in total", N),
+                       "global_batch": global_batch, "rollout_steps": N, "parallelism": "batch-shard x%d" % world,
+                       "collective": "RCCL all-gather of terminal states (C ABI tg_comm_*, no torch)" if comm is not None else None,
+                       "distinct_initial_conditions": global_batch,
+                       "team": r["info"]["team"], "lds_bytes_per_trajectory": r["info"]["lds_bytes_per_trajectory"],
+                       "newton_iterations_per_step": r["newton_iterations"] / float(b_local * N), "failed_trajectories": r["failed"],
                        "writes_X": not args.no_x, "newton_initial_guess": args.predictor},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
-                         "kernel": "k_run<%d> (rollout)" % mvi.info()["team"],
-                         "kernel_avg_ms": 1e3 * avg_kernel_s, "launches": n_launch,
+                         "kernel": "k_run<%d> (rollout)" % r["info"]["team"],
+                         "kernel_avg_ms": 1e3 * avg_kernel_s, "launches": r["launches"],
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "path is fp64-VALU/LDS-latency bound, not HBM bound (SURVEY.md §8d)"},
         }
-        fp64 = pmc_fp64(B, N, "Puppet(string_constraints=True)") if (world == 1 and args.system == "puppet") else None
+        for mode in modes[1:]:     # the other scaling mode of the same run
+            r2, gb2, bl2 = results[mode]
+            out["%s_scaling" % mode] = {"value": float(gb2) * N * args.steps / r2["elapsed"], "unit": "DEL-steps/s",
+                                        "global_batch": gb2, "batch_per_gpu": bl2, "ms_per_step": 1e3 * r2["elapsed"] / args.steps,
+                                        "kernel_avg_ms": r2["kernel_ms"] / max(r2["launches"], 1),
+                                        "note": "BASELINE config 3 as written: 8192 rollouts in total" if mode == "strong" else "fixed work per GPU"}
+        fp64 = pmc_fp64(b_local, N, "Puppet(string_constraints=True)") if (world == 1 and args.system == "puppet") else None
         if fp64:   # secondary figure: the path is compute/latency bound, so also say how far from the fp64 peak
             out["fp64"] = {"estimated_tflops": fp64[0] / avg_kernel_s / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
                            "frac": fp64[0] / avg_kernel_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                           "flop_per_del_step": fp64[0] / (B * N), "f64_wave_instructions_per_del_step": fp64[1] / (B * N), "source": fp64[2]}
-        if not args.no_cpu_baseline and world == 1:
+                           "flop_per_del_step": fp64[0] / (b_local * N), "f64_wave_instructions_per_del_step": fp64[1] / (b_local * N), "source": fp64[2]}
+        if discopt is not None:
+            out["discopt"] = discopt
+        if want_cpu:
             out["cpu_baseline"] = cpu_baseline(system, Q0, K, dt)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    mvi.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -28,13 +28,9 @@ sys.path.insert(0, ROOT)
 REFERENCE_NEWTON_ITER_S = 35.0   # reference, puppet, N~1000: >= 35 s per Newton iteration
 
 
-def sum_over_ranks(value, dist, torch):
-    t = torch.tensor([float(value)], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return float(t.item())
-
-
 def problem(seeds, N, dt, device=0):
+    """S puppet problems of examples/puppet-optimization.py: perturbed initial poses,
+    desired trajectory = moving strings, initial guess = still strings, the script's cost weights."""
     import trep_amd
     from trep_amd import systems
     system = systems.puppet()
@@ -52,63 +48,64 @@ def problem(seeds, N, dt, device=0):
     return system, Xd, K_move, Xi, K_still, np.diag(wq), np.diag([0.1] * system.nQk)
 
 
-def run_batched(args):
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = torch = None
-    if world > 1:   # torch first: one HIP runtime in the process
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29534")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+def measure(seeds, horizon, quasi=1, newton=1, comm=None, device=0, armijo_chunk=None, predictor="reference",
+            stages=False):
+    """Times `quasi` + `newton` batched DOptimizer steps of `seeds` puppet problems (sharded over the ranks of `comm`,
+    a trep_amd.rccl.Communicator, if given) after one untimed warm-up step; returns the result dict (same on every
+    rank).  Seeds whose Armijo search is exhausted (where the reference raises) do not count as iterations."""
     import trep_amd
     from trep_amd import discopt, _lib, distributed
-    dt, N = 0.01, args.horizon
-    system, Xd, Ud, Xi, Ui, Qc, Rc = problem(args.seeds, N, dt, device=local_rank)
-    lo, hi = distributed.shard_bounds(args.seeds, rank, world)     # this rank's seeds
+    world = comm.world if comm is not None else 1
+    rank = comm.rank if comm is not None else 0
+    dt, N = 0.01, horizon
+    system, Xd, Ud, Xi, Ui, Qc, Rc = problem(seeds, N, dt, device=device)
+    lo, hi = distributed.shard_bounds(seeds, rank, world)     # this rank's seeds
     Xd, Ud, Xi, Ui = Xd[lo:hi], Ud[lo:hi], Xi[lo:hi], Ui[lo:hi]
     S = hi - lo
-    dsys = discopt.DSystem(trep_amd.MidpointVI(system, device=local_rank), dt * np.arange(N + 1))
-    opt = discopt.BatchDOptimizer(dsys, Xd, Ud, Qc, Rc, device=local_rank, armijo_chunk=args.armijo_chunk,
-                                  predictor=args.predictor)
+    dsys = discopt.DSystem(trep_amd.MidpointVI(system, device=device), dt * np.arange(N + 1))
+    opt = discopt.BatchDOptimizer(dsys, Xd, Ud, Qc, Rc, device=device, armijo_chunk=armijo_chunk, predictor=predictor)
     L = _lib.lib()
-    methods = ["quasi"] * args.quasi + ["newton"] * args.newton
+    methods = ["quasi"] * quasi + ["newton"] * newton
     opt.set_trajectories(Xi, Ui)
     opt.step(methods[0])                      # warm-up (allocations, code objects), not timed
     opt.set_trajectories(Xi, Ui)
-    L.tg_device_synchronize(local_rank)
-    if dist is not None:
-        dist.barrier()
+    L.tg_device_synchronize(device)
+    if comm is not None:
+        comm.barrier()
     per = {"quasi": [], "newton": []}
     costs = []
     n_failed = 0
+    good_iters = 0
     t0 = time.perf_counter()
     for m in methods:
         ts = time.perf_counter()
         r = opt.step(m)
-        L.tg_device_synchronize(local_rank)
+        L.tg_device_synchronize(device)
         per[m].append(time.perf_counter() - ts)
-        costs.append([float(np.nanmean(r.cost0)), float(np.nanmean(r.cost1))])
+        ok = ~r.failed
+        costs.append([float(np.mean(r.cost0[ok])) if ok.any() else None, float(np.mean(r.cost1[ok])) if ok.any() else None])
         n_failed += int(r.failed.sum())
+        good_iters += int(ok.sum())
     elapsed = time.perf_counter() - t0
-    final_cost = r.cost1
-    if dist is not None:                      # every rank sees every seed's cost (what a supervisor would act on)
-        dist.barrier()
-        elapsed = distributed.max_over_ranks(elapsed, device="cuda")
-        final_cost = distributed.all_gather_rows(torch.from_numpy(np.nan_to_num(r.cost1)[:, None]).cuda()).cpu().numpy()[:, 0]
-        n_failed = int(sum_over_ranks(n_failed, dist, torch))
-    stages = None
-    if args.stages and world == 1:             # one more Newton step, synchronising after every stage
-        stages = {}
+    final_cost, final_ok = r.cost1, ~r.failed
+    if comm is not None:                      # every rank sees every seed's cost (what a supervisor would act on)
+        comm.barrier()
+        elapsed = comm.max(elapsed)
+        gathered = comm.all_gather_rows(np.stack([np.where(final_ok, r.cost1, 0.0), final_ok.astype(float)], 1), total_rows=seeds)
+        final_cost, final_ok = gathered[:, 0], gathered[:, 1] > 0.5
+        n_failed = int(round(comm.sum(n_failed)))
+        good_iters = int(round(comm.sum(good_iters)))
+        for m in per:
+            per[m] = [comm.max(x) for x in per[m]]
+    stage_s = None
+    if stages and world == 1:             # one more Newton step, synchronising after every stage
+        stage_s = {}
 
         def timed(name, fn, *a):
             ts = time.perf_counter()
             out = fn(*a)
-            L.tg_device_synchronize(local_rank)
-            stages[name] = stages.get(name, 0.0) + time.perf_counter() - ts
+            L.tg_device_synchronize(device)
+            stage_s[name] = stage_s.get(name, 0.0) + time.perf_counter() - ts
             return out
         timed("linearize (S*N DEL solves + deriv1 -> A,B)", opt.linearize)
         timed("projection gain (Riccati)", opt.projection_gain)
@@ -117,27 +114,40 @@ def run_batched(args):
         timed("LQ sweep + tangent rollout", lambda: (opt._lq(None, opt.Q, opt.Qf, opt.R, opt.HZ, True, opt.K, opt.C),
                                                       opt.descent_direction(None, "quasi")))
         timed("armijo round 1 (S*%d projections + costs)" % opt.M, opt.armijo_chunk, 0)
-    iters = args.seeds * len(methods)
     out = {
-        "metric": "discopt iterations/s (puppet ~40-DOF, fp64)", "value": iters / elapsed, "unit": "iters/s",
+        "metric": "discopt iterations/s (puppet ~40-DOF, fp64)", "value": good_iters / elapsed, "unit": "iters/s",
+        "iters_per_s": good_iters / elapsed, "seeds": seeds, "horizon": N,
         "n_gpus": world, "dtype": "f64", "data": "synthetic", "scaling": "strong",
         "config": {"workload": "puppet-optimization.py problem, nX=80 nU=18, N=%d, %d seeds batched on the device (%d per GPU), %d quasi + %d newton steps each"
-                               % (N, args.seeds, S, args.quasi, args.newton), "armijo_chunk": opt.M,
-                   "newton_initial_guess": args.predictor},
-        "mean_final_cost_all_seeds": float(np.mean(final_cost)),
+                               % (N, seeds, S, quasi, newton), "armijo_chunk": opt.M,
+                   "newton_initial_guess": predictor},
+        "seed_iterations_counted": good_iters, "elapsed_s": elapsed,
+        "mean_final_cost_successful_seeds": float(np.mean(final_cost[final_ok])) if final_ok.any() else None,
         "s_per_batched_quasi_step": float(np.mean(per["quasi"])) if per["quasi"] else None,
         "s_per_batched_newton_step": float(np.mean(per["newton"])) if per["newton"] else None,
         "mean_cost_before_after_per_step": costs,
         "armijo_failures": n_failed,   # seeds where the reference would raise ConvergenceError("Armijo Failed to Converge")
-        "stage_seconds": stages,
+        "stage_seconds": stage_s,
         "reference_s_per_newton_step_N1000_one_seed": REFERENCE_NEWTON_ITER_S,
     }
     opt.close()
-    if rank == 0:
+    return out
+
+
+def run_batched(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    comm = None
+    if world > 1:   # torch-free: RCCL behind the C ABI (trep_amd/rccl.py)
+        from trep_amd import rccl
+        comm = rccl.Communicator.from_env()
+    device = comm.device if comm is not None else 0
+    out = measure(args.seeds, args.horizon, args.quasi, args.newton, comm=comm, device=device,
+                  armijo_chunk=args.armijo_chunk, predictor=args.predictor, stages=args.stages)
+    if comm is None or comm.rank == 0:
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 def run_sequential(args):

@@ -236,7 +236,8 @@ int tg_memcpy_d2h(int32_t device, void *dst_host, const void *src_dev, uint64_t 
 int tg_batch_synchronize(tg_batch *b);
 /* Use an externally created hipStream_t (e.g. torch's current stream); NULL = own stream. */
 int tg_batch_set_stream(tg_batch *b, void *hip_stream);
-/* HIP-event timing of the kernels launched on the batch's stream since the last reset:
+/* HIP-event timing of the kernels launched on the batch's stream since the last reset (opt-in: the first call switches
+ * the per-launch events on and returns zeros; launches before it are not timed):
  * number of launches and the sum of their durations in milliseconds. */
 int tg_batch_timing(tg_batch *b, int32_t reset, int32_t *n_launches, double *total_ms);
 
@@ -362,6 +363,27 @@ int tg_armijo_candidates(int32_t device, int32_t n_problems, int32_t n_lambdas, 
 int tg_copy_rows(int32_t device, int32_t n_rows, uint64_t row_doubles, const int32_t *dst_rows_dev,
                  const int32_t *src_rows_dev, const double *src_dev, double *dst_dev);
 int tg_device_synchronize(int32_t device);
+
+/* ---- multi-GPU: one process per GPU, batch sharded, one collective ----------------------
+ * The reference has no counterpart (one trajectory per System object, one process).  The only exchange of the path
+ * is an all-gather of per-trajectory results (terminal states, costs) after a rollout -- what the discopt line search
+ * (trep/discopt/doptimizer.py:405-459) looks at -- plus scalar reductions for barriers / timings.  Implemented on
+ * RCCL directly (librccl is dlopen'ed on first use; xGMI on the GPU box).  Rank 0 makes the 128-byte id with
+ * tg_comm_unique_id and passes it to the other ranks out of band BEFORE they call tg_comm_create. */
+#define TG_COMM_ID_BYTES 128
+enum { TG_REDUCE_SUM = 0, TG_REDUCE_MAX = 1, TG_REDUCE_MIN = 2 };
+typedef struct tg_comm tg_comm;
+int tg_comm_unique_id(uint8_t id_out[TG_COMM_ID_BYTES]);
+tg_comm *tg_comm_create(int32_t device, int32_t world, int32_t rank, const uint8_t id_in[TG_COMM_ID_BYTES]);
+void tg_comm_destroy(tg_comm *comm);
+int tg_comm_info(const tg_comm *comm, int32_t out[3]);   /* world, rank, device */
+/* recv_dev [world][bytes_per_rank] <- every rank's send_dev [bytes_per_rank]; asynchronous on the communicator's
+ * stream, which is ordered after the default stream and the tg_batch streams of the device. */
+int tg_comm_all_gather(tg_comm *comm, const void *send_dev, void *recv_dev, uint64_t bytes_per_rank);
+int tg_comm_synchronize(tg_comm *comm);
+/* In-place reduction of n host doubles over all ranks (blocking); tg_comm_barrier is a 1-element sum. */
+int tg_comm_all_reduce_host(tg_comm *comm, double *values, int32_t n, int32_t op);
+int tg_comm_barrier(tg_comm *comm);
 
 #ifdef __cplusplus
 }

@@ -470,3 +470,108 @@ def test_dual_pendulums_first_order_only_like_the_reference():
     assert relerr(mvi.q2, g["b0_Q"][1]) < 1e-10 and relerr(mvi.p2_dq1(), g["b0_d1_1_p2_dq1"].T) < 1e-9
     with pytest.raises(Exception, match="LinearSpring"):     # the spring, not the damper: the reference raises here too
         mvi.q2_dq1dq1()
+
+
+def _secondary_workload(name, B, N):
+    """BASELINE configs 2 and 5 with the synthetic inputs of SURVEY.md section 8(d)."""
+    from trep_amd import systems
+    if name == "cart":
+        system = systems.pend_on_cart()
+        rng = np.random.default_rng(20250 + 2)
+        Q0 = np.stack([rng.uniform(-1, 1, B), rng.uniform(-np.pi, np.pi, B)], 1)
+        return system, Q0, rng.standard_normal((B, N, 1)) * 2.0
+    system = systems.scissor_lift(4)
+    rng = np.random.default_rng(20250 + 5)
+    th = rng.uniform(0.03 * np.pi, 0.12 * np.pi, B)
+    return system, np.array([systems.scissor_q(system, t) for t in th]), None
+
+
+@pytest.mark.parametrize("name", ["cart", "scissor"])
+def test_full_size_properties_cart_and_scissor(name):
+    """BASELINE configs 2 (pend-on-cart, TEAM = 4: sixteen trajectories per wavefront, level sweep, shuffle pivots) and 5
+    (scissor lift, eight holonomic constraints) at their full size B = 4096 x N = 200: every trajectory converges, the
+    DEL residual of the final state vanishes, duplicated initial conditions are bit-identical wherever they sit in the
+    batch, a sub-batch reproduces its trajectories bit for bit, and a sample agrees with the oracle to 1e-10."""
+    from trep_amd import descriptor
+    from oracle.oracle import OracleMVI
+    B, N = 4096, 200
+    system, Q0, U = _secondary_workload(name, B - 64, N)
+    Q0 = np.concatenate([Q0, Q0[5:69]], 0)                      # 64 duplicates at the end of the batch
+    U = None if U is None else np.concatenate([U, U[5:69]], 0)
+    mvi = _batch(system, B)
+    nd = mvi.nd
+    mvi.initialize_from_configs(0.0, Q0, DT, Q0)
+    X = mvi.rollout(N, DT, U, None)
+    iters, status = mvi.status()
+    assert (status == 0).all()
+    f = mvi.calc_f()
+    assert np.abs(f).max() < 1e-10
+    assert np.array_equal(X[5:69], X[B - 64:])
+    sub = _batch(system, 37)
+    sub.initialize_from_configs(0.0, Q0[100:137], DT, Q0[100:137])
+    Xs = sub.rollout(N, DT, None if U is None else U[100:137], None)
+    assert np.array_equal(Xs, X[100:137])
+    o = OracleMVI(descriptor.flatten(system))
+    for b in (0, 1000, 4000):
+        o.initialize_from_configs(0.0, Q0[b], DT, Q0[b])
+        Xo, _ = o.rollout(N, DT, None if U is None else U[b], None)
+        assert relerr(X[b], Xo) < (1e-9 if name == "cart" else TOL), (b, relerr(X[b], Xo))   # the cart is chaotic over 200 driven steps
+    mvi.close(); sub.close()
+
+
+def test_parameter_change_keeps_integrator_state():
+    """The reference's integrator survives parameter writes (Gravity.gravity, Damping coefficients ...): they are
+    plain attributes of the potential / force objects and MidpointVI only re-allocates on structure changes
+    (trep/midpointvi.py:25).  Here: 40 steps, change gravity and damping, 40 more -- against the oracle doing the same."""
+    import trep_amd
+    from trep_amd import systems, descriptor
+    from oracle.oracle import OracleMVI
+    system = systems.pend_on_cart()
+    mvi = trep_amd.MidpointVI(system)
+    q0 = np.array([0.1, 0.7])
+    mvi.initialize_from_configs(0.0, q0, DT, q0)
+    o = OracleMVI(descriptor.flatten(system))
+    o.initialize_from_configs(0.0, q0, DT, q0)
+    u = lambda k: [0.5 * np.sin(0.1 * k)]
+    for k in range(40):
+        mvi.step(mvi.t2 + DT, u(k)); o.step(o.times()[1] + DT, u(k))
+    grav = [p for p in system.potentials if hasattr(p, "gravity")][0]
+    grav.gravity = (0.0, -3.7, 0.0)
+    assert abs(mvi.t2 - 41 * DT) < 1e-12 and relerr(mvi.q2, o.q2) < TOL      # state survived the parameter write
+    o2 = OracleMVI(descriptor.flatten(system))
+    o2.initialize_from_state(o.times()[1], o.q2, o.p2, o.lambda1)
+    o2.q1 = o.q1; o2.p1 = o.p1
+    for k in range(40, 80):
+        mvi.step(mvi.t2 + DT, u(k)); o2.step(o2.times()[1] + DT, u(k))
+    assert relerr(mvi.q2, o2.q2) < TOL and relerr(mvi.p2, o2.p2) < TOL
+    # and it did change the dynamics: with the old gravity the same 40 steps end elsewhere
+    for k in range(40, 80):
+        o.step(o.times()[1] + DT, u(k))
+    assert np.abs(o.q2 - o2.q2).max() > 1e-3
+    # a cached batch engine follows the change as well
+    eng = trep_amd.BatchMidpointVI(system, 2)
+    eng.initialize_from_configs(0.0, np.stack([q0, q0]), DT, np.stack([q0, q0]))
+    eng.step(2 * DT, np.ones((2, 1)), None)
+    grav.gravity = (0.0, -9.8, 0.0)
+    eng.step(3 * DT, np.ones((2, 1)), None)
+    o3 = OracleMVI(descriptor.flatten(system))
+    o3.initialize_from_state(2 * DT, eng.q1[0], eng.p1[0])
+    o3.step(3 * DT, [1.0])
+    assert relerr(eng.q2[0], o3.q2) < TOL
+    eng.close()
+
+
+def test_rccl_communicator_single_rank():
+    """The torch-free collective path of bench.py (C ABI tg_comm_*, RCCL through dlopen) with a world of one rank:
+    unique id, communicator, all-gather of device rows, host-scalar reductions, barrier."""
+    from trep_amd import rccl, _lib
+    uid = rccl.Communicator.new_unique_id()
+    assert len(uid) == rccl.ID_BYTES
+    comm = rccl.Communicator(0, 1, 0, uid)
+    try:
+        comm.barrier()
+        assert comm.max(3.5) == 3.5 and comm.sum(2.0) == 2.0
+        rows = np.arange(12.0).reshape(4, 3)
+        assert np.array_equal(comm.all_gather_rows(rows, total_rows=4), rows)
+    finally:
+        comm.close()

@@ -481,8 +481,70 @@ def gen_discopt_cart():
     save("discopt_pend_on_cart", **out)
 
 
+def gen_discopt_puppet(N=50):
+    """One DOptimizer trace on the problem of examples/puppet-optimization.py (BASELINE config 4) at a short
+    horizon: Puppet(string_constraints=True), desired trajectory = the four limb strings moving sinusoidally
+    (:27-105), initial guess = strings held still (:127-155), weights QD 100, QK 1, PD 1, VK 1, RHO 0.1 (:20-24).
+    Recorded: projection gain, Newton model Q/S/R at selected k, both descent directions, then one quasi-Newton and
+    one Newton DOptimizer.step (cost0, dcost0, accepted Armijo exponent, cost1, new trajectory)."""
+    system = systems.puppet(api=trep)
+    nd, nk = system.nQd, system.nQk
+    Q0 = systems.puppet_initial_conditions(system, 2, seed=20250 + 4)[1]
+    t = DT * np.arange(N + 1)
+    K_move = systems.puppet_string_schedule(system, Q0[None, nd:], N, DT)[0]
+    K_still = np.repeat(Q0[None, nd:], N, axis=0)
+    mvi = trep.MidpointVI(system, num_threads=1)
+    dsys = trep.discopt.DSystem(mvi, t)
+    x0 = dsys.build_state(Q0, np.zeros(nd), np.zeros(nk))
+
+    def simulate(Uk):
+        X = np.zeros((N + 1, dsys.nX))
+        X[0] = x0
+        for k in range(N):
+            if k == 0:
+                dsys.set(X[0], Uk[0], 0)
+            else:
+                dsys.step(Uk[k])
+            X[k + 1] = dsys.f()
+        return X
+    Xd, Ud = simulate(K_move), K_move
+    X, U = simulate(K_still), K_still.copy()
+    wq = [100.0] * nd + [1.0] * nk + [1.0] * nd + [1.0] * nk
+    Qc, Rc = np.diag(wq), np.diag([0.1] * nk)
+    cost = trep.discopt.DCost(Xd, Ud, Qc, Rc)
+
+    class Rec(trep.discopt.DOptimizerMonitor):
+        def __init__(self):
+            self.m = []
+        def armijo_evaluation(self, armijo_iteration, nX, nU, bX, bU, cost, max_cost):
+            self.m.append(armijo_iteration)
+    mon = Rec()
+    opt = trep.discopt.DOptimizer(dsys, cost, monitor=mon)
+    ks = np.array([0, 1, N // 2, N - 1], dtype=np.int32)
+    out = dict(t=t, q0=Q0, X0=X.copy(), U0=U.copy(), Xd=Xd, Ud=Ud, Q=Qc, R=Rc, model_k=ks)
+    (Kproj, dX, dU, Qm, Rm, Sm) = opt.calc_descent_direction(X, U, 'newton')
+    out.update(dd_newton_dX=dX, dd_newton_dU=dU, dd_Kproj=np.array(Kproj),
+               dd_newton_Q=np.array([Qm(k) for k in ks]), dd_newton_Qf=Qm(N),
+               dd_newton_S=np.array([Sm(k) for k in ks]), dd_newton_R=np.array([Rm(k) for k in ks]),
+               dd_newton_dcost=np.array([opt.calc_dcost(X, U, dX, dU)]))
+    (Kproj, dX, dU, Qm, Rm, Sm) = opt.calc_descent_direction(X, U, 'quasi')
+    out.update(dd_quasi_dX=dX, dd_quasi_dU=dU, dd_quasi_dcost=np.array([opt.calc_dcost(X, U, dX, dU)]))
+    out["cost_initial"] = np.array([opt.calc_cost(X, U)])
+    methods = ['quasi', 'newton']
+    for i, method in enumerate(methods):
+        mon.m = []
+        cost0 = opt.calc_cost(X, U)
+        (done, X, U, dcost0, cost1) = opt.step(i, X, U, method)
+        out["it%d_cost0" % i] = np.array([cost0]); out["it%d_dcost0" % i] = np.array([dcost0])
+        out["it%d_cost1" % i] = np.array([cost1]); out["it%d_m" % i] = np.array([mon.m[-1] if mon.m else -1])
+        out["it%d_X" % i] = X.copy(); out["it%d_U" % i] = U.copy()
+        print("  puppet discopt it %d (%s): cost %.6f -> %.6f, dcost0 %.4e, m = %s" % (i, method, cost0, cost1, dcost0, out["it%d_m" % i]))
+    out["methods"] = np.array(methods)
+    save("discopt_puppet", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "wrench_torque", "dual_pendulums", "wrench_spatial", "wrench_body", "damper_link", "discopt"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "wrench_torque", "dual_pendulums", "wrench_spatial", "wrench_body", "damper_link", "discopt", "discopt_puppet"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -521,3 +583,5 @@ if __name__ == "__main__":
         gen_spring_arm()
     if "discopt" in which:
         gen_discopt_cart()
+    if "discopt_puppet" in which:
+        gen_discopt_puppet()

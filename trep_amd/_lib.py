@@ -102,6 +102,15 @@ _SIGNATURES = {
     "tg_armijo_candidates": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tg_copy_rows": (ctypes.c_int, [_i32, _i32, ctypes.c_uint64, _vp, _vp, _vp, _vp]),
     "tg_device_synchronize": (ctypes.c_int, [_i32]),
+    # multi-GPU: RCCL all-gather / scalar reductions (csrc/comm.hip)
+    "tg_comm_unique_id": (ctypes.c_int, [_vp]),
+    "tg_comm_create": (_vp, [_i32, _i32, _i32, _vp]),
+    "tg_comm_destroy": (None, [_vp]),
+    "tg_comm_info": (ctypes.c_int, [_vp, _c_ip]),
+    "tg_comm_all_gather": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint64]),
+    "tg_comm_synchronize": (ctypes.c_int, [_vp]),
+    "tg_comm_all_reduce_host": (ctypes.c_int, [_vp, _c_dp, _i32, _i32]),
+    "tg_comm_barrier": (ctypes.c_int, [_vp]),
 }
 
 

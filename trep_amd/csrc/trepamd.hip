@@ -72,6 +72,10 @@ struct tg_batch {
     int predictor = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
+    static constexpr size_t TIMING_CAP = 4096;
+    bool timing = false;       // HIP-event timing of the launches: off until tg_batch_timing is called once
+    double folded_ms = 0.0;    // launches recycled past TIMING_CAP
+    long long folded_n = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<hipEvent_t> pool;
 };
@@ -172,17 +176,35 @@ int launch(tg_batch *b, tg::RunArgs &A) {
     const int per_team = A.mode == tg::MODE_DERIV2Z ? b->P.e_lds_per_team : (A.mode == tg::MODE_DERIV1 ? b->P.d_lds_per_team : (A.mode == tg::MODE_DYN_DERIV1 ? b->P.g_lds_per_team : b->P.lds_per_team));
     const size_t lds = (size_t)per_block * per_team * sizeof(double);
     if (lds > 160 * 1024) return fail(TG_ERR_UNSUPPORTED, "system too large for the LDS-resident kernel");
-    hipEvent_t e0, e1;
-    if (b->pool.size() >= 2) { e0 = b->pool.back(); b->pool.pop_back(); e1 = b->pool.back(); b->pool.pop_back(); }
-    else { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); }
-    HIP_TRY(hipEventRecord(e0, b->stream));
+    // HIP-event timing is opt-in (the first tg_batch_timing call switches it on): a plain MidpointVI.step() loop creates
+    // no events.  When on, at most TIMING_CAP launches are kept; older pairs are recycled (their time is folded into
+    // the running totals), and every error path hands the pair back to the pool.
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (b->timing) {
+        if (b->events.size() >= tg_batch::TIMING_CAP) {
+            auto old = b->events.front();
+            float t = 0.f;
+            if (hipEventSynchronize(old.second) == hipSuccess && hipEventElapsedTime(&t, old.first, old.second) == hipSuccess) { b->folded_ms += t; b->folded_n++; }
+            b->events.erase(b->events.begin());
+            e0 = old.first; e1 = old.second;
+        } else if (b->pool.size() >= 2) { e0 = b->pool.back(); b->pool.pop_back(); e1 = b->pool.back(); b->pool.pop_back(); }
+        else {
+            HIP_TRY(hipEventCreate(&e0));
+            if (hipEventCreate(&e1) != hipSuccess) { b->pool.push_back(e0); return fail(TG_ERR_HIP, "hipEventCreate failed"); }
+        }
+        if (hipEventRecord(e0, b->stream) != hipSuccess) { b->pool.push_back(e0); b->pool.push_back(e1); return fail(TG_ERR_HIP, "hipEventRecord failed"); }
+    }
     int rc = team == 64 ? launch_team<64>(b, A, grid, lds) : (team == 16 ? launch_team<16>(b, A, grid, lds)
              : (team == 4 ? launch_team<4>(b, A, grid, lds) : launch_team<1>(b, A, grid, lds)));
-    if (rc) return rc;
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e1, b->stream));
-    b->events.emplace_back(e0, e1);
-    return TG_SUCCESS;
+    if (rc == TG_SUCCESS && hipGetLastError() != hipSuccess) rc = fail(TG_ERR_HIP, "kernel launch failed");
+    if (b->timing) {
+        if (rc != TG_SUCCESS || hipEventRecord(e1, b->stream) != hipSuccess) {
+            b->pool.push_back(e0); b->pool.push_back(e1);
+            return rc != TG_SUCCESS ? rc : fail(TG_ERR_HIP, "hipEventRecord failed");
+        }
+        b->events.emplace_back(e0, e1);
+    }
+    return rc;
 }
 
 // Host-facing derivative outputs: the twelve first-derivative arrays and the contraction buffers.  Allocated on
@@ -824,17 +846,19 @@ int tg_batch_timing(tg_batch *b, int32_t reset, int32_t *n_launches, double *tot
     if (!b) return fail(TG_ERR_INVALID, "null batch");
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
-    double ms = 0.0;
+    b->timing = true;
+    double ms = b->folded_ms;
     for (auto &e : b->events) {
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, e.first, e.second));
         ms += t;
     }
-    if (n_launches) *n_launches = (int32_t)b->events.size();
+    if (n_launches) *n_launches = (int32_t)(b->events.size() + b->folded_n);
     if (total_ms) *total_ms = ms;
     if (reset) {
         for (auto &e : b->events) { b->pool.push_back(e.first); b->pool.push_back(e.second); }
         b->events.clear();
+        b->folded_ms = 0.0; b->folded_n = 0;
     }
     return TG_SUCCESS;
 }

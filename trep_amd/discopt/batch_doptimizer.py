@@ -143,6 +143,7 @@ class BatchDOptimizer(object):
         self.x0 = pool.empty((S, nX))
         self._sel = pool.empty((S,), np.int32)
         self._rows_a, self._rows_b = pool.empty((S,), np.int32), pool.empty((S,), np.int32)
+        self._lq_failed = np.zeros(S, dtype=bool)
         self.iteration = 0
 
     def close(self):
@@ -176,12 +177,13 @@ class BatchDOptimizer(object):
 
     def linearize(self):
         """A, B about the current (X, U) for every seed and step; leaves the S*N solved steps resident."""
+        self.lin.refresh()
         self._check(self.L.tg_batch_set_from_trajectories(self.lin._h, self.S, self.N, self.t0, self.dt, self.X.ptr, self.U.ptr, 200))
         _, status = self.lin.status()
-        if (status != 0).any():
-            bad = np.nonzero(status)[0][:5]
-            raise ConvergenceError("linearisation: DEL solve failed at (seed, k) = %s" % [(int(t // self.N), int(t % self.N)) for t in bad])
         self._check(self.L.tg_batch_linearize(self.lin._h, self.A.ptr, self.B.ptr))
+        # per seed: a seed with a failed DEL solve anywhere along its horizon has no linearisation (the reference raises
+        # ConvergenceError out of DSystem.set for that one problem); the other seeds are unaffected
+        return (status.reshape(self.S, self.N) != 0).any(axis=1)
 
     def _lq(self, seeds, Q, Qf, R, hz, affine, K, C=None):
         sel, n = self._select(seeds)
@@ -202,6 +204,9 @@ class BatchDOptimizer(object):
         p.status_dev = self.lq_status.ptr
         import ctypes
         self._check(self.L.tg_tv_lq(self.device, ctypes.byref(p)))
+        st = self.lq_status.get()       # TG_SINGULAR: the nU x nU matrix of a Riccati step of that seed has no usable pivot
+        idx = np.arange(self.S) if seeds is None else np.asarray(seeds, dtype=np.int64)      # status is indexed by seed
+        self._lq_failed[idx[st[idx] != 0]] = True
 
     def projection_gain(self):
         """Kproj = solve_tv_lqr(A, B, I, I) (doptimizer.py:272-287)."""
@@ -294,11 +299,16 @@ class BatchDOptimizer(object):
         """One DOptimizer.step for every active seed (doptimizer.py:462-506).  `method` is a name or a
         per-seed list.  Returns arrays over all seeds (inactive seeds: done=True, costs NaN)."""
         S = self.S
+        self.lin.refresh()      # parameter writes on the system since the engines were built (see BatchMidpointVI.refresh)
+        self.arm.refresh()
         active = np.ones(S, dtype=bool) if active is None else np.asarray(active, dtype=bool).copy()
         methods = np.array([method] * S if isinstance(method, str) else list(method), dtype=object)
-        self.linearize()
+        self._lq_failed[:] = False
+        broken = self.linearize() & active
         self.projection_gain()
         cost0 = self.gradients_and_cost()
+        broken |= self._lq_failed & active
+        active &= ~broken               # their step ends here (flagged failed below); everything is per seed from now on
         dcost0 = np.full(S, np.nan)
         pending = active.copy()
         while pending.any():
@@ -309,6 +319,10 @@ class BatchDOptimizer(object):
                 self.descent_direction(None if len(seeds) == S else seeds, name)
                 dc = self.dcost.get()
                 dcost0[seeds] = dc[seeds]
+            lost = pending & (self._lq_failed | ~np.isfinite(dcost0))     # singular LQ model: no direction for that seed
+            broken |= lost
+            active &= ~lost
+            pending &= ~lost
             bad = pending & (dcost0 > 0)
             pending = bad
             for s in np.nonzero(bad)[0]:
@@ -345,9 +359,10 @@ class BatchDOptimizer(object):
             m0 += count
         # a seed whose search is exhausted is where the reference raises ConvergenceError("Armijo Failed to
         # Converge") (doptimizer.py:456-459); here it is flagged and left unchanged, the other seeds carry on
-        failed = search.copy()
+        failed = search | broken
         self.iteration += 1
-        return self.step_return(done | failed, np.where(active, cost0, np.nan), dcost0, cost1, list(methods), armijo, failed)
+        shown = active | broken
+        return self.step_return(done | failed, np.where(shown, cost0, np.nan), dcost0, np.where(broken, cost0, cost1), list(methods), armijo, failed)
 
     def optimize(self, max_steps=50):
         """Runs every seed until |dcost| < descent_tolerance, an Armijo failure, or max_steps;

@@ -140,6 +140,7 @@ class DOptimizer(object):
             if self._lin is not None:
                 self._lin.close()
             self._lin = BatchMidpointVI(self.dsys.system, n, device=self._device)
+        self._lin.refresh()
         return self._lin
 
     def _arm_engine(self, n):
@@ -147,14 +148,41 @@ class DOptimizer(object):
             if self._arm is not None:
                 self._arm.close()
             self._arm = BatchMidpointVI(self.dsys.system, n, device=self._device)
+        self._arm.refresh()
         return self._arm
 
     # -- cost -------------------------------------------------------------------------------------
+    def _vectorised_cost(self):
+        """The array-at-once DCost.total / DCost.gradients are an extension of this package; any other cost object
+        (a subclass overriding l / m / l_dx ..., or a duck-typed one) is evaluated step by step through the reference's
+        DCost contract (dcost.py:30-118), like the reference's own loops (doptimizer.py:249-270)."""
+        from .dcost import DCost
+        return type(self.cost) is DCost
+
+    def _cost_gradients(self, X, U):
+        c = self.cost
+        if self._vectorised_cost():
+            return c.gradients(X, U)
+        n = len(X)
+        q = np.array([c.l_dx(X[k], U[k], k) for k in range(n - 1)] + [c.m_dx(X[-1])])
+        r = np.array([c.l_du(X[k], U[k], k) for k in range(n - 1)])
+        return q, r
+
+    def _cost_total(self, X, U):
+        """Cost of one trajectory, or of a stack of trajectories [M][N+1][nX] / [M][N][nU] (array of M costs)."""
+        c = self.cost
+        X, U = np.asarray(X), np.asarray(U)
+        if self._vectorised_cost():
+            return c.total(X, U)
+        if X.ndim == 3:
+            return np.array([self._cost_total(X[m], U[m]) for m in range(len(X))])
+        return sum(c.l(X[k], U[k], k) for k in range(len(X) - 1)) + c.m(X[-1])
+
     def calc_cost(self, X, U):
-        return float(self.cost.total(np.asarray(X), np.asarray(U)))
+        return float(self._cost_total(X, U))
 
     def calc_dcost(self, X, U, dX, dU):
-        q, r = self.cost.gradients(X, U)
+        q, r = self._cost_gradients(X, U)
         return float(np.sum(q * dX) + np.sum(r * dU))
 
     def calc_ddcost(self, X, U, dX, dU, Q, R, S):
@@ -219,7 +247,7 @@ class DOptimizer(object):
         linearize(X, U): the contractions reuse the solved steps resident in the horizon batch."""
         c, ds = self.cost, self.dsys
         n = len(X)
-        q, r = c.gradients(X, U)
+        q, r = self._cost_gradients(X, U)
         Z = np.zeros((n - 1, ds.nX))
         z = q[-1]
         for k in range(n - 2, -1, -1):
@@ -239,7 +267,7 @@ class DOptimizer(object):
 
     def calc_descent_direction(self, X, U, method='steepest'):
         (Kproj, A, B) = self.calc_feedback_controller(X, U)
-        q, r = self.cost.gradients(X, U)
+        q, r = self._cost_gradients(X, U)
         if method == 'steepest':
             (Q, R, S) = self.calc_steepest_model()
         elif method == 'quasi':
@@ -281,7 +309,7 @@ class DOptimizer(object):
         dcost0 = self.calc_dcost(X, U, dX, dU)
         lambdas = self.armijo_beta ** np.arange(self.armijo_max_iterations)
         nX, nU, ok = self.project_candidates(X, U, Kproj, dX, dU, lambdas)
-        costs = self.cost.total(nX, nU)
+        costs = self._cost_total(nX, nU)
         for m in range(self.armijo_max_iterations):
             max_cost = cost0 + self.armijo_alpha * lambdas[m] * dcost0
             if not ok[m]:

@@ -282,6 +282,7 @@ class DSystem(_Packing):
     def _projection_engine(self):
         if getattr(self, "_proj", None) is None:
             self._proj = BatchMidpointVI(self.system, 1, tolerance=self.varint.tolerance, device=self.varint._device)
+        self._proj.refresh()
         return self._proj
 
     def dproject(self, A, B, bdX, bdU, K):

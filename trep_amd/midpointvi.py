@@ -41,6 +41,42 @@ class BatchMidpointVI(object):
         self.tolerance = tolerance
         self._owned_dev = []
 
+    def refresh(self):
+        """Re-flatten the system if it changed since the device program was built.  The reference treats parameter
+        writes (Gravity.gravity, spring constants, damping, Distance.distance ...) as plain attribute updates and its
+        integrator keeps its state across them (trep/potentials/gravity.py, trep/midpointvi.py:25-136 only
+        re-allocates on *structure* changes); here every change re-builds the few-kB device schedule, and the batch
+        state (times, q1, q2, p1, p2, u1, lambda1, tolerance, predictor) is carried over whenever the sizes are
+        unchanged.  Returns True if a rebuild happened."""
+        if self._structure_version == self._system._structure_version:
+            return False
+        old_sizes = (self.nq, self.nd, self.nk, self.nu, self.nc)
+        desc = flatten(self._system)
+        sys_h = self._L.tg_system_create(desc.byref())
+        if not sys_h:
+            raise _lib.LibraryError(self._L.tg_last_error().decode())
+        h = self._L.tg_batch_create(sys_h, self._batch, self._device)
+        if not h:
+            msg = self._L.tg_last_error().decode()
+            self._L.tg_system_destroy(sys_h)
+            raise _lib.LibraryError(msg)
+        keep = None
+        if old_sizes == (int(desc.n_configs), int(desc.n_dyn), int(desc.n_kin), int(desc.n_inputs), int(desc.n_constraints)):
+            keep = (self.times(), [getattr(self, n) for n in ("q1", "q2", "p1", "p2", "u1", "lambda1")], self.tolerance,
+                    self.predictor)
+        self._L.tg_batch_destroy(self._h)
+        self._L.tg_system_destroy(self._sys_h)
+        self._desc, self._sys_h, self._h = desc, sys_h, h
+        self._structure_version = self._system._structure_version
+        if keep is not None:
+            (t1, t2), fields, tol, pred = keep
+            self.set_times(t1, t2)
+            for n, v in zip(("q1", "q2", "p1", "p2", "u1", "lambda1"), fields):
+                setattr(self, n, v)
+            self.tolerance = tol
+            self.predictor = pred
+        return True
+
     def close(self):
         if getattr(self, "_h", None):
             for p in self._owned_dev:
@@ -125,6 +161,7 @@ class BatchMidpointVI(object):
     # -- reference semantics, batched -------------------------------------------------------------
     def initialize_from_state(self, t1, q1, p1, lambda1=None):
         """midpointvi.py:138-153: (t2,q2,p2) <- (t1,q1,p1), lambda1 <- given or 0."""
+        self.refresh()
         self.set_times(t1, t1)
         self.q1 = q1
         self.p1 = p1
@@ -134,6 +171,7 @@ class BatchMidpointVI(object):
 
     def initialize_from_configs(self, t0, q0, t1, q1, lambda1=None):
         """midpointvi.py:155-172: p2 = D2L2(q0, q1) computed on the device."""
+        self.refresh()
         self.set_times(t0, t1)
         self.q1 = q0
         self.q2 = q1
@@ -141,9 +179,11 @@ class BatchMidpointVI(object):
         self.lambda1 = np.zeros((self._batch, self.nc)) if lambda1 is None else lambda1
 
     def calc_p2(self):
+        self.refresh()
         _lib.check(self._L.tg_batch_calc_p2(self._h))
 
     def calc_f(self):
+        self.refresh()
         out = np.zeros((self._batch, self.nd + self.nc))
         _lib.check(self._L.tg_batch_calc_f(self._h, out.ctypes.data))
         return out
@@ -154,6 +194,7 @@ class BatchMidpointVI(object):
 
     def calc_deriv1(self):
         """Compute all twelve first-derivative arrays of the last solved step on the device."""
+        self.refresh()
         _lib.check(self._L.tg_batch_deriv1(self._h))
 
     def deriv1(self, name):
@@ -170,6 +211,7 @@ class BatchMidpointVI(object):
         """Second derivatives contracted with Z [B][nX] over the output index: HZ [B][R][R] with the
         derivative variables ordered (q1[nq], p1[nd], u1[nu], k2[nk]).  HZ[b][A][B] =
         sum_o Z[b][o] q2_dAdB[A][B][o] + Z[b][nq+o] p2_dAdB[A][B][o] (what DSystem.fdxdx/fdxdu/fdudu use)."""
+        self.refresh()
         R = self.nq + self.nd + self.nu + self.nk
         Z = _lib.as_f64(np.broadcast_to(np.asarray(Z, dtype=float), (self._batch, self.nX)), (self._batch, self.nX))
         HZ = np.zeros((self._batch, R, R))
@@ -182,6 +224,7 @@ class BatchMidpointVI(object):
 
     def step(self, t2, u1=None, k2=None, max_iterations=200, q2_hint=None, lambda1_hint=None):
         """One MidpointVI.step for every trajectory.  Returns (iterations[B], status[B])."""
+        self.refresh()
         B = self._batch
         u = None if self.nu == 0 else _lib.as_f64(np.broadcast_to(np.asarray(u1, dtype=float), (B, self.nu)), (B, self.nu))
         k = None if self.nk == 0 else _lib.as_f64(np.broadcast_to(np.asarray(k2, dtype=float), (B, self.nk)), (B, self.nk))
@@ -222,11 +265,13 @@ class BatchMidpointVI(object):
 
     def rollout_device(self, n_steps, dt, U_dev=None, K_dev=None, X_dev=None, max_iterations=200):
         """Asynchronous n_steps-step rollout entirely on the device (one kernel launch)."""
+        self.refresh()
         _lib.check(self._L.tg_batch_rollout(self._h, int(n_steps), float(dt), U_dev, K_dev, X_dev,
                                             int(max_iterations)))
 
     def rollout(self, n_steps, dt, U=None, K=None, max_iterations=200):
         """Convenience: upload U [B][N][nu] / K [B][N][nk], roll out, download X [B][N+1][nX]."""
+        self.refresh()
         B = self._batch
         U_dev = self.device_array(_lib.as_f64(U, (B, n_steps, self.nu))) if self.nu else None
         K_dev = self.device_array(_lib.as_f64(K, (B, n_steps, self.nk))) if self.nk else None
@@ -243,6 +288,7 @@ class BatchMidpointVI(object):
     def rollout_closed_loop(self, n_steps, dt, Kproj, bX, bU, group_size=1, max_iterations=200):
         """Projection-operator rollout: U_k = bU_k - Kproj_k (X_k - bX_k) evaluated in the kernel.
         Kproj [groups][N][nU][nX], bX [B][N+1][nX], bU [B][N][nU] (host arrays); returns (X, U)."""
+        self.refresh()
         B, nX, nU = self._batch, self.nX, self.nU
         groups = (B + group_size - 1) // group_size
         K_dev = self.device_array(_lib.as_f64(Kproj, (groups, n_steps, nU, nX)))
@@ -264,6 +310,7 @@ class BatchMidpointVI(object):
         """Continuous dynamics of B states at once (the reference's System.f() / System.lambda_(), system.py:951-1024):
         Q, dQ [B][nq]; U [B][nu]; ddQk [B][nk] accelerations of the kinematic configs (zeros when omitted).
         Returns (ddq [B][nd], lambda [B][nc], status [B]).  The integrator state is left alone."""
+        self.refresh()
         B = self._batch
         Q = _lib.as_f64(np.broadcast_to(np.asarray(Q, dtype=float), (B, self.nq)), (B, self.nq))
         dQ = _lib.as_f64(np.broadcast_to(np.asarray(dQ, dtype=float), (B, self.nq)), (B, self.nq))
@@ -278,6 +325,7 @@ class BatchMidpointVI(object):
     def lagrangian(self, Q, dQ):
         """First and second derivatives of the Lagrangian of B states: dict with L_dq, L_ddq [B][nq] and L_dqdq,
         L_ddqdq (velocity config = row), L_ddqddq [B][nq][nq] (System.L_dq() ... L_ddqddq(), system.py:852-925)."""
+        self.refresh()
         B = self._batch
         Q = _lib.as_f64(np.broadcast_to(np.asarray(Q, dtype=float), (B, self.nq)), (B, self.nq))
         dQ = _lib.as_f64(np.broadcast_to(np.asarray(dQ, dtype=float), (B, self.nq)), (B, self.nq))
@@ -302,6 +350,7 @@ class BatchMidpointVI(object):
     def energy(self, Q, dQ):
         """Kinetic and potential energy of B states: [B][2] = (T, V); the reference's System.L() is T - V and
         System.total_energy() T + V (system.py:844-850)."""
+        self.refresh()
         B = self._batch
         Q = _lib.as_f64(np.broadcast_to(np.asarray(Q, dtype=float), (B, self.nq)), (B, self.nq))
         dQ = _lib.as_f64(np.broadcast_to(np.asarray(dQ, dtype=float), (B, self.nq)), (B, self.nq))
@@ -314,6 +363,7 @@ class BatchMidpointVI(object):
     def dynamics_deriv1(self, Q, dQ, U=None, ddQk=None):
         """First derivatives of the continuous dynamics of B states at once (System.f_dq() ... lambda_du() of the
         reference, system.py:961-1044).  Returns ({name: [B][output][derivative variable]}, status [B])."""
+        self.refresh()
         B = self._batch
         Q = _lib.as_f64(np.broadcast_to(np.asarray(Q, dtype=float), (B, self.nq)), (B, self.nq))
         dQ = _lib.as_f64(np.broadcast_to(np.asarray(dQ, dtype=float), (B, self.nq)), (B, self.nq))
@@ -379,7 +429,11 @@ class MidpointVI(object):
 
     def _batch(self):
         if self._stale:
-            self._rebuild()
+            # BatchMidpointVI.refresh() rebuilds the device schedule and, when the sizes are unchanged (a parameter
+            # write such as `gravity.gravity = ...`), carries t, q, p, u, lambda over like the reference does
+            if self._b.refresh():
+                self._cache = 0
+            self._stale = False
         return self._b
 
     def __repr__(self):
@@ -567,6 +621,7 @@ class MidpointVI(object):
         k2 = np.array(k2, dtype=float)
         assert u1.shape == (self.nu,)
         assert k2.shape == (self.nk,)
+        self._cache = 0     # the reference's setters zero the cache before the solve (midpointvi.py:188-197, 250-323)
         iters, status = self._batch().step(t2, u1[None, :], k2[None, :], max_iterations, q2_hint, lambda1_hint)
         if status[0] == _lib.NOT_CONVERGED:
             raise ConvergenceError("failed to converge after %d iterations" % (max_iterations + 1))
