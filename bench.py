@@ -166,8 +166,9 @@ def measure_rollouts(args, system, Q0, U, K, dt, B, N, device, comm, gather_rows
     import trep_amd
     from trep_amd import _lib
     L = _lib.lib()
-    mvi = trep_amd.BatchMidpointVI(system, B, device=device)
+    mvi = trep_amd.BatchMidpointVI(system, B, device=device, specialize="auto" if args.specialize else False)
     mvi.predictor = args.predictor
+    specialised = mvi._specialized is not None
     nX = mvi.nX
     K_dev = mvi.device_array(K) if K is not None else None
     U_dev = mvi.device_array(U) if U is not None else None
@@ -212,7 +213,7 @@ def measure_rollouts(args, system, Q0, U, K, dt, B, N, device, comm, gather_rows
     n_launch, kernel_ms = mvi.timing(reset=True)
     iters, status = mvi.status()
     res = {"elapsed": elapsed, "launches": n_launch, "kernel_ms": kernel_ms, "newton_iterations": int(iters.sum()),
-           "failed": int((status != 0).sum()), "info": mvi.info(), "nX": mvi.nX, "nU": mvi.nU, "nc": mvi.nc}
+           "failed": int((status != 0).sum()), "info": mvi.info(), "specialised": bool(specialised), "nX": mvi.nX, "nU": mvi.nU, "nc": mvi.nc}
     mvi.close()
     return res
 
@@ -237,6 +238,9 @@ def main():
     ap.add_argument("--predictor", choices=["reference", "extrapolate"], default="reference",
                     help="Newton initial guess of the rollout; 'reference' (default) keeps the reference's semantics and "
                          "iteration counts, 'extrapolate' is an opt-in warm start (reported separately, not the headline)")
+    ap.add_argument("--no-specialize", dest="specialize", action="store_false",
+                    help="run the generic rollout kernel (schedule interpreted at run time) instead of the system-specialised one "
+                         "(trep_amd/specialize.py: the same kernel source compiled against the system's schedule)")
     ap.add_argument("--force-dist", action="store_true", help="take the RCCL path even with one rank (self-test)")
     args = ap.parse_args()
 
@@ -247,10 +251,6 @@ def main():
     if want_cpu:      # compile the checker (a `make` child process) BEFORE this process touches the GPU
         from oracle import oracle as _oracle
         _oracle.build()
-    comm = None
-    if world > 1 or args.force_dist:
-        from trep_amd import rccl
-        comm = rccl.Communicator.from_env()
     import trep_amd  # noqa: F401
 
     from trep_amd.distributed import shard_bounds
@@ -261,6 +261,13 @@ def main():
     else:
         system, Q0, U, K, dt = build_secondary(args, rank)
     B = args.batch
+    if args.specialize:    # hipcc as a child process (about 5 s, cached in trep_amd/_spec): before this process touches the GPU
+        from trep_amd import specialize
+        specialize.build(system)
+    comm = None
+    if world > 1 or args.force_dist:      # first GPU call of the process
+        from trep_amd import rccl
+        comm = rccl.Communicator.from_env()
 
     def shard_of_global():    # this rank's slice of ONE global batch of --batch trajectories (strong scaling)
         lo, hi = shard_bounds(B, rank, world)
@@ -312,7 +319,8 @@ def main():
                        "distinct_initial_conditions": global_batch,
                        "team": r["info"]["team"], "lds_bytes_per_trajectory": r["info"]["lds_bytes_per_trajectory"],
                        "newton_iterations_per_step": r["newton_iterations"] / float(b_local * N), "failed_trajectories": r["failed"],
-                       "writes_X": not args.no_x, "newton_initial_guess": args.predictor},
+                       "writes_X": not args.no_x, "newton_initial_guess": args.predictor,
+                       "kernel_variant": "system-specialised (schedule compiled in)" if r["specialised"] else "generic (schedule interpreted)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,

@@ -236,6 +236,15 @@ int tg_memcpy_d2h(int32_t device, void *dst_host, const void *src_dev, uint64_t 
 int tg_batch_synchronize(tg_batch *b);
 /* Use an externally created hipStream_t (e.g. torch's current stream); NULL = own stream. */
 int tg_batch_set_stream(tg_batch *b, void *hip_stream);
+/* System-specialised rollout kernel.  The reference interprets the frame tree at run time; the generic kernels here
+ * interpret a flat schedule.  For long rollouts of one system the schedule can instead be compiled into the kernel:
+ * tg_system_spec_header returns a generated C++ header (every size, count and LDS offset a constant, the index tables
+ * constant arrays); trep_amd/specialize.py compiles csrc/spec_kernel.hip against it with hipcc and
+ * tg_batch_load_specialized makes the rollouts of a batch use that kernel (same template source as the generic
+ * kernel, bit-identical results).  Returns the text length incl. terminator (or -1). */
+int64_t tg_system_spec_header(const tg_system *sys, char *buf, uint64_t capacity);
+int tg_batch_load_specialized(tg_batch *b, const char *library_path);
+
 /* HIP-event timing of the kernels launched on the batch's stream since the last reset (opt-in: the first call switches
  * the per-launch events on and returns zeros; launches before it are not timed):
  * number of launches and the sum of their durations in milliseconds. */

@@ -68,3 +68,25 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 for b in banned:
                     assert b not in text, (f, b)
+
+
+def test_specialisation_emitter_is_in_sync_and_header_is_complete():
+    """csrc/spec_emit.inc is generated from struct DevProg (tools/gen_spec_emitter.py); the header it prints for a system
+    must define every field of the struct as a compile-time constant (host-only: no GPU involved)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_spec_emitter.py"), "--check"]).returncode == 0, \
+        "trep_amd/csrc/spec_emit.inc is stale: run tools/gen_spec_emitter.py"
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import gen_spec_emitter
+    from trep_amd import specialize, systems
+    ints, dbl_arrays, pointers = gen_spec_emitter.parse_fields()
+    text = specialize.header(systems.scissor_lift(4))
+    for f in ints:
+        assert "static constexpr int %s = " % f in text, f
+    for ctype, name in pointers:
+        assert "static constexpr const %s *%s = " % (ctype, name) in text, name
+    assert "#define SPEC_TEAM 64" in text and "static constexpr int nc = 8;" in text
+    # a different system gives a different header (and cache key)
+    assert specialize.library_path(systems.pend_on_cart())[0] != specialize.library_path(systems.scissor_lift(4))[0]

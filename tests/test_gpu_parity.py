@@ -575,3 +575,32 @@ def test_rccl_communicator_single_rank():
         assert np.array_equal(comm.all_gather_rows(rows, total_rows=4), rows)
     finally:
         comm.close()
+
+
+@pytest.mark.parametrize("name", ["puppet40", "scissor4", "pend_on_cart", "spring_arm"])
+def test_specialised_kernel_matches_generic_and_reference(name):
+    """The system-specialised rollout kernel (trep_amd/specialize.py: the schedule compiled into the kernel) is the same
+    template source as the generic kernel: identical Newton iteration counts and states equal up to the compiler's
+    FMA contraction (<= 1e-12 relative over 100 steps); both within 1e-10 of the reference goldens."""
+    import trep_amd
+    system, d = build(name)
+    N = 100
+    prefix, q0, U, K = trajectories(name)[0]
+    g = golden(name)
+    out = []
+    for mode in (False, True):
+        m = trep_amd.BatchMidpointVI(system, 3, specialize=mode)
+        assert (m._specialized is not None) == mode
+        Q0 = np.stack([q0, q0, q0])
+        m.initialize_from_configs(0.0, Q0, DT, Q0)
+        X = m.rollout(N, DT, None if U.shape[1] == 0 else np.stack([U[:N]] * 3), None if K.shape[1] == 0 else np.stack([K[:N]] * 3))
+        it, st = m.status()
+        assert (st == 0).all()
+        out.append((X, it))
+        m.close()
+    assert np.array_equal(out[0][1], out[1][1])
+    assert relerr(out[0][0], out[1][0]) < 1e-12
+    nq = d.n_configs
+    for X, _ in out:
+        assert relerr(X[0][:, :nq], g[prefix + "Q"][:N + 1]) < TOL
+        assert np.array_equal(X[0], X[2])

@@ -98,6 +98,40 @@ struct RunArgs {
     double *lag1_out, *lag2_out;           // MODE_LAGRANGIAN: [batch][2][nq] (L_dq, L_ddq) and [batch][3][nq][nq] (L_dqdq, L_ddqdq, L_ddqddq), zeroed by the caller
 };
 
+// The kernels read the schedule (DevProg) and the launch arguments (RunArgs) through CONSTANT-address-space references:
+// every field access is then a scalar load from the kernel-argument segment.  Left alone the optimiser hoists all of those
+// loop-invariant loads to the kernel prologue and keeps ~150 values alive in SGPRs for the whole rollout -- far more than
+// the 100 or so there are, so it spills them into VGPR lanes and re-reads them with v_readlane at every use (1 267
+// v_readlane + 372 v_writelane in the round-1 rollout kernel, next to 820 fp64 instructions).  tg_fresh() launders the
+// struct's address through an empty asm at the head of every phase: the loads cannot move above it, a phase loads the few
+// fields it needs when it starts (K$-resident, issued back to back) and nothing stays alive across phases.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) DevProg CProg;
+typedef const RunArgs CArgs;   // by-value kernel argument (few fields are used inside the loops)
+template <class T> __device__ __forceinline__ T &tg_fresh_always(T &r) { T *p = &r; asm volatile("" : "+s"(p)); return *p; }
+#if defined(TG_FRESH_PHASES)
+template <class T> __device__ __forceinline__ T &tg_fresh(T &r) { return tg_fresh_always(r); }
+#else
+template <class T> __device__ __forceinline__ T &tg_fresh(T &r) { return r; }
+#endif
+#if defined(TG_FRESH_STEP)
+template <class T> __device__ __forceinline__ T &tg_fresh_step(T &r) { return tg_fresh_always(r); }
+#else
+template <class T> __device__ __forceinline__ T &tg_fresh_step(T &r) { return r; }
+#endif
+// launch arguments read through a constant-address-space reference (specialised kernel: RunArgs in device memory)
+typedef const __attribute__((address_space(4))) RunArgs KArgs;
+__device__ __forceinline__ KArgs &tg_fresh_args(KArgs &r) { return tg_fresh_always(r); }
+template <class T> __device__ __forceinline__ T &tg_fresh_args(T &r) { return r; }
+#else
+typedef const DevProg CProg;
+typedef const RunArgs CArgs;
+typedef const RunArgs KArgs;
+template <class T> inline T &tg_fresh_args(T &r) { return r; }
+template <class T> inline T &tg_fresh(T &r) { return r; }
+template <class T> inline T &tg_fresh_step(T &r) { return r; }
+#endif
+
 // sin and cos together for joint angles.  |x| < 2^17: three-constant Cody-Waite reduction to [-pi/4, pi/4]
 // (k * pi/2 split so that the first two products are exact for k < 2^19) and the minimax polynomials of the
 // classic fdlibm kernels (error < 1 ulp); larger arguments take the library routine.  About a fifth of the
@@ -185,7 +219,7 @@ TG_HD void team_argmax(double &v, int &i) {
 
 // SPRINGS: the spring potentials (ConfigSpring, LinearSpring) and the plane constraints are compiled in only for systems that have them, so
 // that the spring-free kernels keep their instruction stream and register allocation.
-template <int TEAM, bool SPRINGS = false>
+template <int TEAM, bool SPRINGS = false, class PROG = CProg>
 struct Core {
     TG_HD bool has_cs() const { return SPRINGS && P.has_cs; }
     TG_HD int n_springs() const { return SPRINGS ? P.n_springs : 0; }
@@ -197,14 +231,15 @@ struct Core {
     TG_HD int n_wdh() const { return SPRINGS ? P.n_wdh : 0; }
     TG_HD int n_wpair() const { return SPRINGS ? P.n_wpair : 0; }
     const double *d2w = nullptr;   // adjoint weights while the second-derivative kernel evaluates the midpoint, else null
-    const DevProg &P;
+    PROG &P;
     double *S;
     int lane;
     double dt;
+    int oGc;   // LDS offset of the joint poses that the end-point / constraint evaluation reads (P.o_G, or the second pose set of a dual sweep)
     long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long prof_last = 0;
 
-    TG_HD Core(const DevProg &p, double *s, int l, double dt_) : P(p), S(s), lane(l), dt(dt_) {}
+    TG_HD Core(PROG &p, double *s, int l, double dt_) : P(p), S(s), lane(l), dt(dt_), oGc(p.o_G) {}
 
     // Phase loop over n independent items, two per lane and trip: compute(i) only READS and returns its results,
     // store(i, r) writes them.  Both items' loads are issued before either item's stores -- the compiler cannot
@@ -242,6 +277,7 @@ struct Core {
     // (12 * first joint | chain length << 16) and 12 * parent joint (or -1: the world), length 0 for an empty slot.
     // Keeps global-memory look-ups (and their latency) out of the sweep.
     TG_HD void init_sweep_schedule() {
+        PROG &P = tg_fresh(this->P);
         TG_FOR(i, 4 * P.n_bodies) S[P.o_I + i] = P.b_inertia[i];   // body inertias: LDS copy for the whole kernel
         TG_FOR(c, P.nc) S[P.o_ctol + c] = P.c_tol[c];
         if (!P.sched_ok || TEAM != 64) { TG_SYNC(); return; }
@@ -259,6 +295,7 @@ struct Core {
     }
 
     TG_HD void pose_sweep(bool on, int sel) {
+        PROG &P = tg_fresh(this->P);
         double *sc = S + P.o_sc, *G = S + P.o_G;
         if (on) TG_FOR(j, P.n_joints) {
             const double x = qval(sel, P.j_cfg[j]);
@@ -350,8 +387,124 @@ struct Core {
         }
     }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+    // ---- two pose sweeps in one pass (rollout Newton loop, full-wave teams) ---------------------------------------
+    // Every Newton iteration needs the joint poses at the midpoint (Lagrangian terms) AND at q2 (constraint values
+    // and Jacobians).  Swept one after the other they are two latency-bound recurrences of 8 barriers; here both run
+    // through the same phases: the second pose set lives in the W area and its sin/cos in the J area (both dead until
+    // the Jacobians / prefix velocities are formed), every chain lane carries the two row recurrences side by side
+    // (two independent FMA chains per lane), and the local-transform pass covers 2 x 12 x n_joints entries.
+    TG_HD void pose_sweep_dual(bool on) {
+        PROG &P = tg_fresh(this->P);
+        double *sc = S + P.o_sc, *sc2 = S + P.o_J, *G = S + P.o_G, *G2 = S + P.o_W;
+        const int nj = P.n_joints;
+        if (on) TG_FOR(idx, 2 * nj) {
+            const bool second = idx >= nj;
+            const int j = second ? idx - nj : idx;
+            const double x = qval(second ? 2 : 0, P.j_cfg[j]);
+            double *dst = (second ? sc2 : sc) + 2 * j;
+            if (P.j_kind[j] >= TG_RX) tg_sincos(x, &dst[0], &dst[1]);
+            else { dst[0] = x; dst[1] = 0.0; }
+        }
+        TG_SYNC();
+        if (on) {
+            const int n12 = 12 * nj, n24 = 2 * n12;
+            for (int base = lane; base < n24; base += 4 * TEAM) {
+                double k0[4], k1[4], k2[4];
+                int jj[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int idx2 = base + u * TEAM;
+                    const bool ok = idx2 < n24;
+                    const int idx = ok ? (idx2 >= n12 ? idx2 - n12 : idx2) : 0;
+                    const int j = idx / 12, e = idx % 12;
+                    const double *k = P.jcoef + 4 * (size_t)(16 * j + e);
+                    k0[u] = k[0]; k1[u] = k[1]; k2[u] = k[2]; jj[u] = j;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int idx2 = base + u * TEAM;
+                    if (idx2 < n24) {
+                        const bool second = idx2 >= n12;
+                        const double *scx = second ? sc2 : sc;
+                        (second ? G2 : G)[second ? idx2 - n12 : idx2] = k0[u] + k1[u] * scx[2 * jj[u] + 1] + k2[u] * scx[2 * jj[u]];
+                    }
+                }
+            }
+        }
+        TG_SYNC();
+        const int *sched = (const int *)(S + P.o_sched);
+        for (int r = 0; r < P.n_rounds; r++) {
+            if (on) TG_FOR(idx, 64) {
+                const int row = idx & 3;
+                const int w0 = sched[2 * (16 * r + (idx >> 2))];
+                const int opar = sched[2 * (16 * r + (idx >> 2)) + 1];
+                const int o0 = w0 & 0xFFFF, len = w0 >> 16;
+                if (row < 3 && len > 0) {
+                    double p0, p1, p2, p3, q0, q1, q2, q3;
+                    if (opar >= 0) {
+                        const double *gp = G + opar + 4 * row, *gq = G2 + opar + 4 * row;
+                        p0 = gp[0]; p1 = gp[1]; p2 = gp[2]; p3 = gp[3]; q0 = gq[0]; q1 = gq[1]; q2 = gq[2]; q3 = gq[3];
+                    } else {
+                        p0 = q0 = row == 0 ? 1.0 : 0.0; p1 = q1 = row == 1 ? 1.0 : 0.0; p2 = q2 = row == 2 ? 1.0 : 0.0; p3 = q3 = 0.0;
+                    }
+                    double m[12], h[12];
+#pragma unroll
+                    for (int e = 0; e < 12; e++) { m[e] = G[o0 + e]; h[e] = G2[o0 + e]; }
+                    for (int s = 0; s < len; s++) {
+                        double *gj = G + o0 + 12 * s, *hj = G2 + o0 + 12 * s;
+                        double n[12], g[12];                          // next local transforms: loads before this step's stores
+                        const int nxt = s + 1 < len ? 12 : 0;
+#pragma unroll
+                        for (int e = 0; e < 12; e++) { n[e] = gj[nxt + e]; g[e] = hj[nxt + e]; }
+                        const double v0 = p0 * m[0] + p1 * m[4] + p2 * m[8];
+                        const double w0_ = q0 * h[0] + q1 * h[4] + q2 * h[8];
+                        const double v1 = p0 * m[1] + p1 * m[5] + p2 * m[9];
+                        const double w1 = q0 * h[1] + q1 * h[5] + q2 * h[9];
+                        const double v2 = p0 * m[2] + p1 * m[6] + p2 * m[10];
+                        const double w2 = q0 * h[2] + q1 * h[6] + q2 * h[10];
+                        const double v3 = p0 * m[3] + p1 * m[7] + p2 * m[11] + p3;
+                        const double w3 = q0 * h[3] + q1 * h[7] + q2 * h[11] + q3;
+                        double *out = gj + 4 * row, *out2 = hj + 4 * row;
+                        out[0] = v0; out[1] = v1; out[2] = v2; out[3] = v3;
+                        out2[0] = w0_; out2[1] = w1; out2[2] = w2; out2[3] = w3;
+                        p0 = v0; p1 = v1; p2 = v2; p3 = v3; q0 = w0_; q1 = w1; q2 = w2; q3 = w3;
+#pragma unroll
+                        for (int e = 0; e < 12; e++) { m[e] = n[e]; h[e] = g[e]; }
+                    }
+                }
+            }
+            TG_SYNC();
+        }
+    }
+    // the dual sweep needs the chain schedule in LDS and room for the second pose set in the J / W areas
+    TG_HD bool dual_ok() const { return TEAM == 64 && !SPRINGS && P.sched_ok && P.nc > 0 && 6 * P.n_items >= 12 * P.n_joints; }
+
+    // eval_midpoint followed by eval_constraints(on, 2, true, Dh2) with the two pose sweeps fused
+    TG_HD void eval_both(bool on) {
+        PROG &P = tg_fresh(this->P);
+        if (on) TG_FOR(i, P.nq) S[P.o_dq + i] = (S[P.o_q2 + i] - S[P.o_q1 + i]) / dt;
+        TG_SYNC();
+        TG_STAMP(0);
+        pose_sweep_dual(on);
+        TG_STAMP(1);
+        oGc = P.o_W;
+        attach_points(on, true, true);            // bodies from the midpoint poses, end points from the q2 poses
+        constraints(on, 2, true, S + P.o_Dh2, 0);
+        oGc = P.o_G;
+        TG_STAMP(6);
+        jacobians(on);
+        TG_STAMP(2);
+        velocities(on);
+        TG_STAMP(3);
+        residual_dyn(on);
+        TG_STAMP(4);
+    }
+#endif
+
     // ---- poses of the massive frames and positions of the constraint end points --------------------
     TG_HD void attach_points(bool on, bool bodies, bool endpoints) {
+        PROG &P = tg_fresh(this->P);
         const double *G = S + P.o_G;
         // Branch-free: an unanchored frame (anchor < 0: fixed to the world) reads joint 0 and weights it out.  A branch
         // would split the loop body into basic blocks that each wait for their own loads.
@@ -370,7 +523,7 @@ struct Core {
             const double *o = P.e_off + 3 * e;
             const int anchor = P.e_anchor[e];
             const double o0 = o[0], o1 = o[1], o2 = o[2], orr = o[r];
-            const double *g = G + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
+            const double *g = S + oGc + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
             const double val = g[0] * o0 + g[1] * o1 + g[2] * o2 + g[3];
             S[P.o_pE + idx] = anchor < 0 ? orr : val;
         }
@@ -395,6 +548,7 @@ struct Core {
 
     // ---- body Jacobian columns J_{F,k} and gravity in body coordinates ------------------------------
     TG_HD void jacobians(bool on) {
+        PROG &P = tg_fresh(this->P);
         const double *G = S + P.o_G;
         struct JacOut { double J[6], dq; };
         if (on) for_pairs(P.n_items, [&](int it) {
@@ -433,6 +587,7 @@ struct Core {
 
     // ---- prefix velocities, W_j = [P_j, J_j], body velocity v_F --------------------------------------
     TG_HD void velocities(bool on) {
+        PROG &P = tg_fresh(this->P);
         // (1) one lane per (body, twist component): serial prefix sum along the body's path,
         //     P_j = sum_{k<j} J_k dq_k written into the W slot of item j, total = body velocity;
         // (2) one lane per item: W_j = [P_j, J_j] in place.
@@ -458,6 +613,7 @@ struct Core {
 
     // ---- L_dq, L_ddq per config and the dynamic part of the DEL residual (midpointvi.c:533-551) -------
     TG_HD void residual_dyn(bool on) {
+        PROG &P = tg_fresh(this->P);
         // per-item terms <J,v> and <W,v> + m gam.Jv, stored in config-sorted order in the (now dead) joint
         // pose area, then one contiguous sum per dynamic config
         double *terms = S + P.o_G;
@@ -510,7 +666,7 @@ struct Core {
 
     // same with the joint given by its pose offset and kind, the end point by its offset (packed dh records)
     TG_HD void dpos_rec(int oe, int oj, int kind, double *d) const {
-        const double *gj = S + P.o_G + oj, *pe = S + P.o_pE + oe;
+        const double *gj = S + oGc + oj, *pe = S + P.o_pE + oe;
         const bool prismatic = kind <= TG_TZ;
         const int a = prismatic ? kind - TG_TX : kind - TG_RX;
         const double wx = gj[a], wy = gj[4 + a], wz = gj[8 + a];
@@ -523,6 +679,7 @@ struct Core {
     // ---- constraint values (into f[nd..]) and Jacobian Dh (into dest) at the swept state -------------
     // distance.c:16-63, point.c:16-38.  `sel` picks the config vector for the length configs.
     TG_HD void constraints(bool on, int sel, bool want_h, double *Dh, int ld) {
+        PROG &P = tg_fresh(this->P);
         if (on && want_h) TG_FOR(c, P.nc) {
             const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
             const double vx = a[0] - b[0], vy = a[1] - b[1], vz = a[2] - b[2];
@@ -568,6 +725,7 @@ struct Core {
 
     // ---- Newton matrix [Df | f] (midpointvi.c:577-670) ---------------------------------------------------
     TG_HD void newton_matrix(bool on) {
+        PROG &P = tg_fresh(this->P);
         const int nd = P.nd, nf = P.nf, ld = P.df_ld;
         double *A = S + P.o_Df;
         // zero fill, then the few structurally non-zero constant entries: damping on the diagonal
@@ -808,6 +966,87 @@ struct Core {
                     for (int jj = j; jj < N; jj++) asm volatile("" : "+v"(row[jj]));
                 }
             }
+        }
+        if (mine && ok && mycol >= 0 && mycol < n) A[mycol * ld + n] = rhs / diag;
+        __syncthreads();
+        return ok;
+    }
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    // ---- the same solver with the pivot row broadcast through LDS instead of v_readlane ---------------------------
+    //      gj_rows() spends two v_readlane_b32 (+ SGPR hazard wait states) per (step, column) pair: ~950 readlanes and
+    //      ~700 s_nops around ~500 FMAs, all on the VALU that the wave shares with its SIMD neighbour.  Here the lane
+    //      that owns the pivot row writes [1/pivot | rest of the row | rhs] into the (dead) matrix storage and every
+    //      lane reads it back with wave-uniform LDS reads (hardware broadcast): the VALU work drops to the FMAs and the
+    //      pivot search, the broadcasts ride on the LDS pipe.  Every lane inverts its own candidate while the wave max
+    //      is in flight, so the reciprocal is off the critical path.  Rounding differs from gj_rows() only in the
+    //      order of one multiplication (l = a_ik * (1/p_kk) in both).
+    template <int N>
+    static __device__ __noinline__ bool gj_rows_lds(bool on, double *A_generic, int n, int ld, int lane) {
+        typedef __attribute__((address_space(3))) double lds_double;
+        lds_double *A = (lds_double *)A_generic;
+        double row[N], rhs = 0.0, scale = 0.0, diag = 1.0;
+        int mycol = -1;
+        const bool mine = on && lane < N;
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            row[j] = (mine && lane < n && j < n) ? A[lane * ld + j] : ((mine && lane >= n && j == lane) ? 1.0 : 0.0);
+        if (mine) {
+            rhs = lane < n ? A[lane * ld + n] : 0.0;
+            double s = -1.0;
+#pragma unroll
+            for (int j = 0; j < N; j++) { const double a = fabs(row[j]); s = a > s ? a : s; }
+            scale = 1.0 / s;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();                 // every row is in registers: the matrix storage becomes the broadcast buffer
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        lds_double *buf = A;
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const double cand64 = (mine && mycol < 0) ? fabs(row[k] * scale) : 0.0;
+            const float cand = (float)cand64;
+            unsigned int key = (__float_as_uint(cand) & ~0x3Fu) | (unsigned int)(63 - (lane & 63));
+            if (TEAM == 64) {
+                key = __ockl_wfred_max_u32(key);
+            } else {
+#pragma unroll
+                for (int m = TEAM / 2; m >= 1; m >>= 1) {
+                    const unsigned int o = __shfl_xor(key, m, TEAM);
+                    key = o > key ? o : key;
+                }
+            }
+            // own reciprocal, speculatively (independent of the reduction above)
+            double rp = __builtin_amdgcn_rcp(row[k]);
+            rp = fma(rp, fma(-row[k], rp, 1.0), rp);
+            rp = fma(rp, fma(-row[k], rp, 1.0), rp);
+            int piv = 63 - (int)(key & 0x3Fu);
+            const float best = __uint_as_float(key & ~0x3Fu);
+            if (TEAM != 64) piv = (piv & (TEAM - 1));
+            if (on && ok && !(best > 1.0e-20f)) ok = false;
+            const bool go = on && ok;
+            const bool is_piv = mine && (lane & (TEAM - 1)) == piv;
+            if (go && is_piv) {
+                buf[0] = rp;
+#pragma unroll
+                for (int j = k + 1; j < N; j++) buf[j - k] = row[j];
+                buf[N - k] = rhs;
+                mycol = k; diag = row[k];
+            }
+            // one wave owns the team: its LDS operations execute in order, the loads below see the stores above
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            const double prp = buf[0];
+            const double l = (go && mine && !is_piv) ? row[k] * prp : 0.0;
+#pragma unroll
+            for (int j = k + 1; j < N; j++) row[j] = fma(-l, buf[j - k], row[j]);
+            rhs = fma(-l, buf[N - k], rhs);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();             // reads of this step before the next step's stores
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         }
         if (mine && ok && mycol >= 0 && mycol < n) A[mycol * ld + n] = rhs / diag;
         __syncthreads();
@@ -1090,13 +1329,13 @@ struct Core {
         return gauss_jordan(on, AUG, nf, R + (extra ? nc : 0), ld, S + P.o_scal);
     }
 
-    TG_HD void deriv1(bool on, const RunArgs &A, size_t t) {
+    TG_HD void deriv1(bool on, CArgs &A, size_t t) {
         const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nf = P.nf;
         const int ld = P.d_aug_ld, R = P.d_nrhs;
         double *AUG = S + P.d_o_AUG, *T12 = S + P.d_o_T12, *T22 = S + P.d_o_T22;
         const bool ok = deriv1_solve(on, false);
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-        struct ProfDump { Core &c; const RunArgs &A; size_t t; int lane;
+        struct ProfDump { Core &c; CArgs &A; size_t t; int lane;
             __device__ ~ProfDump() { long long t_ = (long long)__builtin_amdgcn_s_memtime(); c.prof[13] += t_ - c.prof_last;
                           if (A.prof_out && t == 0 && lane == 0) for (int i = 0; i < 16; i++) A.prof_out[i] = c.prof[i]; } } dump_{*this, A, t, lane};
 #endif
@@ -1637,7 +1876,7 @@ struct Core {
         return r;
     }
 
-    TG_HD void deriv2z(bool on, const RunArgs &A, size_t t) {
+    TG_HD void deriv2z(bool on, CArgs &A, size_t t) {
         const int nq = P.nq, nd = P.nd, nu = P.nu, nc = P.nc, nf = P.nf;
         const int ld = P.d_aug_ld, R = P.d_nrhs, hl = nq | 1;   // odd row stride of the H tables: no LDS bank conflicts
         double *AUG = S + P.d_o_AUG, *T22 = S + P.d_o_T22;
@@ -2107,6 +2346,7 @@ struct Core {
 
     // team-uniform convergence test (midpointvi.c:672-689)
     TG_HD bool solved(double tolerance) const {
+        PROG &P = tg_fresh(this->P);
         double norm = 0.0;
         for (int i = 0; i < P.nd; i++) norm += S[P.o_f + i] * S[P.o_f + i];
         if (sqrt(norm) > tolerance) return false;
@@ -2146,7 +2386,7 @@ struct Core {
     //     D_i = sum_{items a of config i} ( m gam.J_a - <J_a, S_F> - <[J_a, v_F], v_F> ) + F_i
     // (the <W_a, v> parts of L_dq and L_ddqdq dq cancel).  q must be loaded in both q1 and q2.
     // =====================================================================================================
-    TG_HD bool dynamics(bool on, const RunArgs &A, size_t t) {
+    TG_HD bool dynamics(bool on, CArgs &A, size_t t) {
         const int nq = P.nq, nd = P.nd, nk = P.nk, nc = P.nc, nf = P.nf, ld = P.df_ld;
         // The KKT matrix shares its storage with the poses (program.hpp, LDS layout): the right-hand side is
         // accumulated in f while the poses are alive, the matrix is assembled afterwards from J and the Dh items.
@@ -2237,7 +2477,7 @@ struct Core {
 
     // Kinetic and potential energy at (q, dq) (System_total_energy / System_L, system.c:78-127): T = sum 1/2 <v_F, I v_F>,
     // V = -sum m g.p_F + config springs + two-point springs.  One lane per term, summed through an LDS atomic.
-    TG_HD void energy(bool on, const RunArgs &A, size_t t) {
+    TG_HD void energy(bool on, CArgs &A, size_t t) {
         double *acc = S + P.o_f;   // [0] = T, [1] = V
         if (on) {
             TG_FOR(i, P.nq) S[P.o_dq + i] = A.dq_in[t * P.nq + i];
@@ -2272,7 +2512,7 @@ struct Core {
     // First and second derivatives of the Lagrangian for every config / pair of configs at (q, dq) (System_L_dq ...
     // System_L_ddqddq, system.c:129-489): the per-item and per-pair quantities of the integrator, summed into the caller's
     // (zeroed) output arrays.  lag1 = [L_dq | L_ddq], lag2 = [L_dqdq | L_ddqdq (dq row, q column) | L_ddqddq].
-    TG_HD void lagrangian(bool on, const RunArgs &A, size_t t) {
+    TG_HD void lagrangian(bool on, CArgs &A, size_t t) {
         const int nq = P.nq;
         if (on) TG_FOR(i, nq) S[P.o_dq + i] = A.dq_in[t * nq + i];
         TG_SYNC();
@@ -2338,7 +2578,7 @@ struct Core {
     //     da_F/ddq_k = 2 W_k + [J_k, v]
     // is O(1), and the torque tau_a = m gam.J_a - <J_a, a_F> - <[J_a, v], v> of item a is differentiated pair by pair.
     // =====================================================================================================
-    TG_HD bool dyn_deriv1(bool on, const RunArgs &A, size_t t) {
+    TG_HD bool dyn_deriv1(bool on, CArgs &A, size_t t) {
         const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nf = P.nf, ld = P.g_ld;
         double *AUG = S + P.g_o_AUG, *X = S + P.g_o_X, *aF = S + P.g_o_aF, *xs = S + P.g_o_x, *acc = xs + nf;
         const double *dq = S + P.o_dq;
@@ -2512,6 +2752,7 @@ struct Core {
 
     // midpoint evaluation shared by every mode: rates, poses, Jacobians, velocities, residual
     TG_HD void eval_midpoint(bool on) {
+        PROG &P = tg_fresh(this->P);
         if (on) TG_FOR(i, P.nq) S[P.o_dq + i] = (S[P.o_q2 + i] - S[P.o_q1 + i]) / dt;
         TG_SYNC();
         TG_STAMP(0);
@@ -2542,13 +2783,15 @@ struct Core {
 // every TG_SYNC.
 // MODE is a compile-time parameter so that every kernel mode gets its own register allocation (the
 // derivative modes are far larger than the rollout loop).
-template <int TEAM, int MODE, bool SPRINGS = false>
-TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lane, int traj) {
+template <int TEAM, int MODE, bool SPRINGS = false, class PROG = CProg, class ARGS = CArgs>
+TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj) {
+    PROG &P = tg_fresh(P0);
+    ARGS &A = A0;
     const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc;
     const bool live = traj < A.batch;
     const size_t t = (size_t)(live ? traj : 0);
     double dt = MODE == MODE_ROLLOUT ? A.dt : (A.t2 - A.t1);
-    Core<TEAM, SPRINGS> core(P, S, lane, dt);
+    Core<TEAM, SPRINGS, PROG> core(P, S, lane, dt);
     core.init_sweep_schedule();
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     core.prof_last = (long long)__builtin_amdgcn_s_memtime();
@@ -2619,6 +2862,9 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
     bool failed = false;
     int status = TG_OK, total_iters = 0;
     for (int step = 0; step < A.n_steps; step++) {
+        PROG &P = tg_fresh_step(P0);      // per step: nothing of the schedule / the arguments stays in SGPRs across steps
+        ARGS &A = tg_fresh_args(A0);
+        const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nX = P.nX;
         const bool on = live && !failed;
         if (A.Kproj) {  // feedback inputs from the state entering this step (before the shift: v needs q1)
             const int nU = nu + nk;
@@ -2674,8 +2920,16 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
         int iterations = 0;
         bool done = !on;
         for (;;) {
-            core.eval_midpoint(!done);
-            core.eval_constraints(!done, 2, true, S + P.o_Dh2);
+            PROG &P = tg_fresh(P0);
+            const int nd = P.nd, nc = P.nc;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_DUAL_SWEEP)
+            if (core.dual_ok()) core.eval_both(!done);
+            else
+#endif
+            {
+                core.eval_midpoint(!done);
+                core.eval_constraints(!done, 2, true, S + P.o_Dh2);
+            }
             if (!done && core.solved(A.tolerance)) done = true;
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
             { long long t_ = (long long)__builtin_amdgcn_s_memtime(); core.prof[12] += t_ - core.prof_last; core.prof_last = t_; }
@@ -2693,6 +2947,17 @@ TG_HD void run_trajectory(const DevProg &P, const RunArgs &A, double *S, int lan
             const int nb4 = (P.nf + 3) >> 2;   // matrix size in blocks of 4 rows
             if (TEAM >= 4 && 4 * nb4 <= TEAM && nb4 <= 8) {
                 double *Ad = S + P.o_Df;
+#if defined(TG_GJ_LDS)
+                if (nb4 >= 2 && P.nf * P.df_ld >= 4 * nb4 + 1) switch (nb4) {
+                case 2: ok = Core<TEAM>::template gj_rows_lds<(TEAM >= 8 ? 8 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 3: ok = Core<TEAM>::template gj_rows_lds<(TEAM >= 12 ? 12 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 4: ok = Core<TEAM>::template gj_rows_lds<(TEAM >= 16 ? 16 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 5: ok = Core<TEAM>::template gj_rows_lds<(TEAM >= 20 ? 20 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 6: ok = Core<TEAM>::template gj_rows_lds<(TEAM >= 24 ? 24 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 7: ok = Core<TEAM>::template gj_rows_lds<(TEAM >= 28 ? 28 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                default: ok = Core<TEAM>::template gj_rows_lds<(TEAM >= 32 ? 32 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                } else
+#endif
                 switch (nb4) {
                 case 1: ok = Core<TEAM>::template gj_rows<4>(!done, Ad, P.nf, P.df_ld, lane); break;
                 case 2: ok = Core<TEAM>::template gj_rows<(TEAM >= 8 ? 8 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;

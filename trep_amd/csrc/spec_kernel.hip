@@ -1,0 +1,54 @@
+// spec_kernel.hip -- the rollout kernel of ONE system with its schedule compiled in (trep_amd/specialize.py).
+//
+// The generic kernel k_run<TEAM, MODE_ROLLOUT> reads ~110 integers (sizes, counts, LDS offsets) and ~65 table pointers
+// of the schedule at run time; they do not fit the scalar register file, so the compiler spills them into VGPR lanes and
+// every use pays a v_readlane plus the address arithmetic around it.  Here the same source (mvi_core.hpp) is
+// instantiated on `SpecProg` (generated header, -DTG_SPEC_HEADER=...): integers are immediates (LDS offsets fold into
+// the ds_* offset fields, loop bounds are known), tables are constant arrays in the code object.  Nothing about the
+// arithmetic changes -- it is the same template -- so results are bit-identical to the generic kernel.
+#include <hip/hip_runtime.h>
+
+#include "mvi_core.hpp"
+#include TG_SPEC_HEADER
+
+namespace {
+// SPEC_ARGS_IN_MEMORY: the launch arguments are read from device memory through a constant-address-space reference and
+// re-read at the head of every step, instead of ~50 scalar registers held (and spilled) for the whole rollout
+#if defined(SPEC_ARGS_IN_MEMORY)
+__global__ __launch_bounds__(64, 2) void k_spec_rollout(const tg::RunArgs *__restrict__ Ag) {
+    tg::KArgs &A = *(tg::KArgs *)Ag;
+#else
+__global__ __launch_bounds__(64, 2) void k_spec_rollout(const tg::RunArgs A) {
+#endif
+    extern __shared__ double lds[];
+    const SpecProg P{};
+    const int team = threadIdx.x / SPEC_TEAM, lane = threadIdx.x % SPEC_TEAM;
+    const int traj = blockIdx.x * (64 / SPEC_TEAM) + team;
+    tg::run_trajectory<SPEC_TEAM, tg::MODE_ROLLOUT, SPEC_SPRINGS, const SpecProg>(P, A, lds + (size_t)team * SpecProg::lds_per_team, lane, traj);
+}
+}  // namespace
+
+extern "C" {
+const int *tg_spec_sizes(void) {
+    static const int s[8] = {(int)sizeof(tg::DevProg), (int)sizeof(tg::RunArgs), SpecProg::nq, SpecProg::nd, SpecProg::nc, SpecProg::n_items,
+                             SpecProg::n_pairs, SpecProg::lds_per_team};
+    return s;
+}
+int tg_spec_launch_rollout(const tg::DevProg *, const tg::RunArgs *A, int grid, size_t lds, void *stream) {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spec_rollout), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+#if defined(SPEC_ARGS_IN_MEMORY)
+    // a small ring of device-side argument blocks: a launch's block is not reused before 16 later launches were issued on
+    // streams ordered with this one (launches of one batch are stream ordered anyway)
+    static tg::RunArgs *ring = nullptr;
+    static unsigned next = 0;
+    if (!ring && hipMalloc(&ring, 16 * sizeof(tg::RunArgs)) != hipSuccess) return 1;
+    tg::RunArgs *slot = ring + (next++ % 16);
+    if (hipMemcpyAsync(slot, A, sizeof(tg::RunArgs), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return 1;
+    hipLaunchKernelGGL(k_spec_rollout, dim3(grid), dim3(64), lds, (hipStream_t)stream, (const tg::RunArgs *)slot);
+#else
+    hipLaunchKernelGGL(k_spec_rollout, dim3(grid), dim3(64), lds, (hipStream_t)stream, *A);
+#endif
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+}

@@ -14,6 +14,8 @@
 #include <vector>
 
 #include "mvi_core.hpp"
+#include "spec_emit.inc"
+#include <dlfcn.h>
 
 namespace {
 
@@ -32,8 +34,12 @@ int fail(int code, const std::string &msg) {
 // The derivative modes keep 60-80 KB of LDS per trajectory, i.e. at most two wavefronts per CU: they may use the whole
 // register file of a SIMD (no spills, deeper unrolling); the rollout modes run two wavefronts per SIMD.
 template <int TEAM, int MODE, bool SPRINGS>
-__global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z || MODE == tg::MODE_DYN_DERIV1) ? 1 : 2) void k_run(const tg::DevProg P, const tg::RunArgs A) {
+__global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z || MODE == tg::MODE_DYN_DERIV1) ? 1 : 2) void k_run(const tg::DevProg *__restrict__ Pg, const tg::RunArgs A) {
     extern __shared__ double lds[];
+    // The schedule sits in device memory and is read through a CONSTANT-address-space reference (mvi_core.hpp, CProg):
+    // every field access is a scalar load that a phase issues when it needs it, instead of ~150 kernel-argument values
+    // that the compiler would hoist, keep alive for the whole rollout and spill into VGPR lanes.
+    tg::CProg &P = *(tg::CProg *)Pg;
     const int team = threadIdx.x / TEAM, lane = threadIdx.x % TEAM;
     const int traj = blockIdx.x * (64 / TEAM) + team;
     const int stride = MODE == tg::MODE_DERIV2Z ? P.e_lds_per_team : (MODE == tg::MODE_DERIV1 ? P.d_lds_per_team : (MODE == tg::MODE_DYN_DERIV1 ? P.g_lds_per_team : P.lds_per_team));
@@ -51,6 +57,10 @@ struct tg_batch {
     tg_system *sys = nullptr;
     int batch = 0, device = 0;
     tg::DevProg P{};           // device-pointer view
+    tg::DevProg *d_prog = nullptr;   // the same view in device memory: what the kernels read (constant address space)
+    // optional system-specialised rollout kernel (tg_batch_load_specialized): launcher exported by a generated library
+    void *spec_lib = nullptr;
+    int (*spec_launch)(const tg::DevProg *, const tg::RunArgs *, int, size_t, void *) = nullptr;
     int *d_ints = nullptr;
     double *d_dbls = nullptr;
     double *q1 = nullptr, *q2 = nullptr, *p1 = nullptr, *p2 = nullptr, *lam = nullptr, *u1 = nullptr;
@@ -136,7 +146,7 @@ template <int TEAM, int MODE, bool SPRINGS>
 int launch_variant(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<TEAM, MODE, SPRINGS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_run<TEAM, MODE, SPRINGS>), dim3(grid), dim3(64), lds, b->stream, b->P, A);
+    hipLaunchKernelGGL((k_run<TEAM, MODE, SPRINGS>), dim3(grid), dim3(64), lds, b->stream, b->d_prog, A);
     return TG_SUCCESS;
 }
 
@@ -194,7 +204,11 @@ int launch(tg_batch *b, tg::RunArgs &A) {
         }
         if (hipEventRecord(e0, b->stream) != hipSuccess) { b->pool.push_back(e0); b->pool.push_back(e1); return fail(TG_ERR_HIP, "hipEventRecord failed"); }
     }
-    int rc = team == 64 ? launch_team<64>(b, A, grid, lds) : (team == 16 ? launch_team<16>(b, A, grid, lds)
+    int rc;
+    if (b->spec_launch && A.mode == tg::MODE_ROLLOUT) {
+        rc = b->spec_launch(b->d_prog, &A, grid, lds, (void *)b->stream) == 0 ? TG_SUCCESS : fail(TG_ERR_HIP, "specialised kernel launch failed");
+    } else
+    rc = team == 64 ? launch_team<64>(b, A, grid, lds) : (team == 16 ? launch_team<16>(b, A, grid, lds)
              : (team == 4 ? launch_team<4>(b, A, grid, lds) : launch_team<1>(b, A, grid, lds)));
     if (rc == TG_SUCCESS && hipGetLastError() != hipSuccess) rc = fail(TG_ERR_HIP, "kernel launch failed");
     if (b->timing) {
@@ -334,6 +348,8 @@ tg_batch *tg_batch_create(tg_system *sys, int32_t batch, int32_t device) {
               hipMemcpy(b->d_dbls, dbls.data(), dbls.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
     tg::DevProg &P = b->P;
     H.bind(P, b->d_ints, b->d_dbls);
+    if (ok) ok = hipMalloc(&b->d_prog, sizeof(tg::DevProg)) == hipSuccess &&
+                 hipMemcpy(b->d_prog, &P, sizeof(tg::DevProg), hipMemcpyHostToDevice) == hipSuccess;
     auto dalloc = [&](double **p, size_t n) {
         if (!ok) return;
         ok = hipMalloc(p, (n ? n : 1) * sizeof(double)) == hipSuccess && hipMemset(*p, 0, (n ? n : 1) * sizeof(double)) == hipSuccess;
@@ -361,11 +377,12 @@ void tg_batch_destroy(tg_batch *b) {
     if (b->stream) hipStreamSynchronize(b->stream);
     for (auto &e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : b->pool) hipEventDestroy(e);
-    void *ptrs[] = {b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
+    void *ptrs[] = {b->d_prog, b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
                     b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev, b->zl_dev, b->dyn, b->dyn_ints, b->dyn_d1, b->energy, b->lag,
                     b->d1[0], b->d1[1], b->d1[2], b->d1[3], b->d1[4], b->d1[5], b->d1[6], b->d1[7], b->d1[8], b->d1[9], b->d1[10], b->d1[11]};
     for (void *p : ptrs) if (p) hipFree(p);
     if (b->stream && b->own_stream) hipStreamDestroy(b->stream);
+    if (b->spec_lib) dlclose(b->spec_lib);
     delete b;
 }
 
@@ -839,6 +856,40 @@ int tg_batch_set_stream(tg_batch *b, void *hip_stream) {
     if (b->own_stream && b->stream) HIP_TRY(hipStreamDestroy(b->stream));
     if (hip_stream) { b->stream = (hipStream_t)hip_stream; b->own_stream = false; }
     else { HIP_TRY(hipStreamCreate(&b->stream)); b->own_stream = true; }
+    return TG_SUCCESS;
+}
+
+/* Text of the specialisation header of a system (spec_emit.inc); returns the length needed (incl. the terminator). */
+int64_t tg_system_spec_header(const tg_system *sys, char *buf, uint64_t capacity) {
+    if (!sys) { fail(TG_ERR_INVALID, "null system"); return -1; }
+    std::string out;
+    char line[160];
+    std::snprintf(line, sizeof(line), "#define SPEC_TEAM %d\n#define SPEC_SPRINGS %s\n", sys->team,
+                  (sys->H.p.has_cs || sys->H.p.n_springs || sys->H.p.has_plane || sys->H.p.n_wrenches) ? "true" : "false");
+    out += line;
+    emit_spec_header(sys->H, out);
+    if (buf && capacity) {
+        const size_t n = std::min((size_t)capacity - 1, out.size());
+        std::memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)out.size() + 1;
+}
+
+/* Rollouts of this batch use the kernel of a library built by trep_amd/specialize.py for exactly this system. */
+int tg_batch_load_specialized(tg_batch *b, const char *library_path) {
+    if (!b || !library_path) return fail(TG_ERR_INVALID, "null argument");
+    void *h = dlopen(library_path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(TG_ERR_INVALID, std::string("cannot load ") + library_path + ": " + (dlerror() ? dlerror() : "?"));
+    auto launch_fn = reinterpret_cast<int (*)(const tg::DevProg *, const tg::RunArgs *, int, size_t, void *)>(dlsym(h, "tg_spec_launch_rollout"));
+    auto sizes_fn = reinterpret_cast<const int *(*)(void)>(dlsym(h, "tg_spec_sizes"));
+    if (!launch_fn || !sizes_fn) { dlclose(h); return fail(TG_ERR_INVALID, "not a specialised trep_amd kernel library"); }
+    const tg::DevProg &P = b->P;
+    const int want[8] = {(int)sizeof(tg::DevProg), (int)sizeof(tg::RunArgs), P.nq, P.nd, P.nc, P.n_items, P.n_pairs, P.lds_per_team};
+    const int *got = sizes_fn();
+    for (int i = 0; i < 8; i++) if (got[i] != want[i]) { dlclose(h); return fail(TG_ERR_INVALID, "specialised kernel was built for a different system or library version"); }
+    if (b->spec_lib) dlclose(b->spec_lib);
+    b->spec_lib = h; b->spec_launch = launch_fn;
     return TG_SUCCESS;
 }
 

@@ -11,6 +11,8 @@ include/trep_amd.h.  State lives in device memory; the properties copy it
 in/out.  There is no CPU execution path: without the library or without a GPU
 every call raises.
 """
+import os
+
 import numpy as np
 
 from . import _lib
@@ -21,8 +23,12 @@ from .errors import ConvergenceError
 class BatchMidpointVI(object):
     """B trajectories of ``system`` on HIP device ``device`` (state arrays are [B][width])."""
 
-    def __init__(self, system, batch, tolerance=1e-10, device=0):
+    def __init__(self, system, batch, tolerance=1e-10, device=0, specialize="auto"):
+        """specialize: "auto" (default) uses a system-specialised rollout kernel if one has been built for this system
+        (trep_amd/specialize.py; never compiles implicitly), True builds one if needed, False keeps the generic kernel."""
         self._system = system
+        self._specialize_mode = specialize
+        self._specialized = None
         self._batch = int(batch)
         self._device = int(device)
         self._L = _lib.lib()
@@ -40,6 +46,22 @@ class BatchMidpointVI(object):
             raise _lib.LibraryError(msg)
         self.tolerance = tolerance
         self._owned_dev = []
+        if specialize is True:
+            self.specialize(build=True)
+        elif specialize == "auto" and os.environ.get("TREPAMD_NO_SPECIALIZE") is None:
+            self.specialize(build=False)
+
+    def specialize(self, build=True):
+        """Use a rollout kernel compiled for exactly this system (trep_amd/specialize.py): same results, fewer
+        instructions.  With build=False only an already cached specialisation is used (returns False if there is
+        none).  A later structure / parameter change of the system drops back to the generic kernel."""
+        from . import specialize as _spec
+        if not build and not _spec.is_built(self._system):
+            return False
+        path = _spec.build(self._system)
+        _lib.check(self._L.tg_batch_load_specialized(self._h, path.encode()))
+        self._specialized = path
+        return True
 
     def refresh(self):
         """Re-flatten the system if it changed since the device program was built.  The reference treats parameter
@@ -68,6 +90,9 @@ class BatchMidpointVI(object):
         self._L.tg_system_destroy(self._sys_h)
         self._desc, self._sys_h, self._h = desc, sys_h, h
         self._structure_version = self._system._structure_version
+        self._specialized = None
+        if self._specialize_mode is True or (self._specialize_mode == "auto" and os.environ.get("TREPAMD_NO_SPECIALIZE") is None):
+            self.specialize(build=False)      # a cached specialisation of the NEW schedule, if there is one
         if keep is not None:
             (t1, t2), fields, tol, pred = keep
             self.set_times(t1, t2)

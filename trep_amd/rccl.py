@@ -12,8 +12,10 @@ then builds the RCCL communicator of ``csrc/comm.hip``:
 Collectives offered: ``all_gather_rows`` (row blocks of device or host arrays, ragged by at most the shard
 imbalance), ``max`` / ``sum`` of host scalars, ``barrier``.  The rollouts themselves need none of them.
 """
+import contextlib
 import ctypes
 import os
+import sys
 import time
 
 import numpy as np
@@ -57,6 +59,24 @@ def exchange_unique_id(rank, world, make_id, timeout=300.0):
         time.sleep(0.01)
 
 
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """RCCL prints a version banner on the C-level stdout when the first communicator comes up; programs that print
+    one JSON line on stdout (bench.py) must not see it there."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 class Communicator(object):
     """RCCL communicator of this process (world size 1 works too: the collectives are then local copies)."""
 
@@ -64,7 +84,10 @@ class Communicator(object):
         self.L = _lib.lib()
         self.device, self.world, self.rank = int(device), int(world), int(rank)
         buf = (ctypes.c_uint8 * ID_BYTES).from_buffer_copy(unique_id)
-        self._h = self.L.tg_comm_create(self.device, self.world, self.rank, ctypes.cast(buf, ctypes.c_void_p))
+        with _stdout_to_stderr():
+            self._h = self.L.tg_comm_create(self.device, self.world, self.rank, ctypes.cast(buf, ctypes.c_void_p))
+            if self._h:     # the banner is printed (buffered) during the first collective at the latest
+                self.L.tg_comm_barrier(self._h)
         if not self._h:
             raise _lib.LibraryError(self.L.tg_last_error().decode())
         self._bufs = {}
@@ -73,7 +96,8 @@ class Communicator(object):
     def new_unique_id():
         L = _lib.lib()
         buf = (ctypes.c_uint8 * ID_BYTES)()
-        _lib.check(L.tg_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+        with _stdout_to_stderr():
+            _lib.check(L.tg_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
         return bytes(buf)
 
     @classmethod

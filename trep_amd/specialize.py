@@ -1,0 +1,91 @@
+"""System-specialised rollout kernels: the schedule of one ``System`` compiled into the kernel.
+
+The generic kernels of ``libtrepamd.so`` interpret a flat schedule (``csrc/program.hpp``: ~110 integers and ~65 table
+pointers per system) at run time.  For the long rollouts of the benchmark configurations that is where a large share
+of the instructions goes: scalar registers cannot hold the schedule, so it is spilled into vector-register lanes and
+re-read (``v_readlane``) at every use, and every LDS address is computed from run-time offsets.  ``build(system)``
+asks the library for the specialisation header of the system (``tg_system_spec_header``: every integer a
+``static constexpr``, every table a constant array), compiles ``csrc/spec_kernel.hip`` -- the SAME template source as
+the generic kernel, instantiated on that header -- with hipcc for gfx950, and caches the result under
+``trep_amd/_spec/`` keyed by the hash of header and sources.  ``BatchMidpointVI.specialize()`` then makes the batch's
+rollouts use it.  Results are bit-identical to the generic kernel (same arithmetic, same order).
+
+hipcc runs as a child process and needs no GPU, so specialisations can be built ahead of time (``__graft_entry__.build``
+builds the BASELINE systems') and travel with the package; building on first use works too, as long as hipcc is there.
+"""
+import ctypes
+import hashlib
+import os
+import subprocess
+
+from . import _lib
+from .descriptor import flatten
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+CACHE = os.path.join(_HERE, "_spec")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+_SOURCES = ["spec_kernel.hip", "mvi_core.hpp", "program.hpp"]
+DEFAULT_FLAGS = "-DSPEC_ARGS_IN_MEMORY"
+
+
+def header(system):
+    """The generated C++ header for `system` (host-only: no GPU is touched)."""
+    L = _lib.lib()
+    desc = flatten(system)
+    h = L.tg_system_create(desc.byref())
+    if not h:
+        raise _lib.LibraryError(L.tg_last_error().decode())
+    try:
+        n = L.tg_system_spec_header(h, None, 0)
+        if n <= 0:
+            raise _lib.LibraryError(L.tg_last_error().decode())
+        buf = ctypes.create_string_buffer(int(n))
+        L.tg_system_spec_header(h, buf, n)
+        return buf.value.decode()
+    finally:
+        L.tg_system_destroy(h)
+
+
+def _flags():
+    """Extra compiler flags of the specialised kernel (TREPAMD_SPEC_FLAGS overrides; part of the cache key)."""
+    return os.environ.get("TREPAMD_SPEC_FLAGS", DEFAULT_FLAGS).split()
+
+
+def _key(text):
+    m = hashlib.sha256(text.encode())
+    m.update(" ".join(_flags()).encode())
+    for f in _SOURCES + [os.path.join("..", "..", "include", "trep_amd.h")]:
+        with open(os.path.join(_CSRC, f), "rb") as fh:
+            m.update(fh.read())
+    return m.hexdigest()[:16]
+
+
+def library_path(system):
+    text = header(system)
+    return os.path.join(CACHE, "libtrepamd_spec_%s.so" % _key(text)), text
+
+
+def build(system, force=False, verbose=False):
+    """Path of the specialised kernel library of `system`, compiling it if it is not cached."""
+    path, text = library_path(system)
+    if os.path.exists(path) and not force:
+        return path
+    os.makedirs(CACHE, exist_ok=True)
+    hdr = path[:-3] + ".hpp"
+    with open(hdr, "w") as fh:
+        fh.write(text)
+    tmp = path + ".tmp%d" % os.getpid()
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-I", _CSRC, '-DTG_SPEC_HEADER="%s"' % hdr] + _flags() + ["-o", tmp, os.path.join(_CSRC, "spec_kernel.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    if r.returncode != 0:
+        raise _lib.LibraryError("specialisation failed:\n" + r.stderr[-4000:])
+    os.replace(tmp, path)
+    return path
+
+
+def is_built(system):
+    return os.path.exists(library_path(system)[0])
