@@ -15,16 +15,41 @@ namespace {
 // SPEC_ARGS_IN_MEMORY: the launch arguments are read from device memory through a constant-address-space reference and
 // re-read at the head of every step, instead of ~50 scalar registers held (and spilled) for the whole rollout
 #if defined(SPEC_ARGS_IN_MEMORY)
-__global__ __launch_bounds__(64, 2) void k_spec_rollout(const tg::RunArgs *__restrict__ Ag) {
-    tg::KArgs &A = *(tg::KArgs *)Ag;
+#define SPEC_KERNEL_ARGS const tg::RunArgs *__restrict__ Ag
+#define SPEC_ARGS_REF tg::KArgs &A = *(tg::KArgs *)Ag
 #else
-__global__ __launch_bounds__(64, 2) void k_spec_rollout(const tg::RunArgs A) {
+#define SPEC_KERNEL_ARGS const tg::RunArgs A
+#define SPEC_ARGS_REF ((void)0)
 #endif
+
+template <int MODE>
+__global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z) ? 1 : 2) void k_spec(SPEC_KERNEL_ARGS) {
+    SPEC_ARGS_REF;
     extern __shared__ double lds[];
     const SpecProg P{};
     const int team = threadIdx.x / SPEC_TEAM, lane = threadIdx.x % SPEC_TEAM;
     const int traj = blockIdx.x * (64 / SPEC_TEAM) + team;
-    tg::run_trajectory<SPEC_TEAM, tg::MODE_ROLLOUT, SPEC_SPRINGS, const SpecProg>(P, A, lds + (size_t)team * SpecProg::lds_per_team, lane, traj);
+    constexpr int stride = MODE == tg::MODE_DERIV2Z ? SpecProg::e_lds_per_team : (MODE == tg::MODE_DERIV1 ? SpecProg::d_lds_per_team : SpecProg::lds_per_team);
+    tg::run_trajectory<SPEC_TEAM, MODE, SPEC_SPRINGS, const SpecProg>(P, A, lds + (size_t)team * stride, lane, traj);
+}
+
+template <int MODE>
+int launch_mode(const tg::RunArgs *A, int grid, size_t lds, hipStream_t stream) {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spec<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+#if defined(SPEC_ARGS_IN_MEMORY)
+    // a small ring of device-side argument blocks: a block is not reused before 16 later launches were issued (launches of one
+    // batch are stream ordered; the copy below is ordered with the launch on the same stream)
+    static tg::RunArgs *ring = nullptr;
+    static unsigned next = 0;
+    if (!ring && hipMalloc(&ring, 16 * sizeof(tg::RunArgs)) != hipSuccess) return 1;
+    tg::RunArgs *slot = ring + (next++ % 16);
+    if (hipMemcpyAsync(slot, A, sizeof(tg::RunArgs), hipMemcpyHostToDevice, stream) != hipSuccess) return 1;
+    hipLaunchKernelGGL(k_spec<MODE>, dim3(grid), dim3(64), lds, stream, (const tg::RunArgs *)slot);
+#else
+    hipLaunchKernelGGL(k_spec<MODE>, dim3(grid), dim3(64), lds, stream, *A);
+#endif
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 }  // namespace
 
@@ -34,21 +59,22 @@ const int *tg_spec_sizes(void) {
                              SpecProg::n_pairs, SpecProg::lds_per_team};
     return s;
 }
-int tg_spec_launch_rollout(const tg::DevProg *, const tg::RunArgs *A, int grid, size_t lds, void *stream) {
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spec_rollout), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-#if defined(SPEC_ARGS_IN_MEMORY)
-    // a small ring of device-side argument blocks: a launch's block is not reused before 16 later launches were issued on
-    // streams ordered with this one (launches of one batch are stream ordered anyway)
-    static tg::RunArgs *ring = nullptr;
-    static unsigned next = 0;
-    if (!ring && hipMalloc(&ring, 16 * sizeof(tg::RunArgs)) != hipSuccess) return 1;
-    tg::RunArgs *slot = ring + (next++ % 16);
-    if (hipMemcpyAsync(slot, A, sizeof(tg::RunArgs), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return 1;
-    hipLaunchKernelGGL(k_spec_rollout, dim3(grid), dim3(64), lds, (hipStream_t)stream, (const tg::RunArgs *)slot);
-#else
-    hipLaunchKernelGGL(k_spec_rollout, dim3(grid), dim3(64), lds, (hipStream_t)stream, *A);
+// bit m set: kernel mode m (tg::MODE_*) has a specialised instantiation in this library
+int tg_spec_modes(void) {
+    int m = 1 << tg::MODE_ROLLOUT;
+#if defined(SPEC_DERIVATIVES)
+    m |= (1 << tg::MODE_DERIV1) | (1 << tg::MODE_DERIV2Z);
 #endif
-    return hipGetLastError() == hipSuccess ? 0 : 1;
+    return m;
+}
+int tg_spec_launch(int mode, const tg::RunArgs *A, int grid, size_t lds, void *stream) {
+    switch (mode) {
+    case tg::MODE_ROLLOUT: return launch_mode<tg::MODE_ROLLOUT>(A, grid, lds, (hipStream_t)stream);
+#if defined(SPEC_DERIVATIVES)
+    case tg::MODE_DERIV1: return launch_mode<tg::MODE_DERIV1>(A, grid, lds, (hipStream_t)stream);
+    case tg::MODE_DERIV2Z: return launch_mode<tg::MODE_DERIV2Z>(A, grid, lds, (hipStream_t)stream);
+#endif
+    default: return 2;
+    }
 }
 }

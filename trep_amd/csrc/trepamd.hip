@@ -60,7 +60,8 @@ struct tg_batch {
     tg::DevProg *d_prog = nullptr;   // the same view in device memory: what the kernels read (constant address space)
     // optional system-specialised rollout kernel (tg_batch_load_specialized): launcher exported by a generated library
     void *spec_lib = nullptr;
-    int (*spec_launch)(const tg::DevProg *, const tg::RunArgs *, int, size_t, void *) = nullptr;
+    int (*spec_launch)(int, const tg::RunArgs *, int, size_t, void *) = nullptr;
+    int spec_modes = 0;
     int *d_ints = nullptr;
     double *d_dbls = nullptr;
     double *q1 = nullptr, *q2 = nullptr, *p1 = nullptr, *p2 = nullptr, *lam = nullptr, *u1 = nullptr;
@@ -205,8 +206,8 @@ int launch(tg_batch *b, tg::RunArgs &A) {
         if (hipEventRecord(e0, b->stream) != hipSuccess) { b->pool.push_back(e0); b->pool.push_back(e1); return fail(TG_ERR_HIP, "hipEventRecord failed"); }
     }
     int rc;
-    if (b->spec_launch && A.mode == tg::MODE_ROLLOUT) {
-        rc = b->spec_launch(b->d_prog, &A, grid, lds, (void *)b->stream) == 0 ? TG_SUCCESS : fail(TG_ERR_HIP, "specialised kernel launch failed");
+    if (b->spec_launch && ((b->spec_modes >> A.mode) & 1)) {
+        rc = b->spec_launch(A.mode, &A, grid, lds, (void *)b->stream) == 0 ? TG_SUCCESS : fail(TG_ERR_HIP, "specialised kernel launch failed");
     } else
     rc = team == 64 ? launch_team<64>(b, A, grid, lds) : (team == 16 ? launch_team<16>(b, A, grid, lds)
              : (team == 4 ? launch_team<4>(b, A, grid, lds) : launch_team<1>(b, A, grid, lds)));
@@ -881,15 +882,16 @@ int tg_batch_load_specialized(tg_batch *b, const char *library_path) {
     if (!b || !library_path) return fail(TG_ERR_INVALID, "null argument");
     void *h = dlopen(library_path, RTLD_NOW | RTLD_LOCAL);
     if (!h) return fail(TG_ERR_INVALID, std::string("cannot load ") + library_path + ": " + (dlerror() ? dlerror() : "?"));
-    auto launch_fn = reinterpret_cast<int (*)(const tg::DevProg *, const tg::RunArgs *, int, size_t, void *)>(dlsym(h, "tg_spec_launch_rollout"));
+    auto launch_fn = reinterpret_cast<int (*)(int, const tg::RunArgs *, int, size_t, void *)>(dlsym(h, "tg_spec_launch"));
     auto sizes_fn = reinterpret_cast<const int *(*)(void)>(dlsym(h, "tg_spec_sizes"));
-    if (!launch_fn || !sizes_fn) { dlclose(h); return fail(TG_ERR_INVALID, "not a specialised trep_amd kernel library"); }
+    auto modes_fn = reinterpret_cast<int (*)(void)>(dlsym(h, "tg_spec_modes"));
+    if (!launch_fn || !sizes_fn || !modes_fn) { dlclose(h); return fail(TG_ERR_INVALID, "not a specialised trep_amd kernel library"); }
     const tg::DevProg &P = b->P;
     const int want[8] = {(int)sizeof(tg::DevProg), (int)sizeof(tg::RunArgs), P.nq, P.nd, P.nc, P.n_items, P.n_pairs, P.lds_per_team};
     const int *got = sizes_fn();
     for (int i = 0; i < 8; i++) if (got[i] != want[i]) { dlclose(h); return fail(TG_ERR_INVALID, "specialised kernel was built for a different system or library version"); }
     if (b->spec_lib) dlclose(b->spec_lib);
-    b->spec_lib = h; b->spec_launch = launch_fn;
+    b->spec_lib = h; b->spec_launch = launch_fn; b->spec_modes = modes_fn();
     return TG_SUCCESS;
 }
 
