@@ -18,6 +18,45 @@ from .config import Config, Input
 from .frame import Frame, WORLD
 
 
+def dynamics_deriv2_from_deriv1(deriv1, q, dq, u, ddqk, step=1e-4):
+    """Second derivatives of the continuous dynamics from a batched evaluator of the analytic FIRST derivatives.
+
+    deriv1(Q [M][nq], dQ [M][nq], U [M][nu], ddK [M][nk]) -> {"f_dq": [M][nd][nq], "f_ddq", "f_dddk" [M][nd][nk], "f_du",
+    "lambda_dq" [M][nc][nq], ...} (BatchMidpointVI.dynamics_deriv1 without the status; the tests also drive it with the
+    oracle and the host emulation).  Fourth-order central differences over q, dq and u: M = 4 (2 nq + nu) states in one
+    call.  Returns the reference's fourteen arrays, [first variable][second variable][output] (system.py:982-1078)."""
+    q, dq, u, ddqk = (np.asarray(a, dtype=float) for a in (q, dq, u, ddqk))
+    nq, nu = len(q), len(u)
+    nv = 2 * nq + nu
+    x0 = np.concatenate([q, dq, u])
+    h = step * np.maximum(1.0, np.abs(x0))
+    X = np.repeat(x0[None], 4 * nv, axis=0)
+    for v in range(nv):
+        X[4 * v:4 * v + 4, v] += np.array([-2.0, -1.0, 1.0, 2.0]) * h[v]
+    d = deriv1(X[:, :nq], X[:, nq:2 * nq], X[:, 2 * nq:], np.repeat(ddqk[None], 4 * nv, axis=0))
+    w = np.array([1.0, -8.0, 8.0, -1.0]) / 12.0
+
+    def diff(name, lo, hi):
+        """d(name[output][var1]) / d x_v for v in [lo, hi): -> [var1][v][output]"""
+        a = np.asarray(d[name])
+        a = a.reshape(nv, 4, *a.shape[1:])[lo:hi]                              # [v][stencil][out][var1]
+        g = np.tensordot(a, w, axes=([1], [0])) / h[lo:hi, None, None]         # [v][out][var1]
+        return np.ascontiguousarray(np.transpose(g, (2, 0, 1)))
+    out = {}
+    for pre in ("f", "lambda"):
+        out[pre + "_dqdq"] = diff(pre + "_dq", 0, nq)
+        out[pre + "_ddqdq"] = diff(pre + "_ddq", 0, nq)
+        out[pre + "_ddqddq"] = diff(pre + "_ddq", nq, 2 * nq)
+        out[pre + "_dddkdq"] = diff(pre + "_dddk", 0, nq)
+        out[pre + "_dudq"] = diff(pre + "_du", 0, nq)
+        out[pre + "_duddq"] = diff(pre + "_du", nq, 2 * nq)
+        out[pre + "_dudu"] = diff(pre + "_du", 2 * nq, 2 * nq + nu)
+        for sym in ("_dqdq", "_ddqddq", "_dudu"):     # symmetric by construction in the reference (filled by symmetry)
+            a = out[pre + sym]
+            out[pre + sym] = 0.5 * (a + np.transpose(a, (1, 0, 2)))
+    return out
+
+
 class System(object):
     def __init__(self):
         self._dyn_configs = tuple()
@@ -448,6 +487,66 @@ class System(object):
     lambda_dddk = _dyn_d1_accessor("lambda_dddk", "c", "k")
     lambda_du = _dyn_d1_accessor("lambda_du", "c", "u")
     del _dyn_d1_accessor
+
+    # -- second derivatives of the continuous dynamics (system.py:982-1078; calc_dynamics_deriv2, system.c:1301-2029) ----
+    def _dynamics_deriv2(self):
+        """All fourteen second-derivative arrays of ddq = f(q, dq, u, ddq_k) and lambda at the current state, laid out
+        like the reference's ([first variable][second variable][output]).
+
+        The reference assembles them from fourth-order Lagrangian tables (M_dqdq is nq^4 entries).  Here they are the
+        derivatives of the ANALYTIC first-derivative arrays (MODE_DYN_DERIV1) with respect to q, dq and u, taken with
+        a fourth-order central difference: the 4 * (2 nq + nu) perturbed states form one batch, i.e. one launch of the
+        first-derivative kernel.  Truncation is O(h^4) with h = 1e-4 (relative to max(1, |x|)), round-off
+        eps |f'| / h: agreement with the reference is 1e-12 ... 3e-10 relative to each array's largest entry on the test
+        systems (tested at 1e-8).  An analytic kernel (nested brackets one order above deriv2z) is future work.
+        Systems with a LinearDamper: the reference's own f_ddqdq is inconsistent with its first derivatives there
+        (lineardamper.c:88 uses length_dq where length_dqdq is meant); these are the derivatives of the first derivatives."""
+        from .midpointvi import BatchMidpointVI
+        self._dynamics()                       # the reference's side effect on Config.ddq; builds the engine
+        nq, nd, nk, nu, nc = self.nQ, self.nQd, self.nQk, self.nu, self.nc
+        nv = 2 * nq + nu
+        eng = getattr(self, "_dyn2_engine", None)
+        if eng is None or self._dyn2_engine_version != self._structure_version or eng.batch != 4 * nv:
+            if eng is not None:
+                eng.close()
+            eng = self._dyn2_engine = BatchMidpointVI(self, 4 * nv)
+            self._dyn2_engine_version = self._structure_version
+        def deriv1(Q, dQ, U, ddK):
+            d, status = eng.dynamics_deriv1(Q, dQ, U, ddK)
+            if (status != 0).any():
+                raise ValueError("singular inertia or constraint matrix")
+            return d
+        return dynamics_deriv2_from_deriv1(deriv1, self.q, self.dq, self.u, self.ddqk)
+
+    def _dyn_d2_accessor(name, out_kind, kind1, kind2):
+        def pick(obj, kind):
+            if obj is None:
+                return slice(None)
+            if kind == "d":
+                assert not obj.kinematic
+                return obj.index
+            return obj.k_index if kind == "k" else obj.index
+        def accessor(self, out=None, var1=None, var2=None):
+            """[first variable][second variable][output] like the reference (system.py:982-1016, 1046-1078)."""
+            return np.array(self._dynamics_deriv2()[name][pick(var1, kind1), pick(var2, kind2), pick(out, out_kind)])
+        accessor.__name__ = name
+        return accessor
+
+    f_dqdq = _dyn_d2_accessor("f_dqdq", "d", "q", "q")
+    f_ddqdq = _dyn_d2_accessor("f_ddqdq", "d", "q", "q")
+    f_ddqddq = _dyn_d2_accessor("f_ddqddq", "d", "q", "q")
+    f_dddkdq = _dyn_d2_accessor("f_dddkdq", "d", "k", "q")
+    f_dudq = _dyn_d2_accessor("f_dudq", "d", "u", "q")
+    f_duddq = _dyn_d2_accessor("f_duddq", "d", "u", "q")
+    f_dudu = _dyn_d2_accessor("f_dudu", "d", "u", "u")
+    lambda_dqdq = _dyn_d2_accessor("lambda_dqdq", "c", "q", "q")
+    lambda_ddqdq = _dyn_d2_accessor("lambda_ddqdq", "c", "q", "q")
+    lambda_ddqddq = _dyn_d2_accessor("lambda_ddqddq", "c", "q", "q")
+    lambda_dddkdq = _dyn_d2_accessor("lambda_dddkdq", "c", "k", "q")
+    lambda_dudq = _dyn_d2_accessor("lambda_dudq", "c", "u", "q")
+    lambda_duddq = _dyn_d2_accessor("lambda_duddq", "c", "u", "q")
+    lambda_dudu = _dyn_d2_accessor("lambda_dudu", "c", "u", "u")
+    del _dyn_d2_accessor
 
     # -- numeric validators (system.py:1080-1203): func() -> float or array, func_d(config) -> its derivative -------
     def _test_derivative(self, attr, func, func_d, delta, tolerance, verbose, test_name):
