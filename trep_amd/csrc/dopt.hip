@@ -13,6 +13,7 @@
 // with the (blocking) streams of the tg_batch objects.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 
 #include "../../include/trep_amd.h"
@@ -33,6 +34,7 @@ using tg_detail::fail;
     } while (0)
 
 constexpr int LQ_T = 256;  // threads per workgroup of the sweep kernels
+constexpr int LQM_T = 512; // ... of the matrix-core sweep: two wavefronts per SIMD hide the 200-cycle latency of a dependent f64 MFMA
 
 // Diagnostic build only (-DTG_PROFILE): cycles per phase of the LQ sweep, workgroup 0 thread 0, read by tg_lq_profile.
 #if defined(TG_PROFILE)
@@ -323,6 +325,357 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
     if (a.status_dev && tid == 0) a.status_dev[s] = s_sing ? TG_SINGULAR : TG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The same sweep on the matrix cores.
+//
+// k_tv_lq above is bound by LDS latency: its products are register-tiled VALU loops (10 LDS reads per 25 FMAs) run by
+// ONE wavefront per SIMD (153 KB of LDS = one workgroup per CU), and its nU x nU solve is 18 barrier-separated LDS
+// passes: 206 k cycles per Riccati step for the 40-DOF puppet where the flops alone need about 20 k.  Here
+//   * every product -- P A, P B, B'(P B), B'(P A), A'(P A), Kpart' K -- is a chain of v_mfma_f64_16x16x4_f64 over
+//     16 x 16 output tiles (wave w owns tiles w, w+4, ...): two LDS reads feed 2048 flops instead of 5, and all
+//     operand reads are row segments of 16 consecutive doubles (P is symmetric, so P' rows serve as P columns;
+//     P B is stored instead of B'P for the same reason) -- no bank conflicts, no transposes;
+//   * the solve [C | K] = gamma^-1 [B'b + r | Kpart] runs in registers without a single barrier: each wavefront
+//     takes the nU columns of gamma plus its quarter of the 1 + nX right-hand-side columns, one column per lane,
+//     rows in registers; every wave repeats the (identical) pivot search on its own copy of gamma.  LAPACK's pivot
+//     rule (largest magnitude in the column, rows never move) as before.
+// Same arithmetic up to summation order; tests/test_gpu_discopt_device.py holds both kernels to the numpy sweep.
+// ------------------------------------------------------------------------------------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// One wavefront: Gauss-Jordan on [gamma | its slice of the right-hand sides], one column per lane, NR >= nU rows in
+// registers.  G [nU][ldw] = [gamma | rhs(1 + nX)] is only READ (every wave loads gamma and its own slice); solutions go
+// to Cs [nU] (rhs 0) and Ks [nU][ldx] (rhs 1 + j), in variable order.  scr: 3 * NR doubles of per-wave LDS scratch.
+template <int NR>
+__device__ __forceinline__ void lq_gj_wave(const double *G_generic, int ldw, int nU, int rhs_lo, int rhs_n, double *Ks_generic, int ldx,
+                                        double *Cs_generic, double *scr_generic, int lane, int *sing) {
+    typedef __attribute__((address_space(3))) double lds_double;
+    const lds_double *G = (const lds_double *)G_generic;
+    lds_double *Ks = (lds_double *)Ks_generic, *Cs = (lds_double *)Cs_generic, *colbuf = (lds_double *)scr_generic, *dinv = colbuf + NR;
+    __attribute__((address_space(3))) int *var = (__attribute__((address_space(3))) int *)(colbuf + 2 * NR);
+    const bool is_rhs = lane >= nU && lane < nU + rhs_n;
+    const int gcol = lane < nU ? lane : nU + rhs_lo + (lane - nU);       // column of G this lane holds
+    const bool have = lane < nU || is_rhs;
+    double a[NR];
+#pragma unroll
+    for (int i = 0; i < NR; i++) a[i] = (have && i < nU) ? G[i * ldw + gcol] : 0.0;
+    unsigned int used = 0u;
+    bool ok = true;
+    for (int k = 0; k < nU; k++) {
+        if (lane == k) {
+#pragma unroll
+            for (int i = 0; i < NR; i++) colbuf[i] = a[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        float mf = 0.0f;
+        if (lane < nU && !((used >> lane) & 1u)) mf = (float)fabs(colbuf[lane]);
+        const unsigned int key = __ockl_wfred_max_u32((__float_as_uint(mf) & ~0x3Fu) | (unsigned int)(63 - lane));
+        const int r = __builtin_amdgcn_readfirstlane(63 - (int)(key & 0x3Fu));
+        if (!(__uint_as_float(key & ~0x3Fu) > 0.0f)) ok = false;
+        used |= 1u << r;
+        // the whole pivot column in registers first (wave-uniform addresses: LDS broadcasts, all in flight together); a
+        // load inside a `(i == r) ? ... : ...` arm becomes a scalar branch with its own s_waitcnt per row
+        double cb[NR];
+#pragma unroll
+        for (int i = 0; i < NR; i++) cb[i] = colbuf[i];
+        // this lane's pivot-row entry and the pivot: r is wave-uniform but not a compile-time register index.  A chain of
+        // uniform branches picks them (a 0/1-weighted FMA sum would be NR dependent fp64 FMAs, ~30 cycles each)
+        double p = 0.0, piv = 1.0;
+#pragma unroll
+        for (int i = 0; i < NR; i++) if (i == r) { p = a[i]; piv = cb[i]; }
+        double inv = __builtin_amdgcn_rcp(piv);
+        inv = fma(inv, fma(-piv, inv, 1.0), inv);
+        inv = fma(inv, fma(-piv, inv, 1.0), inv);
+        if (lane == 0) { var[r] = k; dinv[r] = inv; }
+        const double q = ok ? -(inv * p) : 0.0;    // a_i <- a_i - (c_i / pivot) p for the other rows
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+            const double upd = fma(cb[i], q, a[i]);
+            a[i] = (i == r) ? a[i] : upd;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    if (!ok && lane == 0) *sing = 1;
+    if (is_rhs) {
+        const int g = rhs_lo + (lane - nU);
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+            if (i < nU) {
+                const int v = var[i];
+                const double x = a[i] * dinv[i];
+                if (g == 0) Cs[v] = x; else Ks[v * ldx + g - 1] = x;
+            }
+        }
+    }
+}
+
+struct LqLayout {   // LDS layout of k_tv_lq_mfma in doubles
+    int ldx, nUp, ldw, Pm, Am, Bm, Kp, Ks, G, bv, bn, wv, rv, scr, total;
+    __host__ __device__ LqLayout(int nX, int nU) {
+        ldx = round_up(nX, 16); nUp = round_up(nU, 4); ldw = nU + 1 + ldx;
+        int o = 0;
+        Pm = o; o += ldx * ldx; Am = o; o += ldx * ldx; Bm = o; o += ldx * nU;
+        Kp = o; o += nUp * ldx;
+        Ks = o; o += (nUp * ldx > ldx * nUp ? nUp * ldx : ldx * nUp);   // K_k [nUp][ldx]; before the solve: P B [ldx][nUp]
+        G = o; o += nU * ldw; bv = o; o += ldx; bn = o; o += ldx; wv = o; o += nUp; rv = o; o += nUp;
+        scr = o; o += 8 * 3 * 32;
+        total = o;
+    }
+};
+
+template <int NT, int NR>   // 16 x 16 tiles per dimension: nX <= 16 NT; rows of the input solve in registers: nU <= NR
+__global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
+    extern __shared__ double lds[];
+    __shared__ int s_sing;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int s = a.select_dev ? a.select_dev[blockIdx.x] : blockIdx.x;
+    const int nX = a.nX, nU = a.nU, N = a.horizon;
+    const LqLayout L(16 * NT, nU);
+    constexpr int ldx = 16 * NT, NTILES = NT * NT, NW = LQM_T / 64, TMAX = (NTILES + NW - 1) / NW;
+    const int nUp = L.nUp, ldw = L.ldw, NUT = (nU + 15) >> 4;
+    double *Pm = lds + L.Pm, *Am = lds + L.Am, *Bm = lds + L.Bm, *Kp = lds + L.Kp, *Ks = lds + L.Ks, *PB = Ks, *G = lds + L.G;
+    double *bv = lds + L.bv, *bn = lds + L.bn, *wv = lds + L.wv, *rv = lds + L.rv, *scr = lds + L.scr + wave * 3 * NR;
+    for (int i = tid; i < L.total; i += LQM_T) lds[i] = 0.0;
+    if (tid == 0) s_sing = 0;
+    __syncthreads();
+    const size_t sN = (size_t)s * N;
+    const bool affine = a.q_dev != nullptr;
+    const int nxh = a.hz_nx, hzR = a.hz_R;
+    {
+        const double *Qf = a.Qf_dev + (size_t)s * a.Qf_seed_stride;
+        for (int e = tid; e < nX * nX; e += LQM_T) Pm[(e / nX) * ldx + e % nX] = Qf[e];
+        if (affine) for (int i = tid; i < nX; i += LQM_T) bv[i] = a.q_dev[(sN + s + N) * nX + i];
+    }
+    // next A_k, B_k: global -> registers while the step computes -> LDS at its end (8 row groups x 32 columns per pass)
+    constexpr int RG = LQM_T / 32, RI = (ldx + RG - 1) / RG, CI = (ldx + 31) / 32, PBN = (ldx * 32 + LQM_T - 1) / LQM_T;
+    const int pr0 = tid >> 5, pc0 = tid & 31;   // LQM_T / 32 row groups x 32 columns per pass
+    double preA[RI * CI], preB[PBN];
+    auto prefetch = [&](int k) {
+        const double *Ak = a.A_dev + (sN + k) * (size_t)nX * nX, *Bk = a.B_dev + (sN + k) * (size_t)nX * nU;
+#pragma unroll
+        for (int ri = 0; ri < RI; ri++)
+#pragma unroll
+            for (int ci = 0; ci < CI; ci++) {
+                const int r = pr0 + RG * ri, c = pc0 + 32 * ci;
+                if (r < nX && c < nX) preA[ri * CI + ci] = Ak[r * nX + c];
+            }
+#pragma unroll
+        for (int i = 0; i < PBN; i++) { const int e = tid + i * LQM_T; if (e < nX * nU) preB[i] = Bk[e]; }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int ri = 0; ri < RI; ri++)
+#pragma unroll
+            for (int ci = 0; ci < CI; ci++) {
+                const int r = pr0 + RG * ri, c = pc0 + 32 * ci;
+                if (r < nX && c < nX) Am[r * ldx + c] = preA[ri * CI + ci];
+            }
+#pragma unroll
+        for (int i = 0; i < PBN; i++) { const int e = tid + i * LQM_T; if (e < nX * nU) Bm[e] = preB[i]; }
+    };
+    prefetch(N - 1);
+    commit();
+    __syncthreads();
+    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+    v4d acc[TMAX];
+    const int rhs_total = 1 + nX, slice = (rhs_total + NW - 1) / NW;
+#if defined(TG_PROFILE)
+    long long lq_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lq_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    for (int k = N - 1; k >= 0; k--) {
+        if (k > 0) prefetch(k - 1);
+        const double *hz = a.hz_dev ? a.hz_dev + (sN + k) * (size_t)hzR * hzR : nullptr;
+        // ---- phase 1: P A tiles (registers), P B -> LDS, B'b ---------------------------------------------------
+        // all tiles of the wave at once: TMAX independent accumulation chains (a dependent f64 MFMA issues every ~200 cycles,
+        // independent ones every ~64: tools/micro/mfma_f64_rate.hip)
+        {
+            int ti_[TMAX], tj_[TMAX];
+            bool ok_[TMAX];
+#pragma unroll
+            for (int i = 0; i < TMAX; i++) {
+                const int t = wave + NW * i;
+                ok_[i] = t < NTILES; ti_[i] = ok_[i] ? t / NT : 0; tj_[i] = ok_[i] ? t % NT : 0; acc[i] = zero4;
+            }
+#pragma unroll 2
+            for (int k0 = 0; k0 < ldx; k0 += 4) {
+                double av[TMAX], bw[TMAX];
+#pragma unroll
+                for (int i = 0; i < TMAX; i++) {
+                    av[i] = Pm[(k0 + lk) * ldx + 16 * ti_[i] + lr];      // P[i][k] = P[k][i]
+                    bw[i] = Am[(k0 + lk) * ldx + 16 * tj_[i] + lr];
+                }
+#pragma unroll
+                for (int i = 0; i < TMAX; i++) if (ok_[i]) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bw[i], acc[i], 0, 0, 0);
+            }
+        }
+        for (int t = wave; t < NT * NUT; t += NW) {
+            const int ti = t / NUT, tu = t % NUT, u = 16 * tu + lr;
+            v4d c = zero4;
+#pragma unroll 4
+            for (int k0 = 0; k0 < ldx; k0 += 4) {
+                const double av = Pm[(k0 + lk) * ldx + 16 * ti + lr];
+                const double bw = u < nU ? Bm[(k0 + lk) * nU + u] : 0.0;
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bw, c, 0, 0, 0);
+            }
+            if (u < nU) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) PB[(16 * ti + lk + 4 * r) * nUp + u] = c[r];
+            }
+        }
+        if (affine && tid < nU) {
+            double w = 0.0;
+            for (int i = 0; i < nX; i++) w += Bm[i * nU + tid] * bv[i];
+            wv[tid] = w;
+            rv[tid] = a.r_dev[(sN + k) * nU + tid];
+        }
+        __syncthreads();
+        LQ_STAMP(0);
+        // ---- phase 2a: P A -> LDS (over P) -------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < TMAX; i++) {
+            const int t = wave + NW * i;
+            if (t < NTILES) {
+                const int ti = t / NT, tj = t % NT;
+#pragma unroll
+                for (int r = 0; r < 4; r++) Pm[(16 * ti + lk + 4 * r) * ldx + 16 * tj + lr] = acc[i][r];
+            }
+        }
+        __syncthreads();
+        // ---- phase 2b: gamma = R + B'(P B), Kpart = B'(P A) + S' -> [gamma | r + B'b | Kpart] ------------------------
+        for (int t = wave; t < NUT * (NUT + NT); t += NW) {
+            const int tu = t / (NUT + NT), tc = t % (NUT + NT), u = 16 * tu + lr;
+            const bool is_gamma = tc < NUT;
+            const int tj = is_gamma ? tc : tc - NUT, col = 16 * tj + lr;
+            v4d c = zero4;
+#pragma unroll 4
+            for (int k0 = 0; k0 < ldx; k0 += 4) {
+                const double av = u < nU ? Bm[(k0 + lk) * nU + u] : 0.0;       // B'[u][k]
+                const double bw = is_gamma ? (col < nU ? PB[(k0 + lk) * nUp + col] : 0.0) : Pm[(k0 + lk) * ldx + col];
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bw, c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int uo = 16 * tu + lk + 4 * r;      // output row (input index u), column `col`
+                if (uo < nU) {
+                    if (is_gamma) {
+                        if (col < nU) {
+                            double g = c[r] + a.R_dev[(size_t)s * a.R_seed_stride + (size_t)k * a.R_step_stride + uo * nU + col];
+                            if (hz) g += hz[(size_t)(nxh + uo) * hzR + nxh + col];
+                            G[uo * ldw + col] = g;
+                        }
+                    } else {
+                        double v = c[r];
+                        if (hz && col < nxh) v += hz[(size_t)col * hzR + nxh + uo];
+                        Kp[uo * ldx + col] = v; G[uo * ldw + nU + 1 + col] = v;
+                    }
+                }
+            }
+        }
+        if (tid < nU) { const double rw = affine ? wv[tid] + rv[tid] : 0.0; rv[tid] = rw; G[tid * ldw + nU] = rw; }   // r_k + B'b
+        __syncthreads();
+        LQ_STAMP(1);
+        // ---- phase 3: [C | K] = gamma^-1 [. | .]: every wave its quarter of the right-hand sides, no barrier inside ------
+        {
+            const int lo = wave * slice, n = lo < rhs_total ? (rhs_total - lo < slice ? rhs_total - lo : slice) : 0;
+            lq_gj_wave<NR>(G, ldw, nU, lo, n, Ks, ldx, wv, scr, lane, &s_sing);
+        }
+        LQ_STAMP(6);
+        for (int o = tid; o < (nUp - nU) * ldx; o += LQM_T) Ks[nU * ldx + o] = 0.0;   // padding rows (the buffer held P B)
+        __syncthreads();
+        LQ_STAMP(2);
+        double *Cs = wv;
+        // ---- phase 4: outputs K_k, C_k; new P tiles = Q + A'(P A) - Kpart' K (registers); new b ----------------------
+        {
+            double *Ko = a.K_dev + (sN + k) * (size_t)nU * nX;
+            for (int o = tid; o < nU * nX; o += LQM_T) Ko[o] = Ks[(o / nX) * ldx + o % nX];
+            if (a.C_dev && tid < nU) a.C_dev[(sN + k) * nU + tid] = Cs[tid];
+        }
+        const double *Qk = a.Q_dev + (size_t)s * a.Q_seed_stride + (size_t)k * a.Q_step_stride;
+        {
+            int ti_[TMAX], tj_[TMAX];
+            bool ok_[TMAX];
+#pragma unroll
+            for (int i = 0; i < TMAX; i++) {
+                const int t = wave + NW * i;
+                ok_[i] = t < NTILES; ti_[i] = ok_[i] ? t / NT : 0; tj_[i] = ok_[i] ? t % NT : 0;
+                // the weights Q_k (+ curvature) first: their global-memory latency hides behind the MFMA chains
+                v4d c = zero4;
+                const int col = 16 * tj_[i] + lr;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = 16 * ti_[i] + lk + 4 * r;
+                    if (ok_[i] && row < nX && col < nX) {
+                        c[r] = Qk[(size_t)row * nX + col];
+                        if (hz && row < nxh && col < nxh) c[r] += hz[(size_t)row * hzR + col];
+                    }
+                }
+                acc[i] = c;
+            }
+#pragma unroll 2
+            for (int k0 = 0; k0 < ldx; k0 += 4) {
+                double av[TMAX], bw[TMAX];
+#pragma unroll
+                for (int i = 0; i < TMAX; i++) {
+                    av[i] = Am[(k0 + lk) * ldx + 16 * ti_[i] + lr];      // A'[i][k] = A[k][i]
+                    bw[i] = Pm[(k0 + lk) * ldx + 16 * tj_[i] + lr];      // (P A)[k][j]
+                }
+#pragma unroll
+                for (int i = 0; i < TMAX; i++) if (ok_[i]) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bw[i], acc[i], 0, 0, 0);
+            }
+            for (int u0 = 0; u0 < nUp; u0 += 4) {
+                double av[TMAX], bw[TMAX];
+#pragma unroll
+                for (int i = 0; i < TMAX; i++) {
+                    av[i] = -Kp[(u0 + lk) * ldx + 16 * ti_[i] + lr];     // -Kpart'[i][u]
+                    bw[i] = Ks[(u0 + lk) * ldx + 16 * tj_[i] + lr];
+                }
+#pragma unroll
+                for (int i = 0; i < TMAX; i++) if (ok_[i]) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bw[i], acc[i], 0, 0, 0);
+            }
+        }
+        if (affine) for (int i = tid; i < nX; i += LQM_T) {
+            double v = a.q_dev[(sN + s + k) * nX + i];
+            for (int m = 0; m < nX; m++) v += Am[m * ldx + i] * bv[m];
+            for (int u = 0; u < nU; u++) v -= Ks[u * ldx + i] * rv[u];
+            bn[i] = v;
+        }
+        __syncthreads();
+        LQ_STAMP(3);
+        // ---- phase 5: P <- new tiles, b <- new b, next A, B into LDS ---------------------------------------------
+#pragma unroll
+        for (int i = 0; i < TMAX; i++) {
+            const int t = wave + NW * i;
+            if (t < NTILES) {
+                const int ti = t / NT, tj = t % NT;
+#pragma unroll
+                for (int r = 0; r < 4; r++) Pm[(16 * ti + lk + 4 * r) * ldx + 16 * tj + lr] = acc[i][r];
+            }
+        }
+        if (affine) for (int i = tid; i < nX; i += LQM_T) bv[i] = bn[i];
+        if (k > 0) commit();
+        __syncthreads();
+        LQ_STAMP(4);
+        // ---- phase 6: P <- (P + P')/2 ---------------------------------------------------------------------------
+        // along diagonals: (i, i + d) and (i + d, i) are both strided by ldx + 1 doubles over the lanes (no bank conflicts; a
+        // row-wise pass reads the transposed element with stride ldx = 16-way conflicts)
+        for (int d = 1 + wave; d < nX; d += NW)
+            for (int i = lane; i < nX - d; i += 64) {
+                const double v = 0.5 * (Pm[i * ldx + i + d] + Pm[(i + d) * ldx + i]);
+                Pm[i * ldx + i + d] = v; Pm[(i + d) * ldx + i] = v;
+            }
+        __syncthreads();
+        LQ_STAMP(5);
+    }
+#if defined(TG_PROFILE)
+    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 8; i++) g_lq_prof[i] = lq_acc[i];
+#endif
+    if (a.P0_dev) for (int e = tid; e < nX * nX; e += LQM_T) a.P0_dev[(size_t)s * nX * nX + e] = Pm[(e / nX) * ldx + e % nX];
+    if (a.b0_dev && affine) for (int i = tid; i < nX; i += LQM_T) a.b0_dev[(size_t)s * nX + i] = bv[i];
+    if (a.status_dev && tid == 0) a.status_dev[s] = s_sing ? TG_SINGULAR : TG_OK;
+}
+
 size_t lq_lds_bytes(int nX, int nU, int ts) {
     const int ldx = round_up(nX, ts), ldw = nU + 1 + ldx;
     return sizeof(double) * ((size_t)2 * ldx * ldx + (size_t)ldx * nU + 2 * (size_t)nU * ldx + (size_t)nU * ldw + 2 * ldx + 3 * nU);
@@ -589,12 +942,50 @@ int tg_tv_lq(int32_t device, const tg_lq_problem *p) {
     if (p->nU > 64) return fail(TG_ERR_UNSUPPORTED, "more than 64 inputs");
     // size class: tile size TS with nX <= 16*TS (one tile per thread), prefetch registers RI*CI >= nX*ceil(nX/32)/8
     const int nX = p->nX, nXU = p->nX * p->nU;
+    HIP_TRY(hipSetDevice(device));
+    // matrix-core sweep (k_tv_lq_mfma) whenever it fits: nX <= 96, nU <= 32, LDS; TREPAMD_LQ_LEGACY=1 keeps the VALU kernel
+    {
+        const LqLayout L(p->nX, p->nU);
+        const size_t lds2 = sizeof(double) * (size_t)L.total;
+        const char *legacy = std::getenv("TREPAMD_LQ_LEGACY");
+        if (!(legacy && legacy[0] == '1') && nX <= 96 && p->nU <= 32 && 1 + nX <= 8 * (64 - p->nU) && lds2 <= 160 * 1024 - 256) {
+            // instantiated size classes: nX <= 16, 32, 48, 80, 96 (tiles per dimension 1, 2, 3, 5, 6) x nU <= 4, 8, 20, 32
+            const int nt = nX <= 16 ? 1 : (nX <= 32 ? 2 : (nX <= 48 ? 3 : (nX <= 80 ? 5 : 6)));
+            const int nr = p->nU <= 4 ? 4 : (p->nU <= 8 ? 8 : (p->nU <= 20 ? 20 : 32));
+            const LqLayout L2(16 * nt, p->nU);   // the kernel pads nX to 16 * nt
+            const size_t ldsk = sizeof(double) * (size_t)L2.total;
+            if (ldsk <= 160 * 1024 - 256) {
+#define TG_LQ_LAUNCH(NT_, NR_)                                                                                                   \
+                do {                                                                                                             \
+                    if (ldsk > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_tv_lq_mfma<NT_, NR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsk)); \
+                    hipLaunchKernelGGL((k_tv_lq_mfma<NT_, NR_>), dim3(p->n_problems), dim3(LQM_T), ldsk, 0, *p);                   \
+                } while (0)
+#define TG_LQ_NR(NT_)                                                                                                            \
+                switch (nr) {                                                                                                    \
+                case 4: TG_LQ_LAUNCH(NT_, 4); break;                                                                             \
+                case 8: TG_LQ_LAUNCH(NT_, 8); break;                                                                             \
+                case 20: TG_LQ_LAUNCH(NT_, 20); break;                                                                           \
+                default: TG_LQ_LAUNCH(NT_, 32); break;                                                                           \
+                }
+                switch (nt) {
+                case 1: TG_LQ_NR(1) break;
+                case 2: TG_LQ_NR(2) break;
+                case 3: TG_LQ_NR(3) break;
+                case 5: TG_LQ_NR(5) break;
+                default: TG_LQ_NR(6) break;
+                }
+#undef TG_LQ_NR
+#undef TG_LQ_LAUNCH
+                HIP_TRY(hipGetLastError());
+                return TG_SUCCESS;
+            }
+        }
+    }
     const int cls = (nX <= 32 && nXU <= 2 * LQ_T) ? 0 : ((nX <= 64 && nXU <= 6 * LQ_T) ? 1 : ((nX <= 80 && nXU <= 8 * LQ_T) ? 2 : ((nX <= 96 && nXU <= 12 * LQ_T) ? 3 : -1)));
     if (cls < 0) return fail(TG_ERR_UNSUPPORTED, "state dimension too large for the LDS-resident Riccati kernel");
     const int ts = cls == 0 ? 2 : (cls == 1 ? 4 : (cls == 2 ? 5 : 6));
     const size_t lds = lq_lds_bytes(p->nX, p->nU, ts);
     if (lds > 160 * 1024 - 64) return fail(TG_ERR_UNSUPPORTED, "state dimension too large for the LDS-resident Riccati kernel");
-    HIP_TRY(hipSetDevice(device));
     const void *fn = cls == 0 ? (const void *)k_tv_lq<2, 4, 1, 2> : (cls == 1 ? (const void *)k_tv_lq<4, 8, 2, 6>
                      : (cls == 2 ? (const void *)k_tv_lq<5, 10, 3, 8> : (const void *)k_tv_lq<6, 12, 3, 12>));
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
