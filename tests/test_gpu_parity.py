@@ -604,3 +604,72 @@ def test_specialised_kernel_matches_generic_and_reference(name):
     for X, _ in out:
         assert relerr(X[0][:, :nq], g[prefix + "Q"][:N + 1]) < TOL
         assert np.array_equal(X[0], X[2])
+
+
+def _oracle_lu(A, b):
+    import ctypes
+    from oracle import oracle as O
+    L = O.lib()
+    n = len(b)
+    A = np.ascontiguousarray(A, dtype=float); b = np.ascontiguousarray(b, dtype=float)
+    x = np.zeros(n); idx = np.zeros(n, dtype=np.int32)
+    L.to_debug_lu.restype = ctypes.c_int
+    rc = L.to_debug_lu(ctypes.c_int(n), A.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
+                       x.ctypes.data_as(ctypes.c_void_p), idx.ctypes.data_as(ctypes.c_void_p))
+    return rc, x, idx
+
+
+def _device_solve(A, b):
+    import ctypes
+    from trep_amd import _lib
+    L = _lib.lib()
+    n = len(b)
+    aug = np.ascontiguousarray(np.hstack([A, b[:, None]]), dtype=float)
+    x = np.zeros(n); piv = np.zeros(n, dtype=np.int32); st = np.zeros(1, dtype=np.int32)
+    _lib.check(L.tg_debug_solve(0, n, aug.ctypes.data, x.ctypes.data, piv.ctypes.data, st.ctypes.data))
+    return int(st[0]), x, piv
+
+
+def test_newton_solver_pivot_rule_matches_reference_lu():
+    """The register Gauss-Jordan of the rollout kernels against the reference's LU_decomp (math-code.c:337-432, restated in
+    the oracle): same pivot ROW for every column -- on random matrices, on matrices with near ties (scaled candidates
+    within 1e-9 relative: below the resolution of the single-precision ranking key), on exact ties (mirror-symmetric rows,
+    where the reference's strict `>` scan keeps the first row in its current, swapped, order) -- and the same singular /
+    non-singular verdict around the 1e-20 threshold on the scaled pivot."""
+    rng = np.random.default_rng(7)
+    cases = []
+    for n in (3, 7, 12, 22, 28, 32):
+        cases.append(rng.standard_normal((n, n)))
+        # near ties: pairs of rows that differ by 1e-9 relative in the pivot column after scaling
+        A = rng.standard_normal((n, n))
+        A[1] = A[0] * (1.0 + 1e-9 * rng.standard_normal(n)); A[1, 0] = A[0, 0] * (1.0 - 3e-10)
+        if n > 4:
+            A[4] = A[3] * (1.0 + 1e-9 * rng.standard_normal(n)); A[4, 1] = A[3, 1] * (1.0 + 2e-10)
+        A += 1e-3 * rng.standard_normal((n, n)) * (np.arange(n)[:, None] > 4)
+        cases.append(A)
+        # exact ties: integer-valued mirror-symmetric blocks (all scaled candidates of the first columns are equal)
+        A = rng.integers(-3, 4, (n, n)).astype(float) + 4.0 * np.eye(n)
+        A[:, 0] = 4.0 * np.where(np.arange(n) % 2 == 0, 1.0, -1.0); A[np.arange(n), np.arange(n)] = 4.0
+        A = np.where(np.abs(A) > 4.0, 4.0, A)        # every row has max |a_ij| = 4: equal scale factors, exact ties in column 0
+        cases.append(A)
+    checked_ties = 0
+    for A in cases:
+        n = len(A)
+        b = rng.standard_normal(n)
+        rc, xo, idx = _oracle_lu(A, b)
+        st, xd, piv = _device_solve(A, b)
+        if rc != 0:
+            assert st == 2
+            continue
+        assert st == 0
+        assert np.array_equal(piv, idx), (n, piv, idx)
+        assert relerr(xd, xo) < 1e-9 * max(1.0, np.linalg.cond(A) * 1e-6)
+        checked_ties += 1
+    assert checked_ties >= 12
+    # singular verdict: a matrix whose last scaled pivot is ~1e-21 (singular for the reference) and one at ~1e-19 (regular)
+    for eps, singular in ((1e-21, True), (1e-19, False)):
+        A = np.eye(5); A[4, 4] = eps; A[4, 0] = 1.0; A[0, 4] = 0.0
+        b = np.ones(5)
+        rc, xo, idx = _oracle_lu(A, b)
+        st, xd, piv = _device_solve(A, b)
+        assert (rc != 0) == singular and (st == 2) == singular, (eps, rc, st)

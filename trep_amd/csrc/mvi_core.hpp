@@ -892,12 +892,16 @@ struct Core {
     //      compile-time constant and the body carries no guards.
     //      Reads [A | rhs(1 column)] from LDS, leaves x in A[i*ld + n] like gauss_jordan().
     template <int N>
-    static __device__ __noinline__ bool gj_rows(bool on, double *A_generic, int n, int ld, int lane) {
+    static __device__ __noinline__ bool gj_rows(bool on, double *A_generic, int n, int ld, int lane, int *trace = nullptr) {
         typedef __attribute__((address_space(3))) double lds_double;
         lds_double *A = (lds_double *)A_generic;
         double row[N], rhs = 0.0, scale = 0.0, diag = 1.0;
         int mycol = -1;
+        // position of this lane's row in the reference's row order (math-code.c swaps rows physically; here rows never move):
+        // only needed to break EXACT ties the way the reference's strict `>` scan does -- first row in its current order
+        int pos = lane;
         const bool mine = on && lane < N;
+        const int wl = (int)(threadIdx.x & 63u), team_base = wl - lane;
 #pragma unroll
         for (int j = 0; j < N; j++)
             row[j] = (mine && lane < n && j < n) ? A[lane * ld + j] : ((mine && lane >= n && j == lane) ? 1.0 : 0.0);
@@ -911,11 +915,15 @@ struct Core {
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            // arg-max of |a_ik| * scale_i over the rows not yet used as pivots; the magnitude only ranks
-            // candidates, so single precision is plenty: one 32-bit wave max carries the lane index in the
-            // 6 low mantissa bits
-            const float cand = (mine && mycol < 0) ? (float)fabs(row[k] * scale) : 0.0f;
-            unsigned int key = (__float_as_uint(cand) & ~0x3Fu) | (unsigned int)(63 - (lane & 63));
+            // arg-max of |a_ik| * scale_i over the rows not yet used as pivots.  Fast path: the candidates are ranked in single
+            // precision with the 6 low mantissa bits replaced by the lane (one 32-bit wave max); the cast and the mask are
+            // monotonic, so a UNIQUE truncated maximum is the exact fp64 maximum.  If several candidates share it (within
+            // 2^-17 relative, or exactly equal -- mirror-symmetric mechanisms do that), the slow path below compares the
+            // doubles exactly and takes, among exactly equal ones, the row that comes first in the reference's row order.
+            const bool cand_ok = mine && mycol < 0;
+            const double cand64 = cand_ok ? fabs(row[k] * scale) : 0.0;
+            const unsigned int tkey = __float_as_uint((float)cand64) & ~0x3Fu;
+            unsigned int key = tkey | (unsigned int)(63 - (lane & 63));
             if (TEAM == 64) {
                 key = __ockl_wfred_max_u32(key);
             } else {
@@ -926,12 +934,43 @@ struct Core {
                 }
             }
             int piv = 63 - (int)(key & 0x3Fu);
-            const float best = __uint_as_float(key & ~0x3Fu);
             if (TEAM != 64) piv = (piv & (TEAM - 1));
-            if (on && ok && !(best > 1.0e-20f)) ok = false;
+            const unsigned long long team_mask = TEAM == 64 ? ~0ull : (((1ull << TEAM) - 1ull) << team_base);
+            const unsigned long long tied = __ballot(cand_ok && tkey == (key & ~0x3Fu)) & team_mask;
+            const bool multi = (tied & (tied - 1ull)) != 0ull;
+            if (__any(multi ? 1 : 0)) {      // wave-uniform: some team has more than one candidate at the truncated maximum
+                // exact maximum of the doubles (non-negative: their bit patterns order like the values) ...
+                unsigned long long best = cand_ok ? (unsigned long long)__double_as_longlong(cand64) : 0ull;
+                if (TEAM == 64) {
+                    best = __ockl_wfred_max_u64(best);
+                } else {
+#pragma unroll
+                    for (int m = TEAM / 2; m >= 1; m >>= 1) {
+                        const unsigned long long o = __shfl_xor(best, m, TEAM);
+                        best = o > best ? o : best;
+                    }
+                }
+                // ... and among the rows that attain it the first one in the reference's order (smallest position)
+                const bool at_max = cand_ok && (unsigned long long)__double_as_longlong(cand64) == best;
+                unsigned int k2 = at_max ? ((unsigned int)(63 - pos) << 6) | (unsigned int)(lane & 63) : 0u;
+                if (TEAM == 64) {
+                    k2 = __ockl_wfred_max_u32(k2);
+                } else {
+#pragma unroll
+                    for (int m = TEAM / 2; m >= 1; m >>= 1) {
+                        const unsigned int o = __shfl_xor(k2, m, TEAM);
+                        k2 = o > k2 ? o : k2;
+                    }
+                }
+                piv = (int)(k2 & 0x3Fu);
+                if (TEAM != 64) piv = (piv & (TEAM - 1));
+            }
+            // singular test on the winner's exact value (math-code.c:393: scaled pivot <= 1e-20)
+            const unsigned long long big = __ballot(cand64 > 1.0e-20);
+            const int src = (TEAM == 64) ? __builtin_amdgcn_readfirstlane(piv) : piv;
+            if (on && ok && !((big >> (team_base + src)) & 1ull)) ok = false;
             const bool go = on && ok;
             // broadcast the pivot row (columns k..N-1 and the rhs)
-            const int src = (TEAM == 64) ? __builtin_amdgcn_readfirstlane(piv) : piv;
             auto bcast = [&](double v) -> double {
                 if (TEAM == 64) {
                     const long long b = __double_as_longlong(v);
@@ -944,6 +983,13 @@ struct Core {
             const double pkk = bcast(row[k]);
             const double prhs = bcast(rhs);
             const bool is_piv = mine && (lane & (TEAM - 1)) == src;
+            // bookkeeping of the reference's row order: it swaps the pivot row with the row at position k
+            {
+                const int pos_p = (TEAM == 64) ? __builtin_amdgcn_readlane(pos, src) : __shfl(pos, src, TEAM);
+                if (pos == k) pos = pos_p;
+                if (is_piv) pos = k;
+            }
+            if (trace && go && is_piv) trace[k] = lane;
             // 1/pivot: hardware seed + two Newton steps (the multipliers need not be correctly rounded)
             double rp = __builtin_amdgcn_rcp(pkk);
             rp = fma(rp, fma(-pkk, rp, 1.0), rp);

@@ -283,6 +283,32 @@ __global__ void k_init_from_X(const tg::DevProg P, const double *X, size_t strid
     for (int i = threadIdx.x; i < P.nc; i += blockDim.x) lam[t * P.nc + i] = 0.0;
 }
 
+// Test hook: the Newton-system solver of the rollout kernels (gj_rows) on a caller-supplied matrix, with its pivot order.
+__global__ void k_debug_solve(int n, int ld, const double *A_in, double *x_out, int *piv_out, int *status_out) {
+#if defined(__HIP_DEVICE_COMPILE__)   // gj_rows exists in the device pass only
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    int *trace = (int *)(lds + n * ld);
+    for (int e = lane; e < n * (n + 1); e += 64) lds[(e / (n + 1)) * ld + e % (n + 1)] = A_in[e];
+    if (lane < 32) trace[lane] = -1;
+    __syncthreads();
+    bool ok = true;
+    switch ((n + 3) >> 2) {
+    case 1: ok = tg::Core<64>::gj_rows<4>(true, lds, n, ld, lane, trace); break;
+    case 2: ok = tg::Core<64>::gj_rows<8>(true, lds, n, ld, lane, trace); break;
+    case 3: ok = tg::Core<64>::gj_rows<12>(true, lds, n, ld, lane, trace); break;
+    case 4: ok = tg::Core<64>::gj_rows<16>(true, lds, n, ld, lane, trace); break;
+    case 5: ok = tg::Core<64>::gj_rows<20>(true, lds, n, ld, lane, trace); break;
+    case 6: ok = tg::Core<64>::gj_rows<24>(true, lds, n, ld, lane, trace); break;
+    case 7: ok = tg::Core<64>::gj_rows<28>(true, lds, n, ld, lane, trace); break;
+    default: ok = tg::Core<64>::gj_rows<32>(true, lds, n, ld, lane, trace); break;
+    }
+    __syncthreads();
+    if (lane < n) { x_out[lane] = lds[lane * ld + n]; piv_out[lane] = trace[lane]; }
+    if (lane == 0) *status_out = ok ? TG_OK : TG_SINGULAR;
+#endif
+}
+
 }  // namespace
 
 namespace tg_detail {
@@ -857,6 +883,26 @@ int tg_batch_set_stream(tg_batch *b, void *hip_stream) {
     if (b->own_stream && b->stream) HIP_TRY(hipStreamDestroy(b->stream));
     if (hip_stream) { b->stream = (hipStream_t)hip_stream; b->own_stream = false; }
     else { HIP_TRY(hipStreamCreate(&b->stream)); b->own_stream = true; }
+    return TG_SUCCESS;
+}
+
+/* Test hook (tests/test_gpu_parity.py): solves the n x n system [A | b] (row-major [n][n+1], n <= 32) with the register
+ * Gauss-Jordan of the rollout kernels and reports which original row was the pivot of each column: the reference's
+ * LU_decomp (math-code.c:337-432, implicit scaling, strict `>` scan) must pick the same rows, ties included. */
+int tg_debug_solve(int32_t device, int32_t n, const double *A_aug_host, double *x_host, int32_t *pivot_rows_host, int32_t *status_host) {
+    if (n <= 0 || n > 32 || !A_aug_host || !x_host || !pivot_rows_host || !status_host) return fail(TG_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    double *dA = nullptr, *dx = nullptr; int *dp = nullptr, *ds = nullptr;
+    const int ld = (n + 1) | 1;
+    HIP_TRY(hipMalloc(&dA, sizeof(double) * n * (n + 1))); HIP_TRY(hipMalloc(&dx, sizeof(double) * n));
+    HIP_TRY(hipMalloc(&dp, sizeof(int) * n)); HIP_TRY(hipMalloc(&ds, sizeof(int)));
+    HIP_TRY(hipMemcpy(dA, A_aug_host, sizeof(double) * n * (n + 1), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_solve, dim3(1), dim3(64), sizeof(double) * n * ld + sizeof(int) * 32, 0, n, ld, dA, dx, dp, ds);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(x_host, dx, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pivot_rows_host, dp, sizeof(int) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(status_host, ds, sizeof(int), hipMemcpyDeviceToHost));
+    hipFree(dA); hipFree(dx); hipFree(dp); hipFree(ds);
     return TG_SUCCESS;
 }
 
