@@ -236,12 +236,18 @@ int tg_memcpy_d2h(int32_t device, void *dst_host, const void *src_dev, uint64_t 
 int tg_batch_synchronize(tg_batch *b);
 /* Use an externally created hipStream_t (e.g. torch's current stream); NULL = own stream. */
 int tg_batch_set_stream(tg_batch *b, void *hip_stream);
-/* Test hook for the Newton-system solver of the rollout kernels (replaces LU_decomp + LU_solve_vec, math-code.c:337-461, as
- * used by MidpointVI_solve_DEL, midpointvi.c:720-733): solves [A | b] (row-major [n][n+1], n <= 32) on the device and
- * reports, per column, which original row served as pivot.  The reference's rule -- implicit row scaling, first maximum
- * of a strict `>` scan over its (physically swapped) rows, singular if the scaled pivot is <= 1e-20 -- must be matched
- * exactly, ties included.  status: TG_OK or TG_SINGULAR. */
-int tg_debug_solve(int32_t device, int32_t n, const double *A_aug_host, double *x_host, int32_t *pivot_rows_host, int32_t *status_host);
+/* Pivot rule of the Newton-system solve (replaces LU_decomp + LU_solve_vec, math-code.c:337-461, as used by
+ * MidpointVI_solve_DEL, midpointvi.c:720-733).  Both settings are Gauss-Jordan with implicit row scaling and partial
+ * pivoting over the rows not used yet, singular if the scaled pivot is <= 1e-20:
+ *   exact = 0 (default): candidates are ranked in single precision (one 32-bit wave max per step); candidates within
+ *       2^-17 relative of each other are taken in row order.  Fast; the solution agrees with the reference's to rounding.
+ *   exact = 1: the reference's rule bit for bit -- fp64 comparison, ties to the first row of its (swapped) row order,
+ *       exact singular test -- i.e. the same pivot ROW for every column, also where candidates differ by one ulp
+ *       (every row's largest entry scales to 1 +- 1 ulp, so that happens in most puppet solves).  About 9 % slower.
+ * tg_debug_solve (test hook) solves [A | b] (row-major [n][n+1], n <= 32) with either rule and reports which original row
+ * served as pivot of each column; status TG_OK or TG_SINGULAR. */
+int tg_batch_set_pivot_rule(tg_batch *b, int32_t exact);
+int tg_debug_solve(int32_t device, int32_t n, int32_t exact, const double *A_aug_host, double *x_host, int32_t *pivot_rows_host, int32_t *status_host);
 
 /* System-specialised rollout kernel.  The reference interprets the frame tree at run time; the generic kernels here
  * interpret a flat schedule.  For long rollouts of one system the schedule can instead be compiled into the kernel:

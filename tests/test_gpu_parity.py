@@ -619,57 +619,119 @@ def _oracle_lu(A, b):
     return rc, x, idx
 
 
-def _device_solve(A, b):
+def _device_solve(A, b, exact):
     import ctypes
     from trep_amd import _lib
     L = _lib.lib()
     n = len(b)
     aug = np.ascontiguousarray(np.hstack([A, b[:, None]]), dtype=float)
     x = np.zeros(n); piv = np.zeros(n, dtype=np.int32); st = np.zeros(1, dtype=np.int32)
-    _lib.check(L.tg_debug_solve(0, n, aug.ctypes.data, x.ctypes.data, piv.ctypes.data, st.ctypes.data))
+    _lib.check(L.tg_debug_solve(0, n, 1 if exact else 0, aug.ctypes.data, x.ctypes.data, piv.ctypes.data, st.ctypes.data))
     return int(st[0]), x, piv
 
 
-def test_newton_solver_pivot_rule_matches_reference_lu():
-    """The register Gauss-Jordan of the rollout kernels against the reference's LU_decomp (math-code.c:337-432, restated in
-    the oracle): same pivot ROW for every column -- on random matrices, on matrices with near ties (scaled candidates
-    within 1e-9 relative: below the resolution of the single-precision ranking key), on exact ties (mirror-symmetric rows,
-    where the reference's strict `>` scan keeps the first row in its current, swapped, order) -- and the same singular /
-    non-singular verdict around the 1e-20 threshold on the scaled pivot."""
-    rng = np.random.default_rng(7)
-    cases = []
+def _pivot_cases(rng):
+    out = []
     for n in (3, 7, 12, 22, 28, 32):
-        cases.append(rng.standard_normal((n, n)))
-        # near ties: pairs of rows that differ by 1e-9 relative in the pivot column after scaling
+        out.append(("random", rng.standard_normal((n, n))))
+        # near ties: pairs of rows that differ by ~1e-9 relative in the pivot column after scaling
         A = rng.standard_normal((n, n))
         A[1] = A[0] * (1.0 + 1e-9 * rng.standard_normal(n)); A[1, 0] = A[0, 0] * (1.0 - 3e-10)
         if n > 4:
             A[4] = A[3] * (1.0 + 1e-9 * rng.standard_normal(n)); A[4, 1] = A[3, 1] * (1.0 + 2e-10)
         A += 1e-3 * rng.standard_normal((n, n)) * (np.arange(n)[:, None] > 4)
-        cases.append(A)
-        # exact ties: integer-valued mirror-symmetric blocks (all scaled candidates of the first columns are equal)
+        out.append(("near ties", A))
+        # exact ties: integer-valued rows with equal scale factors and equal magnitudes in the first column
         A = rng.integers(-3, 4, (n, n)).astype(float) + 4.0 * np.eye(n)
         A[:, 0] = 4.0 * np.where(np.arange(n) % 2 == 0, 1.0, -1.0); A[np.arange(n), np.arange(n)] = 4.0
-        A = np.where(np.abs(A) > 4.0, 4.0, A)        # every row has max |a_ij| = 4: equal scale factors, exact ties in column 0
-        cases.append(A)
-    checked_ties = 0
-    for A in cases:
+        out.append(("exact ties", np.where(np.abs(A) > 4.0, 4.0, A)))
+        # the structural case of the Newton systems: rows whose largest entries share a column scale to 1 +- 1 ulp
+        A = rng.standard_normal((n, n))
+        A[:, 0] = 10.0 * (1.0 + rng.random(n))
+        out.append(("row maxima in one column", A))
+    return out
+
+
+def test_newton_solver_exact_pivot_rule_matches_reference_lu():
+    """gj_rows_exact (tg_batch_set_pivot_rule(b, 1)) against the reference's LU_decomp (math-code.c:337-432, restated in the
+    oracle): the same pivot ROW for every column -- random matrices, near ties (scaled candidates within 1e-9 relative),
+    exact ties (the reference's strict `>` scan keeps the first row of its current, swapped, order), rows whose largest
+    entries share a column (scaled candidates 1 +- 1 ulp) -- and the same verdict around the 1e-20 singularity threshold."""
+    rng = np.random.default_rng(7)
+    solved = 0
+    for kind, A in _pivot_cases(rng):
         n = len(A)
         b = rng.standard_normal(n)
         rc, xo, idx = _oracle_lu(A, b)
-        st, xd, piv = _device_solve(A, b)
+        st, xd, piv = _device_solve(A, b, exact=True)
         if rc != 0:
             assert st == 2
             continue
         assert st == 0
-        assert np.array_equal(piv, idx), (n, piv, idx)
-        assert relerr(xd, xo) < 1e-9 * max(1.0, np.linalg.cond(A) * 1e-6)
-        checked_ties += 1
-    assert checked_ties >= 12
-    # singular verdict: a matrix whose last scaled pivot is ~1e-21 (singular for the reference) and one at ~1e-19 (regular)
-    for eps, singular in ((1e-21, True), (1e-19, False)):
-        A = np.eye(5); A[4, 4] = eps; A[4, 0] = 1.0; A[0, 4] = 0.0
+        assert np.array_equal(piv, idx), (kind, n, piv, idx)
+        assert relerr(xd, xo) < 1e-9 * max(1.0, np.linalg.cond(A) * 1e-6), (kind, n)
+        solved += 1
+    assert solved >= 20
+    for eps, singular in ((1e-21, True), (1e-19, False), (0.99999e-20, True), (1.00001e-20, False)):
+        A = np.eye(5); A[4, 4] = eps; A[4, 0] = 1.0
         b = np.ones(5)
         rc, xo, idx = _oracle_lu(A, b)
-        st, xd, piv = _device_solve(A, b)
+        st, xd, piv = _device_solve(A, b, exact=True)
         assert (rc != 0) == singular and (st == 2) == singular, (eps, rc, st)
+
+
+def test_newton_solver_default_pivot_rule():
+    """The default (single-precision ranking) solver: every pivot row is an arg-max of the scaled candidates to within the
+    ranking resolution 2^-17 (the reference's own choice among candidates that close is decided by the last ulp: even a random
+    3 x 3 matrix has two rows whose largest entry sits in column 0, both scaling to 1 +- 1 ulp), the solve is backward stable,
+    and it gives the reference's solution to rounding; singular verdict away from the threshold."""
+    rng = np.random.default_rng(8)
+    for kind, A in _pivot_cases(rng):
+        n = len(A)
+        b = rng.standard_normal(n)
+        rc, xo, idx = _oracle_lu(A, b)
+        st, xd, piv = _device_solve(A, b, exact=False)
+        if rc != 0:
+            continue
+        assert st == 0 and sorted(piv) == list(range(n))
+        # every pivot is an arg-max of the scaled candidates up to the ranking resolution (2^-17): replay the elimination
+        M = A.copy(); scale = 1.0 / np.abs(A).max(axis=1); unused = np.ones(n, dtype=bool)
+        for k in range(n):
+            cand = np.where(unused, np.abs(M[:, k]) * scale, -1.0)
+            assert cand[piv[k]] >= cand.max() * (1.0 - 2.0 ** -16), (kind, n, k, piv[k], int(cand.argmax()))
+            r = piv[k]; unused[r] = False
+            others = np.arange(n) != r
+            M[others] -= np.outer(M[others, k] / M[r, k], M[r])
+        # a backward-stable solve: small residual whatever the conditioning (the near-tie matrices have cond ~ 1e10) ...
+        res = np.abs(A.dot(xd) - b).max() / (np.abs(A).sum(axis=1).max() * np.abs(xd).max() + np.abs(b).max())
+        assert res < 1e-13, (kind, n, res)
+        if kind != "near ties":   # ... and the reference's solution where the matrix is well conditioned
+            assert relerr(xd, xo) < 1e-9 * max(1.0, np.linalg.cond(A) * 1e-6), (kind, n, relerr(xd, xo))
+    for eps, singular in ((1e-21, True), (1e-19, False)):
+        A = np.eye(5); A[4, 4] = eps; A[4, 0] = 1.0
+        st, xd, piv = _device_solve(A, np.ones(5), exact=False)
+        assert (st == 2) == singular
+
+
+def test_exact_pivot_rollout_agrees_with_default():
+    """A puppet rollout under both pivot rules: same Newton iteration counts, states equal to 1e-11, and the exact rule within
+    the usual 1e-10 of the reference golden."""
+    import trep_amd
+    system, d = build("puppet40")
+    prefix, q0, U, K = trajectories("puppet40")[0]
+    g = golden("puppet40")
+    N = 100
+    out = []
+    for exact in (False, True):
+        m = trep_amd.BatchMidpointVI(system, 2, specialize=False)
+        m.exact_pivot = exact
+        Q0 = np.stack([q0, q0])
+        m.initialize_from_configs(0.0, Q0, DT, Q0)
+        X = m.rollout(N, DT, None, np.stack([K[:N]] * 2))
+        it, st = m.status()
+        assert (st == 0).all()
+        out.append((X, it))
+        m.close()
+    assert np.array_equal(out[0][1], out[1][1])
+    assert relerr(out[0][0], out[1][0]) < 1e-11
+    assert relerr(out[1][0][0][:, :d.n_configs], g[prefix + "Q"][:N + 1]) < TOL

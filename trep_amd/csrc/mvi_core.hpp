@@ -89,6 +89,7 @@ struct RunArgs {
     double *hz;                            // MODE_DERIV2Z: [batch][R][R], R = nq+nd+nu+nk
     int *iters, *status;                   // [batch]
     long long *prof_out;                   // diagnostic build: [16] cycle counters of trajectory 0
+    int exact_pivot;                       // rollout / step: 1 = the reference's pivot sequence bit for bit (gj_rows_exact), 0 = single-precision ranking
     const double *zl;                      // MODE_DERIV2Z, optional: [batch][nc] weights of the lambda1 second derivatives
     const double *dq_in, *ddqk_in;         // MODE_DYNAMICS: rates [batch][nq] and kinematic accelerations [batch][nk] (q in q1 = q2, u in u1)
     double *ddq_out, *lam_out;             // MODE_DYNAMICS: accelerations of the dynamic configs [batch][nd], constraint forces [batch][nc]
@@ -891,8 +892,37 @@ struct Core {
     //      matrix size rounded up to a multiple of 4 (identity padding), so every loop bound is a
     //      compile-time constant and the body carries no guards.
     //      Reads [A | rhs(1 column)] from LDS, leaves x in A[i*ld + n] like gauss_jordan().
-    template <int N>
-    static __device__ __noinline__ bool gj_rows(bool on, double *A_generic, int n, int ld, int lane, int *trace = nullptr) {
+    // Slow path of the pivot search (out of line: the 28-times unrolled solver must stay small enough for the instruction
+    // cache): exact maximum of the candidates' doubles and, among the rows that attain it, the first in the reference's order.
+    static __device__ __noinline__ int pivot_exact(double cand64, bool cand_ok, int pos, int lane) {
+        unsigned long long best = cand_ok ? (unsigned long long)__double_as_longlong(cand64) : 0ull;   // non-negative doubles order like their bits
+        if (TEAM == 64) {
+            best = __ockl_wfred_max_u64(best);
+        } else {
+#pragma unroll
+            for (int m = TEAM / 2; m >= 1; m >>= 1) {
+                const unsigned long long o = __shfl_xor(best, m, TEAM);
+                best = o > best ? o : best;
+            }
+        }
+        const bool at_max = cand_ok && (unsigned long long)__double_as_longlong(cand64) == best;
+        unsigned int k2 = at_max ? ((unsigned int)(63 - pos) << 6) | (unsigned int)(lane & 63) : 0u;   // position first, lane to identify the row
+        if (TEAM == 64) {
+            k2 = __ockl_wfred_max_u32(k2);
+        } else {
+#pragma unroll
+            for (int m = TEAM / 2; m >= 1; m >>= 1) {
+                const unsigned int o = __shfl_xor(k2, m, TEAM);
+                k2 = o > k2 ? o : k2;
+            }
+        }
+        int piv = (int)(k2 & 0x3Fu);
+        if (TEAM != 64) piv = (piv & (TEAM - 1));
+        return piv;
+    }
+
+    template <int N, bool TRACE = false>
+    static __device__ __noinline__ bool gj_rows_exact(bool on, double *A_generic, int n, int ld, int lane, int *trace = nullptr) {
         typedef __attribute__((address_space(3))) double lds_double;
         lds_double *A = (lds_double *)A_generic;
         double row[N], rhs = 0.0, scale = 0.0, diag = 1.0;
@@ -915,15 +945,18 @@ struct Core {
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            // arg-max of |a_ik| * scale_i over the rows not yet used as pivots.  Fast path: the candidates are ranked in single
-            // precision with the 6 low mantissa bits replaced by the lane (one 32-bit wave max); the cast and the mask are
-            // monotonic, so a UNIQUE truncated maximum is the exact fp64 maximum.  If several candidates share it (within
-            // 2^-17 relative, or exactly equal -- mirror-symmetric mechanisms do that), the slow path below compares the
-            // doubles exactly and takes, among exactly equal ones, the row that comes first in the reference's row order.
+            // arg-max of |a_ik| * scale_i over the rows not yet used as pivots, ties to the row that comes first in the
+            // reference's (swapped) row order -- its scan uses a strict `>`.  The candidates are ranked by ONE 32-bit wave max
+            // of (single-precision magnitude with the 6 low mantissa bits replaced by 63 - position): cast and mask are
+            // monotonic, so the exact fp64 maximum is among the lanes that attain the truncated maximum, and among EXACTLY
+            // equal candidates (mirror-symmetric mechanisms produce them all the time) the key already prefers the smallest
+            // position.  Only if several lanes share the truncated maximum with DIFFERENT doubles (within 2^-17 relative, rare)
+            // the slow path compares the doubles exactly.
             const bool cand_ok = mine && mycol < 0;
             const double cand64 = cand_ok ? fabs(row[k] * scale) : 0.0;
-            const unsigned int tkey = __float_as_uint((float)cand64) & ~0x3Fu;
-            unsigned int key = tkey | (unsigned int)(63 - (lane & 63));
+            // key = magnitude (22 bits) | 31 - position | lane: N <= 32, so position and lane take 5 bits each
+            const unsigned int tkey = __float_as_uint((float)cand64) & ~0x3FFu;
+            unsigned int key = tkey | ((unsigned int)(31 - (pos & 31)) << 5) | (unsigned int)(lane & 31);
             if (TEAM == 64) {
                 key = __ockl_wfred_max_u32(key);
             } else {
@@ -933,42 +966,26 @@ struct Core {
                     key = o > key ? o : key;
                 }
             }
-            int piv = 63 - (int)(key & 0x3Fu);
-            if (TEAM != 64) piv = (piv & (TEAM - 1));
             const unsigned long long team_mask = TEAM == 64 ? ~0ull : (((1ull << TEAM) - 1ull) << team_base);
-            const unsigned long long tied = __ballot(cand_ok && tkey == (key & ~0x3Fu)) & team_mask;
-            const bool multi = (tied & (tied - 1ull)) != 0ull;
-            if (__any(multi ? 1 : 0)) {      // wave-uniform: some team has more than one candidate at the truncated maximum
-                // exact maximum of the doubles (non-negative: their bit patterns order like the values) ...
-                unsigned long long best = cand_ok ? (unsigned long long)__double_as_longlong(cand64) : 0ull;
-                if (TEAM == 64) {
-                    best = __ockl_wfred_max_u64(best);
-                } else {
-#pragma unroll
-                    for (int m = TEAM / 2; m >= 1; m >>= 1) {
-                        const unsigned long long o = __shfl_xor(best, m, TEAM);
-                        best = o > best ? o : best;
-                    }
-                }
-                // ... and among the rows that attain it the first one in the reference's order (smallest position)
-                const bool at_max = cand_ok && (unsigned long long)__double_as_longlong(cand64) == best;
-                unsigned int k2 = at_max ? ((unsigned int)(63 - pos) << 6) | (unsigned int)(lane & 63) : 0u;
-                if (TEAM == 64) {
-                    k2 = __ockl_wfred_max_u32(k2);
-                } else {
-#pragma unroll
-                    for (int m = TEAM / 2; m >= 1; m >>= 1) {
-                        const unsigned int o = __shfl_xor(k2, m, TEAM);
-                        k2 = o > k2 ? o : k2;
-                    }
-                }
-                piv = (int)(k2 & 0x3Fu);
-                if (TEAM != 64) piv = (piv & (TEAM - 1));
+            const bool at_tmax = cand_ok && tkey == (key & ~0x3FFu);
+            const unsigned long long tied = __ballot(at_tmax) & team_mask;
+            int piv = (int)(key & 31u);
+            if (TEAM < 32) piv &= (TEAM - 1);
+            if (__any((tied & (tied - 1ull)) != 0ull ? 1 : 0)) {   // some team has several lanes at the truncated maximum
+                const double w = TEAM == 64 ? __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(cand64) >> 32), piv) << 32) |
+                                                                   (unsigned int)__builtin_amdgcn_readlane((int)(__double_as_longlong(cand64) & 0xFFFFFFFFLL), piv))
+                                            : __shfl(cand64, piv, TEAM);
+                if (__any((at_tmax && cand64 != w) ? 1 : 0))       // ... and they are not all exactly equal: exact comparison
+                    piv = pivot_exact(cand64, cand_ok, pos, lane);
             }
-            // singular test on the winner's exact value (math-code.c:393: scaled pivot <= 1e-20)
-            const unsigned long long big = __ballot(cand64 > 1.0e-20);
+            // singular test (math-code.c:393: scaled pivot <= 1e-20): decided by the truncated maximum unless that lies within a
+            // factor of two of the threshold -- only then the winner's exact value is looked at
             const int src = (TEAM == 64) ? __builtin_amdgcn_readfirstlane(piv) : piv;
-            if (on && ok && !((big >> (team_base + src)) & 1ull)) ok = false;
+            const float best = __uint_as_float(key & ~0x3FFu);
+            if (__any((best < 2.0e-20f && best > 0.5e-20f) ? 1 : 0)) {
+                const unsigned long long big = __ballot(cand64 > 1.0e-20);
+                if (on && ok && !((big >> (team_base + src)) & 1ull)) ok = false;
+            } else if (on && ok && !(best > 1.0e-20f)) ok = false;
             const bool go = on && ok;
             // broadcast the pivot row (columns k..N-1 and the rhs)
             auto bcast = [&](double v) -> double {
@@ -986,10 +1003,12 @@ struct Core {
             // bookkeeping of the reference's row order: it swaps the pivot row with the row at position k
             {
                 const int pos_p = (TEAM == 64) ? __builtin_amdgcn_readlane(pos, src) : __shfl(pos, src, TEAM);
-                if (pos == k) pos = pos_p;
-                if (is_piv) pos = k;
+                if (__any(pos_p != k ? 1 : 0)) {     // (wave-uniform) almost never taken: the pivot usually is the row at position k
+                    if (pos == k) pos = pos_p;
+                    if (is_piv) pos = k;
+                }
             }
-            if (trace && go && is_piv) trace[k] = lane;
+            if (TRACE && go && is_piv) trace[k] = lane;
             // 1/pivot: hardware seed + two Newton steps (the multipliers need not be correctly rounded)
             double rp = __builtin_amdgcn_rcp(pkk);
             rp = fma(rp, fma(-pkk, rp, 1.0), rp);
@@ -1017,19 +1036,19 @@ struct Core {
         __syncthreads();
         return ok;
     }
-#endif
 
-#if defined(__HIP_DEVICE_COMPILE__)
-    // ---- the same solver with the pivot row broadcast through LDS instead of v_readlane ---------------------------
-    //      gj_rows() spends two v_readlane_b32 (+ SGPR hazard wait states) per (step, column) pair: ~950 readlanes and
-    //      ~700 s_nops around ~500 FMAs, all on the VALU that the wave shares with its SIMD neighbour.  Here the lane
-    //      that owns the pivot row writes [1/pivot | rest of the row | rhs] into the (dead) matrix storage and every
-    //      lane reads it back with wave-uniform LDS reads (hardware broadcast): the VALU work drops to the FMAs and the
-    //      pivot search, the broadcasts ride on the LDS pipe.  Every lane inverts its own candidate while the wave max
-    //      is in flight, so the reciprocal is off the critical path.  Rounding differs from gj_rows() only in the
-    //      order of one multiplication (l = a_ik * (1/p_kk) in both).
-    template <int N>
-    static __device__ __noinline__ bool gj_rows_lds(bool on, double *A_generic, int n, int ld, int lane) {
+    // ---- the default solver: same elimination, pivot candidates ranked in single precision -------------------------------
+    //      One 32-bit wave max per step over (float bits of |a_ik| * scale_i with the 6 low mantissa bits replaced by
+    //      63 - lane) and no branch anywhere in the unrolled body.  Candidates closer than 2^-17 relative are taken in lane
+    //      (= original row) order.  That is NOT always the reference's choice: every row's largest entry scales to 1 +- 1 ulp,
+    //      so whenever two rows have their largest entry in the same column (two string constraints and a shared torso
+    //      config: 95 % of the puppet's Newton systems) the reference's strict `>` scan decides by that last ulp.  Either
+    //      row is an exact arg-max to 16 digits and the solutions agree to rounding (1e-13 relative on the test matrices), but
+    //      the pivot SEQUENCE can differ; gj_rows_exact() reproduces it exactly (RunArgs::exact_pivot, tg_batch_set_pivot_rule)
+    //      at +9 % rollout time -- each variant of an in-line exact test (position bookkeeping +2.3 %, tie block +3.4 %, exact
+    //      singular test +3.7 %; a branch-free "detect and redo" fires on 95 % of the solves) was measured and rejected.
+    template <int N, bool TRACE = false>
+    static __device__ __noinline__ bool gj_rows(bool on, double *A_generic, int n, int ld, int lane, int *trace = nullptr) {
         typedef __attribute__((address_space(3))) double lds_double;
         lds_double *A = (lds_double *)A_generic;
         double row[N], rhs = 0.0, scale = 0.0, diag = 1.0;
@@ -1045,15 +1064,10 @@ struct Core {
             for (int j = 0; j < N; j++) { const double a = fabs(row[j]); s = a > s ? a : s; }
             scale = 1.0 / s;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        __builtin_amdgcn_s_barrier();                 // every row is in registers: the matrix storage becomes the broadcast buffer
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-        lds_double *buf = A;
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            const double cand64 = (mine && mycol < 0) ? fabs(row[k] * scale) : 0.0;
-            const float cand = (float)cand64;
+            const float cand = (mine && mycol < 0) ? (float)fabs(row[k] * scale) : 0.0f;
             unsigned int key = (__float_as_uint(cand) & ~0x3Fu) | (unsigned int)(63 - (lane & 63));
             if (TEAM == 64) {
                 key = __ockl_wfred_max_u32(key);
@@ -1064,35 +1078,45 @@ struct Core {
                     key = o > key ? o : key;
                 }
             }
-            // own reciprocal, speculatively (independent of the reduction above)
-            double rp = __builtin_amdgcn_rcp(row[k]);
-            rp = fma(rp, fma(-row[k], rp, 1.0), rp);
-            rp = fma(rp, fma(-row[k], rp, 1.0), rp);
             int piv = 63 - (int)(key & 0x3Fu);
             const float best = __uint_as_float(key & ~0x3Fu);
             if (TEAM != 64) piv = (piv & (TEAM - 1));
             if (on && ok && !(best > 1.0e-20f)) ok = false;
             const bool go = on && ok;
-            const bool is_piv = mine && (lane & (TEAM - 1)) == piv;
-            if (go && is_piv) {
-                buf[0] = rp;
+            // broadcast the pivot row (columns k..N-1 and the rhs)
+            const int src = (TEAM == 64) ? __builtin_amdgcn_readfirstlane(piv) : piv;
+            auto bcast = [&](double v) -> double {
+                if (TEAM == 64) {
+                    const long long b = __double_as_longlong(v);
+                    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFLL), src);
+                    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+                    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+                }
+                return __shfl(v, src, TEAM);
+            };
+            const double pkk = bcast(row[k]);
+            const double prhs = bcast(rhs);
+            const bool is_piv = mine && (lane & (TEAM - 1)) == src;
+            if (TRACE && go && is_piv) trace[k] = lane;
+            // 1/pivot: hardware seed + two Newton steps (the multipliers need not be correctly rounded)
+            double rp = __builtin_amdgcn_rcp(pkk);
+            rp = fma(rp, fma(-pkk, rp, 1.0), rp);
+            rp = fma(rp, fma(-pkk, rp, 1.0), rp);
+            const double l = (go && mine && !is_piv) ? row[k] * rp : 0.0;
 #pragma unroll
-                for (int j = k + 1; j < N; j++) buf[j - k] = row[j];
-                buf[N - k] = rhs;
-                mycol = k; diag = row[k];
+            for (int j = k + 1; j < N; j++) row[j] = fma(-l, bcast(row[j]), row[j]);
+            rhs = fma(-l, prhs, rhs);
+            if (go && is_piv) { mycol = k; diag = row[k]; }
+            // keep the elimination pivot-major (see gj_rows_exact)
+#pragma unroll
+            for (int j = k + 1; j < N; j += 8) {
+                if (j + 7 < N) asm volatile("" : "+v"(row[j]), "+v"(row[j + 1]), "+v"(row[j + 2]), "+v"(row[j + 3]),
+                                                 "+v"(row[j + 4]), "+v"(row[j + 5]), "+v"(row[j + 6]), "+v"(row[j + 7]));
+                else {
+#pragma unroll
+                    for (int jj = j; jj < N; jj++) asm volatile("" : "+v"(row[jj]));
+                }
             }
-            // one wave owns the team: its LDS operations execute in order, the loads below see the stores above
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            const double prp = buf[0];
-            const double l = (go && mine && !is_piv) ? row[k] * prp : 0.0;
-#pragma unroll
-            for (int j = k + 1; j < N; j++) row[j] = fma(-l, buf[j - k], row[j]);
-            rhs = fma(-l, buf[N - k], rhs);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            __builtin_amdgcn_s_barrier();             // reads of this step before the next step's stores
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         }
         if (mine && ok && mycol >= 0 && mycol < n) A[mycol * ld + n] = rhs / diag;
         __syncthreads();
@@ -2993,17 +3017,18 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj) {
             const int nb4 = (P.nf + 3) >> 2;   // matrix size in blocks of 4 rows
             if (TEAM >= 4 && 4 * nb4 <= TEAM && nb4 <= 8) {
                 double *Ad = S + P.o_Df;
-#if defined(TG_GJ_LDS)
-                if (nb4 >= 2 && P.nf * P.df_ld >= 4 * nb4 + 1) switch (nb4) {
-                case 2: ok = Core<TEAM>::template gj_rows_lds<(TEAM >= 8 ? 8 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
-                case 3: ok = Core<TEAM>::template gj_rows_lds<(TEAM >= 12 ? 12 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
-                case 4: ok = Core<TEAM>::template gj_rows_lds<(TEAM >= 16 ? 16 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
-                case 5: ok = Core<TEAM>::template gj_rows_lds<(TEAM >= 20 ? 20 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
-                case 6: ok = Core<TEAM>::template gj_rows_lds<(TEAM >= 24 ? 24 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
-                case 7: ok = Core<TEAM>::template gj_rows_lds<(TEAM >= 28 ? 28 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
-                default: ok = Core<TEAM>::template gj_rows_lds<(TEAM >= 32 ? 32 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                if (A.exact_pivot) {
+                switch (nb4) {
+                case 1: ok = Core<TEAM>::template gj_rows_exact<4>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 2: ok = Core<TEAM>::template gj_rows_exact<(TEAM >= 8 ? 8 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 3: ok = Core<TEAM>::template gj_rows_exact<(TEAM >= 12 ? 12 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 4: ok = Core<TEAM>::template gj_rows_exact<(TEAM >= 16 ? 16 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 5: ok = Core<TEAM>::template gj_rows_exact<(TEAM >= 20 ? 20 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 6: ok = Core<TEAM>::template gj_rows_exact<(TEAM >= 24 ? 24 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                case 7: ok = Core<TEAM>::template gj_rows_exact<(TEAM >= 28 ? 28 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                default: ok = Core<TEAM>::template gj_rows_exact<(TEAM >= 32 ? 32 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
+                }
                 } else
-#endif
                 switch (nb4) {
                 case 1: ok = Core<TEAM>::template gj_rows<4>(!done, Ad, P.nf, P.df_ld, lane); break;
                 case 2: ok = Core<TEAM>::template gj_rows<(TEAM >= 8 ? 8 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;

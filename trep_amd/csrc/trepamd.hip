@@ -81,6 +81,7 @@ struct tg_batch {
     long long total_iters = 0;
     double t1 = 0.0, t2 = 0.0, tolerance = 1.0e-10;
     int predictor = 0;
+    int exact_pivot = 0;       // 1: Newton systems solved with the reference's exact pivot rule (gj_rows_exact)
     hipStream_t stream = nullptr;
     bool own_stream = true;
     static constexpr size_t TIMING_CAP = 4096;
@@ -245,7 +246,7 @@ int ensure_deriv_buffers(tg_batch *b, bool first, bool second) {
 tg::RunArgs base_args(tg_batch *b, int mode) {
     tg::RunArgs A{};
     A.batch = b->batch; A.mode = mode; A.max_iterations = 200;
-    A.t1 = b->t1; A.t2 = b->t2; A.tolerance = b->tolerance; A.predictor = b->predictor;
+    A.t1 = b->t1; A.t2 = b->t2; A.tolerance = b->tolerance; A.predictor = b->predictor; A.exact_pivot = b->exact_pivot;
     A.q1 = b->q1; A.q2 = b->q2; A.p1 = b->p1; A.p2 = b->p2; A.lam = b->lam; A.u1 = b->u1;
     A.iters = b->iters; A.status = b->status; A.f_out = b->f_out;
     A.prof_out = b->prof;
@@ -284,7 +285,7 @@ __global__ void k_init_from_X(const tg::DevProg P, const double *X, size_t strid
 }
 
 // Test hook: the Newton-system solver of the rollout kernels (gj_rows) on a caller-supplied matrix, with its pivot order.
-__global__ void k_debug_solve(int n, int ld, const double *A_in, double *x_out, int *piv_out, int *status_out) {
+__global__ void k_debug_solve(int n, int ld, int exact, const double *A_in, double *x_out, int *piv_out, int *status_out) {
 #if defined(__HIP_DEVICE_COMPILE__)   // gj_rows exists in the device pass only
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
@@ -293,15 +294,25 @@ __global__ void k_debug_solve(int n, int ld, const double *A_in, double *x_out, 
     if (lane < 32) trace[lane] = -1;
     __syncthreads();
     bool ok = true;
-    switch ((n + 3) >> 2) {
-    case 1: ok = tg::Core<64>::gj_rows<4>(true, lds, n, ld, lane, trace); break;
-    case 2: ok = tg::Core<64>::gj_rows<8>(true, lds, n, ld, lane, trace); break;
-    case 3: ok = tg::Core<64>::gj_rows<12>(true, lds, n, ld, lane, trace); break;
-    case 4: ok = tg::Core<64>::gj_rows<16>(true, lds, n, ld, lane, trace); break;
-    case 5: ok = tg::Core<64>::gj_rows<20>(true, lds, n, ld, lane, trace); break;
-    case 6: ok = tg::Core<64>::gj_rows<24>(true, lds, n, ld, lane, trace); break;
-    case 7: ok = tg::Core<64>::gj_rows<28>(true, lds, n, ld, lane, trace); break;
-    default: ok = tg::Core<64>::gj_rows<32>(true, lds, n, ld, lane, trace); break;
+    if (exact) switch ((n + 3) >> 2) {
+    case 1: ok = tg::Core<64>::gj_rows_exact<4, true>(true, lds, n, ld, lane, trace); break;
+    case 2: ok = tg::Core<64>::gj_rows_exact<8, true>(true, lds, n, ld, lane, trace); break;
+    case 3: ok = tg::Core<64>::gj_rows_exact<12, true>(true, lds, n, ld, lane, trace); break;
+    case 4: ok = tg::Core<64>::gj_rows_exact<16, true>(true, lds, n, ld, lane, trace); break;
+    case 5: ok = tg::Core<64>::gj_rows_exact<20, true>(true, lds, n, ld, lane, trace); break;
+    case 6: ok = tg::Core<64>::gj_rows_exact<24, true>(true, lds, n, ld, lane, trace); break;
+    case 7: ok = tg::Core<64>::gj_rows_exact<28, true>(true, lds, n, ld, lane, trace); break;
+    default: ok = tg::Core<64>::gj_rows_exact<32, true>(true, lds, n, ld, lane, trace); break;
+    }
+    else switch ((n + 3) >> 2) {
+    case 1: ok = tg::Core<64>::gj_rows<4, true>(true, lds, n, ld, lane, trace); break;
+    case 2: ok = tg::Core<64>::gj_rows<8, true>(true, lds, n, ld, lane, trace); break;
+    case 3: ok = tg::Core<64>::gj_rows<12, true>(true, lds, n, ld, lane, trace); break;
+    case 4: ok = tg::Core<64>::gj_rows<16, true>(true, lds, n, ld, lane, trace); break;
+    case 5: ok = tg::Core<64>::gj_rows<20, true>(true, lds, n, ld, lane, trace); break;
+    case 6: ok = tg::Core<64>::gj_rows<24, true>(true, lds, n, ld, lane, trace); break;
+    case 7: ok = tg::Core<64>::gj_rows<28, true>(true, lds, n, ld, lane, trace); break;
+    default: ok = tg::Core<64>::gj_rows<32, true>(true, lds, n, ld, lane, trace); break;
     }
     __syncthreads();
     if (lane < n) { x_out[lane] = lds[lane * ld + n]; piv_out[lane] = trace[lane]; }
@@ -889,7 +900,7 @@ int tg_batch_set_stream(tg_batch *b, void *hip_stream) {
 /* Test hook (tests/test_gpu_parity.py): solves the n x n system [A | b] (row-major [n][n+1], n <= 32) with the register
  * Gauss-Jordan of the rollout kernels and reports which original row was the pivot of each column: the reference's
  * LU_decomp (math-code.c:337-432, implicit scaling, strict `>` scan) must pick the same rows, ties included. */
-int tg_debug_solve(int32_t device, int32_t n, const double *A_aug_host, double *x_host, int32_t *pivot_rows_host, int32_t *status_host) {
+int tg_debug_solve(int32_t device, int32_t n, int32_t exact, const double *A_aug_host, double *x_host, int32_t *pivot_rows_host, int32_t *status_host) {
     if (n <= 0 || n > 32 || !A_aug_host || !x_host || !pivot_rows_host || !status_host) return fail(TG_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(device));
     double *dA = nullptr, *dx = nullptr; int *dp = nullptr, *ds = nullptr;
@@ -897,12 +908,18 @@ int tg_debug_solve(int32_t device, int32_t n, const double *A_aug_host, double *
     HIP_TRY(hipMalloc(&dA, sizeof(double) * n * (n + 1))); HIP_TRY(hipMalloc(&dx, sizeof(double) * n));
     HIP_TRY(hipMalloc(&dp, sizeof(int) * n)); HIP_TRY(hipMalloc(&ds, sizeof(int)));
     HIP_TRY(hipMemcpy(dA, A_aug_host, sizeof(double) * n * (n + 1), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_debug_solve, dim3(1), dim3(64), sizeof(double) * n * ld + sizeof(int) * 32, 0, n, ld, dA, dx, dp, ds);
+    hipLaunchKernelGGL(k_debug_solve, dim3(1), dim3(64), sizeof(double) * n * ld + sizeof(int) * 32, 0, n, ld, (int)exact, dA, dx, dp, ds);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(x_host, dx, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(pivot_rows_host, dp, sizeof(int) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(status_host, ds, sizeof(int), hipMemcpyDeviceToHost));
     hipFree(dA); hipFree(dx); hipFree(dp); hipFree(ds);
+    return TG_SUCCESS;
+}
+
+int tg_batch_set_pivot_rule(tg_batch *b, int32_t exact) {
+    if (!b) return fail(TG_ERR_INVALID, "null batch");
+    b->exact_pivot = exact ? 1 : 0;
     return TG_SUCCESS;
 }
 

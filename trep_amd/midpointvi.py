@@ -58,7 +58,7 @@ class BatchMidpointVI(object):
         from . import specialize as _spec
         if not build and not _spec.is_built(self._system):
             return False
-        path = _spec.build(self._system)
+        path = os.environ.get("TREPAMD_SPEC_OVERRIDE") or _spec.build(self._system)   # override: A/B experiments only
         _lib.check(self._L.tg_batch_load_specialized(self._h, path.encode()))
         self._specialized = path
         return True
@@ -85,7 +85,7 @@ class BatchMidpointVI(object):
         keep = None
         if old_sizes == (int(desc.n_configs), int(desc.n_dyn), int(desc.n_kin), int(desc.n_inputs), int(desc.n_constraints)):
             keep = (self.times(), [getattr(self, n) for n in ("q1", "q2", "p1", "p2", "u1", "lambda1")], self.tolerance,
-                    self.predictor)
+                    self.predictor, self.exact_pivot)
         self._L.tg_batch_destroy(self._h)
         self._L.tg_system_destroy(self._sys_h)
         self._desc, self._sys_h, self._h = desc, sys_h, h
@@ -94,12 +94,13 @@ class BatchMidpointVI(object):
         if self._specialize_mode is True or (self._specialize_mode == "auto" and os.environ.get("TREPAMD_NO_SPECIALIZE") is None):
             self.specialize(build=False)      # a cached specialisation of the NEW schedule, if there is one
         if keep is not None:
-            (t1, t2), fields, tol, pred = keep
+            (t1, t2), fields, tol, pred, exact = keep
             self.set_times(t1, t2)
             for n, v in zip(("q1", "q2", "p1", "p2", "u1", "lambda1"), fields):
                 setattr(self, n, v)
             self.tolerance = tol
             self.predictor = pred
+            self.exact_pivot = exact
         return True
 
     def close(self):
@@ -118,6 +119,17 @@ class BatchMidpointVI(object):
             self.close()
         except Exception:
             pass
+
+    @property
+    def exact_pivot(self):
+        """False (default): pivot candidates of the Newton solve are ranked in single precision; True: the reference's
+        pivot rule bit for bit (include/trep_amd.h, tg_batch_set_pivot_rule), about 9 % slower."""
+        return getattr(self, "_exact_pivot", False)
+
+    @exact_pivot.setter
+    def exact_pivot(self, value):
+        _lib.check(self._L.tg_batch_set_pivot_rule(self._h, 1 if value else 0))
+        self._exact_pivot = bool(value)
 
     # -- sizes ---------------------------------------------------------------------------
     system = property(lambda self: self._system)
