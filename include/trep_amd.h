@@ -236,6 +236,13 @@ int tg_memcpy_d2h(int32_t device, void *dst_host, const void *src_dev, uint64_t 
 int tg_batch_synchronize(tg_batch *b);
 /* Use an externally created hipStream_t (e.g. torch's current stream); NULL = own stream. */
 int tg_batch_set_stream(tg_batch *b, void *hip_stream);
+/* Non-uniform time base.  The reference's DSystem takes an arbitrary time vector (trep/discopt/dsystem.py:229-274: every
+ * set / step uses t[k+1] - t[k]).  A list of `count` step sizes on the batch replaces the scalar dt of the entry points
+ * below it: by_trajectory = 0: step k of a rollout / closed-loop rollout uses dt[k] (n_steps <= count); by_trajectory = 1:
+ * trajectory t of a one-step batch (tg_batch_step, tg_batch_set_from_trajectories and the derivative kernels that follow:
+ * batch = seeds x horizon) uses dt[t % count].  count = 0 removes the list. */
+int tg_batch_set_step_sizes(tg_batch *b, int32_t count, const double *dt_host, int32_t by_trajectory);
+
 /* Pivot rule of the Newton-system solve (replaces LU_decomp + LU_solve_vec, math-code.c:337-461, as used by
  * MidpointVI_solve_DEL, midpointvi.c:720-733).  Both settings are Gauss-Jordan with implicit row scaling and partial
  * pivoting over the rows not used yet, singular if the scaled pivot is <= 1e-20:

@@ -21,7 +21,7 @@ class RunArgs(ctypes.Structure):
                 ("tolerance", ctypes.c_double),
                 ("q1", _D), ("q2", _D), ("p1", _D), ("p2", _D), ("lam", _D), ("u1", _D),
                 ("U", _D), ("K", _D), ("q2_hint", _D), ("lam_hint", _D), ("Kproj", _D), ("bX", _D), ("bU", _D), ("Uout", _D), ("group_size", ctypes.c_int), ("group_map", _I), ("X", _D), ("f_out", _D),
-                ("d1", _D * 12), ("A_out", _D), ("B_out", _D), ("z", _D), ("hz", _D), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p), ("exact_pivot", ctypes.c_int),
+                ("d1", _D * 12), ("A_out", _D), ("B_out", _D), ("z", _D), ("hz", _D), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p), ("dt_steps", _D), ("dt_period", ctypes.c_int), ("exact_pivot", ctypes.c_int),
                 ("zl", _D), ("dq_in", _D), ("ddqk_in", _D), ("ddq_out", _D), ("lam_out", _D), ("g1", _D * 8), ("energy_out", _D), ("lag1_out", _D), ("lag2_out", _D)]
 
 
@@ -204,11 +204,18 @@ class EmuBatch(object):
         self.L.emu_run(self.h, ctypes.byref(a))
         return HZ
 
-    def rollout(self, n_steps, dt, U=None, K=None, want_X=True, q2_hint=None, lam_hint=None):
+    def rollout(self, n_steps, dt, U=None, K=None, want_X=True, q2_hint=None, lam_hint=None, dts=None):
+        """dts: optional step sizes, one per step (non-uniform time base: RunArgs.dt_steps)."""
         U = None if U is None else np.ascontiguousarray(U, dtype=float)
         K = None if K is None else np.ascontiguousarray(K, dtype=float)
         X = np.zeros((self.B, n_steps + 1, self.nX)) if want_X else None
         a = self._args(0, n_steps, dt, U, K, X, q2_hint=q2_hint, lam_hint=lam_hint)
+        if dts is not None:
+            dts = np.ascontiguousarray(dts, dtype=float)
+            a.dt_steps, a.dt_period = _p(dts), 0
         self.L.emu_run(self.h, ctypes.byref(a))
-        self.t1, self.t2 = self.t2 + (n_steps - 1) * dt, self.t2 + n_steps * dt
+        if dts is None:
+            self.t1, self.t2 = self.t2 + (n_steps - 1) * dt, self.t2 + n_steps * dt
+        else:
+            self.t1, self.t2 = self.t2 + float(dts[:n_steps - 1].sum()), self.t2 + float(dts[:n_steps].sum())
         return X

@@ -195,3 +195,27 @@ def test_emulated_star_matches_oracle():
     o.initialize_from_configs(0.0, q0, DT, q0)
     Xo, _ = o.rollout(N, DT, np.zeros((N, 0)), np.zeros((N, 0)))
     assert relerr(X[0], Xo) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4"])
+def test_emulated_rollout_non_uniform_time_base(name):
+    """RunArgs.dt_steps: one step size per step (the reference's DSystem takes any time vector, dsystem.py:229-274) --
+    the kernel source under emulation against the oracle stepping through the same times."""
+    from common import build, trajectories, relerr
+    from emu_harness import EmuBatch
+    from oracle.oracle import OracleMVI
+    _, d = build(name)
+    prefix, q0, U, K = trajectories(name)[0]
+    N = 40
+    rng = np.random.default_rng(3)
+    dts = 0.01 * (0.5 + rng.random(N))
+    e = EmuBatch(d, 1)
+    e.initialize_from_configs(0.0, q0[None], 0.01, q0[None])
+    X = e.rollout(N, dts[0], None if U.shape[1] == 0 else U[None, :N], None if K.shape[1] == 0 else K[None, :N], dts=dts)
+    o = OracleMVI(d)
+    o.initialize_from_configs(0.0, q0, 0.01, q0)
+    nq = d.n_configs
+    for k in range(N):
+        o.step(o.times()[1] + dts[k], U[k], K[k])
+        assert relerr(X[0, k + 1, :nq], o.q2) < 1e-10, k
+    assert relerr(X[0, N, nq:nq + d.n_dyn], o.p2) < 1e-10

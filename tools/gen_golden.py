@@ -543,8 +543,60 @@ def gen_discopt_puppet(N=50):
     save("discopt_puppet", **out)
 
 
+def gen_discopt_cart_nonuniform():
+    """The pend-on-cart problem of gen_discopt_cart on a NON-uniform time base (the reference's DSystem takes any time
+    vector, dsystem.py:229-274): linearisation, projection gain, both descent directions and one quasi + one Newton step."""
+    from math import pi as mpi, cos
+    system = systems.pend_on_cart(torque_force=True, api=trep)
+    mvi = trep.MidpointVI(system, num_threads=1)
+    rng = np.random.default_rng(20250 + 77)
+    dts = DT * (0.5 + rng.random(120))
+    t = np.concatenate([[0.0], np.cumsum(dts)])
+    dsys = trep.discopt.DSystem(mvi, t)
+    (X, U) = dsys.build_trajectory()
+    for k in range(dsys.kf()):
+        if k == 0:
+            dsys.set(X[k], U[k], 0)
+        else:
+            dsys.step(U[k])
+        X[k + 1] = dsys.f()
+    amp = 60 * mpi / 180
+    qd = np.zeros((len(t), system.nQ))
+    th = system.get_config('theta').index
+    qd[:, th] = (1 - np.cos(2 * mpi * t / t[-1])) * amp / 2
+    (Xd, Ud) = dsys.build_trajectory(qd)
+    wq = 0.01 * np.ones(dsys.nX); wq[th] = 100.0
+    Qc, Rc = np.diag(wq), np.diag(0.01 * np.ones(dsys.nU))
+    cost = trep.discopt.DCost(Xd, Ud, Qc, Rc)
+
+    class Rec(trep.discopt.DOptimizerMonitor):
+        def __init__(self):
+            self.m = []
+        def armijo_evaluation(self, armijo_iteration, nX, nU, bX, bU, cost, max_cost):
+            self.m.append(armijo_iteration)
+    mon = Rec()
+    opt = trep.discopt.DOptimizer(dsys, cost, monitor=mon)
+    out = dict(t=t, X0=X.copy(), U0=U.copy(), Xd=Xd, Ud=Ud, Q=Qc, R=Rc)
+    (A, B) = dsys.linearize_trajectory(X, U)
+    out.update(lin_A=np.array(A), lin_B=np.array(B))
+    (Kproj, dX, dU, Qm, Rm, Sm) = opt.calc_descent_direction(X, U, 'newton')
+    out.update(dd_newton_dX=dX, dd_newton_dU=dU, dd_Kproj=np.array(Kproj))
+    (Kproj, dX, dU, Qm, Rm, Sm) = opt.calc_descent_direction(X, U, 'quasi')
+    out.update(dd_quasi_dX=dX, dd_quasi_dU=dU)
+    methods = ['quasi', 'newton']
+    for i, method in enumerate(methods):
+        mon.m = []
+        cost0 = opt.calc_cost(X, U)
+        (done, X, U, dcost0, cost1) = opt.step(i, X, U, method)
+        out["it%d_cost0" % i] = np.array([cost0]); out["it%d_dcost0" % i] = np.array([dcost0])
+        out["it%d_cost1" % i] = np.array([cost1]); out["it%d_m" % i] = np.array([mon.m[-1] if mon.m else -1])
+        out["it%d_X" % i] = X.copy(); out["it%d_U" % i] = U.copy()
+    out["methods"] = np.array(methods)
+    save("discopt_cart_nonuniform", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "wrench_torque", "dual_pendulums", "wrench_spatial", "wrench_body", "damper_link", "discopt", "discopt_puppet"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "wrench_torque", "dual_pendulums", "wrench_spatial", "wrench_body", "damper_link", "discopt", "discopt_puppet", "discopt_nonuniform"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -585,3 +637,5 @@ if __name__ == "__main__":
         gen_discopt_cart()
     if "discopt_puppet" in which:
         gen_discopt_puppet()
+    if "discopt_nonuniform" in which:
+        gen_discopt_cart_nonuniform()

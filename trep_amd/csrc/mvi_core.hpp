@@ -89,6 +89,8 @@ struct RunArgs {
     double *hz;                            // MODE_DERIV2Z: [batch][R][R], R = nq+nd+nu+nk
     int *iters, *status;                   // [batch]
     long long *prof_out;                   // diagnostic build: [16] cycle counters of trajectory 0
+    const double *dt_steps;                // optional non-uniform time base: step sizes; rollout: dt of step k = dt_steps[k]; with
+    int dt_period;                         // dt_period > 0 (one step per trajectory, batch = seeds x horizon): dt of trajectory t = dt_steps[t % dt_period]
     int exact_pivot;                       // rollout / step: 1 = the reference's pivot sequence bit for bit (gj_rows_exact), 0 = single-precision ranking
     const double *zl;                      // MODE_DERIV2Z, optional: [batch][nc] weights of the lambda1 second derivatives
     const double *dq_in, *ddqk_in;         // MODE_DYNAMICS: rates [batch][nq] and kinematic accelerations [batch][nk] (q in q1 = q2, u in u1)
@@ -2861,6 +2863,7 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj) {
     const bool live = traj < A.batch;
     const size_t t = (size_t)(live ? traj : 0);
     double dt = MODE == MODE_ROLLOUT ? A.dt : (A.t2 - A.t1);
+    if (A.dt_steps && A.dt_period > 0) dt = A.dt_steps[t % (size_t)A.dt_period];   // per-trajectory step size (k-parallel linearisation)
     Core<TEAM, SPRINGS, PROG> core(P, S, lane, dt);
     core.init_sweep_schedule();
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -2935,6 +2938,8 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj) {
         PROG &P = tg_fresh_step(P0);      // per step: nothing of the schedule / the arguments stays in SGPRs across steps
         ARGS &A = tg_fresh_args(A0);
         const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nX = P.nX;
+        const double dt_prev = dt;             // step size of the step that produced the incoming state (feedback: v = dq_k / dt_prev)
+        if (A.dt_steps && A.dt_period == 0) { dt = A.dt_steps[step]; core.dt = dt; }   // non-uniform time base (dsystem.py:229-274 takes any t)
         const bool on = live && !failed;
         if (A.Kproj) {  // feedback inputs from the state entering this step (before the shift: v needs q1)
             const int nU = nu + nk;
@@ -2942,7 +2947,7 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj) {
                 const size_t grp = A.group_map ? (size_t)A.group_map[t / A.group_size] : (size_t)(t / A.group_size);
                 const double *Kr = A.Kproj + ((grp * A.n_steps + step) * nU + j) * nX;
                 const double *bx = A.bX + (t * (size_t)(A.n_steps + 1) + step) * nX;
-                const double dtp = step == 0 ? (A.t2 - A.t1) : dt;
+                const double dtp = step == 0 ? (A.t2 - A.t1) : dt_prev;
                 double acc = A.bU[(t * A.n_steps + step) * nU + j];
                 if (step > 0)   // X_0 = bX_0 by definition of the projection: no correction at k = 0
                 for (int i = 0; i < nq; i++) acc -= Kr[i] * (S[P.o_q2 + i] - bx[i]);

@@ -81,6 +81,9 @@ struct tg_batch {
     long long total_iters = 0;
     double t1 = 0.0, t2 = 0.0, tolerance = 1.0e-10;
     int predictor = 0;
+    double *dt_dev = nullptr;  // optional non-uniform time base (tg_batch_set_step_sizes)
+    std::vector<double> dt_host;
+    int dt_by_trajectory = 0;
     int exact_pivot = 0;       // 1: Newton systems solved with the reference's exact pivot rule (gj_rows_exact)
     hipStream_t stream = nullptr;
     bool own_stream = true;
@@ -247,6 +250,8 @@ tg::RunArgs base_args(tg_batch *b, int mode) {
     tg::RunArgs A{};
     A.batch = b->batch; A.mode = mode; A.max_iterations = 200;
     A.t1 = b->t1; A.t2 = b->t2; A.tolerance = b->tolerance; A.predictor = b->predictor; A.exact_pivot = b->exact_pivot;
+    A.dt_steps = b->dt_host.empty() ? nullptr : b->dt_dev;
+    A.dt_period = (b->dt_by_trajectory && !b->dt_host.empty()) ? (int)b->dt_host.size() : 0;
     A.q1 = b->q1; A.q2 = b->q2; A.p1 = b->p1; A.p2 = b->p2; A.lam = b->lam; A.u1 = b->u1;
     A.iters = b->iters; A.status = b->status; A.f_out = b->f_out;
     A.prof_out = b->prof;
@@ -415,7 +420,7 @@ void tg_batch_destroy(tg_batch *b) {
     if (b->stream) hipStreamSynchronize(b->stream);
     for (auto &e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : b->pool) hipEventDestroy(e);
-    void *ptrs[] = {b->d_prog, b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
+    void *ptrs[] = {b->dt_dev, b->d_prog, b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
                     b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev, b->zl_dev, b->dyn, b->dyn_ints, b->dyn_d1, b->energy, b->lag,
                     b->d1[0], b->d1[1], b->d1[2], b->d1[3], b->d1[4], b->d1[5], b->d1[6], b->d1[7], b->d1[8], b->d1[9], b->d1[10], b->d1[11]};
     for (void *p : ptrs) if (p) hipFree(p);
@@ -519,9 +524,40 @@ int tg_batch_step(tg_batch *b, double t2_new, const double *u1_host, const doubl
     return tg_batch_status(b, iterations_out, status_out);
 }
 
+// t1, t2 after n_steps steps from t2 with the uniform step dt or the batch's step-size list
+static int advance_times(tg_batch *b, int n_steps, double dt) {
+    if (!b->dt_host.empty() && !b->dt_by_trajectory) {
+        if ((size_t)n_steps > b->dt_host.size()) return fail(TG_ERR_INVALID, "rollout longer than the step-size list of tg_batch_set_step_sizes");
+        double t = b->t2, tp = b->t2;
+        for (int k = 0; k < n_steps; k++) { tp = t; t += b->dt_host[k]; }
+        b->t1 = tp; b->t2 = t;
+    } else {
+        b->t1 = b->t2 + (n_steps - 1) * dt;
+        b->t2 = b->t2 + n_steps * dt;
+    }
+    return TG_SUCCESS;
+}
+
+int tg_batch_set_step_sizes(tg_batch *b, int32_t count, const double *dt_host, int32_t by_trajectory) {
+    if (!b || count < 0 || (count > 0 && !dt_host)) return fail(TG_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));          // a launch in flight may still read the old list
+    if (b->dt_dev) { HIP_TRY(hipFree(b->dt_dev)); b->dt_dev = nullptr; }
+    b->dt_host.clear();
+    b->dt_by_trajectory = 0;
+    if (count == 0) return TG_SUCCESS;
+    for (int i = 0; i < count; i++) if (dt_host[i] == 0.0) return fail(TG_ERR_INVALID, "zero step size");
+    HIP_TRY(hipMalloc(&b->dt_dev, sizeof(double) * (size_t)count));
+    HIP_TRY(hipMemcpy(b->dt_dev, dt_host, sizeof(double) * (size_t)count, hipMemcpyHostToDevice));
+    b->dt_host.assign(dt_host, dt_host + count);
+    b->dt_by_trajectory = by_trajectory ? 1 : 0;
+    return TG_SUCCESS;
+}
+
 int tg_batch_rollout(tg_batch *b, int32_t n_steps, double dt, const double *U_dev, const double *K_dev, double *X_dev,
                      int32_t max_iterations) {
     if (!b || n_steps <= 0 || dt == 0.0) return fail(TG_ERR_INVALID, "bad arguments");
+    if (!b->dt_host.empty() && !b->dt_by_trajectory && (size_t)n_steps > b->dt_host.size()) return fail(TG_ERR_INVALID, "rollout longer than the step-size list");
     const tg::DevProg &P = b->P;
     if ((P.nu && !U_dev) || (P.nk && !K_dev)) return fail(TG_ERR_INVALID, "U / K device buffers required");
     HIP_TRY(hipSetDevice(b->device));
@@ -530,9 +566,7 @@ int tg_batch_rollout(tg_batch *b, int32_t n_steps, double dt, const double *U_de
     A.U = U_dev; A.K = K_dev; A.X = X_dev;
     int rc = launch(b, A);
     if (rc) return rc;
-    b->t1 = b->t2 + (n_steps - 1) * dt;
-    b->t2 = b->t2 + n_steps * dt;
-    return TG_SUCCESS;
+    return advance_times(b, n_steps, dt);
 }
 
 int tg_batch_rollout_closed_loop(tg_batch *b, int32_t n_steps, double dt, const double *Kproj_dev, int32_t group_size,
@@ -546,9 +580,7 @@ int tg_batch_rollout_closed_loop(tg_batch *b, int32_t n_steps, double dt, const 
     A.Kproj = Kproj_dev; A.bX = bX_dev; A.bU = bU_dev; A.Uout = U_dev; A.group_size = group_size; A.X = X_dev;
     int rc = launch(b, A);
     if (rc) return rc;
-    b->t1 = b->t2 + (n_steps - 1) * dt;
-    b->t2 = b->t2 + n_steps * dt;
-    return TG_SUCCESS;
+    return advance_times(b, n_steps, dt);
 }
 
 int tg_batch_rollout_closed_loop_subset(tg_batch *b, int32_t n_trajectories, int32_t n_steps, double dt, const double *Kproj_dev,
@@ -565,9 +597,7 @@ int tg_batch_rollout_closed_loop_subset(tg_batch *b, int32_t n_trajectories, int
     A.group_map = group_select_dev;
     int rc = launch(b, A);
     if (rc) return rc;
-    b->t1 = b->t2 + (n_steps - 1) * dt;
-    b->t2 = b->t2 + n_steps * dt;
-    return TG_SUCCESS;
+    return advance_times(b, n_steps, dt);
 }
 
 int tg_batch_rollout_stats(tg_batch *b, int64_t *total_iterations, int32_t *n_failed) {

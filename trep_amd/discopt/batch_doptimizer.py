@@ -96,10 +96,9 @@ class BatchDOptimizer(object):
             raise ValueError("Xd must be [S][N+1][nX] and Ud [S][N][nU]")
         if self.N != ds.kf():
             raise ValueError("the DSystem's time base has %d steps, the trajectories %d" % (ds.kf(), self.N))
-        steps = np.diff(ds.time)
-        if not np.allclose(steps, steps[0], rtol=1e-9, atol=1e-12):
-            raise NotImplementedError("the batched optimizer needs a uniform time base")
+        steps = np.diff(np.asarray(ds.time, dtype=float))
         self.dt, self.t0 = float(steps[0]), float(ds.time[0])
+        self._steps = None if np.allclose(steps, steps[0], rtol=1e-13, atol=0.0) else steps      # non-uniform time base
         self.armijo_beta = 0.7
         self.armijo_alpha = 0.00001
         self.armijo_max_iterations = 30
@@ -121,6 +120,9 @@ class BatchDOptimizer(object):
         self.lin = BatchMidpointVI(sysm, S * N, device=device)
         self.arm = BatchMidpointVI(sysm, S * self.M, device=device)
         self.arm.predictor = predictor    # Newton start of the Armijo projections ("extrapolate": opt-in warm start)
+        if self._steps is not None:       # trajectory (s, k) of the horizon batch steps by t[k+1] - t[k]; step k of a projection too
+            self.lin.set_step_sizes(self._steps, by_trajectory=True)
+            self.arm.set_step_sizes(self._steps)
         # device state
         self.Xd, self.Ud = pool.upload(Xd), pool.upload(Ud)
         self.Q = pool.upload(np.asarray(Q, dtype=float).reshape(nX, nX))

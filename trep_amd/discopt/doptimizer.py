@@ -19,7 +19,7 @@ What is different is *where the parallelism is* (the reference is a serial Pytho
   decrease test is accepted, which is exactly what the sequential search returns.
 
 The Riccati / LQ sweeps (dlqr.py) stay on the host: sequential in k, O(N nX^3), negligible.
-A uniform time base is required for the k-parallel parts (every example uses one).
+Any time base works: the horizon batch steps trajectory k by t[k+1] - t[k], the rollouts take one step size per step.
 """
 from collections import namedtuple
 
@@ -129,11 +129,8 @@ class DOptimizer(object):
 
     # -- engines ---------------------------------------------------------------------------------
     def _dt(self):
-        t = self.dsys.time
-        steps = np.diff(t)
-        if not np.allclose(steps, steps[0], rtol=1e-9, atol=1e-12):
-            raise NotImplementedError("the k-parallel optimizer needs a uniform time base")
-        return float(steps[0])
+        """Step sizes of the DSystem's time base, one per step (the reference takes any time vector, dsystem.py:229-274)."""
+        return np.diff(np.asarray(self.dsys.time, dtype=float))
 
     def _lin_engine(self, n):
         if self._lin is None or self._lin.batch != n:
@@ -196,12 +193,14 @@ class DOptimizer(object):
         """A [N][nX][nX], B [N][nX][nU] about (X, U); leaves the N solved steps resident on the device."""
         ds = self.dsys
         N = len(X) - 1
-        dt = self._dt()
+        dts = self._dt()[:N]
         eng = self._lin_engine(N)
+        eng.set_step_sizes(dts, by_trajectory=True)      # trajectory k of the horizon batch steps by t[k+1] - t[k]
+        dt = dts[:, None, None]                            # ... and its A_k / B_k blocks carry 1/dt_k
         Q, p, _ = ds.split_state(X)
         u, rho = ds.split_input(U)
         eng.initialize_from_state(ds.time[0], Q[:-1], p[:-1])
-        iters, status = eng.step(ds.time[0] + dt, u if ds._nu else None, rho if ds._nrho else None,
+        iters, status = eng.step(ds.time[0] + float(dts[0]), u if ds._nu else None, rho if ds._nrho else None,
                                  q2_hint=Q[1:, :eng.nd])
         if (status != 0).any():
             raise ConvergenceError("linearisation: DEL solve failed at k=%s" % np.nonzero(status)[0][:5])
@@ -214,13 +213,13 @@ class DOptimizer(object):
         A[:, ds._slice_Qd, ds._slice_p] = d["q2_dp1"]
         A[:, ds._slice_p, ds._slice_Q] = d["p2_dq1"]
         A[:, ds._slice_p, ds._slice_p] = d["p2_dp1"]
-        A[:, ds._slice_v, ds._slice_Qk] = np.diag(np.ones(ds._nv) * -1.0 / dt)
+        A[:, ds._slice_v, ds._slice_Qk] = -np.eye(ds._nv)[None] / dt
         B[:, ds._slice_Qd, ds._slice_u] = d["q2_du1"]
         B[:, ds._slice_Qd, ds._slice_rho] = d["q2_dk2"]
         B[:, ds._slice_Qk, ds._slice_rho] = np.eye(ds._nrho)
         B[:, ds._slice_p, ds._slice_u] = d["p2_du1"]
         B[:, ds._slice_p, ds._slice_rho] = d["p2_dk2"]
-        B[:, ds._slice_v, ds._slice_rho] = np.diag(np.ones(ds._nrho) * 1.0 / dt)
+        B[:, ds._slice_v, ds._slice_rho] = np.eye(ds._nrho)[None] / dt
         return A, B
 
     def calc_feedback_controller(self, X, U):

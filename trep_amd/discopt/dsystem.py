@@ -251,33 +251,24 @@ class DSystem(_Packing):
     # -- projection onto the trajectory manifold (dsystem.py:426-494) ----------------------------------
     def project(self, bX, bU, Kproj=None):
         """X[0] = bX[0]; U[k] = bU[k] - Kproj[k] (X[k] - bX[k]); X[k+1] = f(X[k], U[k], k).
-        The N dependent steps run as one closed-loop device rollout when the time base is uniform."""
+        The N dependent steps run as one closed-loop device rollout (one step size per step)."""
         bX, bU = np.asarray(bX, dtype=float), np.asarray(bU, dtype=float)
         if Kproj is None:
             Kproj = self.calc_feedback_controller(bX, bU)
         steps = np.diff(self._time)
         N = len(bX) - 1
-        if N > 0 and np.allclose(steps, steps[0], rtol=1e-9, atol=1e-12):
-            eng = self._projection_engine()
-            Q0, p0, _ = self.split_state(bX[0])
-            eng.initialize_from_state(self._time[0], Q0[None], p0[None])
-            nX, nU = eng.rollout_closed_loop(N, float(steps[0]), np.asarray(Kproj)[None], bX[None], bU[None])
-            _, status = eng.status()
-            if status[0] != 0:
-                from ..errors import ConvergenceError
-                raise ConvergenceError("project: DEL solve failed")
-            nX[0, 0, :] = bX[0]
-            return self.trajectory_return(nX[0], nU[0])
-        nX, nU = np.zeros(bX.shape), np.zeros(bU.shape)
-        nX[0] = bX[0]
-        for k in range(N):
-            nU[k] = bU[k] - np.dot(Kproj[k], nX[k] - bX[k])
-            if k == 0:
-                self.set(nX[k], nU[k], k, xk_hint=bX[k + 1])
-            else:
-                self.step(nU[k], xk_hint=bX[k + 1])
-            nX[k + 1] = self.f()
-        return self.trajectory_return(nX, nU)
+        if N == 0:
+            return self.trajectory_return(bX.copy(), bU.copy())
+        eng = self._projection_engine()
+        Q0, p0, _ = self.split_state(bX[0])
+        eng.initialize_from_state(self._time[0], Q0[None], p0[None])
+        nX, nU = eng.rollout_closed_loop(N, steps[:N], np.asarray(Kproj)[None], bX[None], bU[None])   # any time base
+        _, status = eng.status()
+        if status[0] != 0:
+            from ..errors import ConvergenceError
+            raise ConvergenceError("project: DEL solve failed")
+        nX[0, 0, :] = bX[0]
+        return self.trajectory_return(nX[0], nU[0])
 
     def _projection_engine(self):
         if getattr(self, "_proj", None) is None:

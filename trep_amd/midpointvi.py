@@ -101,6 +101,9 @@ class BatchMidpointVI(object):
             self.tolerance = tol
             self.predictor = pred
             self.exact_pivot = exact
+        ss = getattr(self, "_step_sizes", None)
+        if ss is not None:
+            self.set_step_sizes(ss[0], ss[1])
         return True
 
     def close(self):
@@ -119,6 +122,29 @@ class BatchMidpointVI(object):
             self.close()
         except Exception:
             pass
+
+    def set_step_sizes(self, dts=None, by_trajectory=False):
+        """Non-uniform time base (include/trep_amd.h, tg_batch_set_step_sizes): `dts` replaces the scalar dt of the rollouts
+        (step k uses dts[k]) or, with by_trajectory, of a one-step batch (trajectory t uses dts[t % len(dts)]).  None clears."""
+        if dts is None:
+            _lib.check(self._L.tg_batch_set_step_sizes(self._h, 0, None, 0))
+            self._step_sizes = None
+            return
+        d = np.ascontiguousarray(dts, dtype=np.float64).reshape(-1)
+        _lib.check(self._L.tg_batch_set_step_sizes(self._h, len(d), d.ctypes.data, 1 if by_trajectory else 0))
+        self._step_sizes = (d.copy(), bool(by_trajectory))
+
+    @staticmethod
+    def _dt_argument(dt, n_steps):
+        """(scalar dt for the C call, step-size list or None): rollouts accept a scalar or one step size per step."""
+        if np.ndim(dt) == 0:
+            return float(dt), None
+        d = np.ascontiguousarray(dt, dtype=np.float64).reshape(-1)
+        if len(d) != n_steps:
+            raise ValueError("expected %d step sizes, got %d" % (n_steps, len(d)))
+        if np.allclose(d, d[0], rtol=1e-13, atol=0.0):
+            return float(d[0]), None
+        return float(d[0]), d
 
     @property
     def exact_pivot(self):
@@ -307,8 +333,17 @@ class BatchMidpointVI(object):
                                             int(max_iterations)))
 
     def rollout(self, n_steps, dt, U=None, K=None, max_iterations=200):
-        """Convenience: upload U [B][N][nu] / K [B][N][nk], roll out, download X [B][N+1][nX]."""
+        """Convenience: upload U [B][N][nu] / K [B][N][nk], roll out, download X [B][N+1][nX].  `dt` is a scalar or one step
+        size per step (non-uniform time base)."""
         self.refresh()
+        dt, dts = self._dt_argument(dt, n_steps)
+        if dts is not None:
+            saved = getattr(self, "_step_sizes", None)
+            self.set_step_sizes(dts)
+            try:
+                return self.rollout(n_steps, dt, U, K, max_iterations)
+            finally:
+                self.set_step_sizes(*(saved if saved is not None else (None,)))
         B = self._batch
         U_dev = self.device_array(_lib.as_f64(U, (B, n_steps, self.nu))) if self.nu else None
         K_dev = self.device_array(_lib.as_f64(K, (B, n_steps, self.nk))) if self.nk else None
@@ -324,8 +359,17 @@ class BatchMidpointVI(object):
 
     def rollout_closed_loop(self, n_steps, dt, Kproj, bX, bU, group_size=1, max_iterations=200):
         """Projection-operator rollout: U_k = bU_k - Kproj_k (X_k - bX_k) evaluated in the kernel.
-        Kproj [groups][N][nU][nX], bX [B][N+1][nX], bU [B][N][nU] (host arrays); returns (X, U)."""
+        Kproj [groups][N][nU][nX], bX [B][N+1][nX], bU [B][N][nU] (host arrays); returns (X, U).  `dt`: scalar or one step
+        size per step."""
         self.refresh()
+        dt, dts = self._dt_argument(dt, n_steps)
+        if dts is not None:
+            saved = getattr(self, "_step_sizes", None)
+            self.set_step_sizes(dts)
+            try:
+                return self.rollout_closed_loop(n_steps, dt, Kproj, bX, bU, group_size, max_iterations)
+            finally:
+                self.set_step_sizes(*(saved if saved is not None else (None,)))
         B, nX, nU = self._batch, self.nX, self.nU
         groups = (B + group_size - 1) // group_size
         K_dev = self.device_array(_lib.as_f64(Kproj, (groups, n_steps, nU, nX)))
