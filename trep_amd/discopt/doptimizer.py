@@ -322,21 +322,34 @@ class DOptimizer(object):
 
     # -- iteration --------------------------------------------------------------------------------------
     def step(self, iteration, X, U, method='steepest'):
+        """One iteration of the projection-operator descent.  Semantics of the reference's ``DOptimizer.step``
+        (doptimizer.py:462-506), written as a loop over the method ladder instead of its recursion:
+
+        1. build the descent direction of ``method`` about (X, U) and its directional derivative ``dcost0``;
+        2. a direction that is not a descent direction (dcost0 > 0) demotes the method (newton -> quasi -> steepest,
+           ``select_fallback_method``) and step 1 is repeated;
+        3. |dcost0| below ``descent_tolerance`` ends the optimisation: returns (True, X, U, dcost0, cost0) unchanged;
+        4. otherwise the Armijo search picks the step length along the direction (every candidate projected by a
+           closed-loop rollout, all candidates in one batch) and the new trajectory is returned with done = False.
+        The monitor sees the same sequence of events as the reference's."""
         self.monitor.step_begin(iteration)
-        (Kproj, dX, dU, Q, R, S) = self.calc_descent_direction(X, U, method)
-        cost0 = self.calc_cost(X, U)
-        dcost0 = self.calc_dcost(X, U, dX, dU)
-        self.monitor.step_info(method, cost0, dcost0, X, U, dX, dU, Kproj)
-        if dcost0 > 0:
-            fallback = self.select_fallback_method(iteration, method)
-            self.monitor.step_method_failure(method, cost0, dcost0, fallback)
-            return self.step(iteration, X, U, fallback)
+        while True:
+            direction = self.calc_descent_direction(X, U, method)
+            cost0 = self.calc_cost(X, U)
+            dcost0 = self.calc_dcost(X, U, direction.dX, direction.dU)
+            self.monitor.step_info(method, cost0, dcost0, X, U, direction.dX, direction.dU, direction.Kproj)
+            if dcost0 <= 0:
+                break
+            demoted = self.select_fallback_method(iteration, method)     # raises for 'steepest': nothing left to try
+            self.monitor.step_method_failure(method, cost0, dcost0, demoted)
+            method = demoted
+            self.monitor.step_begin(iteration)      # the reference re-enters step() here
         if abs(dcost0) < self.descent_tolerance:
             self.monitor.step_termination(cost0, dcost0)
             return self.step_return(True, X, U, dcost0, cost0)
-        (X, U, cost1) = self.armijo_search(X, U, Kproj, dX, dU)
-        self.monitor.step_completed(method, cost1, X, U)
-        return self.step_return(False, X, U, dcost0, cost1)
+        found = self.armijo_search(X, U, direction.Kproj, direction.dX, direction.dU)
+        self.monitor.step_completed(method, found.cost1, found.nX, found.nU)
+        return self.step_return(False, found.nX, found.nU, dcost0, found.cost1)
 
     def armijo_simulate(self, bX, bU, Kproj):
         """Project (bX, bU) like DSystem.project; reports failure instead of raising (doptimizer.py:405-428).  The
