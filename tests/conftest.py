@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # compile the checker (a `make` child process) before any test initialises the GPU in this process
+    try:
+        from oracle import oracle as _oracle
+        _oracle.build()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

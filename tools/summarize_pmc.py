@@ -9,20 +9,21 @@ import csv
 import json
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ROLLOUT_KERNELS = ("k_spec<0>", "k_spec<(int)0>", "k_run<64, 0")   # system-specialised / generic rollout kernel
 src = "gpurun_out/%s" % tag
 
 
 def mean_counter(path, kernel_substr):
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kernel_substr in r["Kernel_Name"]]
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if any(k in r["Kernel_Name"] for k in kernel_substr)]
     return sum(vals) / len(vals), len(vals)
 
 
-fetch_kb, nf = mean_counter(src + "/pmc_fetch.csv", "k_run<64, 0")
-write_kb, nw = mean_counter(src + "/pmc_write.csv", "k_run<64, 0")
+fetch_kb, nf = mean_counter(src + "/pmc_fetch.csv", ROLLOUT_KERNELS)
+write_kb, nw = mean_counter(src + "/pmc_write.csv", ROLLOUT_KERNELS)
 bench = json.load(open(src + "/bench.json"))
 out = {
-    "kernel": "k_run<64, 0, false> (rollout)",
+    "kernel": "k_spec<0> (system-specialised rollout; k_run<64, 0, false> when run with --no-specialize)",
     "workload": bench["config"]["workload"],
     "global_batch": bench["config"]["global_batch"], "rollout_steps": bench["config"]["rollout_steps"],
     "FETCH_SIZE_kB_raw": fetch_kb, "WRITE_SIZE_kB": write_kb, "dispatches_averaged": [nf, nw],

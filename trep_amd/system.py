@@ -9,8 +9,10 @@ cache_index, config.masses) are exactly what the device library consumes
 (``trep_amd.descriptor``) and are checked bit-for-bit against tables dumped from
 the reference (tests/test_topology.py).
 
-Continuous dynamics (System.f & friends), SLSQP constraint satisfaction and
-.mat I/O are outside the MidpointVI hot path and are not provided.
+Next to the hot path the class also offers the continuous dynamics -- ``f``, ``lambda_``, their first
+derivatives (analytic kernels) and second derivatives (batched differences of the first-derivative kernel), energies
+and Lagrangian derivatives -- ``satisfy_constraints`` (SLSQP on the host, gradients from the device) and the
+trajectory ``.mat`` files (``save_trajectory`` / ``load_trajectory``).
 """
 import numpy as np
 
