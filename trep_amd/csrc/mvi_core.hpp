@@ -1174,14 +1174,16 @@ struct Core {
             const int r = __builtin_amdgcn_readfirstlane(63 - (int)(key & 0x3Fu));
             if (on && ok && !(__uint_as_float(key & ~0x3Fu) > 1.0e-20f)) ok = false;
             used |= 1u << r;
-            // this lane's pivot-row entries: 0/1-weighted sums (r is uniform but not a compile-time index)
-            double p0 = 0.0, p1 = 0.0;
+            // the pivot column in registers first (wave-uniform addresses: LDS broadcasts, all in flight together): a load inside
+            // a `(i == r) ? .. : ..` arm turns into a scalar branch with its own s_waitcnt per row
+            double cb[NR];
 #pragma unroll
-            for (int i = 0; i < NR; i++) {
-                const double e = (i == r) ? 1.0 : 0.0;
-                p0 = fma(e, a0[i], p0); p1 = fma(e, a1[i], p1);
-            }
-            const double piv = colbuf[r];
+            for (int i = 0; i < NR; i++) cb[i] = colbuf[i];
+            // this lane's pivot-row entries and the pivot: r is wave-uniform but not a compile-time register index, so a chain of
+            // uniform branches picks them (a 0/1-weighted FMA sum is NR dependent fp64 FMAs at ~30 cycles each)
+            double p0 = 0.0, p1 = 0.0, piv = 1.0;
+#pragma unroll
+            for (int i = 0; i < NR; i++) if (i == r) { p0 = a0[i]; p1 = a1[i]; piv = cb[i]; }
             double inv = __builtin_amdgcn_rcp(piv);
             inv = fma(inv, fma(-piv, inv, 1.0), inv);
             inv = fma(inv, fma(-piv, inv, 1.0), inv);
@@ -1189,7 +1191,7 @@ struct Core {
             const double ginv = (on && ok) ? inv : 0.0;
 #pragma unroll
             for (int i = 0; i < NR; i++) {
-                const double l = (i == r) ? 0.0 : colbuf[i] * ginv;     // uniform address: one LDS broadcast read
+                const double l = cb[i] * ((i == r) ? 0.0 : ginv);
                 a0[i] = fma(-l, p0, a0[i]); a1[i] = fma(-l, p1, a1[i]);
             }
             // the next step overwrites colbuf: its reads above are ordered before those writes (same wavefront, in-order LDS)
