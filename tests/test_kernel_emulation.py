@@ -87,7 +87,7 @@ def test_emulated_first_derivatives_match_reference(name):
         Br[nq:nqd, :nu], Br[nq:nqd, nu:] = out["p2_du1"][0].T, out["p2_dk2"][0].T
         Br[nd:nq, nu:] = np.eye(nk)
         Br[nqd:, nu:] = np.eye(nk) / DT
-        assert relerr(A[0], Ar) < 1e-13 and relerr(B[0], Br) < 1e-13, (name, s_)   # 1/dt from t2 - t1
+        assert relerr(A[0], Ar) < 1e-12 and relerr(B[0], Br) < 1e-12, (name, s_)   # same numbers up to the summation order of the two output paths; 1/dt from t2 - t1
 
 
 def oracle_hz(o, d, z):

@@ -222,6 +222,8 @@ TG_HD void team_argmax(double &v, int &i) {
 
 // SPRINGS: the spring potentials (ConfigSpring, LinearSpring) and the plane constraints are compiled in only for systems that have them, so
 // that the spring-free kernels keep their instruction stream and register allocation.
+template <int V> struct IntTag { static constexpr int value = V; };
+
 template <int TEAM, bool SPRINGS = false, class PROG = CProg>
 struct Core {
     TG_HD bool has_cs() const { return SPRINGS && P.has_cs; }
@@ -1049,8 +1051,13 @@ struct Core {
     //      the pivot SEQUENCE can differ; gj_rows_exact() reproduces it exactly (RunArgs::exact_pivot, tg_batch_set_pivot_rule)
     //      at +9 % rollout time -- each variant of an in-line exact test (position bookkeeping +2.3 %, tie block +3.4 %, exact
     //      singular test +3.7 %; a branch-free "detect and redo" fires on 95 % of the solves) was measured and rejected.
+#if defined(TG_GJ_INLINE)
+#define TG_GJ_ATTR __forceinline__
+#else
+#define TG_GJ_ATTR __noinline__
+#endif
     template <int N, bool TRACE = false>
-    static __device__ __noinline__ bool gj_rows(bool on, double *A_generic, int n, int ld, int lane, int *trace = nullptr) {
+    static __device__ TG_GJ_ATTR bool gj_rows(bool on, double *A_generic, int n, int ld, int lane, int *trace = nullptr) {
         typedef __attribute__((address_space(3))) double lds_double;
         lds_double *A = (lds_double *)A_generic;
         double row[N], rhs = 0.0, scale = 0.0, diag = 1.0;
@@ -1420,17 +1427,22 @@ struct Core {
             if (on) {
                 const int nX = P.nX, nU = nu + nk, nqd = nq + nd;
                 double *Ao = A.A_out + t * (size_t)nX * nX, *Bo = A.B_out + t * (size_t)nX * nU;
-                // p2 derivative = T12 / T22 row + T22' x: four output rows per pass share the loads of x
-                for (int o0 = 0; o0 < nd; o0 += 4) TG_FOR(vv, nX + nU) {
-                    double x[4] = {NAN, NAN, NAN, NAN}, p[4] = {NAN, NAN, NAN, NAN};
+                // p2 derivative = T12 / T22 row + T22' x: OB output rows per pass share the loads of x and run as OB independent
+                // accumulation chains (a single chain is nd dependent fp64 FMAs at ~30 cycles each)
+                constexpr int OB = 8;
+                for (int o0 = 0; o0 < nd; o0 += OB) TG_FOR(vv, nX + nU) {
+                    double x[OB], p[OB];
+#pragma unroll
+                    for (int j = 0; j < OB; j++) { x[j] = NAN; p[j] = NAN; }
                     if (vv >= nqd && vv < nX) {                           // columns of the v part of X
-                        for (int j = 0; j < 4; j++) { x[j] = 0.0; p[j] = 0.0; }
+#pragma unroll
+                        for (int j = 0; j < OB; j++) { x[j] = 0.0; p[j] = 0.0; }
                     } else if (ok) {
                         const int sv = vv < nqd ? vv : vv - nk;           // index among (q1, p1, u1, k2)
                         const int kind = sv < nq ? 0 : (sv < nqd ? 1 : (sv < nqd + nu ? 2 : 3));
                         const int i = kind == 0 ? sv : (kind == 3 ? sv - nqd - nu : 0);
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
+                        for (int j = 0; j < OB; j++) {
                             const int o = o0 + j < nd ? o0 + j : nd - 1;
                             x[j] = AUG[o * ld + nf + sv];
                             p[j] = kind == 0 ? T12[i * nd + o] : (kind == 3 ? T22[(nd + i) * nd + o] : 0.0);
@@ -1440,15 +1452,16 @@ struct Core {
                             const double a = AUG[i2 * ld + nf + sv];
                             const double *tr = T22 + i2 * nd;
 #pragma unroll
-                            for (int j = 0; j < 4; j++) p[j] += tr[o0 + j < nd ? o0 + j : nd - 1] * a;
+                            for (int j = 0; j < OB; j++) p[j] = fma(tr[o0 + j < nd ? o0 + j : nd - 1], a, p[j]);
                         }
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
+                    for (int j = 0; j < OB; j++) {
                         const int o = o0 + j;
-                        if (o >= nd) break;
-                        if (vv < nX) { Ao[(size_t)o * nX + vv] = x[j]; Ao[(size_t)(nq + o) * nX + vv] = p[j]; }
-                        else { Bo[(size_t)o * nU + vv - nX] = x[j]; Bo[(size_t)(nq + o) * nU + vv - nX] = p[j]; }
+                        if (o < nd) {
+                            if (vv < nX) { Ao[(size_t)o * nX + vv] = x[j]; Ao[(size_t)(nq + o) * nX + vv] = p[j]; }
+                            else { Bo[(size_t)o * nU + vv - nX] = x[j]; Bo[(size_t)(nq + o) * nU + vv - nX] = p[j]; }
+                        }
                     }
                 }
                 const double rdt = 1.0 / dt;
@@ -2308,84 +2321,92 @@ struct Core {
             TG_SYNC();
         }
         TG_D2STAMP(2);
-        // ---- assemble HZ, four columns per pass --------------------------------------------------------------
+        // ---- assemble HZ, CB columns per pass ------------------------------------------------------------------
         // tangents: y_b = (x_b, e_i for a k2 variable) with x_b = AUG[0..nd)[nf+b]; l_b = AUG[nd..nf)[nf+b].
         // HZ is symmetric; the value computed for (row a, column b) is stored at [b][a] so that the lanes of a phase
-        // write contiguous rows.  Four columns share every load of H22 / H12 (tangent products) and of the
-        // tangent matrix (row products): the loops are bound by LDS latency, not arithmetic.
+        // write contiguous rows.  CB columns share every load of H22 / H12 (tangent products) and of the
+        // tangent matrix (row products) and run as 2 CB independent accumulation chains.  CB = 8 when the three [CB][nq]
+        // scratch tables fit the J / W area (dead by now: 12 n_items doubles), else 4 in the `vec` area.
         const int first_k2 = nq + nd + nu;
-        double *hy = vec, *h12y = vec + 4 * nq, *g1l = vec + 8 * nq;     // [4][nq] each (vec and vec2 are adjacent)
-        for (int b0 = 0; b0 < R; b0 += 4) {
-            const int nb = R - b0 < 4 ? R - b0 : 4;
-            if (on) TG_FOR(j, nq) {
-                double a22[4] = {0, 0, 0, 0}, a12[4] = {0, 0, 0, 0}, ag[4] = {0, 0, 0, 0};
+        auto assemble = [&](auto cb_tag, double *scratch) {
+            constexpr int CB = decltype(cb_tag)::value;
+            double *hy = scratch, *h12y = scratch + CB * nq, *g1l = scratch + 2 * CB * nq;     // [CB][nq] each
+            for (int b0 = 0; b0 < R; b0 += CB) {
+                const int nb = R - b0 < CB ? R - b0 : CB;
+                if (on) TG_FOR(j, nq) {
+                    double a22[CB], a12[CB], ag[CB];
+#pragma unroll
+                    for (int c = 0; c < CB; c++) { a22[c] = 0.0; a12[c] = 0.0; ag[c] = 0.0; }
 #pragma unroll 2
-                for (int i2 = 0; i2 < nd; i2++) {
-                    const double h22 = H22[sym(j, i2)], h12 = H12[j * hl + i2];
-                    const double *yr = AUG + i2 * ld + nf + b0;
+                    for (int i2 = 0; i2 < nd; i2++) {
+                        const double h22 = H22[sym(j, i2)], h12 = H12[j * hl + i2];
+                        const double *yr = AUG + i2 * ld + nf + b0;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) { const double yb = yr[c < nb ? c : 0]; a22[c] += h22 * yb; a12[c] += h12 * yb; }
+                        for (int c = 0; c < CB; c++) { const double yb = yr[c < nb ? c : 0]; a22[c] = fma(h22, yb, a22[c]); a12[c] = fma(h12, yb, a12[c]); }
+                    }
+#pragma unroll
+                    for (int c = 0; c < CB; c++) if (c < nb && b0 + c >= first_k2) {
+                        a22[c] += H22[sym(j, nd + (b0 + c - first_k2))]; a12[c] += H12[j * hl + nd + (b0 + c - first_k2)];
+                    }
+                    for (int c0 = 0; c0 < nc; c0 += 4) {       // multiplier tangents, four constraints at a time: loads first
+                        double g[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) g[q] = c0 + q < nc ? G1[j * nc + c0 + q] : 0.0;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const double *lr = AUG + (nd + (c0 + q < nc ? c0 + q : 0)) * ld + nf + b0;
+#pragma unroll
+                            for (int c = 0; c < CB; c++) ag[c] = fma(g[q], lr[c < nb ? c : 0], ag[c]);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < CB; c++) { hy[c * nq + j] = a22[c]; h12y[c * nq + j] = a12[c]; g1l[c * nq + j] = ag[c]; }
                 }
+                TG_SYNC();
+                if (on) TG_FOR(a, R) {
+                    double acc[CB], s12[CB];
+                    // straight-line loop body (clamped row for the columns without an H12 term, weighted out below): a
+                    // branch per column would split the body into basic blocks, each waiting for its own LDS reads
+                    int hrow[CB];
 #pragma unroll
-                for (int c = 0; c < 4; c++) if (c < nb && b0 + c >= first_k2) {
-                    a22[c] += H22[sym(j, nd + (b0 + c - first_k2))]; a12[c] += H12[j * hl + nd + (b0 + c - first_k2)];
-                }
-                for (int c0 = 0; c0 < nc; c0 += 4) {       // multiplier tangents, four constraints at a time: loads first
-                    double g[4];
+                    for (int c = 0; c < CB; c++) { acc[c] = 0.0; s12[c] = 0.0; hrow[c] = (c < nb && b0 + c < nq) ? (b0 + c) * hl : 0; }
+#pragma unroll 2
+                    for (int i2 = 0; i2 < nd; i2++) {
+                        const double x = AUG[i2 * ld + nf + a];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) g[q] = c0 + q < nc ? G1[j * nc + c0 + q] : 0.0;
+                        for (int c = 0; c < CB; c++) {
+                            acc[c] = fma(x, hy[c * nq + i2], acc[c]);
+                            s12[c] = fma(H12[hrow[c] + i2], x, s12[c]);
+                        }
+                    }
+                    // row-dependent extras without divergent branches: clamped indices and 0/1 weights, so that all the LDS
+                    // reads of the epilogue can be in flight together
+                    const bool k2row = a >= first_k2, qrow = a < nq;
+                    const int ak = k2row ? nd + (a - first_k2) : 0, aq = qrow ? a : 0;
+                    const double wk = k2row ? 1.0 : 0.0, wq = qrow ? 1.0 : 0.0;
+                    double xl[8];                                  // multiplier tangents of this row (constraints in groups of 8)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const double *lr = AUG + (nd + (c0 + q < nc ? c0 + q : 0)) * ld + nf + b0;
+                    for (int q = 0; q < 8; q++) xl[q] = q < nc ? AUG[(nd + q) * ld + nf + a] : 0.0;
 #pragma unroll
-                        for (int c = 0; c < 4; c++) ag[c] += g[q] * lr[c < nb ? c : 0];
+                    for (int c = 0; c < CB; c++) {
+                        const int bcol = b0 + c;
+                        if (c >= nb) break;
+                        double v = acc[c] + wk * hy[c * nq + ak] + wq * (h12y[c * nq + aq] + g1l[c * nq + aq]);
+                        if (bcol < nq) {                           // uniform over the wavefront
+                            double sg = 0.0;
+#pragma unroll
+                            for (int q = 0; q < 8; q++) sg += (q < nc ? G1[bcol * nc + q] : 0.0) * xl[q];
+                            for (int cc = 8; cc < nc; cc++) sg += G1[bcol * nc + cc] * AUG[(nd + cc) * ld + nf + a];
+                            v += s12[c] + wk * H12[bcol * hl + ak] + sg + wq * H11[sym(aq, bcol)];
+                        }
+                        A.hz[(t * R + bcol) * R + a] = ok ? v : NAN;
                     }
                 }
-#pragma unroll
-                for (int c = 0; c < 4; c++) { hy[c * nq + j] = a22[c]; h12y[c * nq + j] = a12[c]; g1l[c * nq + j] = ag[c]; }
+                TG_SYNC();
             }
-            TG_SYNC();
-            if (on) TG_FOR(a, R) {
-                double acc[4] = {0, 0, 0, 0}, s12[4] = {0, 0, 0, 0};
-                // straight-line loop body (clamped row for the columns without an H12 term, weighted out below): a
-                // branch per column would split the body into basic blocks, each waiting for its own LDS reads
-                int hrow[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) hrow[c] = (c < nb && b0 + c < nq) ? (b0 + c) * hl : 0;
-#pragma unroll 4
-                for (int i2 = 0; i2 < nd; i2++) {
-                    const double x = AUG[i2 * ld + nf + a];
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        acc[c] += x * hy[c * nq + i2];
-                        s12[c] += H12[hrow[c] + i2] * x;
-                    }
-                }
-                // row-dependent extras without divergent branches: clamped indices and 0/1 weights, so that all the LDS
-                // reads of the epilogue can be in flight together
-                const bool k2row = a >= first_k2, qrow = a < nq;
-                const int ak = k2row ? nd + (a - first_k2) : 0, aq = qrow ? a : 0;
-                const double wk = k2row ? 1.0 : 0.0, wq = qrow ? 1.0 : 0.0;
-                double xl[8];                                  // multiplier tangents of this row (constraints in groups of 8)
-#pragma unroll
-                for (int q = 0; q < 8; q++) xl[q] = q < nc ? AUG[(nd + q) * ld + nf + a] : 0.0;
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int bcol = b0 + c;
-                    if (c >= nb) break;
-                    double v = acc[c] + wk * hy[c * nq + ak] + wq * (h12y[c * nq + aq] + g1l[c * nq + aq]);
-                    if (bcol < nq) {                           // uniform over the wavefront
-                        double sg = 0.0;
-#pragma unroll
-                        for (int q = 0; q < 8; q++) sg += (q < nc ? G1[bcol * nc + q] : 0.0) * xl[q];
-                        for (int cc = 8; cc < nc; cc++) sg += G1[bcol * nc + cc] * AUG[(nd + cc) * ld + nf + a];
-                        v += s12[c] + wk * H12[bcol * hl + ak] + sg + wq * H11[sym(aq, bcol)];
-                    }
-                    A.hz[(t * R + bcol) * R + a] = ok ? v : NAN;
-                }
-            }
-            TG_SYNC();
-        }
+        };
+        if (TEAM == 64 && 12 * P.n_items >= 24 * nq && P.o_W == P.o_J + 6 * P.n_items) assemble(IntTag<8>{}, S + P.o_J);
+        else assemble(IntTag<4>{}, vec);
         if (n_wrenches() && nu > 0) {
             // input blocks of the point forces: D1D3fm2 = D2D3fm2 = dt/2 F_dudq (midpointvi.c:1500-1512) couple an input
             // column with the total configuration tangent of the other variable:  HZ[a][u] += sum_i (dq1_i/da + dq2_i/da) Hu[i][u]
@@ -2421,8 +2442,15 @@ struct Core {
     // team-uniform convergence test (midpointvi.c:672-689)
     TG_HD bool solved(double tolerance) const {
         PROG &P = tg_fresh(this->P);
-        double norm = 0.0;
-        for (int i = 0; i < P.nd; i++) norm += S[P.o_f + i] * S[P.o_f + i];
+        // four partial sums: a single accumulator is a chain of nd dependent fp64 FMAs (~30 cycles each on this part)
+        double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+        int i = 0;
+        for (; i + 3 < P.nd; i += 4) {
+            const double a = S[P.o_f + i], b = S[P.o_f + i + 1], c = S[P.o_f + i + 2], d = S[P.o_f + i + 3];
+            n0 = fma(a, a, n0); n1 = fma(b, b, n1); n2 = fma(c, c, n2); n3 = fma(d, d, n3);
+        }
+        for (; i < P.nd; i++) n0 = fma(S[P.o_f + i], S[P.o_f + i], n0);
+        const double norm = (n0 + n1) + (n2 + n3);
         if (sqrt(norm) > tolerance) return false;
         for (int c = 0; c < P.nc; c++) if (fabs(S[P.o_f + P.nd + c]) > S[P.o_ctol + c]) return false;
         return true;
