@@ -600,9 +600,19 @@ struct Core {
             const int b = idx / 6, m = idx % 6;
             const int first = P.b_item_off[b], last = P.b_item_off[b + 1];
             double acc = 0.0;
-            for (int k = first; k < last; k++) {
-                S[P.o_W + 6 * k + m] = acc;
-                acc += S[P.o_J + 6 * k + m] * S[P.o_dqi + k];
+            // four items per trip, their loads ahead of the stores (an LDS store may alias the next load as far as the compiler
+            // knows, so a load-fma-store loop waits out the LDS latency once per item)
+            for (int k = first; k < last; k += 4) {
+                double jv[4], dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int kk = k + u < last ? k + u : last - 1;
+                    jv[u] = S[P.o_J + 6 * kk + m]; dv[u] = S[P.o_dqi + kk];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (k + u < last) { S[P.o_W + 6 * (k + u) + m] = acc; acc = fma(jv[u], dv[u], acc); }
+                }
             }
             S[P.o_vB + idx] = acc;
         }
@@ -754,9 +764,16 @@ struct Core {
         // matrix entry, so the accumulation uses LDS floating-point atomics (ds_add_f64).  One wavefront
         // owns the trajectory and its LDS operations retire in order, so the summation order -- and with
         // it the result -- is the same on every run.
-        if (on) TG_FOR(pp, P.n_npairs) {
-            const int *pw = P.pair4 + 4 * (size_t)pp;
-            const int ia = pw[0], ib = pw[1], ca = pw[2] & 0xFFFF, cb = pw[2] >> 16, b = pw[3];
+        if (on) for (int pp = tg_opaque(lane), r0 = 0, r1 = 0, r2 = 0, r3 = 0, first_ = 1; pp < P.n_npairs; pp += TEAM) {
+            // the record of the next trip is fetched while this trip computes (a table look-up per trip otherwise sits in
+            // front of the trip's LDS reads)
+            if (first_) { const int *p0 = P.pair4 + 4 * (size_t)pp; r0 = p0[0]; r1 = p0[1]; r2 = p0[2]; r3 = p0[3]; first_ = 0; }
+            const int ia = r0, ib = r1, ca = r2 & 0xFFFF, cb = r2 >> 16, b = r3;
+            {
+                const int pn = pp + TEAM < P.n_npairs ? pp + TEAM : pp;
+                const int *p1 = P.pair4 + 4 * (size_t)pn;
+                r0 = p1[0]; r1 = p1[1]; r2 = p1[2]; r3 = p1[3];
+            }
             const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
             const double *Ja = S + P.o_J + 6 * ia, *Jb = S + P.o_J + 6 * ib;
             const double *Wa = S + P.o_W + 6 * ia, *Wb = S + P.o_W + 6 * ib;
