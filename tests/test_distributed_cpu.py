@@ -79,3 +79,42 @@ def test_two_rank_gloo_gather_matches_single_process(tmp_path):
         g = np.load(os.path.join(str(tmp_path), "gather_%d.npy" % r))
         assert g.shape == (B, X.shape[2])
         assert np.array_equal(g, X[:, N, :])
+
+
+def _rendezvous_worker(rank, world, key, directory, queue):
+    import os
+    os.environ["TREPAMD_RUN_KEY"] = key
+    os.environ["TREPAMD_RENDEZVOUS_DIR"] = directory
+    from trep_amd import rccl
+    calls = []
+
+    def make_id():
+        calls.append(1)
+        return bytes(range(128))
+    blob, path = rccl.exchange_unique_id(rank, world, make_id, timeout=30.0)
+    queue.put((rank, blob, len(calls)))
+
+
+def test_rccl_unique_id_rendezvous_through_a_file(tmp_path):
+    """The torch-free launcher glue of trep_amd/rccl.py without a GPU: rank 0 makes the 128-byte id once and publishes it
+    atomically, the other ranks (started first, so they have to poll) read exactly those bytes."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, key = 3, "cpu-test-%d" % os.getpid()
+    procs = [ctx.Process(target=_rendezvous_worker, args=(r, world, key, str(tmp_path), q)) for r in (1, 2, 0)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=60) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+    assert [g[0] for g in got] == [0, 1, 2]
+    assert all(g[1] == bytes(range(128)) for g in got)
+    assert [g[2] for g in got] == [1, 0, 0]          # only rank 0 asked the library for an id
+    from trep_amd import rccl
+    os.environ["TREPAMD_RUN_KEY"] = key
+    os.environ["TREPAMD_RENDEZVOUS_DIR"] = str(tmp_path)
+    try:
+        assert os.path.exists(rccl._rendezvous_path())
+    finally:
+        del os.environ["TREPAMD_RUN_KEY"], os.environ["TREPAMD_RENDEZVOUS_DIR"]
