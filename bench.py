@@ -324,7 +324,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
-                         "kernel": "k_run<%d> (rollout)" % r["info"]["team"],
+                         "kernel": ("k_spec<0> (system-specialised rollout, team %d)" if r["specialised"] else "k_run<%d, 0> (generic rollout)") % r["info"]["team"],
                          "kernel_avg_ms": 1e3 * avg_kernel_s, "launches": r["launches"],
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "path is fp64-VALU/LDS-latency bound, not HBM bound (SURVEY.md §8d)"},
@@ -338,6 +338,7 @@ def main():
         fp64 = pmc_fp64(b_local, N, "Puppet(string_constraints=True)") if (world == 1 and args.system == "puppet") else None
         if fp64:   # secondary figure: the path is compute/latency bound, so also say how far from the fp64 peak
             out["fp64"] = {"estimated_tflops": fp64[0] / avg_kernel_s / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                           "measured_v_fma_f64_ceiling_tflops": 51.6,   # tools/micro/mfma_f64_rate.hip, two waves per SIMD (profiles/r02_mfma_f64_rate.txt)
                            "frac": fp64[0] / avg_kernel_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                            "flop_per_del_step": fp64[0] / (b_local * N), "f64_wave_instructions_per_del_step": fp64[1] / (b_local * N), "source": fp64[2]}
         if discopt is not None:
