@@ -34,16 +34,13 @@ __global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DE
 }
 
 template <int MODE>
-int launch_mode(const tg::RunArgs *A, int grid, size_t lds, hipStream_t stream) {
+int launch_mode(const tg::RunArgs *A, tg::RunArgs *slot, int grid, size_t lds, hipStream_t stream) {
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spec<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
 #if defined(SPEC_ARGS_IN_MEMORY)
-    // a small ring of device-side argument blocks: a block is not reused before 16 later launches were issued (launches of one
-    // batch are stream ordered; the copy below is ordered with the launch on the same stream)
-    static tg::RunArgs *ring = nullptr;
-    static unsigned next = 0;
-    if (!ring && hipMalloc(&ring, 16 * sizeof(tg::RunArgs)) != hipSuccess) return 1;
-    tg::RunArgs *slot = ring + (next++ % 16);
+    // `slot` is the batch's own device-side argument block: copy and kernel are ordered on the batch's stream, so the block is
+    // never rewritten before the previous launch that reads it has finished (the host copy is staged before the call returns)
+    if (!slot) return 3;
     if (hipMemcpyAsync(slot, A, sizeof(tg::RunArgs), hipMemcpyHostToDevice, stream) != hipSuccess) return 1;
     hipLaunchKernelGGL(k_spec<MODE>, dim3(grid), dim3(64), lds, stream, (const tg::RunArgs *)slot);
 #else
@@ -67,12 +64,12 @@ int tg_spec_modes(void) {
 #endif
     return m;
 }
-int tg_spec_launch(int mode, const tg::RunArgs *A, int grid, size_t lds, void *stream) {
+int tg_spec_launch(int mode, const tg::RunArgs *A, tg::RunArgs *device_slot, int grid, size_t lds, void *stream) {
     switch (mode) {
-    case tg::MODE_ROLLOUT: return launch_mode<tg::MODE_ROLLOUT>(A, grid, lds, (hipStream_t)stream);
+    case tg::MODE_ROLLOUT: return launch_mode<tg::MODE_ROLLOUT>(A, device_slot, grid, lds, (hipStream_t)stream);
 #if defined(SPEC_DERIVATIVES)
-    case tg::MODE_DERIV1: return launch_mode<tg::MODE_DERIV1>(A, grid, lds, (hipStream_t)stream);
-    case tg::MODE_DERIV2Z: return launch_mode<tg::MODE_DERIV2Z>(A, grid, lds, (hipStream_t)stream);
+    case tg::MODE_DERIV1: return launch_mode<tg::MODE_DERIV1>(A, device_slot, grid, lds, (hipStream_t)stream);
+    case tg::MODE_DERIV2Z: return launch_mode<tg::MODE_DERIV2Z>(A, device_slot, grid, lds, (hipStream_t)stream);
 #endif
     default: return 2;
     }

@@ -60,7 +60,8 @@ struct tg_batch {
     tg::DevProg *d_prog = nullptr;   // the same view in device memory: what the kernels read (constant address space)
     // optional system-specialised rollout kernel (tg_batch_load_specialized): launcher exported by a generated library
     void *spec_lib = nullptr;
-    int (*spec_launch)(int, const tg::RunArgs *, int, size_t, void *) = nullptr;
+    int (*spec_launch)(int, const tg::RunArgs *, tg::RunArgs *, int, size_t, void *) = nullptr;
+    tg::RunArgs *d_args = nullptr;   // device-side argument block of the specialised kernels (rewritten per launch, stream ordered)
     int spec_modes = 0;
     int *d_ints = nullptr;
     double *d_dbls = nullptr;
@@ -211,7 +212,7 @@ int launch(tg_batch *b, tg::RunArgs &A) {
     }
     int rc;
     if (b->spec_launch && ((b->spec_modes >> A.mode) & 1)) {
-        rc = b->spec_launch(A.mode, &A, grid, lds, (void *)b->stream) == 0 ? TG_SUCCESS : fail(TG_ERR_HIP, "specialised kernel launch failed");
+        rc = b->spec_launch(A.mode, &A, b->d_args, grid, lds, (void *)b->stream) == 0 ? TG_SUCCESS : fail(TG_ERR_HIP, "specialised kernel launch failed");
     } else
     rc = team == 64 ? launch_team<64>(b, A, grid, lds) : (team == 16 ? launch_team<16>(b, A, grid, lds)
              : (team == 4 ? launch_team<4>(b, A, grid, lds) : launch_team<1>(b, A, grid, lds)));
@@ -420,7 +421,7 @@ void tg_batch_destroy(tg_batch *b) {
     if (b->stream) hipStreamSynchronize(b->stream);
     for (auto &e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : b->pool) hipEventDestroy(e);
-    void *ptrs[] = {b->dt_dev, b->d_prog, b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
+    void *ptrs[] = {b->d_args, b->dt_dev, b->d_prog, b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
                     b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev, b->zl_dev, b->dyn, b->dyn_ints, b->dyn_d1, b->energy, b->lag,
                     b->d1[0], b->d1[1], b->d1[2], b->d1[3], b->d1[4], b->d1[5], b->d1[6], b->d1[7], b->d1[8], b->d1[9], b->d1[10], b->d1[11]};
     for (void *p : ptrs) if (p) hipFree(p);
@@ -975,7 +976,7 @@ int tg_batch_load_specialized(tg_batch *b, const char *library_path) {
     if (!b || !library_path) return fail(TG_ERR_INVALID, "null argument");
     void *h = dlopen(library_path, RTLD_NOW | RTLD_LOCAL);
     if (!h) return fail(TG_ERR_INVALID, std::string("cannot load ") + library_path + ": " + (dlerror() ? dlerror() : "?"));
-    auto launch_fn = reinterpret_cast<int (*)(int, const tg::RunArgs *, int, size_t, void *)>(dlsym(h, "tg_spec_launch"));
+    auto launch_fn = reinterpret_cast<int (*)(int, const tg::RunArgs *, tg::RunArgs *, int, size_t, void *)>(dlsym(h, "tg_spec_launch"));
     auto sizes_fn = reinterpret_cast<const int *(*)(void)>(dlsym(h, "tg_spec_sizes"));
     auto modes_fn = reinterpret_cast<int (*)(void)>(dlsym(h, "tg_spec_modes"));
     if (!launch_fn || !sizes_fn || !modes_fn) { dlclose(h); return fail(TG_ERR_INVALID, "not a specialised trep_amd kernel library"); }
@@ -983,6 +984,10 @@ int tg_batch_load_specialized(tg_batch *b, const char *library_path) {
     const int want[8] = {(int)sizeof(tg::DevProg), (int)sizeof(tg::RunArgs), P.nq, P.nd, P.nc, P.n_items, P.n_pairs, P.lds_per_team};
     const int *got = sizes_fn();
     for (int i = 0; i < 8; i++) if (got[i] != want[i]) { dlclose(h); return fail(TG_ERR_INVALID, "specialised kernel was built for a different system or library version"); }
+    if (!b->d_args) {
+        HIP_TRY(hipSetDevice(b->device));
+        if (hipMalloc(&b->d_args, sizeof(tg::RunArgs)) != hipSuccess) { dlclose(h); return fail(TG_ERR_HIP, "device allocation failed"); }
+    }
     if (b->spec_lib) dlclose(b->spec_lib);
     b->spec_lib = h; b->spec_launch = launch_fn; b->spec_modes = modes_fn();
     return TG_SUCCESS;
