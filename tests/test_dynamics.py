@@ -303,3 +303,24 @@ def test_gpu_dynamics_second_derivatives_match_reference(name):
         c = system.constraints[0]
         refl = g2[name + "_lam_ddqddq"][g2[name + "_states"][-1]]
         assert abs(system.lambda_ddqddq(c, q1, q2) - refl[q1.index, q2.index, c.index]) < 1e-8 * max(1.0, np.abs(refl).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["pendulum5", "scissor4", "puppet40", "spring_arm", "plane_link"])
+def test_gpu_higher_order_lagrangian_accessors_match_reference(name):
+    """System.L_dqdqdq, L_ddqdqdq, L_ddqddqdq (third order) and L_ddqdqdqdq, L_ddqddqdqdq (fourth order), system.py:869-949:
+    fourth-order differences of the analytic second-order arrays of the Lagrangian kernel against the reference's table
+    look-ups, for seeded index tuples.  1e-8 / 1e-6 relative to the accessor's largest value over the tuples (or 1)."""
+    g = golden()
+    gh = dict(np.load(os.path.join(GOLDEN, "lagrangian_higher.npz")))
+    system, d = build(name)
+    system.q, system.dq, system.u, system.ddqk = g[name + "_q"][0], g[name + "_dq"][0], g[name + "_u"][0], g[name + "_ddqk"][0]
+    C = system.configs
+    idx, ref = gh[name + "_idx"], gh[name + "_vals"]
+    scale = np.maximum(1.0, np.abs(ref).max(axis=0))
+    worst = np.zeros(5)
+    for (a, b, c, e), r in zip(idx[:24], ref[:24]):
+        got = np.array([system.L_dqdqdq(C[a], C[b], C[c]), system.L_ddqdqdq(C[a], C[b], C[c]), system.L_ddqdqdqdq(C[a], C[b], C[c], C[e]),
+                        system.L_ddqddqdq(C[a], C[b], C[c]), system.L_ddqddqdqdq(C[a], C[b], C[c], C[e])])
+        worst = np.maximum(worst, np.abs(got - r) / scale)
+    assert (worst[[0, 1, 3]] < 1e-8).all() and (worst[[2, 4]] < 1e-6).all(), worst

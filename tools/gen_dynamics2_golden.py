@@ -68,5 +68,29 @@ def main():
     print("wrote %s (%.1f kB)" % (path, os.path.getsize(path) / 1e3))
 
 
+def lagrangian_higher():
+    """tests/golden/lagrangian_higher.npz: the reference's L_dqdqdq, L_ddqdqdq, L_ddqdqdqdq, L_ddqddqdq, L_ddqddqdqdq
+    (system.py:869-949) for seeded index tuples (biased to the first 14 configs so that the puppet's tuples share kinematic chains)."""
+    g = dict(np.load(os.path.join(REPO, "tests", "golden", "dynamics.npz")))
+    out = {}
+    rng = np.random.default_rng(5)
+    for name in ("pendulum5", "scissor4", "puppet40", "spring_arm", "plane_link"):
+        system = BUILDERS[name][0]()
+        system.q, system.dq, system.u, system.ddqk = g[name + "_q"][0], g[name + "_dq"][0], g[name + "_u"][0], g[name + "_ddqk"][0]
+        C = system.configs
+        n = min(len(C), 14)
+        idx = [tuple(int(x) for x in rng.integers(0, n, 4)) for _ in range(60)] + [(0, 0, 0, 0), (1, 1, 1, 1), (0, 1, 0, 1), (2, 1, 1, 2)]
+        idx = [t for t in idx if max(t) < len(C)]
+        vals = [[system.L_dqdqdq(C[a], C[b], C[c]), system.L_ddqdqdq(C[a], C[b], C[c]), system.L_ddqdqdqdq(C[a], C[b], C[c], C[d]),
+                 system.L_ddqddqdq(C[a], C[b], C[c]), system.L_ddqddqdqdq(C[a], C[b], C[c], C[d])] for (a, b, c, d) in idx]
+        out[name + "_idx"] = np.array(idx, dtype=np.int32)
+        out[name + "_vals"] = np.array(vals)
+        print(name, "largest |value| per accessor", np.abs(out[name + "_vals"]).max(axis=0), "non-zero", (np.abs(out[name + "_vals"]) > 1e-12).sum(axis=0))
+    np.savez_compressed(os.path.join(REPO, "tests", "golden", "lagrangian_higher.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["lagrangian_higher"]:
+        lagrangian_higher()
+    else:
+        main()

@@ -459,6 +459,65 @@ class System(object):
     def L_ddqddq(self, dq1, dq2):
         return float(self._lagrangian()["L_ddqddq"][dq1.index, dq2.index])
 
+    # -- third- and fourth-order derivatives of the Lagrangian (system.py:869-949; System_L_dqdqdq ... L_ddqddqdqdq, system.c:204-557)
+    def _lagrangian_batch(self, Q):
+        """L_dqdq, L_ddqdq, L_ddqddq [M][nq][nq] at the configurations Q [M][nq] (M <= 8) with the current rates."""
+        from .midpointvi import BatchMidpointVI
+        eng = getattr(self, "_lag_engine", None)
+        if eng is None or self._lag_engine_version != self._structure_version:
+            if eng is not None:
+                eng.close()
+            eng = self._lag_engine = BatchMidpointVI(self, 8)
+            self._lag_engine_version = self._structure_version
+        Qp = np.repeat(self.q[None], 8, axis=0)
+        Qp[:len(Q)] = Q
+        return eng.lagrangian(Qp, np.repeat(self.dq[None], 8, axis=0))
+
+    def _L_higher(self, name, i, j, wrt):
+        """d^n (name[i][j]) / dq_wrt[0] (dq_wrt[1]) with name in L_dqdq / L_ddqdq / L_ddqddq, n = len(wrt) in (1, 2): the
+        reference evaluates these from its third- and fourth-order frame tables; the device formulation has no such tables
+        (DESIGN.md section 3), so the ANALYTIC second-order arrays of the Lagrangian kernel are differenced -- fourth-order
+        central stencils, all stencil points in one launch.  Agreement with the reference: about 1e-10 (third order),
+        1e-7 (fourth order) relative to the largest entry."""
+        q0 = self.q
+        h = 1e-3 * np.maximum(1.0, np.abs(q0))
+        if len(wrt) == 1:
+            k = wrt[0]
+            Q = np.repeat(q0[None], 4, axis=0)
+            Q[:, k] += np.array([-2.0, -1.0, 1.0, 2.0]) * h[k]
+            f = self._lagrangian_batch(Q)[name][:4, i, j]
+            return float(np.dot(f, [1.0, -8.0, 8.0, -1.0]) / (12.0 * h[k]))
+        k, l = wrt
+        if k == l:
+            Q = np.repeat(q0[None], 5, axis=0)
+            Q[:, k] += np.array([-2.0, -1.0, 0.0, 1.0, 2.0]) * h[k]
+            f = self._lagrangian_batch(Q)[name][:5, i, j]
+            return float(np.dot(f, [-1.0, 16.0, -30.0, 16.0, -1.0]) / (12.0 * h[k] ** 2))
+        Q = np.repeat(q0[None], 8, axis=0)
+        signs = [(1, 1), (1, -1), (-1, 1), (-1, -1)]
+        for n, (a, b) in enumerate(signs):
+            Q[n, k] += a * h[k]; Q[n, l] += b * h[l]
+            Q[4 + n, k] += 2 * a * h[k]; Q[4 + n, l] += 2 * b * h[l]
+        f = self._lagrangian_batch(Q)[name][:, i, j]
+        d1 = (f[0] - f[1] - f[2] + f[3]) / (4.0 * h[k] * h[l])
+        d2 = (f[4] - f[5] - f[6] + f[7]) / (16.0 * h[k] * h[l])
+        return float((4.0 * d1 - d2) / 3.0)          # Richardson: the h^2 terms of the two mixed differences cancel
+
+    def L_dqdqdq(self, q1, q2, q3):
+        return self._L_higher("L_dqdq", q1.index, q2.index, (q3.index,))
+
+    def L_ddqdqdq(self, dq1, q2, q3):
+        return self._L_higher("L_ddqdq", dq1.index, q2.index, (q3.index,))
+
+    def L_ddqdqdqdq(self, dq1, q2, q3, q4):
+        return self._L_higher("L_ddqdq", dq1.index, q2.index, (q3.index, q4.index))
+
+    def L_ddqddqdq(self, dq1, dq2, q3):
+        return self._L_higher("L_ddqddq", dq1.index, dq2.index, (q3.index,))
+
+    def L_ddqddqdqdq(self, dq1, dq2, q3, q4):
+        return self._L_higher("L_ddqddq", dq1.index, dq2.index, (q3.index, q4.index))
+
     def _dynamics_deriv1(self):
         self._dynamics()                      # engine + the reference's side effect on Config.ddq
         d, status = self._dyn_engine.dynamics_deriv1(self.q[None], self.dq[None], self.u[None], self.ddqk[None])
