@@ -23,7 +23,6 @@ from collections import namedtuple
 import numpy as np
 
 from .. import _lib
-from ..errors import ConvergenceError
 from ..midpointvi import BatchMidpointVI
 
 METHODS = ("steepest", "quasi", "newton")

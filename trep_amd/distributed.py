@@ -7,7 +7,6 @@ line-search needs to see on every rank.  One process per GPU; ``torch.distribute
 process group (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
 torch is plumbing here, imported lazily; the integrator itself never needs it.
 """
-import numpy as np
 
 
 def shard_bounds(total, rank, world):
