@@ -384,9 +384,8 @@ __device__ __forceinline__ void lq_gj_wave(const double *G_generic, int ldw, int
         double p = 0.0, piv = 1.0;
 #pragma unroll
         for (int i = 0; i < NR; i++) if (i == r) { p = a[i]; piv = cb[i]; }
-        double inv = __builtin_amdgcn_rcp(piv);
-        inv = fma(inv, fma(-piv, inv, 1.0), inv);
-        inv = fma(inv, fma(-piv, inv, 1.0), inv);
+        double inv = __builtin_amdgcn_rcp(piv);            // seed + one cubic refinement: three dependent fp64 operations
+        { const double e = fma(-piv, inv, 1.0); inv = fma(inv, fma(e, e, e), inv); }
         if (lane == 0) { var[r] = k; dinv[r] = inv; }
         const double q = ok ? -(inv * p) : 0.0;    // a_i <- a_i - (c_i / pivot) p for the other rows
 #pragma unroll

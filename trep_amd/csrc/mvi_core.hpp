@@ -62,6 +62,29 @@ extern "C" __device__ __attribute__((const)) unsigned int __ockl_wfred_max_u32(u
 #define TG_STAMP(id) ((void)0)
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// 1/p to full precision: hardware seed (4.6e-8 relative, tools/micro/rcp_f64_accuracy.hip) and ONE cubic refinement
+// r (1 + e + e^2), e = 1 - p r: three dependent fp64 operations instead of the four of two Newton steps (a dependent fp64
+// operation costs ~30 cycles on this part); the error is e^3 ~ 1e-22 plus rounding.
+__device__ __forceinline__ double tg_rcp(double p) {
+    const double r = __builtin_amdgcn_rcp(p);
+    const double e = fma(-p, r, 1.0);
+    return fma(r, fma(e, e, e), r);
+}
+// max over lanes 0..31 of a wavefront (the register solvers hold at most 32 rows): four row-shift steps leave each 16-lane
+// row's maximum in its last lane; the two row maxima are combined on the scalar unit.  Two DPP steps shorter than the
+// library's full-wave reduction, and this sits on the critical path of every pivot step.
+__device__ __forceinline__ unsigned int tg_max_u32_lanes32(unsigned int v) {
+    unsigned int t;
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); v = t > v ? t : v;   // row_shr:1
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true); v = t > v ? t : v;   // row_shr:2
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true); v = t > v ? t : v;   // row_shr:4
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true); v = t > v ? t : v;   // row_shr:8
+    const unsigned int a = (unsigned int)__builtin_amdgcn_readlane((int)v, 15), b = (unsigned int)__builtin_amdgcn_readlane((int)v, 31);
+    return a > b ? a : b;
+}
+#endif
+
 namespace tg {
 
 enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3, MODE_DERIV2Z = 4, MODE_DYNAMICS = 5, MODE_DYN_DERIV1 = 6, MODE_ENERGY = 7, MODE_LAGRANGIAN = 8 };
@@ -1031,9 +1054,7 @@ struct Core {
             }
             if (TRACE && go && is_piv) trace[k] = lane;
             // 1/pivot: hardware seed + two Newton steps (the multipliers need not be correctly rounded)
-            double rp = __builtin_amdgcn_rcp(pkk);
-            rp = fma(rp, fma(-pkk, rp, 1.0), rp);
-            rp = fma(rp, fma(-pkk, rp, 1.0), rp);
+            double rp = tg_rcp(pkk);
             const double l = (go && mine && !is_piv) ? row[k] * rp : 0.0;
 #pragma unroll
             for (int j = k + 1; j < N; j++) row[j] = fma(-l, bcast(row[j]), row[j]);
@@ -1096,7 +1117,7 @@ struct Core {
             const float cand = (mine && mycol < 0) ? (float)fabs(row[k] * scale) : 0.0f;
             unsigned int key = (__float_as_uint(cand) & ~0x3Fu) | (unsigned int)(63 - (lane & 63));
             if (TEAM == 64) {
-                key = __ockl_wfred_max_u32(key);
+                key = tg_max_u32_lanes32(key);       // N <= 32: only lanes 0..31 hold rows (the others carry key 0 | lane bits)
             } else {
 #pragma unroll
                 for (int m = TEAM / 2; m >= 1; m >>= 1) {
@@ -1120,14 +1141,11 @@ struct Core {
                 }
                 return __shfl(v, src, TEAM);
             };
-            const double pkk = bcast(row[k]);
             const double prhs = bcast(rhs);
             const bool is_piv = mine && (lane & (TEAM - 1)) == src;
             if (TRACE && go && is_piv) trace[k] = lane;
-            // 1/pivot: hardware seed + two Newton steps (the multipliers need not be correctly rounded)
-            double rp = __builtin_amdgcn_rcp(pkk);
-            rp = fma(rp, fma(-pkk, rp, 1.0), rp);
-            rp = fma(rp, fma(-pkk, rp, 1.0), rp);
+            const double pkk = bcast(row[k]);
+            double rp = tg_rcp(pkk);          // 1/pivot (the multipliers need not be correctly rounded)
             const double l = (go && mine && !is_piv) ? row[k] * rp : 0.0;
 #pragma unroll
             for (int j = k + 1; j < N; j++) row[j] = fma(-l, bcast(row[j]), row[j]);
@@ -1208,9 +1226,7 @@ struct Core {
             double p0 = 0.0, p1 = 0.0, piv = 1.0;
 #pragma unroll
             for (int i = 0; i < NR; i++) if (i == r) { p0 = a0[i]; p1 = a1[i]; piv = cb[i]; }
-            double inv = __builtin_amdgcn_rcp(piv);
-            inv = fma(inv, fma(-piv, inv, 1.0), inv);
-            inv = fma(inv, fma(-piv, inv, 1.0), inv);
+            double inv = tg_rcp(piv);
             if (lane == 0 && on) { ((__attribute__((address_space(3))) int *)(scal + 2 * NR))[r] = k; dinv[r] = 1.0 / piv; }
             const double ginv = (on && ok) ? inv : 0.0;
 #pragma unroll
