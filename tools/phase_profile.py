@@ -7,9 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import trep_amd
 from trep_amd import systems, _lib
 
-NAMES = ["update+rates+step setup", "pose sweep (mid)", "attach+jacobians", "velocities", "residual", "pose sweep (q1/q2)",
+NAMES = ["update+rates+step setup", "pose sweep: chains (dual) | whole (mid)", "attach+jacobians", "velocities", "residual", "sin/cos (dual sweep) | pose sweep (q1/q2)",
          "attach+constraints", "newton init", "newton pairs", "GJ scales", "GJ pivot+swap", "GJ eliminate",
-         "converged?", "tail", "Gauss-Jordan (registers)", ""]
+         "converged?", "tail", "Gauss-Jordan (registers)", "local transforms (dual sweep)"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 system = systems.puppet()
@@ -29,4 +29,4 @@ it, st = mvi.status()
 print("B=%d N=%d  its/step %.2f  total cycles (traj 0) %.3e  per step %.0f" % (B, N, it.mean() / N, v.sum(), v.sum() / N))
 for n, c in zip(NAMES, v):
     if c:
-        print("  %-22s %12.0f  %5.1f%%  %8.0f /step" % (n, c, 100 * c / v.sum(), c / N))
+        print("  %-44s %12.0f  %5.1f%%  %8.0f /step" % (n, c, 100 * c / v.sum(), c / N))

@@ -426,6 +426,24 @@ struct Core {
         PROG &P = tg_fresh(this->P);
         double *sc = S + P.o_sc, *sc2 = S + P.o_J, *G = S + P.o_G, *G2 = S + P.o_W;
         const int nj = P.n_joints;
+        const int n12 = 12 * nj, n24 = 2 * n12;
+        // coefficient rows of local-transform entry idx2 (of the 2 x 12 x n_joints of both pose sets; clamped past the end).  They
+        // come from global memory (hundreds of cycles), so every trip's rows are requested one trip ahead -- the first
+        // trip's before the sin/cos pass, which does not need them.
+        struct Rows { double k0[4], k1[4], k2[4]; int j[4]; };
+        auto rows_of = [&](int first) {
+            Rows r;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx2 = first + u * TEAM;
+                const int idx = idx2 < n24 ? (idx2 >= n12 ? idx2 - n12 : idx2) : 0;
+                const int j = idx / 12, e = idx % 12;
+                const double *k = P.jcoef + 4 * (size_t)(16 * j + e);
+                r.k0[u] = k[0]; r.k1[u] = k[1]; r.k2[u] = k[2]; r.j[u] = j;
+            }
+            return r;
+        };
+        Rows cur = rows_of(lane);
         if (on) TG_FOR(idx, 2 * nj) {
             const bool second = idx >= nj;
             const int j = second ? idx - nj : idx;
@@ -435,33 +453,64 @@ struct Core {
             else { dst[0] = x; dst[1] = 0.0; }
         }
         TG_SYNC();
-        if (on) {
-            const int n12 = 12 * nj, n24 = 2 * n12;
-            for (int base = lane; base < n24; base += 4 * TEAM) {
-                double k0[4], k1[4], k2[4];
-                int jj[4];
+        TG_STAMP(5);
+        for (int b0 = 0; b0 < n24; b0 += 4 * TEAM) {       // (uniform trip count: unrolled when the schedule is compiled in)
+            const Rows nxt = b0 + 4 * TEAM < n24 ? rows_of(b0 + 4 * TEAM + lane) : cur;
+            if (on) {
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const int idx2 = base + u * TEAM;
-                    const bool ok = idx2 < n24;
-                    const int idx = ok ? (idx2 >= n12 ? idx2 - n12 : idx2) : 0;
-                    const int j = idx / 12, e = idx % 12;
-                    const double *k = P.jcoef + 4 * (size_t)(16 * j + e);
-                    k0[u] = k[0]; k1[u] = k[1]; k2[u] = k[2]; jj[u] = j;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int idx2 = base + u * TEAM;
+                    const int idx2 = b0 + lane + u * TEAM;
                     if (idx2 < n24) {
                         const bool second = idx2 >= n12;
                         const double *scx = second ? sc2 : sc;
-                        (second ? G2 : G)[second ? idx2 - n12 : idx2] = k0[u] + k1[u] * scx[2 * jj[u] + 1] + k2[u] * scx[2 * jj[u]];
+                        (second ? G2 : G)[second ? idx2 - n12 : idx2] = cur.k0[u] + cur.k1[u] * scx[2 * cur.j[u] + 1] + cur.k2[u] * scx[2 * cur.j[u]];
                     }
                 }
             }
+            cur = nxt;
         }
         TG_SYNC();
+        TG_STAMP(15);
         const int *sched = (const int *)(S + P.o_sched);
+        if (P.sched_ok == 2) {
+            // at most 8 chains per round: lanes 0-31 sweep the midpoint poses, lanes 32-63 the q2 poses -- one row recurrence
+            // per lane, so the instruction stream of a chain step is half that of two recurrences side by side
+            double *Gh = lane >= 32 ? G2 : G;
+            const int slot = (lane & 31) >> 2, row = lane & 3;
+            for (int r = 0; r < P.n_rounds; r++) {
+                if (on) {
+                    const int w0 = sched[2 * (16 * r + slot)];
+                    const int opar = sched[2 * (16 * r + slot) + 1];
+                    const int o0 = w0 & 0xFFFF, len = w0 >> 16;
+                    if (row < 3 && len > 0) {
+                        double p0, p1, p2, p3;
+                        if (opar >= 0) { const double *gp = Gh + opar + 4 * row; p0 = gp[0]; p1 = gp[1]; p2 = gp[2]; p3 = gp[3]; }
+                        else { p0 = row == 0 ? 1.0 : 0.0; p1 = row == 1 ? 1.0 : 0.0; p2 = row == 2 ? 1.0 : 0.0; p3 = 0.0; }
+                        double m[12];
+#pragma unroll
+                        for (int e = 0; e < 12; e++) m[e] = Gh[o0 + e];
+                        for (int s = 0; s < len; s++) {
+                            double *gj = Gh + o0 + 12 * s;
+                            double n[12];                                // next local transform: loads before this step's stores
+                            const int nx = s + 1 < len ? 12 : 0;
+#pragma unroll
+                            for (int e = 0; e < 12; e++) n[e] = gj[nx + e];
+                            const double v0 = p0 * m[0] + p1 * m[4] + p2 * m[8];
+                            const double v1 = p0 * m[1] + p1 * m[5] + p2 * m[9];
+                            const double v2 = p0 * m[2] + p1 * m[6] + p2 * m[10];
+                            const double v3 = p0 * m[3] + p1 * m[7] + p2 * m[11] + p3;
+                            double *out = gj + 4 * row;
+                            out[0] = v0; out[1] = v1; out[2] = v2; out[3] = v3;
+                            p0 = v0; p1 = v1; p2 = v2; p3 = v3;
+#pragma unroll
+                            for (int e = 0; e < 12; e++) m[e] = n[e];
+                        }
+                    }
+                }
+                TG_SYNC();
+            }
+            return;
+        }
         for (int r = 0; r < P.n_rounds; r++) {
             if (on) TG_FOR(idx, 64) {
                 const int row = idx & 3;
@@ -1179,7 +1228,7 @@ struct Core {
     //      gauss_jordan().  `scal` is 4*NR doubles of scratch (scale factors, pivot reciprocals, row -> variable
     //      map, current column).
     template <int NR>
-    static __device__ __noinline__ bool gj_cols(bool on, double *A_generic, int n, int w, int ld, double *scal_generic, int lane) {
+    static __device__ TG_GJ_ATTR bool gj_cols(bool on, double *A_generic, int n, int w, int ld, double *scal_generic, int lane) {
         typedef __attribute__((address_space(3))) double lds_double;
         lds_double *A = (lds_double *)A_generic, *scal = (lds_double *)scal_generic;
         lds_double *dinv = scal + NR;                      // pivot reciprocal of physical row i
@@ -2312,11 +2361,14 @@ struct Core {
                     // ---- eo: L_ddqddqdq(dq x, dq y; q o), alpha-weighted (system.c:491-530) ----
                     const double Eo = inner6(I, JxSx, Jy) + inner6(I, Jx, JySy);
                     // ---- dO, ey, ex: o in a dq slot, beta-weighted ----
-                    double PxJx[6], PyJy[6];
-                    bracket(qx + 12, Jx, PxJx); bracket(qy + 12, Jy, PyJy);    // [PJb_t, J_t] = sum_{o < t} beta_o [J_o, J_t]
-                    bracket(x < y ? PxJx : PyJy, Jhi, t1);                     // [[PJb_lo, J_lo], J_hi]
-                    const double DO = inner6(I, TJb, v2xy) + inner6(I, PxJx, Wy) + inner6(I, PyJy, Wx) + inner6(I, t1, v);
-                    double Ey = inner6(I, Jx, PyJy), Ex = inner6(I, Jy, PxJx);
+                    // (by lo / hi rather than x / y: choosing between two local arrays per lane would force both into scratch memory)
+                    const double *Whi = S + P.o_W + 6 * hi;
+                    double PJlo[6], PJhi[6];
+                    bracket(qlo + 12, Jlo, PJlo); bracket(qhi + 12, Jhi, PJhi);   // [PJb_t, J_t] = sum_{o < t} beta_o [J_o, J_t]
+                    bracket(PJlo, Jhi, t1);                                    // [[PJb_lo, J_lo], J_hi]
+                    const double DO = inner6(I, TJb, v2xy) + inner6(I, PJlo, Whi) + inner6(I, PJhi, Wlo) + inner6(I, t1, v);
+                    const double Ea = inner6(I, Jlo, PJhi), Eb = inner6(I, Jhi, PJlo);
+                    double Ey = x < y ? Ea : Eb, Ex = x < y ? Eb : Ea;         // (x == y: the same value)
                     if (x < y) Ey += inner6(I, Jxy, TJb);
                     else if (y < x) Ex += inner6(I, Jxy, TJb);
                     const double q_ = c8 * Q, dx = 0.25 * Dx, dy = 0.25 * Dy, eo = c2 * Eo, dO = 0.25 * DO, ey = c2 * Ey, ex = c2 * Ex;
@@ -2918,7 +2970,9 @@ struct Core {
 // every TG_SYNC.
 // MODE is a compile-time parameter so that every kernel mode gets its own register allocation (the
 // derivative modes are far larger than the rollout loop).
-template <int TEAM, int MODE, bool SPRINGS = false, class PROG = CProg, class ARGS = CArgs>
+// PIVOT: -1 the pivot rule is read from the arguments at run time (generic kernels); 0 / 1 compile the single-precision ranking /
+// the reference's exact rule in alone (specialised kernels: the variant not asked for is not in the kernel's call graph at all)
+template <int TEAM, int MODE, bool SPRINGS = false, class PROG = CProg, class ARGS = CArgs, int PIVOT = -1>
 TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj) {
     PROG &P = tg_fresh(P0);
     ARGS &A = A0;
@@ -3085,7 +3139,7 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj) {
             const int nb4 = (P.nf + 3) >> 2;   // matrix size in blocks of 4 rows
             if (TEAM >= 4 && 4 * nb4 <= TEAM && nb4 <= 8) {
                 double *Ad = S + P.o_Df;
-                if (A.exact_pivot) {
+                if (PIVOT < 0 ? A.exact_pivot != 0 : PIVOT == 1) {
                 switch (nb4) {
                 case 1: ok = Core<TEAM>::template gj_rows_exact<4>(!done, Ad, P.nf, P.df_ld, lane); break;
                 case 2: ok = Core<TEAM>::template gj_rows_exact<(TEAM >= 8 ? 8 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;

@@ -8,6 +8,8 @@
 // arithmetic changes -- it is the same template -- so results are bit-identical to the generic kernel.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "mvi_core.hpp"
 #include TG_SPEC_HEADER
 
@@ -22,7 +24,9 @@ namespace {
 #define SPEC_ARGS_REF ((void)0)
 #endif
 
-template <int MODE>
+// PIVOT (rollouts): 0 single-precision pivot ranking, 1 the reference's exact pivot rule -- two kernels, so that neither carries
+// the other's solver (registers, callee-saved spills) in its call graph
+template <int MODE, int PIVOT = 0>
 __global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z) ? 1 : 2) void k_spec(SPEC_KERNEL_ARGS) {
     SPEC_ARGS_REF;
     extern __shared__ double lds[];
@@ -30,21 +34,21 @@ __global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DE
     const int team = threadIdx.x / SPEC_TEAM, lane = threadIdx.x % SPEC_TEAM;
     const int traj = blockIdx.x * (64 / SPEC_TEAM) + team;
     constexpr int stride = MODE == tg::MODE_DERIV2Z ? SpecProg::e_lds_per_team : (MODE == tg::MODE_DERIV1 ? SpecProg::d_lds_per_team : SpecProg::lds_per_team);
-    tg::run_trajectory<SPEC_TEAM, MODE, SPEC_SPRINGS, const SpecProg>(P, A, lds + (size_t)team * stride, lane, traj);
+    tg::run_trajectory<SPEC_TEAM, MODE, SPEC_SPRINGS, const SpecProg, std::remove_reference<decltype(A)>::type, PIVOT>(P, A, lds + (size_t)team * stride, lane, traj);
 }
 
-template <int MODE>
+template <int MODE, int PIVOT = 0>
 int launch_mode(const tg::RunArgs *A, tg::RunArgs *slot, int grid, size_t lds, hipStream_t stream) {
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spec<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spec<MODE, PIVOT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
 #if defined(SPEC_ARGS_IN_MEMORY)
     // `slot` is the batch's own device-side argument block: copy and kernel are ordered on the batch's stream, so the block is
     // never rewritten before the previous launch that reads it has finished (the host copy is staged before the call returns)
     if (!slot) return 3;
     if (hipMemcpyAsync(slot, A, sizeof(tg::RunArgs), hipMemcpyHostToDevice, stream) != hipSuccess) return 1;
-    hipLaunchKernelGGL(k_spec<MODE>, dim3(grid), dim3(64), lds, stream, (const tg::RunArgs *)slot);
+    hipLaunchKernelGGL((k_spec<MODE, PIVOT>), dim3(grid), dim3(64), lds, stream, (const tg::RunArgs *)slot);
 #else
-    hipLaunchKernelGGL(k_spec<MODE>, dim3(grid), dim3(64), lds, stream, *A);
+    hipLaunchKernelGGL((k_spec<MODE, PIVOT>), dim3(grid), dim3(64), lds, stream, *A);
 #endif
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -66,7 +70,9 @@ int tg_spec_modes(void) {
 }
 int tg_spec_launch(int mode, const tg::RunArgs *A, tg::RunArgs *device_slot, int grid, size_t lds, void *stream) {
     switch (mode) {
-    case tg::MODE_ROLLOUT: return launch_mode<tg::MODE_ROLLOUT>(A, device_slot, grid, lds, (hipStream_t)stream);
+    case tg::MODE_ROLLOUT:
+        return A->exact_pivot ? launch_mode<tg::MODE_ROLLOUT, 1>(A, device_slot, grid, lds, (hipStream_t)stream)
+                              : launch_mode<tg::MODE_ROLLOUT, 0>(A, device_slot, grid, lds, (hipStream_t)stream);
 #if defined(SPEC_DERIVATIVES)
     case tg::MODE_DERIV1: return launch_mode<tg::MODE_DERIV1>(A, device_slot, grid, lds, (hipStream_t)stream);
     case tg::MODE_DERIV2Z: return launch_mode<tg::MODE_DERIV2Z>(A, device_slot, grid, lds, (hipStream_t)stream);

@@ -26,7 +26,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 CACHE = os.path.join(_HERE, "_spec")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 _SOURCES = ["spec_kernel.hip", "mvi_core.hpp", "program.hpp"]
-DEFAULT_FLAGS = "-DSPEC_ARGS_IN_MEMORY -DSPEC_DERIVATIVES"
+DEFAULT_FLAGS = "-DSPEC_ARGS_IN_MEMORY -DSPEC_DERIVATIVES -DTG_GJ_INLINE -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp"
 
 
 def header(system):
