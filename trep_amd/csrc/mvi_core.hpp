@@ -264,6 +264,11 @@ struct Core {
     int lane;
     double dt;
     int oGc;   // LDS offset of the joint poses that the end-point / constraint evaluation reads (P.o_G, or the second pose set of a dual sweep)
+    // table rows this lane needs in every Newton iteration of a rollout, read once per kernel (P.tab_ok, eval_both_tab):
+    // joint (config | kind << 16) of the two sin/cos trips, the body's item range of the velocity prefix sums, and the
+    // constant Newton-matrix entries (damping of this row, (constraint, config) of the lane's two Dh items, first pair record)
+    int jck[2] = {0, 0}, bio[2] = {0, 0}, tck[2][2] = {{0, 0}, {0, 0}}, tpair[4] = {0, 0, 0, 0};
+    double tdamp = 0.0;
     long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long prof_last = 0;
 
@@ -308,6 +313,21 @@ struct Core {
         PROG &P = tg_fresh(this->P);
         TG_FOR(i, 4 * P.n_bodies) S[P.o_I + i] = P.b_inertia[i];   // body inertias: LDS copy for the whole kernel
         TG_FOR(c, P.nc) S[P.o_ctol + c] = P.c_tol[c];
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (TEAM == 64 && P.tab_ok) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int j = lane + u * TEAM < 2 * P.n_joints ? (lane + u * TEAM) % P.n_joints : 0;
+                jck[u] = P.j_cfg[j] | (P.j_kind[j] << 16);
+                const int n = lane + u * TEAM < P.n_dh ? lane + u * TEAM : 0;
+                if (P.n_dh) { tck[u][0] = P.dh_pack[8 * (size_t)n]; tck[u][1] = P.dh_pack[8 * (size_t)n + 1]; }
+            }
+            const int b = lane < 6 * P.n_bodies ? lane / 6 : 0;
+            bio[0] = P.b_item_off[b]; bio[1] = P.b_item_off[b + 1];
+            tdamp = P.damp[lane < P.nd ? lane : 0];
+            if (P.n_npairs) { const int *p0 = P.pair4 + 4 * (size_t)(lane < P.n_npairs ? lane : 0); tpair[0] = p0[0]; tpair[1] = p0[1]; tpair[2] = p0[2]; tpair[3] = p0[3]; }
+        }
+#endif
         if (!P.sched_ok || TEAM != 64) { TG_SYNC(); return; }
         int *sched = (int *)(S + P.o_sched);
         TG_FOR(idx, 16 * P.n_rounds) {
@@ -444,6 +464,22 @@ struct Core {
             return r;
         };
         Rows cur = rows_of(lane);
+        if (P.tab_ok) {
+            if (on) {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int idx = lane + u * TEAM;
+                    if (idx < 2 * nj) {
+                        const bool second = idx >= nj;
+                        const int j = second ? idx - nj : idx;
+                        const double x = qval(second ? 2 : 0, jck[u] & 0xFFFF);
+                        double *dst = (second ? sc2 : sc) + 2 * j;
+                        if ((jck[u] >> 16) >= TG_RX) tg_sincos(x, &dst[0], &dst[1]);
+                        else { dst[0] = x; dst[1] = 0.0; }
+                    }
+                }
+            }
+        } else
         if (on) TG_FOR(idx, 2 * nj) {
             const bool second = idx >= nj;
             const int j = second ? idx - nj : idx;
@@ -575,6 +611,263 @@ struct Core {
         velocities(on);
         TG_STAMP(3);
         residual_dyn(on);
+        TG_STAMP(4);
+    }
+    // ---- the same with every phase's table rows requested ONE PHASE AHEAD (P.tab_ok: each per-lane table walk fits two trips) ----
+    // A phase of the Newton iteration starts with look-ups in the schedule tables (global memory: several hundred cycles) and
+    // only then reads LDS; with the rows of phase k+1 requested before phase k runs, that latency is covered by phase k.
+    // The arithmetic of every phase is that of attach_points / constraints / jacobians / velocities / residual_dyn, in the same order.
+    struct AttachTab { double ce[2], c0[2], c1[2], c2[2]; int ga[2]; double o0, o1, o2, orr; int ea; };
+    struct ConTab { int e1, e2, type, comp, cfg; double dist; int rec[2][6]; };
+    struct ItemTab { int rec[2][4]; };
+    struct ResTab { int n0, n1; int look[8]; };
+    TG_HD AttachTab fetch_attach() const {
+        AttachTab t;
+        const int l = tg_opaque(lane);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int ii = l + u * TEAM < 12 * P.n_bodies ? l + u * TEAM : 0;
+            const int b = ii / 12, e = ii % 12, c = e & 3;
+            const double *C = P.b_C + 12 * b;
+            t.ce[u] = C[e]; t.c0[u] = C[c]; t.c1[u] = C[4 + c]; t.c2[u] = C[8 + c]; t.ga[u] = P.b_anchor[b];
+        }
+        const int ii = l < 3 * P.n_endpoints ? l : 0;
+        const int e = ii / 3, r = ii % 3;
+        const double *o = P.e_off + 3 * e;
+        t.o0 = o[0]; t.o1 = o[1]; t.o2 = o[2]; t.orr = o[r]; t.ea = P.e_anchor[e];
+        return t;
+    }
+    TG_HD ConTab fetch_constraints() const {
+        ConTab t;
+        const int l = tg_opaque(lane);
+        const int c = l < P.nc ? l : 0;
+        t.e1 = P.c_e1[c]; t.e2 = P.c_e2[c]; t.type = P.c_type[c]; t.comp = P.c_comp[c]; t.cfg = P.c_cfg[c]; t.dist = P.c_dist[c];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int *rec = P.dh_pack + 8 * (size_t)(l + u * TEAM < P.n_dh ? l + u * TEAM : 0);
+#pragma unroll
+            for (int i = 0; i < 6; i++) t.rec[u][i] = rec[i];
+        }
+        return t;
+    }
+    TG_HD ItemTab fetch_items() const {
+        ItemTab t;
+        const int l = tg_opaque(lane);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int *rec = P.it_pack + 4 * (size_t)(l + u * TEAM < P.n_items ? l + u * TEAM : 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) t.rec[u][i] = rec[i];
+        }
+        return t;
+    }
+    TG_HD ResTab fetch_residual() const {
+        ResTab t;
+        const int l = tg_opaque(lane);
+        const int i = l < P.nd ? l : 0;
+        t.n0 = P.cfg_item_off[i]; t.n1 = P.cfg_item_off[i + 1];
+#pragma unroll
+        for (int c = 0; c < 8; c++) t.look[c] = c < P.nc ? P.dh_lookup[c * P.nq + i] : -1;
+        return t;
+    }
+
+    TG_HD void eval_both_tab(bool on) {
+        PROG &P = tg_fresh(this->P);
+        const AttachTab at = fetch_attach();
+        if (on) TG_FOR(i, P.nq) S[P.o_dq + i] = (S[P.o_q2 + i] - S[P.o_q1 + i]) / dt;
+        TG_SYNC();
+        TG_STAMP(0);
+        pose_sweep_dual(on);
+        TG_STAMP(1);
+        const double *G = S + P.o_G, *G2 = S + P.o_W;
+        // ---- body poses (midpoint) and constraint end points (q2 poses): attach_points ----
+        const ConTab ct = fetch_constraints();
+        if (on) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int idx = lane + u * TEAM;
+                if (idx < 12 * P.n_bodies) {
+                    const int e = idx % 12, r = e >> 2, c = e & 3;
+                    const int anchor = at.ga[u];
+                    const double *g = G + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
+                    const double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+                    const double val = g0 * at.c0[u] + g1 * at.c1[u] + g2 * at.c2[u] + (c == 3 ? g3 : 0.0);
+                    S[P.o_gB + idx] = anchor < 0 ? at.ce[u] : val;
+                }
+            }
+            if (lane < 3 * P.n_endpoints) {
+                const int r = lane % 3;
+                const double *g = G2 + 12 * (at.ea < 0 ? 0 : at.ea) + 4 * r;
+                const double val = g[0] * at.o0 + g[1] * at.o1 + g[2] * at.o2 + g[3];
+                S[P.o_pE + lane] = at.ea < 0 ? at.orr : val;
+            }
+        }
+        TG_SYNC();
+        // ---- constraint values and Dh2 at q2: constraints(on, 2, true, Dh2, 0) ----
+        const ItemTab it = fetch_items();
+        if (on) {
+            if (lane < P.nc) {
+                const double *a = S + P.o_pE + 3 * ct.e1, *b = S + P.o_pE + 3 * ct.e2;
+                const double vx = a[0] - b[0], vy = a[1] - b[1], vz = a[2] - b[2];
+                double h;
+                if (ct.type == TG_CONSTRAINT_POINT) h = ct.comp == 0 ? vx : (ct.comp == 1 ? vy : vz);
+                else {
+                    const double len = ct.cfg >= 0 ? S[P.o_q2 + (ct.cfg >= 0 ? ct.cfg : 0)] : ct.dist;
+                    h = (vx * vx + vy * vy + vz * vz) - len * len;
+                }
+                S[P.o_f + P.nd + lane] = h;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int n = lane + u * TEAM;
+                if (n < P.n_dh) {
+                    const int k = ct.rec[u][1], oj = ct.rec[u][2], w = ct.rec[u][3], oe1 = ct.rec[u][4], oe2 = ct.rec[u][5];
+                    const int side = w & 0xFF, kind = (w >> 8) & 0xFF, type = (w >> 16) & 0xFF, comp = w >> 24;
+                    const int ojc = oj < 0 ? 0 : oj;
+                    double d1[3], d2[3];
+                    const double *gj = G2 + ojc;
+                    const bool prismatic = kind <= TG_TZ;
+                    const int ax = prismatic ? kind - TG_TX : kind - TG_RX;
+                    const double wx = gj[ax], wy = gj[4 + ax], wz = gj[8 + ax];
+                    {
+                        const double *pe = S + P.o_pE + oe1;
+                        const double dx = pe[0] - gj[3], dy = pe[1] - gj[7], dz = pe[2] - gj[11];
+                        d1[0] = prismatic ? wx : wy * dz - wz * dy; d1[1] = prismatic ? wy : wz * dx - wx * dz; d1[2] = prismatic ? wz : wx * dy - wy * dx;
+                    }
+                    {
+                        const double *pe = S + P.o_pE + oe2;
+                        const double dx = pe[0] - gj[3], dy = pe[1] - gj[7], dz = pe[2] - gj[11];
+                        d2[0] = prismatic ? wx : wy * dz - wz * dy; d2[1] = prismatic ? wy : wz * dx - wx * dz; d2[2] = prismatic ? wz : wx * dy - wy * dx;
+                    }
+                    const double s1 = (side & 1) ? 1.0 : 0.0, s2 = (side & 2) ? 1.0 : 0.0;
+                    const double dx = s1 * d1[0] - s2 * d2[0], dy = s1 * d1[1] - s2 * d2[1], dz = s1 * d1[2] - s2 * d2[2];
+                    double val;
+                    if (type == TG_CONSTRAINT_POINT) val = comp == 0 ? dx : (comp == 1 ? dy : dz);
+                    else {
+                        const double *a = S + P.o_pE + oe1, *b = S + P.o_pE + oe2;
+                        val = (a[0] - b[0]) * dx + (a[1] - b[1]) * dy + (a[2] - b[2]) * dz;
+                        if (side & 4) val -= S[P.o_q2 + k];
+                        val *= 2.0;
+                    }
+                    S[P.o_Dh2 + n] = val;
+                }
+            }
+        }
+        TG_SYNC();
+        TG_STAMP(6);
+        // ---- body Jacobian columns and body-frame gravity: jacobians ----
+        const ResTab rt = fetch_residual();
+        if (on) {
+            double Jv[2][6], dqv[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int b = it.rec[u][0], oj = it.rec[u][1], kind = it.rec[u][2], cfg = it.rec[u][3] & 0xFFFF;
+                const double *gb = S + P.o_gB + 12 * b, *gj = G + oj;
+                const bool prismatic = kind <= TG_TZ;
+                const int ax = prismatic ? kind - TG_TX : kind - TG_RX;
+                const double a0 = gj[ax], a1 = gj[4 + ax], a2 = gj[8 + ax];
+                const double dx = gb[3] - gj[3], dy = gb[7] - gj[7], dz = gb[11] - gj[11];
+                double lin[3], ang[3];
+                ang[0] = prismatic ? 0.0 : a0; ang[1] = prismatic ? 0.0 : a1; ang[2] = prismatic ? 0.0 : a2;
+                lin[0] = prismatic ? a0 : a1 * dz - a2 * dy;
+                lin[1] = prismatic ? a1 : a2 * dx - a0 * dz;
+                lin[2] = prismatic ? a2 : a0 * dy - a1 * dx;
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    Jv[u][r] = gb[r] * lin[0] + gb[4 + r] * lin[1] + gb[8 + r] * lin[2];
+                    Jv[u][3 + r] = gb[r] * ang[0] + gb[4 + r] * ang[1] + gb[8 + r] * ang[2];
+                }
+                dqv[u] = S[P.o_dq + cfg];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = lane + u * TEAM;
+                if (i < P.n_items) {
+                    double *J = S + P.o_J + 6 * i;
+#pragma unroll
+                    for (int r = 0; r < 6; r++) J[r] = Jv[u][r];
+                    S[P.o_dqi + i] = dqv[u];
+                }
+            }
+            if (lane < 3 * P.n_bodies) {
+                const int b = lane / 3, r = lane % 3;
+                const double *gb = S + P.o_gB + 12 * b;
+                S[P.o_gam + lane] = gb[r] * P.grav[0] + gb[4 + r] * P.grav[1] + gb[8 + r] * P.grav[2];
+            }
+        }
+        TG_SYNC();
+        TG_STAMP(2);
+        // ---- prefix velocities, W = [P, J], body velocities: velocities ----
+        if (on && lane < 6 * P.n_bodies) {
+            const int m = lane % 6;
+            const int first = bio[0], last = bio[1];
+            double acc = 0.0;
+            for (int k = first; k < last; k += 4) {
+                double jv[4], dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int kk = k + u < last ? k + u : last - 1;
+                    jv[u] = S[P.o_J + 6 * kk + m]; dv[u] = S[P.o_dqi + kk];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (k + u < last) { S[P.o_W + 6 * (k + u) + m] = acc; acc = fma(jv[u], dv[u], acc); }
+                }
+            }
+            S[P.o_vB + lane] = acc;
+        }
+        TG_SYNC();
+        if (on) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = lane + u * TEAM;
+                if (i < P.n_items) {
+                    double *W = S + P.o_W + 6 * i;
+                    const double *J = S + P.o_J + 6 * i;
+                    const double Pp[6] = {W[0], W[1], W[2], W[3], W[4], W[5]};
+                    bracket(Pp, J, W);
+                }
+            }
+        }
+        TG_SYNC();
+        TG_STAMP(3);
+        // ---- L_dq, L_ddq and the dynamic part of the residual: residual_dyn ----
+        double *terms = S + P.o_G;
+        if (on) {
+            double ta[2], tb[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = lane + u * TEAM < P.n_items ? lane + u * TEAM : lane;
+                const int b = it.rec[u][0];
+                const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b;
+                const double *J = S + P.o_J + 6 * i, *W = S + P.o_W + 6 * i, *gam = S + P.o_gam + 3 * b;
+                ta[u] = inner6(I, J, v);
+                tb[u] = inner6(I, W, v) + I[0] * (gam[0] * J[0] + gam[1] * J[1] + gam[2] * J[2]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (lane + u * TEAM < P.n_items) { const int slot = it.rec[u][3] >> 16; terms[2 * slot] = ta[u]; terms[2 * slot + 1] = tb[u]; }
+            }
+        }
+        TG_SYNC();
+        if (on && lane < P.nd) {
+            const int i = lane;
+            double ldq = 0.0, lddq = 0.0;
+            for (int n = rt.n0; n < rt.n1; n++) { lddq += terms[2 * n]; ldq += terms[2 * n + 1]; }
+            S[P.o_Ldq + i] = ldq; S[P.o_Lddq + i] = lddq;
+            double force = -tdamp * S[P.o_dq + i];
+            for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
+            double f = S[P.o_p1 + i] + (0.5 * dt * ldq - lddq) + dt * force;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                if (c < P.nc) {
+                    const int n = rt.look[c];
+                    f -= (n >= 0 ? S[P.o_lam + c] : 0.0) * S[P.o_Dh1 + (n >= 0 ? n : 0)];
+                }
+            }
+            S[P.o_f + i] = f;
+        }
+        TG_SYNC();
         TG_STAMP(4);
     }
 #endif
@@ -819,6 +1112,21 @@ struct Core {
         // (damping.c:21-27), the right-hand side f, and -Dh1^T / Dh2 from the (constraint, config) items
         if (on) TG_FOR(i, nf * ld) A[i] = 0.0;
         TG_SYNC();
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (TEAM == 64 && P.tab_ok) {    // table rows held in registers since the kernel started (init_sweep_schedule)
+            if (on) {
+                if (lane < nf) {
+                    A[lane * ld + nf] = S[P.o_f + lane];
+                    if (lane < nd) A[lane * ld + lane] = -tdamp - (has_cs() ? 0.25 * dt * P.cs_k[lane] : 0.0);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int n = lane + u * TEAM, c = tck[u][0], k = tck[u][1];
+                    if (n < P.n_dh && k < nd) { A[k * ld + nd + c] = -S[P.o_Dh1 + n]; A[(nd + c) * ld + k] = S[P.o_Dh2 + n]; }
+                }
+            }
+        } else
+#endif
         if (on) {
             TG_FOR(r, nf) {
                 A[r * ld + nf] = S[P.o_f + r];
@@ -839,7 +1147,11 @@ struct Core {
         if (on) for (int pp = tg_opaque(lane), r0 = 0, r1 = 0, r2 = 0, r3 = 0, first_ = 1; pp < P.n_npairs; pp += TEAM) {
             // the record of the next trip is fetched while this trip computes (a table look-up per trip otherwise sits in
             // front of the trip's LDS reads)
-            if (first_) { const int *p0 = P.pair4 + 4 * (size_t)pp; r0 = p0[0]; r1 = p0[1]; r2 = p0[2]; r3 = p0[3]; first_ = 0; }
+            if (first_) {
+                if (TEAM == 64 && P.tab_ok) { r0 = tpair[0]; r1 = tpair[1]; r2 = tpair[2]; r3 = tpair[3]; }
+                else { const int *p0 = P.pair4 + 4 * (size_t)pp; r0 = p0[0]; r1 = p0[1]; r2 = p0[2]; r3 = p0[3]; }
+                first_ = 0;
+            }
             const int ia = r0, ib = r1, ca = r2 & 0xFFFF, cb = r2 >> 16, b = r3;
             {
                 const int pn = pp + TEAM < P.n_npairs ? pp + TEAM : pp;
@@ -3115,7 +3427,7 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj) {
             PROG &P = tg_fresh(P0);
             const int nd = P.nd, nc = P.nc;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_DUAL_SWEEP)
-            if (core.dual_ok()) core.eval_both(!done);
+            if (core.dual_ok()) { if (P.tab_ok) core.eval_both_tab(!done); else core.eval_both(!done); }
             else
 #endif
             {

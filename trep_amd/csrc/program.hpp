@@ -84,6 +84,7 @@ struct DevProg {
     // LDS layout (offsets in doubles from the team's base)
     int o_q1, o_q2, o_p1, o_lam, o_u, o_dq, o_f, o_sc, o_G, o_gB, o_pE, o_J, o_W, o_vB, o_gam, o_Ldq, o_Lddq,
         o_Dh1, o_Dh2, o_Df, o_scal, o_misc, o_dqi, o_nu, o_sched, o_I, o_ctol, gjc_ok;
+    int tab_ok;               // 1: the per-lane table rows of the rollout's Newton iteration fit two trips of a wavefront (mvi_core.hpp eval_both_tab)
     int sched_ok;             // 1 / 2: every round has <= 16 / <= 8 chains: the chain schedule is staged in LDS (o_sched)
     int df_ld;
     int dh_ld;                // 0: the step kernel keeps Dh1/Dh2 compact (one value per dh item)
@@ -511,6 +512,8 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.sched_ok = (12 * nj < 65536) ? 1 : 0;
     for (int r = 0; r < P.n_rounds; r++) if (H.round_off[r + 1] - H.round_off[r] > 16) P.sched_ok = 0;
     for (int c : H.ch_len) if (c >= 32768) P.sched_ok = 0;
+    P.tab_ok = (12 * (int)P.n_bodies <= 128 && 3 * (int)P.n_endpoints <= 64 && P.n_dh <= 128 && P.n_items <= 128 && P.nc <= 8 && P.nd + P.nc <= 64 &&
+                6 * (int)P.n_bodies <= 64 && 2 * nj <= 128) ? 1 : 0;
     if (P.sched_ok) {   // 2: no round has more than 8 chains (the dual sweep gives each pose set half a wavefront)
         P.sched_ok = 2;
         for (int r = 0; r < P.n_rounds; r++) if (H.round_off[r + 1] - H.round_off[r] > 8) P.sched_ok = 1;
