@@ -324,7 +324,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
-                         "kernel": ("k_spec<0> (system-specialised rollout, team %d)" if r["specialised"] else "k_run<%d, 0> (generic rollout)") % r["info"]["team"],
+                         "kernel": ("k_spec<0, 0> (system-specialised rollout, team %d)" if r["specialised"] else "k_run<%d, 0> (generic rollout)") % r["info"]["team"],
                          "kernel_avg_ms": 1e3 * avg_kernel_s, "launches": r["launches"],
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "path is fp64-VALU/LDS-latency bound, not HBM bound (SURVEY.md §8d)"},

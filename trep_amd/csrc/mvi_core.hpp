@@ -2802,6 +2802,124 @@ struct Core {
                 TG_SYNC();
             }
         };
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_HZ_MFMA)
+        // ---- the same assembly on the matrix cores (full-wave teams) --------------------------------------------------
+        // HZ = Y2' H22 Y2 + N + N' + D with Y2 = [X; e_k2] the q2 tangents, N = [H12 Y2 + G1 L; 0] the rows of the q1 variables and
+        // D the H11 block.  Per block of 16 columns b:  TB = H22 Y2[:, b] (staged in LDS), then every 16 x 16 output tile (a, b) is ONE
+        // accumulator fed by chains of v_mfma_f64_16x16x4:  X[:, a]' (TB + H12[b, :]')  +  L[:, a]' G1[b, :]'  (S and N'), and for the tiles
+        // with q1 rows  H12[a, :] X[:, b] + G1[a, :] L[:, b]  (N);  the unit rows / columns of the k2 variables and H11 are added per
+        // element.  Operand layout of the instruction: A: lane holds A[lane & 15][lane >> 4], B: B[lane >> 4][lane & 15], C / D: column
+        // lane & 15, rows (lane >> 4) + 4 r.  Up to GA tiles are accumulated side by side: a dependent MFMA issues every ~200 cycles,
+        // independent ones every ~64 (tools/micro/mfma_f64_rate.hip).  Rows of a tile are stored as HZ[a][b] (= HZ[b][a]): 16 lanes
+        // write 128 contiguous bytes.
+        typedef double hz4 __attribute__((ext_vector_type(4)));
+        auto assemble_mfma = [&](double *TB) {
+            constexpr int GA = 3;
+            const int l15 = lane & 15, l4 = lane >> 4;
+            const int n_jt = (nq + 15) >> 4, n_at = (R + 15) >> 4, n_k = (nd + 3) >> 2, n_kc = (nc + 3) >> 2;
+            for (int b0 = 0; b0 < R; b0 += 16) {
+                const int bcol = b0 + l15;
+                const bool bin = bcol < R, bq = bcol < nq;
+                if (on) for (int jt0 = 0; jt0 < n_jt; jt0 += GA) {
+                    hz4 acc[GA];
+#pragma unroll
+                    for (int g = 0; g < GA; g++) acc[g] = hz4{0.0, 0.0, 0.0, 0.0};
+                    for (int ks = 0; ks < n_k; ks++) {
+                        const int i2 = 4 * ks + l4;
+                        const double bw = (i2 < nd && bin) ? AUG[i2 * ld + nf + bcol] : 0.0;
+                        double av[GA];
+#pragma unroll
+                        for (int g = 0; g < GA; g++) { const int j = 16 * (jt0 + g) + l15; av[g] = (j < nq && i2 < nd) ? H22[sym(j, i2)] : 0.0; }
+#pragma unroll
+                        for (int g = 0; g < GA; g++) if (jt0 + g < n_jt) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g], bw, acc[g], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int g = 0; g < GA; g++) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int j = 16 * (jt0 + g) + l4 + 4 * r;
+                            if (j < nq) {
+                                double v = acc[g][r];
+                                if (bin && bcol >= first_k2) v += H22[sym(j, nd + bcol - first_k2)];
+                                TB[j * 16 + l15] = v;
+                            }
+                        }
+                    }
+                }
+                TG_SYNC();
+                if (on) for (int at0 = 0; at0 < n_at; at0 += GA) {
+                    hz4 acc[GA];
+#pragma unroll
+                    for (int g = 0; g < GA; g++) acc[g] = hz4{0.0, 0.0, 0.0, 0.0};
+                    for (int ks = 0; ks < n_k; ks++) {            // S and N': X[:, a]' (TB + H12[b, :]')
+                        const int i2 = 4 * ks + l4;
+                        const bool kin = i2 < nd;
+                        const double tb = kin ? TB[i2 * 16 + l15] : 0.0, hb = (kin && bq) ? H12[bcol * hl + i2] : 0.0;
+                        const double bw = tb + hb;
+                        double av[GA];
+#pragma unroll
+                        for (int g = 0; g < GA; g++) { const int a = 16 * (at0 + g) + l15; av[g] = (kin && a < R) ? AUG[i2 * ld + nf + a] : 0.0; }
+#pragma unroll
+                        for (int g = 0; g < GA; g++) if (at0 + g < n_at) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g], bw, acc[g], 0, 0, 0);
+                    }
+                    if (b0 < nq) for (int kc = 0; kc < n_kc; kc++) {   // N': L[:, a]' G1[b, :]'
+                        const int c = 4 * kc + l4;
+                        const bool cin = c < nc;
+                        const double bw = (cin && bq) ? G1[bcol * nc + c] : 0.0;
+                        double av[GA];
+#pragma unroll
+                        for (int g = 0; g < GA; g++) { const int a = 16 * (at0 + g) + l15; av[g] = (cin && a < R) ? AUG[(nd + c) * ld + nf + a] : 0.0; }
+#pragma unroll
+                        for (int g = 0; g < GA; g++) if (at0 + g < n_at) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g], bw, acc[g], 0, 0, 0);
+                    }
+                    if (16 * at0 < nq) {                              // N: H12[a, :] X[:, b] + G1[a, :] L[:, b] for the tiles with q1 rows
+                        for (int ks = 0; ks < n_k; ks++) {
+                            const int i2 = 4 * ks + l4;
+                            const bool kin = i2 < nd;
+                            const double bw = (kin && bin) ? AUG[i2 * ld + nf + bcol] : 0.0;
+                            double av[GA];
+#pragma unroll
+                            for (int g = 0; g < GA; g++) { const int a = 16 * (at0 + g) + l15; av[g] = (kin && a < nq) ? H12[a * hl + i2] : 0.0; }
+#pragma unroll
+                            for (int g = 0; g < GA; g++) if (16 * (at0 + g) < nq) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g], bw, acc[g], 0, 0, 0);
+                        }
+                        for (int kc = 0; kc < n_kc; kc++) {
+                            const int c = 4 * kc + l4;
+                            const bool cin = c < nc;
+                            const double bw = (cin && bin) ? AUG[(nd + c) * ld + nf + bcol] : 0.0;
+                            double av[GA];
+#pragma unroll
+                            for (int g = 0; g < GA; g++) { const int a = 16 * (at0 + g) + l15; av[g] = (cin && a < nq) ? G1[a * nc + c] : 0.0; }
+#pragma unroll
+                            for (int g = 0; g < GA; g++) if (16 * (at0 + g) < nq) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g], bw, acc[g], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < GA; g++) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int a = 16 * (at0 + g) + l4 + 4 * r;
+                            if (a < R && bin) {
+                                double v = acc[g][r];
+                                if (a >= first_k2) {                  // unit row of a k2 variable
+                                    const int kk = nd + (a - first_k2);
+                                    v += TB[kk * 16 + l15] + (bq ? H12[bcol * hl + kk] : 0.0);
+                                }
+                                if (a < nq) {
+                                    if (bcol >= first_k2) v += H12[a * hl + nd + (bcol - first_k2)];   // unit column of a k2 variable
+                                    if (bq) v += H11[sym(a, bcol)];
+                                }
+                                A.hz[(t * R + a) * R + bcol] = ok ? v : NAN;
+                            }
+                        }
+                    }
+                }
+                TG_SYNC();
+            }
+        };
+        if (TEAM == 64 && 12 * P.n_items >= 16 * nq && P.o_W == P.o_J + 6 * P.n_items) assemble_mfma(S + P.o_J);
+        else
+#endif
         if (TEAM == 64 && 12 * P.n_items >= 24 * nq && P.o_W == P.o_J + 6 * P.n_items) assemble(IntTag<8>{}, S + P.o_J);
         else assemble(IntTag<4>{}, vec);
         if (n_wrenches() && nu > 0) {
