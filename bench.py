@@ -290,7 +290,7 @@ def main():
         discopt = {k: d[k] for k in ("iters_per_s", "seeds", "horizon", "n_gpus", "seed_iterations_counted", "elapsed_s",
                                      "s_per_batched_quasi_step", "s_per_batched_newton_step", "armijo_failures",
                                      "mean_cost_before_after_per_step", "mean_final_cost_successful_seeds")}
-        discopt["unit"] = "DOptimizer.step equivalents (seed-iterations) per second: 1 quasi-Newton + 1 Newton step of every seed, after one untimed warm-up step"
+        discopt["unit"] = "DOptimizer.step equivalents (seed-iterations) per second: 1 quasi-Newton + 1 Newton step of every seed, after one untimed warm-up step of each method"
         discopt["scaling"] = "strong (seeds sharded over the ranks)"
         discopt["reference_s_per_newton_step_one_seed"] = d["reference_s_per_newton_step_N1000_one_seed"]
 

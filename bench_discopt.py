@@ -51,7 +51,7 @@ def problem(seeds, N, dt, device=0):
 def measure(seeds, horizon, quasi=1, newton=1, comm=None, device=0, armijo_chunk=None, predictor="reference",
             stages=False):
     """Times `quasi` + `newton` batched DOptimizer steps of `seeds` puppet problems (sharded over the ranks of `comm`,
-    a trep_amd.rccl.Communicator, if given) after one untimed warm-up step; returns the result dict (same on every
+    a trep_amd.rccl.Communicator, if given) after one untimed warm-up step per method; returns the result dict (same on every
     rank).  Seeds whose Armijo search is exhausted (where the reference raises) do not count as iterations."""
     import trep_amd
     from trep_amd import discopt, _lib, distributed
@@ -67,7 +67,9 @@ def measure(seeds, horizon, quasi=1, newton=1, comm=None, device=0, armijo_chunk
     L = _lib.lib()
     methods = ["quasi"] * quasi + ["newton"] * newton
     opt.set_trajectories(Xi, Ui)
-    opt.step(methods[0])                      # warm-up (allocations, code objects), not timed
+    for m in dict.fromkeys(methods):          # warm-up, not timed: one step of every method used (a first Newton step allocates the
+        opt.set_trajectories(Xi, Ui)          # 13 GB of z-contracted second derivatives: 0.36 s of hipMalloc, once per optimizer)
+        opt.step(m)
     opt.set_trajectories(Xi, Ui)
     L.tg_device_synchronize(device)
     if comm is not None:

@@ -13,7 +13,7 @@ import csv, collections, json
 rows=list(csv.DictReader(open("$out/fp64.csv")))
 acc=collections.defaultdict(list)
 for r in rows:
-    if ('k_spec<0>' in r['Kernel_Name'] or 'k_spec<(int)0>' in r['Kernel_Name']) or ('k_run' in r['Kernel_Name'] and ', 0>' in r['Kernel_Name']):
+    if any(k in r['Kernel_Name'] for k in ('k_spec<0>', 'k_spec<0,', 'k_spec<(int)0')) or ('k_run' in r['Kernel_Name'] and ', 0>' in r['Kernel_Name']):
         acc[r['Counter_Name']].append(float(r['Counter_Value']))
 res={k: sum(v)/len(v) for k,v in acc.items()}
 print(json.dumps(res))

@@ -10,6 +10,8 @@ timeout 900 python bench.py --steps 10 --warmup 2 > $out/bench.json 2> $out/benc
 timeout 900 python bench.py --steps 10 --warmup 2 --no-specialize --no-discopt --no-cpu-baseline > $out/bench_generic.json 2> $out/bench_generic.err; echo "bench generic rc=$?"
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_under_trace.json 2> $out/trace.err; echo "trace rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_rollout -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-discopt > $out/bench_under_trace_rollout.json 2> $out/trace_rollout.err; echo "rollout trace rc=$?"
+cp $(find $out/trace_rollout -name "*kernel_stats.csv" | head -1) $out/kernel_stats_rollout.csv 2>/dev/null; rm -rf $out/trace_rollout
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-discopt > $out/bench_under_pmc_fetch.json 2> $out/pmc_fetch.err; echo "pmc fetch rc=$?"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-discopt > $out/bench_under_pmc_write.json 2> $out/pmc_write.err; echo "pmc write rc=$?"
 cd $GRAFT_REPO_ROOT

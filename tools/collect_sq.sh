@@ -21,7 +21,7 @@ for i in (1,2,3):
     except Exception as e: print(i, e); continue
     acc=collections.defaultdict(list)
     for r in rows:
-        if ('k_spec<0>' in r['Kernel_Name'] or 'k_spec<(int)0>' in r['Kernel_Name']) or ('k_run' in r['Kernel_Name'] and ', 0>' in r['Kernel_Name']):
+        if any(k in r['Kernel_Name'] for k in ('k_spec<0>', 'k_spec<0,', 'k_spec<(int)0')) or ('k_run' in r['Kernel_Name'] and ', 0>' in r['Kernel_Name']):
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in acc.items(): print("%-28s %16.0f  (n=%d)"%(k, sum(v)/len(v), len(v)))
 PY

@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "r02")
 DST = os.path.join(ROOT, "profiles")
-ROLLOUT = ("k_spec<0>", "k_spec<(int)0>", "k_run<64, 0")
+ROLLOUT = ("k_spec<0>", "k_spec<0,", "k_spec<(int)0", "k_run<64, 0")
 
 
 def load(name):
@@ -33,7 +33,7 @@ bench = load("bench.json")
 fetch, nf = mean_counter(os.path.join(SRC, "pmc_fetch.csv"))
 write, nw = mean_counter(os.path.join(SRC, "pmc_write.csv"))
 traffic = {
-    "kernel": "k_spec<0> (system-specialised rollout kernel)", "workload": bench["config"]["workload"],
+    "kernel": "k_spec<0, 0> (system-specialised rollout kernel)", "workload": bench["config"]["workload"],
     "global_batch": bench["config"]["global_batch"], "rollout_steps": bench["config"]["rollout_steps"],
     "FETCH_SIZE_kB_raw": fetch["FETCH_SIZE"], "WRITE_SIZE_kB": write["WRITE_SIZE"], "dispatches_averaged": [nf["FETCH_SIZE"], nw["WRITE_SIZE"]],
     "read_bytes_corrected": 2.0 * fetch["FETCH_SIZE"] * 1024.0, "write_bytes": write["WRITE_SIZE"] * 1024.0,
@@ -45,7 +45,7 @@ c = load("fp64/fp64.json")
 lanes = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
 f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]
 flop = (2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"]) * 64.0 * lanes
-json.dump({"kernel": "k_spec<0> (rollout)", "workload": bench["config"]["workload"], "global_batch": bench["config"]["global_batch"],
+json.dump({"kernel": "k_spec<0, 0> (rollout)", "workload": bench["config"]["workload"], "global_batch": bench["config"]["global_batch"],
            "rollout_steps": bench["config"]["rollout_steps"], "counters_per_launch": c,
            "valu_f64_wave_instructions_per_launch": f64, "valu_wave_instructions_per_launch": c["SQ_INSTS_VALU"],
            "mean_active_lane_fraction": lanes, "estimated_fp64_flop_per_launch": flop,
@@ -56,7 +56,7 @@ for i in (1, 2, 3):
     m, _ = mean_counter(os.path.join(SRC, "sq", "p%d.csv" % i))
     sq.update(m)
 wc = sq["SQ_WAVE_CYCLES"]
-sq_out = {"kernel": "k_spec<0> (rollout), B=8192 x 200 steps", "counters_per_launch": sq,
+sq_out = {"kernel": "k_spec<0, 0> (rollout), B=8192 x 200 steps", "counters_per_launch": sq,
           "derived": {"valu_busy_fraction_of_simd_time": 4.0 * sq["SQ_ACTIVE_INST_VALU"] / (4.0 * sq["SQ_BUSY_CYCLES"] * 4) if False else None,
                       "wave_waiting_fraction (SQ_WAIT_ANY / SQ_WAVE_CYCLES)": sq["SQ_WAIT_ANY"] / wc,
                       "wave_issue_stalled_fraction (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES)": sq["SQ_WAIT_INST_ANY"] / wc,

@@ -4,9 +4,9 @@ Host-side mirror of the reference's ``trep.Frame`` and the ``tx/ty/.../const_se3
 frame-definition helpers (/root/reference/trep/frame.py:11-36, 112-162, 195-220,
 321-358, 658-691).  A frame is a single one-parameter SE(3) transform from its
 parent (translation along / rotation about one axis, driven by a ``Config`` or
-by a constant), or a constant SE(3).  Only model building and a plain numpy
-forward-kinematics helper (``g()``/``p()``, used to set up initial conditions)
-live here; every derivative and the integrator run on the device.
+by a constant), or a constant SE(3).  Model building and plain numpy kinematic
+queries of a single frame (``g()``, ``p()``, ``vb()`` and their derivatives, for set-up,
+inspection and tests) live here; the integrator and all of its derivatives run on the device.
 """
 import math
 
@@ -272,6 +272,184 @@ class Frame(object):
 
     def lg(self):
         return local_transform(self._transform, self.transform_value, self._lg_const)
+
+    # ---- kinematic queries of one frame (reference accessors frame.py:398-646) -------------------------------------
+    # Host-side numpy helpers for inspection and tests; the integrator never calls them (its kinematics run on the
+    # device in twist form, csrc/mvi_core.hpp).  Every parametric local transform is exp(T q) for a constant unit
+    # twist T (frame.c:839-1068), so d^n lg / dq^n = lg T^n and d^n lg^-1 / dq^n = (-T)^n lg^-1; a derivative of the
+    # world pose g = lg_1 lg_2 ... with respect to a set of configs puts T^(multiplicity) behind the frames they drive.
+    def twist_hat(self):
+        """Unit twist of the frame's local transform as a 4x4 se(3) matrix (frame.py:469)."""
+        t = np.zeros((4, 4))
+        k = self._transform
+        if k is TX:
+            t[0, 3] = 1.0
+        elif k is TY:
+            t[1, 3] = 1.0
+        elif k is TZ:
+            t[2, 3] = 1.0
+        elif k is RX:
+            t[2, 1], t[1, 2] = 1.0, -1.0
+        elif k is RY:
+            t[0, 2], t[2, 0] = 1.0, -1.0
+        elif k is RZ:
+            t[1, 0], t[0, 1] = 1.0, -1.0
+        return t
+
+    def _lg_n(self, n):
+        return self.lg().dot(np.linalg.matrix_power(self.twist_hat(), n))
+
+    def lg_dq(self):
+        return self._lg_n(1)
+
+    def lg_dqdq(self):
+        return self._lg_n(2)
+
+    def lg_dqdqdq(self):
+        return self._lg_n(3)
+
+    def lg_dqdqdqdq(self):
+        return self._lg_n(4)
+
+    def lg_inv(self):
+        m = self.lg()
+        out = np.eye(4)
+        out[:3, :3] = m[:3, :3].T
+        out[:3, 3] = -m[:3, :3].T.dot(m[:3, 3])
+        return out
+
+    def _lg_inv_n(self, n):
+        return np.linalg.matrix_power(-self.twist_hat(), n).dot(self.lg_inv())
+
+    def lg_inv_dq(self):
+        return self._lg_inv_n(1)
+
+    def lg_inv_dqdq(self):
+        return self._lg_inv_n(2)
+
+    def lg_inv_dqdqdq(self):
+        return self._lg_inv_n(3)
+
+    def lg_inv_dqdqdqdq(self):
+        return self._lg_inv_n(4)
+
+    def _path(self):
+        chain = []
+        f = self
+        while f is not None:
+            chain.append(f)
+            f = f._parent
+        chain.reverse()
+        return chain
+
+    def _check(self, configs):
+        """True if the frame depends on every config of the list (else the derivative is zero, frame.py:56-75)."""
+        for q in configs:
+            if not isinstance(q, Config):
+                raise TypeError("expected a Config, got %r" % (q,))
+            if not self.uses_config(q):
+                return False
+        return True
+
+    def _g_n(self, configs):
+        m = np.eye(4)
+        for f in self._path():
+            m = m.dot(f.lg())
+            n = sum(1 for q in configs if q is f._config) if f._config is not None else 0
+            if n:
+                m = m.dot(np.linalg.matrix_power(f.twist_hat(), n))
+        return m
+
+    def _g_inv_n(self, configs):
+        m = np.eye(4)
+        for f in reversed(self._path()):
+            n = sum(1 for q in configs if q is f._config) if f._config is not None else 0
+            if n:
+                m = m.dot(np.linalg.matrix_power(-f.twist_hat(), n))
+            m = m.dot(f.lg_inv())
+        return m
+
+    def g_dq(self, q1):
+        return self._g_n((q1,)) if self._check((q1,)) else np.zeros((4, 4))
+
+    def g_dqdq(self, q1, q2):
+        return self._g_n((q1, q2)) if self._check((q1, q2)) else np.zeros((4, 4))
+
+    def g_dqdqdq(self, q1, q2, q3):
+        return self._g_n((q1, q2, q3)) if self._check((q1, q2, q3)) else np.zeros((4, 4))
+
+    def g_dqdqdqdq(self, q1, q2, q3, q4):
+        return self._g_n((q1, q2, q3, q4)) if self._check((q1, q2, q3, q4)) else np.zeros((4, 4))
+
+    def g_inv(self):
+        return self._g_inv_n(())
+
+    def g_inv_dq(self, q1):
+        return self._g_inv_n((q1,)) if self._check((q1,)) else np.zeros((4, 4))
+
+    def g_inv_dqdq(self, q1, q2):
+        return self._g_inv_n((q1, q2)) if self._check((q1, q2)) else np.zeros((4, 4))
+
+    def p_dqdq(self, q1, q2):
+        return self.g_dqdq(q1, q2)[:, 3].copy()
+
+    def p_dqdqdq(self, q1, q2, q3):
+        return self.g_dqdqdq(q1, q2, q3)[:, 3].copy()
+
+    def p_dqdqdqdq(self, q1, q2, q3, q4):
+        return self.g_dqdqdqdq(q1, q2, q3, q4)[:, 3].copy()
+
+    # body velocity vb = g^-1 dg/dt = sum_k (g^-1 g_dq(k)) dq_k as a 4x4 se(3) matrix, and its derivatives by the
+    # product rule over the subsets of the differentiation variables
+    def _vb_term(self, k, configs):
+        """d^n / d(configs) of g^-1 g_dq(k)."""
+        n = len(configs)
+        out = np.zeros((4, 4))
+        for mask in range(1 << n):
+            left = tuple(configs[i] for i in range(n) if mask >> i & 1)
+            right = tuple(configs[i] for i in range(n) if not mask >> i & 1)
+            out += self._g_inv_n(left).dot(self._g_n((k,) + right))
+        return out
+
+    def _driving(self):
+        return [f._config for f in self._path() if f._config is not None]
+
+    def _vb_n(self, configs):
+        if not self._check(configs):
+            return np.zeros((4, 4))
+        out = np.zeros((4, 4))
+        for k in self._driving():
+            out += self._vb_term(k, tuple(configs)) * k.dq
+        return out
+
+    def _vb_ddq_n(self, dq1, configs):
+        if not self._check((dq1,) + tuple(configs)):
+            return np.zeros((4, 4))
+        return self._vb_term(dq1, tuple(configs))
+
+    def vb(self):
+        return self._vb_n(())
+
+    def vb_dq(self, q1):
+        return self._vb_n((q1,))
+
+    def vb_dqdq(self, q1, q2):
+        return self._vb_n((q1, q2))
+
+    def vb_dqdqdq(self, q1, q2, q3):
+        return self._vb_n((q1, q2, q3))
+
+    def vb_ddq(self, dq1):
+        return self._vb_ddq_n(dq1, ())
+
+    def vb_ddqdq(self, dq1, q2):
+        return self._vb_ddq_n(dq1, (q2,))
+
+    def vb_ddqdqdq(self, dq1, q2, q3):
+        return self._vb_ddq_n(dq1, (q2, q3))
+
+    def vb_ddqdqdqdq(self, dq1, q2, q3, q4):
+        return self._vb_ddq_n(dq1, (q2, q3, q4))
 
     def g(self):
         chain = []
