@@ -147,6 +147,32 @@ def test_descent_model_validators_and_monitors(capsys):
     assert "Armijo evaluation" in capsys.readouterr().out
 
 
+@pytest.mark.gpu
+def test_descent_curves_are_consistent_with_the_descent_model():
+    """descent_curves (the data behind the reference's descent_plot, doptimizer.py:569-617): the projected cost along the
+    direction is tangent to the quadratic model at z = 0, the accepted Armijo step lies below the required-improvement line."""
+    import trep_amd
+    from trep_amd import discopt
+    g, system, cost = _problem()
+    dsys = discopt.DSystem(trep_amd.MidpointVI(system), g["t"])
+    opt = discopt.DOptimizer(dsys, cost)
+    method = str(g["methods"][0])
+    d = opt.descent_curves(g["X0"].copy(), g["U0"].copy(), method, points=12)
+    assert len(d["z"]) == 32 and np.all(np.diff(d["z"]) >= 0) and len(d["armijo"]) == 20
+    assert abs(d["dcost"] - g["it0_dcost0"][0]) < 1e-5 * abs(g["it0_dcost0"][0])
+    small = (d["z"] > 0) & (d["z"] < 5e-3)
+    assert small.sum() >= 3
+    assert np.all(np.abs(d["true"][small] - d["model"][small]) <= 2e-2 * np.abs(d["model"][small]) + 1e-9)
+    ok = d["armijo"] < d["required"][np.searchsorted(d["z"], d["armijo_z"])]
+    assert ok.any()
+    assert abs(d["armijo_z"][ok].max() - opt.armijo_beta ** int(g["it0_m"][0])) < 1e-15    # the step the reference trace accepted
+    with pytest.raises(RuntimeError):
+        import importlib.util
+        if importlib.util.find_spec("matplotlib") is not None:
+            raise RuntimeError("matplotlib present: plotting not exercised here")
+        opt.descent_plot(g["X0"], g["U0"], "quasi", points=4)
+
+
 # ---- non-uniform time base (the reference's DSystem takes any time vector, dsystem.py:229-274) -----------------------------
 def _nonuniform():
     import trep_amd

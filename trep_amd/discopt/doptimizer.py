@@ -391,6 +391,41 @@ class DOptimizer(object):
         error = approx - exact
         return self.check_ddcost_return(abs(error) <= tolerance, error, dcosts[1], dcosts[0], approx, exact)
 
+    # -- cost along a descent direction (doptimizer.py:569-617) ------------------------------------------------------------
+    def descent_curves(self, X, U, method='steepest', points=40):
+        """The data of the reference's descent plot: the projected cost g(z) = cost(P(X + z dX, U + z dU)) on `points` values of
+        z in [-0.1, 1.01] plus the Armijo steps beta^m, m < 20, the quadratic model cost + z dcost + z^2 ddcost / 2 and the
+        Armijo bound cost + alpha z dcost.  All projections are ONE batch of closed-loop rollouts on the device.  Returns a dict
+        of arrays (differences to the cost at z = 0; NaN where a projection did not converge)."""
+        (Kproj, dX, dU, Q, R, S) = self.calc_descent_direction(X, U, method)
+        armijo_z = np.sort(self.armijo_beta ** np.arange(20.0))
+        z = np.sort(np.concatenate((np.linspace(-0.1, 1.01, points), armijo_z)))
+        cost = self.calc_cost(X, U)
+        dcost = self.calc_dcost(X, U, dX, dU)
+        ddcost = self.calc_ddcost(X, U, dX, dU, Q, R, S)
+        nX, nU, ok = self.project_candidates(X, U, Kproj, dX, dU, z)
+        true = np.array([self.calc_cost(nX[i], nU[i]) if ok[i] else np.nan for i in range(len(z))])
+        pick = np.searchsorted(z, armijo_z)
+        return {"z": z, "true": true - cost, "model": dcost * z + 0.5 * ddcost * z * z, "armijo_z": armijo_z,
+                "armijo": true[pick] - cost, "required": self.armijo_alpha * z * dcost, "cost": cost, "dcost": dcost, "ddcost": ddcost}
+
+    def descent_plot(self, X, U, method='steepest', points=40, legend=True):
+        """Plot descent_curves() with matplotlib (same four curves and labels as the reference's plot)."""
+        try:
+            from matplotlib import pyplot
+        except ImportError:
+            raise RuntimeError("Importing matplotlib failed. Cannot create plot.")
+        d = self.descent_curves(X, U, method, points)
+        pyplot.plot(d["z"], d["model"], '-,', linewidth=2.0, color='blue', label='Modeled Cost')
+        pyplot.plot(d["z"], d["true"], '.-', linewidth=1.0, color='black', label='True Cost')
+        pyplot.plot(d["armijo_z"], d["armijo"], 'o', color='gray', label='Armijo Evaluations')
+        pyplot.plot(d["z"], d["required"], '-.', color='black', label='Required Cost Improvement')
+        if legend:
+            pyplot.legend(loc=0)
+        pyplot.title('Cost along descent direction for method: "%s".' % method)
+        pyplot.xlabel('z')
+        pyplot.ylabel(r'$\Delta$ cost')
+
     def select_method(self, iteration):
         return self.first_method if iteration < self.first_method_iterations else self.second_method
 

@@ -46,12 +46,17 @@ def exchange_unique_id(rank, world, make_id, timeout=300.0):
         os.replace(tmp, path)
         return blob, path
     t0 = time.time()
+    try:        # a file left behind by an earlier launch with the same key is older than this process: never take it
+        born = os.stat("/proc/%d" % os.getpid()).st_ctime - 30.0
+    except OSError:
+        born = 0.0
     while True:
         try:
-            with open(path, "rb") as fh:
-                blob = fh.read()
-            if len(blob) == ID_BYTES:
-                return blob, path
+            if os.stat(path).st_mtime >= born:
+                with open(path, "rb") as fh:
+                    blob = fh.read()
+                if len(blob) == ID_BYTES:
+                    return blob, path
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout:
