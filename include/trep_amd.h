@@ -97,6 +97,16 @@ typedef struct tg_system_desc {
     const int32_t *linear_damper_frame1; /* [n_linear_dampers] */
     const int32_t *linear_damper_frame2; /* [n_linear_dampers] */
     const double  *linear_damper_c;      /* [n_linear_dampers] */
+    /* potentials/nonlinear_config_spring.c:24-61: dV/dq = -y(m q + b) on one config, y a piecewise-quintic Spline
+     * (trep/spline.py:6-259, evaluation _trep/spline.c:8-57).  Spring i uses the table rows first[i] .. first[i+1]-1, one row per
+     * polynomial piece in x order: (left knot, a, b, c, d, e, f), y = a t^5 + b t^4 + c t^3 + d t^2 + e t + f with t = x - left knot;
+     * the first / last piece also serve x below / above the knots. */
+    int32_t n_nonlinear_springs;
+    const int32_t *nonlinear_spring_config; /* [n_nonlinear_springs] config index */
+    const double  *nonlinear_spring_m;      /* [n_nonlinear_springs] */
+    const double  *nonlinear_spring_b;      /* [n_nonlinear_springs] */
+    const int32_t *nonlinear_spring_first;  /* [n_nonlinear_springs + 1] CSR offsets into the rows of nonlinear_spring_pieces */
+    const double  *nonlinear_spring_pieces; /* [rows * 7] */
 } tg_system_desc;
 
 /* Per-trajectory status written by every solve (reference: ConvergenceError / ValueError("singular")

@@ -15,6 +15,7 @@ BUILDERS = {
     "puppet40": lambda: systems.puppet(),
     "puppet_basic": lambda: systems.puppet_basic(),
     "spring_arm": lambda: systems.spring_arm(),
+    "nonlinear_spring_arm": lambda: systems.nonlinear_spring_arm(),
     "spring_link": lambda: systems.spring_link(),
     "plane_link": lambda: systems.plane_link(),
     "wrench_arm": lambda: systems.wrench_arm(),

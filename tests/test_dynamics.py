@@ -7,7 +7,7 @@ import pytest
 
 from common import GOLDEN, build, relerr
 
-NAMES = ["pendulum5", "pend_on_cart", "scissor4", "puppet40", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "wrench_torque", "dual_pendulums", "wrench_spatial", "wrench_body", "damper_link"]
+NAMES = ["pendulum5", "pend_on_cart", "scissor4", "puppet40", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "wrench_torque", "dual_pendulums", "wrench_spatial", "wrench_body", "damper_link", "nonlinear_spring_arm"]
 
 
 def golden():

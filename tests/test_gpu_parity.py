@@ -132,7 +132,7 @@ def test_residual_matches_oracle():
 
 
 @pytest.mark.parametrize("name,B,N", [("puppet40", 48, 40), ("scissor4", 33, 60), ("pend_on_cart", 67, 100),
-                                      ("spring_arm", 37, 80), ("spring_link", 29, 60), ("wrench_arm", 41, 80), ("wrench_torque", 23, 60), ("wrench_spatial", 19, 60), ("wrench_body", 17, 60),
+                                      ("spring_arm", 37, 80), ("nonlinear_spring_arm", 37, 80), ("spring_link", 29, 60), ("wrench_arm", 41, 80), ("wrench_torque", 23, 60), ("wrench_spatial", 19, 60), ("wrench_body", 17, 60),
                                       ("extensor_tendon", 21, 100), ("dual_pendulums", 35, 120)])
 def test_random_batch_matches_oracle(name, B, N):
     """Seeded random initial conditions / inputs, HIP vs oracle, ragged batch sizes."""
@@ -322,7 +322,7 @@ def test_deriv1_accessors_dropin():
     assert mvi.q2_dk2().shape == (2, 0)
 
 
-@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "pendulum5", "spring_arm", "plane_link", "wrench_arm", "puppet_forces", "wrench_torque", "wrench_spatial", "wrench_body", "damper_link"])
+@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "pendulum5", "spring_arm", "nonlinear_spring_arm", "plane_link", "wrench_arm", "puppet_forces", "wrench_torque", "wrench_spatial", "wrench_body", "damper_link"])
 def test_dsystem_linearization_matches_reference(name):
     """DSystem.set(X[k],U[k],k,xk_hint=X[k+1]) -> f, fdx (A_k), fdu (B_k) vs the reference's DSystem."""
     import trep_amd
@@ -351,7 +351,7 @@ def test_dsystem_linearization_matches_reference(name):
     assert lin.A.shape == (3, one.nX, one.nX) and lin.B.shape == (3, one.nX, one.nU)
 
 
-@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "pendulum5", "spring_arm", "plane_link", "wrench_arm", "puppet_forces", "wrench_torque", "wrench_spatial", "wrench_body", "damper_link"])
+@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "pendulum5", "spring_arm", "nonlinear_spring_arm", "plane_link", "wrench_arm", "puppet_forces", "wrench_torque", "wrench_spatial", "wrench_body", "damper_link"])
 def test_dsystem_second_order_matches_reference(name):
     """fdxdx(z), fdxdu(z), fdudu(z) vs the reference DSystem (dsystem.py:320-386) for two z."""
     import trep_amd
@@ -375,7 +375,7 @@ def test_dsystem_second_order_matches_reference(name):
     assert np.array_equal(xx[0], xx[2])
 
 
-@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "puppet_basic", "spring_arm", "plane_link", "wrench_arm", "puppet_forces", "wrench_torque", "wrench_spatial", "wrench_body", "damper_link"])
+@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "puppet_basic", "spring_arm", "nonlinear_spring_arm", "plane_link", "wrench_arm", "puppet_forces", "wrench_torque", "wrench_spatial", "wrench_body", "damper_link"])
 def test_full_second_derivative_tensors_match_reference(name):
     """MidpointVI.q2_dq1dq1() ... p2_dk2dk2(), lambda1_dq1dq1() ... accessors vs the reference's [A][B][out] tensors."""
     import trep_amd

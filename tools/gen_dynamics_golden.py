@@ -34,6 +34,7 @@ BUILDERS = {
     "wrench_spatial": lambda: systems.wrench_spatial(api=trep),
     "wrench_body": lambda: systems.wrench_body(api=trep),
     "damper_link": lambda: systems.damper_link(api=trep),
+    "nonlinear_spring_arm": lambda: systems.nonlinear_spring_arm(api=trep),
 }
 N_STATES = 4
 

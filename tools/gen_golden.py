@@ -276,6 +276,32 @@ def gen_spring_arm():
     save("spring_arm", **arrays, **ds)
 
 
+def gen_nonlinear_spring_arm():
+    """Synthetic system with NonlinearConfigSpring potentials (nonlinear_config_spring.c, spline.py): free-running rollouts
+    under a random torque and a moving base that leave the splines' knot ranges, full derivative tensors, DSystem captures;
+    also the spline tables themselves (x points, coefficients) of the three curves."""
+    system = systems.nonlinear_spring_arm(api=trep)
+    rng = np.random.default_rng(20250 + 27)
+    B, N = 2, 200
+    arrays = dict(dt=DT, **topology(system))
+    for i, pot in enumerate(p for p in system.potentials if hasattr(p, "spline")):
+        arrays["spline%d_x" % i] = pot.spline.x_points
+        arrays["spline%d_y" % i] = pot.spline.y_points
+        arrays["spline%d_c" % i] = pot.spline.coefficients
+    for b in range(B):
+        q0 = np.concatenate([rng.uniform(-0.8, 0.8, size=3), [0.2 * b]])
+        U = 3.0 * rng.standard_normal((N, 1))
+        K = (0.2 * b + 0.9 * np.sin(2.0 * DT * np.arange(1, N + 1)))[:, None]
+        r = rollout(system, q0, U, K, N, deriv_steps=(1, 50, N) if b == 0 else (), deriv2_full=True)
+        for key, val in r.items():
+            arrays["b%d_%s" % (b, key)] = val
+        arrays["b%d_q0" % b] = q0
+        arrays["b%d_U" % b] = U
+        arrays["b%d_K" % b] = K
+    ds = dsystem_captures(system, arrays["b0_Q"], arrays["b0_P"], arrays["b0_U"], arrays["b0_K"], (0, 10, 100), seed=36)
+    save("nonlinear_spring_arm", **arrays, **ds)
+
+
 def gen_spring_link():
     """Synthetic system with LinearSpring potentials and a distance constraint.  The reference defines no third
     derivative for LinearSpring, so only first derivatives are recorded."""
@@ -596,7 +622,7 @@ def gen_discopt_cart_nonuniform():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "wrench_torque", "dual_pendulums", "wrench_spatial", "wrench_body", "damper_link", "discopt", "discopt_puppet", "discopt_nonuniform"]
+    which = sys.argv[1:] or ["known", "pend1", "pend5", "cart", "scissor", "puppet", "puppet_basic", "spring_arm", "nonlinear_spring_arm", "spring_link", "plane_link", "wrench_arm", "puppet_forces", "extensor_tendon", "wrench_torque", "dual_pendulums", "wrench_spatial", "wrench_body", "damper_link", "discopt", "discopt_puppet", "discopt_nonuniform"]
     if "known" in which:
         gen_known_answer()
     if "pend1" in which:
@@ -633,6 +659,8 @@ if __name__ == "__main__":
         gen_spring_link()
     if "spring_arm" in which:
         gen_spring_arm()
+    if "nonlinear_spring_arm" in which:
+        gen_nonlinear_spring_arm()
     if "discopt" in which:
         gen_discopt_cart()
     if "discopt_puppet" in which:

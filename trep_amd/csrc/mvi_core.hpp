@@ -250,6 +250,31 @@ template <int V> struct IntTag { static constexpr int value = V; };
 template <int TEAM, bool SPRINGS = false, class PROG = CProg>
 struct Core {
     TG_HD bool has_cs() const { return SPRINGS && P.has_cs; }
+    // Potentials on a single config: d1 = V_dq, d2 = V_dqdq, d3 = V_dqdqdq of config i at the value q.  ConfigSpring
+    // (configspring.c:22-45): k (q - q0), k, 0, summed per config on the host.  NonlinearConfigSpring
+    // (nonlinear_config_spring.c:24-61): -y(x), -y'(x) m, +y''(x) m^2 with x = m q + b and y the piecewise quintic of
+    // trep/spline.py (table rows: left knot, a..f; piece = number of later pieces whose left knot is <= x, spline.c:8-22).
+    // The sign of the third derivative is the reference's (-ddy * -m * m, :48-58), not the derivative of the second.
+    TG_HD void cs_eval(int i, double q, double &d1, double &d2, double &d3) const {
+        d1 = P.cs_k[i] * q - P.cs_kq0[i]; d2 = P.cs_k[i]; d3 = 0.0;
+        for (int sp = 0; sp < P.n_ncs; sp++) {
+            if (P.ncs_i[3 * sp] != i) continue;
+            const double m = P.ncs_mb[2 * sp], x = m * q + P.ncs_mb[2 * sp + 1];
+            const double *tab = P.ncs_tab + 7 * (size_t)P.ncs_i[3 * sp + 1];
+            const int pieces = P.ncs_i[3 * sp + 2];
+            int seg = 0;
+            for (int j = 1; j < pieces; j++) seg += x >= tab[7 * j] ? 1 : 0;
+            const double *c = tab + 7 * seg;
+            const double t = x - c[0];
+            const double y = c[1] * t * t * t * t * t + c[2] * t * t * t * t + c[3] * t * t * t + c[4] * t * t + c[5] * t + c[6];
+            const double dy = 5 * c[1] * t * t * t * t + 4 * c[2] * t * t * t + 3 * c[3] * t * t + 2 * c[4] * t + 1 * c[5];
+            const double ddy = 20 * c[1] * t * t * t + 12 * c[2] * t * t + 6 * c[3] * t + 2 * c[4];
+            d1 -= y; d2 -= dy * m; d3 += ddy * m * m;
+        }
+    }
+    TG_HD double cs_d1(int i, double q) const { double a, b, c; cs_eval(i, q, a, b, c); return a; }
+    TG_HD double cs_d2(int i, double q) const { double a, b, c; cs_eval(i, q, a, b, c); return b; }
+    TG_HD double cs_d3(int i, double q) const { double a, b, c; cs_eval(i, q, a, b, c); return c; }
     TG_HD int n_springs() const { return SPRINGS ? P.n_springs : 0; }
     TG_HD int n_spair() const { return SPRINGS ? P.n_spair : 0; }
     TG_HD int n_sdh() const { return SPRINGS ? P.n_sdh : 0; }
@@ -1013,7 +1038,7 @@ struct Core {
             double ldq = 0.0, lddq = 0.0;
             const int n1 = P.cfg_item_off[i + 1];
             for (int n = P.cfg_item_off[i]; n < n1; n++) { lddq += terms[2 * n]; ldq += terms[2 * n + 1]; }
-            if (has_cs()) ldq -= P.cs_k[i] * qval(0, i) - P.cs_kq0[i];   // config springs (configspring.c:22-31)
+            if (has_cs()) ldq -= cs_d1(i, qval(0, i));   // config springs (configspring.c:22-31, nonlinear_config_spring.c:24-34)
             if (n_springs()) ldq -= S[P.o_sV + i];
             S[P.o_Ldq + i] = ldq; S[P.o_Lddq + i] = lddq;
             double force = -P.damp[i] * S[P.o_dq + i];
@@ -1117,7 +1142,7 @@ struct Core {
             if (on) {
                 if (lane < nf) {
                     A[lane * ld + nf] = S[P.o_f + lane];
-                    if (lane < nd) A[lane * ld + lane] = -tdamp - (has_cs() ? 0.25 * dt * P.cs_k[lane] : 0.0);
+                    if (lane < nd) A[lane * ld + lane] = -tdamp - (has_cs() ? 0.25 * dt * cs_d2(lane, qval(0, lane)) : 0.0);
                 }
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
@@ -1130,7 +1155,7 @@ struct Core {
         if (on) {
             TG_FOR(r, nf) {
                 A[r * ld + nf] = S[P.o_f + r];
-                if (r < nd) A[r * ld + r] = -P.damp[r] - (has_cs() ? 0.25 * dt * P.cs_k[r] : 0.0);   // + dt/4 (-V_dqdq)
+                if (r < nd) A[r * ld + r] = -P.damp[r] - (has_cs() ? 0.25 * dt * cs_d2(r, qval(0, r)) : 0.0);   // + dt/4 (-V_dqdq)
             }
             TG_FOR(n, P.n_dh) {
                 const int c = P.dh_pack[8 * (size_t)n], k = P.dh_pack[8 * (size_t)n + 1];
@@ -1671,7 +1696,7 @@ struct Core {
                 AUG[o * ld + c_q1 + o] -= P.damp[o];       // -(D1D1L2_D1fm2): -( - dF_o/d(dq_o) )
                 AUG[o * ld + c_p1 + o] = -1.0;
                 if (has_cs()) {   // a = dt/4 (-V_dqdq) on the diagonal of all four second-order tables
-                    const double a_ = -0.25 * dt * P.cs_k[o];
+                    const double a_ = -0.25 * dt * cs_d2(o, qval(0, o));
                     AUG[o * ld + c_q1 + o] -= a_; AUG[o * ld + o] += a_;
                     T12[o * nd + o] += a_; T22[o * nd + o] += a_;
                 }
@@ -2575,6 +2600,12 @@ struct Core {
             lds_add(&H11[sym(ka, kb)], val);
             lds_add(&H22[sym(ka, kb)], val);
         }
+        if (has_cs() && P.n_ncs && on) TG_FOR(i, nd) {   // -dt V(q_mid): every third derivative D_a D_b D_o L2 on config i is -dt/8 V_dqdqdq
+            const double val = (zp[i] - w[i]) * (-0.125 * dt * cs_d3(i, qval(0, i)));
+            lds_add(&H12[i * hl + i], val);
+            lds_add(&H11[sym(i, i)], val);
+            lds_add(&H22[sym(i, i)], val);
+        }
         TG_SYNC();
         TG_D2STAMP(1);
         const double c8 = 0.125 * dt, c2 = 0.5 / dt;
@@ -3061,7 +3092,7 @@ struct Core {
             TG_FOR(i, nd) {
                 double force = -P.damp[i] * S[P.o_dq + i];
                 for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
-                if (has_cs()) force -= P.cs_k[i] * S[P.o_q2 + i] - P.cs_kq0[i];
+                if (has_cs()) force -= cs_d1(i, S[P.o_q2 + i]);
                 if (n_springs()) force -= S[P.o_sV + i];
                 if (n_wrenches()) force += S[P.o_wF + i];
                 if (has_damper()) force += S[P.o_sF + i];
@@ -3113,7 +3144,7 @@ struct Core {
             }
             if (has_cs()) TG_FOR(i, P.nq) {
                 const double q = S[P.o_q2 + i];
-                lds_add(&acc[1], 0.5 * P.cs_k[i] * q * q - P.cs_kq0[i] * q + P.cs_c0[i]);
+                lds_add(&acc[1], 0.5 * P.cs_k[i] * q * q - P.cs_kq0[i] * q + P.cs_c0[i]);   // (a NonlinearConfigSpring's V() is 0 in the reference, :15-22)
             }
             TG_FOR(sp, n_springs()) {
                 const int c = P.nc + sp;
@@ -3170,8 +3201,10 @@ struct Core {
                 }
             }
             if (has_cs()) TG_FOR(i, nq) {
-                gl_add(&o1[i], -(P.cs_k[i] * S[P.o_q2 + i] - P.cs_kq0[i]));
-                gl_add(&o2[(size_t)i * nq + i], -P.cs_k[i]);
+                double d1_, d2_, d3_;
+                cs_eval(i, S[P.o_q2 + i], d1_, d2_, d3_);
+                gl_add(&o1[i], -d1_);
+                gl_add(&o2[(size_t)i * nq + i], -d2_);
             }
             if (n_springs()) TG_FOR(i, nq) gl_add(&o1[i], -S[P.o_sV + i]);
             TG_FOR(pp, n_spair()) {
@@ -3301,7 +3334,7 @@ struct Core {
             TG_FOR(i, nd) {
                 lds_add(&AUG[i * ld + c_dq + i], -P.damp[i]);
                 for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) lds_add(&AUG[i * ld + c_u + P.cf_in[k]], 1.0);
-                if (has_cs()) lds_add(&AUG[i * ld + c_q + i], -P.cs_k[i]);
+                if (has_cs()) lds_add(&AUG[i * ld + c_q + i], -cs_d2(i, S[P.o_q2 + i]));
             }
             TG_FOR(pp, n_wpair()) {
                 const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + n_spair() + pp);

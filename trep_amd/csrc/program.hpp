@@ -113,6 +113,8 @@ struct DevProg {
     const int *tab_i; const double *tab_d; int n_tab_i, n_tab_d;  // the packed table buffers (all pointers above point into them)
     int e_o_H11, e_o_H12, e_o_H22, e_o_G1, e_o_w, e_o_zq, e_o_zp, e_o_vec, e_o_vec2, e_lds_per_team;
     const double *cs_c0;          // [nq] 1/2 sum k q0^2 (constant part of V)
+    // NonlinearConfigSpring: per spring (config, first table row, pieces), (m, b); table rows (left knot, a, b, c, d, e, f) per piece
+    const int *ncs_i; const double *ncs_mb, *ncs_tab; int n_ncs;
 };
 
 struct HostProgram {
@@ -127,7 +129,8 @@ struct HostProgram {
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
     std::vector<double> c_dist, c_tol;
     std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
-    std::vector<double> damp, cs_k, cs_kq0, cs_c0, s_k, s_x0, s_c, c_nloc, wr_const, wr_Rloc;
+    std::vector<double> damp, cs_k, cs_kq0, cs_c0, s_k, s_x0, s_c, c_nloc, wr_const, wr_Rloc, ncs_mb, ncs_tab;
+    std::vector<int> ncs_i;
     std::vector<int> wr_in, wr_kind;
     std::vector<int> cf_cfg, cf_in;
     std::vector<double> jcoef;      // [n_joints*16*4] local-transform coefficients (see pose_sweep)
@@ -473,6 +476,13 @@ inline HostProgram build_program(const tg_system_desc *d) {
         H.cs_k[c] += d->config_spring_k[i]; H.cs_kq0[c] += d->config_spring_k[i] * d->config_spring_q0[i];
         H.cs_c0[c] += 0.5 * d->config_spring_k[i] * d->config_spring_q0[i] * d->config_spring_q0[i];
     }
+    for (int i = 0, row = 0; i < d->n_nonlinear_springs; i++) {
+        const int c = d->nonlinear_spring_config[i], r0 = d->nonlinear_spring_first[i], r1 = d->nonlinear_spring_first[i + 1];
+        if (c < 0 || c >= nq || r1 - r0 < 1) throw std::runtime_error("nonlinear config spring: bad config index or empty spline");
+        H.ncs_i.push_back(c); H.ncs_i.push_back(row); H.ncs_i.push_back(r1 - r0);
+        H.ncs_mb.push_back(d->nonlinear_spring_m[i]); H.ncs_mb.push_back(d->nonlinear_spring_b[i]);
+        for (int r = r0; r < r1; r++, row++) for (int k = 0; k < 7; k++) H.ncs_tab.push_back(d->nonlinear_spring_pieces[(size_t)7 * r + k]);
+    }
     for (int i = 0; i < d->n_config_forces; i++) {
         H.cf_cfg.push_back(d->config_force_config[i]); H.cf_in.push_back(d->config_force_input[i]);
     }
@@ -485,7 +495,8 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.n_cfgitems = (int)H.cfg_items.size();
     P.n_npairs = (int)(H.pair4.size() / 4);
     P.n_tri = (int)(H.tri4.size() / 4); P.n_cpair = n_cpair_con; P.n_spair = n_cpair_spr - n_cpair_con; P.n_wpair = (int)(H.cpair4.size() / 4) - n_cpair_spr;
-    P.has_cs = d->n_config_springs > 0 ? 1 : 0;
+    P.has_cs = (d->n_config_springs > 0 || d->n_nonlinear_springs > 0) ? 1 : 0;
+    P.n_ncs = d->n_nonlinear_springs;
     P.n_cpath = (int)H.cpath_items.size();
     P.grav[0] = P.grav[1] = P.grav[2] = 0.0;
     for (int i = 0; i < d->n_gravity; i++)
@@ -603,8 +614,8 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(level_off) X(lvl_joints) X(round_off) X(ch_first) X(ch_len) X(ch_parent) X(j_parent) X(j_kind) X(j_cfg) X(j_pre_ident) X(b_anchor) X(b_item_off) X(b_pair_off) X(it_body) \
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
-    X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in) X(wr_kind)
-#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c) X(wr_Rloc)
+    X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in) X(wr_kind) X(ncs_i)
+#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c) X(wr_Rloc) X(ncs_mb) X(ncs_tab)
 
 inline void HostProgram::pack() {
     ipool.clear(); dpool.clear(); ioff.clear(); doff.clear();

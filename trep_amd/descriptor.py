@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 
 from . import frame as _frame
-from .dynamics import Gravity, ConfigSpring, LinearSpring, Damping, ConfigForce, HybridWrench, SpatialWrench, BodyWrench, LinearDamper, Distance, PointToPoint1D, PointOnPlane
+from .dynamics import Gravity, ConfigSpring, NonlinearConfigSpring, LinearSpring, Damping, ConfigForce, HybridWrench, SpatialWrench, BodyWrench, LinearDamper, Distance, PointToPoint1D, PointOnPlane
 
 _I32 = ctypes.POINTER(ctypes.c_int32)
 _F64 = ctypes.POINTER(ctypes.c_double)
@@ -36,7 +36,9 @@ _TAIL = [("n_config_springs", None), ("config_spring_config", _I32), ("config_sp
          ("n_linear_springs", None), ("linear_spring_frame1", _I32), ("linear_spring_frame2", _I32),
          ("linear_spring_k", _F64), ("linear_spring_x0", _F64), ("constraint_normal", _F64),
          ("n_hybrid_wrenches", None), ("hybrid_wrench_frame", _I32), ("hybrid_wrench_input", _I32), ("hybrid_wrench_const", _F64), ("hybrid_wrench_kind", _I32),
-         ("n_linear_dampers", None), ("linear_damper_frame1", _I32), ("linear_damper_frame2", _I32), ("linear_damper_c", _F64)]   # in struct order (include/trep_amd.h)
+         ("n_linear_dampers", None), ("linear_damper_frame1", _I32), ("linear_damper_frame2", _I32), ("linear_damper_c", _F64),
+         ("n_nonlinear_springs", None), ("nonlinear_spring_config", _I32), ("nonlinear_spring_m", _F64), ("nonlinear_spring_b", _F64),
+         ("nonlinear_spring_first", _I32), ("nonlinear_spring_pieces", _F64)]   # in struct order (include/trep_amd.h)
 _TAIL_SCALARS = [n for n, t in _TAIL if t is None]
 _TAIL_ARRAYS = [(n, t) for n, t in _TAIL if t is not None]
 
@@ -124,6 +126,7 @@ def flatten(system):
 
     grav, damp, cf_c, cf_u = [], [], [], []
     cs_c, cs_k, cs_q0 = [], [], []
+    ns_c, ns_m, ns_b, ns_first, ns_rows = [], [], [], [0], []
     ls_f1, ls_f2, ls_k, ls_x0 = [], [], [], []
     hw_f, hw_in, hw_c, hw_kind = [], [], [], []
     ld_f1, ld_f2, ld_c = [], [], []
@@ -139,6 +142,13 @@ def flatten(system):
             cs_c.append(cidx[id(pot.config)])
             cs_k.append(pot.k)
             cs_q0.append(pot.q0)
+        elif isinstance(pot, NonlinearConfigSpring):
+            ns_c.append(cidx[id(pot.config)])
+            ns_m.append(float(pot.m))
+            ns_b.append(float(pot.b))
+            xp, co = pot.spline.x_points, pot.spline.coefficients
+            ns_rows += [[xp[k]] + list(co[k]) for k in range(len(co))]
+            ns_first.append(len(ns_rows))
         else:
             raise NotImplementedError("potential %r is outside the device path's scope" % (pot,))
     for force in system.forces:
@@ -179,6 +189,12 @@ def flatten(system):
     t["hybrid_wrench_input"] = np.array(hw_in, dtype=np.int32)
     t["hybrid_wrench_const"] = np.array(hw_c, dtype=np.float64)
     t["hybrid_wrench_kind"] = np.array(hw_kind, dtype=np.int32)
+    t["n_nonlinear_springs"] = len(ns_c)
+    t["nonlinear_spring_config"] = np.array(ns_c, dtype=np.int32)
+    t["nonlinear_spring_m"] = np.array(ns_m, dtype=np.float64)
+    t["nonlinear_spring_b"] = np.array(ns_b, dtype=np.float64)
+    t["nonlinear_spring_first"] = np.array(ns_first, dtype=np.int32)
+    t["nonlinear_spring_pieces"] = np.array(ns_rows, dtype=np.float64).reshape(-1)
     t["n_linear_dampers"] = len(ld_c)
     t["linear_damper_frame1"] = np.array(ld_f1, dtype=np.int32)
     t["linear_damper_frame2"] = np.array(ld_f2, dtype=np.int32)

@@ -89,6 +89,37 @@ class ConfigSpring(Potential):
         return 0.5 * self._k * (self._config.q - self._q0) ** 2
 
 
+class NonlinearConfigSpring(Potential):
+    """A spring on one configuration variable whose force is a curve: dV/dq = -f(m q + b), f a ``trep_amd.Spline``
+    (potentials/nonlinear_config_spring.py:15-40, _trep/potentials/nonlinear_config_spring.c:15-61).  As in the reference the
+    potential VALUE is not defined (``V()`` returns 0: only its derivatives enter simulation and optimisation) and the
+    spline is copied at construction."""
+
+    def __init__(self, system, config, spline, m=1.0, b=0.0, name=None):
+        from .spline import Spline
+        Potential.__init__(self, system, name)
+        if not system.get_config(config):
+            raise ValueError("Could not find config %r" % config)
+        self._config = system.get_config(config)
+        if not isinstance(spline, Spline):
+            raise TypeError("spline must be a trep_amd.Spline")
+        self._spline = spline.copy()
+        self._m = float(m)
+        self._b = float(b)
+        system._structure_changed()
+
+    def __repr__(self):
+        return "<NonlinearConfigSpring %r m=%f b=%f>" % (self._config.name, self._m, self._b)
+
+    config = property(lambda self: self._config)
+    spline = property(lambda self: self._spline)
+    m = property(lambda self: self._m)
+    b = property(lambda self: self._b)
+
+    def V(self):
+        return 0.0
+
+
 class LinearSpring(Potential):
     """V = 1/2 k (|p(frame1) - p(frame2)| - x0)^2 (potentials/linearspring.py:15-70)."""
 

@@ -78,6 +78,36 @@ def spring_arm(api=None):
     return system
 
 
+def nonlinear_spring_arm(api=None):
+    """The arm of spring_arm() with NonlinearConfigSpring potentials (force curves given by splines): two curves on one
+    config (one of them scaled and shifted, m = -1.5, b = 0.4), one next to a ConfigSpring, one on the kinematic slider,
+    curves with prescribed end slopes / curvatures and with none, and states that leave the knot range on both sides.
+    Synthetic test system for potentials/nonlinear_config_spring.c and trep/spline.py."""
+    T = _api(api)
+    system = T.System()
+    system.import_frames([
+        T.tx('slide', name='Base', kinematic=True), [
+            T.rz('a', name='Shoulder'), [
+                T.tx(1.0, name='Upper', mass=2.0), [
+                    T.ry('b', name='Elbow'), [
+                        T.tx(0.8, name='Fore', mass=(1.0, 0.1, 0.2, 0.3)), [
+                            T.rx('c', name='Wrist'), [
+                                T.tz(-0.5, name='Hand', mass=0.5)]]]]]]])
+    T.potentials.Gravity(system, (0.3, 0, -9.8))
+    soft = T.Spline([(-1.0, -6.0), (-0.3, -1.0), (0.2, 0.5), (0.9, 4.0), (1.6, 5.0)])
+    stiff = T.Spline([(-0.8, 3.0, -2.0), (0.0, 0.0), (0.5, -1.0, None, 0.5), (1.2, -4.0, -6.0, 0.0)])
+    bump = T.Spline([(-0.5, 0.0, 0.0, 0.0), (0.0, 1.5), (0.4, 0.2), (0.7, 0.0, 0.0, 0.0)])
+    T.potentials.NonlinearConfigSpring(system, 'a', soft)
+    T.potentials.NonlinearConfigSpring(system, 'a', bump, m=-1.5, b=0.4)
+    T.potentials.NonlinearConfigSpring(system, 'b', stiff, m=0.8, b=-0.1)
+    T.potentials.ConfigSpring(system, 'b', k=5.0, q0=0.1)
+    T.potentials.NonlinearConfigSpring(system, 'c', bump, m=2.0)
+    T.potentials.NonlinearConfigSpring(system, 'slide', soft, m=1.0, b=0.2)
+    T.forces.Damping(system, 0.1)
+    T.forces.ConfigForce(system, 'a', 'a-torque')
+    return system
+
+
 def spring_link(api=None):
     """Two branches joined by two-point springs: a 3-D arm on a kinematic slider and a telescopic pendulum held at
     unit length by a distance constraint; one LinearSpring from the arm's tip to a fixed anchor (rest length 1), one
