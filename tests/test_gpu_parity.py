@@ -205,6 +205,31 @@ def test_long_chain_matches_oracle(links, B, N):
     mvi.close()
 
 
+@pytest.mark.parametrize("segments,B,N", [(6, 7, 40), (8, 5, 30)])
+def test_large_constrained_system_matches_oracle(segments, B, N):
+    """Shape edge: scissor lifts with 13 / 17 bodies have constraints (so a Newton iteration sweeps the midpoint and the q2 poses
+    in one dual pass) but more per-lane table rows than two trips of a wavefront hold, so they take the dual pass WITHOUT the
+    one-phase-ahead table fetches (eval_both instead of eval_both_tab); 8 segments (nf = 33) also use the LDS Gauss-Jordan."""
+    from oracle.oracle import OracleMVI
+    from trep_amd import systems, descriptor
+    system = systems.scissor_lift(segments)
+    d = descriptor.flatten(system)
+    rng = np.random.default_rng(segments)
+    th = rng.uniform(0.04 * np.pi, 0.1 * np.pi, B)
+    Q0 = np.array([systems.scissor_q(system, t) for t in th])
+    mvi = _batch(system, B)
+    mvi.initialize_from_configs(0.0, Q0, DT, Q0)
+    X = mvi.rollout(N, DT, np.zeros((B, N, 0)), np.zeros((B, N, 0)))
+    iters, status = mvi.status()
+    assert (status == 0).all()
+    o = OracleMVI(d)
+    for b in range(B):
+        o.initialize_from_configs(0.0, Q0[b], DT, Q0[b])
+        Xo, tot = o.rollout(N, DT, np.zeros((N, 0)), np.zeros((N, 0)))
+        assert relerr(X[b], Xo) < TOL, (segments, b, relerr(X[b], Xo))
+    mvi.close()
+
+
 def test_many_chains_matches_oracle():
     """Shape edge: 20 two-link chains hanging off the world -- more chains in a sweep round than the LDS chain
     schedule holds (16), so the sweep reads its schedule from the global tables; 40 bodies, nd = 40 > 32 (LDS
