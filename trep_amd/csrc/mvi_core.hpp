@@ -38,6 +38,25 @@
 #define TG_SYNC() ((void)0)
 #endif
 
+#if defined(__HIPCC__)
+// The LDS slice of a workgroup.  The kernels of this library have no static LDS, so their dynamic LDS starts at LDS address 0.
+// Saying so -- instead of going through the `extern __shared__` symbol, whose address is only known at link time -- makes every
+// "LDS base + offset" a plain number: with the schedule compiled in (spec_kernel.hip) ~50 loop-invariant addresses fold into the
+// offset fields of the ds_* instructions and stop occupying scalar registers (-7 % rollout time), in the generic kernels one add
+// per address goes away.  A literal 0 would be the null pointer, which is -1 in this address space: hence 8 - 1 element.  The
+// symbol's real address is checked once per kernel (a workgroup-uniform compare) and the kernel traps if it is not 0.
+__device__ __forceinline__ double *tg_lds_base() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) double lds_double;
+    extern __shared__ double tg_dynamic_lds[];
+    if ((__UINTPTR_TYPE__)(lds_double *)tg_dynamic_lds != 0) __builtin_trap();
+    return (double *)((lds_double *)(__UINTPTR_TYPE__)8 - 1);
+#else
+    return nullptr;
+#endif
+}
+#endif
+
 // The lane index is laundered through an empty asm at the head of every phase loop: the optimiser then
 // cannot hoist lane-derived addresses and table look-ups of ALL phases out of the Newton / step loops
 // (which made it keep hundreds of loop-invariant values alive and spill).

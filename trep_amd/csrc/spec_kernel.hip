@@ -29,7 +29,7 @@ namespace {
 template <int MODE, int PIVOT = 0>
 __global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z) ? 1 : 2) void k_spec(SPEC_KERNEL_ARGS) {
     SPEC_ARGS_REF;
-    extern __shared__ double lds[];
+double *lds = tg_lds_base();
     const SpecProg P{};
     const int team = threadIdx.x / SPEC_TEAM, lane = threadIdx.x % SPEC_TEAM;
     const int traj = blockIdx.x * (64 / SPEC_TEAM) + team;

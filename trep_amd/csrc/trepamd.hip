@@ -35,7 +35,7 @@ int fail(int code, const std::string &msg) {
 // register file of a SIMD (no spills, deeper unrolling); the rollout modes run two wavefronts per SIMD.
 template <int TEAM, int MODE, bool SPRINGS>
 __global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z || MODE == tg::MODE_DYN_DERIV1) ? 1 : 2) void k_run(const tg::DevProg *__restrict__ Pg, const tg::RunArgs A) {
-    extern __shared__ double lds[];
+    double *lds = tg_lds_base();
     // The schedule sits in device memory and is read through a CONSTANT-address-space reference (mvi_core.hpp, CProg):
     // every field access is a scalar load that a phase issues when it needs it, instead of ~150 kernel-argument values
     // that the compiler would hoist, keep alive for the whole rollout and spill into VGPR lanes.
