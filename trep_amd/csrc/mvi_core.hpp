@@ -1552,8 +1552,16 @@ struct Core {
             const double pkk = bcast(row[k]);
             double rp = tg_rcp(pkk);          // 1/pivot (the multipliers need not be correctly rounded)
             const double l = (go && mine && !is_piv) ? row[k] * rp : 0.0;
+            // two pivot-row entries are broadcast before their two FMAs: a v_readlane result cannot be consumed by the next VALU
+            // instruction (two wait states), so one broadcast-FMA pair at a time costs an s_nop per column (groups of four make
+            // the unroller give up on the row registers: 420 instead of 66 ms)
 #pragma unroll
-            for (int j = k + 1; j < N; j++) row[j] = fma(-l, bcast(row[j]), row[j]);
+            for (int j = k + 1; j < N; j += 2) {
+                const double b0 = bcast(row[j]);
+                const double b1 = bcast(row[j + 1 < N ? j + 1 : j]);
+                row[j] = fma(-l, b0, row[j]);
+                if (j + 1 < N) row[j + 1] = fma(-l, b1, row[j + 1]);
+            }
             rhs = fma(-l, prhs, rhs);
             if (go && is_piv) { mycol = k; diag = row[k]; }
             // keep the elimination pivot-major (see gj_rows_exact)
