@@ -19,6 +19,7 @@ damper, point-on-plane, Python-defined callbacks) are out of scope (SURVEY.md §
 import numpy as np
 
 from .config import Config, Input
+from . import element_queries as _eq
 
 
 class Potential(object):
@@ -28,6 +29,40 @@ class Potential(object):
         system._add_potential(self)
 
     system = property(lambda self: self._system)
+
+    # value / derivative queries at the system's current configuration (potential.py:42-76); host-side, see element_queries.py
+    def _query(self, configs):
+        raise NotImplementedError("%s defines no potential queries" % type(self).__name__)
+
+    def V(self):
+        return self._query(())
+
+    def V_dq(self, q1):
+        _eq.check_configs(q1)
+        return self._query((q1,))
+
+    def V_dqdq(self, q1, q2):
+        _eq.check_configs(q1, q2)
+        return self._query((q1, q2))
+
+    def V_dqdqdq(self, q1, q2, q3):
+        _eq.check_configs(q1, q2, q3)
+        return self._query((q1, q2, q3))
+
+    # finite-difference checks of the derivative queries (potential.py:78-110)
+    def validate_V_dq(self, delta=1e-6, tolerance=1e-6, verbose=False):
+        return self._system.test_derivative_dq(self.V, self.V_dq, delta, tolerance, verbose=verbose,
+                                               test_name='%s.V_dq()' % type(self).__name__)
+
+    def validate_V_dqdq(self, delta=1e-6, tolerance=1e-6, verbose=False):
+        return all([self._system.test_derivative_dq(lambda q1=q1: self.V_dq(q1), lambda q2, q1=q1: self.V_dqdq(q1, q2), delta, tolerance,
+                                                    verbose=verbose, test_name='%s.V_dqdq()' % type(self).__name__)
+                    for q1 in self._system.configs])
+
+    def validate_V_dqdqdq(self, delta=1e-6, tolerance=1e-6, verbose=False):
+        return all([self._system.test_derivative_dq(lambda q1=q1, q2=q2: self.V_dqdq(q1, q2), lambda q3, q1=q1, q2=q2: self.V_dqdqdq(q1, q2, q3),
+                                                    delta, tolerance, verbose=verbose, test_name='%s.V_dqdqdq()' % type(self).__name__)
+                    for q1, q2 in _eq.pairs(self._system, 2)])
 
 
 class Gravity(Potential):
@@ -48,6 +83,9 @@ class Gravity(Potential):
     def gravity(self, g):
         self._gravity = (float(g[0]), float(g[1]), float(g[2]))
         self._system._structure_changed()
+
+    def _query(self, configs):
+        return _eq.gravity(self, configs)
 
 
 class ConfigSpring(Potential):
@@ -85,8 +123,8 @@ class ConfigSpring(Potential):
         self._q0 = float(value)
         self._system._structure_changed()
 
-    def V(self):
-        return 0.5 * self._k * (self._config.q - self._q0) ** 2
+    def _query(self, configs):
+        return _eq.config_spring(self, configs)
 
 
 class NonlinearConfigSpring(Potential):
@@ -116,8 +154,8 @@ class NonlinearConfigSpring(Potential):
     m = property(lambda self: self._m)
     b = property(lambda self: self._b)
 
-    def V(self):
-        return 0.0
+    def _query(self, configs):
+        return _eq.nonlinear_config_spring(self, configs)
 
 
 class LinearSpring(Potential):
@@ -159,9 +197,8 @@ class LinearSpring(Potential):
         self._x0 = float(value)
         self._system._structure_changed()
 
-    def V(self):
-        x = float(np.linalg.norm(self._frame1.p()[:3] - self._frame2.p()[:3]))
-        return 0.5 * self._k * (x - self._x0) ** 2
+    def _query(self, configs):
+        return _eq.linear_spring(self, configs)
 
 
 class Force(object):
@@ -176,6 +213,44 @@ class Force(object):
         new_input = Input(self._system, name)
         new_input._force = self
         return new_input
+
+    # generalized force on config q and its derivatives at the system's current state (force.py:46-145); host-side, see
+    # element_queries.py.  The defaults (zero) are what the reference's elements return for the derivatives they do not have.
+    def f(self, q):
+        return 0.0
+
+    def f_dq(self, q, q1):
+        return 0.0
+
+    def f_ddq(self, q, dq1):
+        return 0.0
+
+    def f_du(self, q, u1):
+        return 0.0
+
+    def f_dqdq(self, q, q1, q2):
+        return 0.0
+
+    def f_ddqdq(self, q, dq1, q2):
+        return 0.0
+
+    def f_ddqddq(self, q, dq1, dq2):
+        return 0.0
+
+    def f_dudq(self, q, u1, q2):
+        return 0.0
+
+    def f_duddq(self, q, u1, dq2):
+        return 0.0
+
+    def f_dudu(self, q, u1, u2):
+        return 0.0
+
+    def validate_f_dq(self, delta=1e-6, tolerance=1e-6, verbose=False):
+        """f_dq() against central differences of f() (force.py:147-160)."""
+        return all([self._system.test_derivative_dq(lambda q=q: self.f(q), lambda q1, q=q: self.f_dq(q, q1), delta, tolerance,
+                                                    verbose=verbose, test_name='%s.f_dq()' % type(self).__name__)
+                    for q in self._system.configs])
 
 
 class Damping(Force):
@@ -208,6 +283,12 @@ class Damping(Force):
             self.coefficients[self._system.get_config(config)] = float(coeff)
         self._system._structure_changed()
 
+    def f(self, q):
+        return -self.get_damping_coefficient(q) * q.dq if not q.kinematic else 0.0
+
+    def f_ddq(self, q, dq1):
+        return -self.get_damping_coefficient(q) if (q is dq1 and not q.kinematic) else 0.0
+
     @property
     def default(self):
         return self._default
@@ -230,6 +311,12 @@ class ConfigForce(Force):
 
     finput = property(lambda self: self._input)
     config = property(lambda self: self._config)
+
+    def f(self, q):
+        return self._input.u if q is self._config else 0.0
+
+    def f_du(self, q, u1):
+        return 1.0 if (q is self._config and u1 is self._input) else 0.0
 
 
 class HybridWrench(Force):
@@ -267,15 +354,40 @@ class HybridWrench(Force):
         self._system._structure_changed()
 
 
+    _twist_kind = "hybrid"
+
+    def _twist(self, q, configs):
+        return _eq.wrench_twist(self, q, configs, self._twist_kind)
+
+    def f(self, q):
+        return float(self._twist(q, ()).dot(_eq.wrench_value(self)))
+
+    def f_dq(self, q, q1):
+        return float(self._twist(q, (q1,)).dot(_eq.wrench_value(self)))
+
+    def f_dqdq(self, q, q1, q2):
+        return float(self._twist(q, (q1, q2)).dot(_eq.wrench_value(self)))
+
+    def f_du(self, q, u1):
+        vec = self._twist(q, ())
+        return float(sum(vec[i] for i in range(6) if self._wrench_vars[i] is u1))
+
+    def f_dudq(self, q, u1, q2):
+        vec = self._twist(q, (q2,))
+        return float(sum(vec[i] for i in range(6) if self._wrench_vars[i] is u1))
+
+
 class SpatialWrench(HybridWrench):
     """A wrench given in spatial (world) coordinates: its six components multiply the spatial twist of each joint of the
     frame's path, i.e. the force acts at the point of the frame that coincides with the world origin
     (forces/spatialwrench.py:14-37, spatialwrench.c:16-38)."""
+    _twist_kind = "spatial"
 
 
 class BodyWrench(HybridWrench):
     """A wrench given in the coordinates of the frame it is applied to: its six components multiply the body twist of each
     joint of the frame's path (forces/bodywrench.py, bodywrench.c:16-38)."""
+    _twist_kind = "body"
 
 
 class LinearDamper(Force):
@@ -305,6 +417,33 @@ class LinearDamper(Force):
         self._c = float(value)
         self._system._structure_changed()
 
+    # lineardamper.c:14-92 with x = |p1 - p2| and v = dx/dt = sum_k x_k dq_k
+    def _on(self, *configs):
+        return all(self._frame1.uses_config(c) or self._frame2.uses_config(c) for c in configs)
+
+    def f(self, q):
+        return -self._c * _eq.velocity(self) * _eq.length_dq(self, q) if self._on(q) else 0.0
+
+    def f_dq(self, q, q1):
+        if not self._on(q, q1):
+            return 0.0
+        return -self._c * (_eq.velocity_dq(self, q1) * _eq.length_dq(self, q) + _eq.velocity(self) * _eq.length_dqdq(self, q, q1))
+
+    def f_ddq(self, q, dq1):
+        return -self._c * _eq.length_dq(self, dq1) * _eq.length_dq(self, q) if self._on(q, dq1) else 0.0
+
+    def f_dqdq(self, q, q1, q2):
+        if not self._on(q, q1, q2):
+            return 0.0
+        return -self._c * (_eq.velocity_dqdq(self, q1, q2) * _eq.length_dq(self, q) + _eq.velocity_dq(self, q1) * _eq.length_dqdq(self, q, q2) +
+                           _eq.velocity_dq(self, q2) * _eq.length_dqdq(self, q, q1) + _eq.velocity(self) * _eq.length_dqdqdq(self, q, q1, q2))
+
+    def f_ddqdq(self, q, dq1, q2):
+        """(The second term uses d x / d q2 where d2 x / dq dq2 is meant -- the reference's expression, lineardamper.c:88.)"""
+        if not self._on(q, dq1, q2):
+            return 0.0
+        return -self._c * (_eq.length_dqdq(self, dq1, q2) * _eq.length_dq(self, q) + _eq.length_dq(self, dq1) * _eq.length_dq(self, q2))
+
 
 class Constraint(object):
     def __init__(self, system, name=None, tolerance=1e-10):
@@ -325,6 +464,49 @@ class Constraint(object):
         p1 = self.frame1.p()
         p2 = self.frame2.p()
         return ((p1[0] - p2[0]) ** 2.0 + (p1[1] - p2[1]) ** 2.0 + (p1[2] - p2[2]) ** 2.0) ** 0.5
+
+    # value / derivative queries at the system's current configuration (constraint.py:56-102); host-side, see element_queries.py
+    def _query(self, configs):
+        raise NotImplementedError("%s defines no constraint queries" % type(self).__name__)
+
+    def h(self):
+        return self._query(())
+
+    def h_dq(self, q1):
+        _eq.check_configs(q1)
+        return self._query((q1,))
+
+    def h_dqdq(self, q1, q2):
+        _eq.check_configs(q1, q2)
+        return self._query((q1, q2))
+
+    def h_dqdqdq(self, q1, q2, q3):
+        _eq.check_configs(q1, q2, q3)
+        return self._query((q1, q2, q3))
+
+    def h_dqdqdqdq(self, q1, q2, q3, q4):
+        _eq.check_configs(q1, q2, q3, q4)
+        return self._query((q1, q2, q3, q4))
+
+    # finite-difference checks (constraint.py:104-150)
+    def validate_h_dq(self, delta=1e-6, tolerance=1e-6, verbose=False):
+        return self._system.test_derivative_dq(self.h, self.h_dq, delta, tolerance, verbose=verbose, test_name='%s.h_dq()' % type(self).__name__)
+
+    def _validate_higher(self, order, delta, tolerance, verbose):
+        lower = (self.h_dq, self.h_dqdq, self.h_dqdqdq)[order - 2]
+        upper = (self.h_dqdq, self.h_dqdqdq, self.h_dqdqdqdq)[order - 2]
+        return all([self._system.test_derivative_dq(lambda qs=qs: lower(*qs), lambda qn, qs=qs: upper(*(qs + (qn,))), delta, tolerance,
+                                                    verbose=verbose, test_name='%s.h_%s()' % (type(self).__name__, 'dq' * order))
+                    for qs in _eq.pairs(self._system, order - 1)])
+
+    def validate_h_dqdq(self, delta=1e-6, tolerance=1e-6, verbose=False):
+        return self._validate_higher(2, delta, tolerance, verbose)
+
+    def validate_h_dqdqdq(self, delta=1e-6, tolerance=1e-6, verbose=False):
+        return self._validate_higher(3, delta, tolerance, verbose)
+
+    def validate_h_dqdqdqdq(self, delta=1e-6, tolerance=1e-6, verbose=False):
+        return self._validate_higher(4, delta, tolerance, verbose)
 
 
 class Distance(Constraint):
@@ -351,17 +533,8 @@ class Distance(Constraint):
     frame1 = property(lambda self: self._frame1)
     frame2 = property(lambda self: self._frame2)
 
-    def h(self):
-        """Constraint value at the system's current configuration (host, setup only; distance.c:16-33)."""
-        d = self.frame1.p()[:3] - self.frame2.p()[:3]
-        return float(d.dot(d) - self.distance ** 2)
-
-    def h_dq(self, config):
-        d = self.frame1.p()[:3] - self.frame2.p()[:3]
-        val = 2.0 * d.dot(self.frame1.p_dq(config)[:3] - self.frame2.p_dq(config)[:3])
-        if self._config is not None and config is self._config:
-            val -= 2.0 * self.distance
-        return float(val)
+    def _query(self, configs):
+        return _eq.distance(self, configs)
 
     @property
     def distance(self):
@@ -395,12 +568,8 @@ class PointToPoint1D(Constraint):
     frame2 = property(lambda self: self._frame2)
     component = property(lambda self: self._component)
 
-    def h(self):
-        """Constraint value at the system's current configuration (host, setup only; point.c:16-27)."""
-        return float((self.frame1.p() - self.frame2.p())[self._component])
-
-    def h_dq(self, config):
-        return float((self.frame1.p_dq(config) - self.frame2.p_dq(config))[self._component])
+    def _query(self, configs):
+        return _eq.point_1d(self, configs)
 
 
 class PointOnPlane(Constraint):
@@ -431,19 +600,8 @@ class PointOnPlane(Constraint):
         self._normal = (float(normal[0]), float(normal[1]), float(normal[2]))
         self._system._structure_changed()
 
-    def h_dq(self, config):
-        """dh/dq by central differences (host, setup only: satisfy_constraints / minimize_potential_energy)."""
-        q, d = config.q, 1e-7
-        config.q = q + d
-        hp = self.h()
-        config.q = q - d
-        hm = self.h()
-        config.q = q
-        return (hp - hm) / (2 * d)
-
-    def h(self):
-        g = self._plane_frame.g()
-        return float(np.dot(g[:3, :3].dot(self._normal), (self._plane_frame.p() - self._point_frame.p())[:3]))
+    def _query(self, configs):
+        return _eq.point_on_plane(self, configs)
 
 
 class _PointGroup(object):

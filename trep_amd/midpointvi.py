@@ -695,6 +695,23 @@ class MidpointVI(object):
     def calc_f(self):
         return self._batch().calc_f()[0]
 
+    def set_midpoint(self):
+        """Put the System object at the midpoint of the current step: q = (q1 + q2) / 2, dq = (q2 - q1) / (t2 - t1), u = u1,
+        t = (t1 + t2) / 2 (midpointvi.c:430-455).  Host-side state of the model object only; the device state is untouched."""
+        sys_ = self._system
+        sys_.t = 0.5 * (self.t1 + self.t2)
+        sys_.q = 0.5 * (np.asarray(self.q1) + np.asarray(self.q2))
+        sys_.dq = (np.asarray(self.q2) - np.asarray(self.q1)) / (self.t2 - self.t1)
+        if self.nu:
+            sys_.u = self.u1
+
+    def discrete_fm2(self):
+        """The discrete forcing of the step, fm2_i = (t2 - t1) sum_forces f(q_i) at the midpoint state, for every dynamic
+        config (midpointvi.c:478-482, 2710-2728).  Evaluated through the host-side force queries (Force.f)."""
+        self.set_midpoint()
+        dt = self.t2 - self.t1
+        return np.array([dt * sum(f.f(q) for f in self._system.forces) for q in self._system.dyn_configs])
+
     def step(self, t2, u1=tuple(), k2=tuple(), max_iterations=200, q2_hint=None, lambda1_hint=None):
         """Advance to t2; returns the Newton iteration count, raises ConvergenceError like the
         reference (midpointvi.py:174-201; midpointvi.c:715-718; singular -> :198-201)."""
