@@ -90,3 +90,19 @@ def test_set_midpoint_and_discrete_fm2_match_reference():
     mvi.set_midpoint()
     assert np.abs(np.array(system.q) - g["fm2_mid_q"]).max() < 1e-14 and np.abs(np.array(system.dq) - g["fm2_mid_dq"]).max() < 1e-11
     assert abs(system.t - g["fm2_mid_t"][0]) < 1e-15
+
+
+def test_tape_measure_matches_reference():
+    import trep_amd
+    from trep_amd import systems
+    g = golden("elements")
+    system = systems.extensor_tendon()
+    system.q, system.dq = g["tape_q"], g["tape_dq"]
+    tape = trep_amd.TapeMeasure(system, [str(n) for n in g["tape_frames"]])
+    C = list(system.configs)
+    for acc in ("length", "length_dq", "length_dqdq", "length_dqdqdq", "velocity", "velocity_dq", "velocity_dqdq", "velocity_ddq", "velocity_ddqdq"):
+        want = g["tape_" + acc]
+        got = _tensor(getattr(tape, acc), [C] * want.ndim)
+        assert np.abs(got - want).max() <= 1e-11 * max(1.0, np.abs(want).max()), acc
+    assert tape.validate_length_dq() and tape.validate_length_dqdq() and tape.validate_velocity_dq() and tape.validate_velocity_ddq()
+    assert tape.validate_velocity_ddqdq() and tape.validate_velocity_dqdq(tolerance=1e-5) and tape.validate_length_dqdqdq(tolerance=1e-5)

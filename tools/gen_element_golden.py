@@ -77,6 +77,19 @@ def main():
     out["fm2_q1"], out["fm2_q2"], out["fm2_u1"], out["fm2_value"] = q1, q2, u1, np.array(mvi.discrete_fm2())
     mvi.set_midpoint()
     out["fm2_mid_q"], out["fm2_mid_dq"], out["fm2_mid_t"] = np.array(ref.q), np.array(ref.dq), np.array([ref.t])
+    # TapeMeasure through five frames of the extensor-tendon arm (tapemeasure.py:14-70)
+    ref = systems.extensor_tendon(api=trep)
+    rng = np.random.default_rng(9)
+    ref.q = np.array(ref.q) + 0.3 * rng.standard_normal(ref.nQ)
+    ref.dq = rng.standard_normal(ref.nQ)
+    names = [f.name for f in ref.frames if f.name][1::3][:5]
+    tape = trep.TapeMeasure(ref, names)
+    C = list(ref.configs)
+    out["tape_q"], out["tape_dq"] = np.array(ref.q), np.array(ref.dq)
+    out["tape_frames"] = np.array(names)
+    for acc, n in (("length", 0), ("length_dq", 1), ("length_dqdq", 2), ("length_dqdqdq", 3), ("velocity", 0), ("velocity_dq", 1),
+                   ("velocity_dqdq", 2), ("velocity_ddq", 1), ("velocity_ddqdq", 2)):
+        out["tape_" + acc] = tensor(getattr(tape, acc), [C] * n)
     path = os.path.join(REPO, "tests", "golden", "elements.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

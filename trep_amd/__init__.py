@@ -16,9 +16,10 @@ from .dynamics import Potential, Force, Constraint
 from . import potentials, forces, constraints, puppets, systems
 from .errors import ConvergenceError
 from .spline import Spline
+from .tapemeasure import TapeMeasure
 from .midpointvi import MidpointVI, BatchMidpointVI
 from . import discopt
 
-__all__ = ["Spline", "System", "save_trajectory", "load_trajectory", "Frame", "Config", "Input", "Potential", "Force", "Constraint", "MidpointVI",
+__all__ = ["Spline", "TapeMeasure", "System", "save_trajectory", "load_trajectory", "Frame", "Config", "Input", "Potential", "Force", "Constraint", "MidpointVI",
            "BatchMidpointVI", "ConvergenceError", "tx", "ty", "tz", "rx", "ry", "rz", "const_se3",
            "const_txyz", "WORLD", "TX", "TY", "TZ", "RX", "RY", "RZ", "CONST_SE3"]
