@@ -1,8 +1,8 @@
 #!/bin/bash
-# Register / scratch / spill figures of every k_run instantiation (hipcc -Rpass-analysis=kernel-resource-usage).
+# Register / scratch / spill figures of every k_run instantiation (hipcc -Rpass-analysis=kernel-resource-usage, flags of csrc/Makefile).
 #   tools/resource_usage.sh ["extra flags"] [filter]
 cd "$(dirname "$0")/../trep_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $1 -Rpass-analysis=kernel-resource-usage -c -o /dev/null trepamd.hip 2>&1 | \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -disable-machine-licm $1 -Rpass-analysis=kernel-resource-usage -c -o /dev/null trepamd.hip 2>&1 | \
 python3 -c '
 import re, sys
 cur = None; rows = []
