@@ -312,6 +312,7 @@ struct Core {
     // joint (config | kind << 16) of the two sin/cos trips, the body's item range of the velocity prefix sums, and the
     // constant Newton-matrix entries (damping of this row, (constraint, config) of the lane's two Dh items, first pair record)
     int jck[2] = {0, 0}, bio[2] = {0, 0}, tck[2][2] = {{0, 0}, {0, 0}}, tpair[4] = {0, 0, 0, 0};
+    int sc_rot2 = 0;   // number of (pose set, rotary joint) items of the dual sin/cos pass: they come first in the lane order
     double tdamp = 0.0;
     long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long prof_last = 0;
@@ -359,10 +360,24 @@ struct Core {
         TG_FOR(c, P.nc) S[P.o_ctol + c] = P.c_tol[c];
 #if defined(__HIP_DEVICE_COMPILE__)
         if (TEAM == 64 && P.tab_ok) {
+            // Lane order of the 2 x n_joints (pose set, joint) items of the sin/cos pass: the rotary joints of both pose sets first,
+            // then the prismatic ones -- so that the second trip of the wavefront (puppet: 68 items, 38 of them rotary) has no
+            // sin/cos to evaluate and skips that code.  jck: config | kind << 12 | joint << 16 | pose set << 28.
+            int n_rot = 0;
+            for (int j = 0; j < P.n_joints; j++) n_rot += P.j_kind[j] >= TG_RX ? 1 : 0;
+            sc_rot2 = 2 * n_rot;
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                const int j = lane + u * TEAM < 2 * P.n_joints ? (lane + u * TEAM) % P.n_joints : 0;
-                jck[u] = P.j_cfg[j] | (P.j_kind[j] << 16);
+                const int pos = lane + u * TEAM;
+                const bool rot = pos < 2 * n_rot;
+                const int per_set = rot ? n_rot : P.n_joints - n_rot, t = rot ? pos : pos - 2 * n_rot;
+                const int set = (per_set > 0 && t >= per_set) ? 1 : 0, rank = t - set * per_set;
+                int jj = 0, seen = 0;
+                for (int j = 0; j < P.n_joints; j++) {
+                    const bool r_ = P.j_kind[j] >= TG_RX;
+                    if (r_ == rot) { if (seen == rank) jj = j; seen++; }
+                }
+                jck[u] = pos < 2 * P.n_joints ? (P.j_cfg[jj] | (P.j_kind[jj] << 12) | (jj << 16) | (set << 28)) : 0;
                 const int n = lane + u * TEAM < P.n_dh ? lane + u * TEAM : 0;
                 if (P.n_dh) { tck[u][0] = P.dh_pack[8 * (size_t)n]; tck[u][1] = P.dh_pack[8 * (size_t)n + 1]; }
             }
@@ -514,12 +529,14 @@ struct Core {
                 for (int u = 0; u < 2; u++) {
                     const int idx = lane + u * TEAM;
                     if (idx < 2 * nj) {
-                        const bool second = idx >= nj;
-                        const int j = second ? idx - nj : idx;
-                        const double x = qval(second ? 2 : 0, jck[u] & 0xFFFF);
+                        const bool second = (jck[u] >> 28) != 0;
+                        const int j = (jck[u] >> 16) & 0xFFF, kind = (jck[u] >> 12) & 0xF;
+                        const double x = qval(second ? 2 : 0, jck[u] & 0xFFF);
                         double *dst = (second ? sc2 : sc) + 2 * j;
-                        if ((jck[u] >> 16) >= TG_RX) tg_sincos(x, &dst[0], &dst[1]);
-                        else { dst[0] = x; dst[1] = 0.0; }
+                        if (u * TEAM < sc_rot2) {          // (wave-uniform) a trip with rotary joints in it
+                            if (kind >= TG_RX) tg_sincos(x, &dst[0], &dst[1]);
+                            else { dst[0] = x; dst[1] = 0.0; }
+                        } else { dst[0] = x; dst[1] = 0.0; }
                     }
                 }
             }

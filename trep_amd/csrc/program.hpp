@@ -523,7 +523,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.sched_ok = (12 * nj < 65536) ? 1 : 0;
     for (int r = 0; r < P.n_rounds; r++) if (H.round_off[r + 1] - H.round_off[r] > 16) P.sched_ok = 0;
     for (int c : H.ch_len) if (c >= 32768) P.sched_ok = 0;
-    P.tab_ok = (12 * (int)P.n_bodies <= 128 && 3 * (int)P.n_endpoints <= 64 && P.n_dh <= 128 && P.n_items <= 128 && P.nc <= 8 && P.nd + P.nc <= 64 &&
+    P.tab_ok = (nq < 4096 && nj < 4096 && 12 * (int)P.n_bodies <= 128 && 3 * (int)P.n_endpoints <= 64 && P.n_dh <= 128 && P.n_items <= 128 && P.nc <= 8 && P.nd + P.nc <= 64 &&
                 6 * (int)P.n_bodies <= 64 && 2 * nj <= 128) ? 1 : 0;
     if (P.sched_ok) {   // 2: no round has more than 8 chains (the dual sweep gives each pose set half a wavefront)
         P.sched_ok = 2;
