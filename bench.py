@@ -8,6 +8,7 @@ K[b,k,:]) already resident in HBM, states X[b,k,:] written back to HBM.  value =
 ranks / wall time between barriers.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
+  python bench.py --gpus N --steps K --warmup W         (no launcher: starts its own N rank processes, see self_launch)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -161,6 +162,78 @@ def pmc_fp64(batch, rollout_steps, workload_prefix):
     return best
 
 
+def self_launch(args):
+    """`bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N rank processes ourselves -- plain child
+    processes with RANK / LOCAL_RANK / WORLD_SIZE / TREPAMD_RUN_KEY in their environment, BEFORE this process has made any
+    GPU call (it never makes one) -- pass rank 0's JSON line through and exit with the worst return code."""
+    import subprocess
+    n = args.gpus
+    env0 = dict(os.environ)
+    env0["WORLD_SIZE"] = str(n)
+    env0["TREPAMD_RUN_KEY"] = "self%d_%d" % (os.getpid(), int(time.time() * 1e3) % 10 ** 9)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(env0)
+        env["RANK"] = env["LOCAL_RANK"] = str(r)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * n
+    first_failure = None
+    while any(c is None for c in codes):
+        for i, pr in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = pr.poll()
+                if codes[i] not in (None, 0) and first_failure is None:
+                    first_failure = time.time()
+        # a rank died: the others hang in a collective -- give them a moment, then stop exactly those children
+        if first_failure is not None and time.time() - first_failure > 30.0:
+            for i, pr in enumerate(procs):
+                if codes[i] is None:
+                    pr.kill()
+                    codes[i] = pr.wait()
+        time.sleep(0.05)
+    reader.join(timeout=10.0)
+    sys.stdout.write(b"".join(chunks).decode())
+    sys.stdout.flush()
+    sys.exit(max(abs(c) for c in codes))
+
+
+def dry_run_rank(args, world, rank):
+    """--dry-run-ranks: what a rank does before its first GPU call -- the file rendezvous of the communicator id and the
+    shard arithmetic -- and nothing else.  Used by the CPU test of the self-launcher (no GPU, no RCCL)."""
+    import hashlib
+    from trep_amd import rccl
+    from trep_amd.distributed import shard_bounds
+    blob, path = rccl.exchange_unique_id(rank, world, lambda: os.urandom(rccl.ID_BYTES), timeout=60.0)
+    digest = hashlib.sha256(blob).hexdigest()[:16]
+    mine = "%s.rank%d" % (path, rank)
+    with open(mine + ".tmp", "w") as fh:
+        fh.write(digest)
+    os.replace(mine + ".tmp", mine)
+    if rank != 0:
+        return
+    seen = []
+    t0 = time.time()
+    for r in range(world):
+        f = "%s.rank%d" % (path, r)
+        while not os.path.exists(f):
+            if time.time() - t0 > 60.0:
+                raise TimeoutError("rank %d never reported" % r)
+            time.sleep(0.01)
+        seen.append(open(f).read())
+        os.remove(f)
+    os.remove(path)
+    shards = [shard_bounds(args.batch, r, world) for r in range(world)]
+    print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_reported": len(seen), "same_id_on_every_rank": len(set(seen)) == 1,
+                      "shards": shards, "run_key": os.environ.get("TREPAMD_RUN_KEY")}))
+
+
 def measure_rollouts(args, system, Q0, U, K, dt, B, N, device, comm, gather_rows):
     """W warm-up + K timed passes of B trajectories x N steps on this rank; returns timing and status figures."""
     import trep_amd
@@ -187,9 +260,12 @@ def measure_rollouts(args, system, Q0, U, K, dt, B, N, device, comm, gather_rows
         mvi.restore()   # device-to-device: every pass integrates the same N-step window
         mvi.rollout_device(N, dt, U_dev, K_dev, X_dev)
         if comm is not None:
-            if rows is not None:   # term[b] = X[b][N] (default stream: ordered after the rollout, before the collective)
+            # the collective runs on the communicator's own stream: ordered after its producer by an event (tg_comm_wait_stream)
+            if rows is not None:   # term[b] = X[b][N], a NULL-stream kernel (the NULL stream waits for the batch's blocking stream)
                 _lib.check(L.tg_copy_rows(device, B, nX, None, rows, X_dev, term))
-            comm.all_gather_device(term, gather, gather_rows * nX * 8, synchronize=False)
+                comm.all_gather_device(term, gather, gather_rows * nX * 8, synchronize=False, after=None)
+            else:                  # --no-x: nothing between rollout and collective, the batch's stream is the producer
+                comm.all_gather_device(term, gather, gather_rows * nX * 8, synchronize=False, after=mvi.stream)
 
     def sync():
         mvi.synchronize()
@@ -212,8 +288,12 @@ def measure_rollouts(args, system, Q0, U, K, dt, B, N, device, comm, gather_rows
         elapsed = comm.max(elapsed)
     n_launch, kernel_ms = mvi.timing(reset=True)
     iters, status = mvi.status()
+    kinfo = mvi.kernel_info()
+    if specialised and "rollout" not in kinfo["spec_launched"]:
+        raise RuntimeError("the specialised rollout kernel was loaded but the launches went through the generic one: %r" % (kinfo,))
     res = {"elapsed": elapsed, "launches": n_launch, "kernel_ms": kernel_ms, "newton_iterations": int(iters.sum()),
-           "failed": int((status != 0).sum()), "info": mvi.info(), "specialised": bool(specialised), "nX": mvi.nX, "nU": mvi.nU, "nc": mvi.nc}
+           "failed": int((status != 0).sum()), "info": mvi.info(), "specialised": bool(specialised), "nX": mvi.nX, "nU": mvi.nU, "nc": mvi.nc,
+           "spec_library": os.path.relpath(kinfo["spec_library"], ROOT) if kinfo["spec_library"] else None}
     mvi.close()
     return res
 
@@ -242,11 +322,20 @@ def main():
                     help="run the generic rollout kernel (schedule interpreted at run time) instead of the system-specialised one "
                          "(trep_amd/specialize.py: the same kernel source compiled against the system's schedule)")
     ap.add_argument("--force-dist", action="store_true", help="take the RCCL path even with one rank (self-test)")
+    ap.add_argument("--dry-run-ranks", action="store_true",
+                    help="ranks only do the communicator-id rendezvous and the shard arithmetic (no GPU call): CPU test of the launcher")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)          # never returns; this process makes no GPU call
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
+    if args.dry_run_ranks:
+        dry_run_rank(args, world, rank)
+        return
     want_cpu = not args.no_cpu_baseline and world == 1 and args.system == "puppet"
     if want_cpu:      # compile the checker (a `make` child process) BEFORE this process touches the GPU
         from oracle import oracle as _oracle
@@ -268,6 +357,11 @@ def main():
     if world > 1 or args.force_dist:      # first GPU call of the process
         from trep_amd import rccl
         comm = rccl.Communicator.from_env()
+    rccl_ranks = 1
+    if comm is not None:      # what RCCL itself reports (ncclCommCount), not what the launcher said
+        rccl_ranks = comm.info()[0]
+        if rccl_ranks != world:
+            raise RuntimeError("RCCL reports %d ranks, the launcher %d" % (rccl_ranks, world))
 
     def shard_of_global():    # this rank's slice of ONE global batch of --batch trajectories (strong scaling)
         lo, hi = shard_bounds(B, rank, world)
@@ -307,7 +401,8 @@ def main():
         traffic = pmc_traffic(b_local, N, "Puppet(string_constraints=True)") if (world == 1 and args.system == "puppet") else None
         out = {
             "metric": "DEL-steps/sec x batch (%s, fp64)" % ("puppet ~40-DOF" if args.system == "puppet" else args.system),
-            "value": value, "unit": "DEL-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "DEL-steps/s", "n_gpus": rccl_ranks, "rccl_ranks": rccl_ranks if comm is not None else None,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("Puppet(string_constraints=True) nq=40 nd=22 nk=18 nc=6" if args.system == "puppet" else
@@ -320,7 +415,8 @@ def main():
                        "team": r["info"]["team"], "lds_bytes_per_trajectory": r["info"]["lds_bytes_per_trajectory"],
                        "newton_iterations_per_step": r["newton_iterations"] / float(b_local * N), "failed_trajectories": r["failed"],
                        "writes_X": not args.no_x, "newton_initial_guess": args.predictor,
-                       "kernel_variant": "system-specialised (schedule compiled in)" if r["specialised"] else "generic (schedule interpreted)"},
+                       "kernel_variant": "system-specialised (schedule compiled in)" if r["specialised"] else "generic (schedule interpreted)",
+                       "spec_library": r["spec_library"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,

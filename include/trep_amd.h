@@ -271,9 +271,19 @@ int tg_debug_solve(int32_t device, int32_t n, int32_t exact, const double *A_aug
  * tg_system_spec_header returns a generated C++ header (every size, count and LDS offset a constant, the index tables
  * constant arrays); trep_amd/specialize.py compiles csrc/spec_kernel.hip against it with hipcc and
  * tg_batch_load_specialized makes the rollouts of a batch use that kernel (same template source as the generic
- * kernel, bit-identical results).  Returns the text length incl. terminator (or -1). */
+ * kernel: identical Newton iteration counts, states equal up to the compiler's FMA contraction choices, <= 1e-12
+ * relative).  Returns the text length incl. terminator (or -1).
+ * tg_system_spec_key is the 64-bit FNV-1a hash of that text; a specialised library exports the key of the header it
+ * was compiled against (tg_spec_key) and tg_batch_load_specialized refuses a library whose key or sizes differ.
+ * tg_batch_info: out[0] bit m = kernel mode m has a specialised kernel loaded; out[1] / out[2] bit m = a mode-m launch
+ * went through a specialised / generic kernel since the batch was created; out[3] / out[4] = number of such launches;
+ * out[5] pivot rule; out[6] team size.  (Modes: 0 rollout/step, 1 calc_p2, 2 calc_f, 3 deriv1, 4 deriv2z, 5.. dynamics.) */
 int64_t tg_system_spec_header(const tg_system *sys, char *buf, uint64_t capacity);
+uint64_t tg_system_spec_key(const tg_system *sys);
 int tg_batch_load_specialized(tg_batch *b, const char *library_path);
+int tg_batch_info(const tg_batch *b, int32_t out[8]);
+/* The HIP stream (hipStream_t) the batch launches on, for ordering foreign work after it (tg_comm_wait_stream). */
+void *tg_batch_stream(tg_batch *b);
 
 /* HIP-event timing of the kernels launched on the batch's stream since the last reset (opt-in: the first call switches
  * the per-launch events on and returns zeros; launches before it are not timed):
@@ -415,10 +425,16 @@ typedef struct tg_comm tg_comm;
 int tg_comm_unique_id(uint8_t id_out[TG_COMM_ID_BYTES]);
 tg_comm *tg_comm_create(int32_t device, int32_t world, int32_t rank, const uint8_t id_in[TG_COMM_ID_BYTES]);
 void tg_comm_destroy(tg_comm *comm);
-int tg_comm_info(const tg_comm *comm, int32_t out[3]);   /* world, rank, device */
-/* recv_dev [world][bytes_per_rank] <- every rank's send_dev [bytes_per_rank]; asynchronous on the communicator's
- * stream, which is ordered after the default stream and the tg_batch streams of the device. */
+int tg_comm_info(const tg_comm *comm, int32_t out[3]);   /* ranks and this rank as RCCL reports them (ncclCommCount / ncclCommUserRank), device */
+/* recv_dev [world][bytes_per_rank] <- every rank's send_dev [bytes_per_rank]; asynchronous on the communicator's own
+ * stream.  That stream is ordered after work on the device's NULL stream only: a buffer produced on another stream (a
+ * tg_batch's: tg_batch_stream) must be handed over with tg_comm_wait_stream(comm, producer_stream) first -- it records an
+ * event on the producer and makes the communicator's stream wait for it (no host synchronisation).
+ * tg_comm_all_gather_after does both in one call.  tg_comm_stream_wait_comm is the other direction (a consumer stream waits for the collective). */
 int tg_comm_all_gather(tg_comm *comm, const void *send_dev, void *recv_dev, uint64_t bytes_per_rank);
+int tg_comm_wait_stream(tg_comm *comm, void *producer_hip_stream);
+int tg_comm_all_gather_after(tg_comm *comm, void *producer_hip_stream, const void *send_dev, void *recv_dev, uint64_t bytes_per_rank);
+int tg_comm_stream_wait_comm(tg_comm *comm, void *consumer_hip_stream);
 int tg_comm_synchronize(tg_comm *comm);
 /* In-place reduction of n host doubles over all ranks (blocking); tg_comm_barrier is a 1-element sum. */
 int tg_comm_all_reduce_host(tg_comm *comm, double *values, int32_t n, int32_t op);

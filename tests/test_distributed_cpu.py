@@ -118,3 +118,32 @@ def test_rccl_unique_id_rendezvous_through_a_file(tmp_path):
         assert os.path.exists(rccl._rendezvous_path())
     finally:
         del os.environ["TREPAMD_RUN_KEY"], os.environ["TREPAMD_RENDEZVOUS_DIR"]
+
+
+@pytest.mark.timeout(120)
+def test_bench_self_launcher_dry_run(tmp_path):
+    """`bench.py --gpus 2` with no launcher in the environment starts its own two rank processes (RANK / LOCAL_RANK /
+    WORLD_SIZE / TREPAMD_RUN_KEY) before any GPU call and prints rank 0's line; with --dry-run-ranks the ranks only do the
+    communicator-id rendezvous and the shard arithmetic, so this runs without a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TREPAMD_RUN_KEY")}
+    env["TREPAMD_RENDEZVOUS_DIR"] = str(tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-ranks", "--batch", "8193"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=100)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["dry_run"] and out["n_gpus"] == 2 and out["ranks_reported"] == 2 and out["same_id_on_every_rank"]
+    assert out["shards"] == [[0, 4097], [4097, 8193]]
+    assert out["run_key"].startswith("self")
+    assert not os.listdir(str(tmp_path))          # the rendezvous files are gone
+
+
+def test_bench_refuses_a_rank_count_that_contradicts_the_launcher():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run-ranks"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=100)
+    assert r.returncode != 0 and "--gpus 4" in r.stderr

@@ -16,6 +16,24 @@ def _batch(system, B):
     return trep_amd.BatchMidpointVI(system, B)
 
 
+# systems whose rollout / deriv1 / deriv2z kernels are ALSO run system-specialised (trep_amd/specialize.py) in the derivative
+# and pivot-rule tests below; every other system runs the generic kernels only (specialize=False is then the only case)
+SPEC_SYSTEMS = ("puppet40", "scissor4", "pend_on_cart")
+
+
+def _spec_cases(names):
+    return [(n, False) for n in names] + [(n, True) for n in names if n in SPEC_SYSTEMS]
+
+
+def _assert_kernels(info, spec, modes):
+    """The launches of `modes` went through the kind of kernel the test asked for -- and only through it."""
+    for m in modes:
+        if spec:
+            assert m in info["spec_modes"] and m in info["spec_launched"] and m not in info["generic_launched"], (m, info)
+        else:
+            assert m in info["generic_launched"] and m not in info["spec_launched"], (m, info)
+
+
 def test_library_reports_device():
     from trep_amd import _lib
     assert _lib.lib().tg_device_count() >= 1
@@ -259,16 +277,20 @@ def test_full_size_properties_puppet():
     """BASELINE puppet size (B=8192, N=200): every trajectory converges, the DEL residual of the final
     state vanishes, and results do not depend on batch composition (bit-identical sub-batch)."""
     from trep_amd import systems
+    from oracle.oracle import OracleMVI
+    from trep_amd import descriptor
     system, d = build("puppet40")
     B, N = 8192, 200
     nd = d.n_dyn
-    base = systems.puppet_initial_conditions(system, 64, seed=20250 + 3)
-    Q0 = np.tile(base, (B // 64, 1))
+    # the bench.py workload: 8192 DISTINCT initial conditions (SURVEY 8d), except that the last 64 slots repeat the first 64
+    Q0 = systems.puppet_initial_conditions(system, B, seed=20250 + 3)
+    Q0[B - 64:] = Q0[:64]
     K = systems.puppet_string_schedule(system, Q0[:, nd:], N, DT)
     mvi = _batch(system, B)
     mvi.initialize_from_configs(0.0, Q0, DT, Q0)
     K_dev = mvi.device_array(K)
-    mvi.rollout_device(N, DT, None, K_dev, None)
+    X_dev = mvi.device_empty(B * (N + 1) * mvi.nX)
+    mvi.rollout_device(N, DT, None, K_dev, X_dev)
     mvi.synchronize()
     iters, status = mvi.status()
     assert (status == 0).all()
@@ -277,11 +299,19 @@ def test_full_size_properties_puppet():
     assert np.linalg.norm(f[:, :nd], axis=1).max() < 1e-10
     assert np.abs(f[:, nd:]).max() < 1e-10
     q2 = mvi.q2
-    assert np.array_equal(q2[:64], q2[64:128])      # duplicates are bit-identical
+    assert np.array_equal(q2[:64], q2[B - 64:])     # duplicates are bit-identical
+    assert len(np.unique(np.round(q2[:B - 64], 9), axis=0)) == B - 64   # ... and the distinct ones stay distinct
     sub = _batch(system, 64)
-    sub.initialize_from_configs(0.0, base, DT, base)
+    sub.initialize_from_configs(0.0, Q0[:64], DT, Q0[:64])
     sub.rollout(N, DT, None, K[:64])
     assert np.array_equal(sub.q2, q2[:64])          # independent of batch size / placement
+    # three trajectories from the middle and the end of the batch against the oracle, whole state history
+    X = mvi.download(X_dev, (B, N + 1, mvi.nX))
+    o = OracleMVI(descriptor.flatten(system))
+    for b in (1, 4099, B - 65):
+        o.initialize_from_configs(0.0, Q0[b], DT, Q0[b])
+        Xo, _ = o.rollout(N, DT, None, K[b])
+        assert relerr(X[b], Xo) < TOL, b
     mvi.close(); sub.close()
 
 
@@ -303,9 +333,10 @@ def test_failure_statuses_and_edge_cases():
     mvi.close()
 
 
-@pytest.mark.parametrize("name", sorted(BUILDERS))
-def test_first_derivatives_match_reference(name):
-    """A_k / B_k ingredients: the twelve deriv1 arrays after a teacher-forced step."""
+@pytest.mark.parametrize("name,spec", _spec_cases(sorted(BUILDERS)))
+def test_first_derivatives_match_reference(name, spec):
+    """A_k / B_k ingredients: the twelve deriv1 arrays after a teacher-forced step -- generic kernels, and for the
+    BASELINE systems also the system-specialised ones (the mode bits of tg_batch_info prove which ran)."""
     import trep_amd
     from common import D1
     g = golden(name)
@@ -314,7 +345,7 @@ def test_first_derivatives_match_reference(name):
     Q, P, LAM = g[prefix + "Q"], g[prefix + "P"], g[prefix + "LAM"]
     steps = sorted(int(k.split("_")[-3]) for k in g if k.startswith(prefix + "d1_") and k.endswith("q2_dq1"))
     B = 3  # same case in every slot: also checks batch independence
-    mvi = trep_amd.BatchMidpointVI(system, B)
+    mvi = trep_amd.BatchMidpointVI(system, B, specialize=spec)
     for s_ in steps:
         k = s_ - 1
         mvi.initialize_from_state((k + 1) * DT, Q[k], P[k], LAM[k])
@@ -325,6 +356,7 @@ def test_first_derivatives_match_reference(name):
             got = mvi.deriv1(n)
             assert relerr(got[0], g["%sd1_%d_%s" % (prefix, s_, n)]) < 1e-9, (name, s_, n)
             assert np.array_equal(got[0], got[2])
+    _assert_kernels(mvi.kernel_info(), spec, ["rollout", "deriv1"])
     mvi.close()
 
 
@@ -376,8 +408,8 @@ def test_dsystem_linearization_matches_reference(name):
     assert lin.A.shape == (3, one.nX, one.nX) and lin.B.shape == (3, one.nX, one.nU)
 
 
-@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "pendulum5", "spring_arm", "nonlinear_spring_arm", "plane_link", "wrench_arm", "puppet_forces", "wrench_torque", "wrench_spatial", "wrench_body", "damper_link"])
-def test_dsystem_second_order_matches_reference(name):
+@pytest.mark.parametrize("name,spec", _spec_cases(["pend_on_cart", "scissor4", "puppet40", "pendulum5", "spring_arm", "nonlinear_spring_arm", "plane_link", "wrench_arm", "puppet_forces", "wrench_torque", "wrench_spatial", "wrench_body", "damper_link"]))
+def test_dsystem_second_order_matches_reference(name, spec):
     """fdxdx(z), fdxdu(z), fdudu(z) vs the reference DSystem (dsystem.py:320-386) for two z."""
     import trep_amd
     from trep_amd import discopt
@@ -385,23 +417,25 @@ def test_dsystem_second_order_matches_reference(name):
     system, d = build(name)
     X, U, Z = g["ds_X"], g["ds_U"], g["ds_Z"]
     t = DT * np.arange(len(X))
-    one = discopt.DSystem(trep_amd.MidpointVI(system), t)
+    one = discopt.DSystem(trep_amd.MidpointVI(system, specialize=spec), t)
     for k in [int(k) for k in g["ds_k"]]:
         one.set(X[k], U[k], k, xk_hint=X[k + 1])
         for zi in range(2):
             assert relerr(one.fdxdx(Z[zi]), g["ds_%d_fdxdx_%d" % (k, zi)]) < 1e-8, (name, k)
             assert relerr(one.fdxdu(Z[zi]), g["ds_%d_fdxdu_%d" % (k, zi)]) < 1e-8, (name, k)
             assert relerr(one.fdudu(Z[zi]), g["ds_%d_fdudu_%d" % (k, zi)]) < 1e-8, (name, k)
+    _assert_kernels(one.varint._batch().kernel_info(), spec, ["rollout", "deriv1", "deriv2z"])
     k = int(g["ds_k"][1])
-    bd = discopt.BatchDSystem(system, t, 3)
+    bd = discopt.BatchDSystem(system, t, 3, specialize=spec)
     bd.set(np.tile(X[k], (3, 1)), np.tile(U[k], (3, 1)), k, Xk_hint=np.tile(X[k + 1], (3, 1)))
     xx, xu, uu = bd.second_order(np.stack([Z[0], Z[1], Z[0]]))
     assert relerr(xx[1], g["ds_%d_fdxdx_1" % k]) < 1e-8 and relerr(uu[2], g["ds_%d_fdudu_0" % k]) < 1e-8
     assert np.array_equal(xx[0], xx[2])
+    _assert_kernels(bd.varint.kernel_info(), spec, ["rollout", "deriv2z"])
 
 
-@pytest.mark.parametrize("name", ["pend_on_cart", "scissor4", "puppet40", "puppet_basic", "spring_arm", "nonlinear_spring_arm", "plane_link", "wrench_arm", "puppet_forces", "wrench_torque", "wrench_spatial", "wrench_body", "damper_link"])
-def test_full_second_derivative_tensors_match_reference(name):
+@pytest.mark.parametrize("name,spec", _spec_cases(["pend_on_cart", "scissor4", "puppet40", "puppet_basic", "spring_arm", "nonlinear_spring_arm", "plane_link", "wrench_arm", "puppet_forces", "wrench_torque", "wrench_spatial", "wrench_body", "damper_link"]))
+def test_full_second_derivative_tensors_match_reference(name, spec):
     """MidpointVI.q2_dq1dq1() ... p2_dk2dk2(), lambda1_dq1dq1() ... accessors vs the reference's [A][B][out] tensors."""
     import trep_amd
     g = golden(name)
@@ -411,7 +445,7 @@ def test_full_second_derivative_tensors_match_reference(name):
     keys = [k for k in g if k.startswith(prefix + "d2_")]
     step = sorted(set(int(k.split("_")[-3]) for k in keys))[0]
     k0 = step - 1
-    mvi = trep_amd.MidpointVI(system)
+    mvi = trep_amd.MidpointVI(system, specialize=spec)
     mvi.initialize_from_state((k0 + 1) * DT, Q[k0], P[k0], LAM[k0])
     mvi.step((k0 + 2) * DT, U[k0], K[k0])
     checked = n_lambda = 0
@@ -426,6 +460,7 @@ def test_full_second_derivative_tensors_match_reference(name):
         checked += 1
         n_lambda += nm.startswith("lambda1")
     assert checked >= 4 and (n_lambda > 0 or system.nc == 0)
+    _assert_kernels(mvi._batch().kernel_info(), spec, ["rollout", "deriv1", "deriv2z"])
 
 
 def test_second_derivatives_undefined_with_linear_springs():
@@ -738,9 +773,11 @@ def test_newton_solver_default_pivot_rule():
         assert (st == 2) == singular
 
 
-def test_exact_pivot_rollout_agrees_with_default():
+@pytest.mark.parametrize("spec", [False, True])
+def test_exact_pivot_rollout_agrees_with_default(spec):
     """A puppet rollout under both pivot rules: same Newton iteration counts, states equal to 1e-11, and the exact rule within
-    the usual 1e-10 of the reference golden."""
+    the usual 1e-10 of the reference golden.  spec=True runs k_spec<0, 0> and k_spec<0, 1> (the specialised kernels of the two
+    rules), spec=False the generic ones."""
     import trep_amd
     system, d = build("puppet40")
     prefix, q0, U, K = trajectories("puppet40")[0]
@@ -748,7 +785,7 @@ def test_exact_pivot_rollout_agrees_with_default():
     N = 100
     out = []
     for exact in (False, True):
-        m = trep_amd.BatchMidpointVI(system, 2, specialize=False)
+        m = trep_amd.BatchMidpointVI(system, 2, specialize=spec)
         m.exact_pivot = exact
         Q0 = np.stack([q0, q0])
         m.initialize_from_configs(0.0, Q0, DT, Q0)
@@ -756,6 +793,9 @@ def test_exact_pivot_rollout_agrees_with_default():
         it, st = m.status()
         assert (st == 0).all()
         out.append((X, it))
+        info = m.kernel_info()
+        _assert_kernels(info, spec, ["rollout"])
+        assert info["exact_pivot"] == exact
         m.close()
     assert np.array_equal(out[0][1], out[1][1])
     assert relerr(out[0][0], out[1][0]) < 1e-11

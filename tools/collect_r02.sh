@@ -31,5 +31,5 @@ timeout 600 python tools/bench_derivs.py --batch 65536 > $out/bench_derivs.json 
 TREPAMD_NO_SPECIALIZE=1 timeout 600 python tools/bench_derivs.py --batch 65536 > $out/bench_derivs_generic.json 2>&1
 for sys in cart scissor puppet-basic; do timeout 600 python bench.py --system $sys --batch $([ $sys = puppet-basic ] && echo 8192 || echo 4096) --steps 10 --warmup 2 > $out/bench_$sys.json 2> $out/bench_$sys.err; done
 python tools/time_lq.py > $out/lq_mfma.json 2>/dev/null; TREPAMD_LQ_LEGACY=1 python tools/time_lq.py > $out/lq_legacy.json 2>/dev/null
-./tools/micro/mfma_f64_rate > $out/mfma_f64_rate.txt 2>&1
+tools/micro/build.sh > /dev/null && ./tools/micro/bin/mfma_f64_rate > $out/mfma_f64_rate.txt 2>&1
 ls -la $out; cat $out/bench.json | cut -c1-600; head -12 $out/kernel_stats.csv

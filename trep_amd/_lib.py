@@ -92,7 +92,10 @@ _SIGNATURES = {
     "tg_batch_set_pivot_rule": (ctypes.c_int, [_vp, _i32]),
     "tg_batch_set_step_sizes": (ctypes.c_int, [_vp, _i32, _vp, _i32]),
     "tg_system_spec_header": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64]),
+    "tg_system_spec_key": (ctypes.c_uint64, [ctypes.c_void_p]),
     "tg_batch_load_specialized": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
+    "tg_batch_info": (ctypes.c_int, [ctypes.c_void_p, _c_ip]),
+    "tg_batch_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
     # device-side discopt primitives
     "tg_batch_set_from_trajectories": (ctypes.c_int, [_vp, _i32, _i32, _f64, _f64, _vp, _vp, _i32]),
     "tg_batch_linearize": (ctypes.c_int, [_vp, _vp, _vp]),
@@ -113,6 +116,9 @@ _SIGNATURES = {
     "tg_comm_destroy": (None, [_vp]),
     "tg_comm_info": (ctypes.c_int, [_vp, _c_ip]),
     "tg_comm_all_gather": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint64]),
+    "tg_comm_wait_stream": (ctypes.c_int, [_vp, _vp]),
+    "tg_comm_all_gather_after": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_uint64]),
+    "tg_comm_stream_wait_comm": (ctypes.c_int, [_vp, _vp]),
     "tg_comm_synchronize": (ctypes.c_int, [_vp]),
     "tg_comm_all_reduce_host": (ctypes.c_int, [_vp, _c_dp, _i32, _i32]),
     "tg_comm_barrier": (ctypes.c_int, [_vp]),

@@ -36,6 +36,8 @@ struct Rccl {
     int (*GetUniqueId)(ncclUniqueId *) = nullptr;
     int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommCount)(const ncclComm_t, int *) = nullptr;
+    int (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -60,6 +62,8 @@ Rccl &rccl() {
     R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(sym("ncclGetUniqueId"));
     R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(sym("ncclCommInitRank"));
     R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
+    R.CommCount = reinterpret_cast<decltype(R.CommCount)>(sym("ncclCommCount"));
+    R.CommUserRank = reinterpret_cast<decltype(R.CommUserRank)>(sym("ncclCommUserRank"));
     R.AllGather = reinterpret_cast<decltype(R.AllGather)>(sym("ncclAllGather"));
     R.AllReduce = reinterpret_cast<decltype(R.AllReduce)>(sym("ncclAllReduce"));
     R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
@@ -85,6 +89,8 @@ struct tg_comm {
     hipStream_t stream = nullptr;
     double *scratch = nullptr;    // device staging of the host-scalar reductions
     size_t scratch_n = 0;
+    hipEvent_t handoff = nullptr; // producer stream -> communicator stream (tg_comm_wait_stream)
+    hipEvent_t done = nullptr;    // communicator stream -> consumer stream (tg_comm_stream_wait_comm)
 };
 
 extern "C" {
@@ -111,8 +117,15 @@ tg_comm *tg_comm_create(int32_t device, int32_t world, int32_t rank, const uint8
     std::memcpy(id.internal, id_in, TG_COMM_ID_BYTES);
     const int rc = R.CommInitRank(&c->comm, world, id, rank);
     if (rc != ncclSuccess) { rccl_fail("ncclCommInitRank", rc); delete c; return nullptr; }
-    // a blocking stream: ordered after the device's default stream and the tg_batch streams (see dopt.hip)
-    if (hipStreamCreate(&c->stream) != hipSuccess) { tg_detail::fail(TG_ERR_HIP, "hipStreamCreate failed"); R.CommDestroy(c->comm); delete c; return nullptr; }
+    // a blocking stream: implicitly ordered with the device's NULL stream only; work of any other stream (a tg_batch's) is
+    // handed over with an event (tg_comm_wait_stream)
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreateWithFlags(&c->handoff, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
+        tg_detail::fail(TG_ERR_HIP, "stream / event creation failed");
+        if (c->handoff) hipEventDestroy(c->handoff);
+        if (c->stream) hipStreamDestroy(c->stream);
+        R.CommDestroy(c->comm); delete c; return nullptr;
+    }
     return c;
 }
 
@@ -121,6 +134,8 @@ void tg_comm_destroy(tg_comm *c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm) rccl().CommDestroy(c->comm);
+    if (c->handoff) hipEventDestroy(c->handoff);
+    if (c->done) hipEventDestroy(c->done);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->scratch) hipFree(c->scratch);
     delete c;
@@ -128,7 +143,13 @@ void tg_comm_destroy(tg_comm *c) {
 
 int tg_comm_info(const tg_comm *c, int32_t out[3]) {
     if (!c) return tg_detail::fail(TG_ERR_INVALID, "null communicator");
-    out[0] = c->world; out[1] = c->rank; out[2] = c->device;
+    // what RCCL itself says about the communicator (not what the caller passed in)
+    int n = 0, r = -1;
+    int rc = rccl().CommCount(c->comm, &n);
+    if (rc != ncclSuccess) return rccl_fail("ncclCommCount", rc);
+    rc = rccl().CommUserRank(c->comm, &r);
+    if (rc != ncclSuccess) return rccl_fail("ncclCommUserRank", rc);
+    out[0] = n; out[1] = r; out[2] = c->device;
     return TG_SUCCESS;
 }
 
@@ -140,6 +161,27 @@ int tg_comm_all_gather(tg_comm *c, const void *send_dev, void *recv_dev, uint64_
     if (bytes_per_rank % 8 == 0) rc = rccl().AllGather(send_dev, recv_dev, (size_t)(bytes_per_rank / 8), ncclFloat64, c->comm, c->stream);
     else rc = rccl().AllGather(send_dev, recv_dev, (size_t)bytes_per_rank, ncclInt8, c->comm, c->stream);
     if (rc != ncclSuccess) return rccl_fail("ncclAllGather", rc);
+    return TG_SUCCESS;
+}
+
+int tg_comm_wait_stream(tg_comm *c, void *producer) {
+    if (!c) return tg_detail::fail(TG_ERR_INVALID, "null communicator");
+    HIP_TRYC(hipSetDevice(c->device));
+    HIP_TRYC(hipEventRecord(c->handoff, (hipStream_t)producer));
+    HIP_TRYC(hipStreamWaitEvent(c->stream, c->handoff, 0));
+    return TG_SUCCESS;
+}
+
+int tg_comm_all_gather_after(tg_comm *c, void *producer, const void *send_dev, void *recv_dev, uint64_t bytes_per_rank) {
+    const int rc = tg_comm_wait_stream(c, producer);
+    return rc != TG_SUCCESS ? rc : tg_comm_all_gather(c, send_dev, recv_dev, bytes_per_rank);
+}
+
+int tg_comm_stream_wait_comm(tg_comm *c, void *consumer) {
+    if (!c) return tg_detail::fail(TG_ERR_INVALID, "null communicator");
+    HIP_TRYC(hipSetDevice(c->device));
+    HIP_TRYC(hipEventRecord(c->done, c->stream));
+    HIP_TRYC(hipStreamWaitEvent((hipStream_t)consumer, c->done, 0));
     return TG_SUCCESS;
 }
 

@@ -5,7 +5,8 @@
 // every use pays a v_readlane plus the address arithmetic around it.  Here the same source (mvi_core.hpp) is
 // instantiated on `SpecProg` (generated header, -DTG_SPEC_HEADER=...): integers are immediates (LDS offsets fold into
 // the ds_* offset fields, loop bounds are known), tables are constant arrays in the code object.  Nothing about the
-// arithmetic changes -- it is the same template -- so results are bit-identical to the generic kernel.
+// arithmetic changes -- it is the same template -- so results equal the generic kernel's up to the compiler's FMA
+// contraction choices (<= 1e-12 relative, identical Newton iteration counts; tests/test_gpu_parity.py).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -42,8 +43,9 @@ int launch_mode(const tg::RunArgs *A, tg::RunArgs *slot, int grid, size_t lds, h
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spec<MODE, PIVOT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
 #if defined(SPEC_ARGS_IN_MEMORY)
-    // `slot` is the batch's own device-side argument block: copy and kernel are ordered on the batch's stream, so the block is
-    // never rewritten before the previous launch that reads it has finished (the host copy is staged before the call returns)
+    // `slot` is one of the batch's device-side argument blocks and `A` lives in the batch's pinned host ring (trepamd.hip,
+    // launch()): an asynchronous copy ordered before the kernel on the batch's stream; the caller reuses a (slot, ring entry)
+    // pair only after the event recorded behind this launch has completed
     if (!slot) return 3;
     if (hipMemcpyAsync(slot, A, sizeof(tg::RunArgs), hipMemcpyHostToDevice, stream) != hipSuccess) return 1;
     hipLaunchKernelGGL((k_spec<MODE, PIVOT>), dim3(grid), dim3(64), lds, stream, (const tg::RunArgs *)slot);
@@ -59,6 +61,14 @@ const int *tg_spec_sizes(void) {
     static const int s[8] = {(int)sizeof(tg::DevProg), (int)sizeof(tg::RunArgs), SpecProg::nq, SpecProg::nd, SpecProg::nc, SpecProg::n_items,
                              SpecProg::n_pairs, SpecProg::lds_per_team};
     return s;
+}
+// hash of the generated header this library was compiled against (tg_system_spec_key; trep_amd/specialize.py passes it)
+unsigned long long tg_spec_key(void) {
+#if defined(TG_SPEC_KEY)
+    return TG_SPEC_KEY;
+#else
+    return 0ull;
+#endif
 }
 // bit m set: kernel mode m (tg::MODE_*) has a specialised instantiation in this library
 int tg_spec_modes(void) {

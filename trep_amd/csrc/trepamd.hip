@@ -61,8 +61,18 @@ struct tg_batch {
     // optional system-specialised rollout kernel (tg_batch_load_specialized): launcher exported by a generated library
     void *spec_lib = nullptr;
     int (*spec_launch)(int, const tg::RunArgs *, tg::RunArgs *, int, size_t, void *) = nullptr;
-    tg::RunArgs *d_args = nullptr;   // device-side argument block of the specialised kernels (rewritten per launch, stream ordered)
+    // argument blocks of the specialised kernels: ARG_SLOTS device-side blocks fed from a pinned host ring (a truly asynchronous
+    // hipMemcpyAsync; a slot is reused only after the launch that read it has finished: arg_done[i])
+    static constexpr int ARG_SLOTS = 4;
+    tg::RunArgs *d_args = nullptr;   // [ARG_SLOTS] device
+    tg::RunArgs *h_args = nullptr;   // [ARG_SLOTS] pinned host
+    hipEvent_t arg_done[ARG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    bool arg_used[ARG_SLOTS] = {false, false, false, false};
+    int arg_next = 0;
     int spec_modes = 0;
+    unsigned int spec_launched_modes = 0, generic_launched_modes = 0;   // bit m: a kernel of mode m went through that path (tg_batch_info)
+    long long spec_launches = 0, generic_launches = 0;
+    std::string spec_path;
     int *d_ints = nullptr;
     double *d_dbls = nullptr;
     double *q1 = nullptr, *q2 = nullptr, *p1 = nullptr, *p2 = nullptr, *lam = nullptr, *u1 = nullptr;
@@ -212,10 +222,22 @@ int launch(tg_batch *b, tg::RunArgs &A) {
     }
     int rc;
     if (b->spec_launch && ((b->spec_modes >> A.mode) & 1)) {
-        rc = b->spec_launch(A.mode, &A, b->d_args, grid, lds, (void *)b->stream) == 0 ? TG_SUCCESS : fail(TG_ERR_HIP, "specialised kernel launch failed");
-    } else
+        const int i = b->arg_next;
+        b->arg_next = (i + 1) % tg_batch::ARG_SLOTS;
+        rc = TG_SUCCESS;
+        if (b->arg_used[i] && hipEventSynchronize(b->arg_done[i]) != hipSuccess) rc = fail(TG_ERR_HIP, "hipEventSynchronize failed");
+        if (rc == TG_SUCCESS) {
+            b->h_args[i] = A;
+            rc = b->spec_launch(A.mode, &b->h_args[i], b->d_args + i, grid, lds, (void *)b->stream) == 0 ? TG_SUCCESS : fail(TG_ERR_HIP, "specialised kernel launch failed");
+            b->arg_used[i] = hipEventRecord(b->arg_done[i], b->stream) == hipSuccess;
+            if (!b->arg_used[i]) hipStreamSynchronize(b->stream);
+            b->spec_launched_modes |= 1u << A.mode; b->spec_launches++;
+        }
+    } else {
+    b->generic_launched_modes |= 1u << A.mode; b->generic_launches++;
     rc = team == 64 ? launch_team<64>(b, A, grid, lds) : (team == 16 ? launch_team<16>(b, A, grid, lds)
              : (team == 4 ? launch_team<4>(b, A, grid, lds) : launch_team<1>(b, A, grid, lds)));
+    }
     if (rc == TG_SUCCESS && hipGetLastError() != hipSuccess) rc = fail(TG_ERR_HIP, "kernel launch failed");
     if (b->timing) {
         if (rc != TG_SUCCESS || hipEventRecord(e1, b->stream) != hipSuccess) {
@@ -425,6 +447,8 @@ void tg_batch_destroy(tg_batch *b) {
                     b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev, b->zl_dev, b->dyn, b->dyn_ints, b->dyn_d1, b->energy, b->lag,
                     b->d1[0], b->d1[1], b->d1[2], b->d1[3], b->d1[4], b->d1[5], b->d1[6], b->d1[7], b->d1[8], b->d1[9], b->d1[10], b->d1[11]};
     for (void *p : ptrs) if (p) hipFree(p);
+    if (b->h_args) hipHostFree(b->h_args);
+    for (auto &e : b->arg_done) if (e) hipEventDestroy(e);
     if (b->stream && b->own_stream) hipStreamDestroy(b->stream);
     if (b->spec_lib) dlclose(b->spec_lib);
     delete b;
@@ -954,21 +978,43 @@ int tg_batch_set_pivot_rule(tg_batch *b, int32_t exact) {
     return TG_SUCCESS;
 }
 
-/* Text of the specialisation header of a system (spec_emit.inc); returns the length needed (incl. the terminator). */
-int64_t tg_system_spec_header(const tg_system *sys, char *buf, uint64_t capacity) {
-    if (!sys) { fail(TG_ERR_INVALID, "null system"); return -1; }
+}  // extern "C"
+namespace {
+std::string spec_header_text(const tg_system *sys) {
     std::string out;
     char line[160];
     std::snprintf(line, sizeof(line), "#define SPEC_TEAM %d\n#define SPEC_SPRINGS %s\n", sys->team,
                   (sys->H.p.has_cs || sys->H.p.n_springs || sys->H.p.has_plane || sys->H.p.n_wrenches) ? "true" : "false");
     out += line;
     emit_spec_header(sys->H, out);
+    return out;
+}
+uint64_t fnv1a64(const std::string &t) {
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char c : t) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+}  // namespace
+extern "C" {
+
+/* Text of the specialisation header of a system (spec_emit.inc); returns the length needed (incl. the terminator). */
+int64_t tg_system_spec_header(const tg_system *sys, char *buf, uint64_t capacity) {
+    if (!sys) { fail(TG_ERR_INVALID, "null system"); return -1; }
+    const std::string out = spec_header_text(sys);
     if (buf && capacity) {
         const size_t n = std::min((size_t)capacity - 1, out.size());
         std::memcpy(buf, out.data(), n);
         buf[n] = 0;
     }
     return (int64_t)out.size() + 1;
+}
+
+/* FNV-1a (64 bit) of that text: what a specialised library carries as tg_spec_key() (-DTG_SPEC_KEY=...) and what
+ * tg_batch_load_specialized compares, so a library built for another system -- or another parameter set of the same
+ * topology -- is refused even when every size agrees. */
+uint64_t tg_system_spec_key(const tg_system *sys) {
+    if (!sys) { fail(TG_ERR_INVALID, "null system"); return 0; }
+    return fnv1a64(spec_header_text(sys));
 }
 
 /* Rollouts of this batch use the kernel of a library built by trep_amd/specialize.py for exactly this system. */
@@ -979,19 +1025,39 @@ int tg_batch_load_specialized(tg_batch *b, const char *library_path) {
     auto launch_fn = reinterpret_cast<int (*)(int, const tg::RunArgs *, tg::RunArgs *, int, size_t, void *)>(dlsym(h, "tg_spec_launch"));
     auto sizes_fn = reinterpret_cast<const int *(*)(void)>(dlsym(h, "tg_spec_sizes"));
     auto modes_fn = reinterpret_cast<int (*)(void)>(dlsym(h, "tg_spec_modes"));
-    if (!launch_fn || !sizes_fn || !modes_fn) { dlclose(h); return fail(TG_ERR_INVALID, "not a specialised trep_amd kernel library"); }
+    auto key_fn = reinterpret_cast<uint64_t (*)(void)>(dlsym(h, "tg_spec_key"));
+    if (!launch_fn || !sizes_fn || !modes_fn || !key_fn) { dlclose(h); return fail(TG_ERR_INVALID, "not a specialised trep_amd kernel library"); }
     const tg::DevProg &P = b->P;
     const int want[8] = {(int)sizeof(tg::DevProg), (int)sizeof(tg::RunArgs), P.nq, P.nd, P.nc, P.n_items, P.n_pairs, P.lds_per_team};
     const int *got = sizes_fn();
     for (int i = 0; i < 8; i++) if (got[i] != want[i]) { dlclose(h); return fail(TG_ERR_INVALID, "specialised kernel was built for a different system or library version"); }
+    if (key_fn() != tg_system_spec_key(b->sys)) { dlclose(h); return fail(TG_ERR_INVALID, "specialised kernel was built from a different schedule (header hash mismatch)"); }
+    HIP_TRY(hipSetDevice(b->device));
     if (!b->d_args) {
-        HIP_TRY(hipSetDevice(b->device));
-        if (hipMalloc(&b->d_args, sizeof(tg::RunArgs)) != hipSuccess) { dlclose(h); return fail(TG_ERR_HIP, "device allocation failed"); }
+        bool ok = hipMalloc(&b->d_args, sizeof(tg::RunArgs) * tg_batch::ARG_SLOTS) == hipSuccess &&
+                  hipHostMalloc(&b->h_args, sizeof(tg::RunArgs) * tg_batch::ARG_SLOTS, hipHostMallocDefault) == hipSuccess;
+        for (int i = 0; i < tg_batch::ARG_SLOTS && ok; i++) ok = hipEventCreateWithFlags(&b->arg_done[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { dlclose(h); return fail(TG_ERR_HIP, "allocation of the argument blocks failed"); }
     }
-    if (b->spec_lib) dlclose(b->spec_lib);
-    b->spec_lib = h; b->spec_launch = launch_fn; b->spec_modes = modes_fn();
+    if (b->spec_lib) { hipStreamSynchronize(b->stream); dlclose(b->spec_lib); }
+    b->spec_lib = h; b->spec_launch = launch_fn; b->spec_modes = modes_fn(); b->spec_path = library_path;
     return TG_SUCCESS;
 }
+
+/* Which kernels this batch runs: out[0] bit m = mode m (tg::MODE_*) has a specialised kernel loaded; out[1] / out[2] bit m = a
+ * mode-m launch has gone through a specialised / a generic kernel since the batch was created; out[3] / out[4] the number of
+ * such launches; out[5] pivot rule; out[6] team size; out[7] 0. */
+int tg_batch_info(const tg_batch *b, int32_t out[8]) {
+    if (!b || !out) return fail(TG_ERR_INVALID, "null argument");
+    out[0] = b->spec_launch ? b->spec_modes : 0;
+    out[1] = (int32_t)b->spec_launched_modes; out[2] = (int32_t)b->generic_launched_modes;
+    out[3] = (int32_t)std::min<long long>(b->spec_launches, 0x7fffffff); out[4] = (int32_t)std::min<long long>(b->generic_launches, 0x7fffffff);
+    out[5] = b->exact_pivot; out[6] = b->sys->team; out[7] = 0;
+    return TG_SUCCESS;
+}
+
+/* The HIP stream the batch launches on (hipStream_t as void *): for ordering foreign work after it (tg_comm_wait_stream). */
+void *tg_batch_stream(tg_batch *b) { return b ? (void *)b->stream : nullptr; }
 
 int tg_batch_timing(tg_batch *b, int32_t reset, int32_t *n_launches, double *total_ms) {
     if (!b) return fail(TG_ERR_INVALID, "null batch");

@@ -369,8 +369,8 @@ class DSystem(_Packing):
 class BatchDSystem(_Packing):
     """B independent copies of the discrete system on one GPU."""
 
-    def __init__(self, system, t, batch, device=0, tolerance=1e-10):
-        self.varint = BatchMidpointVI(system, batch, tolerance=tolerance, device=device)
+    def __init__(self, system, t, batch, device=0, tolerance=1e-10, specialize="auto"):
+        self.varint = BatchMidpointVI(system, batch, tolerance=tolerance, device=device, specialize=specialize)
         self._setup_packing(system, t)
         self._k = None
 

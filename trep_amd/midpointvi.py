@@ -175,6 +175,25 @@ class BatchMidpointVI(object):
         keys = ["team", "lds_bytes_per_trajectory", "joints", "levels", "bodies", "items", "pairs", "dh_items"]
         return dict(zip(keys, (int(v) for v in out)))
 
+    MODES = {"rollout": 0, "calc_p2": 1, "calc_f": 2, "deriv1": 3, "deriv2z": 4}
+
+    def kernel_info(self):
+        """Which kernels this batch has launched (tg_batch_info): `spec_modes` = set of mode names with a specialised kernel
+        loaded, `spec_launched` / `generic_launched` = mode names that have actually gone through a specialised / generic
+        kernel, and the launch counts; `spec_library` the loaded file."""
+        out = np.zeros(8, dtype=np.int32)
+        _lib.check(self._L.tg_batch_info(self._h, out.ctypes.data_as(_lib._c_ip)))
+        names = lambda bits: sorted(n for n, m in self.MODES.items() if (int(bits) >> m) & 1)
+        return {"spec_modes": names(out[0]), "spec_launched": names(out[1]), "generic_launched": names(out[2]),
+                "spec_launch_mask": int(out[1]), "generic_launch_mask": int(out[2]),
+                "spec_launches": int(out[3]), "generic_launches": int(out[4]), "exact_pivot": bool(out[5]), "team": int(out[6]),
+                "spec_library": self._specialized}
+
+    @property
+    def stream(self):
+        """The batch's HIP stream (hipStream_t as an integer), e.g. for ``Communicator.wait_stream``."""
+        return self._L.tg_batch_stream(self._h)
+
     # -- state ---------------------------------------------------------------------------
     @property
     def tolerance(self):
@@ -488,12 +507,13 @@ class BatchMidpointVI(object):
 class MidpointVI(object):
     """Drop-in for ``trep.MidpointVI`` (one trajectory) on top of a batch of one."""
 
-    def __init__(self, system, tolerance=1e-10, num_threads=None, device=0):
+    def __init__(self, system, tolerance=1e-10, num_threads=None, device=0, specialize="auto"):
         # num_threads: accepted and ignored (the reference's pthread pool, midpointvi.c:9-293,
-        # is replaced by GPU parallelism).
+        # is replaced by GPU parallelism).  specialize: as in BatchMidpointVI (not a reference argument).
         self._system = system
         self._device = device
         self._tolerance = tolerance
+        self._specialize = specialize
         self._b = None
         self._cache = 0
         self._rebuild()
@@ -505,7 +525,7 @@ class MidpointVI(object):
     def _rebuild(self):
         if self._b is not None:
             self._b.close()
-        self._b = BatchMidpointVI(self._system, 1, self._tolerance, self._device)
+        self._b = BatchMidpointVI(self._system, 1, self._tolerance, self._device, specialize=self._specialize)
         self._stale = False
 
     def _batch(self):

@@ -120,6 +120,17 @@ class Communicator(object):
                 pass
         return comm
 
+    def info(self):
+        """(ranks, rank, device) as RCCL itself reports them (ncclCommCount / ncclCommUserRank)."""
+        out = np.zeros(3, dtype=np.int32)
+        _lib.check(self.L.tg_comm_info(self._h, out.ctypes.data_as(_lib._c_ip)))
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def wait_stream(self, hip_stream=None):
+        """Order the communicator's stream after everything enqueued so far on `hip_stream` (None: the NULL stream; a
+        batch's stream: ``mvi.stream``) -- an event, no host synchronisation."""
+        _lib.check(self.L.tg_comm_wait_stream(self._h, hip_stream))
+
     def close(self):
         if self._h:
             for p in self._bufs.values():
@@ -156,8 +167,12 @@ class Communicator(object):
             self._bufs[name] = cur
         return cur[0]
 
-    def all_gather_device(self, send_ptr, recv_ptr, bytes_per_rank, synchronize=True):
-        """recv [world][bytes_per_rank] <- send [bytes_per_rank] of every rank (device pointers)."""
+    def all_gather_device(self, send_ptr, recv_ptr, bytes_per_rank, synchronize=True, after=False):
+        """recv [world][bytes_per_rank] <- send [bytes_per_rank] of every rank (device pointers).  `after`: the HIP stream
+        that produces `send` (a batch's ``stream``; None for the NULL stream) -- the collective is ordered after it by an
+        event; False: the caller has ordered it already (tg_comm_wait_stream) or synchronised."""
+        if after is not False:
+            self.wait_stream(after)
         _lib.check(self.L.tg_comm_all_gather(self._h, send_ptr, recv_ptr, bytes_per_rank))
         if synchronize:
             _lib.check(self.L.tg_comm_synchronize(self._h))

@@ -8,7 +8,10 @@ asks the library for the specialisation header of the system (``tg_system_spec_h
 ``static constexpr``, every table a constant array), compiles ``csrc/spec_kernel.hip`` -- the SAME template source as
 the generic kernel, instantiated on that header -- with hipcc for gfx950, and caches the result under
 ``trep_amd/_spec/`` keyed by the hash of header and sources.  ``BatchMidpointVI.specialize()`` then makes the batch's
-rollouts use it.  Results are bit-identical to the generic kernel (same arithmetic, same order).
+rollouts use it.  Same arithmetic as the generic kernel: identical Newton iteration counts, states equal up to the
+compiler's FMA-contraction choices (<= 1e-12 relative; the specialised build also uses its own scheduler flags).  The
+library carries the FNV-1a hash of the header it was compiled against (``tg_spec_key``); ``tg_batch_load_specialized``
+compares it with the batch's own system, also for a ``TREPAMD_SPEC_OVERRIDE`` library.
 
 hipcc runs as a child process and needs no GPU, so specialisations can be built ahead of time (``__graft_entry__.build``
 builds the BASELINE systems') and travel with the package; building on first use works too, as long as hipcc is there.
@@ -29,8 +32,8 @@ _SOURCES = ["spec_kernel.hip", "mvi_core.hpp", "program.hpp"]
 DEFAULT_FLAGS = "-DSPEC_ARGS_IN_MEMORY -DSPEC_DERIVATIVES -DTG_GJ_INLINE -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp"
 
 
-def header(system):
-    """The generated C++ header for `system` (host-only: no GPU is touched)."""
+def header(system, with_key=False):
+    """The generated C++ header for `system` (host-only: no GPU is touched); with_key: also its 64-bit hash."""
     L = _lib.lib()
     desc = flatten(system)
     h = L.tg_system_create(desc.byref())
@@ -42,7 +45,8 @@ def header(system):
             raise _lib.LibraryError(L.tg_last_error().decode())
         buf = ctypes.create_string_buffer(int(n))
         L.tg_system_spec_header(h, buf, n)
-        return buf.value.decode()
+        text = buf.value.decode()
+        return (text, int(L.tg_system_spec_key(h))) if with_key else text
     finally:
         L.tg_system_destroy(h)
 
@@ -61,28 +65,38 @@ def _key(text):
     return m.hexdigest()[:16]
 
 
-def library_path(system):
-    text = header(system)
-    return os.path.join(CACHE, "libtrepamd_spec_%s.so" % _key(text)), text
+def library_path(system, with_key=False):
+    text, key = header(system, with_key=True)
+    path = os.path.join(CACHE, "libtrepamd_spec_%s.so" % _key(text))
+    return (path, text, key) if with_key else (path, text)
 
 
 def build(system, force=False, verbose=False):
-    """Path of the specialised kernel library of `system`, compiling it if it is not cached."""
-    path, text = library_path(system)
+    """Path of the specialised kernel library of `system`, compiling it if it is not cached.  Safe to call from several
+    processes at once (every rank of a multi-GPU launch does): each compiles against its own copy of the header and
+    publishes header and library by atomic rename."""
+    path, text, key = library_path(system, with_key=True)
     if os.path.exists(path) and not force:
         return path
     os.makedirs(CACHE, exist_ok=True)
     hdr = path[:-3] + ".hpp"
-    with open(hdr, "w") as fh:
+    mine = ".tmp%d" % os.getpid()
+    with open(hdr + mine, "w") as fh:
         fh.write(text)
-    tmp = path + ".tmp%d" % os.getpid()
+    tmp = path + mine
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-I", _CSRC, '-DTG_SPEC_HEADER="%s"' % hdr] + _flags() + ["-o", tmp, os.path.join(_CSRC, "spec_kernel.hip")]
+           "-I", _CSRC, '-DTG_SPEC_HEADER="%s"' % (hdr + mine), "-DTG_SPEC_KEY=0x%016xull" % key] + _flags() + \
+          ["-o", tmp, os.path.join(_CSRC, "spec_kernel.hip")]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
     if r.returncode != 0:
+        try:
+            os.remove(hdr + mine)
+        except OSError:
+            pass
         raise _lib.LibraryError("specialisation failed:\n" + r.stderr[-4000:])
+    os.replace(hdr + mine, hdr)      # kept next to the library for inspection
     os.replace(tmp, path)
     return path
 
