@@ -424,7 +424,7 @@ def test_dsystem_second_order_matches_reference(name, spec):
             assert relerr(one.fdxdx(Z[zi]), g["ds_%d_fdxdx_%d" % (k, zi)]) < 1e-8, (name, k)
             assert relerr(one.fdxdu(Z[zi]), g["ds_%d_fdxdu_%d" % (k, zi)]) < 1e-8, (name, k)
             assert relerr(one.fdudu(Z[zi]), g["ds_%d_fdudu_%d" % (k, zi)]) < 1e-8, (name, k)
-    _assert_kernels(one.varint._batch().kernel_info(), spec, ["rollout", "deriv1", "deriv2z"])
+    _assert_kernels(one.varint._batch().kernel_info(), spec, ["rollout", "deriv2z"])
     k = int(g["ds_k"][1])
     bd = discopt.BatchDSystem(system, t, 3, specialize=spec)
     bd.set(np.tile(X[k], (3, 1)), np.tile(U[k], (3, 1)), k, Xk_hint=np.tile(X[k + 1], (3, 1)))
@@ -460,7 +460,7 @@ def test_full_second_derivative_tensors_match_reference(name, spec):
         checked += 1
         n_lambda += nm.startswith("lambda1")
     assert checked >= 4 and (n_lambda > 0 or system.nc == 0)
-    _assert_kernels(mvi._batch().kernel_info(), spec, ["rollout", "deriv1", "deriv2z"])
+    _assert_kernels(mvi._batch().kernel_info(), spec, ["rollout", "deriv2z"])
 
 
 def test_second_derivatives_undefined_with_linear_springs():

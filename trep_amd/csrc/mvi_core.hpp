@@ -1596,6 +1596,143 @@ struct Core {
         __syncthreads();
         return ok;
     }
+
+    // ---- the full-wave solver (TEAM == 64, 16 < n < 32): panels of four columns + trailing update on the matrix cores ---------
+    //      gj_rows keeps one matrix row per lane (28 of 64 lanes busy) and pays two v_readlane per FMA for the pivot-row
+    //      broadcast: ~68 VALU instructions per pivot step, and the solver is bound by exactly that instruction stream.  Here the
+    //      [A | b] matrix (b = column n) stays in LDS in its [n][ld] layout AND lives in the accumulator layout of
+    //      v_mfma_f64_16x16x4_f64 on all 64 lanes: lane (g = lane >> 4, c = lane & 15), register v of tile (TR, TC) holds entry
+    //      [16 TR + 4 v + g][16 TC + c] -- 16 doubles per lane instead of 29.  Per panel of four columns:
+    //        1. lane i < n reads the four panel entries of row i from LDS (one row per lane);
+    //        2. the four columns are eliminated exactly like gj_rows does it (scaled partial pivoting, rows never move, same
+    //           single-precision ranking) -- but the broadcasts only cover the other panel columns and the columns of Z: 3 per step;
+    //        3. Z [32][4] accumulates what the four elementary row operations do to any OTHER column: after the panel,
+    //           A' = A + Z A[R, :] with R the four pivot rows as they were at the panel's start (block Gauss-Jordan; Z[:, t] is
+    //           column r_t of the accumulated row-operation matrix minus the identity: z_t <- l at step t, z_s += l z_s[r_t] for s < t);
+    //        4. Z goes through 1 KB of LDS into A-operand form, lane group t reads pivot row r_t straight from the LDS image as
+    //           its B operand, the rank-4 update of the four (later two) 16 x 16 tiles is one v_mfma_f64_16x16x4_f64 each, and the
+    //           live tiles are written back to the LDS image.
+    //      No branch, no run-time register index.  Same pivot rule as gj_rows (the default rule); the trailing columns see the block
+    //      update instead of four rank-1 updates, so results differ from gj_rows' by rounding only.  `scratch`: 128 doubles of LDS
+    //      outside [A | b].
+    template <int N, bool TRACE = false>
+    static __device__ TG_GJ_ATTR bool gj_panel(bool on, double *A_generic, int n, int ld, int lane, double *scratch_generic, int *trace = nullptr) {
+        static_assert(N % 4 == 0 && N > 16 && N <= 32, "gj_panel: 16 < N <= 32");
+        typedef __attribute__((address_space(3))) double lds_double;
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        lds_double *A = (lds_double *)A_generic, *WL = (lds_double *)scratch_generic;
+        const int g = (lane >> 4) & 3, c = lane & 15;
+        auto lds_fence = [] {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        };
+        // rows 16 TR + 4 v + g of a register exist for every lane group / for none / for some (only when n is not a multiple of 4)
+        auto rows_all = [&](int TR, int v) { return 16 * TR + 4 * v + 3 < n; };
+        auto rows_none = [&](int TR, int v) { return 16 * TR + 4 * v >= n; };
+        const bool in1 = 16 + c <= n;             // this lane's column of tile column 1 exists (b is column n)
+        const int c1 = in1 ? 16 + c : 0;
+        // ---- the matrix into the accumulator layout, the rows' scale factors one row per lane
+        v4d T[2][2];
+#pragma unroll
+        for (int TR = 0; TR < 2; TR++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int row = 16 * TR + 4 * v + g;
+                if (rows_none(TR, v)) { T[TR][0][v] = 0.0; T[TR][1][v] = 0.0; continue; }
+                const bool rin = rows_all(TR, v) || row < n;
+                const int ro = rin ? row * ld : 0;
+                const double a0 = A[ro + c], a1 = A[ro + c1];
+                T[TR][0][v] = rin ? a0 : 0.0;
+                T[TR][1][v] = (rin && in1) ? a1 : 0.0;
+            }
+        const bool mine = lane < n;
+        const int myrow = (mine ? lane : 0) * ld;     // lanes without a row mirror row 0: finite values that end up nowhere
+        double scale = 0.0;
+        {
+            double s = -1.0;
+#pragma unroll
+            for (int j = 0; j < N; j++) if (j < n) { const double a = fabs(A[myrow + j]); s = a > s ? a : s; }
+            scale = 1.0 / s;
+        }
+        bool ok = true, avail = mine;
+        double rdiag = 0.0;
+        int mycol = -1, prow = 0;
+#pragma unroll
+        for (int p = 0; p < N / 4; p++) {
+            // 1. the panel's entries of this lane's row
+            double cp[4], z[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < 4; t++) cp[t] = A[myrow + (4 * p + t < n ? 4 * p + t : 0)];
+            // 2. / 3. the four pivot steps
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int k = 4 * p + t;
+                if (k < n) {
+                    const double own_rp = tg_rcp(cp[t]);      // every lane inverts its own candidate while the search runs
+                    const float cand = avail ? (float)fabs(cp[t] * scale) : 0.0f;
+                    unsigned int key = (__float_as_uint(cand) & ~0x3Fu) | (unsigned int)(63 - (lane & 63));
+                    key = tg_max_u32_lanes32(key);
+                    const float best = __uint_as_float(key & ~0x3Fu);
+                    if (!(best > 1.0e-20f)) ok = false;
+                    const int src = __builtin_amdgcn_readfirstlane(63 - (int)(key & 0x3Fu));
+                    auto bcast = [&](double v) -> double {
+                        const long long b = __double_as_longlong(v);
+                        const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFLL), src);
+                        const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+                        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+                    };
+                    const bool is_piv = lane == src;
+                    if (TRACE && on && ok && is_piv) trace[k] = lane;
+                    if (g == t) prow = src * ld;              // lane group t fetches pivot row r_t as its B operand
+                    const double rp = bcast(own_rp);
+                    const double l = is_piv ? 0.0 : cp[t] * -rp;
+#pragma unroll
+                    for (int t2 = t + 1; t2 < 4; t2++) cp[t2] = fma(l, bcast(cp[t2]), cp[t2]);
+#pragma unroll
+                    for (int s = 0; s < t; s++) z[s] = fma(l, bcast(z[s]), z[s]);
+                    z[t] = l;
+                    if (is_piv) { mycol = k; rdiag = rp; avail = false; }
+                }
+            }
+            // 4. Z -> A-operand form; pivot rows from the LDS image (as of the panel's start); trailing update; write back
+            //    (tile column 0 is dead once the panel has passed column 11)
+            if (lane < 32) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) WL[lane * 4 + t] = z[t];
+            }
+            lds_fence();
+            const double a0 = WL[c * 4 + g], a1 = WL[(16 + c) * 4 + g];
+            const double b1r = A[prow + c1];
+            const double b1 = in1 ? b1r : 0.0;
+            const bool live0 = 4 * p + 4 < 16;
+            if (live0) {
+                const double b0 = A[prow + c];
+                T[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, T[0][0], 0, 0, 0);
+                T[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, T[1][0], 0, 0, 0);
+            }
+            T[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, T[0][1], 0, 0, 0);
+            T[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, T[1][1], 0, 0, 0);
+            lds_fence();      // every lane has its operands before the image changes
+#pragma unroll
+            for (int TR = 0; TR < 2; TR++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    if (rows_none(TR, v)) continue;
+                    const int row = 16 * TR + 4 * v + g;
+                    if (rows_all(TR, v) || row < n) {
+                        if (live0) A[row * ld + c] = T[TR][0][v];
+                        if (in1) A[row * ld + 16 + c] = T[TR][1][v];
+                    }
+                }
+            lds_fence();
+        }
+        // x = b / pivot, row by row: the right-hand side is column n of the image
+        const double xr = A[myrow + n] * rdiag;
+        lds_fence();
+        if (on && mine && ok && mycol >= 0) A[mycol * ld + n] = xr;
+        __syncthreads();
+        return ok;
+    }
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
