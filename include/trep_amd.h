@@ -261,8 +261,11 @@ int tg_batch_set_step_sizes(tg_batch *b, int32_t count, const double *dt_host, i
  *   exact = 1: the reference's rule bit for bit -- fp64 comparison, ties to the first row of its (swapped) row order,
  *       exact singular test -- i.e. the same pivot ROW for every column, also where candidates differ by one ulp
  *       (every row's largest entry scales to 1 +- 1 ulp, so that happens in most puppet solves).  About 9 % slower.
- * tg_debug_solve (test hook) solves [A | b] (row-major [n][n+1], n <= 32) with either rule and reports which original row
- * served as pivot of each column; status TG_OK or TG_SINGULAR. */
+ * Full-wave teams with 17..31 unknowns (the puppet: 28) run the default rule as gj_panel -- panels of four columns eliminated one
+ * row per lane, the trailing matrix kept in the accumulator layout of v_mfma_f64_16x16x4_f64 and updated on the matrix cores --
+ * which ranks the candidates exactly as above and differs in rounding only (block update instead of four rank-1 updates).
+ * tg_debug_solve (test hook) solves [A | b] (row-major [n][n+1], n <= 32) with either rule (exact = 0 / 1; exact = 2: the default
+ * rule through gj_panel, 16 < n < 32) and reports which original row served as pivot of each column; status TG_OK or TG_SINGULAR. */
 int tg_batch_set_pivot_rule(tg_batch *b, int32_t exact);
 int tg_debug_solve(int32_t device, int32_t n, int32_t exact, const double *A_aug_host, double *x_host, int32_t *pivot_rows_host, int32_t *status_host);
 

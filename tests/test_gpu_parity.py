@@ -686,7 +686,7 @@ def _device_solve(A, b, exact):
     n = len(b)
     aug = np.ascontiguousarray(np.hstack([A, b[:, None]]), dtype=float)
     x = np.zeros(n); piv = np.zeros(n, dtype=np.int32); st = np.zeros(1, dtype=np.int32)
-    _lib.check(L.tg_debug_solve(0, n, 1 if exact else 0, aug.ctypes.data, x.ctypes.data, piv.ctypes.data, st.ctypes.data))
+    _lib.check(L.tg_debug_solve(0, n, int(exact) if exact in (0, 1, 2) else (1 if exact else 0), aug.ctypes.data, x.ctypes.data, piv.ctypes.data, st.ctypes.data))
     return int(st[0]), x, piv
 
 
@@ -770,6 +770,57 @@ def test_newton_solver_default_pivot_rule():
     for eps, singular in ((1e-21, True), (1e-19, False)):
         A = np.eye(5); A[4, 4] = eps; A[4, 0] = 1.0
         st, xd, piv = _device_solve(A, np.ones(5), exact=False)
+        assert (st == 2) == singular
+
+
+def test_newton_solver_panel_variant_follows_the_default_rule():
+    """gj_panel (full-wave teams, 17..31 unknowns: panels of four columns, trailing update on the matrix cores) is the default rule
+    in another arithmetic order: on every test matrix -- sizes that are and are not multiples of four, near ties, exact ties, shared
+    column maxima, KKT-shaped systems with a zero block -- each pivot is an arg-max of the scaled candidates up to the ranking
+    resolution, the solve is backward stable, the solution is the oracle's LU solution and gj_rows' to rounding, and away from
+    near-ties the pivot rows are gj_rows' rows; the singular verdict is the same."""
+    rng = np.random.default_rng(81)
+    cases = []
+    for n in (17, 18, 20, 23, 24, 26, 28, 29, 31):
+        for kind, A in _pivot_cases(rng):
+            if len(A) == 28:
+                B = A if n == 28 else rng.standard_normal((n, n)) if kind == "random" else None
+                if B is not None:
+                    cases.append((kind, B))
+        # KKT shape: [[M, -C'], [C, 0]] with sparse constraint rows, the Newton matrix of a constrained step
+        nc = 6 if n > 20 else 3
+        nd = n - nc
+        M = rng.standard_normal((nd, nd)) * 0.3 + np.diag(2.0 + rng.random(nd))
+        C = rng.standard_normal((nc, nd)) * (rng.random((nc, nd)) < 0.35)
+        C[np.arange(nc), rng.permutation(nd)[:nc]] = 1.0
+        cases.append(("kkt", np.block([[M, -C.T], [C, np.zeros((nc, nc))]])))
+    for kind, A in cases:
+        n = len(A)
+        b = rng.standard_normal(n)
+        rc, xo, idx = _oracle_lu(A, b)
+        st, xd, piv = _device_solve(A, b, exact=2)
+        st0, x0, piv0 = _device_solve(A, b, exact=0)
+        assert (st == 0) == (rc == 0) and st == st0, (kind, n, st, st0, rc)
+        if rc != 0:
+            continue
+        assert sorted(piv) == list(range(n)), (kind, n, piv)
+        M = A.copy(); scale = 1.0 / np.abs(A).max(axis=1); unused = np.ones(n, dtype=bool)
+        for k in range(n):
+            cand = np.where(unused, np.abs(M[:, k]) * scale, -1.0)
+            assert cand[piv[k]] >= cand.max() * (1.0 - 2.0 ** -16), (kind, n, k, piv[k], int(cand.argmax()))
+            r = piv[k]; unused[r] = False
+            others = np.arange(n) != r
+            M[others] -= np.outer(M[others, k] / M[r, k], M[r])
+        res = np.abs(A.dot(xd) - b).max() / (np.abs(A).sum(axis=1).max() * np.abs(xd).max() + np.abs(b).max())
+        assert res < 1e-13, (kind, n, res)
+        if kind != "near ties":
+            tol = 1e-9 * max(1.0, np.linalg.cond(A) * 1e-6)
+            assert relerr(xd, xo) < tol and relerr(xd, x0) < tol, (kind, n, relerr(xd, xo), relerr(xd, x0))
+        if kind in ("random", "kkt"):
+            assert np.array_equal(piv, piv0), (kind, n, piv, piv0)
+    for eps, singular in ((1e-21, True), (1e-19, False)):
+        A = np.eye(20); A[19, 19] = eps; A[19, 0] = 1.0
+        st, xd, piv = _device_solve(A, np.ones(20), exact=2)
         assert (st == 2) == singular
 
 

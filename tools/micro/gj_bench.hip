@@ -19,7 +19,7 @@
 #define GJ_N 28
 #endif
 
-template <int VARIANT>
+template <int VARIANT, bool TRACE>
 __global__ __launch_bounds__(64, 2) void k_solve(int n_arg, int ld_arg, int reps, const double *A_in, double *x_out, int *piv_out, long long *cycles) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #if defined(GJ_STATIC_N)     // like the system-specialised kernel: sizes are compile-time constants
@@ -40,8 +40,8 @@ __global__ __launch_bounds__(64, 2) void k_solve(int n_arg, int ld_arg, int reps
     for (int r = 0; r < reps; r++) {
         for (int e = lane; e < n * ld; e += 64) lds[e] = lds[n * ld + e];
         __syncthreads();
-        if (VARIANT == 0) ok &= tg::Core<64>::gj_rows<GJ_N, true>(true, lds, n, ld, lane, trace);
-        else ok &= tg::Core<64>::gj_panel<GJ_N, true>(true, lds, n, ld, lane, lds + 2 * n * ld + 32, trace);
+        if (VARIANT == 0) ok &= tg::Core<64>::gj_rows<GJ_N, TRACE>(true, lds, n, ld, lane, trace);
+        else ok &= tg::Core<64>::gj_panel<GJ_N, TRACE>(true, lds, n, ld, lane, lds + 2 * n * ld + 32, trace);
         __syncthreads();
     }
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
@@ -55,7 +55,9 @@ __global__ __launch_bounds__(64, 2) void k_solve(int n_arg, int ld_arg, int reps
 int main(int argc, char **argv) {
     const int n = argc > 1 ? std::atoi(argv[1]) : GJ_N, reps = argc > 2 ? std::atoi(argv[2]) : 2000;
     const int ld = (n + 1) | 1;
-    const int grid = 2048 * 2;   // two full rounds of 8 workgroups per CU
+    // workgroups resident per CU: 8 (two waves per SIMD, the rollout kernel's occupancy) or 4 (one wave per SIMD: the solver's own latency)
+    const int per_cu = argc > 3 ? std::atoi(argv[3]) : 8;
+    const int grid = 256 * per_cu * 2;   // two full rounds
     std::vector<double> A(64 * (size_t)n * (n + 1));
     srand(12345);
     auto rnd = []() { return 2.0 * rand() / RAND_MAX - 1.0; };
@@ -76,7 +78,7 @@ int main(int argc, char **argv) {
     double *dA, *dx; int *dp; long long *dc;
     hipMalloc(&dA, A.size() * 8); hipMalloc(&dx, 64 * 32 * 8 * 2); hipMalloc(&dp, 64 * 32 * 4 * 2); hipMalloc(&dc, 64 * 8 * 2);
     hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
-    const size_t lds = 19520;    // the puppet's LDS slice: 8 workgroups per CU
+    const size_t lds = per_cu >= 8 ? 19520 : 160 * 1024 / per_cu - 512;    // 19520 B = the puppet's LDS slice: 8 workgroups per CU
     if (2 * n * ld * 8 + 128 + 256 + 1024 > (int)lds) { printf("n too large for the benchmark's LDS slice\n"); return 1; }
     std::vector<double> x(2 * 64 * 32); std::vector<int> piv(2 * 64 * 32); std::vector<long long> cyc(2 * 64);
     for (int variant = 0; variant < 2; variant++) {
@@ -84,15 +86,20 @@ int main(int argc, char **argv) {
         float best = 1e30f;
         for (int it = 0; it < 3; it++) {
             hipEventRecord(e0);
-            if (variant == 0) hipLaunchKernelGGL(k_solve<0>, dim3(grid), dim3(64), lds, 0, n, ld, reps, dA, dx, dp, dc);
-            else hipLaunchKernelGGL(k_solve<1>, dim3(grid), dim3(64), lds, 0, n, ld, reps, dA, dx + 64 * 32, dp + 64 * 32, dc + 64);
+            if (lds > 64 * 1024) { hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
+            if (variant == 0) hipLaunchKernelGGL((k_solve<0, false>), dim3(grid), dim3(64), lds, 0, n, ld, reps, dA, dx, dp, dc);
+            else hipLaunchKernelGGL((k_solve<1, false>), dim3(grid), dim3(64), lds, 0, n, ld, reps, dA, dx + 64 * 32, dp + 64 * 32, dc + 64);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
         }
         if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); return 1; }
+        hipMemcpy(cyc.data(), dc, cyc.size() * 8, hipMemcpyDeviceToHost);
+        // one traced solve for the pivot rows and the solution
+        if (variant == 0) hipLaunchKernelGGL((k_solve<0, true>), dim3(64), dim3(64), 19520, 0, n, ld, 1, dA, dx, dp, dc);
+        else hipLaunchKernelGGL((k_solve<1, true>), dim3(64), dim3(64), 19520, 0, n, ld, 1, dA, dx + 64 * 32, dp + 64 * 32, dc + 64);
+        hipDeviceSynchronize();
         hipMemcpy(x.data(), dx, x.size() * 8, hipMemcpyDeviceToHost);
         hipMemcpy(piv.data(), dp, piv.size() * 4, hipMemcpyDeviceToHost);
-        hipMemcpy(cyc.data(), dc, cyc.size() * 8, hipMemcpyDeviceToHost);
         // residual of every one of the 64 systems
         double worst = 0.0; int bad = 0;
         for (int m = 0; m < 64; m++) {
@@ -108,8 +115,8 @@ int main(int argc, char **argv) {
         }
         double cavg = 0; for (int m = 0; m < 64; m++) cavg += (double)cyc[variant * 64 + m] / 64.0;
         // grid = 2 rounds of 2048 resident waves -> wall time of one solve of a resident wave = ms / (2 * reps)
-        printf("variant %d (%s): n=%d  %.3f ms  -> %.0f ns per solve per resident wave (%.0f cycles @2.4GHz); s_memtime ticks/solve %.0f; worst scaled residual %.2e; not-ok %d\n",
-               variant, variant == 0 ? "gj_rows" : "gj_panel", n, best, best * 1e6 / (2.0 * reps), best * 1e6 / (2.0 * reps) * 2.4, cavg / reps, worst, bad);
+        printf("variant %d (%s): %d waves/CU n=%d  %.3f ms  -> %.0f ns per solve per resident wave (%.0f cycles @2.4GHz); s_memtime ticks/solve %.0f; worst scaled residual %.2e; not-ok %d\n",
+               variant, variant == 0 ? "gj_rows" : "gj_panel", per_cu, n, best, best * 1e6 / (2.0 * reps), best * 1e6 / (2.0 * reps) * 2.4, cavg / reps, worst, bad);
     }
     double dmax = 0.0; int pdiff = 0;
     for (int m = 0; m < 64; m++) for (int i = 0; i < n; i++) {

@@ -1534,6 +1534,9 @@ struct Core {
             scale = 1.0 / s;
         }
         bool ok = true;
+#if defined(GJR_EXEC32)
+        if (lane < 32)
+#endif
 #pragma unroll
         for (int k = 0; k < N; k++) {
             const float cand = (mine && mycol < 0) ? (float)fabs(row[k] * scale) : 0.0f;
@@ -1614,18 +1617,21 @@ struct Core {
     //           live tiles are written back to the LDS image.
     //      No branch, no run-time register index.  Same pivot rule as gj_rows (the default rule); the trailing columns see the block
     //      update instead of four rank-1 updates, so results differ from gj_rows' by rounding only.  `scratch`: 128 doubles of LDS
-    //      outside [A | b].
+    //      outside [A | b] (the Z table).
+    //      Always an out-of-line function: inlined into the 20 k-instruction rollout kernel it shares that kernel's register
+    //      allocation and schedule (91 instead of 53 SGPR spills, every other phase ~10 % slower: 63.3 ms per benchmark launch);
+    //      as a call it keeps its own (61.7 ms; gj_rows: 65.1 ms).
     template <int N, bool TRACE = false>
-    static __device__ TG_GJ_ATTR bool gj_panel(bool on, double *A_generic, int n, int ld, int lane, double *scratch_generic, int *trace = nullptr) {
+    static __device__ __noinline__ bool gj_panel(bool on, double *A_generic, int n, int ld, int lane, double *scratch_generic, int *trace = nullptr) {
         static_assert(N % 4 == 0 && N > 16 && N <= 32, "gj_panel: 16 < N <= 32");
         typedef __attribute__((address_space(3))) double lds_double;
         typedef double v4d __attribute__((ext_vector_type(4)));
         lds_double *A = (lds_double *)A_generic, *WL = (lds_double *)scratch_generic;
         const int g = (lane >> 4) & 3, c = lane & 15;
-        auto lds_fence = [] {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-        };
+        // TEAM == 64: the workgroup is ONE wavefront, whose LDS operations execute in program order -- a read issued after a write of
+        // the same wave sees it, so no fence / s_waitcnt stands between the phases below; the compiler only has to keep may-alias
+        // LDS accesses in program order, which it does (WL and A are both plain LDS pointers)
+        auto lds_fence = [] { asm volatile("" ::: "memory"); };
         // rows 16 TR + 4 v + g of a register exist for every lane group / for none / for some (only when n is not a multiple of 4)
         auto rows_all = [&](int TR, int v) { return 16 * TR + 4 * v + 3 < n; };
         auto rows_none = [&](int TR, int v) { return 16 * TR + 4 * v >= n; };
@@ -1654,9 +1660,11 @@ struct Core {
             for (int j = 0; j < N; j++) if (j < n) { const double a = fabs(A[myrow + j]); s = a > s ? a : s; }
             scale = 1.0 / s;
         }
-        bool ok = true, avail = mine;
+        bool ok = true;
+        if (!mine) scale = 0.0;
+        const unsigned int lanetag = (unsigned int)(63 - (lane & 63));
+        int mycol = -1;
         double rdiag = 0.0;
-        int mycol = -1, prow = 0;
 #pragma unroll
         for (int p = 0; p < N / 4; p++) {
             // 1. the panel's entries of this lane's row
@@ -1664,16 +1672,20 @@ struct Core {
 #pragma unroll
             for (int t = 0; t < 4; t++) cp[t] = A[myrow + (4 * p + t < n ? 4 * p + t : 0)];
             // 2. / 3. the four pivot steps
+            int srcs[4] = {0, 0, 0, 0};
+            double b0 = 0.0, b1 = 0.0;
+            const bool live0 = 4 * p + 4 < 16;
+#if !defined(GJP_SKIP_STEPS)
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int k = 4 * p + t;
                 if (k < n) {
                     const double own_rp = tg_rcp(cp[t]);      // every lane inverts its own candidate while the search runs
-                    const float cand = avail ? (float)fabs(cp[t] * scale) : 0.0f;
-                    unsigned int key = (__float_as_uint(cand) & ~0x3Fu) | (unsigned int)(63 - (lane & 63));
+                    // rows already used as pivots (and lanes without a row) carry scale 0: their key is the bare lane tag
+                    const float cand = (float)(cp[t] * scale);
+                    unsigned int key = (__float_as_uint(cand) & 0x7FFFFFC0u) | lanetag;
                     key = tg_max_u32_lanes32(key);
-                    const float best = __uint_as_float(key & ~0x3Fu);
-                    if (!(best > 1.0e-20f)) ok = false;
+                    if (!((key & ~0x3Fu) > 0x1E3CE508u)) ok = false;     // scaled pivot <= 1e-20 (compared as bits: non-negative floats)
                     const int src = __builtin_amdgcn_readfirstlane(63 - (int)(key & 0x3Fu));
                     auto bcast = [&](double v) -> double {
                         const long long b = __double_as_longlong(v);
@@ -1683,17 +1695,29 @@ struct Core {
                     };
                     const bool is_piv = lane == src;
                     if (TRACE && on && ok && is_piv) trace[k] = lane;
-                    if (g == t) prow = src * ld;              // lane group t fetches pivot row r_t as its B operand
+                    srcs[t] = src;
+                    if (t == 3 || k == n - 1) {
+                        // lane group t fetches pivot row r_t of the image (as of the panel's start) as its B operand: requested
+                        // here, as soon as the last pivot row is known, so that the loads travel under the last elimination step
+                        const int prow = (g == 0 ? srcs[0] : (g == 1 ? srcs[1] : (g == 2 ? srcs[2] : srcs[3]))) * ld;
+                        b1 = A[prow + c1];
+                        if (live0) b0 = A[prow + c];
+                    }
                     const double rp = bcast(own_rp);
+                    // branch-free: a divergent if / else costs more (exec bookkeeping, two skipped-block branches) than three selects
                     const double l = is_piv ? 0.0 : cp[t] * -rp;
 #pragma unroll
                     for (int t2 = t + 1; t2 < 4; t2++) cp[t2] = fma(l, bcast(cp[t2]), cp[t2]);
 #pragma unroll
                     for (int s = 0; s < t; s++) z[s] = fma(l, bcast(z[s]), z[s]);
                     z[t] = l;
-                    if (is_piv) { mycol = k; rdiag = rp; avail = false; }
+                    mycol = is_piv ? k : mycol;
+                    rdiag = is_piv ? own_rp : rdiag;
+                    scale = is_piv ? 0.0 : scale;
                 }
             }
+#endif
+#if !defined(GJP_SKIP_UPDATE)
             // 4. Z -> A-operand form; pivot rows from the LDS image (as of the panel's start); trailing update; write back
             //    (tile column 0 is dead once the panel has passed column 11)
             if (lane < 32) {
@@ -1702,29 +1726,27 @@ struct Core {
             }
             lds_fence();
             const double a0 = WL[c * 4 + g], a1 = WL[(16 + c) * 4 + g];
-            const double b1r = A[prow + c1];
-            const double b1 = in1 ? b1r : 0.0;
-            const bool live0 = 4 * p + 4 < 16;
+            if (!in1) b1 = 0.0;
             if (live0) {
-                const double b0 = A[prow + c];
                 T[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, T[0][0], 0, 0, 0);
                 T[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, T[1][0], 0, 0, 0);
             }
             T[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, T[0][1], 0, 0, 0);
             T[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, T[1][1], 0, 0, 0);
             lds_fence();      // every lane has its operands before the image changes
+            auto write_back = [&](int TC) {
 #pragma unroll
-            for (int TR = 0; TR < 2; TR++)
+                for (int TR = 0; TR < 2; TR++)
 #pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    if (rows_none(TR, v)) continue;
-                    const int row = 16 * TR + 4 * v + g;
-                    if (rows_all(TR, v) || row < n) {
-                        if (live0) A[row * ld + c] = T[TR][0][v];
-                        if (in1) A[row * ld + 16 + c] = T[TR][1][v];
+                    for (int v = 0; v < 4; v++) {
+                        const int row = 16 * TR + 4 * v + g;
+                        if (!rows_none(TR, v) && (rows_all(TR, v) || row < n)) A[row * ld + 16 * TC + c] = T[TR][TC][v];
                     }
-                }
+            };
+            if (live0) write_back(0);
+            if (in1) write_back(1);
             lds_fence();
+#endif
         }
         // x = b / pivot, row by row: the right-hand side is column n of the image
         const double xr = A[myrow + n] * rdiag;
@@ -3795,6 +3817,21 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj) {
                 default: ok = Core<TEAM>::template gj_rows_exact<(TEAM >= 32 ? 32 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;
                 }
                 } else
+#if defined(TG_GJ_PANEL_DEFAULT) && !defined(TG_NO_GJ_PANEL)
+                // full-wave teams, 17..31 unknowns: panels of four columns + matrix-core trailing update (scratch: the Jacobian
+                // columns, dead between the Newton matrix's assembly and the next evaluation).  System-specialised kernels only
+                // (spec_kernel.hip defines TG_GJ_PANEL_DEFAULT): with run-time sizes the panel code carries guards and address
+                // arithmetic that make the generic rollout kernel slower (88.5 vs 85.5 ms per benchmark launch), so it keeps gj_rows
+                if (TEAM == 64 && nb4 >= 5 && P.nf <= 31 && 12 * P.n_items >= 128) {
+                    double *scr = S + P.o_J;
+                    switch (nb4) {
+                    case 5: ok = Core<64>::template gj_panel<20>(!done, Ad, P.nf, P.df_ld, lane, scr); break;
+                    case 6: ok = Core<64>::template gj_panel<24>(!done, Ad, P.nf, P.df_ld, lane, scr); break;
+                    case 7: ok = Core<64>::template gj_panel<28>(!done, Ad, P.nf, P.df_ld, lane, scr); break;
+                    default: ok = Core<64>::template gj_panel<32>(!done, Ad, P.nf, P.df_ld, lane, scr); break;
+                    }
+                } else
+#endif
                 switch (nb4) {
                 case 1: ok = Core<TEAM>::template gj_rows<4>(!done, Ad, P.nf, P.df_ld, lane); break;
                 case 2: ok = Core<TEAM>::template gj_rows<(TEAM >= 8 ? 8 : 4)>(!done, Ad, P.nf, P.df_ld, lane); break;

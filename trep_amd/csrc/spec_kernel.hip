@@ -11,6 +11,7 @@
 
 #include <type_traits>
 
+#define TG_GJ_PANEL_DEFAULT 1      // 17..31 unknowns, full-wave team: the Newton systems go through gj_panel (mvi_core.hpp)
 #include "mvi_core.hpp"
 #include TG_SPEC_HEADER
 

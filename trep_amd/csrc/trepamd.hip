@@ -322,7 +322,7 @@ __global__ void k_debug_solve(int n, int ld, int exact, const double *A_in, doub
     if (lane < 32) trace[lane] = -1;
     __syncthreads();
     bool ok = true;
-    if (exact) switch ((n + 3) >> 2) {
+    if (exact == 1) switch ((n + 3) >> 2) {
     case 1: ok = tg::Core<64>::gj_rows_exact<4, true>(true, lds, n, ld, lane, trace); break;
     case 2: ok = tg::Core<64>::gj_rows_exact<8, true>(true, lds, n, ld, lane, trace); break;
     case 3: ok = tg::Core<64>::gj_rows_exact<12, true>(true, lds, n, ld, lane, trace); break;
@@ -331,6 +331,15 @@ __global__ void k_debug_solve(int n, int ld, int exact, const double *A_in, doub
     case 6: ok = tg::Core<64>::gj_rows_exact<24, true>(true, lds, n, ld, lane, trace); break;
     case 7: ok = tg::Core<64>::gj_rows_exact<28, true>(true, lds, n, ld, lane, trace); break;
     default: ok = tg::Core<64>::gj_rows_exact<32, true>(true, lds, n, ld, lane, trace); break;
+    }
+    else if (exact == 2) {     // the full-wave panel solver (default pivot rule), 16 < n < 32; scratch behind the trace words
+        double *scr = lds + n * ld + 16;
+        switch ((n + 3) >> 2) {
+        case 5: ok = tg::Core<64>::gj_panel<20, true>(true, lds, n, ld, lane, scr, trace); break;
+        case 6: ok = tg::Core<64>::gj_panel<24, true>(true, lds, n, ld, lane, scr, trace); break;
+        case 7: ok = tg::Core<64>::gj_panel<28, true>(true, lds, n, ld, lane, scr, trace); break;
+        default: ok = tg::Core<64>::gj_panel<32, true>(true, lds, n, ld, lane, scr, trace); break;
+        }
     }
     else switch ((n + 3) >> 2) {
     case 1: ok = tg::Core<64>::gj_rows<4, true>(true, lds, n, ld, lane, trace); break;
@@ -957,13 +966,14 @@ int tg_batch_set_stream(tg_batch *b, void *hip_stream) {
  * LU_decomp (math-code.c:337-432, implicit scaling, strict `>` scan) must pick the same rows, ties included. */
 int tg_debug_solve(int32_t device, int32_t n, int32_t exact, const double *A_aug_host, double *x_host, int32_t *pivot_rows_host, int32_t *status_host) {
     if (n <= 0 || n > 32 || !A_aug_host || !x_host || !pivot_rows_host || !status_host) return fail(TG_ERR_INVALID, "bad arguments");
+    if (exact == 2 && (n <= 16 || n >= 32)) return fail(TG_ERR_INVALID, "the panel solver takes 16 < n < 32");
     HIP_TRY(hipSetDevice(device));
     double *dA = nullptr, *dx = nullptr; int *dp = nullptr, *ds = nullptr;
     const int ld = (n + 1) | 1;
     HIP_TRY(hipMalloc(&dA, sizeof(double) * n * (n + 1))); HIP_TRY(hipMalloc(&dx, sizeof(double) * n));
     HIP_TRY(hipMalloc(&dp, sizeof(int) * n)); HIP_TRY(hipMalloc(&ds, sizeof(int)));
     HIP_TRY(hipMemcpy(dA, A_aug_host, sizeof(double) * n * (n + 1), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_debug_solve, dim3(1), dim3(64), sizeof(double) * n * ld + sizeof(int) * 32, 0, n, ld, (int)exact, dA, dx, dp, ds);
+    hipLaunchKernelGGL(k_debug_solve, dim3(1), dim3(64), sizeof(double) * (n * ld + 16 + 192), 0, n, ld, (int)exact, dA, dx, dp, ds);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(x_host, dx, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(pivot_rows_host, dp, sizeof(int) * n, hipMemcpyDeviceToHost));
