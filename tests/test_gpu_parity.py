@@ -851,3 +851,35 @@ def test_exact_pivot_rollout_agrees_with_default(spec):
     assert np.array_equal(out[0][1], out[1][1])
     assert relerr(out[0][0], out[1][0]) < 1e-11
     assert relerr(out[1][0][0][:, :d.n_configs], g[prefix + "Q"][:N + 1]) < TOL
+
+
+def test_small_batch_step_mirror_is_invalidated_by_every_other_write():
+    """tg_batch_step of a small batch returns (q2, p2, lambda1, iterations, status) in one copy and later reads are answered from
+    that host mirror; anything else that changes the batch (a field write, a rollout, restore, a derivative launch) must drop it."""
+    import trep_amd
+    system, d = build("pend_on_cart")
+    q0 = np.array([[0.1, 0.5], [0.2, -0.4], [0.0, 1.0]])
+    a = trep_amd.BatchMidpointVI(system, 3)
+    b = trep_amd.BatchMidpointVI(system, 3)
+    for m in (a, b):
+        m.initialize_from_configs(0.0, q0, DT, q0)
+    U = np.array([[0.3], [-0.2], [0.0]])
+    for k in range(5):
+        ia, sa = a.step(a.times()[1] + DT, U)
+        assert (sa == 0).all()
+    Xb = b.rollout(5, DT, np.repeat(U[:, None, :], 5, axis=1), None)      # the same five steps as one device rollout
+    # (t2 + DT) - t2 is not DT to the last bit, so the two paths agree to rounding, not bit for bit
+    assert relerr(a.q2, Xb[:, 5, :2]) < 1e-12 and relerr(a.p2, b.p2) < 1e-12
+    it2, st2 = a.status()
+    assert np.array_equal(it2, ia)
+    a.snapshot()
+    q_new = a.q2 + 0.25
+    a.q2 = q_new                                   # field write: the mirror must not answer the next read
+    assert np.array_equal(a.q2, q_new)
+    a.restore()
+    assert relerr(a.q2, Xb[:, 5, :2]) < 1e-12
+    a.step(a.times()[1] + DT, U)
+    q_step = a.q2.copy()
+    a.rollout(3, DT, np.repeat(U[:, None, :], 3, axis=1), None)
+    assert not np.array_equal(a.q2, q_step)        # the rollout's state, not the mirrored step's
+    a.close(); b.close()

@@ -69,6 +69,12 @@ struct tg_batch {
     hipEvent_t arg_done[ARG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     bool arg_used[ARG_SLOTS] = {false, false, false, false};
     int arg_next = 0;
+    // small batches (the B = 1 drop-in path): tg_batch_step stages its inputs through ONE pinned block, and a pack kernel + ONE
+    // copy bring (q2, p2, lambda1, iterations, status) back into a pinned host mirror that later tg_batch_get / tg_batch_status
+    // calls answer from, until anything else touches the batch (launch(), tg_batch_set, restore ...)
+    double *io_host = nullptr, *io_dev = nullptr;
+    size_t io_in = 0, io_out = 0;      // doubles in the input / output part
+    bool mirror_valid = false;
     int spec_modes = 0;
     unsigned int spec_launched_modes = 0, generic_launched_modes = 0;   // bit m: a kernel of mode m went through that path (tg_batch_info)
     long long spec_launches = 0, generic_launches = 0;
@@ -197,6 +203,7 @@ int launch_team(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
 }
 
 int launch(tg_batch *b, tg::RunArgs &A) {
+    b->mirror_valid = false;
     const int team = b->sys->team, per_block = 64 / team;
     const int grid = (A.batch + per_block - 1) / per_block;
     const int per_team = A.mode == tg::MODE_DERIV2Z ? b->P.e_lds_per_team : (A.mode == tg::MODE_DERIV1 ? b->P.d_lds_per_team : (A.mode == tg::MODE_DYN_DERIV1 ? b->P.g_lds_per_team : b->P.lds_per_team));
@@ -310,6 +317,20 @@ __global__ void k_init_from_X(const tg::DevProg P, const double *X, size_t strid
     for (int i = threadIdx.x; i < P.nq; i += blockDim.x) { q1[t * P.nq + i] = x[i]; q2[t * P.nq + i] = x[i]; }
     for (int i = threadIdx.x; i < P.nd; i += blockDim.x) { p1[t * P.nd + i] = x[P.nq + i]; p2[t * P.nd + i] = x[P.nq + i]; }
     for (int i = threadIdx.x; i < P.nc; i += blockDim.x) lam[t * P.nc + i] = 0.0;
+}
+
+// (q2 [B][nq] | p2 [B][nd] | lambda1 [B][nc] | iterations [B] | status [B]) packed for one device-to-host copy (tg_batch_step)
+__global__ void k_pack_step(int B, int nq, int nd, int nc, const double *q2, const double *p2, const double *lam, const int *iters, const int *status, double *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n0 = B * nq, n1 = n0 + B * nd, n2 = n1 + B * nc;
+    if (i < n0) out[i] = q2[i];
+    else if (i < n1) out[i] = p2[i - n0];
+    else if (i < n2) out[i] = lam[i - n1];
+    else if (i < n2 + B) {
+        int *o = reinterpret_cast<int *>(out + n2);
+        o[i - n2] = iters[i - n2];
+        o[B + i - n2] = status[i - n2];
+    }
 }
 
 // Test hook: the Newton-system solver of the rollout kernels (gj_rows) on a caller-supplied matrix, with its pivot order.
@@ -457,6 +478,8 @@ void tg_batch_destroy(tg_batch *b) {
                     b->d1[0], b->d1[1], b->d1[2], b->d1[3], b->d1[4], b->d1[5], b->d1[6], b->d1[7], b->d1[8], b->d1[9], b->d1[10], b->d1[11]};
     for (void *p : ptrs) if (p) hipFree(p);
     if (b->h_args) hipHostFree(b->h_args);
+    if (b->io_host) hipHostFree(b->io_host);
+    if (b->io_dev) hipFree(b->io_dev);
     for (auto &e : b->arg_done) if (e) hipEventDestroy(e);
     if (b->stream && b->own_stream) hipStreamDestroy(b->stream);
     if (b->spec_lib) dlclose(b->spec_lib);
@@ -486,6 +509,7 @@ int tg_batch_set(tg_batch *b, int32_t field, const double *host) {
     double *dst = field_ptr(b, field);
     if (w < 0 || !dst) return fail(TG_ERR_INVALID, "unknown or read-only field");
     if (w == 0) return TG_SUCCESS;
+    b->mirror_valid = false;
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipMemcpyAsync(dst, host, (size_t)b->batch * w * sizeof(double), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -497,6 +521,13 @@ int tg_batch_get(tg_batch *b, int32_t field, double *host) {
     double *src = field_ptr(b, field);
     if (w < 0 || !src) return fail(TG_ERR_INVALID, "unknown field");
     if (w == 0) return TG_SUCCESS;
+    if (b->mirror_valid && (field == TG_F_Q2 || field == TG_F_P2 || field == TG_F_LAMBDA1)) {   // answered from the last step's mirror
+        const tg::DevProg &P = b->P;
+        const size_t B = (size_t)b->batch;
+        const double *m = b->io_host + b->io_in + (field == TG_F_Q2 ? 0 : (field == TG_F_P2 ? B * P.nq : B * (P.nq + P.nd)));
+        std::memcpy(host, m, B * w * sizeof(double));
+        return TG_SUCCESS;
+    }
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipMemcpyAsync(host, src, (size_t)b->batch * w * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -528,6 +559,14 @@ int tg_batch_calc_f(tg_batch *b, double *f_host) {
 
 int tg_batch_status(tg_batch *b, int32_t *iterations_out, int32_t *status_out) {
     if (!b) return fail(TG_ERR_INVALID, "null batch");
+    if (b->mirror_valid) {
+        const tg::DevProg &P = b->P;
+        const size_t B = (size_t)b->batch;
+        const int32_t *m = reinterpret_cast<const int32_t *>(b->io_host + b->io_in + B * (P.nq + P.nd + P.nc));
+        if (iterations_out) std::memcpy(iterations_out, m, B * sizeof(int32_t));
+        if (status_out) std::memcpy(status_out, m + B, B * sizeof(int32_t));
+        return TG_SUCCESS;
+    }
     HIP_TRY(hipSetDevice(b->device));
     if (iterations_out) HIP_TRY(hipMemcpyAsync(iterations_out, b->iters, (size_t)b->batch * sizeof(int), hipMemcpyDeviceToHost, b->stream));
     if (status_out) HIP_TRY(hipMemcpyAsync(status_out, b->status, (size_t)b->batch * sizeof(int), hipMemcpyDeviceToHost, b->stream));
@@ -543,15 +582,51 @@ int tg_batch_step(tg_batch *b, double t2_new, const double *u1_host, const doubl
     if (t2_new == b->t2) return fail(TG_ERR_STATE, "step needs t2_new != t2");
     HIP_TRY(hipSetDevice(b->device));
     const size_t B = (size_t)b->batch;
+    const bool want_lh = lambda_hint_host && P.nc;
+    // Small batches: the call is host-latency bound (a MidpointVI.step() loop; tools/step_latency.py), so everything crosses the bus
+    // once in each direction: inputs through one pinned block, (q2, p2, lambda1, iterations, status) back into the host mirror.
+    const size_t n_in = B * ((size_t)P.nu + P.nk + P.nd + P.nc), n_out = B * ((size_t)P.nq + P.nd + P.nc) + B;   // 2 B ints = B doubles
+    if ((n_in + n_out) * sizeof(double) <= (1u << 20)) {
+        if (!b->io_host) {
+            if (hipHostMalloc(&b->io_host, (n_in + n_out) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+                hipMalloc(&b->io_dev, (n_in + n_out) * sizeof(double)) != hipSuccess) return fail(TG_ERR_HIP, "allocation of the step staging block failed");
+            b->io_in = n_in; b->io_out = n_out;
+        }
+        double *hu = b->io_host, *hk = hu + B * P.nu, *hq = hk + B * P.nk, *hl = hq + B * P.nd;
+        double *du = b->io_dev, *dk = du + B * P.nu, *dq = dk + B * P.nk, *dl = dq + B * P.nd;
+        if (P.nu) std::memcpy(hu, u1_host, B * P.nu * sizeof(double));
+        if (P.nk) std::memcpy(hk, k2_host, B * P.nk * sizeof(double));
+        if (q2_hint_host) std::memcpy(hq, q2_hint_host, B * P.nd * sizeof(double));
+        if (want_lh) std::memcpy(hl, lambda_hint_host, B * P.nc * sizeof(double));
+        const size_t used = want_lh ? n_in : (q2_hint_host ? B * ((size_t)P.nu + P.nk + P.nd) : B * ((size_t)P.nu + P.nk));
+        if (used) HIP_TRY(hipMemcpyAsync(b->io_dev, b->io_host, used * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        tg::RunArgs A = base_args(b, tg::MODE_ROLLOUT);
+        A.n_steps = 1; A.dt = t2_new - b->t2; A.max_iterations = max_iterations;
+        A.U = du; A.K = dk;
+        A.q2_hint = q2_hint_host ? dq : nullptr;
+        A.lam_hint = want_lh ? dl : nullptr;
+        int rc = launch(b, A);
+        if (rc) return rc;
+        b->t1 = b->t2; b->t2 = t2_new;
+        double *dout = b->io_dev + n_in;
+        const int total = (int)(B * ((size_t)P.nq + P.nd + P.nc + 1));
+        hipLaunchKernelGGL(k_pack_step, dim3((total + 255) / 256), dim3(256), 0, b->stream, (int)B, P.nq, P.nd, P.nc,
+                           (const double *)b->q2, (const double *)b->p2, (const double *)b->lam, (const int *)b->iters, (const int *)b->status, dout);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(b->io_host + n_in, dout, n_out * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        b->mirror_valid = true;
+        return tg_batch_status(b, iterations_out, status_out);
+    }
     if (P.nu) HIP_TRY(hipMemcpyAsync(b->stage_u, u1_host, B * P.nu * sizeof(double), hipMemcpyHostToDevice, b->stream));
     if (P.nk) HIP_TRY(hipMemcpyAsync(b->stage_k, k2_host, B * P.nk * sizeof(double), hipMemcpyHostToDevice, b->stream));
     if (q2_hint_host) HIP_TRY(hipMemcpyAsync(b->stage_qh, q2_hint_host, B * P.nd * sizeof(double), hipMemcpyHostToDevice, b->stream));
-    if (lambda_hint_host && P.nc) HIP_TRY(hipMemcpyAsync(b->stage_lh, lambda_hint_host, B * P.nc * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    if (want_lh) HIP_TRY(hipMemcpyAsync(b->stage_lh, lambda_hint_host, B * P.nc * sizeof(double), hipMemcpyHostToDevice, b->stream));
     tg::RunArgs A = base_args(b, tg::MODE_ROLLOUT);
     A.n_steps = 1; A.dt = t2_new - b->t2; A.max_iterations = max_iterations;
     A.U = b->stage_u; A.K = b->stage_k;
     A.q2_hint = q2_hint_host ? b->stage_qh : nullptr;
-    A.lam_hint = (lambda_hint_host && P.nc) ? b->stage_lh : nullptr;
+    A.lam_hint = want_lh ? b->stage_lh : nullptr;
     int rc = launch(b, A);
     if (rc) return rc;
     b->t1 = b->t2; b->t2 = t2_new;
@@ -673,6 +748,7 @@ int tg_batch_snapshot(tg_batch *b) {
 int tg_batch_restore(tg_batch *b) {
     if (!b) return fail(TG_ERR_INVALID, "null batch");
     HIP_TRY(hipSetDevice(b->device));
+    b->mirror_valid = false;
     b->t1 = b->snap_t1; b->t2 = b->snap_t2;
     return snapshot_copy(b, false);
 }
@@ -891,6 +967,7 @@ int tg_batch_set_from_trajectories(tg_batch *b, int32_t seeds, int32_t horizon, 
     if ((int64_t)seeds * horizon != b->batch) return fail(TG_ERR_INVALID, "batch size must be seeds * horizon");
     HIP_TRY(hipSetDevice(b->device));
     const tg::DevProg &P = b->P;
+    b->mirror_valid = false;
     hipLaunchKernelGGL(k_set_from_trajectories, dim3(b->batch), dim3(64), 0, b->stream, P, seeds, horizon, X_dev, U_dev,
                        b->q1, b->q2, b->p1, b->p2, b->lam, b->stage_u, b->stage_k, b->stage_qh);
     HIP_TRY(hipGetLastError());
@@ -907,6 +984,7 @@ int tg_batch_set_from_trajectories(tg_batch *b, int32_t seeds, int32_t horizon, 
 int tg_batch_initialize_from_state_device(tg_batch *b, double t, const double *X_dev, uint64_t row_stride_doubles) {
     if (!b || !X_dev || row_stride_doubles < (uint64_t)(b->P.nq + b->P.nd)) return fail(TG_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(b->device));
+    b->mirror_valid = false;
     hipLaunchKernelGGL(k_init_from_X, dim3(b->batch), dim3(64), 0, b->stream, b->P, X_dev, (size_t)row_stride_doubles, b->q1, b->q2,
                        b->p1, b->p2, b->lam);
     HIP_TRY(hipGetLastError());
