@@ -239,7 +239,7 @@ def test_gpu_lagrangian_derivatives_match_reference(name):
 
 # ---- second derivatives of the continuous dynamics (system.py:982-1078; calc_dynamics_deriv2, system.c:1301-2029) ---------
 D2_NAMES = ["pendulum5", "pend_on_cart", "scissor4", "spring_arm", "plane_link", "wrench_arm", "wrench_torque", "wrench_body",
-            "damper_link", "puppet40"]
+            "damper_link", "nonlinear_spring_arm", "puppet40"]
 D2_KEYS = ["dqdq", "ddqdq", "ddqddq", "dddkdq", "dudq", "duddq", "dudu"]
 
 
@@ -253,13 +253,9 @@ def _check_second(name, got, g2, s, tol):
             ref = g2["%s_%s_%s" % (name, gpre, key)][s]
             a = got["%s_%s" % (pre, key)]
             assert a.shape == ref.shape, (name, pre, key, a.shape, ref.shape)
-            if name == "damper_link" and key == "ddqdq":
-                # LinearDamper: the reference's analytic f_ddqdq contradicts its own first derivatives (lineardamper.c:88 uses
-                # length_dq where length_dqdq is meant; |analytic - central difference of the reference's f_ddq| = 4.4 on a
-                # scale of 5.2).  The fixture holds that central difference of the REFERENCE's f_ddq: that is the parity target.
-                if pre == "f":
-                    assert relerr(a, g2[name + "_fd_f_ddqdq"]) < 1e-6 and relerr(ref, g2[name + "_fd_f_ddqdq"]) > 0.1
-                continue
+            # the reference's arrays everywhere -- including f_ddqdq with a LinearDamper (lineardamper.c:88) and f_dqdq with a
+            # NonlinearConfigSpring (nonlinear_config_spring.c:56-60), whose element conventions System._apply_reference_conventions
+            # carries into the dynamics exactly as calc_dynamics_deriv2 does
             assert relerr(a, ref) < tol, (name, s, pre, key, relerr(a, ref))
 
 
@@ -279,8 +275,13 @@ def test_emulated_dynamics_second_derivatives_match_reference(name):
         out, status = e.dynamics_deriv1(Q, dQ, U, ddK)
         assert (status == 0).all()
         return dict((rename.get(k, k), v) for k, v in out.items())
+    system, _ = build(name)
     for s in g2[name + "_states"]:
-        got = dynamics_deriv2_from_deriv1(deriv1, g[name + "_q"][s], g[name + "_dq"][s], g[name + "_u"][s], g[name + "_ddqk"][s])
+        q, dq, u, ddqk = g[name + "_q"][s], g[name + "_dq"][s], g[name + "_u"][s], g[name + "_ddqk"][s]
+        got = dynamics_deriv2_from_deriv1(deriv1, q, dq, u, ddqk)
+        # the reference's element conventions (LinearDamper, NonlinearConfigSpring), with the emulated Lagrangian kernel's mass matrix
+        system.q, system.dq, system.u, system.ddqk = q, dq, u, ddqk
+        system._apply_reference_conventions(got, mass_matrix=EmuBatch(d, 1).lagrangian(q[None], dq[None])[1][0, 2])   # L2 = (L_dqdq, L_ddqdq, L_ddqddq)
         _check_second(name, got, g2, s, 1e-8)
 
 
@@ -306,7 +307,7 @@ def test_gpu_dynamics_second_derivatives_match_reference(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["pendulum5", "scissor4", "puppet40", "spring_arm", "plane_link"])
+@pytest.mark.parametrize("name", ["pendulum5", "scissor4", "puppet40", "spring_arm", "plane_link", "nonlinear_spring_arm"])
 def test_gpu_higher_order_lagrangian_accessors_match_reference(name):
     """System.L_dqdqdq, L_ddqdqdq, L_ddqddqdq (third order) and L_ddqdqdqdq, L_ddqddqdqdq (fourth order), system.py:869-949:
     fourth-order differences of the analytic second-order arrays of the Lagrangian kernel against the reference's table
@@ -319,7 +320,8 @@ def test_gpu_higher_order_lagrangian_accessors_match_reference(name):
     idx, ref = gh[name + "_idx"], gh[name + "_vals"]
     scale = np.maximum(1.0, np.abs(ref).max(axis=0))
     worst = np.zeros(5)
-    for (a, b, c, e), r in zip(idx[:24], ref[:24]):
+    pick = list(range(24)) + ([i for i in range(len(idx)) if len(set(idx[i][:3])) == 1] if name == "nonlinear_spring_arm" else [])
+    for (a, b, c, e), r in zip(idx[pick], ref[pick]):
         got = np.array([system.L_dqdqdq(C[a], C[b], C[c]), system.L_ddqdqdq(C[a], C[b], C[c]), system.L_ddqdqdqdq(C[a], C[b], C[c], C[e]),
                         system.L_ddqddqdq(C[a], C[b], C[c]), system.L_ddqddqdqdq(C[a], C[b], C[c], C[e])])
         worst = np.maximum(worst, np.abs(got - r) / scale)

@@ -27,6 +27,7 @@ BUILDERS = {
     "wrench_torque": (lambda: systems.wrench_torque(api=trep), 1),
     "wrench_body": (lambda: systems.wrench_body(api=trep), 1),
     "damper_link": (lambda: systems.damper_link(api=trep), 1),
+    "nonlinear_spring_arm": (lambda: systems.nonlinear_spring_arm(api=trep), 2),
     "puppet40": (lambda: systems.puppet(api=trep), 1),
 }
 NAMES = ["dqdq", "ddqdq", "ddqddq", "dddkdq", "dudq", "duddq", "dudu"]
@@ -73,8 +74,8 @@ def lagrangian_higher():
     (system.py:869-949) for seeded index tuples (biased to the first 14 configs so that the puppet's tuples share kinematic chains)."""
     g = dict(np.load(os.path.join(REPO, "tests", "golden", "dynamics.npz")))
     out = {}
-    rng = np.random.default_rng(5)
-    for name in ("pendulum5", "scissor4", "puppet40", "spring_arm", "plane_link"):
+    rng = np.random.default_rng(5)     # systems are visited in a fixed order: appending one leaves the earlier tuples unchanged
+    for name in ("pendulum5", "scissor4", "puppet40", "spring_arm", "plane_link", "nonlinear_spring_arm"):
         system = BUILDERS[name][0]()
         system.q, system.dq, system.u, system.ddqk = g[name + "_q"][0], g[name + "_dq"][0], g[name + "_u"][0], g[name + "_ddqk"][0]
         C = system.configs

@@ -504,7 +504,16 @@ class System(object):
         return float((4.0 * d1 - d2) / 3.0)          # Richardson: the h^2 terms of the two mixed differences cancel
 
     def L_dqdqdq(self, q1, q2, q3):
-        return self._L_higher("L_dqdq", q1.index, q2.index, (q3.index,))
+        value = self._L_higher("L_dqdq", q1.index, q2.index, (q3.index,))
+        if q1 is q2 and q2 is q3:
+            # NonlinearConfigSpring: the reference's V_dqdqdq is -y'' (-m) m (nonlinear_config_spring.c:56-60), the derivative of
+            # the kernel's V_dqdq is -y'' m m; L holds -V, so the reference's value is the differenced one minus twice its V_dqdqdq
+            from .dynamics import NonlinearConfigSpring
+            from . import element_queries as _eq
+            for p_ in self.potentials:
+                if isinstance(p_, NonlinearConfigSpring) and p_.config is q1:
+                    value -= 2.0 * _eq.nonlinear_config_spring(p_, (q1, q1, q1))
+        return value
 
     def L_ddqdqdq(self, dq1, q2, q3):
         return self._L_higher("L_ddqdq", dq1.index, q2.index, (q3.index,))
@@ -577,7 +586,60 @@ class System(object):
             if (status != 0).any():
                 raise ValueError("singular inertia or constraint matrix")
             return d
-        return dynamics_deriv2_from_deriv1(deriv1, self.q, self.dq, self.u, self.ddqk)
+        out = dynamics_deriv2_from_deriv1(deriv1, self.q, self.dq, self.u, self.ddqk)
+        self._apply_reference_conventions(out)
+        return out
+
+    def _apply_reference_conventions(self, out, mass_matrix=None):
+        """The reference evaluates two element derivatives with its own conventions, and calc_dynamics_deriv2 carries them into
+        f_* / lambda_* (system.c:1301-2029); the discrete path here (MODE_DERIV2Z) reproduces both, so the continuous one does too:
+
+        * ``LinearDamper`` F_ddqdq(q; dq1, q2) = -c (v_ddq1dq2 x_q + v_ddq1 * length_dq(q2)) -- lineardamper.c:88 has length_dq(q2)
+          where the derivative of the first-order term has length_dqdq(q, q2);
+        * ``NonlinearConfigSpring`` V_dqdqdq = -y'' (-m) m (nonlinear_config_spring.c:56-60; the derivative of V_dqdq is -y'' m m).
+
+        A force second derivative enters the dynamics' second derivatives only through D (system.c:775-795) and D only linearly:
+        d(ddq) = M^-1 (dD + Ad^T d(lambda)), d(lambda) = -(Ad M^-1 Ad^T)^-1 Ad M^-1 dD (system.c:840-892).  So the reference's arrays
+        are the consistent ones (differences of the analytic first derivatives) plus that linear response to the difference
+        between the reference's element derivative and the consistent one."""
+        from .dynamics import LinearDamper, NonlinearConfigSpring
+        from . import element_queries as _eq
+        dampers = [f for f in self.forces if isinstance(f, LinearDamper)]
+        springs = [p for p in self.potentials if isinstance(p, NonlinearConfigSpring)]
+        if not dampers and not springs:
+            return
+        nq, nd, nc = self.nQ, self.nQd, self.nc
+        M = (self._lagrangian()["L_ddqddq"] if mass_matrix is None else np.asarray(mass_matrix))[:nd, :nd]   # the tests pass the emulated kernel's
+        Minv = np.linalg.inv(M)
+        if nc:
+            Ad = np.array([[c.h_dq(q) for q in self.dyn_configs] for c in self.constraints])
+            Gl = -np.linalg.solve(Ad.dot(Minv).dot(Ad.T), Ad.dot(Minv))        # d lambda / dD  [nc][nd]
+            Gf = Minv.dot(np.eye(nd) + Ad.T.dot(Gl))                            # d ddq / dD     [nd][nd]
+        else:
+            Gl, Gf = np.zeros((0, nd)), Minv
+        configs = self.configs
+        for f in dampers:
+            used = [q for q in configs if f._on(q)]
+            x_q = dict((q.index, _eq.length_dq(f, q)) for q in used)
+            for dq1 in used:
+                for q2 in used:
+                    dD = np.zeros(nd)
+                    for q in used:
+                        if q.index < nd:
+                            dD[q.index] = -f.c * x_q[dq1.index] * (x_q[q2.index] - _eq.length_dqdq(f, q, q2))
+                    out["f_ddqdq"][dq1.index, q2.index] += Gf.dot(dD)
+                    if nc:
+                        out["lambda_ddqdq"][dq1.index, q2.index] += Gl.dot(dD)
+        for p_ in springs:
+            k = p_.config.index
+            if k >= nd:
+                continue          # a potential on a kinematic config exerts no generalized force on the dynamic ones
+            ref3 = _eq.nonlinear_config_spring(p_, (p_.config, p_.config, p_.config))      # the reference's V_dqdqdq
+            dD = np.zeros(nd)
+            dD[k] = -2.0 * ref3           # D holds -V_dq: reference minus consistent third derivative = 2 * reference's value
+            out["f_dqdq"][k, k] += Gf.dot(dD)
+            if nc:
+                out["lambda_dqdq"][k, k] += Gl.dot(dD)
 
     def _dyn_d2_accessor(name, out_kind, kind1, kind2):
         def pick(obj, kind):
