@@ -669,13 +669,22 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
             if (a.C_dev && tid < nU) a.C_dev[(sN + k) * nU + tid] = Cs[tid];
         }
         const double *Qk = a.Q_dev + (size_t)s * a.Q_seed_stride + (size_t)k * a.Q_step_stride;
+        // The new P is symmetric (Q_k, A'(P A) with symmetric P, Kpart' gamma^-1 Kpart): only the NT (NT + 1) / 2 tiles on and above the
+        // diagonal are computed -- the sweep is bound by the matrix cores' throughput, and this is a quarter of its MFMAs -- and
+        // phase 6 mirrors them instead of averaging the two triangles.
+        constexpr int NTRI = NT * (NT + 1) / 2, TSYM = (NTRI + NW - 1) / NW;
         {
             int ti_[TMAX], tj_[TMAX];
             bool ok_[TMAX];
 #pragma unroll
             for (int i = 0; i < TMAX; i++) {
                 const int t = wave + NW * i;
-                ok_[i] = t < NTILES; ti_[i] = ok_[i] ? t / NT : 0; tj_[i] = ok_[i] ? t % NT : 0;
+                ok_[i] = i < TSYM && t < NTRI;
+                // t-th tile of the upper triangle, row by row: row r holds NT - r tiles
+                int tr = 0, tt = ok_[i] ? t : 0;
+#pragma unroll
+                for (int r = 0; r < NT; r++) if (tt >= NT - r && tr == r) { tt -= NT - r; tr = r + 1; }
+                ti_[i] = tr; tj_[i] = tr + tt;
                 // the weights Q_k (+ curvature) first: their global-memory latency hides behind the MFMA chains
                 v4d c = zero4;
                 const int col = 16 * tj_[i] + lr;
@@ -721,10 +730,13 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
         LQ_STAMP(3);
         // ---- phase 5: P <- new tiles, b <- new b, next A, B into LDS ---------------------------------------------
 #pragma unroll
-        for (int i = 0; i < TMAX; i++) {
+        for (int i = 0; i < TSYM; i++) {
             const int t = wave + NW * i;
-            if (t < NTILES) {
-                const int ti = t / NT, tj = t % NT;
+            if (t < NTRI) {
+                int tr = 0, tt = t;
+#pragma unroll
+                for (int r = 0; r < NT; r++) if (tt >= NT - r && tr == r) { tt -= NT - r; tr = r + 1; }
+                const int ti = tr, tj = tr + tt;
 #pragma unroll
                 for (int r = 0; r < 4; r++) Pm[(16 * ti + lk + 4 * r) * ldx + 16 * tj + lr] = acc[i][r];
             }
@@ -733,12 +745,15 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
         if (k > 0) commit();
         __syncthreads();
         LQ_STAMP(4);
-        // ---- phase 6: P <- (P + P')/2 ---------------------------------------------------------------------------
+        // ---- phase 6: the lower triangle is the mirror of the upper one -------------------------------------------------
         // along diagonals: (i, i + d) and (i + d, i) are both strided by ldx + 1 doubles over the lanes (no bank conflicts; a
-        // row-wise pass reads the transposed element with stride ldx = 16-way conflicts)
+        // row-wise pass reads the transposed element with stride ldx = 16-way conflicts).  Inside the diagonal tiles both
+        // triangles were computed: there the two are averaged as before.
         for (int d = 1 + wave; d < nX; d += NW)
             for (int i = lane; i < nX - d; i += 64) {
-                const double v = 0.5 * (Pm[i * ldx + i + d] + Pm[(i + d) * ldx + i]);
+                const bool diag_tile = (i >> 4) == ((i + d) >> 4);
+                const double up = Pm[i * ldx + i + d];
+                const double v = diag_tile ? 0.5 * (up + Pm[(i + d) * ldx + i]) : up;
                 Pm[i * ldx + i + d] = v; Pm[(i + d) * ldx + i] = v;
             }
         __syncthreads();
@@ -958,6 +973,92 @@ __global__ __launch_bounds__(CT_T) void k_cost(int N, int nX, int nU, int group,
     }
 }
 
+// The same cost on the matrix cores.  k_cost keeps Q', Qf' and R' in LDS (110 KB at the puppet's size: one workgroup per CU) and walks
+// the horizon four steps at a time behind two barriers per trip -- 5.6 us per trip, 11 ms for the 2048 candidates of one Armijo
+// round, 7 % of a discopt iteration.  Here a wavefront takes SIXTEEN consecutive steps as the rows of one v_mfma_f64_16x16x4 tile
+// row: D = DX Q (DX [16][nX] straight from global memory into the A operand, Q row-major in LDS as the B operand, NT independent
+// accumulator chains), then the cost of those steps is sum D .* DX with DX re-read in the accumulator layout; likewise DU R.  The
+// terminal step (weight Qf) is one wavefront's dot products.  No barrier inside the sweep; only Q and R are staged (52 KB).
+template <int NT>
+__global__ __launch_bounds__(CT_T) void k_cost_mfma(int N, int nX, int nU, int group, const int *sel, const double *X, const double *U,
+                                                     const double *Xd, const double *Ud, const double *Q, const double *R,
+                                                     const double *Qf, double *cost) {
+    extern __shared__ double lds[];
+    constexpr int ldx = 16 * NT, NW = CT_T / 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const size_t t = blockIdx.x, s = sel ? (size_t)sel[t / group] : t / group;
+    const int ldu = round_up(nU, 16), NUT = ldu >> 4;
+    double *Qm = lds, *Rm = Qm + ldx * ldx, *red = Rm + ldu * ldu;
+    for (int e = tid; e < ldx * ldx; e += CT_T) { const int r = e / ldx, c = e % ldx; Qm[e] = (r < nX && c < nX) ? Q[r * nX + c] : 0.0; }
+    for (int e = tid; e < ldu * ldu; e += CT_T) { const int r = e / ldu, c = e % ldu; Rm[e] = (r < nU && c < nU) ? R[r * nU + c] : 0.0; }
+    __syncthreads();
+    const double *Xt = X + t * (size_t)(N + 1) * nX, *Xs = Xd + s * (size_t)(N + 1) * nX;
+    const double *Ut = U + t * (size_t)N * nU, *Us = Ud + s * (size_t)N * nU;
+    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+    double part = 0.0;
+    const int n_row_tiles = (N + 15) >> 4;          // steps 0 .. N-1 carry Q and R; step N (Qf) is handled below
+    for (int rt = wave; rt < n_row_tiles; rt += NW) {
+        // ---- state part: rows = steps 16 rt .. 16 rt + 15 (rows >= N contribute nothing) ---------------------------------------
+        {
+            const int row = 16 * rt + lr;
+            double av[ldx / 4];
+#pragma unroll
+            for (int ks = 0; ks < ldx / 4; ks++) {
+                const int c = 4 * ks + lk;
+                av[ks] = (row < N && c < nX) ? Xt[(size_t)row * nX + c] - Xs[(size_t)row * nX + c] : 0.0;
+            }
+            v4d acc[NT];
+#pragma unroll
+            for (int j = 0; j < NT; j++) acc[j] = zero4;
+#pragma unroll
+            for (int ks = 0; ks < ldx / 4; ks++) {
+#pragma unroll
+                for (int j = 0; j < NT; j++)
+                    acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], Qm[(4 * ks + lk) * ldx + 16 * j + lr], acc[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int rr = 16 * rt + lk + 4 * r, c = 16 * j + lr;
+                    if (rr < N && c < nX) part += 0.5 * acc[j][r] * (Xt[(size_t)rr * nX + c] - Xs[(size_t)rr * nX + c]);
+                }
+        }
+        // ---- input part -----------------------------------------------------------------------------------------------------
+        {
+            const int row = 16 * rt + lr;
+            for (int j = 0; j < NUT; j++) {
+                v4d acc = zero4;
+                for (int k0 = 0; k0 < ldu; k0 += 4) {
+                    const int c = k0 + lk;
+                    const double a_ = (row < N && c < nU) ? Ut[(size_t)row * nU + c] - Us[(size_t)row * nU + c] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, Rm[(k0 + lk) * ldu + 16 * j + lr], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int rr = 16 * rt + lk + 4 * r, c = 16 * j + lr;
+                    if (rr < N && c < nU) part += 0.5 * acc[r] * (Ut[(size_t)rr * nU + c] - Us[(size_t)rr * nU + c]);
+                }
+            }
+        }
+    }
+    if (wave == NW - 1) {     // terminal cost 1/2 dx_N' Qf dx_N: one output column per lane
+        const double *xk = Xt + (size_t)N * nX, *xd = Xs + (size_t)N * nX;
+        for (int i = lane; i < nX; i += 64) {
+            double v = 0.0;
+            for (int j = 0; j < nX; j++) v += Qf[j * nX + i] * (xk[j] - xd[j]);
+            part += 0.5 * (xk[i] - xd[i]) * v;
+        }
+    }
+    red[tid] = part;
+    __syncthreads();
+    if (tid == 0) {      // fixed summation order: the result does not depend on timing
+        double t_ = 0.0;
+        for (int i = 0; i < CT_T; i++) t_ += red[i];
+        cost[t] = t_;
+    }
+}
+
 // gradients q_k = (x_k - xd_k)'Q (k < N), q_N = (x_N - xd_N)'Qf, r_k = (u_k - ud_k)'R  (dcost.py:62-84)
 __global__ __launch_bounds__(CT_T) void k_cost_grad(int N, int nX, int nU, const int *sel, const double *X, const double *U,
                                                      const double *Xd, const double *Ud, const double *Q, const double *R,
@@ -1109,9 +1210,23 @@ int tg_quadratic_cost(int32_t device, int32_t n_trajectories, int32_t group, con
                       const double *R_dev, const double *Qf_dev, double *cost_dev) {
     if (n_trajectories <= 0 || group <= 0 || horizon <= 0 || !X_dev || !U_dev || !Xd_dev || !Ud_dev || !Q_dev || !R_dev || !Qf_dev || !cost_dev)
         return fail(TG_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    if (nX <= 96 && nU <= 96 && !std::getenv("TREPAMD_COST_LEGACY")) {     // matrix-core version (k_cost_mfma)
+        const int nt = (nX + 15) / 16, ldx = 16 * nt, ldu = round_up(nU, 16);
+        const size_t ldsm = sizeof(double) * ((size_t)ldx * ldx + (size_t)ldu * ldu + CT_T);
+#define LAUNCH_COST(NT_)                                                                                                                  \
+        case NT_:                                                                                                                         \
+            if (ldsm > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_cost_mfma<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm)); \
+            hipLaunchKernelGGL((k_cost_mfma<NT_>), dim3(n_trajectories), dim3(CT_T), ldsm, 0, horizon, nX, nU, group, select_dev, X_dev, U_dev,       \
+                               Xd_dev, Ud_dev, Q_dev, R_dev, Qf_dev, cost_dev);                                                           \
+            break;
+        switch (nt) { LAUNCH_COST(1) LAUNCH_COST(2) LAUNCH_COST(3) LAUNCH_COST(4) LAUNCH_COST(5) LAUNCH_COST(6) default: break; }
+#undef LAUNCH_COST
+        HIP_TRY(hipGetLastError());
+        return TG_SUCCESS;
+    }
     const size_t lds = sizeof(double) * (2 * (size_t)nX * nX + (size_t)nU * nU + 4 * (size_t)(nX + nU) + CT_T);
     if (lds > 160 * 1024 - 64) return fail(TG_ERR_UNSUPPORTED, "state dimension too large");
-    HIP_TRY(hipSetDevice(device));
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_cost, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_cost, dim3(n_trajectories), dim3(CT_T), lds, 0, horizon, nX, nU, group, select_dev, X_dev, U_dev, Xd_dev, Ud_dev, Q_dev, R_dev,
                        Qf_dev, cost_dev);
