@@ -308,6 +308,7 @@ struct Core {
     int lane;
     double dt;
     int oGc;   // LDS offset of the joint poses that the end-point / constraint evaluation reads (P.o_G, or the second pose set of a dual sweep)
+    int dsA = 0, dsB = 2;   // which configurations the two pose sets of pose_sweep_dual belong to (qval selectors: 0 midpoint, 1 q1, 2 q2)
     // table rows this lane needs in every Newton iteration of a rollout, read once per kernel (P.tab_ok, eval_both_tab):
     // joint (config | kind << 16) of the two sin/cos trips, the body's item range of the velocity prefix sums, and the
     // constant Newton-matrix entries (damping of this row, (constraint, config) of the lane's two Dh items, first pair record)
@@ -531,7 +532,7 @@ struct Core {
                     if (idx < 2 * nj) {
                         const bool second = (jck[u] >> 28) != 0;
                         const int j = (jck[u] >> 16) & 0xFFF, kind = (jck[u] >> 12) & 0xF;
-                        const double x = qval(second ? 2 : 0, jck[u] & 0xFFF);
+                        const double x = qval(second ? dsB : dsA, jck[u] & 0xFFF);
                         double *dst = (second ? sc2 : sc) + 2 * j;
                         if (u * TEAM < sc_rot2) {          // (wave-uniform) a trip with rotary joints in it
                             if (kind >= TG_RX) tg_sincos(x, &dst[0], &dst[1]);
@@ -544,7 +545,7 @@ struct Core {
         if (on) TG_FOR(idx, 2 * nj) {
             const bool second = idx >= nj;
             const int j = second ? idx - nj : idx;
-            const double x = qval(second ? 2 : 0, P.j_cfg[j]);
+            const double x = qval(second ? dsB : dsA, P.j_cfg[j]);
             double *dst = (second ? sc2 : sc) + 2 * j;
             if (P.j_kind[j] >= TG_RX) tg_sincos(x, &dst[0], &dst[1]);
             else { dst[0] = x; dst[1] = 0.0; }
@@ -1755,6 +1756,148 @@ struct Core {
         __syncthreads();
         return ok;
     }
+    // ---- gj_panel for MANY right-hand sides (the derivative solves: n <= 31 rows, [A | B] with w <= 16 NTC columns) ------------
+    //      The same panels, pivot rule and block update as gj_panel, with NTC tile columns in the accumulator layout (two tile
+    //      rows x NTC tiles x 4 doubles per lane) instead of two: every right-hand side rides in the rank-4 matrix-core update
+    //      (2 NTC v_mfma_f64_16x16x4 per panel for ~110 columns, where gj_cols spends 28 x 56 lane-wide FMAs plus the pivot-column
+    //      traffic per PIVOT step).  The LDS image [n][ld] is refreshed after every panel (live tile columns only); at the end every
+    //      lane scales its entries by the reciprocal pivot of their row and stores them in the row of the variable that row solved:
+    //      A[i][n + j] = x_i of right-hand side j, like gauss_jordan() / gj_cols.  `scratch`: 128 + 64 doubles of LDS outside the image.
+    template <int N, int NTC>
+    static __device__ __noinline__ bool gj_panel_rhs(bool on, double *A_generic, int n, int w, int ld, int lane, double *scratch_generic) {
+        static_assert(N % 4 == 0 && N > 16 && N <= 32 && NTC >= 2 && NTC <= 8, "gj_panel_rhs: 16 < N <= 32, 32 .. 128 columns");
+        typedef __attribute__((address_space(3))) double lds_double;
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        lds_double *A = (lds_double *)A_generic, *WL = (lds_double *)scratch_generic, *RD = WL + 128;
+        __attribute__((address_space(3))) int *MC = (__attribute__((address_space(3))) int *)(WL + 160);
+        const int g = (lane >> 4) & 3, c = lane & 15;
+        auto lds_fence = [] { asm volatile("" ::: "memory"); };
+        auto rows_all = [&](int TR, int v) { return 16 * TR + 4 * v + 3 < n; };
+        auto rows_none = [&](int TR, int v) { return 16 * TR + 4 * v >= n; };
+        // ---- [A | B] into the accumulator layout
+        v4d T[2][NTC];
+#pragma unroll
+        for (int TR = 0; TR < 2; TR++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int row = 16 * TR + 4 * v + g;
+                const bool rin = !rows_none(TR, v) && (rows_all(TR, v) || row < n);
+#pragma unroll
+                for (int TC = 0; TC < NTC; TC++) {
+                    const int col = 16 * TC + c;
+                    const bool in = rin && col < w;
+                    const double a = A[in ? row * ld + col : 0];
+                    T[TR][TC][v] = in ? a : 0.0;
+                }
+            }
+        const bool mine = lane < n;
+        const int myrow = (mine ? lane : 0) * ld;
+        double scale = 0.0;
+        {
+            double s = -1.0;
+#pragma unroll
+            for (int j = 0; j < N; j++) if (j < n) { const double a = fabs(A[myrow + j]); s = a > s ? a : s; }
+            scale = 1.0 / s;
+        }
+        bool ok = true;
+        if (!mine) scale = 0.0;
+        const unsigned int lanetag = (unsigned int)(63 - (lane & 63));
+        int mycol = -1;
+        double rdiag = 0.0;
+#pragma unroll
+        for (int p = 0; p < N / 4; p++) {
+            double cp[4], z[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < 4; t++) cp[t] = A[myrow + (4 * p + t < n ? 4 * p + t : 0)];
+            int srcs[4] = {0, 0, 0, 0};
+            const int TC0 = (4 * p + 4) >> 4;        // first tile column with columns right of this panel
+            double bop[NTC];
+#pragma unroll
+            for (int TC = 0; TC < NTC; TC++) bop[TC] = 0.0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int k = 4 * p + t;
+                if (k < n) {
+                    const double own_rp = tg_rcp(cp[t]);
+                    const float cand = (float)(cp[t] * scale);
+                    unsigned int key = (__float_as_uint(cand) & 0x7FFFFFC0u) | lanetag;
+                    key = tg_max_u32_lanes32(key);
+                    if (!((key & ~0x3Fu) > 0x1E3CE508u)) ok = false;
+                    const int src = __builtin_amdgcn_readfirstlane(63 - (int)(key & 0x3Fu));
+                    auto bcast = [&](double v) -> double {
+                        const long long b = __double_as_longlong(v);
+                        const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFLL), src);
+                        const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+                        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+                    };
+                    const bool is_piv = lane == src;
+                    srcs[t] = src;
+                    if (t == 3 || k == n - 1) {   // B operands: lane group t takes pivot row r_t of the image as of the panel's start
+                        const int prow = (g == 0 ? srcs[0] : (g == 1 ? srcs[1] : (g == 2 ? srcs[2] : srcs[3]))) * ld;
+#pragma unroll
+                        for (int TC = 0; TC < NTC; TC++) if (TC >= TC0) { const int col = 16 * TC + c; bop[TC] = A[prow + (col < w ? col : 0)]; }
+                    }
+                    const double rp = bcast(own_rp);
+                    const double l = is_piv ? 0.0 : cp[t] * -rp;
+#pragma unroll
+                    for (int t2 = t + 1; t2 < 4; t2++) cp[t2] = fma(l, bcast(cp[t2]), cp[t2]);
+#pragma unroll
+                    for (int s = 0; s < t; s++) z[s] = fma(l, bcast(z[s]), z[s]);
+                    z[t] = l;
+                    mycol = is_piv ? k : mycol;
+                    rdiag = is_piv ? own_rp : rdiag;
+                    scale = is_piv ? 0.0 : scale;
+                }
+            }
+            if (lane < 32) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) WL[lane * 4 + t] = z[t];
+            }
+            lds_fence();
+            const double a0 = WL[c * 4 + g], a1 = WL[(16 + c) * 4 + g];
+#pragma unroll
+            for (int TC = 0; TC < NTC; TC++) if (TC >= TC0) {
+                const double b = 16 * TC + c < w ? bop[TC] : 0.0;
+                T[0][TC] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, T[0][TC], 0, 0, 0);
+                T[1][TC] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, T[1][TC], 0, 0, 0);
+            }
+            lds_fence();
+            if (p + 1 < N / 4) {        // refresh the image (the last panel's result leaves through the scaled store below)
+#pragma unroll
+                for (int TC = 0; TC < NTC; TC++) if (TC >= TC0 && 16 * TC + c < w) {
+#pragma unroll
+                    for (int TR = 0; TR < 2; TR++)
+#pragma unroll
+                        for (int v = 0; v < 4; v++) {
+                            const int row = 16 * TR + 4 * v + g;
+                            if (!rows_none(TR, v) && (rows_all(TR, v) || row < n)) A[row * ld + 16 * TC + c] = T[TR][TC][v];
+                        }
+                }
+            }
+            lds_fence();
+        }
+        // x = B / pivot, row by row, into the row of the variable each row solved
+        if (mine) { RD[lane] = rdiag; MC[lane] = mycol; }
+        lds_fence();
+        if (on && ok) {
+#pragma unroll
+            for (int TR = 0; TR < 2; TR++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int row = 16 * TR + 4 * v + g;
+                    if (rows_none(TR, v) || !(rows_all(TR, v) || row < n)) continue;
+                    const double rd = RD[row];
+                    const int mc = MC[row];
+#pragma unroll
+                    for (int TC = 0; TC < NTC; TC++) {
+                        const int col = 16 * TC + c;
+                        if (col >= n && col < w && mc >= 0) A[mc * ld + col] = T[TR][TC][v] * rd;
+                    }
+                }
+        }
+        __syncthreads();
+        return ok;
+    }
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1883,6 +2026,22 @@ struct Core {
         TG_SYNC();
         // constraints at q1: Jacobian (held in the KKT matrix) and lambda-weighted Hessian
         if (nc) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_DUAL_SWEEP) && defined(TG_GJ_PANEL_DEFAULT)
+            // (system-specialised kernels only: with the schedule interpreted at run time the fused sweep is 5 % slower here)
+            if (dual_ok()) {      // the q1 and the q2 poses in one fused sweep (second set in the W area, dead until the midpoint evaluation)
+                dsA = 1; dsB = 2;
+                pose_sweep_dual(on);
+                dsA = 0;
+                attach_points(on, false, true);
+                constraints(on, 1, false, Dh1, nq);
+                constraint_hessian_rhs(on, AUG, ld);
+                oGc = P.o_W;
+                attach_points(on, false, true);
+                constraints(on, 2, false, Dh2, nq);
+                oGc = P.o_G;
+            } else
+#endif
+            {
             pose_sweep(on, 1);
             attach_points(on, false, true);
             constraints(on, 1, false, Dh1, nq);
@@ -1890,6 +2049,7 @@ struct Core {
             pose_sweep(on, 2);
             attach_points(on, false, true);
             constraints(on, 2, false, Dh2, nq);
+            }
         }
         eval_midpoint(on);
         // constant blocks: forces (damping.c:21-27, configforce.c:27-33), -Dh1T, Dh2, unit p1 columns, k2 constraint rows
@@ -2011,6 +2171,20 @@ struct Core {
             TG_SYNC();
         }
         TG_STAMP(8);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TG_GJ_PANEL_DEFAULT) && !defined(TG_NO_GJ_PANEL)
+        // system-specialised kernels, full-wave team, 17..31 unknowns, at most 128 columns: panels of four columns with every
+        // right-hand side in the rank-4 matrix-core update (sizes are compile-time constants of the specialisation header)
+        {
+            typedef typename std::remove_const<PROG>::type SP;
+            constexpr int NF = SP::nf, W0 = SP::nf + SP::d_nrhs, W1 = W0 + SP::nc;
+            if constexpr (TEAM == 64 && NF > 16 && NF <= 31 && W1 <= 128) {
+                constexpr int NP = ((NF + 3) >> 2) << 2;
+                double *sc = S + P.o_G;   // the joint poses are dead during the solve
+                if (extra) return Core<64, SPRINGS, PROG>::template gj_panel_rhs<NP, (W1 + 15) / 16>(on, AUG, NF, W1, ld, lane, sc);
+                return Core<64, SPRINGS, PROG>::template gj_panel_rhs<NP, (W0 + 15) / 16>(on, AUG, NF, W0, ld, lane, sc);
+            }
+        }
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
         {   // small KKT matrix, many right-hand sides: register-resident column elimination (whole wavefront)
             const int w = nf + R + (extra ? nc : 0), nb4 = (nf + 3) >> 2;
@@ -2037,6 +2211,7 @@ struct Core {
         const int ld = P.d_aug_ld, R = P.d_nrhs;
         double *AUG = S + P.d_o_AUG, *T12 = S + P.d_o_T12, *T22 = S + P.d_o_T22;
         const bool ok = deriv1_solve(on, false);
+        TG_STAMP(11);     // everything since the pair loop: the KKT solve
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
         struct ProfDump { Core &c; CArgs &A; size_t t; int lane;
             __device__ ~ProfDump() { long long t_ = (long long)__builtin_amdgcn_s_memtime(); c.prof[13] += t_ - c.prof_last;
@@ -2049,10 +2224,85 @@ struct Core {
             if (on) {
                 const int nX = P.nX, nU = nu + nk, nqd = nq + nd;
                 double *Ao = A.A_out + t * (size_t)nX * nX, *Bo = A.B_out + t * (size_t)nX * nU;
+                bool rows_done = false;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_AB_MFMA)
+                if (TEAM == 64 && nd <= 32) {
+                    // The p2 rows are a dense product, P[o][v] = T1x[v][o] + sum_i T22[i][o] X[i][v] (nd x (nX + nU), K = nd): on the
+                    // matrix cores, one v_mfma_f64_16x16x4 tile per 16 outputs x 16 variables, four tiles of a tile row side by side
+                    // (independent accumulator chains).  A operand = T22' (rows o contiguous over the lanes), B operand = the solved
+                    // right-hand sides in the KKT image, both straight from LDS; the accumulator layout has the variable index on the
+                    // lanes, so the stores into A_k / B_k rows are 128-byte segments.  The VALU version below (one LDS read per FMA,
+                    // 22 x 8 FMAs per lane and pass) was 29 % of this kernel.
+                    typedef double v4d __attribute__((ext_vector_type(4)));
+                    const int lr = lane & 15, lk = lane >> 4, nV = nX + nU, NTCv = (nV + 15) >> 4, KS = (nd + 3) >> 2;
+                    auto svar = [&](int vv, int &kind, int &i, bool &vpart) {   // column vv of [A_k | B_k] -> index among (q1, p1, u1, k2)
+                        vpart = vv >= nqd && vv < nX;
+                        const int sv = vv < nqd ? vv : vv - nk;
+                        kind = sv < nq ? 0 : (sv < nqd ? 1 : (sv < nqd + nu ? 2 : 3));
+                        i = kind == 0 ? sv : (kind == 3 ? sv - nqd - nu : 0);
+                        return sv;
+                    };
+                    for (int TR = 0; 16 * TR < nd; TR++) {
+                        double av[8];
+#pragma unroll
+                        for (int ks = 0; ks < 8; ks++) {
+                            const int i2 = 4 * ks + lk, o = 16 * TR + lr;
+                            const bool in = ks < KS && i2 < nd && o < nd;
+                            const double a = T22[in ? i2 * nd + o : 0];
+                            av[ks] = in ? a : 0.0;
+                        }
+                        for (int TC0 = 0; TC0 < NTCv; TC0 += 4) {
+                            v4d acc[4];
+                            int bcol[4];
+                            bool bin[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                acc[j] = (v4d){0.0, 0.0, 0.0, 0.0};
+                                const int vv = 16 * (TC0 + j) + lr;
+                                int kind, i; bool vpart;
+                                const int sv = svar(vv < nV ? vv : 0, kind, i, vpart);
+                                bin[j] = ok && TC0 + j < NTCv && vv < nV && !vpart;
+                                bcol[j] = nf + sv;
+                            }
+#pragma unroll
+                            for (int ks = 0; ks < 8; ks++) if (ks < KS) {
+                                const int i2 = 4 * ks + lk;
+#pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    const bool in = bin[j] && i2 < nd;
+                                    const double b = AUG[in ? i2 * ld + bcol[j] : 0];
+                                    acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], in ? b : 0.0, acc[j], 0, 0, 0);
+                                }
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int vv = 16 * (TC0 + j) + lr;
+                                if (TC0 + j >= NTCv || vv >= nV) continue;
+                                int kind, i; bool vpart;
+                                const int sv = svar(vv, kind, i, vpart);
+#pragma unroll
+                                for (int r = 0; r < 4; r++) {
+                                    const int o = 16 * TR + lk + 4 * r;
+                                    if (o >= nd) continue;
+                                    double x = NAN, pv = NAN;
+                                    if (vpart) { x = 0.0; pv = 0.0; }
+                                    else if (ok) {
+                                        x = AUG[o * ld + nf + sv];
+                                        pv = acc[j][r] + (kind == 0 ? T12[i * nd + o] : (kind == 3 ? T22[(nd + i) * nd + o] : 0.0));
+                                    }
+                                    if (vv < nX) { Ao[(size_t)o * nX + vv] = x; Ao[(size_t)(nq + o) * nX + vv] = pv; }
+                                    else { Bo[(size_t)o * nU + vv - nX] = x; Bo[(size_t)(nq + o) * nU + vv - nX] = pv; }
+                                }
+                            }
+                        }
+                    }
+                    rows_done = true;
+                }
+#endif
                 // p2 derivative = T12 / T22 row + T22' x: OB output rows per pass share the loads of x and run as OB independent
                 // accumulation chains (a single chain is nd dependent fp64 FMAs at ~30 cycles each)
                 constexpr int OB = 8;
-                for (int o0 = 0; o0 < nd; o0 += OB) TG_FOR(vv, nX + nU) {
+                if (!rows_done) for (int o0 = 0; o0 < nd; o0 += OB) TG_FOR(vv, nX + nU) {
                     double x[OB], p[OB];
 #pragma unroll
                     for (int j = 0; j < OB; j++) { x[j] = NAN; p[j] = NAN; }

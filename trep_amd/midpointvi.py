@@ -628,7 +628,7 @@ class MidpointVI(object):
         nd, nq, nu, nk = b.nd, b.nq, b.nu, b.nk
         nc = b.nc
         if getattr(self, "_b2", None) is None or self._b2_version != self._system._structure_version:
-            self._b2 = BatchMidpointVI(self._system, max(2 * nd + nc, 1), self._tolerance, self._device)
+            self._b2 = BatchMidpointVI(self._system, max(2 * nd + nc, 1), self._tolerance, self._device, specialize=self._specialize)
             self._b2_version = self._system._structure_version
         h = self._b2
         h.set_times(*b.times())
