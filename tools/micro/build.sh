@@ -4,6 +4,8 @@ set -e
 cd "$(dirname "$0")"
 mkdir -p bin
 for f in *.hip; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -I ../../trep_amd/csrc $EXTRA -o bin/${f%.hip} $f
+    # gj_bench: sizes as compile-time constants and the flags of the system-specialised kernels (trep_amd/specialize.py)
+    [ $f = gj_bench.hip ] && X="-DGJ_STATIC_N -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp" || X=""
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -I ../../trep_amd/csrc $X $EXTRA -o bin/${f%.hip} $f
 done
 ls bin
