@@ -2077,13 +2077,22 @@ struct Core {
         //   a = dt/4 L_qq, b = L_dqdq/dt, c(r,o) = 1/2 L(dq_r, q_o);  D1D1 = a+b-c-cT, D2D1 = a-b+c-cT,
         //   D1D2 = a-b-c+cT, D2D2 = a+b+c+cT.
         const double qdt = 0.25 * dt, rdt = 1.0 / dt;
-        for (int b = 0; b < P.n_bodies; b++) {
-            const int p0 = P.b_pair_off[b], np = P.b_pair_off[b + 1] - p0;
-            const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // full-wave teams: ALL (item, item) pairs of all bodies in one flat pass (the per-body passes below fill 21 .. 55 of 64 lanes and
+        // put a barrier between bodies); several bodies reach the same table entry, so the accumulation uses LDS atomics -- one
+        // wavefront, whose LDS operations retire in order: the summation order is the same on every run (as in newton_matrix)
+        const bool flat = TEAM == 64;
+#else
+        const bool flat = false;
+#endif
+        for (int b = 0; b < (flat ? 1 : P.n_bodies); b++) {
+            const int p0 = flat ? 0 : P.b_pair_off[b], np = flat ? P.n_pairs : P.b_pair_off[b + 1] - p0;
             if (on) TG_FOR(pp, np) {
                 const int ia = P.pair_a[p0 + pp], ib = P.pair_b[p0 + pp];
                 const int ca = P.it_cfg[ia], cb = P.it_cfg[ib];
                 if (ca >= nd && cb >= nd) continue;
+                const int bb = flat ? P.it_body[ia] : b;
+                const double *I = S + P.o_I + 4 * bb, *v = S + P.o_vB + 6 * bb, *gam = S + P.o_gam + 3 * bb;
                 const double *Ja = S + P.o_J + 6 * ia, *Jb = S + P.o_J + 6 * ib;
                 const double *Wa = S + P.o_W + 6 * ia, *Wb = S + P.o_W + 6 * ib;
                 double tb[6];
@@ -2101,12 +2110,20 @@ struct Core {
                 }
                 auto add = [&](int r, int o, double c_ro, double c_or) {
                     if (o >= nd) return;
-                    AUG[o * ld + c_q1 + r] -= a_ + b_ - c_ro - c_or;
                     const double d21 = a_ - b_ + c_ro - c_or;
-                    if (r < nd) AUG[o * ld + r] += d21;
-                    else AUG[o * ld + c_k2 + (r - nd)] -= d21;
-                    T12[r * nd + o] += a_ - b_ - c_ro + c_or;
-                    T22[r * nd + o] += a_ + b_ + c_ro + c_or;
+                    if (flat) {
+                        lds_add(&AUG[o * ld + c_q1 + r], -(a_ + b_ - c_ro - c_or));
+                        if (r < nd) lds_add(&AUG[o * ld + r], d21);
+                        else lds_add(&AUG[o * ld + c_k2 + (r - nd)], -d21);
+                        lds_add(&T12[r * nd + o], a_ - b_ - c_ro + c_or);
+                        lds_add(&T22[r * nd + o], a_ + b_ + c_ro + c_or);
+                    } else {
+                        AUG[o * ld + c_q1 + r] -= a_ + b_ - c_ro - c_or;
+                        if (r < nd) AUG[o * ld + r] += d21;
+                        else AUG[o * ld + c_k2 + (r - nd)] -= d21;
+                        T12[r * nd + o] += a_ - b_ - c_ro + c_or;
+                        T22[r * nd + o] += a_ + b_ + c_ro + c_or;
+                    }
                 };
                 add(ca, cb, c_ab, c_ba);
                 if (ia != ib) add(cb, ca, c_ba, c_ab);
