@@ -3114,9 +3114,11 @@ struct Core {
                     tb[m] = pwa; tb[6 + m] = sja; tb[12 + m] = pjb;      // TWa, TJa, TJb
                 }
                 TG_SYNC();
-                if (on) for (int pp = P.tri_off[b0] + tg_opaque(lane); pp < P.tri_off[b1]; pp += TEAM) {
-                    const int *pw = P.tri4 + 4 * (size_t)pp;
-                    const int x = pw[0], y = pw[1], kx = pw[2] & 0xFFFF, ky = pw[2] >> 16, b = pw[3];
+                // one lane per UNORDERED pair x <= y (the flat (item, item) list of the first-derivative tables): every ingredient below is
+                // either symmetric under x <-> y (q, eo, dO) or swaps with its partner (dx <-> dy, ex <-> ey), so the pair (y, x) of the
+                // H12 table comes out of the same evaluation -- half the lanes' work of the ordered list (tri4) used until round 2
+                if (on) for (int pp = P.b_pair_off[b0] + tg_opaque(lane); pp < P.b_pair_off[b1]; pp += TEAM) {
+                    const int x = P.pair_a[pp], y = P.pair_b[pp], kx = P.it_cfg[x], ky = P.it_cfg[y], b = P.it_body[x];
                     const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
                     const int lo = x < y ? x : y, hi = x < y ? y : x;
                     const double *Jx = S + P.o_J + 6 * x, *Jy = S + P.o_J + 6 * y, *Wx = S + P.o_W + 6 * x, *Wy = S + P.o_W + 6 * y;
@@ -3187,7 +3189,8 @@ struct Core {
                     const double q_ = c8 * Q, dx = 0.25 * Dx, dy = 0.25 * Dy, eo = c2 * Eo, dO = 0.25 * DO, ey = c2 * Ey, ex = c2 * Ex;
                     const double h11 = q_ - dx - dy + eo + dO - ey - ex, h12 = q_ - dx + dy - eo + dO - ey + ex, h22 = q_ + dx + dy + eo + dO + ey + ex;
                     lds_add(&H12[kx * hl + ky], h12);
-                    if (x <= y) { lds_add(&H11[sym(kx, ky)], h11); lds_add(&H22[sym(kx, ky)], h22); }   // (y, x) gives the same value
+                    if (x != y) lds_add(&H12[ky * hl + kx], q_ + dx - dy - eo + dO + ey - ex);          // the pair (y, x): dx <-> dy, ex <-> ey
+                    lds_add(&H11[sym(kx, ky)], h11); lds_add(&H22[sym(kx, ky)], h22);
                 }
                 TG_SYNC();
             }
