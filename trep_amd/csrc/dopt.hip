@@ -34,7 +34,10 @@ using tg_detail::fail;
     } while (0)
 
 constexpr int LQ_T = 256;  // threads per workgroup of the sweep kernels
-constexpr int LQM_T = 512; // ... of the matrix-core sweep: two wavefronts per SIMD hide the 200-cycle latency of a dependent f64 MFMA
+#if !defined(LQM_THREADS)
+#define LQM_THREADS 512
+#endif
+constexpr int LQM_T = LQM_THREADS; // ... of the matrix-core sweep: two wavefronts per SIMD hide the 200-cycle latency of a dependent f64 MFMA
 
 // Diagnostic build only (-DTG_PROFILE): cycles per phase of the LQ sweep, workgroup 0 thread 0, read by tg_lq_profile.
 #if defined(TG_PROFILE)
@@ -491,7 +494,7 @@ struct LqLayout {   // LDS layout of k_tv_lq_mfma in doubles
         Kp = o; o += nUp * ldx;
         Ks = o; o += (nUp * ldx > ldx * nUp ? nUp * ldx : ldx * nUp);   // K_k [nUp][ldx]; before the solve: P B [ldx][nUp]
         G = o; o += nU * ldw; bv = o; o += ldx; bn = o; o += ldx; wv = o; o += nUp; rv = o; o += nUp;
-        scr = o; o += 8 * 3 * 32;
+        scr = o; o += nU > 32 ? (LQM_T / 64) * 3 * round_up(nU, 4) : 0;     // scratch of lq_gj_wave (more than 32 inputs) only
         total = o;
     }
 };
@@ -653,7 +656,7 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
 #if defined(TG_LQ_COLUMN_SOLVE)
             lq_gj_wave<NR>(G, ldw, nU, lo, n, Ks, ldx, wv, scr, lane, &s_sing);
 #else
-            if (NR <= 32) lq_gj_rows<NR, 2 * NT + 1>(G, ldw, nU, lo, n, Ks, ldx, wv, lane, &s_sing);
+            if (NR <= 32) lq_gj_rows<NR, (16 * NT + 1 + NW - 1) / NW>(G, ldw, nU, lo, n, Ks, ldx, wv, lane, &s_sing);
             else lq_gj_wave<NR>(G, ldw, nU, lo, n, Ks, ldx, wv, scr, lane, &s_sing);
 #endif
         }
