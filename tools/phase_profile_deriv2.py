@@ -21,7 +21,10 @@ L = _lib.lib()
 out = (ctypes.c_int64 * 16)()
 L.tg_batch_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 _lib.check(L.tg_batch_profile(mvi._h, out))
-v = np.array(list(out)[:4], dtype=float)
+v = np.array(list(out)[:12], dtype=float)
 print("B=%d  kernel %.2f ms (%.0f /s); cycles of trajectory 0 after the deriv1 solve: %.3e" % (B, ms, B / ms * 1e3, v.sum()))
-for n_, c in zip(["constraint terms (sweeps q1,q2 + DDDh, DDh)", "midpoint evaluation", "third-order body triples", "HZ assembly + store"], v):
+NAMES = ["constraints: H22 pairs (DDh at q2)", "midpoint evaluation", "third-order body triples", "HZ assembly + store",
+         "constraints: seed, w = Kinv' r, sweep q1 + attach", "constraints: prefix / suffix sums along the paths", "constraints: H11 pairs (w-contracted DDDh)",
+         "constraints: G1", "constraints: sweep q2 + attach"]
+for n_, c in zip(NAMES, v):
     print("  %-46s %12.0f  %5.1f%%" % (n_, c, 100 * c / v.sum()))

@@ -27,15 +27,33 @@
 // Phase boundary.  Lanes of a team exchange data through LDS only, so the fence is restricted to the LDS address
 // space: a plain __syncthreads() also waits for every outstanding GLOBAL store (s_waitcnt vmcnt(0)), which puts
 // the HBM write latency of the result rows on the critical path of the next phase.
+// Helper waves (-DTG_HELPER_WAVES=n, system-specialised builds of full-wave teams): the second-derivative kernel runs n wavefronts per
+// trajectory.  Wave 0 owns every wave-scoped phase (sweeps, register solvers, DPP searches); the flat pair / tile loops -- which
+// only read LDS tables and accumulate with LDS atomics -- are shared by all n waves (TG_FORW) between workgroup barriers (TG_WSYNC).
+// A phase boundary INSIDE wave 0's part must then not be a workgroup barrier: TG_SYNC becomes a wave-local fence (in a one-wave
+// workgroup that is all s_barrier ever was).
 #if defined(__HIP_DEVICE_COMPILE__)
-#define TG_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
+#define TG_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
+#if defined(TG_HELPER_WAVES)
+#define TG_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_wave_barrier(); \
                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
 #else
+#define TG_SYNC() TG_WSYNC()
+#endif
+#else
 #define TG_SYNC() ((void)0)
+#define TG_WSYNC() ((void)0)
 #endif
 #else
 #define TG_HD inline
 #define TG_SYNC() ((void)0)
+#define TG_WSYNC() ((void)0)
+#endif
+#if defined(TG_HELPER_WAVES)
+constexpr int TG_NW = TG_HELPER_WAVES;
+#else
+constexpr int TG_NW = 1;
 #endif
 
 #if defined(__HIPCC__)
@@ -66,6 +84,8 @@ __device__ __forceinline__ int tg_opaque(int x) { asm volatile("" : "+v"(x)); re
 inline int tg_opaque(int x) { return x; }
 #endif
 #define TG_FOR(idx, n) for (int idx = tg_opaque(lane); idx < (n); idx += TEAM)
+// the same over all the waves of a trajectory (helper-wave kernels; `wave` is 0 and `nw` 1 everywhere else)
+#define TG_FORW(idx, n) for (int idx = tg_opaque(lane + TEAM * wave); idx < (n); idx += TEAM * nw)
 
 #if defined(__HIPCC__)
 // ROCm device-library wavefront reduction (DPP based); declared in hip/amd_detail only behind an opt-in macro
@@ -318,6 +338,12 @@ struct Core {
     long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long prof_last = 0;
 
+    int wave = 0, nw = 1;   // helper-wave kernels: index of this wavefront within the trajectory's workgroup, number of waves (uniform)
+    // this wave's part [lo, hi) of a two-part pair list (program.hpp, wp_* / wt_* / wcp4): the parts never meet at a table entry
+    TG_HD void wave_part(int first, int split, int last, int &lo, int &hi) const {
+        lo = first; hi = last;
+        if (nw > 1) { lo = wave ? split : first; hi = wave ? last : split; }
+    }
     TG_HD Core(PROG &p, double *s, int l, double dt_) : P(p), S(s), lane(l), dt(dt_), oGc(p.o_G) {}
 
     // Phase loop over n independent items, two per lane and trip: compute(i) only READS and returns its results,
@@ -1895,7 +1921,7 @@ struct Core {
                     }
                 }
         }
-        __syncthreads();
+        TG_SYNC();
         return ok;
     }
 #endif
@@ -2000,28 +2026,37 @@ struct Core {
     TG_HD void constraint_hessian_rhs(bool on, double *AUG, int ld) {
         const int nd = P.nd, nf = P.nf;
         // one lane per (constraint, a <= b) pair of the flat list (second derivatives are symmetric); several
-        // constraints reach the same entry, hence LDS atomics (one wavefront: deterministic order)
-        if (on) TG_FOR(pp, P.n_cpair) {
-            const int *pw = P.cpair4 + 4 * (size_t)pp;
+        // constraints reach the same entry, hence LDS atomics (one wavefront: deterministic order; helper waves take the two
+        // parts of the list that never meet at an entry)
+        int p_lo, p_hi;
+        wave_part(0, P.wc_split, P.n_cpair, p_lo, p_hi);
+        const int *cp4 = nw > 1 ? P.wcp4 : P.cpair4;
+        if (on) for (int pp = p_lo + tg_opaque(lane); pp < p_hi; pp += TEAM) {
+            const int *pw = cp4 + 4 * (size_t)pp;
             const int c = pw[0], na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
             const double h = S[P.o_lam + c] * con_d2(c, na, nb);
             if (kb < nd) lds_add(&AUG[kb * ld + nf + ka], h);
             if (na != nb && ka < nd) lds_add(&AUG[ka * ld + nf + kb], h);
         }
-        TG_SYNC();
+        TG_WSYNC();
     }
 
-    // builds and solves the augmented KKT system; `extra` appends nc unit columns e_{nd+c}
+    // builds and solves the augmented KKT system; `extra` appends nc unit columns e_{nd+c}.  Helper-wave kernels: called by every
+    // wave of the trajectory; the sweeps, the constant blocks and the solve are wave 0's, the (constraint, a <= b) and (item, item)
+    // pair loops are shared, the last helper wave clears the tables while wave 0 sweeps; every wave returns the solve's verdict.
     TG_HD bool deriv1_solve(bool on, bool extra) {
+        const bool w0 = wave == 0;
         const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nf = P.nf;
         const int ld = P.d_aug_ld, R = P.d_nrhs;
         double *AUG = S + P.d_o_AUG, *T12 = S + P.d_o_T12, *T22 = S + P.d_o_T22;
         double *Dh1 = S + P.d_o_Dh1, *Dh2 = S + P.d_o_Dh2;
         const int c_q1 = nf, c_p1 = nf + nq, c_u1 = nf + nq + nd, c_k2 = nf + nq + nd + nu;
         if (on) {
-            TG_FOR(i, nf * ld) AUG[i] = 0.0;
-            TG_FOR(i, nq * nd) { T12[i] = 0.0; T22[i] = 0.0; }
-            TG_FOR(i, nc * nq) { Dh1[i] = 0.0; Dh2[i] = 0.0; }
+            if (wave == nw - 1) {
+                TG_FOR(i, nf * ld) AUG[i] = 0.0;
+                TG_FOR(i, nq * nd) { T12[i] = 0.0; T22[i] = 0.0; }
+            }
+            if (w0) TG_FOR(i, nc * nq) { Dh1[i] = 0.0; Dh2[i] = 0.0; }
         }
         TG_SYNC();
         // constraints at q1: Jacobian (held in the KKT matrix) and lambda-weighted Hessian
@@ -2029,31 +2064,41 @@ struct Core {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_DUAL_SWEEP) && defined(TG_GJ_PANEL_DEFAULT)
             // (system-specialised kernels only: with the schedule interpreted at run time the fused sweep is 5 % slower here)
             if (dual_ok()) {      // the q1 and the q2 poses in one fused sweep (second set in the W area, dead until the midpoint evaluation)
-                dsA = 1; dsB = 2;
-                pose_sweep_dual(on);
-                dsA = 0;
-                attach_points(on, false, true);
-                constraints(on, 1, false, Dh1, nq);
+                if (w0) {
+                    dsA = 1; dsB = 2;
+                    pose_sweep_dual(on);
+                    dsA = 0;
+                    attach_points(on, false, true);
+                    constraints(on, 1, false, Dh1, nq);
+                }
+                TG_WSYNC();
                 constraint_hessian_rhs(on, AUG, ld);
-                oGc = P.o_W;
-                attach_points(on, false, true);
-                constraints(on, 2, false, Dh2, nq);
-                oGc = P.o_G;
+                if (w0) {
+                    oGc = P.o_W;
+                    attach_points(on, false, true);
+                    constraints(on, 2, false, Dh2, nq);
+                    oGc = P.o_G;
+                }
             } else
 #endif
             {
-            pose_sweep(on, 1);
-            attach_points(on, false, true);
-            constraints(on, 1, false, Dh1, nq);
-            constraint_hessian_rhs(on, AUG, ld);
-            pose_sweep(on, 2);
-            attach_points(on, false, true);
-            constraints(on, 2, false, Dh2, nq);
+            if (w0) {
+                pose_sweep(on, 1);
+                attach_points(on, false, true);
+                constraints(on, 1, false, Dh1, nq);
             }
-        }
-        eval_midpoint(on);
+            TG_WSYNC();
+            constraint_hessian_rhs(on, AUG, ld);
+            if (w0) {
+                pose_sweep(on, 2);
+                attach_points(on, false, true);
+                constraints(on, 2, false, Dh2, nq);
+            }
+            }
+        } else TG_WSYNC();   // (the cleared tables)
+        if (w0) eval_midpoint(on);
         // constant blocks: forces (damping.c:21-27, configforce.c:27-33), -Dh1T, Dh2, unit p1 columns, k2 constraint rows
-        if (on) {
+        if (on && w0) {
             TG_FOR(o, nd) {
                 AUG[o * ld + o] -= P.damp[o];              // D2D1L2_D2fm2: + dF_o/d(dq_o)
                 AUG[o * ld + c_q1 + o] -= P.damp[o];       // -(D1D1L2_D1fm2): -( - dF_o/d(dq_o) )
@@ -2072,7 +2117,7 @@ struct Core {
                 if (extra) AUG[(nd + c) * ld + nf + R + c] = 1.0;
             }
         }
-        TG_SYNC();
+        TG_WSYNC();
         // second-order discrete-Lagrangian tables from the (item,item) pairs (calc_deriv1_cache :749-861):
         //   a = dt/4 L_qq, b = L_dqdq/dt, c(r,o) = 1/2 L(dq_r, q_o);  D1D1 = a+b-c-cT, D2D1 = a-b+c-cT,
         //   D1D2 = a-b-c+cT, D2D2 = a+b+c+cT.
@@ -2087,8 +2132,11 @@ struct Core {
 #endif
         for (int b = 0; b < (flat ? 1 : P.n_bodies); b++) {
             const int p0 = flat ? 0 : P.b_pair_off[b], np = flat ? P.n_pairs : P.b_pair_off[b + 1] - p0;
-            if (on) TG_FOR(pp, np) {
-                const int ia = P.pair_a[p0 + pp], ib = P.pair_b[p0 + pp];
+            int p_lo = 0, p_hi = np;
+            if (flat) wave_part(0, P.wp_split, np, p_lo, p_hi);
+            const int *pa = flat && nw > 1 ? P.wp_a : P.pair_a + p0, *pb = flat && nw > 1 ? P.wp_b : P.pair_b + p0;
+            if (on && (flat || w0)) for (int pp = p_lo + tg_opaque(lane); pp < p_hi; pp += TEAM) {
+                const int ia = pa[pp], ib = pb[pp];
                 const int ca = P.it_cfg[ia], cb = P.it_cfg[ib];
                 if (ca >= nd && cb >= nd) continue;
                 const int bb = flat ? P.it_body[ia] : b;
@@ -2128,8 +2176,24 @@ struct Core {
                 add(ca, cb, c_ab, c_ba);
                 if (ia != ib) add(cb, ca, c_ba, c_ab);
             }
-            TG_SYNC();
+            TG_WSYNC();
         }
+        bool ok = false;
+        if (w0) ok = kkt_rest(on, extra);
+        if (nw > 1) {     // (the matrix part of the image is dead after the solve)
+            if (w0 && lane == 0) AUG[0] = ok ? 1.0 : 0.0;
+            TG_WSYNC();
+            ok = AUG[0] != 0.0;
+        }
+        return ok;
+    }
+    // remaining force terms and the solve (one wave)
+    TG_HD bool kkt_rest(bool on, bool extra) {
+        const int nq = P.nq, nd = P.nd, nu = P.nu, nc = P.nc, nf = P.nf;
+        const int ld = P.d_aug_ld, R = P.d_nrhs;
+        double *AUG = S + P.d_o_AUG, *T12 = S + P.d_o_T12, *T22 = S + P.d_o_T22;
+        const int c_q1 = nf, c_u1 = nf + nq + nd, c_k2 = nf + nq + nd + nu;
+        const double qdt = 0.25 * dt;
         if (n_wrenches()) {   // D1 fm2 = D2 fm2 = dt/2 F_dq into the q1 columns and M2 / the k2 columns; D3 fm2 = dt F_du
             if (on && lane == 0) {
                 const int m0 = P.n_dh + n_sdh(), p0 = P.n_cpair + n_spair(), c0 = nc + n_springs();
@@ -2228,11 +2292,12 @@ struct Core {
         const int ld = P.d_aug_ld, R = P.d_nrhs;
         double *AUG = S + P.d_o_AUG, *T12 = S + P.d_o_T12, *T22 = S + P.d_o_T22;
         const bool ok = deriv1_solve(on, false);
+        const bool w0 = wave == 0;
         TG_STAMP(11);     // everything since the pair loop: the KKT solve
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
         struct ProfDump { Core &c; CArgs &A; size_t t; int lane;
             __device__ ~ProfDump() { long long t_ = (long long)__builtin_amdgcn_s_memtime(); c.prof[13] += t_ - c.prof_last;
-                          if (A.prof_out && t == 0 && lane == 0) for (int i = 0; i < 16; i++) A.prof_out[i] = c.prof[i]; } } dump_{*this, A, t, lane};
+                          if (A.prof_out && t == 0 && lane == 0 && c.wave == 0) for (int i = 0; i < 16; i++) A.prof_out[i] = c.prof[i]; } } dump_{*this, A, t, lane};
 #endif
         if (A.A_out) {
             // linearisation of the DSystem state map X_{k+1} = f(X_k, U_k), X = [Q; p; v], U = [u; rho]
@@ -2259,7 +2324,7 @@ struct Core {
                         i = kind == 0 ? sv : (kind == 3 ? sv - nqd - nu : 0);
                         return sv;
                     };
-                    for (int TR = 0; 16 * TR < nd; TR++) {
+                    for (int TR = wave; 16 * TR < nd; TR += nw) {     // (helper waves: a tile row each)
                         double av[8];
 #pragma unroll
                         for (int ks = 0; ks < 8; ks++) {
@@ -2319,7 +2384,7 @@ struct Core {
                 // p2 derivative = T12 / T22 row + T22' x: OB output rows per pass share the loads of x and run as OB independent
                 // accumulation chains (a single chain is nd dependent fp64 FMAs at ~30 cycles each)
                 constexpr int OB = 8;
-                if (!rows_done) for (int o0 = 0; o0 < nd; o0 += OB) TG_FOR(vv, nX + nU) {
+                if (!rows_done && w0) for (int o0 = 0; o0 < nd; o0 += OB) TG_FOR(vv, nX + nU) {
                     double x[OB], p[OB];
 #pragma unroll
                     for (int j = 0; j < OB; j++) { x[j] = NAN; p[j] = NAN; }
@@ -2354,7 +2419,7 @@ struct Core {
                     }
                 }
                 const double rdt = 1.0 / dt;
-                for (int i = 0; i < nk; i++) TG_FOR(vv, nX + nU) {        // Qk_{k+1} = rho_k, v_{k+1} = (rho_k - Qk_k)/dt
+                for (int i = wave; i < nk; i += nw) TG_FOR(vv, nX + nU) {        // Qk_{k+1} = rho_k, v_{k+1} = (rho_k - Qk_k)/dt
                     if (vv < nX) { Ao[(size_t)(nd + i) * nX + vv] = 0.0; Ao[(size_t)(nqd + i) * nX + vv] = vv == nd + i ? -rdt : 0.0; }
                     else {
                         const bool hit = vv - nX == nu + i;
@@ -2366,7 +2431,7 @@ struct Core {
             return;
         }
         // outputs in the reference layout [derivative variable][output] (trep.h:425-437)
-        if (on) {
+        if (on && w0) {
             const int cwl = tile_log2<TEAM>(nd), cw = 1 << cwl, rstep = TEAM >> cwl;
             for (int vv = lane >> cwl; vv < R; vv += rstep) {
                 int kind, i;
@@ -2859,14 +2924,17 @@ struct Core {
         double *H11 = S + P.e_o_H11, *H12 = S + P.e_o_H12, *H22 = S + P.e_o_H22, *G1 = S + P.e_o_G1;
         double *w = S + P.e_o_w, *zq = S + P.e_o_zq, *zp = S + P.e_o_zp, *vec = S + P.e_o_vec;
         const int c_p1 = nf + nq, c_ex = nf + R;
-        const bool ok = deriv1_solve(on, true);
+        // helper waves (nw > 1): everything wave-scoped is wave 0's; the other waves join the flat pair loops and the HZ tiles
+        const bool w0 = wave == 0;
+        bool ok = deriv1_solve(on, true);
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-        long long d2t[6] = {0, 0, 0, 0, 0, 0};
+        long long d2t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         long long d2last = (long long)__builtin_amdgcn_s_memtime();
 #define TG_D2STAMP(i) do { long long t_ = (long long)__builtin_amdgcn_s_memtime(); d2t[i] += t_ - d2last; d2last = t_; } while (0)
 #else
 #define TG_D2STAMP(i) ((void)0)
 #endif
+        if (w0) {
         if (on) {
             TG_FOR(i, nq * nc) G1[i] = 0.0;
             TG_FOR(i, nd) { zq[i] = A.z[t * P.nX + i]; zp[i] = A.z[t * P.nX + nq + i]; }
@@ -2896,10 +2964,17 @@ struct Core {
             w[j] = acc;
         }
         TG_SYNC();
+        }
         // ---- constraints at q1: G1 and the lambda-weighted third derivative (calc_h1_deriv2 :1559-1595) -----
+        int cp_lo, cp_hi;
+        wave_part(0, P.wc_split, P.n_cpair, cp_lo, cp_hi);
+        const int *cp4 = nw > 1 ? P.wcp4 : P.cpair4;
         if (nc) {
-            pose_sweep(on, 1);
-            attach_points(on, false, true);
+            if (w0) {
+                pose_sweep(on, 1);
+                attach_points(on, false, true);
+            }
+            TG_D2STAMP(4);
             if (P.o_cps >= 0) {
                 // The sums over the output index o are pushed into prefix / suffix sums along each end point's joint
                 // path, which makes the w-contracted third derivative of a constraint O(1) per (a, b) pair instead
@@ -2920,7 +2995,7 @@ struct Core {
                 auto cross = [](const double *a, const double *b, double *r) {
                     r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0];
                 };
-                if (on) TG_FOR(ce, 2 * nc) {
+                if (w0 && on) TG_FOR(ce, 2 * nc) {
                     const int t0 = P.cpath_off[ce], t1 = P.cpath_off[ce + 1], E = ce & 1;
                     double pw[3] = {0, 0, 0}, sd[3] = {0, 0, 0}, D[3], Om[3], wt;
                     for (int t = t0; t < t1; t++) {
@@ -2936,7 +3011,8 @@ struct Core {
                     double *vw = cps + 6 * P.n_cpath + 3 * ce;       // sum_o w_o D_o over the whole path
                     vw[0] = sd[0]; vw[1] = sd[1]; vw[2] = sd[2];
                 }
-                TG_SYNC();
+                TG_WSYNC();
+                TG_D2STAMP(5);
                 // per dh item a: v_a, V2w_a (differences end point 1 - end point 2); returns false if a has no joint
                 auto first_second = [&](int c, int n, double *va, double *V2) {
                     va[0] = va[1] = va[2] = V2[0] = V2[1] = V2[2] = 0.0;
@@ -2951,8 +3027,8 @@ struct Core {
                         for (int m = 0; m < 3; m++) { va[m] += sg * D[m]; V2[m] += sg * (x1[m] + x2[m]); }
                     }
                 };
-                if (on) TG_FOR(pp, P.n_cpair) {
-                    const int *pw4 = P.cpair4 + 4 * (size_t)pp;
+                if (on) for (int pp = cp_lo + tg_opaque(lane); pp < cp_hi; pp += TEAM) {
+                    const int *pw4 = cp4 + 4 * (size_t)pp;
                     const int c = pw4[0], na = pw4[1], nb = pw4[2], ka = pw4[3] & 0xFFFF, kb = pw4[3] >> 16;
                     const int *rc = P.dh_pack + 8 * (size_t)na;
                     const int type = (rc[3] >> 16) & 0xFF, comp = rc[3] >> 24;
@@ -2988,7 +3064,8 @@ struct Core {
                     }
                     lds_add(&H11[sym(ka, kb)], S[P.o_lam + c] * acc);
                 }
-                if (on) TG_FOR(na, P.n_dh) {  // G1[ka][c] = sum_o w_o h_c,dqdq(ka, o) = 2 (v_a . Vw + d . V2w_a)
+                TG_D2STAMP(6);
+                if (on) TG_FORW(na, P.n_dh) {  // G1[ka][c] = sum_o w_o h_c,dqdq(ka, o) = 2 (v_a . Vw + d . V2w_a)
                     const int *rc = P.dh_pack + 8 * (size_t)na;
                     const int c = rc[0], type = (rc[3] >> 16) & 0xFF, comp = rc[3] >> 24;
                     double va[3], V2a[3], Vw[3];
@@ -3003,12 +3080,14 @@ struct Core {
                     }
                     G1[rc[1] * nc + c] = g;
                 }
-                TG_SYNC();
+                TG_WSYNC();
+                TG_D2STAMP(7);
             } else {
             // one lane per (constraint, a <= b) pair of the flat list; third derivatives are symmetric in (a, b).
                 // Several constraints reach the same entry: LDS atomics (one wavefront, fixed order, deterministic).
-                if (on) TG_FOR(pp, P.n_cpair) {
-                    const int *pw = P.cpair4 + 4 * (size_t)pp;
+                TG_WSYNC();
+                if (on) for (int pp = cp_lo + tg_opaque(lane); pp < cp_hi; pp += TEAM) {
+                    const int *pw = cp4 + 4 * (size_t)pp;
                     const int c = pw[0], na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
                     const int n0 = P.cu_off[c], n1 = P.cu_off[c + 1];
                     double acc = 0.0;
@@ -3020,7 +3099,7 @@ struct Core {
                     const double val = S[P.o_lam + c] * acc;
                     lds_add(&H11[sym(ka, kb)], val);
                 }
-                if (on) TG_FOR(na, P.n_dh) {  // G1[ka][c] = sum_o w_o h_c,dqdq(ka, o)
+                if (on) TG_FORW(na, P.n_dh) {  // G1[ka][c] = sum_o w_o h_c,dqdq(ka, o)
                     const int c = P.dh_c[na], n0 = P.cu_off[c], n1 = P.cu_off[c + 1];
                     double g = 0.0;
                     for (int no = n0; no < n1; no++) {
@@ -3029,20 +3108,25 @@ struct Core {
                     }
                     G1[P.dh_cfg[na] * nc + c] = g;
                 }
-                TG_SYNC();
+                TG_WSYNC();
             }
             // ---- constraints at q2: H22 -= sum_c w_lambda,c DDh2[c] (calc_h2_deriv2 :1597-1622) -------------
-            pose_sweep(on, 2);
-            attach_points(on, false, true);
-            if (on) TG_FOR(pp, P.n_cpair) {
-                const int *pw = P.cpair4 + 4 * (size_t)pp;
+            if (w0) {
+                pose_sweep(on, 2);
+                attach_points(on, false, true);
+            }
+            TG_WSYNC();
+            TG_D2STAMP(8);
+            if (on) for (int pp = cp_lo + tg_opaque(lane); pp < cp_hi; pp += TEAM) {
+                const int *pw = cp4 + 4 * (size_t)pp;
                 const int c = pw[0], na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
                 const double val = -w[nd + c] * con_d2(c, na, nb);
                 lds_add(&H22[sym(ka, kb)], val);
             }
-            TG_SYNC();
+            TG_WSYNC();     // (the midpoint sweep below overwrites the poses the pair loop reads)
         }
         TG_D2STAMP(0);
+        if (w0) {
         // ---- midpoint: third-order discrete-Lagrangian tables contracted on the fly --------------------------
         if (n_wrenches()) {   // the point forces' second derivatives are contracted while the midpoint poses are alive
             if (on) TG_FOR(i, nq * nu) S[P.e_o_Hu + i] = 0.0;
@@ -3076,7 +3160,8 @@ struct Core {
             lds_add(&H11[sym(i, i)], val);
             lds_add(&H22[sym(i, i)], val);
         }
-        TG_SYNC();
+        }
+        TG_WSYNC();
         TG_D2STAMP(1);
         const double c8 = 0.125 * dt, c2 = 0.5 / dt;
         if (P.n_tchunk > 0) {
@@ -3093,7 +3178,7 @@ struct Core {
             for (int ci = 0; ci < P.n_tchunk; ci++) {
                 const int b0 = P.tchunk[ci], b1 = P.tchunk[ci + 1];
                 const int it0 = P.b_item_off[b0], nit = P.b_item_off[b1] - it0;
-                if (on) TG_FOR(idx, 6 * (b1 - b0)) {
+                if (on) TG_FORW(idx, 6 * (b1 - b0)) {
                     const int b = b0 + idx / 6, m = idx % 6;
                     const int first = P.b_item_off[b], last = P.b_item_off[b + 1];
                     double pwa = 0.0, pjb = 0.0, sja = 0.0;
@@ -3113,12 +3198,15 @@ struct Core {
                     double *tb = tps + 18 * nit + 18 * (b - b0);
                     tb[m] = pwa; tb[6 + m] = sja; tb[12 + m] = pjb;      // TWa, TJa, TJb
                 }
-                TG_SYNC();
+                TG_WSYNC();
                 // one lane per UNORDERED pair x <= y (the flat (item, item) list of the first-derivative tables): every ingredient below is
                 // either symmetric under x <-> y (q, eo, dO) or swaps with its partner (dx <-> dy, ex <-> ey), so the pair (y, x) of the
                 // H12 table comes out of the same evaluation -- half the lanes' work of the ordered list (tri4) used until round 2
-                if (on) for (int pp = P.b_pair_off[b0] + tg_opaque(lane); pp < P.b_pair_off[b1]; pp += TEAM) {
-                    const int x = P.pair_a[pp], y = P.pair_b[pp], kx = P.it_cfg[x], ky = P.it_cfg[y], b = P.it_body[x];
+                int tp_lo, tp_hi;
+                wave_part(P.b_pair_off[b0], nw > 1 ? P.wt_split[ci] : 0, P.b_pair_off[b1], tp_lo, tp_hi);
+                const int *ta = nw > 1 ? P.wt_a : P.pair_a, *tb_ = nw > 1 ? P.wt_b : P.pair_b;
+                if (on) for (int pp = tp_lo + tg_opaque(lane); pp < tp_hi; pp += TEAM) {
+                    const int x = ta[pp], y = tb_[pp], kx = P.it_cfg[x], ky = P.it_cfg[y], b = P.it_body[x];
                     const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
                     const int lo = x < y ? x : y, hi = x < y ? y : x;
                     const double *Jx = S + P.o_J + 6 * x, *Jy = S + P.o_J + 6 * y, *Wx = S + P.o_W + 6 * x, *Wy = S + P.o_W + 6 * y;
@@ -3192,12 +3280,12 @@ struct Core {
                     if (x != y) lds_add(&H12[ky * hl + kx], q_ + dx - dy - eo + dO + ey - ex);          // the pair (y, x): dx <-> dy, ex <-> ey
                     lds_add(&H11[sym(kx, ky)], h11); lds_add(&H22[sym(kx, ky)], h22);
                 }
-                TG_SYNC();
+                TG_WSYNC();
             }
         } else {
             // one lane per ordered (item x, item y) pair of the flat list over all bodies; the output index o runs over the
             // body's items.  Bodies share configs, so the accumulation uses LDS atomics like the Newton matrix.
-            if (on) TG_FOR(pp, P.n_tri) {
+            if (on && w0) TG_FOR(pp, P.n_tri) {     // (fallback: one wave)
                 const int *pw = P.tri4 + 4 * (size_t)pp;
                 const int x = pw[0], y = pw[1], kx = pw[2] & 0xFFFF, ky = pw[2] >> 16, b = pw[3];
                 const int i0 = P.b_item_off[b], i1 = P.b_item_off[b + 1];
@@ -3219,7 +3307,7 @@ struct Core {
                 lds_add(&H12[kx * hl + ky], h12);
                 if (x <= y) { lds_add(&H11[sym(kx, ky)], h11); lds_add(&H22[sym(kx, ky)], h22); }   // (y, x) gives the same value
             }
-            TG_SYNC();
+            TG_WSYNC();
         }
         TG_D2STAMP(2);
         // ---- assemble HZ, CB columns per pass ------------------------------------------------------------------
@@ -3321,7 +3409,7 @@ struct Core {
             constexpr int GA = 3;
             const int l15 = lane & 15, l4 = lane >> 4;
             const int n_jt = (nq + 15) >> 4, n_at = (R + 15) >> 4, n_k = (nd + 3) >> 2, n_kc = (nc + 3) >> 2;
-            for (int b0 = 0; b0 < R; b0 += 16) {
+            for (int b0 = 16 * wave; b0 < R; b0 += 16 * nw) {      // blocks of 16 columns: one wave each, its own TB
                 const int bcol = b0 + l15;
                 const bool bin = bcol < R, bq = bcol < nq;
                 if (on) for (int jt0 = 0; jt0 < n_jt; jt0 += GA) {
@@ -3421,10 +3509,13 @@ struct Core {
                 TG_SYNC();
             }
         };
-        if (TEAM == 64 && 12 * P.n_items >= 16 * nq && P.o_W == P.o_J + 6 * P.n_items) assemble_mfma(S + P.o_J);
+        // staging tiles of the helper waves: the prefix-sum scratch of the body terms (dead pose area), 16 nq doubles each
+        const bool tb_fits = nw == 1 || (P.o_dqi + P.n_items) - P.o_tps >= (nw - 1) * 16 * nq;
+        if (TEAM == 64 && 12 * P.n_items >= 16 * nq && P.o_W == P.o_J + 6 * P.n_items && tb_fits) assemble_mfma(w0 ? S + P.o_J : S + P.o_tps + (wave - 1) * 16 * nq);
         else
 #endif
-        if (TEAM == 64 && 12 * P.n_items >= 24 * nq && P.o_W == P.o_J + 6 * P.n_items) assemble(IntTag<8>{}, S + P.o_J);
+        if (!w0) { }
+        else if (TEAM == 64 && 12 * P.n_items >= 24 * nq && P.o_W == P.o_J + 6 * P.n_items) assemble(IntTag<8>{}, S + P.o_J);
         else assemble(IntTag<4>{}, vec);
         if (n_wrenches() && nu > 0) {
             // input blocks of the point forces: D1D3fm2 = D2D3fm2 = dt/2 F_dudq (midpointvi.c:1500-1512) couple an input
@@ -3436,7 +3527,7 @@ struct Core {
 #endif
             const double *Hu = S + P.e_o_Hu;
             const int c_u = nq + nd;
-            if (on && ok) TG_FOR(idx, R * nu) {
+            if (on && ok && w0) TG_FOR(idx, R * nu) {
                 const int a = idx / nu, m = idx % nu;
                 double corr = 0.0;
                 for (int i = 0; i < nd; i++) corr += AUG[i * ld + nf + a] * Hu[i * nu + m];
@@ -3454,7 +3545,7 @@ struct Core {
         }
         TG_D2STAMP(3);
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-        if (A.prof_out && t == 0 && lane == 0) for (int i = 0; i < 6; i++) A.prof_out[i] = d2t[i];
+        if (A.prof_out && t == 0 && lane == 0 && w0) for (int i = 0; i < 12; i++) A.prof_out[i] = d2t[i];
 #endif
     }
 
@@ -3909,7 +4000,7 @@ struct Core {
 // PIVOT: -1 the pivot rule is read from the arguments at run time (generic kernels); 0 / 1 compile the single-precision ranking /
 // the reference's exact rule in alone (specialised kernels: the variant not asked for is not in the kernel's call graph at all)
 template <int TEAM, int MODE, bool SPRINGS = false, class PROG = CProg, class ARGS = CArgs, int PIVOT = -1>
-TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj) {
+TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int wave = 0, int nw = 1) {
     PROG &P = tg_fresh(P0);
     ARGS &A = A0;
     const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc;
@@ -3918,13 +4009,14 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj) {
     double dt = MODE == MODE_ROLLOUT ? A.dt : (A.t2 - A.t1);
     if (A.dt_steps && A.dt_period > 0) dt = A.dt_steps[t % (size_t)A.dt_period];   // per-trajectory step size (k-parallel linearisation)
     Core<TEAM, SPRINGS, PROG> core(P, S, lane, dt);
-    core.init_sweep_schedule();
+    core.wave = wave; core.nw = nw;
+    if (wave == 0) core.init_sweep_schedule();
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     core.prof_last = (long long)__builtin_amdgcn_s_memtime();
 #endif
 
     // ---- load state ----------------------------------------------------------------------------------
-    if (live) {
+    if (live && wave == 0) {
         TG_FOR(i, nq) { S[P.o_q1 + i] = A.q1[t * nq + i]; S[P.o_q2 + i] = A.q2[t * nq + i]; }
         TG_FOR(i, nd) S[P.o_p1 + i] = (MODE == MODE_ROLLOUT) ? A.p2[t * nd + i] : A.p1[t * nd + i];
         TG_FOR(i, nc) S[P.o_lam + i] = A.lam[t * nc + i];

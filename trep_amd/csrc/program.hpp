@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -70,6 +71,14 @@ struct DevProg {
     const int *tchunk, *tri_off;
     int n_tchunk, o_tps;
     int n_tri, n_cpair;
+    // helper-wave kernels (two wavefronts per trajectory, mvi_core.hpp): the same pair lists split in two parts that never
+    // accumulate into the same table entry -- every pair belongs to the part of its UNORDERED CONFIG PAIR, parts balanced,
+    // order inside a part as in the original list -- so that the two waves' LDS atomics never meet at an address and the
+    // sums keep a fixed order:  wp_a / wp_b [n_pairs] (all (item, item) pairs; part 0 = [0, wp_split)),  wt_a / wt_b
+    // [n_pairs] (the same per chunk of bodies: chunk ci occupies the range of pair_a, part 0 ends at wt_split[ci]),
+    // wcp4 [n_cpair * 4] (constraint pairs, part 0 = [0, wc_split)).
+    const int *wp_a, *wp_b, *wt_a, *wt_b, *wt_split, *wcp4;
+    int wp_split, wc_split;
     const int *cfg_item_off;  // [nq+1] CSR config -> items
     const int *cfg_items;     // [n_items]
     const int *it_slot;       // [n_items] position of the item in the config-sorted order (inverse of cfg_items)
@@ -124,6 +133,7 @@ struct HostProgram {
     std::vector<int> b_anchor;
     std::vector<double> b_C, b_inertia;
     std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4, tri4, cpair4, it_pack, dh_pack, cpath_off, cpath_items, dh_pos, tchunk, tri_off;
+    std::vector<int> wp_a, wp_b, wt_a, wt_b, wt_split, wcp4;
     std::vector<int> e_anchor;
     std::vector<double> e_off;
     std::vector<int> c_type, c_e1, c_e2, c_cfg, c_comp;
@@ -568,6 +578,41 @@ inline HostProgram build_program(const tg_system_desc *d) {
         if (!fits) { H.tchunk.clear(); H.tchunk.push_back(0); }
         P.n_tchunk = (int)H.tchunk.size() - 1;
     }
+    {   // two-part pair lists of the helper-wave kernels
+        // order[] = the indices first..last-1 rearranged as [part 0 | part 1]; returns the size of part 0
+        auto split = [](int first, int last, const std::function<long long(int)> &key, std::vector<int> &order) {
+            std::map<long long, std::vector<int>> groups;
+            for (int n = first; n < last; n++) groups[key(n)].push_back(n);
+            std::vector<const std::vector<int> *> by_size;
+            for (auto &g : groups) by_size.push_back(&g.second);
+            std::stable_sort(by_size.begin(), by_size.end(), [](const std::vector<int> *a, const std::vector<int> *b) { return a->size() > b->size(); });
+            std::vector<int> part[2];
+            for (auto *g : by_size) {
+                std::vector<int> &dst = part[part[0].size() <= part[1].size() ? 0 : 1];
+                dst.insert(dst.end(), g->begin(), g->end());
+            }
+            for (int h = 0; h < 2; h++) { std::sort(part[h].begin(), part[h].end()); order.insert(order.end(), part[h].begin(), part[h].end()); }
+            return (int)part[0].size();
+        };
+        auto cfg_key = [&](int n) {
+            const int a = H.it_cfg[H.pair_a[n]], b = H.it_cfg[H.pair_b[n]];
+            return (long long)std::min(a, b) * 65536 + std::max(a, b);
+        };
+        std::vector<int> order;
+        P.wp_split = split(0, (int)H.pair_a.size(), cfg_key, order);
+        for (int n : order) { H.wp_a.push_back(H.pair_a[n]); H.wp_b.push_back(H.pair_b[n]); }
+        for (int ci = 0; ci < P.n_tchunk; ci++) {
+            const int first = H.b_pair_off[H.tchunk[ci]], last = H.b_pair_off[H.tchunk[ci + 1]];
+            order.clear();
+            H.wt_split.push_back(first + split(first, last, cfg_key, order));
+            for (int n : order) { H.wt_a.push_back(H.pair_a[n]); H.wt_b.push_back(H.pair_b[n]); }
+        }
+        order.clear();
+        P.wc_split = split(0, n_cpair_con, [&](int n) {
+            const int a = H.cpair4[4 * n + 3] & 0xFFFF, b = H.cpair4[4 * n + 3] >> 16;
+            return (long long)std::min(a, b) * 65536 + std::max(a, b); }, order);
+        for (int n : order) for (int m = 0; m < 4; m++) H.wcp4.push_back(H.cpair4[4 * n + m]);
+    }
     P.o_cps = (!has_plane && 6 * P.n_cpath + 6 * nc <= (P.o_gam + 3 * nb) - P.o_J) ? P.o_J : -1;   // (plane constraints: generic path)
     //   // J, W, vB, gam are dead there (recomputed afterwards)   // prefix / suffix sums of the constraint paths + per-constraint sums
     {   // MODE_DYN_DERIV1 layout on top of the base region
@@ -614,7 +659,8 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(level_off) X(lvl_joints) X(round_off) X(ch_first) X(ch_len) X(ch_parent) X(j_parent) X(j_kind) X(j_cfg) X(j_pre_ident) X(b_anchor) X(b_item_off) X(b_pair_off) X(it_body) \
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
-    X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in) X(wr_kind) X(ncs_i)
+    X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in) X(wr_kind) X(ncs_i) \
+    X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4)
 #define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c) X(wr_Rloc) X(ncs_mb) X(ncs_tab)
 
 inline void HostProgram::pack() {

@@ -28,15 +28,20 @@ namespace {
 
 // PIVOT (rollouts): 0 single-precision pivot ranking, 1 the reference's exact pivot rule -- two kernels, so that neither carries
 // the other's solver (registers, callee-saved spills) in its call graph
+// wavefronts per workgroup: the derivative kernels of a full-wave team run with helper waves (mvi_core.hpp, TG_HELPER_WAVES)
+template <int MODE> constexpr int spec_waves() { return ((MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z) && SPEC_TEAM == 64) ? TG_NW : 1; }
+static_assert(TG_NW == 1 || SPEC_TEAM == 64, "helper waves are for full-wave teams (trep_amd/specialize.py passes TG_HELPER_WAVES only then)");
+
 template <int MODE, int PIVOT = 0>
-__global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z) ? 1 : 2) void k_spec(SPEC_KERNEL_ARGS) {
+__global__ __launch_bounds__(64 * spec_waves<MODE>(), (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z) ? 1 : 2) void k_spec(SPEC_KERNEL_ARGS) {
     SPEC_ARGS_REF;
 double *lds = tg_lds_base();
     const SpecProg P{};
-    const int team = threadIdx.x / SPEC_TEAM, lane = threadIdx.x % SPEC_TEAM;
+    const int wave = spec_waves<MODE>() > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0, tid = threadIdx.x & 63;
+    const int team = tid / SPEC_TEAM, lane = tid % SPEC_TEAM;
     const int traj = blockIdx.x * (64 / SPEC_TEAM) + team;
     constexpr int stride = MODE == tg::MODE_DERIV2Z ? SpecProg::e_lds_per_team : (MODE == tg::MODE_DERIV1 ? SpecProg::d_lds_per_team : SpecProg::lds_per_team);
-    tg::run_trajectory<SPEC_TEAM, MODE, SPEC_SPRINGS, const SpecProg, std::remove_reference<decltype(A)>::type, PIVOT>(P, A, lds + (size_t)team * stride, lane, traj);
+    tg::run_trajectory<SPEC_TEAM, MODE, SPEC_SPRINGS, const SpecProg, std::remove_reference<decltype(A)>::type, PIVOT>(P, A, lds + (size_t)team * stride, lane, traj, wave, spec_waves<MODE>());
 }
 
 template <int MODE, int PIVOT = 0>
@@ -49,9 +54,9 @@ int launch_mode(const tg::RunArgs *A, tg::RunArgs *slot, int grid, size_t lds, h
     // pair only after the event recorded behind this launch has completed
     if (!slot) return 3;
     if (hipMemcpyAsync(slot, A, sizeof(tg::RunArgs), hipMemcpyHostToDevice, stream) != hipSuccess) return 1;
-    hipLaunchKernelGGL((k_spec<MODE, PIVOT>), dim3(grid), dim3(64), lds, stream, (const tg::RunArgs *)slot);
+    hipLaunchKernelGGL((k_spec<MODE, PIVOT>), dim3(grid), dim3(64 * spec_waves<MODE>()), lds, stream, (const tg::RunArgs *)slot);
 #else
-    hipLaunchKernelGGL((k_spec<MODE, PIVOT>), dim3(grid), dim3(64), lds, stream, *A);
+    hipLaunchKernelGGL((k_spec<MODE, PIVOT>), dim3(grid), dim3(64 * spec_waves<MODE>()), lds, stream, *A);
 #endif
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }

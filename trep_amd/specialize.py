@@ -51,14 +51,20 @@ def header(system, with_key=False):
         L.tg_system_destroy(h)
 
 
-def _flags():
-    """Extra compiler flags of the specialised kernel (TREPAMD_SPEC_FLAGS overrides; part of the cache key)."""
-    return os.environ.get("TREPAMD_SPEC_FLAGS", DEFAULT_FLAGS).split()
+def _flags(text=""):
+    """Extra compiler flags of the specialised kernel (TREPAMD_SPEC_FLAGS overrides; part of the cache key).  A system whose
+    team is a full wavefront gets helper waves in its second-derivative kernel (mvi_core.hpp, TG_HELPER_WAVES;
+    TREPAMD_HELPER_WAVES=1 turns them off)."""
+    flags = os.environ.get("TREPAMD_SPEC_FLAGS", DEFAULT_FLAGS).split()
+    waves = int(os.environ.get("TREPAMD_HELPER_WAVES", "2"))
+    if waves > 1 and "#define SPEC_TEAM 64\n" in text and not any(f.startswith("-DTG_HELPER_WAVES") for f in flags):
+        flags.append("-DTG_HELPER_WAVES=%d" % waves)
+    return flags
 
 
 def _key(text):
     m = hashlib.sha256(text.encode())
-    m.update(" ".join(_flags()).encode())
+    m.update(" ".join(_flags(text)).encode())
     for f in _SOURCES + [os.path.join("..", "..", "include", "trep_amd.h")]:
         with open(os.path.join(_CSRC, f), "rb") as fh:
             m.update(fh.read())
@@ -85,7 +91,7 @@ def build(system, force=False, verbose=False):
         fh.write(text)
     tmp = path + mine
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-I", _CSRC, '-DTG_SPEC_HEADER="%s"' % (hdr + mine), "-DTG_SPEC_KEY=0x%016xull" % key] + _flags() + \
+           "-I", _CSRC, '-DTG_SPEC_HEADER="%s"' % (hdr + mine), "-DTG_SPEC_KEY=0x%016xull" % key] + _flags(text) + \
           ["-o", tmp, os.path.join(_CSRC, "spec_kernel.hip")]
     if verbose:
         print(" ".join(cmd))
