@@ -48,7 +48,7 @@ def problem(seeds, N, dt, device=0):
     return system, Xd, K_move, Xi, K_still, np.diag(wq), np.diag([0.1] * system.nQk)
 
 
-def measure(seeds, horizon, quasi=1, newton=1, comm=None, device=0, armijo_chunk=None, predictor="reference",
+def measure(seeds, horizon, quasi=1, newton=1, comm=None, device=0, armijo_chunk=None, predictor="reference", overlap="auto",
             stages=False):
     """Times `quasi` + `newton` batched DOptimizer steps of `seeds` puppet problems (sharded over the ranks of `comm`,
     a trep_amd.rccl.Communicator, if given) after one untimed warm-up step per method; returns the result dict (same on every
@@ -63,7 +63,8 @@ def measure(seeds, horizon, quasi=1, newton=1, comm=None, device=0, armijo_chunk
     Xd, Ud, Xi, Ui = Xd[lo:hi], Ud[lo:hi], Xi[lo:hi], Ui[lo:hi]
     S = hi - lo
     dsys = discopt.DSystem(trep_amd.MidpointVI(system, device=device), dt * np.arange(N + 1))
-    opt = discopt.BatchDOptimizer(dsys, Xd, Ud, Qc, Rc, device=device, armijo_chunk=armijo_chunk, predictor=predictor)
+    opt = discopt.BatchDOptimizer(dsys, Xd, Ud, Qc, Rc, device=device, armijo_chunk=armijo_chunk, predictor=predictor,
+                                  overlap_sweeps={"auto": "auto", "on": True, "off": False}[overlap])
     L = _lib.lib()
     methods = ["quasi"] * quasi + ["newton"] * newton
     opt.set_trajectories(Xi, Ui)
@@ -112,6 +113,8 @@ def measure(seeds, horizon, quasi=1, newton=1, comm=None, device=0, armijo_chunk
         timed("linearize (S*N DEL solves + deriv1 -> A,B)", opt.linearize)
         timed("projection gain (Riccati)", opt.projection_gain)
         timed("cost + gradients", opt.gradients_and_cost)
+        if opt.overlap:      # what a step really runs with S <= 128 seeds: the two independent sweeps on two streams
+            timed("projection gain || quasi LQ sweep + tangent rollout (side by side, replaces the two alone)", opt.projection_gain_and_quasi_direction)
         timed("newton curvature (adjoint + S*N deriv2z)", opt.newton_curvature, None)
         timed("LQ sweep + tangent rollout", lambda: (opt._lq(None, opt.Q, opt.Qf, opt.R, opt.HZ, True, opt.K, opt.C),
                                                       opt.descent_direction(None, "quasi")))
@@ -122,7 +125,7 @@ def measure(seeds, horizon, quasi=1, newton=1, comm=None, device=0, armijo_chunk
         "n_gpus": world, "dtype": "f64", "data": "synthetic", "scaling": "strong",
         "config": {"workload": "puppet-optimization.py problem, nX=80 nU=18, N=%d, %d seeds batched on the device (%d per GPU), %d quasi + %d newton steps each"
                                % (N, seeds, S, quasi, newton), "armijo_chunk": opt.M,
-                   "newton_initial_guess": predictor},
+                   "newton_initial_guess": predictor, "sweeps_side_by_side": bool(opt.overlap)},
         "seed_iterations_counted": good_iters, "elapsed_s": elapsed,
         "mean_final_cost_successful_seeds": float(np.mean(final_cost[final_ok])) if final_ok.any() else None,
         "s_per_batched_quasi_step": float(np.mean(per["quasi"])) if per["quasi"] else None,
@@ -144,7 +147,7 @@ def run_batched(args):
         comm = rccl.Communicator.from_env()
     device = comm.device if comm is not None else 0
     out = measure(args.seeds, args.horizon, args.quasi, args.newton, comm=comm, device=device,
-                  armijo_chunk=args.armijo_chunk, predictor=args.predictor, stages=args.stages)
+                  armijo_chunk=args.armijo_chunk, predictor=args.predictor, stages=args.stages, overlap=args.overlap)
     if comm is None or comm.rank == 0:
         print(json.dumps(out))
     if comm is not None:
@@ -192,6 +195,8 @@ def main():
     ap.add_argument("--newton", type=int, default=2)
     ap.add_argument("--armijo-chunk", type=int, default=None)
     ap.add_argument("--stages", action="store_true", help="also report per-stage times of one Newton step")
+    ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
+                    help="projection gain and quasi-Newton sweep side by side on two streams (auto: with <= 128 seeds per GPU)")
     ap.add_argument("--predictor", choices=["reference", "extrapolate"], default="reference",
                     help="Newton initial guess of the Armijo projections (default: the reference's)")
     ap.add_argument("--sequential", action="store_true")

@@ -414,6 +414,13 @@ int tg_armijo_candidates(int32_t device, int32_t n_problems, int32_t n_lambdas, 
 /* dst[dst_rows[i]] = src[src_rows[i]], rows of row_doubles doubles (NULL index = identity). */
 int tg_copy_rows(int32_t device, int32_t n_rows, uint64_t row_doubles, const int32_t *dst_rows_dev,
                  const int32_t *src_rows_dev, const double *src_dev, double *dst_dev);
+/* Stream lane of the calling thread for every discrete-optimisation launch above (tg_tv_lq ... tg_copy_rows): 0 = the
+ * device's default stream (initial state), 1 / 2 = two ordinary streams per device.  Streams created without flags order
+ * themselves against the default stream in both directions, so kernels launched on lanes 1 and 2 run side by side and
+ * anything launched after returning to lane 0 waits for both -- BatchDOptimizer runs the projection-gain sweep and the
+ * quasi-Newton LQ sweep of a step this way when the GPU has idle CUs (the reference runs them one after the other,
+ * doptimizer.py:462-480; the results do not depend on it). */
+int tg_dopt_use_stream(int32_t device, int32_t lane);
 int tg_device_synchronize(int32_t device);
 
 /* ---- multi-GPU: one process per GPU, batch sharded, one collective ----------------------

@@ -248,6 +248,45 @@ def test_batch_optimizer_matches_sequential_cart():
         opt.close()
 
 
+def test_side_by_side_sweeps_change_nothing():
+    """overlap_sweeps: projection gain and quasi-Newton sweep on two streams (default with few seeds) against one after the
+    other -- same kernels on the same inputs, so every number of every step is bit-equal, including a step in which some
+    seeds fall back from the Newton to the quasi-Newton direction (taken from the side-by-side sweep's buffers)."""
+    import trep_amd
+    from trep_amd import discopt
+    S = 5
+    g, system, Xd, Ud = _cart_problem(S)
+    dsys = discopt.DSystem(trep_amd.MidpointVI(system), g["t"])
+    X0 = np.repeat(g["X0"][None], S, axis=0)
+    U0 = np.repeat(g["U0"][None], S, axis=0)
+    trace = []
+    for overlap in (False, True):
+        opt = discopt.BatchDOptimizer(dsys, Xd, Ud, g["Q"], g["R"], armijo_chunk=2, overlap_sweeps=overlap)
+        assert opt.overlap == overlap
+        try:
+            opt.set_trajectories(X0, U0)
+            out = []
+            for m in ["quasi", "newton", ["newton", "quasi", "steepest", "newton", "quasi"]]:
+                r = opt.step(m)
+                out.append((r.cost0, r.dcost0, r.cost1, r.armijo, list(r.method)) + opt.get_trajectories())
+            # a Newton step whose model is forced indefinite for two seeds: they fall back to the quasi direction
+            real = opt.descent_direction
+            def sabotaged(seeds, method):
+                real(seeds, method)
+                if method == "newton":
+                    dc = opt.dcost.get(); dc[[1, 3]] = 1.0; opt.dcost.set(dc)
+            opt.descent_direction = sabotaged
+            r = opt.step("newton")
+            assert list(r.method) == ["newton", "quasi", "newton", "quasi", "newton"] and not r.failed.any()
+            out.append((r.cost0, r.dcost0, r.cost1, r.armijo, list(r.method)) + opt.get_trajectories())
+            trace.append(out)
+        finally:
+            opt.close()
+    for a, b in zip(*trace):
+        for x, y in zip(a, b):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
 def test_batch_optimizer_matches_sequential_puppet():
     import trep_amd
     from trep_amd import systems, discopt

@@ -110,6 +110,7 @@ _SIGNATURES = {
     "tg_armijo_candidates": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tg_copy_rows": (ctypes.c_int, [_i32, _i32, ctypes.c_uint64, _vp, _vp, _vp, _vp]),
     "tg_device_synchronize": (ctypes.c_int, [_i32]),
+    "tg_dopt_use_stream": (ctypes.c_int, [_i32, _i32]),
     # multi-GPU: RCCL all-gather / scalar reductions (csrc/comm.hip)
     "tg_comm_unique_id": (ctypes.c_int, [_vp]),
     "tg_comm_create": (_vp, [_i32, _i32, _i32, _vp]),

@@ -13,7 +13,10 @@
 // with the (blocking) streams of the tg_batch objects.
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <string>
 
 #include "../../include/trep_amd.h"
@@ -1112,6 +1115,25 @@ __global__ void k_copy_rows(int n, size_t width, const int *dst_rows, const int 
 
 }  // namespace
 
+namespace {
+// Stream lanes of the discrete-optimisation kernels: every launch of this file goes to the calling thread's current lane --
+// lane 0 is the device's default stream (what every call used before), lanes 1 and 2 are two ordinary (blocking) streams per
+// device.  Work on a blocking stream orders itself against the default stream in both directions, so a caller forks by
+// switching lanes (kernels on lanes 1 and 2 run side by side) and joins by going back to lane 0 -- no events to manage.
+thread_local int g_lane = 0;
+std::mutex g_lane_mutex;
+std::map<int, std::array<hipStream_t, 2>> g_lane_streams;
+hipStream_t dopt_stream(int device) {
+    if (g_lane == 0) return nullptr;
+    std::lock_guard<std::mutex> lock(g_lane_mutex);
+    auto it = g_lane_streams.find(device);
+    if (it == g_lane_streams.end()) it = g_lane_streams.emplace(device, std::array<hipStream_t, 2>{nullptr, nullptr}).first;
+    hipStream_t &st = it->second[g_lane - 1];
+    if (!st && hipStreamCreate(&st) != hipSuccess) st = nullptr;     // (falls back to the default stream: still correct)
+    return st;
+}
+}  // namespace
+
 extern "C" {
 
 int tg_tv_lq(int32_t device, const tg_lq_problem *p) {
@@ -1138,7 +1160,7 @@ int tg_tv_lq(int32_t device, const tg_lq_problem *p) {
 #define TG_LQ_LAUNCH(NT_, NR_)                                                                                                   \
                 do {                                                                                                             \
                     if (ldsk > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_tv_lq_mfma<NT_, NR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsk)); \
-                    hipLaunchKernelGGL((k_tv_lq_mfma<NT_, NR_>), dim3(p->n_problems), dim3(LQM_T), ldsk, 0, *p);                   \
+                    hipLaunchKernelGGL((k_tv_lq_mfma<NT_, NR_>), dim3(p->n_problems), dim3(LQM_T), ldsk, dopt_stream(device), *p);                   \
                 } while (0)
 #define TG_LQ_NR(NT_)                                                                                                            \
                 switch (nr) {                                                                                                    \
@@ -1170,10 +1192,10 @@ int tg_tv_lq(int32_t device, const tg_lq_problem *p) {
                      : (cls == 2 ? (const void *)k_tv_lq<5, 10, 3, 8> : (const void *)k_tv_lq<6, 12, 3, 12>));
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     switch (cls) {
-    case 0: hipLaunchKernelGGL((k_tv_lq<2, 4, 1, 2>), dim3(p->n_problems), dim3(LQ_T), lds, 0, *p); break;
-    case 1: hipLaunchKernelGGL((k_tv_lq<4, 8, 2, 6>), dim3(p->n_problems), dim3(LQ_T), lds, 0, *p); break;
-    case 2: hipLaunchKernelGGL((k_tv_lq<5, 10, 3, 8>), dim3(p->n_problems), dim3(LQ_T), lds, 0, *p); break;
-    default: hipLaunchKernelGGL((k_tv_lq<6, 12, 3, 12>), dim3(p->n_problems), dim3(LQ_T), lds, 0, *p); break;
+    case 0: hipLaunchKernelGGL((k_tv_lq<2, 4, 1, 2>), dim3(p->n_problems), dim3(LQ_T), lds, dopt_stream(device), *p); break;
+    case 1: hipLaunchKernelGGL((k_tv_lq<4, 8, 2, 6>), dim3(p->n_problems), dim3(LQ_T), lds, dopt_stream(device), *p); break;
+    case 2: hipLaunchKernelGGL((k_tv_lq<5, 10, 3, 8>), dim3(p->n_problems), dim3(LQ_T), lds, dopt_stream(device), *p); break;
+    default: hipLaunchKernelGGL((k_tv_lq<6, 12, 3, 12>), dim3(p->n_problems), dim3(LQ_T), lds, dopt_stream(device), *p); break;
     }
     HIP_TRY(hipGetLastError());
     return TG_SUCCESS;
@@ -1187,7 +1209,7 @@ int tg_adjoint_sweep(int32_t device, int32_t n_problems, int32_t horizon, int32_
     if (lds > 160 * 1024 - 64 || nX > 96 || nX * nU > 12 * SW_T) return fail(TG_ERR_UNSUPPORTED, "state dimension too large");
     HIP_TRY(hipSetDevice(device));
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_adjoint, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_adjoint, dim3(n_problems), dim3(SW_T), lds, 0, horizon, nX, nU, select_dev, A_dev, B_dev, K_dev, q_dev, r_dev, Z_dev);
+    hipLaunchKernelGGL(k_adjoint, dim3(n_problems), dim3(SW_T), lds, dopt_stream(device), horizon, nX, nU, select_dev, A_dev, B_dev, K_dev, q_dev, r_dev, Z_dev);
     HIP_TRY(hipGetLastError());
     return TG_SUCCESS;
 }
@@ -1202,7 +1224,7 @@ int tg_tangent_rollout(int32_t device, int32_t n_problems, int32_t horizon, int3
     if (lds > 160 * 1024 - 64 || nX > 96 || nX * nU > 12 * SW_T) return fail(TG_ERR_UNSUPPORTED, "state dimension too large");
     HIP_TRY(hipSetDevice(device));
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_tangent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_tangent, dim3(n_problems), dim3(SW_T), lds, 0, horizon, nX, nU, select_dev, A_dev, B_dev, K_dev, C_dev, q_dev,
+    hipLaunchKernelGGL(k_tangent, dim3(n_problems), dim3(SW_T), lds, dopt_stream(device), horizon, nX, nU, select_dev, A_dev, B_dev, K_dev, C_dev, q_dev,
                        r_dev, dX_dev, dU_dev, dcost_dev);
     HIP_TRY(hipGetLastError());
     return TG_SUCCESS;
@@ -1220,7 +1242,7 @@ int tg_quadratic_cost(int32_t device, int32_t n_trajectories, int32_t group, con
 #define LAUNCH_COST(NT_)                                                                                                                  \
         case NT_:                                                                                                                         \
             if (ldsm > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_cost_mfma<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm)); \
-            hipLaunchKernelGGL((k_cost_mfma<NT_>), dim3(n_trajectories), dim3(CT_T), ldsm, 0, horizon, nX, nU, group, select_dev, X_dev, U_dev,       \
+            hipLaunchKernelGGL((k_cost_mfma<NT_>), dim3(n_trajectories), dim3(CT_T), ldsm, dopt_stream(device), horizon, nX, nU, group, select_dev, X_dev, U_dev,       \
                                Xd_dev, Ud_dev, Q_dev, R_dev, Qf_dev, cost_dev);                                                           \
             break;
         switch (nt) { LAUNCH_COST(1) LAUNCH_COST(2) LAUNCH_COST(3) LAUNCH_COST(4) LAUNCH_COST(5) LAUNCH_COST(6) default: break; }
@@ -1231,7 +1253,7 @@ int tg_quadratic_cost(int32_t device, int32_t n_trajectories, int32_t group, con
     const size_t lds = sizeof(double) * (2 * (size_t)nX * nX + (size_t)nU * nU + 4 * (size_t)(nX + nU) + CT_T);
     if (lds > 160 * 1024 - 64) return fail(TG_ERR_UNSUPPORTED, "state dimension too large");
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_cost, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_cost, dim3(n_trajectories), dim3(CT_T), lds, 0, horizon, nX, nU, group, select_dev, X_dev, U_dev, Xd_dev, Ud_dev, Q_dev, R_dev,
+    hipLaunchKernelGGL(k_cost, dim3(n_trajectories), dim3(CT_T), lds, dopt_stream(device), horizon, nX, nU, group, select_dev, X_dev, U_dev, Xd_dev, Ud_dev, Q_dev, R_dev,
                        Qf_dev, cost_dev);
     HIP_TRY(hipGetLastError());
     return TG_SUCCESS;
@@ -1243,7 +1265,7 @@ int tg_quadratic_cost_gradients(int32_t device, int32_t n_problems, int32_t hori
     if (n_problems <= 0 || horizon <= 0 || !X_dev || !U_dev || !Xd_dev || !Ud_dev || !Q_dev || !R_dev || !Qf_dev || !q_dev || !r_dev)
         return fail(TG_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(device));
-    hipLaunchKernelGGL(k_cost_grad, dim3(horizon + 1, n_problems), dim3(CT_T), sizeof(double) * (nX + nU), 0, horizon, nX, nU, select_dev,
+    hipLaunchKernelGGL(k_cost_grad, dim3(horizon + 1, n_problems), dim3(CT_T), sizeof(double) * (nX + nU), dopt_stream(device), horizon, nX, nU, select_dev,
                        X_dev, U_dev, Xd_dev, Ud_dev, Q_dev, R_dev, Qf_dev, q_dev, r_dev);
     HIP_TRY(hipGetLastError());
     return TG_SUCCESS;
@@ -1256,7 +1278,7 @@ int tg_armijo_candidates(int32_t device, int32_t n_problems, int32_t n_lambdas, 
         return fail(TG_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(device));
     const int bx = (int)(((size_t)(horizon + 1) * nX + 255) / 256);
-    hipLaunchKernelGGL(k_candidates, dim3(bx > 64 ? 64 : bx, n_problems * n_lambdas), dim3(256), 0, 0, horizon, nX, nU, n_lambdas, select_dev,
+    hipLaunchKernelGGL(k_candidates, dim3(bx > 64 ? 64 : bx, n_problems * n_lambdas), dim3(256), 0, dopt_stream(device), horizon, nX, nU, n_lambdas, select_dev,
                        lambdas_dev, X_dev, U_dev, dX_dev, dU_dev, bX_dev, bU_dev);
     HIP_TRY(hipGetLastError());
     return TG_SUCCESS;
@@ -1267,7 +1289,7 @@ int tg_copy_rows(int32_t device, int32_t n_rows, uint64_t row_doubles, const int
     if (n_rows <= 0 || !src_dev || !dst_dev) return fail(TG_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(device));
     const int bx = (int)((row_doubles + 255) / 256);
-    hipLaunchKernelGGL(k_copy_rows, dim3(bx > 64 ? 64 : (bx < 1 ? 1 : bx), n_rows > 65535 ? 65535 : n_rows), dim3(256), 0, 0, n_rows, (size_t)row_doubles, dst_rows_dev,
+    hipLaunchKernelGGL(k_copy_rows, dim3(bx > 64 ? 64 : (bx < 1 ? 1 : bx), n_rows > 65535 ? 65535 : n_rows), dim3(256), 0, dopt_stream(device), n_rows, (size_t)row_doubles, dst_rows_dev,
                        src_rows_dev, src_dev, dst_dev);
     HIP_TRY(hipGetLastError());
     return TG_SUCCESS;
@@ -1288,4 +1310,10 @@ int tg_device_synchronize(int32_t device) {
     return TG_SUCCESS;
 }
 
+int tg_dopt_use_stream(int32_t device, int32_t lane) {
+    (void)device;
+    if (lane < 0 || lane > 2) return fail(TG_ERR_INVALID, "stream lane must be 0 (default stream), 1 or 2");
+    g_lane = lane;
+    return TG_SUCCESS;
+}
 }  // extern "C"

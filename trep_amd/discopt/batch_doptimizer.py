@@ -17,6 +17,13 @@ seeds at once and the trajectories, linearisations, gains and candidates never l
 
 Only per-seed scalars (costs, directional derivatives, statuses) come back to the host, which takes the
 accept / fallback / terminate decisions exactly like the reference's ``step``.
+
+The two backward sweeps of a step that do not depend on each other -- the projection gain (Riccati on A, B alone) and the
+quasi-Newton LQ model (A, B, the cost's weights and gradients) -- are each a chain of N dependent steps on ONE workgroup
+per seed.  With at most half as many seeds as the GPU has CUs they are launched side by side on two streams
+(``overlap_sweeps``, tg_dopt_use_stream): in a quasi step that hides the projection gain behind the descent direction,
+in a Newton step the quasi direction is already there for the seeds whose Newton model is not a descent direction
+(doptimizer.py:482-494 computes it only then; the numbers are the same either way).
 """
 from collections import namedtuple
 
@@ -83,8 +90,10 @@ class BatchDOptimizer(object):
 
     step_return = namedtuple("batch_step", "done cost0 dcost0 cost1 method armijo failed")
 
+    CUS = 256       # compute units of an MI355X: one sweep workgroup occupies one
+
     def __init__(self, dsys, Xd, Ud, Q, R, Qf=None, device=0, armijo_chunk=None, first_method_iterations=10,
-                 predictor="reference"):
+                 predictor="reference", overlap_sweeps="auto"):
         self.dsys = dsys
         ds = dsys
         Xd = np.asarray(Xd, dtype=float)
@@ -135,6 +144,13 @@ class BatchDOptimizer(object):
         self.dX, self.dU = pool.empty((S, N + 1, nX)), pool.empty((S, N, nU))
         self.dcost, self.cost = pool.empty((S,)), pool.empty((S,))
         self.lq_status = pool.empty((S,), np.int32)
+        # second set of direction buffers: the quasi-Newton sweep that runs beside the projection gain
+        self.overlap = (2 * S <= self.CUS) if overlap_sweeps == "auto" else bool(overlap_sweeps)
+        if self.overlap:
+            self.K2, self.C2 = pool.empty((S, N, nU, nX)), pool.empty((S, N, nU))
+            self.dX2, self.dU2 = pool.empty((S, N + 1, nX)), pool.empty((S, N, nU))
+            self.dcost2, self.lq_status2 = pool.empty((S,)), pool.empty((S,), np.int32)
+        self._quasi_ready = None      # (dcost [S], failed [S]) of the side-by-side quasi sweep of this step, or None
         self.Z = None
         self.HZ = None
         self.bX, self.bU = pool.empty((S * self.M, N + 1, nX)), pool.empty((S * self.M, N, nU))
@@ -186,10 +202,11 @@ class BatchDOptimizer(object):
         # ConvergenceError out of DSystem.set for that one problem); the other seeds are unaffected
         return (status.reshape(self.S, self.N) != 0).any(axis=1)
 
-    def _lq(self, seeds, Q, Qf, R, hz, affine, K, C=None):
+    def _lq(self, seeds, Q, Qf, R, hz, affine, K, C=None, status=None, collect=True):
         sel, n = self._select(seeds)
         if n == 0:
             return
+        status = self.lq_status if status is None else status
         p = _lib.LqProblem()
         p.n_problems, p.horizon, p.nX, p.nU = n, self.N, self.nX, self.nU
         p.select_dev = sel
@@ -202,16 +219,56 @@ class BatchDOptimizer(object):
         p.q_dev, p.r_dev = (self.q.ptr, self.r.ptr) if affine else (None, None)
         p.K_dev, p.C_dev = K.ptr, (C.ptr if C is not None else None)
         p.P0_dev = p.b0_dev = None
-        p.status_dev = self.lq_status.ptr
+        p.status_dev = status.ptr
         import ctypes
         self._check(self.L.tg_tv_lq(self.device, ctypes.byref(p)))
-        st = self.lq_status.get()       # TG_SINGULAR: the nU x nU matrix of a Riccati step of that seed has no usable pivot
+        if collect:
+            self._lq_collect(seeds, status)
+
+    def _lq_collect(self, seeds, status, into=None):
+        st = status.get()               # TG_SINGULAR: the nU x nU matrix of a Riccati step of that seed has no usable pivot
         idx = np.arange(self.S) if seeds is None else np.asarray(seeds, dtype=np.int64)      # status is indexed by seed
-        self._lq_failed[idx[st[idx] != 0]] = True
+        (self._lq_failed if into is None else into)[idx[st[idx] != 0]] = True
 
     def projection_gain(self):
         """Kproj = solve_tv_lqr(A, B, I, I) (doptimizer.py:272-287)."""
         self._lq(None, self.Ix, self.Ix, self.Iu, None, False, self.Kproj)
+
+    def projection_gain_and_quasi_direction(self):
+        """The projection gain and, beside it on a second stream, the quasi-Newton direction of EVERY seed into the second
+        set of direction buffers (needs q, r: call gradients_and_cost first).  Leaves (dcost, failed) in _quasi_ready."""
+        S, N, nX, nU = self.S, self.N, self.nX, self.nU
+        try:
+            self._check(self.L.tg_dopt_use_stream(self.device, 1))
+            self._lq(None, self.Ix, self.Ix, self.Iu, None, False, self.Kproj, collect=False)
+            self._check(self.L.tg_dopt_use_stream(self.device, 2))
+            self._lq(None, self.Q, self.Qf, self.R, None, True, self.K2, self.C2, status=self.lq_status2, collect=False)
+            self._check(self.L.tg_tangent_rollout(self.device, S, N, nX, nU, None, self.A.ptr, self.B.ptr, self.K2.ptr, self.C2.ptr,
+                                                  self.q.ptr, self.r.ptr, self.dX2.ptr, self.dU2.ptr, self.dcost2.ptr))
+        finally:
+            self._check(self.L.tg_dopt_use_stream(self.device, 0))
+        self._check(self.L.tg_device_synchronize(self.device))
+        self._lq_collect(None, self.lq_status)
+        failed = np.zeros(S, dtype=bool)
+        self._lq_collect(None, self.lq_status2, into=failed)
+        self._quasi_ready = (self.dcost2.get(), failed)
+
+    def _take_quasi_direction(self, seeds):
+        """dX, dU of `seeds` (None = all) <- the quasi direction computed beside the projection gain; returns their dcost."""
+        dc, failed = self._quasi_ready
+        S, N, nX, nU = self.S, self.N, self.nX, self.nU
+        if seeds is None:
+            self.dX, self.dX2 = self.dX2, self.dX
+            self.dU, self.dU2 = self.dU2, self.dU
+            self._quasi_ready = None          # (the buffers now hold whatever dX, dU held)
+            idx = np.arange(S)
+        else:
+            idx = np.asarray(seeds, dtype=np.int64)
+            sel, n = self._select(seeds)
+            self._check(self.L.tg_copy_rows(self.device, n, (N + 1) * nX, sel, sel, self.dX2.ptr, self.dX.ptr))
+            self._check(self.L.tg_copy_rows(self.device, n, N * nU, sel, sel, self.dU2.ptr, self.dU.ptr))
+        self._lq_failed[idx[failed[idx]]] = True
+        return dc[idx]
 
     def gradients_and_cost(self):
         S, N, nX, nU = self.S, self.N, self.nX, self.nU
@@ -306,8 +363,13 @@ class BatchDOptimizer(object):
         methods = np.array([method] * S if isinstance(method, str) else list(method), dtype=object)
         self._lq_failed[:] = False
         broken = self.linearize() & active
-        self.projection_gain()
-        cost0 = self.gradients_and_cost()
+        self._quasi_ready = None
+        if self.overlap and any(m in ("quasi", "newton") for m in methods[active]):
+            cost0 = self.gradients_and_cost()
+            self.projection_gain_and_quasi_direction()
+        else:
+            self.projection_gain()
+            cost0 = self.gradients_and_cost()
         broken |= self._lq_failed & active
         active &= ~broken               # their step ends here (flagged failed below); everything is per seed from now on
         dcost0 = np.full(S, np.nan)
@@ -316,6 +378,9 @@ class BatchDOptimizer(object):
             for name in METHODS:
                 seeds = np.nonzero(pending & (methods == name))[0]
                 if len(seeds) == 0:
+                    continue
+                if name == "quasi" and self._quasi_ready is not None:
+                    dcost0[seeds] = self._take_quasi_direction(None if len(seeds) == S else seeds)
                     continue
                 self.descent_direction(None if len(seeds) == S else seeds, name)
                 dc = self.dcost.get()
