@@ -22,7 +22,7 @@ class RunArgs(ctypes.Structure):
                 ("q1", _D), ("q2", _D), ("p1", _D), ("p2", _D), ("lam", _D), ("u1", _D),
                 ("U", _D), ("K", _D), ("q2_hint", _D), ("lam_hint", _D), ("Kproj", _D), ("bX", _D), ("bU", _D), ("Uout", _D), ("group_size", ctypes.c_int), ("group_map", _I), ("X", _D), ("f_out", _D),
                 ("d1", _D * 12), ("A_out", _D), ("B_out", _D), ("z", _D), ("hz", _D), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p), ("dt_steps", _D), ("dt_period", ctypes.c_int), ("exact_pivot", ctypes.c_int),
-                ("zl", _D), ("dq_in", _D), ("ddqk_in", _D), ("ddq_out", _D), ("lam_out", _D), ("g1", _D * 8), ("energy_out", _D), ("lag1_out", _D), ("lag2_out", _D)]
+                ("zl", _D), ("dq_in", _D), ("ddqk_in", _D), ("ddq_out", _D), ("lam_out", _D), ("g1", _D * 8), ("energy_out", _D), ("lag1_out", _D), ("lag2_out", _D), ("mirror", _D)]
 
 
 def lib():

@@ -161,6 +161,8 @@ struct RunArgs {
                                            // same four for lambda ([..][nc]); derivative variable first, like the reference's arrays
     double *energy_out;                    // MODE_ENERGY: [batch][2] kinetic and potential energy at (q, dq_in)
     double *lag1_out, *lag2_out;           // MODE_LAGRANGIAN: [batch][2][nq] (L_dq, L_ddq) and [batch][3][nq][nq] (L_dqdq, L_ddqdq, L_ddqddq), zeroed by the caller
+    double *mirror;                        // rollout, optional: host-visible copy of the final state, (q2 [batch][nq] | p2 [batch][nd] | lambda1 [batch][nc] |
+                                           // int32 iterations [batch] | int32 status [batch]) -- pinned host memory written by the kernel (tg_batch_step)
 };
 
 // The kernels read the schedule (DevProg) and the launch arguments (RunArgs) through CONSTANT-address-space references:
@@ -4245,6 +4247,14 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
         TG_FOR(i, nc) A.lam[t * nc + i] = S[P.o_lam + i];
         TG_FOR(i, nu) A.u1[t * nu + i] = S[P.o_u + i];
         if (lane == 0) { A.iters[t] = total_iters; A.status[t] = status; }
+        if (A.mirror) {
+            const size_t Bn = (size_t)A.batch;
+            double *m = A.mirror;
+            TG_FOR(i, nq) m[t * nq + i] = S[P.o_q2 + i];
+            TG_FOR(i, nd) m[Bn * nq + t * nd + i] = S[P.o_p1 + i];
+            TG_FOR(i, nc) m[Bn * (nq + nd) + t * nc + i] = S[P.o_lam + i];
+            if (lane == 0) { int *o = reinterpret_cast<int *>(m + Bn * (nq + nd + nc)); o[t] = total_iters; o[Bn + t] = status; }
+        }
     }
     }
 }

@@ -37,8 +37,11 @@ __global__ __launch_bounds__(64 * spec_waves<MODE>(), (MODE == tg::MODE_DERIV1 |
     SPEC_ARGS_REF;
 double *lds = tg_lds_base();
     const SpecProg P{};
-    const int wave = spec_waves<MODE>() > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0, tid = threadIdx.x & 63;
-    const int team = tid / SPEC_TEAM, lane = tid % SPEC_TEAM;
+    int wave = 0, team = threadIdx.x / SPEC_TEAM, lane = threadIdx.x % SPEC_TEAM;
+    if constexpr (spec_waves<MODE>() > 1) {     // (only then: masking the thread index changes the one-wave kernels' register allocation)
+        wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        team = 0; lane = threadIdx.x & 63;
+    }
     const int traj = blockIdx.x * (64 / SPEC_TEAM) + team;
     constexpr int stride = MODE == tg::MODE_DERIV2Z ? SpecProg::e_lds_per_team : (MODE == tg::MODE_DERIV1 ? SpecProg::d_lds_per_team : SpecProg::lds_per_team);
     tg::run_trajectory<SPEC_TEAM, MODE, SPEC_SPRINGS, const SpecProg, std::remove_reference<decltype(A)>::type, PIVOT>(P, A, lds + (size_t)team * stride, lane, traj, wave, spec_waves<MODE>());

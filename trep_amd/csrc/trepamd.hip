@@ -319,19 +319,6 @@ __global__ void k_init_from_X(const tg::DevProg P, const double *X, size_t strid
     for (int i = threadIdx.x; i < P.nc; i += blockDim.x) lam[t * P.nc + i] = 0.0;
 }
 
-// (q2 [B][nq] | p2 [B][nd] | lambda1 [B][nc] | iterations [B] | status [B]) packed for one device-to-host copy (tg_batch_step)
-__global__ void k_pack_step(int B, int nq, int nd, int nc, const double *q2, const double *p2, const double *lam, const int *iters, const int *status, double *out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n0 = B * nq, n1 = n0 + B * nd, n2 = n1 + B * nc;
-    if (i < n0) out[i] = q2[i];
-    else if (i < n1) out[i] = p2[i - n0];
-    else if (i < n2) out[i] = lam[i - n1];
-    else if (i < n2 + B) {
-        int *o = reinterpret_cast<int *>(out + n2);
-        o[i - n2] = iters[i - n2];
-        o[B + i - n2] = status[i - n2];
-    }
-}
 
 // Test hook: the Newton-system solver of the rollout kernels (gj_rows) on a caller-supplied matrix, with its pivot order.
 __global__ void k_debug_solve(int n, int ld, int exact, const double *A_in, double *x_out, int *piv_out, int *status_out) {
@@ -479,7 +466,6 @@ void tg_batch_destroy(tg_batch *b) {
     for (void *p : ptrs) if (p) hipFree(p);
     if (b->h_args) hipHostFree(b->h_args);
     if (b->io_host) hipHostFree(b->io_host);
-    if (b->io_dev) hipFree(b->io_dev);
     for (auto &e : b->arg_done) if (e) hipEventDestroy(e);
     if (b->stream && b->own_stream) hipStreamDestroy(b->stream);
     if (b->spec_lib) dlclose(b->spec_lib);
@@ -583,37 +569,32 @@ int tg_batch_step(tg_batch *b, double t2_new, const double *u1_host, const doubl
     HIP_TRY(hipSetDevice(b->device));
     const size_t B = (size_t)b->batch;
     const bool want_lh = lambda_hint_host && P.nc;
-    // Small batches: the call is host-latency bound (a MidpointVI.step() loop; tools/step_latency.py), so everything crosses the bus
-    // once in each direction: inputs through one pinned block, (q2, p2, lambda1, iterations, status) back into the host mirror.
+    // Small batches: the call is host-latency bound (a MidpointVI.step() loop; tools/step_latency.py).  Inputs and results live in one
+    // pinned, device-visible host block: the kernel reads (u1, k2, hints) from it at the head of the step and writes (q2, p2, lambda1,
+    // iterations, status) into it beside the device state -- one launch on the stream, no copy engine, no packing kernel.
     const size_t n_in = B * ((size_t)P.nu + P.nk + P.nd + P.nc), n_out = B * ((size_t)P.nq + P.nd + P.nc) + B;   // 2 B ints = B doubles
     if ((n_in + n_out) * sizeof(double) <= (1u << 20)) {
         if (!b->io_host) {
-            if (hipHostMalloc(&b->io_host, (n_in + n_out) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-                hipMalloc(&b->io_dev, (n_in + n_out) * sizeof(double)) != hipSuccess) return fail(TG_ERR_HIP, "allocation of the step staging block failed");
+            if (hipHostMalloc(&b->io_host, (n_in + n_out) * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer(reinterpret_cast<void **>(&b->io_dev), b->io_host, 0) != hipSuccess)
+                return fail(TG_ERR_HIP, "allocation of the step staging block failed");
             b->io_in = n_in; b->io_out = n_out;
         }
         double *hu = b->io_host, *hk = hu + B * P.nu, *hq = hk + B * P.nk, *hl = hq + B * P.nd;
-        double *du = b->io_dev, *dk = du + B * P.nu, *dq = dk + B * P.nk, *dl = dq + B * P.nd;
+        double *du = b->io_dev, *dk = du + B * P.nu, *dq = dk + B * P.nk, *dl = dq + B * P.nd;    // the same block as the device sees it
         if (P.nu) std::memcpy(hu, u1_host, B * P.nu * sizeof(double));
         if (P.nk) std::memcpy(hk, k2_host, B * P.nk * sizeof(double));
         if (q2_hint_host) std::memcpy(hq, q2_hint_host, B * P.nd * sizeof(double));
         if (want_lh) std::memcpy(hl, lambda_hint_host, B * P.nc * sizeof(double));
-        const size_t used = want_lh ? n_in : (q2_hint_host ? B * ((size_t)P.nu + P.nk + P.nd) : B * ((size_t)P.nu + P.nk));
-        if (used) HIP_TRY(hipMemcpyAsync(b->io_dev, b->io_host, used * sizeof(double), hipMemcpyHostToDevice, b->stream));
         tg::RunArgs A = base_args(b, tg::MODE_ROLLOUT);
         A.n_steps = 1; A.dt = t2_new - b->t2; A.max_iterations = max_iterations;
         A.U = du; A.K = dk;
         A.q2_hint = q2_hint_host ? dq : nullptr;
         A.lam_hint = want_lh ? dl : nullptr;
+        A.mirror = b->io_dev + n_in;
         int rc = launch(b, A);
         if (rc) return rc;
         b->t1 = b->t2; b->t2 = t2_new;
-        double *dout = b->io_dev + n_in;
-        const int total = (int)(B * ((size_t)P.nq + P.nd + P.nc + 1));
-        hipLaunchKernelGGL(k_pack_step, dim3((total + 255) / 256), dim3(256), 0, b->stream, (int)B, P.nq, P.nd, P.nc,
-                           (const double *)b->q2, (const double *)b->p2, (const double *)b->lam, (const int *)b->iters, (const int *)b->status, dout);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(b->io_host + n_in, dout, n_out * sizeof(double), hipMemcpyDeviceToHost, b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));
         b->mirror_valid = true;
         return tg_batch_status(b, iterations_out, status_out);
