@@ -27,6 +27,7 @@ cd $GRAFT_REPO_ROOT
 cp $(find $out/trace_discopt -name "*kernel_stats.csv" | head -1) $out/kernel_stats_discopt.csv 2>/dev/null
 rm -rf $out/trace_discopt
 for s in 32 64 128 256; do timeout 600 python bench_discopt.py --seeds $s --horizon 1000 --quasi 1 --newton 1 --stages > $out/discopt_$s.json 2> $out/discopt_$s.err; done
+for s in 32 64 128; do timeout 600 python bench_discopt.py --seeds $s --horizon 1000 --quasi 1 --newton 1 --overlap off > $out/discopt_${s}_sequential.json 2> $out/discopt_${s}_sequential.err; done
 timeout 600 python tools/bench_derivs.py --batch 65536 > $out/bench_derivs.json 2>&1
 TREPAMD_NO_SPECIALIZE=1 timeout 600 python tools/bench_derivs.py --batch 65536 > $out/bench_derivs_generic.json 2>&1
 for sys in cart scissor puppet-basic; do timeout 600 python bench.py --system $sys --batch $([ $sys = puppet-basic ] && echo 8192 || echo 4096) --steps 10 --warmup 2 > $out/bench_$sys.json 2> $out/bench_$sys.err; done
@@ -40,4 +41,5 @@ F="-DSPEC_ARGS_IN_MEMORY -DTG_GJ_INLINE -mllvm -disable-machine-licm -mllvm -amd
 (echo "# system-specialised rollout kernel, gj_panel (profiling build: -DTG_PROFILE adds s_memtime stamps)"; TREPAMD_LIB=trep_amd/libtrepamd_prof.so TREPAMD_SPEC_FLAGS="$F" timeout 200 python tools/phase_profile.py;
  echo; echo "# the same with gj_rows (-DTG_NO_GJ_PANEL)"; TREPAMD_LIB=trep_amd/libtrepamd_prof.so TREPAMD_SPEC_FLAGS="$F -DTG_NO_GJ_PANEL" timeout 200 python tools/phase_profile.py;
  echo; echo "# generic rollout kernel"; TREPAMD_LIB=trep_amd/libtrepamd_prof.so TREPAMD_NO_SPECIALIZE=1 timeout 200 python tools/phase_profile.py) > $out/phase_profile.txt 2>&1
+bash tools/gpu_prof_derivs.sh $tag/prof_derivs > /dev/null 2>&1
 ls -la $out; cat $out/bench.json | cut -c1-600; head -12 $out/kernel_stats.csv

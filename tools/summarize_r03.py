@@ -70,6 +70,10 @@ sweep = {}
 for s in (32, 64, 128, 256):
     d = load("discopt_%d.json" % s)
     sweep[str(s)] = {k: d[k] for k in ("value", "s_per_batched_quasi_step", "s_per_batched_newton_step", "stage_seconds", "armijo_failures", "config")}
+    seq = os.path.join(SRC, "discopt_%d_sequential.json" % s)      # the same with the two independent sweeps one after the other
+    if os.path.exists(seq):
+        q = json.load(open(seq))
+        sweep[str(s)]["sweeps_one_after_the_other"] = {k: q[k] for k in ("value", "s_per_batched_quasi_step", "s_per_batched_newton_step")}
 json.dump({"what": "bench_discopt.py --horizon 1000 --quasi 1 --newton 1 --stages on ONE MI355X at 32 / 64 / 128 / 256 seeds: what each of 8 / 4 / 2 / 1 GPUs holds when BASELINE config 4 (256 seeds) is sharded",
            "seeds": sweep}, open(os.path.join(DST, "r03_seed_sweep.json"), "w"), indent=1)
 json.dump({"specialised": load("bench_derivs.json"), "generic": load("bench_derivs_generic.json")}, open(os.path.join(DST, "r03_derivs.json"), "w"), indent=1)
@@ -81,6 +85,13 @@ print("fp64: %.3g flop per launch -> %.2f TFLOP/s" % (flop, flop / (bench["roofl
 print(json.dumps(sq_out["derived"], indent=1))
 for s in sweep:
     print(s, round(sweep[s]["value"], 1), sweep[s]["s_per_batched_quasi_step"], sweep[s]["s_per_batched_newton_step"])
+pd = os.path.join(SRC, "prof_derivs")
+if os.path.exists(os.path.join(pd, "deriv2.txt")):
+    with open(os.path.join(DST, "r03_phase_profile_derivs.txt"), "w") as fh:
+        fh.write("# specialised derivative kernels with helper waves, diagnostic -DTG_PROFILE build: cycles of WAVE 0 of trajectory 0\n"
+                 "# (tools/gpu_prof_derivs.sh; a first-round trajectory: cold caches inflate the first phases)\n")
+        fh.write(open(os.path.join(pd, "deriv2.txt")).read())
+        fh.write(open(os.path.join(pd, "deriv1.txt")).read())
 for a, b in (("gj_bench.txt", "r03_gj_bench.txt"), ("step_latency.json", "r03_step_latency.json"), ("phase_profile.txt", "r03_phase_profile.txt")):
     if os.path.exists(os.path.join(SRC, a)):
         shutil.copy(os.path.join(SRC, a), os.path.join(DST, b))
