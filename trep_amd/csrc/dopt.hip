@@ -601,12 +601,18 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
                 for (int r = 0; r < 4; r++) PB[(16 * ti + lk + 4 * r) * nUp + u] = c[r];
             }
         }
+        // B'b rides along with gamma = R + B'(P B) when P B has a spare padding column (nU not a multiple of 4): b goes into column nU
+        // of the staged P B, and column nU of the gamma tiles comes out as B'b (phase 2b) -- no serial dot products
+        const bool bb_in_tile = affine && nUp > nU;
         if (affine && tid < nU) {
-            double w = 0.0;
-            for (int i = 0; i < nX; i++) w += Bm[i * nU + tid] * bv[i];
-            wv[tid] = w;
+            if (!bb_in_tile) {
+                double w = 0.0;
+                for (int i = 0; i < nX; i++) w += Bm[i * nU + tid] * bv[i];
+                wv[tid] = w;
+            }
             rv[tid] = a.r_dev[(sN + k) * nU + tid];
         }
+        if (bb_in_tile) for (int i = tid; i < ldx; i += LQM_T) PB[i * nUp + nU] = i < nX ? bv[i] : 0.0;
         __syncthreads();
         LQ_STAMP(0);
         // ---- phase 2a: P A -> LDS (over P) -------------------------------------------------------------------
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
 #pragma unroll 4
             for (int k0 = 0; k0 < ldx; k0 += 4) {
                 const double av = u < nU ? Bm[(k0 + lk) * nU + u] : 0.0;       // B'[u][k]
-                const double bw = is_gamma ? (col < nU ? PB[(k0 + lk) * nUp + col] : 0.0) : Pm[(k0 + lk) * ldx + col];
+                const double bw = is_gamma ? (col < nU + (bb_in_tile ? 1 : 0) ? PB[(k0 + lk) * nUp + col] : 0.0) : Pm[(k0 + lk) * ldx + col];
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bw, c, 0, 0, 0);
             }
 #pragma unroll
@@ -641,6 +647,9 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
                             double g = c[r] + a.R_dev[(size_t)s * a.R_seed_stride + (size_t)k * a.R_step_stride + uo * nU + col];
                             if (hz) g += hz[(size_t)(nxh + uo) * hzR + nxh + col];
                             G[uo * ldw + col] = g;
+                        } else if (bb_in_tile && col == nU) {       // r_k + B'b
+                            const double rw = c[r] + rv[uo];
+                            rv[uo] = rw; G[uo * ldw + nU] = rw;
                         }
                     } else {
                         double v = c[r];
@@ -650,7 +659,7 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
                 }
             }
         }
-        if (tid < nU) { const double rw = affine ? wv[tid] + rv[tid] : 0.0; rv[tid] = rw; G[tid * ldw + nU] = rw; }   // r_k + B'b
+        if (tid < nU && !bb_in_tile) { const double rw = affine ? wv[tid] + rv[tid] : 0.0; rv[tid] = rw; G[tid * ldw + nU] = rw; }   // r_k + B'b
         __syncthreads();
         LQ_STAMP(1);
         // ---- phase 3: [C | K] = gamma^-1 [. | .]: every wave its quarter of the right-hand sides, no barrier inside ------
@@ -726,11 +735,18 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
                 for (int i = 0; i < TMAX; i++) if (ok_[i]) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bw[i], acc[i], 0, 0, 0);
             }
         }
-        if (affine) for (int i = tid; i < nX; i += LQM_T) {
-            double v = a.q_dev[(sN + s + k) * nX + i];
-            for (int m = 0; m < nX; m++) v += Am[m * ldx + i] * bv[m];
-            for (int u = 0; u < nU; u++) v -= Ks[u * ldx + i] * rv[u];
-            bn[i] = v;
+        if (affine) for (int i = tid; i < nX; i += LQM_T) {     // new b = q_k + A'b - K'(r_k + B'b): four independent chains (the LDS reads in flight together)
+            double v0 = a.q_dev[(sN + s + k) * nX + i], v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            int m = 0;
+            for (; m + 4 <= nX; m += 4) {
+                v0 = fma(Am[m * ldx + i], bv[m], v0); v1 = fma(Am[(m + 1) * ldx + i], bv[m + 1], v1);
+                v2 = fma(Am[(m + 2) * ldx + i], bv[m + 2], v2); v3 = fma(Am[(m + 3) * ldx + i], bv[m + 3], v3);
+            }
+            for (; m < nX; m++) v0 = fma(Am[m * ldx + i], bv[m], v0);
+            int u = 0;
+            for (; u + 2 <= nU; u += 2) { v1 = fma(-Ks[u * ldx + i], rv[u], v1); v2 = fma(-Ks[(u + 1) * ldx + i], rv[u + 1], v2); }
+            for (; u < nU; u++) v3 = fma(-Ks[u * ldx + i], rv[u], v3);
+            bn[i] = (v0 + v1) + (v2 + v3);
         }
         __syncthreads();
         LQ_STAMP(3);
