@@ -280,7 +280,8 @@ int tg_debug_solve(int32_t device, int32_t n, int32_t exact, const double *A_aug
  * was compiled against (tg_spec_key) and tg_batch_load_specialized refuses a library whose key or sizes differ.
  * tg_batch_info: out[0] bit m = kernel mode m has a specialised kernel loaded; out[1] / out[2] bit m = a mode-m launch
  * went through a specialised / generic kernel since the batch was created; out[3] / out[4] = number of such launches;
- * out[5] pivot rule; out[6] team size.  (Modes: 0 rollout/step, 1 calc_p2, 2 calc_f, 3 deriv1, 4 deriv2z, 5.. dynamics.) */
+ * out[5] pivot rule; out[6] team size; out[7] wavefronts per trajectory in the loaded library's derivative kernels (1, or 2 with
+ * helper waves).  (Modes: 0 rollout/step, 1 calc_p2, 2 calc_f, 3 deriv1, 4 deriv2z, 5.. dynamics.) */
 int64_t tg_system_spec_header(const tg_system *sys, char *buf, uint64_t capacity);
 uint64_t tg_system_spec_key(const tg_system *sys);
 int tg_batch_load_specialized(tg_batch *b, const char *library_path);

@@ -30,6 +30,8 @@ def _assert_kernels(info, spec, modes):
     for m in modes:
         if spec:
             assert m in info["spec_modes"] and m in info["spec_launched"] and m not in info["generic_launched"], (m, info)
+            # the specialised derivative kernels of a full-wave team run two wavefronts per trajectory (helper waves)
+            assert info["helper_waves"] == (2 if info["team"] == 64 else 1), info
         else:
             assert m in info["generic_launched"] and m not in info["spec_launched"], (m, info)
 

@@ -79,6 +79,8 @@ unsigned long long tg_spec_key(void) {
     return 0ull;
 #endif
 }
+// wavefronts per trajectory in the derivative kernels of this library (helper waves, mvi_core.hpp)
+int tg_spec_waves(void) { return spec_waves<tg::MODE_DERIV2Z>(); }
 // bit m set: kernel mode m (tg::MODE_*) has a specialised instantiation in this library
 int tg_spec_modes(void) {
     int m = 1 << tg::MODE_ROLLOUT;

@@ -75,7 +75,7 @@ struct tg_batch {
     double *io_host = nullptr, *io_dev = nullptr;
     size_t io_in = 0, io_out = 0;      // doubles in the input / output part
     bool mirror_valid = false;
-    int spec_modes = 0;
+    int spec_modes = 0, spec_waves = 1;
     unsigned int spec_launched_modes = 0, generic_launched_modes = 0;   // bit m: a kernel of mode m went through that path (tg_batch_info)
     long long spec_launches = 0, generic_launches = 0;
     std::string spec_path;
@@ -1110,6 +1110,8 @@ int tg_batch_load_specialized(tg_batch *b, const char *library_path) {
     }
     if (b->spec_lib) { hipStreamSynchronize(b->stream); dlclose(b->spec_lib); }
     b->spec_lib = h; b->spec_launch = launch_fn; b->spec_modes = modes_fn(); b->spec_path = library_path;
+    auto waves_fn = reinterpret_cast<int (*)(void)>(dlsym(h, "tg_spec_waves"));
+    b->spec_waves = waves_fn ? waves_fn() : 1;
     return TG_SUCCESS;
 }
 
@@ -1121,7 +1123,7 @@ int tg_batch_info(const tg_batch *b, int32_t out[8]) {
     out[0] = b->spec_launch ? b->spec_modes : 0;
     out[1] = (int32_t)b->spec_launched_modes; out[2] = (int32_t)b->generic_launched_modes;
     out[3] = (int32_t)std::min<long long>(b->spec_launches, 0x7fffffff); out[4] = (int32_t)std::min<long long>(b->generic_launches, 0x7fffffff);
-    out[5] = b->exact_pivot; out[6] = b->sys->team; out[7] = 0;
+    out[5] = b->exact_pivot; out[6] = b->sys->team; out[7] = b->spec_launch ? b->spec_waves : 1;
     return TG_SUCCESS;
 }
 

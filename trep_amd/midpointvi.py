@@ -180,14 +180,15 @@ class BatchMidpointVI(object):
     def kernel_info(self):
         """Which kernels this batch has launched (tg_batch_info): `spec_modes` = set of mode names with a specialised kernel
         loaded, `spec_launched` / `generic_launched` = mode names that have actually gone through a specialised / generic
-        kernel, and the launch counts; `spec_library` the loaded file."""
+        kernel, and the launch counts; `helper_waves` = wavefronts per trajectory in the loaded library's derivative kernels;
+        `spec_library` the loaded file."""
         out = np.zeros(8, dtype=np.int32)
         _lib.check(self._L.tg_batch_info(self._h, out.ctypes.data_as(_lib._c_ip)))
         names = lambda bits: sorted(n for n, m in self.MODES.items() if (int(bits) >> m) & 1)
         return {"spec_modes": names(out[0]), "spec_launched": names(out[1]), "generic_launched": names(out[2]),
                 "spec_launch_mask": int(out[1]), "generic_launch_mask": int(out[2]),
                 "spec_launches": int(out[3]), "generic_launches": int(out[4]), "exact_pivot": bool(out[5]), "team": int(out[6]),
-                "spec_library": self._specialized}
+                "helper_waves": int(out[7]), "spec_library": self._specialized}
 
     @property
     def stream(self):
