@@ -3410,8 +3410,14 @@ struct Core {
         auto assemble_mfma = [&](double *TB) {
             constexpr int GA = 3;
             const int l15 = lane & 15, l4 = lane >> 4;
-            const int n_jt = (nq + 15) >> 4, n_at = (R + 15) >> 4, n_k = (nd + 3) >> 2, n_kc = (nc + 3) >> 2;
-            for (int b0 = 16 * wave; b0 < R; b0 += 16 * nw) {      // blocks of 16 columns: one wave each, its own TB
+            const int n_jt = (nq + 15) >> 4, n_bt = (R + 15) >> 4, n_k = (nd + 3) >> 2, n_kc = (nc + 3) >> 2;
+            // HZ is symmetric: block column bt only computes the tiles on and above the diagonal (row tiles 0 .. bt) and stores the
+            // off-diagonal ones a second time, transposed.  Blocks are dealt to the waves largest first in snake order (helper waves:
+            // 8 and 7 of the 15 tiles of an 80 x 80 matrix), each wave with its own TB.
+            for (int bi = 0; bi < n_bt; bi++) {
+                const int ph = bi % (2 * nw);
+                if ((ph < nw ? ph : 2 * nw - 1 - ph) != wave) continue;
+                const int bt = n_bt - 1 - bi, b0 = 16 * bt;
                 const int bcol = b0 + l15;
                 const bool bin = bcol < R, bq = bcol < nq;
                 if (on) for (int jt0 = 0; jt0 < n_jt; jt0 += GA) {
@@ -3441,7 +3447,8 @@ struct Core {
                     }
                 }
                 TG_SYNC();
-                if (on) for (int at0 = 0; at0 < n_at; at0 += GA) {
+                if (on) for (int at0 = 0; at0 <= bt; at0 += GA) {
+                    const int n_at = bt + 1;                      // row tiles of this block column
                     hz4 acc[GA];
 #pragma unroll
                     for (int g = 0; g < GA; g++) acc[g] = hz4{0.0, 0.0, 0.0, 0.0};
@@ -3475,7 +3482,7 @@ struct Core {
 #pragma unroll
                             for (int g = 0; g < GA; g++) { const int a = 16 * (at0 + g) + l15; av[g] = (kin && a < nq) ? H12[a * hl + i2] : 0.0; }
 #pragma unroll
-                            for (int g = 0; g < GA; g++) if (16 * (at0 + g) < nq) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g], bw, acc[g], 0, 0, 0);
+                            for (int g = 0; g < GA; g++) if (16 * (at0 + g) < nq && at0 + g < n_at) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g], bw, acc[g], 0, 0, 0);
                         }
                         for (int kc = 0; kc < n_kc; kc++) {
                             const int c = 4 * kc + l4;
@@ -3485,11 +3492,12 @@ struct Core {
 #pragma unroll
                             for (int g = 0; g < GA; g++) { const int a = 16 * (at0 + g) + l15; av[g] = (cin && a < nq) ? G1[a * nc + c] : 0.0; }
 #pragma unroll
-                            for (int g = 0; g < GA; g++) if (16 * (at0 + g) < nq) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g], bw, acc[g], 0, 0, 0);
+                            for (int g = 0; g < GA; g++) if (16 * (at0 + g) < nq && at0 + g < n_at) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g], bw, acc[g], 0, 0, 0);
                         }
                     }
 #pragma unroll
                     for (int g = 0; g < GA; g++) {
+                        if (at0 + g >= n_at) break;
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const int a = 16 * (at0 + g) + l4 + 4 * r;
@@ -3504,6 +3512,7 @@ struct Core {
                                     if (bq) v += H11[sym(a, bcol)];
                                 }
                                 A.hz[(t * R + a) * R + bcol] = ok ? v : NAN;
+                                if (at0 + g < bt) A.hz[(t * R + bcol) * R + a] = ok ? v : NAN;      // the transposed tile
                             }
                         }
                     }
