@@ -382,6 +382,9 @@ typedef struct tg_lq_problem {
     const double *q_dev, *r_dev;          /* [S][N+1][nX], [S][N][nU] or both NULL */
     double *K_dev, *C_dev, *P0_dev, *b0_dev;
     int32_t *status_dev;
+    double *b_next_dev;                   /* optional (with q, r): [S][N][nX], row k = b_{k+1}, the affine term entering step k.  With
+                                           * the projection weights (Q = R = I) and the cost gradients as q, r this is the adjoint
+                                           * z_{k+1} of the Newton model (doptimizer.py:340-343): tg_adjoint_sweep for free */
 } tg_lq_problem;
 int tg_tv_lq(int32_t device, const tg_lq_problem *problem);
 

@@ -248,6 +248,32 @@ def test_batch_optimizer_matches_sequential_cart():
         opt.close()
 
 
+def test_adjoint_comes_out_of_the_projection_sweep():
+    """projection_gain(with_adjoint=True): the Riccati sweep with the cost gradients as affine terms writes Z[s][k] = z_{k+1}
+    (doptimizer.py:340-343) -- against the separate backward sweep tg_adjoint_sweep; the gain itself is bit-equal either way."""
+    import trep_amd
+    from trep_amd import discopt
+    S = 3
+    g, system, Xd, Ud = _cart_problem(S)
+    dsys = discopt.DSystem(trep_amd.MidpointVI(system), g["t"])
+    opt = discopt.BatchDOptimizer(dsys, Xd, Ud, g["Q"], g["R"], armijo_chunk=2)
+    try:
+        opt.set_trajectories(np.repeat(g["X0"][None], S, axis=0), np.repeat(g["U0"][None], S, axis=0))
+        opt.linearize()
+        opt.gradients_and_cost()
+        opt.projection_gain()
+        K0 = opt.Kproj.get()
+        opt.newton_curvature(None)            # tg_adjoint_sweep
+        Z0 = opt.Z.get()
+        opt.projection_gain(with_adjoint=True)
+        assert opt._adjoint_ready and np.array_equal(opt.Kproj.get(), K0)
+        Z1 = opt.Z.get()
+        assert relerr(Z1, Z0) < 1e-11, relerr(Z1, Z0)
+        assert np.abs(Z0).max() > 0
+    finally:
+        opt.close()
+
+
 def test_side_by_side_sweeps_change_nothing():
     """overlap_sweeps: projection gain and quasi-Newton sweep on two streams (default with few seeds) against one after the
     other -- same kernels on the same inputs, so every number of every step is bit-equal, including a step in which some

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
     for (int k = N - 1; k >= 0; k--) {
         if (k > 0) prefetch(k - 1);
         const double *hz = a.hz_dev ? a.hz_dev + (sN + k) * (size_t)hzR * hzR : nullptr;
+        if (a.b_next_dev && affine) for (int i = tid; i < nX; i += LQ_T) a.b_next_dev[(sN + k) * nX + i] = bv[i];    // b_{k+1}
         // ---- phase 1: PA tile (registers), B'P, B'b ----------------------------------------------------
         if (has_tile) {
 #pragma unroll
@@ -564,6 +565,7 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
     for (int k = N - 1; k >= 0; k--) {
         if (k > 0) prefetch(k - 1);
         const double *hz = a.hz_dev ? a.hz_dev + (sN + k) * (size_t)hzR * hzR : nullptr;
+        if (a.b_next_dev && affine) for (int i = tid; i < nX; i += LQM_T) a.b_next_dev[(sN + k) * nX + i] = bv[i];    // b_{k+1}
         // ---- phase 1: P A tiles (registers), P B -> LDS, B'b ---------------------------------------------------
         // all tiles of the wave at once: TMAX independent accumulation chains (a dependent f64 MFMA issues every ~200 cycles,
         // independent ones every ~64: tools/micro/mfma_f64_rate.hip)

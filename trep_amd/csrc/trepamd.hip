@@ -575,7 +575,7 @@ int tg_batch_step(tg_batch *b, double t2_new, const double *u1_host, const doubl
     const size_t n_in = B * ((size_t)P.nu + P.nk + P.nd + P.nc), n_out = B * ((size_t)P.nq + P.nd + P.nc) + B;   // 2 B ints = B doubles
     if ((n_in + n_out) * sizeof(double) <= (1u << 20)) {
         if (!b->io_host) {
-            if (hipHostMalloc(&b->io_host, (n_in + n_out) * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+            if (hipHostMalloc(&b->io_host, (n_in + n_out) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
                 hipHostGetDevicePointer(reinterpret_cast<void **>(&b->io_dev), b->io_host, 0) != hipSuccess)
                 return fail(TG_ERR_HIP, "allocation of the step staging block failed");
             b->io_in = n_in; b->io_out = n_out;

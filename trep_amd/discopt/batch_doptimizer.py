@@ -25,6 +25,7 @@ per seed.  With at most half as many seeds as the GPU has CUs they are launched 
 in a Newton step the quasi direction is already there for the seeds whose Newton model is not a descent direction
 (doptimizer.py:482-494 computes it only then; the numbers are the same either way).
 """
+import os
 from collections import namedtuple
 
 import numpy as np
@@ -151,6 +152,8 @@ class BatchDOptimizer(object):
             self.dX2, self.dU2 = pool.empty((S, N + 1, nX)), pool.empty((S, N, nU))
             self.dcost2, self.lq_status2 = pool.empty((S,)), pool.empty((S,), np.int32)
         self._quasi_ready = None      # (dcost [S], failed [S]) of the side-by-side quasi sweep of this step, or None
+        self._adjoint_ready = False   # Z holds the adjoint of the current iterate (written by the projection sweep)
+        self.fuse_adjoint = os.environ.get("TREPAMD_SEPARATE_ADJOINT") is None      # (the env switch is for A/B measurements)
         self.Z = None
         self.HZ = None
         self.bX, self.bU = pool.empty((S * self.M, N + 1, nX)), pool.empty((S * self.M, N, nU))
@@ -195,6 +198,7 @@ class BatchDOptimizer(object):
     def linearize(self):
         """A, B about the current (X, U) for every seed and step; leaves the S*N solved steps resident."""
         self.lin.refresh()
+        self._adjoint_ready = False
         self._check(self.L.tg_batch_set_from_trajectories(self.lin._h, self.S, self.N, self.t0, self.dt, self.X.ptr, self.U.ptr, 200))
         _, status = self.lin.status()
         self._check(self.L.tg_batch_linearize(self.lin._h, self.A.ptr, self.B.ptr))
@@ -202,7 +206,7 @@ class BatchDOptimizer(object):
         # ConvergenceError out of DSystem.set for that one problem); the other seeds are unaffected
         return (status.reshape(self.S, self.N) != 0).any(axis=1)
 
-    def _lq(self, seeds, Q, Qf, R, hz, affine, K, C=None, status=None, collect=True):
+    def _lq(self, seeds, Q, Qf, R, hz, affine, K, C=None, status=None, collect=True, b_next=None):
         sel, n = self._select(seeds)
         if n == 0:
             return
@@ -219,6 +223,7 @@ class BatchDOptimizer(object):
         p.q_dev, p.r_dev = (self.q.ptr, self.r.ptr) if affine else (None, None)
         p.K_dev, p.C_dev = K.ptr, (C.ptr if C is not None else None)
         p.P0_dev = p.b0_dev = None
+        p.b_next_dev = b_next.ptr if (b_next is not None and affine) else None
         p.status_dev = status.ptr
         import ctypes
         self._check(self.L.tg_tv_lq(self.device, ctypes.byref(p)))
@@ -230,17 +235,30 @@ class BatchDOptimizer(object):
         idx = np.arange(self.S) if seeds is None else np.asarray(seeds, dtype=np.int64)      # status is indexed by seed
         (self._lq_failed if into is None else into)[idx[st[idx] != 0]] = True
 
-    def projection_gain(self):
-        """Kproj = solve_tv_lqr(A, B, I, I) (doptimizer.py:272-287)."""
-        self._lq(None, self.Ix, self.Ix, self.Iu, None, False, self.Kproj)
+    def _ensure_newton_buffers(self):
+        if self.Z is None:
+            self.Z = self.pool.empty((self.S, self.N, self.nX))
+            self.HZ = self.pool.empty((self.S, self.N, self._R, self._R))
 
-    def projection_gain_and_quasi_direction(self):
+    def projection_gain(self, with_adjoint=False, collect=True):
+        """Kproj = solve_tv_lqr(A, B, I, I) (doptimizer.py:272-287).  with_adjoint (needs q, r: gradients_and_cost first): the same
+        sweep run with the cost gradients as its affine terms -- its vector recursion b_k = q_k - K_k' r_k + (A_k - B_k K_k)' b_{k+1}
+        IS the adjoint z of the Newton model (doptimizer.py:340-343), so Z[s][k] = z_{k+1} comes out of the projection sweep and the
+        separate backward sweep (tg_adjoint_sweep) is not needed."""
+        if with_adjoint:
+            self._ensure_newton_buffers()
+            self._lq(None, self.Ix, self.Ix, self.Iu, None, True, self.Kproj, None, collect=collect, b_next=self.Z)
+        else:
+            self._lq(None, self.Ix, self.Ix, self.Iu, None, False, self.Kproj, collect=collect)
+        self._adjoint_ready = bool(with_adjoint)
+
+    def projection_gain_and_quasi_direction(self, with_adjoint=False):
         """The projection gain and, beside it on a second stream, the quasi-Newton direction of EVERY seed into the second
         set of direction buffers (needs q, r: call gradients_and_cost first).  Leaves (dcost, failed) in _quasi_ready."""
         S, N, nX, nU = self.S, self.N, self.nX, self.nU
         try:
             self._check(self.L.tg_dopt_use_stream(self.device, 1))
-            self._lq(None, self.Ix, self.Ix, self.Iu, None, False, self.Kproj, collect=False)
+            self.projection_gain(with_adjoint, collect=False)
             self._check(self.L.tg_dopt_use_stream(self.device, 2))
             self._lq(None, self.Q, self.Qf, self.R, None, True, self.K2, self.C2, status=self.lq_status2, collect=False)
             self._check(self.L.tg_tangent_rollout(self.device, S, N, nX, nU, None, self.A.ptr, self.B.ptr, self.K2.ptr, self.C2.ptr,
@@ -280,12 +298,11 @@ class BatchDOptimizer(object):
 
     def newton_curvature(self, seeds):
         """HZ[s][k] = second derivatives of step k contracted with the adjoint z_{k+1} (doptimizer.py:319-345)."""
-        if self.Z is None:
-            self.Z = self.pool.empty((self.S, self.N, self.nX))
-            self.HZ = self.pool.empty((self.S, self.N, self._R, self._R))
-        sel, n = self._select(seeds)
-        self._check(self.L.tg_adjoint_sweep(self.device, n, self.N, self.nX, self.nU, sel, self.A.ptr, self.B.ptr, self.Kproj.ptr,
-                                            self.q.ptr, self.r.ptr, self.Z.ptr))
+        self._ensure_newton_buffers()
+        if not self._adjoint_ready:       # (else: Z came out of the projection sweep)
+            sel, n = self._select(seeds)
+            self._check(self.L.tg_adjoint_sweep(self.device, n, self.N, self.nX, self.nU, sel, self.A.ptr, self.B.ptr, self.Kproj.ptr,
+                                                self.q.ptr, self.r.ptr, self.Z.ptr))
         self._check(self.L.tg_batch_deriv2_contract_device(self.lin._h, self.Z.ptr, self.HZ.ptr))
 
     def descent_direction(self, seeds, method):
@@ -364,12 +381,12 @@ class BatchDOptimizer(object):
         self._lq_failed[:] = False
         broken = self.linearize() & active
         self._quasi_ready = None
+        cost0 = self.gradients_and_cost()                       # (q, r do not depend on the projection gain; the sweeps below use them)
+        newton = self.fuse_adjoint and any(m == "newton" for m in methods[active])    # then the projection sweep also carries the adjoint
         if self.overlap and any(m in ("quasi", "newton") for m in methods[active]):
-            cost0 = self.gradients_and_cost()
-            self.projection_gain_and_quasi_direction()
+            self.projection_gain_and_quasi_direction(with_adjoint=newton)
         else:
-            self.projection_gain()
-            cost0 = self.gradients_and_cost()
+            self.projection_gain(with_adjoint=newton)
         broken |= self._lq_failed & active
         active &= ~broken               # their step ends here (flagged failed below); everything is per seed from now on
         dcost0 = np.full(S, np.nan)
