@@ -426,19 +426,20 @@ class BatchDOptimizer(object):
                 count = int(min(self.armijo_max_iterations - m0, max(1, (S * self.M) // len(seeds))))
                 costs, ok = self.armijo_chunk(m0, seeds, count)
             lam = self.armijo_beta ** np.arange(m0, m0 + count)
-            acc_seeds, acc_rows = [], []
-            for i, s in enumerate(seeds):
-                if not search[s]:
-                    continue
-                for j in range(count):
-                    if ok[i, j] and costs[i, j] < cost0[s] + self.armijo_alpha * lam[j] * dcost0[s]:
-                        acc_seeds.append(s)
-                        acc_rows.append(i * costs.shape[1] + j)
-                        cost1[s] = costs[i, j]
-                        armijo[s] = m0 + j
-                        search[s] = False
-                        break
-            self.accept(acc_seeds, acc_rows)
+            seeds = np.asarray(seeds)
+            # first candidate of every searching seed that converged and satisfies the sufficient-decrease test (doptimizer.py:436-459)
+            with np.errstate(invalid="ignore"):
+                good = ok[:, :count] & (costs[:, :count] < cost0[seeds, None] + self.armijo_alpha * lam[None, :] * dcost0[seeds, None])
+            good &= search[seeds][:, None]
+            hit = good.any(axis=1)
+            j = good.argmax(axis=1)
+            rows_i = np.nonzero(hit)[0]
+            acc_seeds = seeds[rows_i]
+            acc_rows = rows_i * costs.shape[1] + j[rows_i]
+            cost1[acc_seeds] = costs[rows_i, j[rows_i]]
+            armijo[acc_seeds] = m0 + j[rows_i]
+            search[acc_seeds] = False
+            self.accept(list(acc_seeds), list(acc_rows))
             m0 += count
         # a seed whose search is exhausted is where the reference raises ConvergenceError("Armijo Failed to
         # Converge") (doptimizer.py:456-459); here it is flagged and left unchanged, the other seeds carry on
