@@ -25,6 +25,6 @@ v = np.array(list(out)[:12], dtype=float)
 print("B=%d  kernel %.2f ms (%.0f /s); cycles of trajectory 0 after the deriv1 solve: %.3e" % (B, ms, B / ms * 1e3, v.sum()))
 NAMES = ["constraints: H22 pairs (DDh at q2)", "midpoint evaluation", "third-order body triples", "HZ assembly + store",
          "constraints: seed, w = Kinv' r, sweep q1 + attach", "constraints: prefix / suffix sums along the paths", "constraints: H11 pairs (w-contracted DDDh)",
-         "constraints: G1", "constraints: sweep q2 + attach"]
+         "constraints: G1", "constraints: sweep q2 + attach", "HZ: staging TB = H22 Y2 per 16-column block", "HZ: tile chains (matrix cores)", "HZ: epilogue + stores"]
 for n_, c in zip(NAMES, v):
     print("  %-46s %12.0f  %5.1f%%" % (n_, c, 100 * c / v.sum()))

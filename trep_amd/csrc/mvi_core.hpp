@@ -3447,6 +3447,7 @@ struct Core {
                     }
                 }
                 TG_SYNC();
+                TG_D2STAMP(9);
                 if (on) for (int at0 = 0; at0 <= bt; at0 += GA) {
                     const int n_at = bt + 1;                      // row tiles of this block column
                     hz4 acc[GA];
@@ -3495,6 +3496,7 @@ struct Core {
                             for (int g = 0; g < GA; g++) if (16 * (at0 + g) < nq && at0 + g < n_at) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g], bw, acc[g], 0, 0, 0);
                         }
                     }
+                    TG_D2STAMP(10);
 #pragma unroll
                     for (int g = 0; g < GA; g++) {
                         if (at0 + g >= n_at) break;
@@ -3516,6 +3518,7 @@ struct Core {
                             }
                         }
                     }
+                    TG_D2STAMP(11);
                 }
                 TG_SYNC();
             }

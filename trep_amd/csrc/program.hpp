@@ -10,6 +10,7 @@
 // (item, item) pairs, constraint end points and constraint-Jacobian items.
 #pragma once
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <algorithm>
 #include <cstring>
@@ -562,7 +563,9 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.d_o_AUG = take(P.nf * P.d_aug_ld);
     {   // chunks of bodies for the prefix-sum form of the third-order body terms; scratch = the dead pose union
         P.o_tps = P.o_sc;
-        const int cap = (P.o_dqi + nitems) - P.o_sc;
+        // from the start of the pose / Newton-matrix union to the end of the base region, plus the two full-width constraint Jacobians
+        // that follow it (dead after the KKT matrix's constant blocks)
+        const int cap = (P.lds_per_team - P.o_sc) + (P.d_o_AUG - P.d_o_Dh1);
         H.tchunk.clear();
         H.tchunk.push_back(0);
         int b = 0;
@@ -576,6 +579,25 @@ inline HostProgram build_program(const tg_system_desc *d) {
             if (b1 == b) fits = false; else { H.tchunk.push_back(b1); b = b1; }
         }
         if (!fits) { H.tchunk.clear(); H.tchunk.push_back(0); }
+        if (fits && H.tchunk.size() > 2) {
+            // same number of chunks, but cut where the (item, item) pair counts balance (the pair loop runs in passes of 64 or 128
+            // lanes per chunk: two chunks of 221 pairs are four passes of two waves, 287 + 155 are five); kept if every chunk fits
+            const int n_c = (int)H.tchunk.size() - 1, total = H.b_pair_off[nb];
+            std::vector<int> cut(1, 0);
+            for (int ci = 1; ci < n_c; ci++) {
+                const long long target = (long long)total * ci / n_c;
+                int b1 = cut.back() + 1;
+                while (b1 < nb - (n_c - ci) && std::llabs((long long)H.b_pair_off[b1 + 1] - target) < std::llabs((long long)H.b_pair_off[b1] - target)) b1++;
+                cut.push_back(b1);
+            }
+            cut.push_back(nb);
+            bool ok_cut = true;
+            for (int ci = 0; ci < n_c; ci++) {
+                const int items = H.b_item_off[cut[ci + 1]] - H.b_item_off[cut[ci]];
+                if (cut[ci + 1] <= cut[ci] || 18 * (items + (cut[ci + 1] - cut[ci])) > cap) ok_cut = false;
+            }
+            if (ok_cut) H.tchunk = cut;
+        }
         P.n_tchunk = (int)H.tchunk.size() - 1;
     }
     {   // two-part pair lists of the helper-wave kernels
