@@ -75,6 +75,21 @@ __device__ __forceinline__ double *tg_lds_base() {
 }
 #endif
 
+// Which trajectory a workgroup of a rollout launch takes.  The dispatcher deals workgroups round-robin to the eight XCDs (workgroup b runs on
+// XCD b % 8) and, inside an XCD, round-robin to its 32 CUs.  With the identity mapping and eight Armijo candidates per seed, candidate j of
+// EVERY seed therefore ran on XCD j, and inside an XCD candidate j sat on the same few CUs: the large steps fail after a few dozen DEL steps,
+// the small ones run the whole horizon, so three XCDs (then: 12 of 32 CUs) did all the full-length projections at full occupancy while the
+// rest of the chip idled.  tg_xcd_block transposes twice: XCD x takes the x-th CONTIGUOUS eighth of the blocks, and the i-th workgroup of an
+// XCD (CU i % 32, its (i / 32)-th resident workgroup) the (i / 32)-th block of that CU's contiguous share -- the eight workgroups resident on
+// a CU are eight NEIGHBOURING trajectories (all candidates of one seed: they also share its gain schedule and reference in that CU's L1 and
+// that XCD's L2).  A bijection on [0, G) for every G.
+TG_HD int tg_xcd_block(int b, int G) {
+    const int q = G >> 3, r = G & 7, x = b & 7, i = b >> 3;
+    const int n = q + (x < r ? 1 : 0);                      // blocks of this XCD
+    const int q2 = n >> 5, r2 = n & 31, u = i & 31, s_ = i >> 5;
+    return x * q + (x < r ? x : r) + u * q2 + (u < r2 ? u : r2) + s_;
+}
+
 // The lane index is laundered through an empty asm at the head of every phase loop: the optimiser then
 // cannot hoist lane-derived addresses and table look-ups of ALL phases out of the Newton / step loops
 // (which made it keep hundreds of loop-invariant values alive and spill).

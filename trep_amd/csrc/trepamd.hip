@@ -41,7 +41,8 @@ __global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DE
     // that the compiler would hoist, keep alive for the whole rollout and spill into VGPR lanes.
     tg::CProg &P = *(tg::CProg *)Pg;
     const int team = threadIdx.x / TEAM, lane = threadIdx.x % TEAM;
-    const int traj = blockIdx.x * (64 / TEAM) + team;
+    const int block = MODE == tg::MODE_ROLLOUT ? tg_xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int traj = block * (64 / TEAM) + team;
     const int stride = MODE == tg::MODE_DERIV2Z ? P.e_lds_per_team : (MODE == tg::MODE_DERIV1 ? P.d_lds_per_team : (MODE == tg::MODE_DYN_DERIV1 ? P.g_lds_per_team : P.lds_per_team));
     tg::run_trajectory<TEAM, MODE, SPRINGS>(P, A, lds + (size_t)team * stride, lane, traj);
 }
