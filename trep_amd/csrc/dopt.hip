@@ -489,8 +489,104 @@ __device__ __forceinline__ void lq_gj_rows(const double *G_generic, int ldw, int
     }
 }
 
+// The same elimination in two parts, so that the 18 dependent pivot steps (search -> reciprocal -> multipliers) are done ONCE per Riccati
+// step instead of once per wavefront.  lq_factor_rows: the matrix alone (one row per lane): pivot lane and multipliers of every step go to
+// LDS -- the multiplier of (row i, step k) over the dead entry G[i][k], the pivot lanes / solved columns / reciprocal pivots to `fac`
+// (32 doubles dinv | 32 ints solved column per row | NR ints pivot lane per step).  lq_apply_rows: a wave replays the steps on its slice of
+// right-hand sides: per step one multiplier read, and per column two v_readlane + one FMA.  Same operations in the same order per column
+// as lq_gj_rows: the results are bit-identical.
+template <int NR>
+__device__ __forceinline__ void lq_factor_rows(double *G_generic, int ldw, int nU, int lane, double *fac_generic, int *sing) {
+    typedef __attribute__((address_space(3))) double lds_double;
+    typedef __attribute__((address_space(3))) int lds_int;
+    lds_double *G = (lds_double *)G_generic, *dinv_s = (lds_double *)fac_generic;
+    lds_int *col_s = (lds_int *)(dinv_s + 32), *piv_s = col_s + 32;
+    const bool mine = lane < nU, ident = lane >= nU && lane < NR;
+    double m[NR];
+#pragma unroll
+    for (int j = 0; j < NR; j++) m[j] = mine ? (j < nU ? G[lane * ldw + j] : 0.0) : ((ident && j == lane) ? 1.0 : 0.0);
+    int mycol = -1;
+    double diag = 1.0;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < NR; k++) if (k < nU) {      // (steps nU .. NR-1 are the identity block: they change nothing; a uniform branch per unrolled step)
+        const bool free_row = (mine || ident) && mycol < 0;
+        const float cand = free_row ? (float)fabs(m[k]) : 0.0f;
+        unsigned int key = (__float_as_uint(cand) & ~0x3Fu) | (unsigned int)(63 - lane);
+        key = max(key, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)key, 0x111, 0xf, 0xf, true));
+        key = max(key, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)key, 0x112, 0xf, 0xf, true));
+        key = max(key, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)key, 0x114, 0xf, 0xf, true));
+        key = max(key, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)key, 0x118, 0xf, 0xf, true));
+        const unsigned int best = max((unsigned int)__builtin_amdgcn_readlane((int)key, 15), (unsigned int)__builtin_amdgcn_readlane((int)key, 31));
+        const int src = 63 - (int)(best & 0x3Fu);
+        if (!(__uint_as_float(best & ~0x3Fu) > 0.0f)) ok = false;
+        auto bcast = [&](double v) -> double {
+            const long long w = __double_as_longlong(v);
+            const int lo = __builtin_amdgcn_readlane((int)(w & 0xFFFFFFFFLL), src), hi = __builtin_amdgcn_readlane((int)(w >> 32), src);
+            return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        };
+        const bool is_piv = lane == src;
+        const double piv = bcast(m[k]);
+        double inv = __builtin_amdgcn_rcp(piv);
+        { const double e = fma(-piv, inv, 1.0); inv = fma(inv, fma(e, e, e), inv); }
+        const double l = (ok && !is_piv) ? m[k] * inv : 0.0;
+#pragma unroll
+        for (int j = k + 1; j < NR; j += 2) {
+            const double p0 = bcast(m[j]), p1 = bcast(m[j + 1 < NR ? j + 1 : j]);
+            m[j] = fma(-l, p0, m[j]);
+            if (j + 1 < NR) m[j + 1] = fma(-l, p1, m[j + 1]);
+        }
+        if (is_piv) { mycol = k; diag = m[k]; }
+        if (mine) G[lane * ldw + k] = l;
+        if (lane == 0) piv_s[k] = src;
+    }
+    if (!ok && lane == 0) *sing = 1;
+    if (lane < 32) { col_s[lane] = mycol; dinv_s[lane] = 1.0 / diag; }
+}
+
+template <int NR, int SL>
+__device__ __forceinline__ void lq_apply_rows(const double *G_generic, int ldw, int nU, int rhs_lo, int rhs_n, double *Ks_generic, int ldx,
+                                              double *Cs_generic, int lane, const double *fac_generic) {
+    typedef __attribute__((address_space(3))) double lds_double;
+    typedef __attribute__((address_space(3))) int lds_int;
+    const lds_double *G = (const lds_double *)G_generic, *dinv_s = (const lds_double *)fac_generic;
+    const lds_int *col_s = (const lds_int *)(dinv_s + 32), *piv_s = col_s + 32;
+    lds_double *Ks = (lds_double *)Ks_generic, *Cs = (lds_double *)Cs_generic;
+    const bool mine = lane < nU;
+    double b[SL];
+#pragma unroll
+    for (int c = 0; c < SL; c++) b[c] = (mine && c < rhs_n) ? G[lane * ldw + nU + rhs_lo + c] : 0.0;
+    for (int k = 0; k < nU; k++) {
+        const int src = __builtin_amdgcn_readfirstlane(piv_s[k]);
+        const double l = mine ? G[lane * ldw + k] : 0.0;
+        auto bcast = [&](double v) -> double {
+            const long long w = __double_as_longlong(v);
+            const int lo = __builtin_amdgcn_readlane((int)(w & 0xFFFFFFFFLL), src), hi = __builtin_amdgcn_readlane((int)(w >> 32), src);
+            return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        };
+#pragma unroll
+        for (int c = 0; c < SL; c += 2) {
+            const double p0 = bcast(b[c]), p1 = bcast(b[c + 1 < SL ? c + 1 : c]);
+            b[c] = fma(-l, p0, b[c]);
+            if (c + 1 < SL) b[c + 1] = fma(-l, p1, b[c + 1]);
+        }
+    }
+    const int mycol = lane < 32 ? col_s[lane] : -1;
+    if (mine && mycol >= 0 && mycol < nU) {
+        const double dinv = dinv_s[lane];
+#pragma unroll
+        for (int c = 0; c < SL; c++) {
+            if (c < rhs_n) {
+                const int g = rhs_lo + c;
+                const double x = b[c] * dinv;
+                if (g == 0) Cs[mycol] = x; else Ks[mycol * ldx + g - 1] = x;
+            }
+        }
+    }
+}
+
 struct LqLayout {   // LDS layout of k_tv_lq_mfma in doubles
-    int ldx, nUp, ldw, Pm, Am, Bm, Kp, Ks, G, bv, bn, wv, rv, scr, total;
+    int ldx, nUp, ldw, Pm, Am, Bm, Kp, Ks, G, bv, bn, wv, rv, scr, fac, total;
     __host__ __device__ LqLayout(int nX, int nU) {
         ldx = round_up(nX, 16); nUp = round_up(nU, 4); ldw = nU + 1 + ldx;
         int o = 0;
@@ -499,6 +595,7 @@ struct LqLayout {   // LDS layout of k_tv_lq_mfma in doubles
         Ks = o; o += (nUp * ldx > ldx * nUp ? nUp * ldx : ldx * nUp);   // K_k [nUp][ldx]; before the solve: P B [ldx][nUp]
         G = o; o += nU * ldw; bv = o; o += ldx; bn = o; o += ldx; wv = o; o += nUp; rv = o; o += nUp;
         scr = o; o += nU > 32 ? (LQM_T / 64) * 3 * round_up(nU, 4) : 0;     // scratch of lq_gj_wave (more than 32 inputs) only
+        fac = o; o += nU <= 32 ? 32 + 16 + 16 : 0;                          // lq_factor_rows: reciprocal pivots, solved column per row, pivot lane per step
         total = o;
     }
 };
@@ -514,7 +611,7 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
     constexpr int ldx = 16 * NT, NTILES = NT * NT, NW = LQM_T / 64, TMAX = (NTILES + NW - 1) / NW;
     const int nUp = L.nUp, ldw = L.ldw, NUT = (nU + 15) >> 4;
     double *Pm = lds + L.Pm, *Am = lds + L.Am, *Bm = lds + L.Bm, *Kp = lds + L.Kp, *Ks = lds + L.Ks, *PB = Ks, *G = lds + L.G;
-    double *bv = lds + L.bv, *bn = lds + L.bn, *wv = lds + L.wv, *rv = lds + L.rv, *scr = lds + L.scr + wave * 3 * NR;
+    double *bv = lds + L.bv, *bn = lds + L.bn, *wv = lds + L.wv, *rv = lds + L.rv, *scr = lds + L.scr + wave * 3 * NR, *fac = lds + L.fac;
     for (int i = tid; i < L.total; i += LQM_T) lds[i] = 0.0;
     if (tid == 0) s_sing = 0;
     __syncthreads();
@@ -628,6 +725,25 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
             }
         }
         __syncthreads();
+        // The upper-triangle tiles of the new P that this wave owns (phases 3 / 4).  (Loading their weights Q_k here, a phase early, takes the
+        // load latency off the tile chains -- 16.5 k -> 7 k cycles -- but the factorising wave needs ~20 k anyway, and the accumulators live
+        // through phase 2b cost phase 1 its registers: 38.4 instead of 35.6 us per step.)
+        constexpr bool SPLIT = NR <= 32;
+        constexpr int NTRI = NT * (NT + 1) / 2, TW = SPLIT ? NW - 1 : NW, TSYM = (NTRI + TW - 1) / TW;
+        static_assert(TSYM <= TMAX, "accumulator array too small for the upper-triangle tiles");
+        const double *Qk = a.Q_dev + (size_t)s * a.Q_seed_stride + (size_t)k * a.Q_step_stride;
+        int ti_[TMAX], tj_[TMAX];
+        bool ok_[TMAX];
+#pragma unroll
+        for (int i = 0; i < TMAX; i++) {
+            const int t = wave + TW * i;
+            ok_[i] = i < TSYM && t < NTRI && wave < TW;
+            // t-th tile of the upper triangle, row by row: row r holds NT - r tiles
+            int tr = 0, tt = ok_[i] ? t : 0;
+#pragma unroll
+            for (int r = 0; r < NT; r++) if (tt >= NT - r && tr == r) { tt -= NT - r; tr = r + 1; }
+            ti_[i] = tr; tj_[i] = tr + tt;
+        }
         // ---- phase 2b: gamma = R + B'(P B), Kpart = B'(P A) + S' -> [gamma | r + B'b | Kpart] ------------------------
         for (int t = wave; t < NUT * (NUT + NT); t += NW) {
             const int tu = t / (NUT + NT), tc = t % (NUT + NT), u = 16 * tu + lr;
@@ -664,45 +780,15 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
         if (tid < nU && !bb_in_tile) { const double rw = affine ? wv[tid] + rv[tid] : 0.0; rv[tid] = rw; G[tid * ldw + nU] = rw; }   // r_k + B'b
         __syncthreads();
         LQ_STAMP(1);
-        // ---- phase 3: [C | K] = gamma^-1 [. | .]: every wave its quarter of the right-hand sides, no barrier inside ------
-        {
-            const int lo = wave * slice, n = lo < rhs_total ? (rhs_total - lo < slice ? rhs_total - lo : slice) : 0;
-#if defined(TG_LQ_COLUMN_SOLVE)
-            lq_gj_wave<NR>(G, ldw, nU, lo, n, Ks, ldx, wv, scr, lane, &s_sing);
-#else
-            if (NR <= 32) lq_gj_rows<NR, (16 * NT + 1 + NW - 1) / NW>(G, ldw, nU, lo, n, Ks, ldx, wv, lane, &s_sing);
-            else lq_gj_wave<NR>(G, ldw, nU, lo, n, Ks, ldx, wv, scr, lane, &s_sing);
-#endif
-        }
-        LQ_STAMP(6);
-        for (int o = tid; o < (nUp - nU) * ldx; o += LQM_T) Ks[nU * ldx + o] = 0.0;   // padding rows (the buffer held P B)
-        __syncthreads();
-        LQ_STAMP(2);
-        double *Cs = wv;
-        // ---- phase 4: outputs K_k, C_k; new P tiles = Q + A'(P A) - Kpart' K (registers); new b ----------------------
-        {
-            double *Ko = a.K_dev + (sN + k) * (size_t)nU * nX;
-            for (int o = tid; o < nU * nX; o += LQM_T) Ko[o] = Ks[(o / nX) * ldx + o % nX];
-            if (a.C_dev && tid < nU) a.C_dev[(sN + k) * nU + tid] = Cs[tid];
-        }
-        const double *Qk = a.Q_dev + (size_t)s * a.Q_seed_stride + (size_t)k * a.Q_step_stride;
-        // The new P is symmetric (Q_k, A'(P A) with symmetric P, Kpart' gamma^-1 Kpart): only the NT (NT + 1) / 2 tiles on and above the
-        // diagonal are computed -- the sweep is bound by the matrix cores' throughput, and this is a quarter of its MFMAs -- and
-        // phase 6 mirrors them instead of averaging the two triangles.
-        constexpr int NTRI = NT * (NT + 1) / 2, TSYM = (NTRI + NW - 1) / NW;
-        {
-            int ti_[TMAX], tj_[TMAX];
-            bool ok_[TMAX];
+        // ---- phase 3 / 4 ----------------------------------------------------------------------------------------------------
+        // The new P tiles = Q + A'(P A) - Kpart' K are symmetric (Q_k, A'(P A) with symmetric P, Kpart' gamma^-1 Kpart): only the
+        // NT (NT + 1) / 2 tiles on and above the diagonal are computed, phase 6 mirrors them.  Up to 32 inputs: the LAST wave factorises
+        // gamma (lq_factor_rows: the 18 dependent pivot steps once per step, not once per wave) WHILE the other waves accumulate
+        // Q + A'(P A) -- that part does not need the gains --; then every wave replays the steps on its slice of the right-hand
+        // sides (lq_apply_rows) and the tile owners add -Kpart' K.  More inputs: every wave solves its slice itself (lq_gj_wave).
+        auto tiles_q_apa = [&]() {      // acc = Q_k (+ curvature) + A'(P A)
 #pragma unroll
             for (int i = 0; i < TMAX; i++) {
-                const int t = wave + NW * i;
-                ok_[i] = i < TSYM && t < NTRI;
-                // t-th tile of the upper triangle, row by row: row r holds NT - r tiles
-                int tr = 0, tt = ok_[i] ? t : 0;
-#pragma unroll
-                for (int r = 0; r < NT; r++) if (tt >= NT - r && tr == r) { tt -= NT - r; tr = r + 1; }
-                ti_[i] = tr; tj_[i] = tr + tt;
-                // the weights Q_k (+ curvature) first: their global-memory latency hides behind the MFMA chains
                 v4d c = zero4;
                 const int col = 16 * tj_[i] + lr;
 #pragma unroll
@@ -726,6 +812,8 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
 #pragma unroll
                 for (int i = 0; i < TMAX; i++) if (ok_[i]) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bw[i], acc[i], 0, 0, 0);
             }
+        };
+        auto tiles_minus_kpk = [&]() {  // acc -= Kpart' K
             for (int u0 = 0; u0 < nUp; u0 += 4) {
                 double av[TMAX], bw[TMAX];
 #pragma unroll
@@ -736,7 +824,32 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
 #pragma unroll
                 for (int i = 0; i < TMAX; i++) if (ok_[i]) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bw[i], acc[i], 0, 0, 0);
             }
+        };
+        const int lo = wave * slice, nrhs = lo < rhs_total ? (rhs_total - lo < slice ? rhs_total - lo : slice) : 0;
+        if constexpr (SPLIT) {
+            if (wave == NW - 1) lq_factor_rows<NR>(G, ldw, nU, lane, fac, &s_sing);
+            else tiles_q_apa();
+            LQ_STAMP(6);
+            for (int o = tid; o < (nUp - nU) * ldx; o += LQM_T) Ks[nU * ldx + o] = 0.0;   // padding rows (the buffer held P B)
+            __syncthreads();
+            lq_apply_rows<NR, (16 * NT + 1 + NW - 1) / NW>(G, ldw, nU, lo, nrhs, Ks, ldx, wv, lane, fac);
+            __syncthreads();
+            LQ_STAMP(2);
+        } else {
+            lq_gj_wave<NR>(G, ldw, nU, lo, nrhs, Ks, ldx, wv, scr, lane, &s_sing);
+            LQ_STAMP(6);
+            for (int o = tid; o < (nUp - nU) * ldx; o += LQM_T) Ks[nU * ldx + o] = 0.0;   // padding rows (the buffer held P B)
+            __syncthreads();
+            LQ_STAMP(2);
+            tiles_q_apa();
         }
+        double *Cs = wv;
+        {   // outputs K_k, C_k
+            double *Ko = a.K_dev + (sN + k) * (size_t)nU * nX;
+            for (int o = tid; o < nU * nX; o += LQM_T) Ko[o] = Ks[(o / nX) * ldx + o % nX];
+            if (a.C_dev && tid < nU) a.C_dev[(sN + k) * nU + tid] = Cs[tid];
+        }
+        tiles_minus_kpk();
         if (affine) for (int i = tid; i < nX; i += LQM_T) {     // new b = q_k + A'b - K'(r_k + B'b): four independent chains (the LDS reads in flight together)
             double v0 = a.q_dev[(sN + s + k) * nX + i], v1 = 0.0, v2 = 0.0, v3 = 0.0;
             int m = 0;
@@ -754,15 +867,10 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
         LQ_STAMP(3);
         // ---- phase 5: P <- new tiles, b <- new b, next A, B into LDS ---------------------------------------------
 #pragma unroll
-        for (int i = 0; i < TSYM; i++) {
-            const int t = wave + NW * i;
-            if (t < NTRI) {
-                int tr = 0, tt = t;
+        for (int i = 0; i < TMAX; i++) {
+            if (ok_[i]) {
 #pragma unroll
-                for (int r = 0; r < NT; r++) if (tt >= NT - r && tr == r) { tt -= NT - r; tr = r + 1; }
-                const int ti = tr, tj = tr + tt;
-#pragma unroll
-                for (int r = 0; r < 4; r++) Pm[(16 * ti + lk + 4 * r) * ldx + 16 * tj + lr] = acc[i][r];
+                for (int r = 0; r < 4; r++) Pm[(16 * ti_[i] + lk + 4 * r) * ldx + 16 * tj_[i] + lr] = acc[i][r];
             }
         }
         if (affine) for (int i = tid; i < nX; i += LQM_T) bv[i] = bn[i];
