@@ -31,7 +31,8 @@ def lib():
         so = os.path.join(_HERE, "emu", "libtrepamd_emu.so")
         srcs = [os.path.join(_HERE, "emu", "emu.cpp"),
                 os.path.join(_ROOT, "trep_amd", "csrc", "mvi_core.hpp"),
-                os.path.join(_ROOT, "trep_amd", "csrc", "program.hpp")]
+                os.path.join(_ROOT, "trep_amd", "csrc", "program.hpp"),
+                os.path.join(_ROOT, "trep_amd", "csrc", "bbd.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]], check=True)
         L = ctypes.CDLL(so)

@@ -1,0 +1,125 @@
+// bbd_solve.hpp -- device part of the structured Newton solve (plan and rationale: bbd.hpp).  Included by mvi_core.hpp after
+// tg_rcp; device pass only.
+#pragma once
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+namespace tg {
+
+// lane k of every 16-lane row broadcast to the row (DPP row_newbcast; K is a compile-time constant)
+template <int K>
+__device__ __forceinline__ double bbd_bcast(double v) {
+    return __longlong_as_double(__builtin_amdgcn_update_dpp((long long)0, __double_as_longlong(v), 0x150 + K, 0xf, 0xf, true));
+}
+// a += l * (lane K's b)
+template <int K>
+__device__ __forceinline__ void bbd_fmac(double &a, double b, double l) {
+#if defined(TG_BBD_ASM)
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(b), "v"(l), "n"(K));
+#else
+    a = fma(l, bbd_bcast<K>(b), a);
+#endif
+}
+
+// One Gauss-Jordan step on column K of a row-per-lane block held in registers a[0 .. NCOL): every lane of a 16-lane row except
+// lane K subtracts its multiple of lane K's row.  Columns < K are already eliminated (only the pivot lanes hold them) and column
+// K itself is not touched (the pivot lane keeps its pivot, the others' entries are dead).  `first` .. `last`: the live columns.
+// rp_out: 1 / pivot (every lane computes it); bad: set on the pivot lane if the pivot fails its guard.
+template <int K, int NCOL>
+__device__ __forceinline__ void bbd_step(double (&a)[NCOL], int r, double guard, double &myrp, bool &bad) {
+    const double p = bbd_bcast<K>(a[K]);
+    const double rp = tg_rcp(p);
+    const bool is_piv = r == K;
+    bad = bad || (is_piv && !(fabs(a[K]) > guard));
+    myrp = is_piv ? rp : myrp;
+    const double l = is_piv ? 0.0 : -a[K] * rp;
+#pragma unroll
+    for (int j = K + 1; j < NCOL; j++) bbd_fmac<K>(a[j], a[j], l);
+}
+template <int K, int KEND, int NCOL>
+__device__ __forceinline__ void bbd_steps(double (&a)[NCOL], int r, double guard, double &myrp, bool &bad) {
+    if constexpr (K < KEND) {
+        bbd_step<K, NCOL>(a, r, guard, myrp, bad);
+        bbd_steps<K + 1, KEND, NCOL>(a, r, guard, myrp, bad);
+    }
+}
+
+// Solve the dense image A [NF][LD] (right-hand side in column NF) along the plan staged in LDS at `tab` (BbdPlan::tab).
+// scratch: T * (T + 1) + T doubles of LDS outside the image.  Returns true and leaves x_i in A[i][NF] if every guard held;
+// otherwise returns false with the image untouched.
+template <int NF, int LD, int NG, int NB, int T, class TVAR>
+__device__ __noinline__ bool gj_bbd(double *A_generic, const int *tab_generic, double *scratch_generic, int lane, TVAR tvar) {
+    typedef __attribute__((address_space(3))) double lds_double;
+    typedef __attribute__((address_space(3))) const int lds_int;
+    lds_double *A = (lds_double *)A_generic, *U = (lds_double *)scratch_generic, *XT = U + T * (T + 1);
+    lds_int *tab = (lds_int *)tab_generic;
+    constexpr int NCOL = NG + NB + 1, UL = T + 1;
+    constexpr double GUARD = 9.5367431640625e-07;   // 2^-20
+    const int g = lane >> 4, r = lane & 15;
+    const int wl = tab[lane];
+    const int row = (wl & 0xFF) - 1, trow = ((wl >> 8) & 0xFF) - 1, timg = ((wl >> 16) & 0xFF) - 1;
+    int wc[NG + NB];
+#pragma unroll
+    for (int j = 0; j < NG + NB; j++) wc[j] = tab[64 + 16 * g + j];
+    // ---- stage 0: registers.  own rows: everything; border rows: the own columns only (the rest accumulates the Schur update)
+    double a[NCOL];
+    const bool own = r < NG, have = row >= 0;
+    const int ro = (have ? row : 0) * LD;
+    double amax = 0.0;
+#pragma unroll
+    for (int j = 0; j < NCOL; j++) {
+        const int col = j < NG + NB ? (wc[j] & 0xFF) - 1 : NF;
+        const bool ld_ = have && col >= 0 && (own || j < NG);
+        const double v = A[ro + (col >= 0 ? col : 0)];
+        a[j] = ld_ ? v : ((own && !have && j == r) ? 1.0 : 0.0);
+        if (j < NG + NB) amax = fmax(amax, fabs(a[j]));
+    }
+    // the trailing system: lane i < T of the first row holds row tvar[i]
+    double tr[T + 1];
+    const bool tl = lane < T;
+    const int to = (tl ? timg : 0) * LD;
+    double tmax = 0.0;
+#pragma unroll
+    for (int j = 0; j <= T; j++) {
+        const double v = A[to + (j < T ? tvar[j] : NF)];
+        tr[j] = tl ? v : ((lane < 16 && j == lane) ? 1.0 : 0.0);
+        if (j < T) tmax = fmax(tmax, fabs(tr[j]));
+    }
+    for (int e = lane; e < T * UL; e += 64) U[e] = 0.0;
+    // ---- stage 1: the groups' own columns
+    double myrp = 0.0;
+    bool bad = false;
+    bbd_steps<0, NG, NCOL>(a, r, GUARD * amax, myrp, bad);
+    // ---- stage 2: Schur updates of the border rows into U, then the trailing system
+    if (trow >= 0) {
+#pragma unroll
+        for (int j = NG; j < NCOL; j++) {
+            const int tc = j < NG + NB ? ((wc[j] >> 8) & 0xFF) - 1 : T;
+            if (tc >= 0) __hip_atomic_fetch_add((double *)(U + trow * UL + tc), a[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    asm volatile("" ::: "memory");
+    double trp = 0.0;
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j <= T; j++) { const double u = U[(tl ? lane : 0) * UL + j]; tr[j] += tl ? u : 0.0; }
+        bbd_steps<0, T, T + 1>(tr, r, GUARD * tmax, trp, bad);
+        if (tl) XT[lane] = tr[T] * trp;
+    }
+    if (__any(bad ? 1 : 0)) return false;
+    asm volatile("" ::: "memory");
+    // ---- stage 3: solutions.  trailing variables straight, own variables by back-substitution from the border's
+    if (tl) A[to + NF] = tr[T] * trp;
+    if (own && have) {
+        double s = a[NG + NB];
+#pragma unroll
+        for (int j = NG; j < NG + NB; j++) {
+            const int tc = ((wc[j] >> 8) & 0xFF) - 1;
+            s = fma(-a[j], XT[tc >= 0 ? tc : 0], s);     // (a border column that does not exist holds zeros)
+        }
+        A[ro + NF] = s * myrp;
+    }
+    __syncthreads();
+    return true;
+}
+
+}  // namespace tg
+#endif

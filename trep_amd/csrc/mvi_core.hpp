@@ -138,8 +138,13 @@ __device__ __forceinline__ unsigned int tg_max_u32_lanes32(unsigned int v) {
     return a > b ? a : b;
 }
 #endif
+#include <type_traits>
+#include "bbd_solve.hpp"
 
 namespace tg {
+// the structured Newton solve needs its plan as compile-time constants: system-specialised schedules (SpecProg: static members) only
+template <class P, class = void> struct tg_static_bbd { static constexpr bool value = false; };
+template <class P> struct tg_static_bbd<P, typename std::enable_if<(P::bbd_ok >= 0)>::type> { static constexpr bool value = P::bbd_ok != 0; };
 
 enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3, MODE_DERIV2Z = 4, MODE_DYNAMICS = 5, MODE_DYN_DERIV1 = 6, MODE_ENERGY = 7, MODE_LAGRANGIAN = 8 };
 
@@ -398,10 +403,16 @@ struct Core {
     // Chain schedule of the sweep in LDS (written once per kernel): for round r and slot s < 16 two words,
     // (12 * first joint | chain length << 16) and 12 * parent joint (or -1: the world), length 0 for an empty slot.
     // Keeps global-memory look-ups (and their latency) out of the sweep.
-    TG_HD void init_sweep_schedule() {
+    TG_HD void init_sweep_schedule(bool rollout = false) {
         PROG &P = tg_fresh(this->P);
         TG_FOR(i, 4 * P.n_bodies) S[P.o_I + i] = P.b_inertia[i];   // body inertias: LDS copy for the whole kernel
         TG_FOR(c, P.nc) S[P.o_ctol + c] = P.c_tol[c];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_BBD)
+        if constexpr (TEAM == 64 && tg_static_bbd<typename std::remove_cv<PROG>::type>::value) {
+            // plan tables of the structured Newton solve (bbd.hpp): staged once per rollout kernel behind the base region
+            if (rollout) { int *tab = (int *)(S + P.o_bbd); TG_FOR(i, 128) tab[i] = P.bbd_tab[i]; }
+        }
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
         if (TEAM == 64 && P.tab_ok) {
             // Lane order of the 2 x n_joints (pose set, joint) items of the sin/cos pass: the rotary joints of both pose sets first,
@@ -4039,7 +4050,7 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
     if (A.dt_steps && A.dt_period > 0) dt = A.dt_steps[t % (size_t)A.dt_period];   // per-trajectory step size (k-parallel linearisation)
     Core<TEAM, SPRINGS, PROG> core(P, S, lane, dt);
     core.wave = wave; core.nw = nw;
-    if (wave == 0) core.init_sweep_schedule();
+    if (wave == 0) core.init_sweep_schedule(MODE == MODE_ROLLOUT);
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     core.prof_last = (long long)__builtin_amdgcn_s_memtime();
 #endif
@@ -4194,7 +4205,19 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
             bool ok;
 #if defined(__HIP_DEVICE_COMPILE__)
             const int nb4 = (P.nf + 3) >> 2;   // matrix size in blocks of 4 rows
-            if (TEAM >= 4 && 4 * nb4 <= TEAM && nb4 <= 8) {
+            bool bbd_done = false;
+#if !defined(TG_NO_BBD)
+            if constexpr (TEAM == 64 && PIVOT == 0 && tg_static_bbd<typename std::remove_cv<PROG>::type>::value) {
+                // structured solve along the system's bordered-block-diagonal plan (bbd.hpp): no pivot search; a failed pivot guard
+                // leaves the image untouched and the pivoting solver below takes over (a full-wave team: done is false here and
+                // the branch is uniform).  Scratch: the Jacobian columns, dead between the matrix's assembly and the next evaluation.
+                typedef typename std::remove_cv<PROG>::type SP;
+                bbd_done = gj_bbd<SP::nf, SP::df_ld, SP::bbd_ng, SP::bbd_nb, SP::bbd_t>(S + P.o_Df, (const int *)(S + P.o_bbd), S + P.o_J, lane, P.bbd_tvar);
+                ok = true;
+            }
+#endif
+            if (bbd_done) { }
+            else if (TEAM >= 4 && 4 * nb4 <= TEAM && nb4 <= 8) {
                 double *Ad = S + P.o_Df;
                 if (PIVOT < 0 ? A.exact_pivot != 0 : PIVOT == 1) {
                 switch (nb4) {

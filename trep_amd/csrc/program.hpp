@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/trep_amd.h"
+#include "bbd.hpp"
 
 namespace tg {
 
@@ -125,6 +126,12 @@ struct DevProg {
     const double *cs_c0;          // [nq] 1/2 sum k q0^2 (constant part of V)
     // NonlinearConfigSpring: per spring (config, first table row, pieces), (m, b); table rows (left knot, a, b, c, d, e, f) per piece
     const int *ncs_i; const double *ncs_mb, *ncs_tab; int n_ncs;
+    // structured Newton solve of the system-specialised rollout kernels (bbd.hpp): groups, largest own block, largest border list,
+    // trailing size; the plan tables (bbd_tab [128], bbd_tvar [16]) and the LDS offset they are staged at (rollout kernels only:
+    // the slice's last 64 doubles, which the derivative layouts overlay)
+    int bbd_ok, bbd_g, bbd_ng, bbd_nb, bbd_t, o_bbd;
+    int bbd_tvar[16];         // image index of trailing variable i
+    const int *bbd_tab;
 };
 
 struct HostProgram {
@@ -141,7 +148,7 @@ struct HostProgram {
     std::vector<double> c_dist, c_tol;
     std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
     std::vector<double> damp, cs_k, cs_kq0, cs_c0, s_k, s_x0, s_c, c_nloc, wr_const, wr_Rloc, ncs_mb, ncs_tab;
-    std::vector<int> ncs_i;
+    std::vector<int> ncs_i, bbd_tab;
     std::vector<int> wr_in, wr_kind;
     std::vector<int> cf_cfg, cf_in;
     std::vector<double> jcoef;      // [n_joints*16*4] local-transform coefficients (see pose_sweep)
@@ -661,6 +668,33 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.e_o_wT = take(P.n_wpair); P.e_o_Hu = take(nw ? nq * P.nu : 0);   // point forces: w-contracted F.d3p per pair, -dt/2 w.F_dudq [nq][nu]
     off = std::max(off, P.d_lds_per_team);
     P.e_lds_per_team = (off + 1) & ~1;
+    {   // structured Newton solve: structural pattern of [[Df11, -Dh1^T], [Dh2, 0]] (newton_matrix in mvi_core.hpp writes exactly these
+        // entries) -> bordered-block-diagonal plan.  Full-wave systems of the size gj_panel serves; the solver's scratch (trailing
+        // system + border solution) lives in the dead J / W area.
+        const int nf = P.nf;
+        H.bbd_tab.assign(128, 0);
+        for (int i = 0; i < 16; i++) P.bbd_tvar[i] = 0;
+        P.bbd_ok = 0; P.bbd_g = P.bbd_ng = P.bbd_nb = P.bbd_t = 0; P.o_bbd = 0;
+        if (nf >= 17 && nf <= 31 && nd >= 2) {
+            std::vector<unsigned char> pat((size_t)nf * nf, 0);
+            auto mark = [&](int i, int j) { if (i < nf && j < nf) { pat[(size_t)i * nf + j] = 1; pat[(size_t)j * nf + i] = 1; } };
+            for (int i = 0; i < nd; i++) mark(i, i);
+            for (int n = 0; n < P.n_npairs; n++) mark(H.pair4[4 * n + 2] & 0xFFFF, H.pair4[4 * n + 2] >> 16);
+            for (int n = 0; n < n_dh_con; n++) if (H.dh_cfg[n] < nd) mark(H.dh_cfg[n], nd + H.dh_c[n]);
+            for (size_t n = (size_t)n_cpair_con; n < H.cpair4.size() / 4; n++) {   // two-point springs / dampers, point forces
+                const int ka = H.cpair4[4 * n + 3] & 0xFFFF, kb = H.cpair4[4 * n + 3] >> 16;
+                if (ka < nd && kb < nd) mark(ka, kb);
+            }
+            const BbdPlan plan = bbd_plan(nf, nd, pat);
+            if (plan.ok && plan.t * (plan.t + 2) <= 12 * nitems) {
+                P.bbd_ok = 1; P.bbd_g = plan.g; P.bbd_ng = plan.ng; P.bbd_nb = plan.nb; P.bbd_t = plan.t;
+                H.bbd_tab.assign(plan.tab, plan.tab + 128);
+                for (int i = 0; i < 16; i++) P.bbd_tvar[i] = plan.tvar[i];
+                P.o_bbd = P.lds_per_team;      // behind the base region; the derivative layouts (which start there) do not keep it
+                P.lds_per_team += 64;
+            }
+        }
+    }
     H.pack();
     return H;
 }
@@ -682,7 +716,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
     X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in) X(wr_kind) X(ncs_i) \
-    X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4)
+    X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4) X(bbd_tab)
 #define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c) X(wr_Rloc) X(ncs_mb) X(ncs_tab)
 
 inline void HostProgram::pack() {

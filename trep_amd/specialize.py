@@ -28,7 +28,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 CACHE = os.path.join(_HERE, "_spec")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-_SOURCES = ["spec_kernel.hip", "mvi_core.hpp", "program.hpp"]
+_SOURCES = ["spec_kernel.hip", "mvi_core.hpp", "program.hpp", "bbd.hpp", "bbd_solve.hpp"]
 DEFAULT_FLAGS = "-DSPEC_ARGS_IN_MEMORY -DSPEC_DERIVATIVES -DTG_GJ_INLINE -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp"
 
 
