@@ -268,6 +268,20 @@ int tg_batch_set_step_sizes(tg_batch *b, int32_t count, const double *dt_host, i
  * rule through gj_panel, 16 < n < 32) and reports which original row served as pivot of each column; status TG_OK or TG_SINGULAR. */
 int tg_batch_set_pivot_rule(tg_batch *b, int32_t exact);
 int tg_debug_solve(int32_t device, int32_t n, int32_t exact, const double *A_aug_host, double *x_host, int32_t *pivot_rows_host, int32_t *status_host);
+/* Structured Newton solve (csrc/bbd.hpp; system-specialised rollout kernels, default pivot rule).  The reference factors the dense
+ * matrix with a pivot search per column (midpointvi.c:720-733 -> math-code.c:337-461).  For a tree mechanism the matrix
+ * [[Df11, -Dh1^T], [Dh2, 0]] is bordered block diagonal -- the limbs couple only through the trunk's configs and the constraints --
+ * and Df11 = -M/dt + O(dt) needs no pivot search: the schedule compiler derives the blocks from the matrix's structural pattern,
+ * the kernel eliminates the blocks side by side on 16-lane DPP rows, then the dense border system (configs first, constraints
+ * last), and back-substitutes.  Every pivot is guarded (|pivot| > 2^-20 of its row's largest entry); a failed guard hands the
+ * untouched matrix to the pivoting solver above, so singular systems are reported exactly as before.
+ * tg_batch_debug_newton_solve (test hook) runs that solve -- as compiled into the batch's loaded specialised library -- on
+ * n_mats caller-supplied systems [nf][nf + 1]; path[m] = 1 structured, 2 pivoting solver (guard failed, no plan, or
+ * skip_structured != 0), -1 singular. */
+/* tg_system_newton_plan (host only): out[0..7] = plan found, groups, largest own block, largest border list, trailing size, nf, nd, 0;
+ * pattern (optional, [nf * nf]): structural non-zeros of the Newton matrix (symmetrised); tab (optional, [128]): packed plan tables. */
+int tg_system_newton_plan(const tg_system *sys, int32_t out[8], uint8_t *pattern, int32_t *tab);
+int tg_batch_debug_newton_solve(tg_batch *b, int32_t n_mats, int32_t skip_structured, const double *A_aug_host, double *x_host, int32_t *path_host);
 
 /* System-specialised rollout kernel.  The reference interprets the frame tree at run time; the generic kernels here
  * interpret a flat schedule.  For long rollouts of one system the schedule can instead be compiled into the kernel:

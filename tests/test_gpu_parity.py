@@ -886,3 +886,114 @@ def test_small_batch_step_mirror_is_invalidated_by_every_other_write():
     a.rollout(3, DT, np.repeat(U[:, None, :], 3, axis=1), None)
     assert not np.array_equal(a.q2, q_step)        # the rollout's state, not the mirrored step's
     a.close(); b.close()
+
+
+def _newton_plan(mvi):
+    from trep_amd import _lib
+    L = _lib.lib()
+    out = np.zeros(8, dtype=np.int32)
+    _lib.check(L.tg_system_newton_plan(mvi._sys_h, out.ctypes.data, None, None))
+    nf = int(out[5])
+    pat = np.zeros((nf, nf), dtype=np.uint8)
+    tab = np.zeros(128, dtype=np.int32)
+    _lib.check(L.tg_system_newton_plan(mvi._sys_h, out.ctypes.data, pat.ctypes.data, tab.ctypes.data))
+    return dict(ok=int(out[0]), groups=int(out[1]), ng=int(out[2]), nb=int(out[3]), t=int(out[4]), nf=nf, nd=int(out[6])), pat.astype(bool), tab
+
+
+def _kernel_newton_solve(mvi, aug, skip_structured=False):
+    from trep_amd import _lib
+    aug = np.ascontiguousarray(aug, dtype=float)
+    n, nf = aug.shape[0], aug.shape[1]
+    x = np.zeros((n, nf)); path = np.zeros(n, dtype=np.int32)
+    _lib.check(_lib.lib().tg_batch_debug_newton_solve(mvi._h, n, 1 if skip_structured else 0, aug.ctypes.data, x.ctypes.data, path.ctypes.data))
+    return x, path
+
+
+def _newton_like(rng, pat, nd, dt=0.01):
+    """A matrix with the structure of the DEL Newton matrix (midpointvi.c:577-670): -M/dt + O(1) on the config block (M symmetric
+    positive definite with the pattern's sparsity), Dh2 / -Dh1^T borders with Dh1 close to Dh2, zero constraint block."""
+    nf = len(pat)
+    L = rng.standard_normal((nd, nd)) * pat[:nd, :nd]
+    M = 0.2 * (L + L.T) * pat[:nd, :nd]
+    M[np.arange(nd), np.arange(nd)] = np.abs(M).sum(axis=1) + 0.5 + rng.random(nd)       # diagonally dominant: positive definite
+    A = np.zeros((nf, nf))
+    A[:nd, :nd] = -M / dt + 0.3 * rng.standard_normal((nd, nd)) * pat[:nd, :nd]
+    D = rng.standard_normal((nf - nd, nd)) * pat[nd:, :nd]
+    A[nd:, :nd] = D
+    A[:nd, nd:] = -(D + 1e-3 * rng.standard_normal(D.shape) * pat[nd:, :nd]).T
+    return A
+
+
+@pytest.mark.parametrize("name", ["puppet40", "puppet_basic", "scissor4"])
+def test_structured_newton_solve_matches_the_pivoting_solvers(name):
+    """The structured solve of the specialised rollout kernels (csrc/bbd.hpp: blocks of the bordered-block-diagonal plan eliminated
+    side by side without a pivot search, then the border system, then back-substitution) against the reference's LU_decomp /
+    LU_solve_vec (math-code.c:337-461, the oracle's restatement) and numpy on matrices with the system's own Newton pattern; the
+    same systems through the kernel's pivoting solver; a zero pivot inside a block (nonsingular matrix: the guard hands over to
+    the pivoting solver, same solution); a singular matrix (reported singular, as before)."""
+    import trep_amd
+    system, _ = build(name)
+    mvi = trep_amd.BatchMidpointVI(system, 1, specialize=True)
+    plan, pat, tab = _newton_plan(mvi)
+    assert plan["ok"] == 1 and plan["groups"] >= 2, plan
+    nf, nd = plan["nf"], plan["nd"]
+    rng = np.random.default_rng(2024)
+    mats = [_newton_like(rng, pat, nd) for _ in range(48)]
+    rhs = [rng.standard_normal(nf) * np.where(np.arange(nf) < nd, 1.0, 1e-3) for _ in mats]
+    aug = np.array([np.hstack([A, b[:, None]]) for A, b in zip(mats, rhs)])
+    x, path = _kernel_newton_solve(mvi, aug)
+    assert (path == 1).all(), path
+    x2, path2 = _kernel_newton_solve(mvi, aug, skip_structured=True)
+    assert (path2 == 2).all(), path2
+    for A, b, xs, xp in zip(mats, rhs, x, x2):
+        rc, xo, _ = _oracle_lu(A, b)
+        assert rc == 0
+        xn = np.linalg.solve(A, b)
+        scale = np.abs(xn).max()
+        assert np.abs(xs - xo).max() < 1e-10 * scale and np.abs(xs - xn).max() < 1e-10 * scale, (np.abs(xs - xo).max(), scale)
+        assert np.abs(xp - xo).max() < 1e-10 * scale
+        res = np.abs(A.dot(xs) - b).max() / (np.abs(A).sum(axis=1).max() * np.abs(xs).max() + np.abs(b).max())
+        assert res < 1e-13, res
+    # a zero pivot inside a block: rows / columns of two coupled own configs carry a [[0, m], [m, 0]] block (nonsingular)
+    own = [((tab[i] & 0xFF) - 1) for i in range(16) if i < plan["ng"] and (tab[i] & 0xFF)]
+    a, c = [(i, j) for i in own for j in own if i < j and pat[i, j]][0]
+    A = mats[0].copy(); b = rhs[0]
+    A[a, a] = 0.0; A[c, c] = 0.0; A[a, c] = A[c, a] = -300.0
+    xg, pg = _kernel_newton_solve(mvi, np.hstack([A, b[:, None]])[None])
+    assert pg[0] == 2, pg
+    xn = np.linalg.solve(A, b)
+    assert np.abs(xg[0] - xn).max() < 1e-10 * np.abs(xn).max()
+    # a tiny but non-zero pivot (2^-30 of the row's scale) must not be accepted either
+    A = mats[1].copy(); b = rhs[1]
+    A[a, a] = -300.0 * 2.0 ** -30; A[a, c] = A[c, a] = -300.0
+    xg, pg = _kernel_newton_solve(mvi, np.hstack([A, b[:, None]])[None])
+    xn = np.linalg.solve(A, b)
+    assert pg[0] == 2 and np.abs(xg[0] - xn).max() < 1e-9 * np.abs(xn).max(), (pg, np.abs(xg[0] - xn).max())
+    # singular: the last constraint's force direction is zero (a zero column)
+    A = mats[2].copy(); b = rhs[2]
+    A[:, nf - 1] = 0.0
+    _, ps = _kernel_newton_solve(mvi, np.hstack([A, b[:, None]])[None])
+    rc, _, _ = _oracle_lu(A, b)
+    assert ps[0] == -1 and rc != 0, (ps, rc)
+
+
+def test_structured_newton_solve_is_what_the_rollout_runs():
+    """The puppet rollout with the structured solve (default) and with the pivoting solver (exact pivot rule: the structured solve
+    is compiled out of that kernel) take the same number of Newton iterations and agree to 1e-10 over 200 steps."""
+    import trep_amd
+    from trep_amd import systems
+    system, _ = build("puppet40")
+    B, N = 64, 200
+    Q0 = systems.puppet_initial_conditions(system, B, seed=5)
+    K = systems.puppet_string_schedule(system, Q0[:, system.nQd:], N, DT)
+    out = []
+    for exact in (False, True):
+        mvi = trep_amd.BatchMidpointVI(system, B, specialize=True)
+        mvi.exact_pivot = exact
+        mvi.initialize_from_configs(0.0, Q0, DT, Q0)
+        X = mvi.rollout(N, DT, None, K)
+        it, st = mvi.status()
+        assert (st == 0).all()
+        out.append((X, it))
+    assert relerr(out[0][0], out[1][0]) < TOL
+    assert np.abs(out[0][1] - out[1][1]).max() <= 1, (out[0][1], out[1][1])

@@ -89,6 +89,8 @@ _SIGNATURES = {
     "tg_batch_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "tg_batch_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _c_ip, _c_dp]),
     "tg_debug_solve": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "tg_system_newton_plan": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "tg_batch_debug_newton_solve": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "tg_batch_set_pivot_rule": (ctypes.c_int, [_vp, _i32]),
     "tg_batch_set_step_sizes": (ctypes.c_int, [_vp, _i32, _vp, _i32]),
     "tg_system_spec_header": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64]),

@@ -149,6 +149,7 @@ struct HostProgram {
     std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
     std::vector<double> damp, cs_k, cs_kq0, cs_c0, s_k, s_x0, s_c, c_nloc, wr_const, wr_Rloc, ncs_mb, ncs_tab;
     std::vector<int> ncs_i, bbd_tab;
+    std::vector<unsigned char> newton_pattern;   // [nf * nf] structural non-zeros of the Newton matrix (symmetrised), host side only
     std::vector<int> wr_in, wr_kind;
     std::vector<int> cf_cfg, cf_in;
     std::vector<double> jcoef;      // [n_joints*16*4] local-transform coefficients (see pose_sweep)
@@ -685,6 +686,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
                 const int ka = H.cpair4[4 * n + 3] & 0xFFFF, kb = H.cpair4[4 * n + 3] >> 16;
                 if (ka < nd && kb < nd) mark(ka, kb);
             }
+            H.newton_pattern = pat;
             const BbdPlan plan = bbd_plan(nf, nd, pat);
             if (plan.ok && plan.t * (plan.t + 2) <= 12 * nitems) {
                 P.bbd_ok = 1; P.bbd_g = plan.g; P.bbd_ng = plan.ng; P.bbd_nb = plan.nb; P.bbd_t = plan.t;

@@ -48,6 +48,39 @@ double *lds = tg_lds_base();
     tg::run_trajectory<SPEC_TEAM, MODE, SPEC_SPRINGS, const SpecProg, std::remove_reference<decltype(A)>::type, PIVOT>(P, A, lds + (size_t)team * stride, lane, traj, wave, spec_waves<MODE>());
 }
 
+// Test hook: the Newton-system solve of this library's rollout kernel (default pivot rule) on caller-supplied matrices [nf][nf + 1],
+// one workgroup per matrix, in the rollout kernel's own LDS layout: the structured solve along the compiled-in plan if the system
+// has one (bbd.hpp), the pivoting solver if a pivot guard fails.  path: 1 structured, 2 pivoting solver, -1 singular.
+__global__ __launch_bounds__(64) void k_spec_debug_solve(const double *A_in, double *x_out, int *path_out, int skip_structured) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double *S = tg_lds_base();
+    const SpecProg P{};
+    constexpr int nf = SpecProg::nf, ld = SpecProg::df_ld, nb4 = (nf + 3) >> 2;
+    const int lane = threadIdx.x;
+    const double *src = A_in + (size_t)blockIdx.x * nf * (nf + 1);
+    for (int e = lane; e < nf * ld; e += 64) S[P.o_Df + e] = 0.0;
+    __syncthreads();
+    for (int e = lane; e < nf * (nf + 1); e += 64) S[P.o_Df + (e / (nf + 1)) * ld + e % (nf + 1)] = src[e];
+    int path = 0;
+    bool ok = false;
+    if constexpr (SPEC_TEAM == 64 && SpecProg::bbd_ok != 0) {
+        int *tab = (int *)(S + P.o_bbd);
+        for (int e = lane; e < 128; e += 64) tab[e] = P.bbd_tab[e];
+        __syncthreads();
+        if (!skip_structured && tg::gj_bbd<nf, ld, SpecProg::bbd_ng, SpecProg::bbd_nb, SpecProg::bbd_t>(S + P.o_Df, tab, S + P.o_J, lane, P.bbd_tvar)) { ok = true; path = 1; }
+    }
+    __syncthreads();
+    if (!ok) {
+        if constexpr (SPEC_TEAM == 64 && nb4 >= 5 && nf <= 31 && 12 * SpecProg::n_items >= 128) ok = tg::Core<64>::gj_panel<4 * nb4>(true, S + P.o_Df, nf, ld, lane, S + P.o_J);
+        else if constexpr (SPEC_TEAM == 64 && nb4 <= 8) ok = tg::Core<64>::gj_rows<4 * nb4>(true, S + P.o_Df, nf, ld, lane);
+        path = ok ? 2 : -1;
+    }
+    __syncthreads();
+    if (lane < nf) x_out[(size_t)blockIdx.x * nf + lane] = S[P.o_Df + lane * ld + nf];
+    if (lane == 0) path_out[blockIdx.x] = path;
+#endif
+}
+
 template <int MODE, int PIVOT = 0>
 int launch_mode(const tg::RunArgs *A, tg::RunArgs *slot, int grid, size_t lds, hipStream_t stream) {
     if (lds > 64 * 1024 &&
@@ -89,6 +122,14 @@ int tg_spec_modes(void) {
     m |= (1 << tg::MODE_DERIV1) | (1 << tg::MODE_DERIV2Z);
 #endif
     return m;
+}
+// (test hook) n_mats systems [nf][nf + 1] in, solutions [nf] and the path taken out; device pointers
+int tg_spec_debug_solve(const double *A_dev, double *x_dev, int *path_dev, int n_mats, int skip_structured) {
+    const size_t lds = sizeof(double) * (size_t)SpecProg::lds_per_team;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spec_debug_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+    hipLaunchKernelGGL(k_spec_debug_solve, dim3(n_mats), dim3(64), lds, 0, A_dev, x_dev, path_dev, skip_structured);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int tg_spec_launch(int mode, const tg::RunArgs *A, tg::RunArgs *device_slot, int grid, size_t lds, void *stream) {
     switch (mode) {

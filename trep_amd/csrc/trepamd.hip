@@ -1116,6 +1116,46 @@ int tg_batch_load_specialized(tg_batch *b, const char *library_path) {
     return TG_SUCCESS;
 }
 
+/* The structured-solve plan of a system (bbd.hpp; host only): out[0..7] = plan found, groups, largest own block, largest border
+ * list, trailing size, nf, nd, 0; pattern (optional, [nf * nf]) the structural non-zeros of the Newton matrix the plan was derived
+ * from (symmetrised; all zero if the system is outside the plan's range); tab (optional, [128]) the packed plan tables. */
+int tg_system_newton_plan(const tg_system *sys, int32_t out[8], uint8_t *pattern, int32_t *tab) {
+    if (!sys || !out) return fail(TG_ERR_INVALID, "null argument");
+    const tg::DevProg &P = sys->H.p;
+    out[0] = P.bbd_ok; out[1] = P.bbd_g; out[2] = P.bbd_ng; out[3] = P.bbd_nb; out[4] = P.bbd_t; out[5] = P.nf; out[6] = P.nd; out[7] = 0;
+    if (pattern) {
+        std::memset(pattern, 0, (size_t)P.nf * P.nf);
+        if (sys->H.newton_pattern.size() == (size_t)P.nf * P.nf) std::memcpy(pattern, sys->H.newton_pattern.data(), sys->H.newton_pattern.size());
+    }
+    if (tab) for (int i = 0; i < 128; i++) tab[i] = i < (int)sys->H.bbd_tab.size() ? sys->H.bbd_tab[i] : 0;
+    return TG_SUCCESS;
+}
+
+/* Test hook (tests/test_gpu_parity.py): the Newton-system solve of the batch's SPECIALISED rollout kernel on caller-supplied
+ * systems [n_mats][nf][nf + 1] (nf = the system's unknowns): the structured solve along the system's plan if it has one (bbd.hpp),
+ * the pivoting solver when a pivot guard fails or skip_structured is set.  path[m]: 1 structured, 2 pivoting, -1 singular. */
+int tg_batch_debug_newton_solve(tg_batch *b, int32_t n_mats, int32_t skip_structured, const double *A_aug_host, double *x_host, int32_t *path_host) {
+    if (!b || n_mats <= 0 || !A_aug_host || !x_host || !path_host) return fail(TG_ERR_INVALID, "bad arguments");
+    if (!b->spec_lib) return fail(TG_ERR_INVALID, "no specialised kernel library loaded");
+    auto fn = reinterpret_cast<int (*)(const double *, double *, int *, int, int)>(dlsym(b->spec_lib, "tg_spec_debug_solve"));
+    if (!fn) return fail(TG_ERR_INVALID, "the specialised library has no solve hook");
+    const int nf = b->P.nf;
+    HIP_TRY(hipSetDevice(b->device));
+    double *dA = nullptr, *dx = nullptr; int *dp = nullptr;
+    HIP_TRY(hipMalloc(&dA, sizeof(double) * (size_t)n_mats * nf * (nf + 1))); HIP_TRY(hipMalloc(&dx, sizeof(double) * (size_t)n_mats * nf));
+    HIP_TRY(hipMalloc(&dp, sizeof(int) * (size_t)n_mats));
+    HIP_TRY(hipMemcpy(dA, A_aug_host, sizeof(double) * (size_t)n_mats * nf * (nf + 1), hipMemcpyHostToDevice));
+    const int rc = fn(dA, dx, dp, n_mats, skip_structured);
+    hipError_t e = hipDeviceSynchronize();
+    if (rc == 0 && e == hipSuccess) {
+        hipMemcpy(x_host, dx, sizeof(double) * (size_t)n_mats * nf, hipMemcpyDeviceToHost);
+        hipMemcpy(path_host, dp, sizeof(int) * (size_t)n_mats, hipMemcpyDeviceToHost);
+    }
+    hipFree(dA); hipFree(dx); hipFree(dp);
+    if (rc != 0 || e != hipSuccess) return fail(TG_ERR_HIP, "solve hook launch failed");
+    return TG_SUCCESS;
+}
+
 /* Which kernels this batch runs: out[0] bit m = mode m (tg::MODE_*) has a specialised kernel loaded; out[1] / out[2] bit m = a
  * mode-m launch has gone through a specialised / a generic kernel since the batch was created; out[3] / out[4] the number of
  * such launches; out[5] pivot rule; out[6] team size; out[7] 0. */
