@@ -30,6 +30,7 @@ namespace {
 // the other's solver (registers, callee-saved spills) in its call graph
 // wavefronts per workgroup: the derivative kernels of a full-wave team run with helper waves (mvi_core.hpp, TG_HELPER_WAVES)
 template <int MODE> constexpr int spec_waves() { return ((MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z) && SPEC_TEAM == 64) ? TG_NW : 1; }
+static_assert(TG_NW >= 1 && TG_NW <= 2, "helper waves: the pair lists of program.hpp are split in exactly two parts (wave_part, wp_* / wt_* / wcp4)");
 static_assert(TG_NW == 1 || SPEC_TEAM == 64, "helper waves are for full-wave teams (trep_amd/specialize.py passes TG_HELPER_WAVES only then)");
 
 template <int MODE, int PIVOT = 0>
@@ -51,7 +52,7 @@ double *lds = tg_lds_base();
 // Test hook: the Newton-system solve of this library's rollout kernel (default pivot rule) on caller-supplied matrices [nf][nf + 1],
 // one workgroup per matrix, in the rollout kernel's own LDS layout: the structured solve along the compiled-in plan if the system
 // has one (bbd.hpp), the pivoting solver if a pivot guard fails.  path: 1 structured, 2 pivoting solver, -1 singular.
-__global__ __launch_bounds__(64) void k_spec_debug_solve(const double *A_in, double *x_out, int *path_out, int skip_structured) {
+__global__ __launch_bounds__(64, 2) void k_spec_debug_solve(const double *A_in, double *x_out, int *path_out, int skip_structured) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double *S = tg_lds_base();
     const SpecProg P{};

@@ -29,7 +29,10 @@ _CSRC = os.path.join(_HERE, "csrc")
 CACHE = os.path.join(_HERE, "_spec")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 _SOURCES = ["spec_kernel.hip", "mvi_core.hpp", "program.hpp", "bbd.hpp", "bbd_solve.hpp"]
-DEFAULT_FLAGS = "-DSPEC_ARGS_IN_MEMORY -DSPEC_DERIVATIVES -DTG_GJ_INLINE -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp"
+# -amdgpu-mfma-vgpr-form: the matrix-core accumulators of the out-of-line solvers (gj_panel) stay in VGPRs.  As AGPRs they are ADDED to the
+# rollout kernel's own 254 VGPRs (288 registers: ONE wave per SIMD instead of two -- 76 instead of 51 ms per benchmark launch)
+DEFAULT_FLAGS = ("-DSPEC_ARGS_IN_MEMORY -DSPEC_DERIVATIVES -DTG_GJ_INLINE -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp "
+                 "-mllvm -amdgpu-mfma-vgpr-form")
 
 
 def header(system, with_key=False):
@@ -57,6 +60,8 @@ def _flags(text=""):
     TREPAMD_HELPER_WAVES=1 turns them off)."""
     flags = os.environ.get("TREPAMD_SPEC_FLAGS", DEFAULT_FLAGS).split()
     waves = int(os.environ.get("TREPAMD_HELPER_WAVES", "2"))
+    if waves not in (1, 2):      # the schedule's pair lists are split in exactly two parts (csrc/program.hpp)
+        raise ValueError("TREPAMD_HELPER_WAVES must be 1 or 2, not %d" % waves)
     if waves > 1 and "#define SPEC_TEAM 64\n" in text and not any(f.startswith("-DTG_HELPER_WAVES") for f in flags):
         flags.append("-DTG_HELPER_WAVES=%d" % waves)
     return flags
