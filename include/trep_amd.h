@@ -399,6 +399,12 @@ typedef struct tg_lq_problem {
     double *b_next_dev;                   /* optional (with q, r): [S][N][nX], row k = b_{k+1}, the affine term entering step k.  With
                                            * the projection weights (Q = R = I) and the cost gradients as q, r this is the adjoint
                                            * z_{k+1} of the Newton model (doptimizer.py:340-343): tg_adjoint_sweep for free */
+    int32_t ds_nd, ds_nk, ds_nu;          /* optional: A_k, B_k have the block structure of DSystem.fdx / fdu (dsystem.py:284-317) for a system with
+                                           * ds_nd dynamic and ds_nk kinematic configs and ds_nu force inputs -- states [Qd | Qk | p | v], inputs
+                                           * [u | rho]: A's Qk rows and v columns are zero and a v row holds one entry (its Qk column); B's Qk and v
+                                           * rows hold one entry each (their rho column).  The sweep then skips those blocks in its matrix products
+                                           * (about half of the matrix-core work at the puppet's sizes); they must hold exact zeros.  ds_nd = 0: dense.
+                                           * Requires nX = 2 (ds_nd + ds_nk), nU = ds_nu + ds_nk. */
 } tg_lq_problem;
 int tg_tv_lq(int32_t device, const tg_lq_problem *problem);
 

@@ -105,6 +105,75 @@ def test_tv_lq_matches_numpy(nX, nU, nxh, N, S):
         pool.close()
 
 
+def _dsystem_structure(rng, A, B, nd, nk, nu, dt=0.01):
+    """Impose the block structure of DSystem.fdx / fdu (dsystem.py:284-317) on random A, B: states [Qd | Qk | p | v], inputs [u | rho]."""
+    nq, nX = nd + nk, 2 * (nd + nk)
+    Qd, Qk, p, v = slice(0, nd), slice(nd, nq), slice(nq, nq + nd), slice(nq + nd, nX)
+    A[..., Qk, :] = 0.0; A[..., v, :] = 0.0; A[..., :, v] = 0.0
+    B[..., Qk, :] = 0.0; B[..., v, :] = 0.0
+    for m in range(nk):
+        steps = dt * (1.0 + 0.3 * rng.random(A.shape[:-2]))       # any time base: the entries are read, not assumed
+        A[..., nq + nd + m, nd + m] = -1.0 / steps
+        B[..., nd + m, nu + m] = 1.0
+        B[..., nq + nd + m, nu + m] = 1.0 / steps
+    return A, B
+
+
+@pytest.mark.parametrize("nd,nk,nu,N,S", [(22, 18, 0, 30, 3), (9, 4, 2, 25, 2), (3, 5, 1, 20, 2), (30, 10, 0, 12, 1), (5, 0, 3, 20, 2)])
+def test_tv_lq_with_dsystem_structure(nd, nk, nu, N, S):
+    """k_tv_lq_mfma with tg_lq_problem::ds_* set: the products skip the zero blocks of DSystem.fdx / fdu (two k-ranges over the dense Qd / p
+    rows, the single-entry Qk / v rows as extra terms, v columns never computed).  Against numpy's dlqr on the same matrices (1e-9) and
+    against the dense sweep of the same kernel (1e-11): LQR, affine LQ and the Newton model with the on-the-fly curvature; the state
+    weights couple every block (a dense Q_k), so P's v rows / columns are exercised too."""
+    from trep_amd import _lib
+    L = _lib.lib()
+    nX, nU, nxh = 2 * (nd + nk), nu + nk, 2 * nd + nk
+    rng = np.random.default_rng(500 + nd)
+    A, B, Q, Qf, R, q, r, hz = _random_problem(rng, S, N, nX, nU, nxh)
+    A, B = _dsystem_structure(rng, A, B, nd, nk, nu)
+    pool = _pool()
+    try:
+        dA, dB, dQ, dQf, dR = pool.upload(A), pool.upload(B), pool.upload(Q), pool.upload(Qf), pool.upload(R)
+        dq, dr, dhz = pool.upload(q), pool.upload(r), pool.upload(hz)
+        for mode in ("lqr", "lq", "newton"):
+            res = {}
+            for structured in (True, False):
+                dK, dC = pool.empty((S, N, nU, nX)), pool.empty((S, N, nU))
+                dP, db, dst = pool.empty((S, nX, nX)), pool.empty((S, nX)), pool.empty((S,), np.int32)
+                p = _lib.LqProblem()
+                p.n_problems, p.horizon, p.nX, p.nU = S, N, nX, nU
+                p.A_dev, p.B_dev = dA.ptr, dB.ptr
+                p.Q_dev, p.Qf_dev, p.R_dev = dQ.ptr, dQf.ptr, dR.ptr
+                p.K_dev, p.C_dev, p.P0_dev, p.b0_dev, p.status_dev = dK.ptr, dC.ptr, dP.ptr, db.ptr, dst.ptr
+                if mode != "lqr":
+                    p.q_dev, p.r_dev = dq.ptr, dr.ptr
+                if mode == "newton":
+                    p.hz_dev, p.hz_R, p.hz_nx = dhz.ptr, nxh + nU, nxh
+                if structured:
+                    p.ds_nd, p.ds_nk, p.ds_nu = nd, nk, nu
+                _lib.check(L.tg_tv_lq(0, ctypes.byref(p)))
+                assert (dst.get() == 0).all()
+                res[structured] = (dK.get(), dC.get(), dP.get(), db.get())
+            for s in range(S):
+                Kh, Ch, Ph, bh = _host_lq(A[s], B[s], Q, Qf, R, None if mode == "lqr" else q[s], None if mode == "lqr" else r[s],
+                                          hz[s] if mode == "newton" else None, nxh)
+                K, C, P0, b0 = (x[s] for x in res[True])
+                assert relerr(K, Kh) < 1e-9 and relerr(P0, Ph) < 1e-9, (mode, s, relerr(K, Kh), relerr(P0, Ph))
+                assert relerr(K, res[False][0][s]) < 1e-11 and relerr(P0, res[False][2][s]) < 1e-11, (mode, s)
+                assert not K[:, nX - nk:].any()       # the v columns of the gains are exactly zero
+                if mode != "lqr":
+                    assert relerr(C, Ch) < 1e-9 and relerr(b0, bh) < 1e-9, (mode, s)
+                    assert relerr(C, res[False][1][s]) < 1e-11 and relerr(b0, res[False][3][s]) < 1e-11
+    finally:
+        pool.close()
+    # sizes that contradict the structure are refused
+    p = _lib.LqProblem()
+    p.n_problems, p.horizon, p.nX, p.nU = 1, 1, nX, nU
+    p.A_dev = p.B_dev = p.Q_dev = p.Qf_dev = p.R_dev = p.K_dev = 8
+    p.ds_nd, p.ds_nk, p.ds_nu = nd + 1, nk, nu
+    assert L.tg_tv_lq(0, ctypes.byref(p)) != 0
+
+
 def test_sweeps_and_cost_match_numpy():
     from trep_amd import _lib
     from trep_amd.discopt import DCost

@@ -17,8 +17,18 @@ for S in (32, 256):
     dA, dB, dQ, dR = pool.upload(A), pool.upload(B), pool.upload(np.eye(nX)), pool.upload(np.eye(nU))
     dq, dr = pool.upload(rng.standard_normal((S, N + 1, nX))), pool.upload(rng.standard_normal((S, N, nU)))
     dK, dC = pool.empty((S, N, nU, nX)), pool.empty((S, N, nU))
-    for affine in (False, True):
+    # the block structure of DSystem.fdx / fdu (puppet: 22 dynamic + 18 kinematic configs): zero Qk rows / v columns of A, single-entry rows
+    nd, nk = 22, 18
+    nq = nd + nk
+    A[:, :, nd:nq, :] = 0.0; A[:, :, nq + nd:, :] = 0.0; A[:, :, :, nq + nd:] = 0.0
+    B[:, :, nd:nq, :] = 0.0; B[:, :, nq + nd:, :] = 0.0
+    for m in range(nk):
+        A[:, :, nq + nd + m, nd + m] = -100.0; B[:, :, nd + m, m] = 1.0; B[:, :, nq + nd + m, m] = 100.0
+    dA.set(A); dB.set(B)
+    for affine, structured in ((False, False), (True, False), (False, True), (True, True)):
         p = _lib.LqProblem()
+        if structured:
+            p.ds_nd, p.ds_nk, p.ds_nu = nd, nk, 0
         p.n_problems, p.horizon, p.nX, p.nU = S, N, nX, nU
         p.A_dev, p.B_dev, p.Q_dev, p.Qf_dev, p.R_dev, p.K_dev, p.C_dev = dA.ptr, dB.ptr, dQ.ptr, dQ.ptr, dR.ptr, dK.ptr, dC.ptr
         if affine:
@@ -30,6 +40,6 @@ for S in (32, 256):
             _lib.check(L.tg_tv_lq(0, ctypes.byref(p)))
             L.tg_device_synchronize(0)
             best = min(best, time.perf_counter() - t0)
-        out["S%d_%s_us_per_k" % (S, "lq" if affine else "lqr")] = round(best / N * 1e6, 2)
+        out["S%d_%s%s_us_per_k" % (S, "lq" if affine else "lqr", "_dsystem" if structured else "")] = round(best / N * 1e6, 2)
     pool.close()
 print(json.dumps(out))

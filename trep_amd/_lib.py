@@ -36,7 +36,8 @@ class LqProblem(ctypes.Structure):
                 ("hz_dev", ctypes.c_void_p), ("hz_R", ctypes.c_int32), ("hz_nx", ctypes.c_int32),
                 ("q_dev", ctypes.c_void_p), ("r_dev", ctypes.c_void_p),
                 ("K_dev", ctypes.c_void_p), ("C_dev", ctypes.c_void_p), ("P0_dev", ctypes.c_void_p), ("b0_dev", ctypes.c_void_p),
-                ("status_dev", ctypes.c_void_p), ("b_next_dev", ctypes.c_void_p)]
+                ("status_dev", ctypes.c_void_p), ("b_next_dev", ctypes.c_void_p),
+                ("ds_nd", ctypes.c_int32), ("ds_nk", ctypes.c_int32), ("ds_nu", ctypes.c_int32)]
 
 
 _vp, _i32, _f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_double

@@ -544,6 +544,62 @@ __device__ __forceinline__ void lq_factor_rows(double *G_generic, int ldw, int n
     if (lane < 32) { col_s[lane] = mycol; dinv_s[lane] = 1.0 / diag; }
 }
 
+// gamma = R_k + B'PB is symmetric and, with a positive definite R_k, positive definite: it can be eliminated in index order without a
+// pivot search.  Same layout as lq_factor_rows (one row per lane, the columns in registers) with the pivot of step k taken from lane k:
+// the broadcasts are v_readlane with a constant lane, and the per-step chain is reciprocal -> multiplier -> first FMA instead of
+// candidate -> four DPP maxima -> two v_readlane -> v_readfirstlane -> reciprocal -> ...  (the pivoted factorisation is ~20 k cycles of
+// the ~70 k of a Riccati step, executed by one wave while seven wait at the barrier).  Every pivot is guarded -- |pivot| must exceed
+// 2^-20 of the largest entry of its row (the Newton model's R_k + HZ_uu can be indefinite far from the optimum) -- and nothing is
+// written before all guards have passed: on failure the caller runs lq_factor_rows on the untouched matrix.  Writes the same tables as
+// lq_factor_rows (pivot lane of step k = k, row i solves column i), so lq_apply_rows replays it unchanged.
+template <int NR>
+__device__ __forceinline__ bool lq_factor_rows_spd(double *G_generic, int ldw, int nU, int lane, double *fac_generic) {
+    typedef __attribute__((address_space(3))) double lds_double;
+    typedef __attribute__((address_space(3))) int lds_int;
+    lds_double *G = (lds_double *)G_generic, *dinv_s = (lds_double *)fac_generic;
+    lds_int *col_s = (lds_int *)(dinv_s + 32), *piv_s = col_s + 32;
+    const bool mine = lane < nU, ident = lane >= nU && lane < NR;
+    double m[NR], amax = 0.0;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        m[j] = mine ? (j < nU ? G[lane * ldw + j] : 0.0) : ((ident && j == lane) ? 1.0 : 0.0);
+        amax = fmax(amax, fabs(m[j]));
+    }
+    const double guard = 9.5367431640625e-07 * amax;   // 2^-20 of the row's largest entry
+    double myinv = 1.0;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < NR; k++) if (k < nU) {
+        auto bcast = [&](double v) -> double {
+            const long long w = __double_as_longlong(v);
+            const int lo = __builtin_amdgcn_readlane((int)(w & 0xFFFFFFFFLL), k), hi = __builtin_amdgcn_readlane((int)(w >> 32), k);
+            return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        };
+        const bool is_piv = lane == k;
+        bad = bad || (is_piv && !(fabs(m[k]) > guard));
+        const double piv = bcast(m[k]);
+        double inv = __builtin_amdgcn_rcp(piv);
+        { const double e = fma(-piv, inv, 1.0); inv = fma(inv, fma(e, e, e), inv); }
+        const double l = is_piv ? 0.0 : m[k] * inv;
+#pragma unroll
+        for (int j = k + 1; j < NR; j += 2) {
+            const double p0 = bcast(m[j]), p1 = bcast(m[j + 1 < NR ? j + 1 : j]);
+            m[j] = fma(-l, p0, m[j]);
+            if (j + 1 < NR) m[j + 1] = fma(-l, p1, m[j + 1]);
+        }
+        myinv = is_piv ? inv : myinv;
+        m[k] = is_piv ? m[k] : l;           // column k is dead below and above the pivot: keep the multiplier there
+    }
+    if (__any(bad ? 1 : 0)) return false;
+    if (mine) {
+#pragma unroll
+        for (int k = 0; k < NR; k++) if (k < nU) G[lane * ldw + k] = lane == k ? 0.0 : m[k];
+    }
+    if (lane < nU) piv_s[lane] = lane;
+    if (lane < 32) { col_s[lane] = lane < nU ? lane : -1; dinv_s[lane] = myinv; }
+    return true;
+}
+
 template <int NR, int SL>
 __device__ __forceinline__ void lq_apply_rows(const double *G_generic, int ldw, int nU, int rhs_lo, int rhs_n, double *Ks_generic, int ldx,
                                               double *Cs_generic, int lane, const double *fac_generic) {
@@ -897,6 +953,517 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
     if (a.P0_dev) for (int e = tid; e < nX * nX; e += LQM_T) a.P0_dev[(size_t)s * nX * nX + e] = Pm[(e / nX) * ldx + e % nX];
     if (a.b0_dev && affine) for (int i = tid; i < nX; i += LQM_T) a.b0_dev[(size_t)s * nX + i] = bv[i];
     if (a.status_dev && tid == 0) a.status_dev[s] = s_sing ? TG_SINGULAR : TG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The same sweep for problems with the block structure of DSystem.fdx / fdu (tg_lq_problem::ds_*; reference
+// trep/discopt/dsystem.py:284-317): states [Qd | Qk | p | v], inputs [u | rho].  A_k has dense rows for Qd and p only
+// (over the Q and p columns); its Qk rows and v columns are zero and a v row holds one entry, A[v_m][Qk_m] (= -1/dt).
+// B_k has dense Qd / p rows; a Qk row and a v row hold one entry each, in column rho_m.  So
+//   * only the dense rows are staged: AD [KC][ldc], KC = 2 round_up(nd, 4) "compact" rows -- the Qd block padded to a multiple of four
+//     with the first Qk rows (zero rows), then the p block padded with the first v rows -- ldc = 16 NTC columns covering Q and p.
+//     Every k-loop of the dense kernel (20 steps at nX = 80) becomes KC / 4 steps (12), every A-shaped result has NTC (4) instead of
+//     NT (5) column tiles: 622 instead of 1355 matrix-core instructions per Riccati step at the puppet's sizes;
+//   * the single-entry rows that are not among the compact rows enter as one or two extra terms per output element;
+//   * the v columns of P A, Kpart and K are zero and are never computed; the v rows / columns of the new P are those of Q_k;
+//   * AD is double buffered and filled by global_load_lds_dwordx4 -- global memory straight into LDS, no staging registers (the dense
+//     kernel holds A_{k-1}, B_{k-1} in 40 VGPRs through the whole step and is the worse for it: 67 spilled VGPRs) and no commit pass;
+//     B_k is dead after the gamma / Kpart tiles and is refilled in place the same way; inside a step the barriers only order LDS
+//     traffic (no vmcnt wait: the loads of step k-1 have the whole of step k to land), the step's last barrier waits for them;
+//   * gamma = R_k + B'PB is factorised without a pivot search (lq_factor_rows_spd), the pivoted factorisation being the fallback;
+//   * Kpart is kept once, as the right-hand-side block of G.
+// Same arithmetic otherwise (the products sum the same non-zero terms in compact-row order).
+// ------------------------------------------------------------------------------------------------------
+struct LqDsLayout {
+    int ldx, nUp, ldw, nd4, KC, ldc, lda, Pm, AD, adsz, Bm, avs, Ks, G, bv, bn, wv, rv, rn, fac, total;
+    __host__ __device__ LqDsLayout(int ldx_, int nU, int nd, int nq) {
+        ldx = ldx_; nUp = round_up(nU, 4); ldw = nU + 1 + ldx; nd4 = round_up(nd, 4); KC = 2 * nd4; ldc = 16 * ((nq + nd + 15) >> 4);
+        // row stride of AD: a ds_read_b64 serves lanes 0-31 (two rows of 16 doubles) in one cycle if the rows sit in opposite halves of the
+        // 64 banks, i.e. stride = 16 mod 32 doubles (ldx = 80 is; ldc = 64 is not: the padding columns are never loaded)
+        lda = (ldc % 32 == 16) ? ldc : ldc + 16;
+        int o = 0;
+        Pm = o; o += ldx * ldx;
+        adsz = round_up(KC * lda, 128); AD = o; o += 2 * adsz;            // two buffers, each a whole number of 1 KB load instructions
+        Bm = o; o += round_up(ldx * nU, 128);
+        avs = o; o += 64;                                                   // A[v_m][Qk_m], two buffers of 32 (nk <= 31)
+        Ks = o; o += nUp * ldx;                                             // K_k [nUp][ldx]; before the solve: P B [ldx][nUp]
+        G = o; o += nUp * ldw;
+        bv = o; o += ldx; bn = o; o += ldx; wv = o; o += nUp; rv = o; o += nUp; rn = o; o += nUp;
+        fac = o; o += 32 + 16 + 16;
+        total = o;
+    }
+};
+
+// Barrier inside a step: orders the waves' plain LDS traffic only.  A workgroup-scope release fence would also wait for the
+// global_load_lds fills in flight (they write LDS, so the compiler counts them in: s_waitcnt vmcnt(0) -- ~8 k cycles at the first
+// barrier after their issue); those land in the OTHER buffer and are awaited by the step's last barrier (__syncthreads).
+#define LQ_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// gamma's factorisation as a CALL: one wave of eight runs it, and inlined its 2 x 20 matrix registers (unpivoted attempt + pivoted fallback)
+// are part of the sweep kernel's register allocation (158 spilled VGPRs)
+template <int NR>
+__device__ __noinline__ void lq_factor_call(double *G, int ldw, int nU, int lane, double *fac, int *sing) {
+    // (arguments of a call travel in vector registers: say that the sizes are wave-uniform, or every `k < nU` becomes a divergent branch)
+    ldw = __builtin_amdgcn_readfirstlane(ldw); nU = __builtin_amdgcn_readfirstlane(nU);
+    if (!lq_factor_rows_spd<NR>(G, ldw, nU, lane, fac)) lq_factor_rows<NR>(G, ldw, nU, lane, fac, sing);
+}
+
+// Launch arguments re-read per phase: the struct sits at the head of the kernel-argument segment; reading it through a laundered
+// constant-address-space pointer at the head of every phase keeps its ~40 scalars -- and everything derived from them -- from being
+// hoisted out of the step loop and held (then spilled: 416 SGPR spills, 90 VGPRs) for the whole sweep.  K$-resident scalar loads.
+typedef const __attribute__((address_space(4))) tg_lq_problem KLq;
+__device__ __forceinline__ KLq &lq_fresh_args() {
+    KLq *p = (KLq *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *p;
+}
+// Everything a phase of k_tv_lq_ds derives from the arguments (sizes, LDS offsets, structure helpers), declared at the head of each phase
+#define LQ_DS_PHASE                                                                                                                   \
+    KLq &a = lq_fresh_args();                                                                                                         \
+    const int nX = a.nX, nU = a.nU, N = a.horizon;                                                                                    \
+    const int nd = a.ds_nd, nq = a.ds_nd + a.ds_nk, nu = a.ds_nu, nv0 = nq + nd;                                                      \
+    const LqDsLayout L(ldx, nU, nd, nq);                                                                                              \
+    const int nUp = L.nUp, ldw = L.ldw, NUT = (nU + 15) >> 4, nd4 = L.nd4, KC = L.KC, ldc = L.ldc, lda = L.lda, NTC = ldc >> 4, mx = nd4 - nd; \
+    double *Pm = lds + L.Pm, *Bm = lds + L.Bm, *Ks = lds + L.Ks, *PB = Ks, *G = lds + L.G;                                            \
+    double *bv = lds + L.bv, *bn = lds + L.bn, *wv = lds + L.wv, *rv = lds + L.rv, *fac = lds + L.fac;                                \
+    const size_t sN = (size_t)s * N;                                                                                                  \
+    const bool affine = a.q_dev != nullptr;                                                                                           \
+    const int nxh = a.hz_nx, hzR = a.hz_R;                                                                                            \
+    const double *AD = lds + L.AD + cur * L.adsz, *avs = lds + L.avs + cur * 32;                                                      \
+    const double *hz = a.hz_dev ? a.hz_dev + (sN + k) * (size_t)hzR * hzR : nullptr;                                                  \
+    const bool bb_in_tile = affine && nUp > nU;                                                                                       \
+    /* global row / P column of compact row cr */                                                                                     \
+    auto grow = [&](int cr) { return cr < nd4 ? cr : nq + (cr - nd4); };                                                              \
+    /* single-entry rows outside the compact rows: v row of Qk column j of A; Qk / v rows of rho column u of B (or -1) */             \
+    auto a_extra = [&](int j) { return (j >= nd + mx && j < nq) ? nv0 + (j - nd) : -1; };                                             \
+    auto b_extra_q = [&](int u) { return (u >= nu + mx && u < nU) ? nd + (u - nu) : -1; };                                            \
+    auto b_extra_v = [&](int u) { return (u >= nu + mx && u < nU) ? nv0 + (u - nu) : -1; };                                           \
+    /* global memory -> LDS, 16 bytes per lane, 1 KB per wave instruction; the instructions of a fill are dealt to the waves */       \
+    auto fill_AD = [&](int kk, double *dst) {                                                                                         \
+        const double *Ak = a.A_dev + (sN + kk) * (size_t)nX * nX;                                                                     \
+        const int npairs = (KC * lda) >> 1;                                                                                           \
+        for (int i = wave; i * 64 < npairs; i += NW) {                                                                                \
+            const int e = 2 * (i * 64 + lane), row = e / lda, col = e - row * lda, gr = grow(row);                                    \
+            if (e < 2 * npairs && gr < nX && col < ldc && col < nX)                                                                   \
+                __builtin_amdgcn_global_load_lds((gl_void *)(Ak + (size_t)gr * nX + col), (lds_void *)(dst + i * 128), 16, 0, 0);     \
+        }                                                                                                                             \
+    };                                                                                                                                \
+    auto fill_B = [&](int kk) {                                                                                                       \
+        const double *Bk = a.B_dev + (sN + kk) * (size_t)nX * nU;                                                                     \
+        const int npairs = (nX * nU) >> 1;                                                                                            \
+        for (int i = wave; i * 64 < npairs; i += NW) {                                                                                \
+            const int e = 2 * (i * 64 + lane);                                                                                        \
+            if (e < 2 * npairs) __builtin_amdgcn_global_load_lds((gl_void *)(Bk + e), (lds_void *)(Bm + i * 128), 16, 0, 0);          \
+        }                                                                                                                             \
+    };                                                                                                                                \
+    auto load_av = [&](int kk) { return tid < nq - nd ? a.A_dev[((sN + kk) * (size_t)nX + nv0 + tid) * nX + nd + tid] : 0.0; };       \
+    (void)N; (void)nu; (void)lda; (void)nUp; (void)ldw; (void)NUT; (void)KC; (void)NTC; (void)Pm; (void)PB; (void)G; (void)bv; (void)bn; (void)wv; (void)rv; (void)fac; \
+    (void)nxh; (void)AD; (void)avs; (void)hz; (void)bb_in_tile
+
+template <int NT, int NR>
+__global__ __launch_bounds__(LQM_T) void k_tv_lq_ds(const tg_lq_problem a0) {
+    extern __shared__ double lds[];
+    __shared__ int s_sing;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void gl_void;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    constexpr int ldx = 16 * NT, NW = LQM_T / 64;
+    const int s = __builtin_amdgcn_readfirstlane(a0.select_dev ? a0.select_dev[blockIdx.x] : (int)blockIdx.x);
+    int cur = 0, k = a0.horizon - 1;
+    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+    constexpr int T1 = 4;                              // chains per wave in phase 1 (P A and P B tiles in one list: at most 32 tiles, see tg_tv_lq)
+    constexpr int NTRI = NT * (NT + 1) / 2, TW = NW - 1, TSYM = (NTRI + TW - 1) / TW;
+    constexpr int TMAX = T1 > TSYM ? T1 : TSYM;
+    v4d acc[TMAX];
+    {
+        LQ_DS_PHASE;
+        for (int i = tid; i < L.total; i += LQM_T) lds[i] = 0.0;
+        if (tid == 0) s_sing = 0;
+        __syncthreads();
+        const double *Qf = a.Qf_dev + (size_t)s * a.Qf_seed_stride;
+        for (int e = tid; e < nX * nX; e += LQM_T) Pm[(e / nX) * ldx + e % nX] = Qf[e];
+        if (affine) for (int i = tid; i < nX; i += LQM_T) bv[i] = a.q_dev[(sN + s + N) * nX + i];
+        fill_AD(N - 1, lds + L.AD);
+        fill_B(N - 1);
+        if (tid < nq - nd) lds[L.avs + tid] = load_av(N - 1);
+        if (affine && tid < nU) lds[L.rn + tid] = a.r_dev[(sN + N - 1) * nU + tid];
+        __syncthreads();
+    }
+    // the upper-triangle tiles of the new P that this wave owns in phases 3 .. 5 (wave 0 factorises gamma meanwhile)
+    int ti_[TSYM], tj_[TSYM];
+    bool ok_[TSYM], mm_[TSYM];
+    {
+        LQ_DS_PHASE;
+#pragma unroll
+        for (int i = 0; i < TSYM; i++) {
+            const int t = (wave - 1) + TW * i;
+            ok_[i] = t < NTRI && wave > 0;
+            int tr = 0, tt = ok_[i] ? t : 0;
+#pragma unroll
+            for (int r = 0; r < NT; r++) if (tt >= NT - r && tr == r) { tt -= NT - r; tr = r + 1; }
+            ti_[i] = tr; tj_[i] = tr + tt;
+            mm_[i] = ok_[i] && tr + tt < NTC;       // tiles in the v columns are Q_k alone
+        }
+    }
+#if defined(TG_PROFILE)
+    long long lq_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lq_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    for (; k >= 0; k--) {
+        double pav = 0.0, prn = 0.0;      // A[v_m][Qk_m] and r of step k - 1: requested at the head of the step, committed at its end
+        {   // ---- phase 1: T = P A (NT x NTC tiles) and P B (NT x NUT tiles) as one list of chains ------------------------------------------
+            LQ_DS_PHASE;
+            if (k > 0) { fill_AD(k - 1, lds + L.AD + (cur ^ 1) * L.adsz); pav = load_av(k - 1); if (affine && tid < nU) prn = a.r_dev[(sN + k - 1) * nU + tid]; }
+            if (a.b_next_dev && affine) for (int i = tid; i < nX; i += LQM_T) a.b_next_dev[(sN + k) * nX + i] = bv[i];    // b_{k+1}
+            const int n_pa = NT * NTC, n_all = n_pa + NT * NUT;
+            int t1_[T1], tc_[T1], bs_[T1];
+            const double *bp_[T1];
+            bool o1_[T1], pa_[T1];
+#pragma unroll
+            for (int i = 0; i < T1; i++) {
+                const int t = wave + NW * i;
+                o1_[i] = t < n_all; pa_[i] = t < n_pa;
+                const int tt = o1_[i] ? (pa_[i] ? t : t - n_pa) : 0, w = pa_[i] ? NTC : NUT;
+                t1_[i] = tt / w; tc_[i] = 16 * (tt - (tt / w) * w) + lr; acc[i] = zero4;
+                bp_[i] = (pa_[i] ? AD : Bm) + tc_[i]; bs_[i] = pa_[i] ? lda : nU;
+            }
+            // operands of step k0 + 4 are requested before the matrix-core instructions of step k0 issue (two register sets, unrolled by two)
+            auto ld = [&](int k0, double (&av)[T1], double (&bw)[T1]) {
+                // no branch in this loop (a guarded load or matrix-core instruction becomes a basic block of its own, with a full
+                // s_waitcnt in front of every one): chains without a tile recompute tile 0 into an accumulator nobody stores, and the
+                // padding columns of a P B tile read whatever follows the row -- column j of a product depends on column j of B alone
+                const int g0 = (grow(k0) + lk);
+#pragma unroll
+                for (int i = 0; i < T1; i++) {
+                    av[i] = Pm[g0 * ldx + 16 * t1_[i] + lr];      // P[i][g] = P[g][i]
+                    bw[i] = bp_[i][(pa_[i] ? k0 + lk : g0) * bs_[i]];
+                }
+            };
+            auto mm = [&](const double (&av)[T1], const double (&bw)[T1]) {
+#pragma unroll
+                for (int i = 0; i < T1; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bw[i], acc[i], 0, 0, 0);
+            };
+            {
+                double a0[T1], b0[T1], a1[T1], b1[T1];
+                ld(0, a0, b0);
+                int k0 = 0;
+                for (; k0 + 8 <= KC; k0 += 8) {
+                    ld(k0 + 4, a1, b1);
+                    mm(a0, b0);
+                    if (k0 + 8 < KC) ld(k0 + 8, a0, b0);
+                    mm(a1, b1);
+                }
+                if (k0 < KC) mm(a0, b0);
+            }
+            LQ_STAMP(7);      // (diagnostic build: the k-loop alone)
+            // the single-entry rows outside the compact rows: one (P A tile: the v row of a Qk column) or two (P B tile: the Qk and the v row of
+            // a rho column) extra terms per element.  Branch-free -- an element without such a row reads row 0 with a zero coefficient --
+            // and all loads ahead of the FMAs: as guarded code this was ~50 basic blocks of one LDS round trip each (6.5 k cycles)
+            {
+                int e1[T1], e2[T1];
+                double c1[T1], c2[T1], p1[T1][4], p2[T1][4];
+#pragma unroll
+                for (int i = 0; i < T1; i++) {
+                    const int col = tc_[i];
+                    const int ra = a_extra(col), rq = col < nU ? b_extra_q(col) : -1, rx = col < nU ? b_extra_v(col) : -1;
+                    e1[i] = pa_[i] ? (ra >= 0 ? ra : 0) : (rq >= 0 ? rq : 0);
+                    e2[i] = (!pa_[i] && rx >= 0) ? rx : 0;
+                    const double xa = avs[(ra >= 0 ? col - nd : 0)], xq = Bm[(rq >= 0 ? rq : 0) * nU + (col < nU ? col : 0)], xv = Bm[(rx >= 0 ? rx : 0) * nU + (col < nU ? col : 0)];
+                    c1[i] = pa_[i] ? (ra >= 0 ? xa : 0.0) : (rq >= 0 ? xq : 0.0);
+                    c2[i] = (!pa_[i] && rx >= 0) ? xv : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < T1; i++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = 16 * t1_[i] + lk + 4 * r;
+                        p1[i][r] = Pm[row * ldx + e1[i]]; p2[i][r] = Pm[row * ldx + e2[i]];
+                    }
+#pragma unroll
+                for (int i = 0; i < T1; i++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[i][r] = fma(p2[i][r], c2[i], fma(p1[i][r], c1[i], acc[i][r]));
+            }
+            if (affine && tid < nU) {
+                if (!bb_in_tile) {
+                    double w = 0.0;
+                    for (int i = 0; i < nX; i++) w += Bm[i * nU + tid] * bv[i];
+                    wv[tid] = w;
+                }
+                rv[tid] = lds[L.rn + tid];      // r_k: fetched during the previous step
+            }
+            LQ_LDS_SYNC();
+            LQ_STAMP(0);
+            // ---- phase 2a: P A over P (its columns < ldc), P B and -- in its padding column -- b -------------------------------------
+#pragma unroll
+            for (int i = 0; i < T1; i++) {
+                if (!o1_[i]) continue;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = 16 * t1_[i] + lk + 4 * r;
+                    if (pa_[i]) Pm[row * ldx + tc_[i]] = acc[i][r];
+                    else if (tc_[i] < nU) PB[row * nUp + tc_[i]] = acc[i][r];
+                }
+            }
+            if (bb_in_tile) for (int i = tid; i < ldx; i += LQM_T) PB[i * nUp + nU] = i < nX ? bv[i] : 0.0;
+            LQ_LDS_SYNC();
+        }
+        {   // ---- phase 2b: gamma = R + B'(P B), Kpart = B'(P A) + S' -> G = [gamma | r + B'b | Kpart] ----------------------------------------
+            LQ_DS_PHASE;
+            // a wave's tiles (two at the puppet's sizes) run side by side, each with its k-loop split into two partial sums: four independent
+            // chains of KC / 8 matrix-core instructions instead of two tiles x KC / 4 dependent ones one after the other
+            constexpr int T2 = 2;
+            const int n2 = NUT * (NUT + NTC);
+            for (int tb = wave; tb < n2; tb += T2 * NW) {
+                int tu_[T2], col_[T2];
+                bool on_[T2], gam_[T2], gcol_[T2];
+                v4d c0[T2], c1[T2];
+#pragma unroll
+                for (int i = 0; i < T2; i++) {
+                    const int t = tb + NW * i;
+                    on_[i] = t < n2;
+                    const int tt = on_[i] ? t : 0, tu = tt / (NUT + NTC), tc = tt - tu * (NUT + NTC);
+                    gam_[i] = tc < NUT; tu_[i] = tu; col_[i] = 16 * (gam_[i] ? tc : tc - NUT) + lr;
+                    gcol_[i] = col_[i] < nU + (bb_in_tile ? 1 : 0);
+                    c0[i] = zero4; c1[i] = zero4;
+                }
+                auto ld = [&](int k0, double (&av)[T2], double (&bw)[T2]) {
+                    const int g0 = grow(k0) + lk;
+#pragma unroll
+                    for (int i = 0; i < T2; i++) {
+                        // (branch-free like phase 1: rows u >= nU of B' and columns past gamma's are garbage in, garbage out, never stored)
+                        av[i] = Bm[g0 * nU + 16 * tu_[i] + lr];       // B'[u][g]
+                        bw[i] = (gam_[i] ? PB + g0 * nUp : Pm + g0 * ldx)[col_[i]];
+                    }
+                };
+                {
+                    double a0[T2], b0[T2], a1[T2], b1[T2];
+                    ld(0, a0, b0);
+                    int k0 = 0;
+                    for (; k0 + 8 <= KC; k0 += 8) {
+                        ld(k0 + 4, a1, b1);
+#pragma unroll
+                        for (int i = 0; i < T2; i++) c0[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[i], c0[i], 0, 0, 0);
+                        if (k0 + 8 < KC) ld(k0 + 8, a0, b0);
+#pragma unroll
+                        for (int i = 0; i < T2; i++) c1[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[i], c1[i], 0, 0, 0);
+                    }
+                    if (k0 < KC) {
+#pragma unroll
+                        for (int i = 0; i < T2; i++) c0[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[i], c0[i], 0, 0, 0);
+                    }
+                }
+                // rows Qk_m / v_m of B outside the compact rows: (B'X)[rho_m][.] += B[Qk_m][rho_m] X[Qk_m][.] + B[v_m][rho_m] X[v_m][.]
+                // (branch-free, all loads first: see phase 1)
+                double ex[T2][4];
+                {
+                    double bq[T2][4], bx[T2][4], xq[T2][4], xx[T2][4];
+#pragma unroll
+                    for (int i = 0; i < T2; i++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int uo = 16 * tu_[i] + lk + 4 * r, uc = uo < nU ? uo : 0;
+                            const int rq = uo < nU ? b_extra_q(uo) : -1, rx = uo < nU ? b_extra_v(uo) : -1, rqc = rq >= 0 ? rq : 0, rxc = rx >= 0 ? rx : 0;
+                            const double *X = gam_[i] ? PB : Pm;
+                            const int xs = gam_[i] ? nUp : ldx;
+                            const double q0 = Bm[rqc * nU + uc], x0 = Bm[rxc * nU + uc];
+                            bq[i][r] = rq >= 0 ? q0 : 0.0; bx[i][r] = rx >= 0 ? x0 : 0.0;
+                            xq[i][r] = X[rqc * xs + col_[i]]; xx[i][r] = X[rxc * xs + col_[i]];
+                        }
+#pragma unroll
+                    for (int i = 0; i < T2; i++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) ex[i][r] = fma(bx[i][r], xx[i][r], bq[i][r] * xq[i][r]);
+                }
+#pragma unroll
+                for (int i = 0; i < T2; i++) {
+                    if (!on_[i]) continue;
+                    const bool is_gamma = gam_[i];
+                    const int col = col_[i];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int uo = 16 * tu_[i] + lk + 4 * r;      // output row (input index u), column `col`
+                        if (uo < nU) {
+                            double v = (c0[i][r] + c1[i][r]) + ex[i][r];
+                            if (is_gamma) {
+                                if (col < nU) {
+                                    double g = v + a.R_dev[(size_t)s * a.R_seed_stride + (size_t)k * a.R_step_stride + uo * nU + col];
+                                    if (hz) g += hz[(size_t)(nxh + uo) * hzR + nxh + col];
+                                    G[uo * ldw + col] = g;
+                                } else if (bb_in_tile && col == nU) {       // r_k + B'b
+                                    const double rw = v + rv[uo];
+                                    rv[uo] = rw; G[uo * ldw + nU] = rw;
+                                }
+                            } else {
+                                if (hz && col < nxh) v += hz[(size_t)col * hzR + nxh + uo];
+                                G[uo * ldw + nU + 1 + col] = v;
+                            }
+                        }
+                    }
+                }
+            }
+            if (tid < nU && !bb_in_tile) { const double rw = affine ? wv[tid] + rv[tid] : 0.0; rv[tid] = rw; G[tid * ldw + nU] = rw; }   // r_k + B'b
+            LQ_LDS_SYNC();
+            LQ_STAMP(1);
+            if (k > 0) fill_B(k - 1);      // B_k is dead from here on
+        }
+        {   // ---- phase 3: wave 0 factorises gamma while the others accumulate Q_k + A'(P A) on the upper-triangle tiles --------------
+            LQ_DS_PHASE;
+            if (wave == 0) lq_factor_call<NR>(G, ldw, nU, lane, fac, &s_sing);
+            else {
+                const double *Qk = a.Q_dev + (size_t)s * a.Q_seed_stride + (size_t)k * a.Q_step_stride;
+                // the weights Q_k (+ curvature) come from global memory: requested here, added behind the chains (as the chains' starting
+                // values they put a global-memory latency in front of the first matrix-core instruction)
+                v4d qw[TSYM];
+#pragma unroll
+                for (int i = 0; i < TSYM; i++) {
+                    v4d c = zero4;
+                    const int col = 16 * tj_[i] + lr;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = 16 * ti_[i] + lk + 4 * r;
+                        if (ok_[i] && row < nX && col < nX) {
+                            c[r] = Qk[(size_t)row * nX + col];
+                            if (hz && row < nxh && col < nxh) c[r] += hz[(size_t)row * hzR + col];
+                        }
+                    }
+                    qw[i] = c; acc[i] = zero4;
+                }
+                // each tile's k-loop in two partial sums (2 x TSYM independent chains), the next step's operands requested ahead
+                v4d acc2[TSYM];
+#pragma unroll
+                for (int i = 0; i < TSYM; i++) acc2[i] = zero4;
+                auto ld = [&](int k0, double (&av)[TSYM], double (&bw)[TSYM]) {
+                    const int g0 = grow(k0) + lk;
+#pragma unroll
+                    for (int i = 0; i < TSYM; i++) {
+                        const double x = AD[(k0 + lk) * lda + (mm_[i] ? 16 * ti_[i] + lr : 0)];
+                        av[i] = mm_[i] ? x : 0.0;                                           // A'[i][g] = A[g][i]; a tile of the v columns adds zero
+                        bw[i] = Pm[g0 * ldx + 16 * tj_[i] + lr];                            // (P A)[g][j]
+                    }
+                };
+                {
+                    double a0[TSYM], b0[TSYM], a1[TSYM], b1[TSYM];
+                    ld(0, a0, b0);
+                    int k0 = 0;
+                    for (; k0 + 8 <= KC; k0 += 8) {
+                        ld(k0 + 4, a1, b1);
+#pragma unroll
+                        for (int i = 0; i < TSYM; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[i], acc[i], 0, 0, 0);
+                        if (k0 + 8 < KC) ld(k0 + 8, a0, b0);
+#pragma unroll
+                        for (int i = 0; i < TSYM; i++) acc2[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[i], acc2[i], 0, 0, 0);
+                    }
+                    if (k0 < KC) {
+#pragma unroll
+                        for (int i = 0; i < TSYM; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[i], acc[i], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TSYM; i++) acc[i] = (acc[i] + acc2[i]) + qw[i];
+                {   // (A'(P A))[Qk_m][j] += A[v_m][Qk_m] (P A)[v_m][j] for the v rows outside the compact rows (branch-free, loads first)
+                    double cx[TSYM][4], px[TSYM][4];
+#pragma unroll
+                    for (int i = 0; i < TSYM; i++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int row = 16 * ti_[i] + lk + 4 * r, rx = a_extra(row), col = 16 * tj_[i] + lr;
+                            const double c = avs[rx >= 0 ? row - nd : 0];
+                            cx[i][r] = (mm_[i] && rx >= 0) ? c : 0.0;
+                            px[i][r] = Pm[(rx >= 0 ? rx : 0) * ldx + col];
+                        }
+#pragma unroll
+                    for (int i = 0; i < TSYM; i++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc[i][r] = fma(cx[i][r], px[i][r], acc[i][r]);
+                }
+            }
+            LQ_STAMP(6);
+            // the buffer that held P B becomes K: padding rows and the v columns (never solved: their right-hand sides are zero) are zero
+            for (int o = tid; o < (nUp - nU) * ldx; o += LQM_T) Ks[nU * ldx + o] = 0.0;
+            for (int o = tid; o < nU * (ldx - ldc); o += LQM_T) { const int u = o / (ldx - ldc); Ks[u * ldx + ldc + (o - u * (ldx - ldc))] = 0.0; }
+            LQ_LDS_SYNC();
+        }
+        {   // ---- phase 4: every wave replays the factorisation on its slice of the right-hand sides --------------------------------------
+            LQ_DS_PHASE;
+            const int rhs_total = 1 + ldc, slice = (rhs_total + NW - 1) / NW;
+            const int lo = wave * slice, nrhs = lo < rhs_total ? (rhs_total - lo < slice ? rhs_total - lo : slice) : 0;
+            lq_apply_rows<NR, (16 * NT + 1 + NW - 1) / NW>(G, ldw, nU, lo, nrhs, Ks, ldx, wv, lane, fac);
+            LQ_LDS_SYNC();
+            LQ_STAMP(2);
+        }
+        {   // ---- outputs K_k, C_k; new P tiles -= Kpart' K; new b ---------------------------------------------------------------------
+            LQ_DS_PHASE;
+            double *Cs = wv;
+            double *Ko = a.K_dev + (sN + k) * (size_t)nU * nX;
+            for (int o = tid; o < nU * nX; o += LQM_T) Ko[o] = Ks[(o / nX) * ldx + o % nX];
+            if (a.C_dev && tid < nU) a.C_dev[(sN + k) * nU + tid] = Cs[tid];
+            for (int u0 = 0; u0 < nUp; u0 += 4) {       // acc -= Kpart' K  (Kpart: the right-hand-side block of G, untouched by the solve)
+                double av[TSYM], bw[TSYM];
+#pragma unroll
+                for (int i = 0; i < TSYM; i++) {
+                    const double x = G[(u0 + lk) * ldw + nU + 1 + 16 * ti_[i] + lr];      // (rows nU .. nUp-1 of G exist and are zero)
+                    av[i] = mm_[i] ? -x : 0.0;
+                    bw[i] = Ks[(u0 + lk) * ldx + 16 * tj_[i] + lr];
+                }
+#pragma unroll
+                for (int i = 0; i < TSYM; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bw[i], acc[i], 0, 0, 0);
+            }
+            if (affine) for (int i = tid; i < nX; i += LQM_T) {     // new b = q_k + A'b - K'(r_k + B'b)
+                const double qi = a.q_dev[(sN + s + k) * nX + i];      // (added last: the chains do not wait for it)
+                double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+                if (i < ldc) {
+                    for (int m = 0; m + 4 <= KC; m += 4) {
+                        const int g0 = grow(m);
+                        v0 = fma(AD[m * lda + i], bv[g0], v0); v1 = fma(AD[(m + 1) * lda + i], bv[g0 + 1], v1);
+                        v2 = fma(AD[(m + 2) * lda + i], bv[g0 + 2], v2); v3 = fma(AD[(m + 3) * lda + i], bv[g0 + 3], v3);
+                    }
+                    const int rx = a_extra(i);
+                    if (rx >= 0) v0 = fma(avs[i - nd], bv[rx], v0);
+                }
+                int u = 0;
+                for (; u + 2 <= nU; u += 2) { v1 = fma(-Ks[u * ldx + i], rv[u], v1); v2 = fma(-Ks[(u + 1) * ldx + i], rv[u + 1], v2); }
+                for (; u < nU; u++) v3 = fma(-Ks[u * ldx + i], rv[u], v3);
+                bn[i] = ((v0 + v1) + (v2 + v3)) + qi;
+            }
+            LQ_LDS_SYNC();
+            LQ_STAMP(3);
+        }
+        {   // ---- phase 5: P <- new upper tiles, b <- new b; phase 6: mirror the upper triangle (see k_tv_lq_mfma) ---------------------------
+            LQ_DS_PHASE;
+#pragma unroll
+            for (int i = 0; i < TSYM; i++) {
+                if (ok_[i]) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Pm[(16 * ti_[i] + lk + 4 * r) * ldx + 16 * tj_[i] + lr] = acc[i][r];
+                }
+            }
+            if (affine) for (int i = tid; i < nX; i += LQM_T) bv[i] = bn[i];
+            if (k > 0 && tid < nq - nd) lds[L.avs + (cur ^ 1) * 32 + tid] = pav;
+            if (k > 0 && affine && tid < nU) lds[L.rn + tid] = prn;
+            LQ_LDS_SYNC();
+            LQ_STAMP(4);
+            for (int d = 1 + wave; d < nX; d += NW)
+                for (int i = lane; i < nX - d; i += 64) {
+                    const bool diag_tile = (i >> 4) == ((i + d) >> 4);
+                    const double up = Pm[i * ldx + i + d];
+                    const double v = diag_tile ? 0.5 * (up + Pm[(i + d) * ldx + i]) : up;
+                    Pm[i * ldx + i + d] = v; Pm[(i + d) * ldx + i] = v;
+                }
+        }
+        cur ^= 1;
+        __syncthreads();           // also waits for this wave's global -> LDS loads of A_{k-1}, B_{k-1}
+        LQ_STAMP(5);
+    }
+#if defined(TG_PROFILE)
+    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 8; i++) g_lq_prof[i] = lq_acc[i];
+#endif
+    {
+        k = 0;
+        LQ_DS_PHASE;
+        if (a.P0_dev) for (int e = tid; e < nX * nX; e += LQM_T) a.P0_dev[(size_t)s * nX * nX + e] = Pm[(e / nX) * ldx + e % nX];
+        if (a.b0_dev && affine) for (int i = tid; i < nX; i += LQM_T) a.b0_dev[(size_t)s * nX + i] = bv[i];
+        if (a.status_dev && tid == 0) a.status_dev[s] = s_sing ? TG_SINGULAR : TG_OK;
+    }
 }
 
 size_t lq_lds_bytes(int nX, int nU, int ts) {
@@ -1268,6 +1835,8 @@ int tg_tv_lq(int32_t device, const tg_lq_problem *p) {
     if ((p->q_dev == nullptr) != (p->r_dev == nullptr)) return fail(TG_ERR_INVALID, "q and r must be given together");
     if (p->hz_dev && (p->hz_R < p->hz_nx + p->nU || p->hz_nx > p->nX)) return fail(TG_ERR_INVALID, "bad curvature block sizes");
     if (p->nU > 64) return fail(TG_ERR_UNSUPPORTED, "more than 64 inputs");
+    if (p->ds_nd < 0 || p->ds_nk < 0 || p->ds_nu < 0 || (p->ds_nd > 0 && (2 * (p->ds_nd + p->ds_nk) != p->nX || p->ds_nu + p->ds_nk != p->nU)))
+        return fail(TG_ERR_INVALID, "DSystem block structure does not match nX / nU");
     // size class: tile size TS with nX <= 16*TS (one tile per thread), prefetch registers RI*CI >= nX*ceil(nX/32)/8
     const int nX = p->nX, nXU = p->nX * p->nU;
     HIP_TRY(hipSetDevice(device));
@@ -1280,6 +1849,37 @@ int tg_tv_lq(int32_t device, const tg_lq_problem *p) {
             // instantiated size classes: nX <= 16, 32, 48, 80, 96 (tiles per dimension 1, 2, 3, 5, 6) x nU <= 4, 8, 20, 32
             const int nt = nX <= 16 ? 1 : (nX <= 32 ? 2 : (nX <= 48 ? 3 : (nX <= 80 ? 5 : 6)));
             const int nr = p->nU <= 4 ? 4 : (p->nU <= 8 ? 8 : (p->nU <= 20 ? 20 : 32));
+            // DSystem block structure: its own kernel (k_tv_lq_ds) when the padding of the dense-row blocks can be taken from the sparse rows
+            const char *dense_env = std::getenv("TREPAMD_LQ_DENSE");
+            if (p->ds_nd > 0 && !(dense_env && dense_env[0] == '1') && p->ds_nk >= round_up(p->ds_nd, 4) - p->ds_nd && p->ds_nk <= 31 && (nX % 2) == 0) {
+                const LqDsLayout D(16 * nt, p->nU, p->ds_nd, p->ds_nd + p->ds_nk);
+                const size_t ldsd = sizeof(double) * (size_t)D.total;
+                if (ldsd <= 160 * 1024 - 256 && nt * (D.ldc / 16) + nt * ((p->nU + 15) / 16) <= 32) {
+#define TG_LQD_LAUNCH(NT_, NR_)                                                                                                  \
+                    do {                                                                                                         \
+                        if (ldsd > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_tv_lq_ds<NT_, NR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd)); \
+                        hipLaunchKernelGGL((k_tv_lq_ds<NT_, NR_>), dim3(p->n_problems), dim3(LQM_T), ldsd, dopt_stream(device), *p);                 \
+                    } while (0)
+#define TG_LQD_NR(NT_)                                                                                                           \
+                    switch (nr) {                                                                                                \
+                    case 4: TG_LQD_LAUNCH(NT_, 4); break;                                                                        \
+                    case 8: TG_LQD_LAUNCH(NT_, 8); break;                                                                        \
+                    case 20: TG_LQD_LAUNCH(NT_, 20); break;                                                                      \
+                    default: TG_LQD_LAUNCH(NT_, 32); break;                                                                      \
+                    }
+                    switch (nt) {
+                    case 1: TG_LQD_NR(1) break;
+                    case 2: TG_LQD_NR(2) break;
+                    case 3: TG_LQD_NR(3) break;
+                    case 5: TG_LQD_NR(5) break;
+                    default: TG_LQD_NR(6) break;
+                    }
+#undef TG_LQD_NR
+#undef TG_LQD_LAUNCH
+                    HIP_TRY(hipGetLastError());
+                    return TG_SUCCESS;
+                }
+            }
             const LqLayout L2(16 * nt, p->nU);   // the kernel pads nX to 16 * nt
             const size_t ldsk = sizeof(double) * (size_t)L2.total;
             if (ldsk <= 160 * 1024 - 256) {

@@ -122,6 +122,9 @@ class BatchDOptimizer(object):
         sysm = ds.system
         self._nxh = len(sysm.configs) + len(sysm.dyn_configs)      # leading [Q; p] part of X the curvature covers
         self._R = self._nxh + nU
+        # block structure of DSystem.fdx / fdu (dsystem.py:284-317) for the LQ sweeps: TREPAMD_LQ_DENSE=1 runs them dense
+        nd_, nk_ = len(sysm.dyn_configs), len(sysm.kin_configs)
+        self._ds = (nd_, nk_, nU - nk_) if (2 * (nd_ + nk_) == nX and os.environ.get("TREPAMD_LQ_DENSE", "0") != "1") else (0, 0, 0)
         # engines: horizon batch (one trajectory per (seed, step)) and candidate batch
         if armijo_chunk is None:   # fill the GPU once (256 CUs x 8 wavefronts) but never more than the search needs
             armijo_chunk = int(min(self.armijo_max_iterations, max(1, 2048 // S)))
@@ -225,6 +228,7 @@ class BatchDOptimizer(object):
         p.P0_dev = p.b0_dev = None
         p.b_next_dev = b_next.ptr if (b_next is not None and affine) else None
         p.status_dev = status.ptr
+        p.ds_nd, p.ds_nk, p.ds_nu = self._ds
         import ctypes
         self._check(self.L.tg_tv_lq(self.device, ctypes.byref(p)))
         if collect:
