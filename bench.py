@@ -162,6 +162,38 @@ def pmc_fp64(batch, rollout_steps, workload_prefix):
     return best
 
 
+def fp64_fma_ceiling():
+    """Sustained v_fma_f64 rate of this part with two waves per SIMD (tools/micro/mfma_f64_rate.hip): read from the newest
+    profiles/r*_mfma_f64_rate.txt, with the file it came from."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_f64_rate.txt")), reverse=True):
+        try:
+            for line in open(path):
+                m = re.match(r"waves/SIMD 2:.*v_fma_f64:.*\(([0-9.]+) TFLOP/s\)\s*$", line)
+                if m:
+                    return float(m.group(1)), os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
+def expected_line_keys(args, world):
+    """Top-level keys of rank 0's JSON line for this invocation (the same for every world size: the roofline's counter traffic, the fp64
+    object and the CPU baseline are rank 0's own figures and do not depend on how many ranks run)."""
+    keys = ["metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline"]
+    if world > 1:
+        keys.append("%s_scaling" % ("strong" if args.scaling == "weak" else "weak"))
+    if args.system == "puppet":
+        keys.append("fp64")
+        if not args.no_discopt:
+            keys.append("discopt")
+    if not args.no_cpu_baseline:
+        keys.append("cpu_baseline")
+    return keys
+
+
 def self_launch(args):
     """`bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N rank processes ourselves -- plain child
     processes with RANK / LOCAL_RANK / WORLD_SIZE / TREPAMD_RUN_KEY in their environment, BEFORE this process has made any
@@ -231,7 +263,7 @@ def dry_run_rank(args, world, rank):
     os.remove(path)
     shards = [shard_bounds(args.batch, r, world) for r in range(world)]
     print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_reported": len(seen), "same_id_on_every_rank": len(set(seen)) == 1,
-                      "shards": shards, "run_key": os.environ.get("TREPAMD_RUN_KEY")}))
+                      "shards": shards, "run_key": os.environ.get("TREPAMD_RUN_KEY"), "line_keys": expected_line_keys(args, world)}))
 
 
 def measure_rollouts(args, system, Q0, U, K, dt, B, N, device, comm, gather_rows):
@@ -336,7 +368,7 @@ def main():
     if args.dry_run_ranks:
         dry_run_rank(args, world, rank)
         return
-    want_cpu = not args.no_cpu_baseline and world == 1 and args.system == "puppet"
+    want_cpu = not args.no_cpu_baseline and rank == 0 and args.system == "puppet"      # rank 0's host cores, whatever the world size
     if want_cpu:      # compile the checker (a `make` child process) BEFORE this process touches the GPU
         from oracle import oracle as _oracle
         _oracle.build()
@@ -398,7 +430,8 @@ def main():
         bytes_per_step = 8.0 * (2 * nX + nU + nc)   # read X_k, U_k; write X_k+1, lambda
         algo_bytes = bytes_per_step * b_local * N
         achieved = algo_bytes / avg_kernel_s / 1e9
-        traffic = pmc_traffic(b_local, N, "Puppet(string_constraints=True)") if (world == 1 and args.system == "puppet") else None
+        # per-launch counter figures of ONE GPU's launch (profiles/): they apply to this rank's launch whenever its batch is the profiled one
+        traffic = pmc_traffic(b_local, N, "Puppet(string_constraints=True)") if args.system == "puppet" else None
         out = {
             "metric": "DEL-steps/sec x batch (%s, fp64)" % ("puppet ~40-DOF" if args.system == "puppet" else args.system),
             "value": value, "unit": "DEL-steps/s", "n_gpus": rccl_ranks, "rccl_ranks": rccl_ranks if comm is not None else None,
@@ -431,12 +464,14 @@ def main():
                                         "global_batch": gb2, "batch_per_gpu": bl2, "ms_per_step": 1e3 * r2["elapsed"] / args.steps,
                                         "kernel_avg_ms": r2["kernel_ms"] / max(r2["launches"], 1),
                                         "note": "BASELINE config 3 as written: 8192 rollouts in total" if mode == "strong" else "fixed work per GPU"}
-        fp64 = pmc_fp64(b_local, N, "Puppet(string_constraints=True)") if (world == 1 and args.system == "puppet") else None
-        if fp64:   # secondary figure: the path is compute/latency bound, so also say how far from the fp64 peak
-            out["fp64"] = {"estimated_tflops": fp64[0] / avg_kernel_s / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                           "measured_v_fma_f64_ceiling_tflops": 51.6,   # tools/micro/mfma_f64_rate.hip, two waves per SIMD (profiles/r02_mfma_f64_rate.txt)
-                           "frac": fp64[0] / avg_kernel_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                           "flop_per_del_step": fp64[0] / (b_local * N), "f64_wave_instructions_per_del_step": fp64[1] / (b_local * N), "source": fp64[2]}
+        fp64 = pmc_fp64(b_local, N, "Puppet(string_constraints=True)") if args.system == "puppet" else None
+        if args.system == "puppet":   # secondary figure: the path is compute/latency bound, so also say how far from the fp64 peak
+            ceiling, ceiling_src = fp64_fma_ceiling()
+            out["fp64"] = None if not fp64 else {
+                "estimated_tflops": fp64[0] / avg_kernel_s / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                "measured_v_fma_f64_ceiling_tflops": ceiling, "ceiling_source": ceiling_src,   # tools/micro/mfma_f64_rate.hip, two waves per SIMD
+                "frac": fp64[0] / avg_kernel_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                "flop_per_del_step": fp64[0] / (b_local * N), "f64_wave_instructions_per_del_step": fp64[1] / (b_local * N), "source": fp64[2]}
         if discopt is not None:
             out["discopt"] = discopt
         if want_cpu:
@@ -444,6 +479,8 @@ def main():
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
+        missing = [k for k in expected_line_keys(args, world) if k not in out]
+        assert not missing, "bench.py line lacks %s" % missing
         print(json.dumps(out))
     if comm is not None:
         comm.barrier()

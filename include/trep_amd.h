@@ -142,6 +142,8 @@ const char *tg_version(void);
 const char *tg_last_error(void);
 /* Number of visible HIP devices (<=0: none; the library then refuses to create batches). */
 int tg_device_count(void);
+/* out[0..3] = compute units, LDS bytes a workgroup may use (opt-in maximum), wavefront size, 0 */
+int tg_device_info(int32_t device, int32_t out[4]);
 
 /* Compile the flattened system into the device schedule.  The descriptor is copied. */
 tg_system *tg_system_create(const tg_system_desc *desc);

@@ -138,6 +138,9 @@ def test_bench_self_launcher_dry_run(tmp_path):
     assert out["dry_run"] and out["n_gpus"] == 2 and out["ranks_reported"] == 2 and out["same_id_on_every_rank"]
     assert out["shards"] == [[0, 4097], [4097, 8193]]
     assert out["run_key"].startswith("self")
+    # rank 0's real line carries the roofline (with the counter traffic), the fp64 object and the CPU baseline for ANY world size
+    for key in ("roofline", "fp64", "cpu_baseline", "discopt", "strong_scaling", "n_gpus", "rccl_ranks"):
+        assert key in out["line_keys"], (key, out["line_keys"])
     assert not os.listdir(str(tmp_path))          # the rendezvous files are gone
 
 

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "tg_version": (ctypes.c_char_p, []),
     "tg_last_error": (ctypes.c_char_p, []),
     "tg_device_count": (ctypes.c_int, []),
+    "tg_device_info": (ctypes.c_int, [ctypes.c_int32, _c_ip]),
     "tg_system_create": (ctypes.c_void_p, [ctypes.POINTER(SystemDescStruct)]),
     "tg_system_destroy": (None, [ctypes.c_void_p]),
     "tg_system_sizes": (ctypes.c_int, [ctypes.c_void_p, _c_ip]),

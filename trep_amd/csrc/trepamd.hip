@@ -383,6 +383,15 @@ int tg_device_count(void) {
     return n;
 }
 
+/* out[0..3] = compute units, LDS bytes a workgroup may use (opt-in maximum), wavefront size, 0 */
+int tg_device_info(int32_t device, int32_t out[4]) {
+    if (!out) return fail(TG_ERR_INVALID, "null argument");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    out[0] = prop.multiProcessorCount; out[1] = (int32_t)prop.sharedMemPerBlockOptin; out[2] = prop.warpSize; out[3] = 0;
+    return TG_SUCCESS;
+}
+
 tg_system *tg_system_create(const tg_system_desc *desc) {
     if (!desc) { fail(TG_ERR_INVALID, "null descriptor"); return nullptr; }
     try {
@@ -574,7 +583,8 @@ int tg_batch_step(tg_batch *b, double t2_new, const double *u1_host, const doubl
     // pinned, device-visible host block: the kernel reads (u1, k2, hints) from it at the head of the step and writes (q2, p2, lambda1,
     // iterations, status) into it beside the device state -- one launch on the stream, no copy engine, no packing kernel.
     const size_t n_in = B * ((size_t)P.nu + P.nk + P.nd + P.nc), n_out = B * ((size_t)P.nq + P.nd + P.nc) + B;   // 2 B ints = B doubles
-    if ((n_in + n_out) * sizeof(double) <= (1u << 20)) {
+    // (gated on the trajectory count: the path was measured at B = 1 .. 64 only; larger batches take the copy engine below)
+    if (B <= 64 && (n_in + n_out) * sizeof(double) <= (1u << 20)) {
         if (!b->io_host) {
             if (hipHostMalloc(&b->io_host, (n_in + n_out) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
                 hipHostGetDevicePointer(reinterpret_cast<void **>(&b->io_dev), b->io_host, 0) != hipSuccess)
@@ -1090,6 +1100,7 @@ uint64_t tg_system_spec_key(const tg_system *sys) {
 /* Rollouts of this batch use the kernel of a library built by trep_amd/specialize.py for exactly this system. */
 int tg_batch_load_specialized(tg_batch *b, const char *library_path) {
     if (!b || !library_path) return fail(TG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(b->device));
     void *h = dlopen(library_path, RTLD_NOW | RTLD_LOCAL);
     if (!h) return fail(TG_ERR_INVALID, std::string("cannot load ") + library_path + ": " + (dlerror() ? dlerror() : "?"));
     auto launch_fn = reinterpret_cast<int (*)(int, const tg::RunArgs *, tg::RunArgs *, int, size_t, void *)>(dlsym(h, "tg_spec_launch"));
@@ -1102,12 +1113,18 @@ int tg_batch_load_specialized(tg_batch *b, const char *library_path) {
     const int *got = sizes_fn();
     for (int i = 0; i < 8; i++) if (got[i] != want[i]) { dlclose(h); return fail(TG_ERR_INVALID, "specialised kernel was built for a different system or library version"); }
     if (key_fn() != tg_system_spec_key(b->sys)) { dlclose(h); return fail(TG_ERR_INVALID, "specialised kernel was built from a different schedule (header hash mismatch)"); }
-    HIP_TRY(hipSetDevice(b->device));
     if (!b->d_args) {
         bool ok = hipMalloc(&b->d_args, sizeof(tg::RunArgs) * tg_batch::ARG_SLOTS) == hipSuccess &&
                   hipHostMalloc(&b->h_args, sizeof(tg::RunArgs) * tg_batch::ARG_SLOTS, hipHostMallocDefault) == hipSuccess;
-        for (int i = 0; i < tg_batch::ARG_SLOTS && ok; i++) ok = hipEventCreateWithFlags(&b->arg_done[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { dlclose(h); return fail(TG_ERR_HIP, "allocation of the argument blocks failed"); }
+        int made = 0;
+        for (; made < tg_batch::ARG_SLOTS && ok; made++) ok = hipEventCreateWithFlags(&b->arg_done[made], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {      // leave nothing half-made behind: a retry must find the batch as it was
+            for (int i = 0; i + 1 < made; i++) { hipEventDestroy(b->arg_done[i]); b->arg_done[i] = nullptr; }
+            if (b->h_args) { hipHostFree(b->h_args); b->h_args = nullptr; }
+            if (b->d_args) { hipFree(b->d_args); b->d_args = nullptr; }
+            dlclose(h);
+            return fail(TG_ERR_HIP, "allocation of the argument blocks failed");
+        }
     }
     if (b->spec_lib) { hipStreamSynchronize(b->stream); dlclose(b->spec_lib); }
     b->spec_lib = h; b->spec_launch = launch_fn; b->spec_modes = modes_fn(); b->spec_path = library_path;

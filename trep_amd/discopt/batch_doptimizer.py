@@ -91,7 +91,6 @@ class BatchDOptimizer(object):
 
     step_return = namedtuple("batch_step", "done cost0 dcost0 cost1 method armijo failed")
 
-    CUS = 256       # compute units of an MI355X: one sweep workgroup occupies one
 
     def __init__(self, dsys, Xd, Ud, Q, R, Qf=None, device=0, armijo_chunk=None, first_method_iterations=10,
                  predictor="reference", overlap_sweeps="auto"):
@@ -149,6 +148,9 @@ class BatchDOptimizer(object):
         self.dcost, self.cost = pool.empty((S,)), pool.empty((S,))
         self.lq_status = pool.empty((S,), np.int32)
         # second set of direction buffers: the quasi-Newton sweep that runs beside the projection gain
+        info = np.zeros(4, dtype=np.int32)
+        _lib.check(self.L.tg_device_info(device, info.ctypes.data_as(_lib._c_ip)))
+        self.CUS = int(info[0])      # one sweep workgroup occupies one compute unit
         self.overlap = (2 * S <= self.CUS) if overlap_sweeps == "auto" else bool(overlap_sweeps)
         if self.overlap:
             self.K2, self.C2 = pool.empty((S, N, nU, nX)), pool.empty((S, N, nU))

@@ -587,7 +587,8 @@ class System(object):
                 raise ValueError("singular inertia or constraint matrix")
             return d
         out = dynamics_deriv2_from_deriv1(deriv1, self.q, self.dq, self.u, self.ddqk)
-        self._apply_reference_conventions(out)
+        if getattr(self, "reference_conventions", True):      # False: the derivatives consistent with this library's own first derivatives
+            self._apply_reference_conventions(out)
         return out
 
     def _apply_reference_conventions(self, out, mass_matrix=None):
