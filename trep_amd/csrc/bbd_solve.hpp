@@ -22,23 +22,24 @@ __device__ __forceinline__ void bbd_fmac(double &a, double b, double l) {
 // One Gauss-Jordan step on column K of a row-per-lane block held in registers a[0 .. NCOL): every lane of a 16-lane row except
 // lane K subtracts its multiple of lane K's row.  Columns < K are already eliminated (only the pivot lanes hold them) and column
 // K itself is not touched (the pivot lane keeps its pivot, the others' entries are dead).  `first` .. `last`: the live columns.
-// rp_out: 1 / pivot (every lane computes it); bad: set on the pivot lane if the pivot fails its guard.
+// myrp: 1 / pivot of the lane's own row, kept by the pivot lane of each step (every lane computes the reciprocal).  The pivot guard is
+// evaluated from it after the last step -- |pivot| > guard  <=>  |1 / pivot| guard < 1 -- instead of a compare and two mask operations
+// in every step.
 template <int K, int NCOL>
-__device__ __forceinline__ void bbd_step(double (&a)[NCOL], int r, double guard, double &myrp, bool &bad) {
+__device__ __forceinline__ void bbd_step(double (&a)[NCOL], int r, double &myrp) {
     const double p = bbd_bcast<K>(a[K]);
     const double rp = tg_rcp(p);
     const bool is_piv = r == K;
-    bad = bad || (is_piv && !(fabs(a[K]) > guard));
     myrp = is_piv ? rp : myrp;
     const double l = is_piv ? 0.0 : -a[K] * rp;
 #pragma unroll
     for (int j = K + 1; j < NCOL; j++) bbd_fmac<K>(a[j], a[j], l);
 }
 template <int K, int KEND, int NCOL>
-__device__ __forceinline__ void bbd_steps(double (&a)[NCOL], int r, double guard, double &myrp, bool &bad) {
+__device__ __forceinline__ void bbd_steps(double (&a)[NCOL], int r, double &myrp) {
     if constexpr (K < KEND) {
-        bbd_step<K, NCOL>(a, r, guard, myrp, bad);
-        bbd_steps<K + 1, KEND, NCOL>(a, r, guard, myrp, bad);
+        bbd_step<K, NCOL>(a, r, myrp);
+        bbd_steps<K + 1, KEND, NCOL>(a, r, myrp);
     }
 }
 
@@ -86,8 +87,9 @@ __device__ __noinline__ bool gj_bbd(double *A_generic, const int *tab_generic, d
     for (int e = lane; e < T * UL; e += 64) U[e] = 0.0;
     // ---- stage 1: the groups' own columns
     double myrp = 0.0;
-    bool bad = false;
-    bbd_steps<0, NG, NCOL>(a, r, GUARD * amax, myrp, bad);
+    bbd_steps<0, NG, NCOL>(a, r, myrp);
+    // a lane that never was a pivot lane keeps 1 / pivot = 0 and passes; a zero pivot gives inf (or NaN further down): fails
+    bool bad = !(fabs(myrp) * (GUARD * amax) < 1.0);
     // ---- stage 2: Schur updates of the border rows into U, then the trailing system
     if (trow >= 0) {
 #pragma unroll
@@ -101,7 +103,8 @@ __device__ __noinline__ bool gj_bbd(double *A_generic, const int *tab_generic, d
     if (lane < 16) {
 #pragma unroll
         for (int j = 0; j <= T; j++) { const double u = U[(tl ? lane : 0) * UL + j]; tr[j] += tl ? u : 0.0; }
-        bbd_steps<0, T, T + 1>(tr, r, GUARD * tmax, trp, bad);
+        bbd_steps<0, T, T + 1>(tr, r, trp);
+        bad = bad || !(fabs(trp) * (GUARD * tmax) < 1.0);
         if (tl) XT[lane] = tr[T] * trp;
     }
     if (__any(bad ? 1 : 0)) return false;
