@@ -3601,6 +3601,15 @@ struct Core {
         }
         for (; i < P.nd; i++) n0 = fma(S[P.o_f + i], S[P.o_f + i], n0);
         const double norm = (n0 + n1) + (n2 + n3);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (TEAM == 64 && P.nc <= 64) {
+            // one constraint per lane and a wave vote: as a loop with an early exit this was a cascade of nc basic blocks, each waiting out
+            // its own LDS read
+            const int c = lane < P.nc ? lane : 0;
+            const bool off = lane < P.nc && fabs(S[P.o_f + P.nd + c]) > S[P.o_ctol + c];
+            return !(sqrt(norm) > tolerance) && !__any(off ? 1 : 0);
+        }
+#endif
         if (sqrt(norm) > tolerance) return false;
         for (int c = 0; c < P.nc; c++) if (fabs(S[P.o_f + P.nd + c]) > S[P.o_ctol + c]) return false;
         return true;
