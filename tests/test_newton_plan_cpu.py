@@ -1,0 +1,89 @@
+"""The bordered-block-diagonal plan of the structured Newton solve (trep_amd/csrc/bbd.hpp, host side: no GPU needed): pattern and plan of
+the BASELINE systems through tg_system_newton_plan, and the property the device code relies on -- every structural non-zero of the
+Newton matrix lies inside one group's (own | border) rows and columns or inside the border system."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from common import build
+
+
+def _plan(name):
+    from trep_amd import _lib
+    L = _lib.lib()
+    system, desc = build(name)
+    h = L.tg_system_create(desc.byref())
+    assert h
+    try:
+        out = np.zeros(8, dtype=np.int32)
+        _lib.check(L.tg_system_newton_plan(h, out.ctypes.data, None, None))
+        nf = int(out[5])
+        pat = np.zeros((nf, nf), dtype=np.uint8)
+        tab = np.zeros(128, dtype=np.int32)
+        _lib.check(L.tg_system_newton_plan(h, out.ctypes.data, pat.ctypes.data, tab.ctypes.data))
+    finally:
+        L.tg_system_destroy(h)
+    return dict(ok=int(out[0]), groups=int(out[1]), ng=int(out[2]), nb=int(out[3]), t=int(out[4]), nf=nf, nd=int(out[6])), pat.astype(bool), tab, system
+
+
+def _groups(plan, tab):
+    own, border = [], []
+    for g in range(4):
+        rows = [(int(tab[16 * g + r]) & 0xFF) - 1 for r in range(16)]
+        own.append([v for v in rows[:plan["ng"]] if v >= 0])
+        border.append([v for v in rows[plan["ng"]:plan["ng"] + plan["nb"]] if v >= 0])
+    trailing = [((int(tab[i]) >> 16) & 0xFF) - 1 for i in range(plan["t"])]
+    return own, border, trailing
+
+
+def test_puppet_plan_is_four_limbs_around_torso_and_strings():
+    plan, pat, tab, system = _plan("puppet40")
+    assert plan == dict(ok=1, groups=4, ng=4, nb=7, t=12, nf=28, nd=22)
+    assert int(pat[:22, :22].sum()) == 292            # of 484: the mass-matrix pattern of the marionette
+    own, border, trailing = _groups(plan, tab)
+    names = [c.name for c in system.dyn_configs]
+    assert [names[i] for i in trailing[:6]] == ["torso_tx", "torso_ty", "torso_tz", "torso_rz", "torso_ry", "torso_rx"]
+    assert trailing[6:] == [22, 23, 24, 25, 26, 27]  # the six string constraints, after the configs
+    limbs = sorted(sorted(names[i] for i in g) for g in own)
+    assert limbs == sorted([sorted(s + j for j in ("hip_rz", "hip_ry", "hip_rx", "knee_rx")) for s in "lr"] +
+                           [sorted(s + j for j in ("shoulder_rz", "shoulder_ry", "shoulder_rx", "elbow_rx")) for s in "lr"])
+    for b in border:                                   # every limb touches the torso and exactly one string
+        assert b[:6] == trailing[:6] and len(b) == 7 and b[6] >= 22
+
+
+@pytest.mark.parametrize("name", ["puppet40", "puppet_basic", "scissor4"])
+def test_every_structural_nonzero_is_covered_by_the_plan(name):
+    plan, pat, tab, _ = _plan(name)
+    assert plan["ok"] == 1 and plan["groups"] >= 2 and plan["ng"] + plan["nb"] <= 16 and plan["t"] <= 16
+    own, border, trailing = _groups(plan, tab)
+    nf, nd = plan["nf"], plan["nd"]
+    where = {}
+    for g, o in enumerate(own):
+        for v in o:
+            assert v < nd and v not in where           # own variables are configs, each in one group
+            where[v] = g
+    assert sorted(list(where) + trailing) == list(range(nf))
+    assert all(v < nd for v in trailing[:sum(1 for v in trailing if v < nd)]) and sorted(trailing[sum(1 for v in trailing if v < nd):]) == list(range(nd, nf))
+    assert (pat == pat.T).all()
+    for i in range(nf):
+        for j in range(nf):
+            if not pat[i, j]:
+                continue
+            gi, gj = where.get(i), where.get(j)
+            if gi is not None and gj is not None:
+                assert gi == gj, (i, j)                # two own variables couple only inside their group
+            elif gi is not None:
+                assert j in border[gi], (i, j)         # own x border: the border variable is in the group's list
+            elif gj is not None:
+                assert i in border[gj], (i, j)
+    # the column tables repeat the row tables (column j of a group is the variable of its row j)
+    for g in range(4):
+        for r in range(16):
+            assert (int(tab[64 + 16 * g + r]) & 0xFFFF) == (int(tab[16 * g + r]) & 0xFFFF)
+
+
+@pytest.mark.parametrize("name", ["pendulum1", "pend_on_cart", "spring_arm"])
+def test_small_systems_have_no_plan(name):
+    plan, pat, tab, _ = _plan(name)
+    assert plan["ok"] == 0 and not pat.any() and not tab.any()
