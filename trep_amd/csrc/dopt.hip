@@ -999,13 +999,20 @@ struct LqDsLayout {
 // barrier after their issue); those land in the OTHER buffer and are awaited by the step's last barrier (__syncthreads).
 #define LQ_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// (the pivoted fallback as a call of its own: its code is only fetched when a guard failed)
+template <int NR>
+__device__ __noinline__ void lq_factor_pivoted_call(double *G, int ldw, int nU, int lane, double *fac, int *sing) {
+    ldw = __builtin_amdgcn_readfirstlane(ldw); nU = __builtin_amdgcn_readfirstlane(nU);
+    lq_factor_rows<NR>(G, ldw, nU, lane, fac, sing);
+}
+
 // gamma's factorisation as a CALL: one wave of eight runs it, and inlined its 2 x 20 matrix registers (unpivoted attempt + pivoted fallback)
 // are part of the sweep kernel's register allocation (158 spilled VGPRs)
 template <int NR>
 __device__ __noinline__ void lq_factor_call(double *G, int ldw, int nU, int lane, double *fac, int *sing) {
     // (arguments of a call travel in vector registers: say that the sizes are wave-uniform, or every `k < nU` becomes a divergent branch)
     ldw = __builtin_amdgcn_readfirstlane(ldw); nU = __builtin_amdgcn_readfirstlane(nU);
-    if (!lq_factor_rows_spd<NR>(G, ldw, nU, lane, fac)) lq_factor_rows<NR>(G, ldw, nU, lane, fac, sing);
+    if (!lq_factor_rows_spd<NR>(G, ldw, nU, lane, fac)) lq_factor_pivoted_call<NR>(G, ldw, nU, lane, fac, sing);
 }
 
 // Launch arguments re-read per phase: the struct sits at the head of the kernel-argument segment; reading it through a laundered
