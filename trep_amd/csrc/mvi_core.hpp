@@ -1226,6 +1226,14 @@ struct Core {
         double *A = S + P.o_Df;
         // zero fill, then the few structurally non-zero constant entries: damping on the diagonal
         // (damping.c:21-27), the right-hand side f, and -Dh1^T / Dh2 from the (constraint, config) items
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (TEAM == 64 && ((P.o_Df | (nf * ld)) & 1) == 0) {   // 16-byte stores: half the LDS instructions of the fill (the image starts on an even offset of a slice at LDS address 0)
+            typedef double tg_d2 __attribute__((ext_vector_type(2)));
+            tg_d2 *A2 = reinterpret_cast<tg_d2 *>(A);
+            const tg_d2 z2 = {0.0, 0.0};
+            if (on) TG_FOR(i, (nf * ld) >> 1) A2[i] = z2;
+        } else
+#endif
         if (on) TG_FOR(i, nf * ld) A[i] = 0.0;
         TG_SYNC();
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -3982,6 +3990,18 @@ struct Core {
         const int R = P.g_nrhs;
 #if defined(__HIP_DEVICE_COMPILE__)
         const int w = nf + R, nb4 = (nf + 3) >> 2;
+        if (TEAM == 64 && nf > 16 && nf <= 31 && w <= 128 && 12 * P.n_joints >= 200) {
+            // 17..31 unknowns, up to 128 columns: panels of four columns, every right-hand side in the rank-4 matrix-core update
+            // (gj_panel_rhs: what the first-derivative kernel of the discrete path uses; gj_cols below spends 28 x 56 lane-wide FMAs
+            // plus the pivot-column traffic per pivot step on the same system)
+            double *sc = S + P.o_G;   // the joint poses are dead during the solve
+            switch (nb4) {
+            case 5: ok = Core<64, SPRINGS, PROG>::template gj_panel_rhs<20, 8>(on, AUG, nf, w, ld, lane, sc); break;
+            case 6: ok = Core<64, SPRINGS, PROG>::template gj_panel_rhs<24, 8>(on, AUG, nf, w, ld, lane, sc); break;
+            case 7: ok = Core<64, SPRINGS, PROG>::template gj_panel_rhs<28, 8>(on, AUG, nf, w, ld, lane, sc); break;
+            default: ok = Core<64, SPRINGS, PROG>::template gj_panel_rhs<32, 8>(on, AUG, nf, w, ld, lane, sc); break;
+            }
+        } else
         if (TEAM == 64 && w <= 128 && nb4 <= 8 && P.gjc_ok) {
             double *sc = S + P.o_G;   // the joint poses are dead during the solve
             switch (nb4) {
