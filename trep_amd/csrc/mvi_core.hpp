@@ -145,6 +145,9 @@ namespace tg {
 // the structured Newton solve needs its plan as compile-time constants: system-specialised schedules (SpecProg: static members) only
 template <class P, class = void> struct tg_static_bbd { static constexpr bool value = false; };
 template <class P> struct tg_static_bbd<P, typename std::enable_if<(P::bbd_ok >= 0)>::type> { static constexpr bool value = P::bbd_ok != 0; };
+// ... and so does the composite assembly of the Newton matrix (its group sums are unrolled over compile-time membership masks)
+template <class P, class = void> struct tg_static_cmp { static constexpr bool value = false; };
+template <class P> struct tg_static_cmp<P, typename std::enable_if<(P::cmp_ok >= 0)>::type> { static constexpr bool value = P::cmp_ok != 0 && P::tab_ok != 0; };
 
 enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3, MODE_DERIV2Z = 4, MODE_DYNAMICS = 5, MODE_DYN_DERIV1 = 6, MODE_ENERGY = 7, MODE_LAGRANGIAN = 8 };
 
@@ -411,6 +414,12 @@ struct Core {
         if constexpr (TEAM == 64 && tg_static_bbd<typename std::remove_cv<PROG>::type>::value) {
             // plan tables of the structured Newton solve (bbd.hpp): staged once per rollout kernel behind the base region
             if (rollout) { int *tab = (int *)(S + P.o_bbd); TG_FOR(i, 128) tab[i] = P.bbd_tab[i]; }
+        }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_CMP)
+        if constexpr (TEAM == 64 && !SPRINGS && tg_static_cmp<typename std::remove_cv<PROG>::type>::value) {
+            // composite Newton matrix: representative item | its body << 12 | subtree group << 20 of every dynamic config
+            if (rollout) { int *tab = (int *)(S + P.o_cmpt); TG_FOR(i, P.nd) { const int it = P.cmp_rep[i]; tab[i] = it | (P.it_pack[4 * (size_t)it] << 12) | (P.cmp_grp[i] << 20); } }
         }
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1219,8 +1228,178 @@ struct Core {
         TG_SYNC();
     }
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_CMP)
+    // ---- Newton matrix, inertial part in COMPOSITE form (system-specialised rollout kernels of full-wave teams) -----------------------
+    // newton_matrix() below walks every (body, item a <= item b) pair -- 442 for the puppet -- and evaluates L_dqdq, L_ddqdq, L_ddqddq
+    // (system.c:158-202, 294-334, 459-489) of that body for that pair from its body-frame Jacobian columns.  All bodies below config b
+    // see the same WORLD-frame joint twists s_k = Ad(g_F) J_{F,k} and w_k = Ad(g_F) W_{F,k} ([.,.] commutes with Ad), so the sum over
+    // the bodies of a config pair (a, b), a on the path to b, is a bilinear form in the composite quantities of the subtree below b:
+    //     M = sum m_F,  C = sum m_F p_F,  D = sum R_F I_F R_F' - m_F [p_F]^2  (world-frame spatial inertia [[M, -[C]], [[C], D]]),
+    //     H = sum Ad(g_F)^-T (I_F v_F)  (spatial momentum about the world origin).
+    // With I s = (M v - C x w, C x v + D w) for a twist s = (v, w), Y_b the co-adjoint vector with [X, s_b] . H = X . Y_b, and
+    // Z_b = Y_b + I w_b,  GG_b = (M v_b + w_b x C) x g:
+    //     L_ddqddq(a, b) = s_a . I s_b,   L_dqdq(a, b) = w_a . Z_b + omega_a . GG_b,   L_ddqdq(dq a, q b) = s_a . Z_b,   L_ddqdq(dq b, q a) = w_a . I s_b
+    // -- 27 FMAs per CONFIG pair (157 for the puppet: one per matrix entry pair, so no two lanes meet at an entry) after 16 numbers per
+    // body, 16 per subtree group (9) and 27 per config.  Same matrix up to rounding; the scratch lives in the J / W area, which is dead
+    // between the residual and the next evaluation (the structured solve's scratch follows in the same place).
+    TG_HD void newton_matrix_composite(bool on) {
+        PROG &P = tg_fresh(this->P);
+        typedef typename std::remove_cv<PROG>::type SP;
+        constexpr int nd = SP::nd, nf = SP::nf, ld = SP::df_ld, NB = SP::n_bodies, NG = SP::n_cgroups, NP = SP::n_cmpairs;
+        constexpr int TP = (NP + TEAM - 1) / TEAM;
+        static_assert(3 * NB <= TEAM && nd <= TEAM, "newton_matrix_composite: one trip per phase");
+        // scratch: per-body world entries BW in the dead joint-pose area of the union (the body poses next to it are still needed; the whole
+        // union becomes the matrix image two phases on); composites, world twists and per-config vectors in the J / W area
+        double *A = S + P.o_Df, *CMP = S + P.o_cmp, *SW = S + P.o_csw, *CZ = S + P.o_ccz, *BW = S + P.o_sc;
+        static_assert(16 * NB <= SP::o_gB - SP::o_sc, "newton_matrix_composite: body entries do not fit the dead pose area");
+        const int *rep = (const int *)(S + P.o_cmpt);
+        // the pair records of all trips: requested now, used three phases later
+        int prec[TP];
+#pragma unroll
+        for (int u = 0; u < TP; u++) prec[u] = P.cmp_pair[lane + u * TEAM < NP ? lane + u * TEAM : 0];
+        // ---- phase A.  (i) lane (body b, axis r): the body's world entries -- M, C_r = m p_r, row r of D = R I R' + m (|p|^2 1 - p p'),
+        //      f_r = (R m v_B)_r, tau_r = (R I w_B)_r + (p x f)_r -- written straight to BW (nothing there is read in this phase);
+        if (on && lane < 3 * NB) {
+            const int b = lane / 3, r = lane - 3 * b;
+            const double *gb = S + P.o_gB + 12 * b, *I = S + P.o_I + 4 * b, *vb = S + P.o_vB + 6 * b;
+            const double m = I[0], px = gb[3], py = gb[7], pz = gb[11], pr = gb[4 * r + 3];
+            const double R0 = gb[4 * r], R1 = gb[4 * r + 1], R2 = gb[4 * r + 2];
+            double f[3], t[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                f[c] = m * (gb[4 * c] * vb[0] + gb[4 * c + 1] * vb[1] + gb[4 * c + 2] * vb[2]);
+                t[c] = gb[4 * c] * (I[1] * vb[3]) + gb[4 * c + 1] * (I[2] * vb[4]) + gb[4 * c + 2] * (I[3] * vb[5]);
+            }
+            const double tx = t[0] + (py * f[2] - pz * f[1]), ty = t[1] + (pz * f[0] - px * f[2]), tz = t[2] + (px * f[1] - py * f[0]);
+            const double p2 = px * px + py * py + pz * pz;
+            double *o = BW + 16 * b;
+            if (r == 0) o[0] = m;
+            o[1 + r] = m * pr;
+            // D row r, columns j >= r: entries 4 + (xx xy xz | yy yz | zz)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const double pj = j == 0 ? px : (j == 1 ? py : pz);
+                const double d = R0 * I[1] * gb[4 * j] + R1 * I[2] * gb[4 * j + 1] + R2 * I[3] * gb[4 * j + 2] + m * ((j == r ? p2 : 0.0) - pr * pj);
+                if (j >= r) o[4 + (r == 0 ? j : (r == 1 ? 2 + j : 5))] = d;
+            }
+            o[10 + r] = r == 0 ? f[0] : (r == 1 ? f[1] : f[2]);
+            o[13 + r] = r == 0 ? tx : (r == 1 ? ty : tz);
+        }
+        //      (ii) lane k: world twists s_k = Ad(g_F) J, w_k = Ad(g_F) W of config k from its representative item (kept in registers: SW
+        //      lies in the J / W area other lanes are still reading)
+        double sw[12];
+        {
+            const int k = lane < nd ? lane : 0, rw = rep[k], it = rw & 0xFFF, b = (rw >> 12) & 0xFF;
+            const double *gb = S + P.o_gB + 12 * b, *J = S + P.o_J + 6 * it, *W = S + P.o_W + 6 * it;
+            const double px = gb[3], py = gb[7], pz = gb[11];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const double *X = h ? W : J;
+                double v[3], w[3];
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    v[r] = gb[4 * r] * X[0] + gb[4 * r + 1] * X[1] + gb[4 * r + 2] * X[2];
+                    w[r] = gb[4 * r] * X[3] + gb[4 * r + 1] * X[4] + gb[4 * r + 2] * X[5];
+                }
+                // velocity of the point at the world origin: R v_B - w x p
+                sw[6 * h + 0] = v[0] - (w[1] * pz - w[2] * py); sw[6 * h + 1] = v[1] - (w[2] * px - w[0] * pz); sw[6 * h + 2] = v[2] - (w[0] * py - w[1] * px);
+                sw[6 * h + 3] = w[0]; sw[6 * h + 4] = w[1]; sw[6 * h + 5] = w[2];
+            }
+        }
+        TG_SYNC();
+        // ---- phase B: twists to SW; composites of the subtree groups (lane = entry; membership is compile-time) to CMP
+        if (on && lane < nd) {
+#pragma unroll
+            for (int r = 0; r < 12; r++) SW[12 * lane + r] = sw[r];
+        }
+        if (on && lane < 16) {
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int b = 0; b < NB; b++) if ((P.cmp_gmask[g] >> b) & 1) acc += BW[16 * b + lane];
+                CMP[16 * g + lane] = acc;
+            }
+        }
+        TG_SYNC();
+        TG_STAMP(7);
+        // ---- phase C: the image (the whole union: poses and BW are dead now) is cleared; per config b: I s_b, Z_b = Y_b + I w_b, GG_b
+        {
+            typedef double tg_d2 __attribute__((ext_vector_type(2)));
+            static_assert(((SP::o_Df | (nf * ld)) & 1) == 0, "newton_matrix_composite: image not 16-byte aligned");
+            tg_d2 *A2 = reinterpret_cast<tg_d2 *>(A);
+            const tg_d2 z2 = {0.0, 0.0};
+            if (on) TG_FOR(i, (nf * ld) >> 1) A2[i] = z2;
+        }
+        if (on && lane < nd) {
+            const double *c = CMP + 16 * (rep[lane] >> 20);
+            const double M = c[0], Cx = c[1], Cy = c[2], Cz = c[3], Dxx = c[4], Dxy = c[5], Dxz = c[6], Dyy = c[7], Dyz = c[8], Dzz = c[9];
+            const double h0 = c[10], h1 = c[11], h2 = c[12], h3 = c[13], h4 = c[14], h5 = c[15];
+            const double *s = SW + 12 * lane, *w = s + 6;
+            auto apply = [&](const double *x, double *y) {      // spatial inertia times twist
+                y[0] = M * x[0] - (Cy * x[5] - Cz * x[4]); y[1] = M * x[1] - (Cz * x[3] - Cx * x[5]); y[2] = M * x[2] - (Cx * x[4] - Cy * x[3]);
+                y[3] = (Cy * x[2] - Cz * x[1]) + Dxx * x[3] + Dxy * x[4] + Dxz * x[5];
+                y[4] = (Cz * x[0] - Cx * x[2]) + Dxy * x[3] + Dyy * x[4] + Dyz * x[5];
+                y[5] = (Cx * x[1] - Cy * x[0]) + Dxz * x[3] + Dyz * x[4] + Dzz * x[5];
+            };
+            double Is[6], Iw[6];
+            apply(s, Is); apply(w, Iw);
+            const double b0 = s[0], b1 = s[1], b2 = s[2], b3 = s[3], b4 = s[4], b5 = s[5];
+            double Z[6];
+            Z[0] = Iw[0] + (b4 * h2 - b5 * h1); Z[1] = Iw[1] + (b5 * h0 - b3 * h2); Z[2] = Iw[2] + (b3 * h1 - b4 * h0);
+            Z[3] = Iw[3] + (b1 * h2 - b2 * h1) + (b4 * h5 - b5 * h4);
+            Z[4] = Iw[4] + (b2 * h0 - b0 * h2) + (b5 * h3 - b3 * h5);
+            Z[5] = Iw[5] + (b0 * h1 - b1 * h0) + (b3 * h4 - b4 * h3);
+            // G = M v + w x C;  GG = G x g
+            const double Gx = M * b0 + (b4 * Cz - b5 * Cy), Gy = M * b1 + (b5 * Cx - b3 * Cz), Gz = M * b2 + (b3 * Cy - b4 * Cx);
+            const double gx = P.grav[0], gy = P.grav[1], gz = P.grav[2];
+            double *o = CZ + 15 * lane;
+#pragma unroll
+            for (int r = 0; r < 6; r++) { o[r] = Is[r]; o[6 + r] = Z[r]; }
+            o[12] = Gy * gz - Gz * gy; o[13] = Gz * gx - Gx * gz; o[14] = Gx * gy - Gy * gx;
+        }
+        TG_SYNC();
+        // ---- phase D: the constant entries (right-hand side, damping, -Dh1' / Dh2) and the config pairs: one lane per pair, one pair per
+        //      entry and its transpose (the damping joins the diagonal pair's sum as an LDS add of its own: same wave, fixed order)
+        if (on) {
+            if (lane < nf) {
+                A[lane * ld + nf] = S[P.o_f + lane];
+                if (lane < nd) lds_add(&A[lane * ld + lane], -tdamp);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int n = lane + u * TEAM, c = tck[u][0], k = tck[u][1];
+                if (n < P.n_dh && k < nd) { A[k * ld + nd + c] = -S[P.o_Dh1 + n]; A[(nd + c) * ld + k] = S[P.o_Dh2 + n]; }
+            }
+        }
+        const double qdt = 0.25 * dt, rdt = 1.0 / dt;
+#pragma unroll
+        for (int u = 0; u < TP; u++) {
+            if (on && lane + u * TEAM < NP) {
+                const int a = prec[u] & 0xFFFF, b = prec[u] >> 16;
+                const double *sa = SW + 12 * a, *wa = sa + 6, *Is = CZ + 15 * b, *Z = Is + 6, *GG = Is + 12;
+                double s_[6], w_[6], i_[6], z_[6];
+#pragma unroll
+                for (int r = 0; r < 6; r++) { s_[r] = sa[r]; w_[r] = wa[r]; i_[r] = Is[r]; z_[r] = Z[r]; }
+                const double g0 = GG[0], g1 = GG[1], g2 = GG[2];
+                double mab = 0.0, lqq = s_[3] * g0 + s_[4] * g1 + s_[5] * g2, cab = 0.0, cba = 0.0;
+#pragma unroll
+                for (int r = 0; r < 6; r++) { mab = fma(s_[r], i_[r], mab); lqq = fma(w_[r], z_[r], lqq); cab = fma(s_[r], z_[r], cab); cba = fma(w_[r], i_[r], cba); }
+                const double sym = qdt * lqq - rdt * mab, skew = 0.5 * (cba - cab);
+                lds_add(&A[a * ld + b], sym + (a != b ? skew : 0.0));
+                if (a != b) lds_add(&A[b * ld + a], sym - skew);
+            }
+        }
+        TG_SYNC();
+        TG_STAMP(8);
+    }
+#endif
+
     // ---- Newton matrix [Df | f] (midpointvi.c:577-670) ---------------------------------------------------
     TG_HD void newton_matrix(bool on) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_CMP)
+        if constexpr (TEAM == 64 && !SPRINGS && tg_static_cmp<typename std::remove_cv<PROG>::type>::value) { newton_matrix_composite(on); return; }
+#endif
         PROG &P = tg_fresh(this->P);
         const int nd = P.nd, nf = P.nf, ld = P.df_ld;
         double *A = S + P.o_Df;

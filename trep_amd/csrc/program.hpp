@@ -129,6 +129,15 @@ struct DevProg {
     // structured Newton solve of the system-specialised rollout kernels (bbd.hpp): groups, largest own block, largest border list,
     // trailing size; the plan tables (bbd_tab [128], bbd_tvar [16]) and the LDS offset they are staged at (rollout kernels only:
     // the slice's last 64 doubles, which the derivative layouts overlay)
+    // composite form of the Newton matrix's inertial part (system-specialised rollout kernels, mvi_core.hpp newton_matrix_composite): the
+    // (body, item, item) pairs of a config pair (a, b) all share the bodies below b, so their sum is a bilinear form of the WORLD-frame
+    // joint twists in the composite inertia / momentum of that subtree.  cmp_rep [nd]: an item of config k (or -1); cmp_grp [nd]: the
+    // subtree group of config k (configs with the same set of bodies below them share one); cmp_goff / cmp_gbody: the bodies of each
+    // group; cmp_pair [n_cmpairs]: a | b << 16 for every dynamic config pair with a on the path to b; LDS (inside the J / W area, dead
+    // once the residual is formed): o_cmp 16 doubles per group, o_csw 12 per config (s, w), o_ccz 15 per config (I s, Z, G x g)
+    int cmp_ok, n_cgroups, n_cmpairs, o_cmp, o_csw, o_ccz, o_cbw, o_cmpt;   // o_cbw: per-body world entries (16 per body, J / W area); o_cmpt: per config item | body << 12 | group << 20 (ints), behind the plan tables
+    int cmp_gmask[32];        // bit F of cmp_gmask[g]: body F belongs to subtree group g
+    const int *cmp_rep, *cmp_grp, *cmp_goff, *cmp_gbody, *cmp_pair;
     int bbd_ok, bbd_g, bbd_ng, bbd_nb, bbd_t, o_bbd;
     int bbd_tvar[16];         // image index of trailing variable i
     const int *bbd_tab;
@@ -148,7 +157,7 @@ struct HostProgram {
     std::vector<double> c_dist, c_tol;
     std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
     std::vector<double> damp, cs_k, cs_kq0, cs_c0, s_k, s_x0, s_c, c_nloc, wr_const, wr_Rloc, ncs_mb, ncs_tab;
-    std::vector<int> ncs_i, bbd_tab;
+    std::vector<int> ncs_i, bbd_tab, cmp_rep, cmp_grp, cmp_goff, cmp_gbody, cmp_pair;
     std::vector<unsigned char> newton_pattern;   // [nf * nf] structural non-zeros of the Newton matrix (symmetrised), host side only
     std::vector<int> wr_in, wr_kind;
     std::vector<int> cf_cfg, cf_in;
@@ -669,6 +678,45 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.e_o_wT = take(P.n_wpair); P.e_o_Hu = take(nw ? nq * P.nu : 0);   // point forces: w-contracted F.d3p per pair, -dt/2 w.F_dudq [nq][nu]
     off = std::max(off, P.d_lds_per_team);
     P.e_lds_per_team = (off + 1) & ~1;
+    {   // composite form of the Newton matrix (see DevProg::cmp_*)
+        P.cmp_ok = 0; P.n_cgroups = 0; P.n_cmpairs = 0; P.o_cmp = P.o_csw = P.o_ccz = P.o_cbw = P.o_cmpt = 0;
+        for (int i = 0; i < 32; i++) P.cmp_gmask[i] = 0;
+        H.cmp_rep.assign(std::max(nd, 1), -1); H.cmp_grp.assign(std::max(nd, 1), 0);
+        std::vector<std::vector<int>> below(nd);            // bodies below each dynamic config
+        for (int it = 0; it < nitems; it++) {
+            const int c = H.it_cfg[it];
+            if (c < nd) { below[c].push_back(H.it_body[it]); if (H.cmp_rep[c] < 0) H.cmp_rep[c] = it; }
+        }
+        std::map<std::vector<int>, int> group_of;
+        H.cmp_goff.assign(1, 0);
+        bool all_rep = nd > 0;
+        for (int c = 0; c < nd; c++) {
+            if (below[c].empty()) { all_rep = false; continue; }
+            auto f = group_of.find(below[c]);
+            if (f == group_of.end()) {
+                f = group_of.emplace(below[c], (int)group_of.size()).first;
+                for (int b : below[c]) H.cmp_gbody.push_back(b);
+                H.cmp_goff.push_back((int)H.cmp_gbody.size());
+            }
+            H.cmp_grp[c] = f->second;
+        }
+        std::vector<unsigned char> from_pairs((size_t)nd * nd, 0), from_cmp((size_t)nd * nd, 0);
+        for (int n = 0; n < P.n_npairs; n++) from_pairs[(size_t)(H.pair4[4 * n + 2] & 0xFFFF) * nd + (H.pair4[4 * n + 2] >> 16)] = 1;
+        for (int c = 0; c < nd && all_rep; c++) {           // ancestors of c (and c itself) along the path of its representative item's body
+            const int b = H.it_body[H.cmp_rep[c]];
+            for (int it = H.b_item_off[b]; it < H.b_item_off[b + 1]; it++) {
+                const int a = H.it_cfg[it];
+                if (a < nd) { H.cmp_pair.push_back(a | (c << 16)); from_cmp[(size_t)a * nd + c] = 1; }
+                if (a == c) break;
+            }
+        }
+        const int need = 16 * (int)group_of.size() + 27 * nd + 16 * nb;
+        if (all_rep && nd >= 8 && nd <= 64 && nb <= 32 && group_of.size() <= 32 && from_pairs == from_cmp && need <= 12 * nitems && nitems < 4096) {
+            P.cmp_ok = 1; P.n_cgroups = (int)group_of.size(); P.n_cmpairs = (int)H.cmp_pair.size();
+            P.o_cmp = P.o_J; P.o_csw = P.o_cmp + 16 * P.n_cgroups; P.o_ccz = P.o_csw + 12 * nd; P.o_cbw = P.o_ccz + 15 * nd;
+            for (auto &g : group_of) for (int b : g.first) P.cmp_gmask[g.second] |= 1 << b;
+        }
+    }
     {   // structured Newton solve: structural pattern of [[Df11, -Dh1^T], [Dh2, 0]] (newton_matrix in mvi_core.hpp writes exactly these
         // entries) -> bordered-block-diagonal plan.  Full-wave systems of the size gj_panel serves; the solver's scratch (trailing
         // system + border solution) lives in the dead J / W area.
@@ -696,6 +744,11 @@ inline HostProgram build_program(const tg_system_desc *d) {
                 P.lds_per_team += 64;
             }
         }
+        if (P.cmp_ok) {     // representative (item | body << 16) of every dynamic config, staged like the plan tables (rollout kernels only)
+            P.o_cmpt = P.lds_per_team;
+            P.lds_per_team += (nd + 1) / 2;
+            P.lds_per_team = (P.lds_per_team + 1) & ~1;
+        }
     }
     H.pack();
     return H;
@@ -718,7 +771,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
     X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in) X(wr_kind) X(ncs_i) \
-    X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4) X(bbd_tab)
+    X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4) X(bbd_tab) X(cmp_rep) X(cmp_grp) X(cmp_goff) X(cmp_gbody) X(cmp_pair)
 #define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c) X(wr_Rloc) X(ncs_mb) X(ncs_tab)
 
 inline void HostProgram::pack() {
