@@ -472,6 +472,20 @@ def main():
                 "measured_v_fma_f64_ceiling_tflops": ceiling, "ceiling_source": ceiling_src,   # tools/micro/mfma_f64_rate.hip, two waves per SIMD
                 "frac": fp64[0] / avg_kernel_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                 "flop_per_del_step": fp64[0] / (b_local * N), "f64_wave_instructions_per_del_step": fp64[1] / (b_local * N), "source": fp64[2]}
+            # The composite form of the Newton matrix (round 4) does the same step with 38 % fewer flops, so the counter-based rate fell while the
+            # throughput rose; for a like-for-like reading against earlier rounds: the rate at which this kernel gets through the WORK of the
+            # previous formulation (its counter-measured flop per DEL step, profiles/r04_fp64_pair_loop.json)
+            ref = os.path.join(ROOT, "profiles", "r04_fp64_pair_loop.json")
+            if out["fp64"] and os.path.exists(ref):
+                try:
+                    d = json.load(open(ref))
+                    per_step = d["estimated_fp64_flop_per_launch"] / float(d["global_batch"] * d["rollout_steps"])
+                    out["fp64"]["pair_loop_formulation"] = {
+                        "flop_per_del_step": per_step, "equivalent_tflops": per_step * b_local * N / avg_kernel_s / 1e12,
+                        "equivalent_frac": per_step * b_local * N / avg_kernel_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "source": os.path.relpath(ref, ROOT),
+                        "note": "flops the (body, item, item) pair loop spends on the same DEL step / this kernel's time: comparable with the fp64.frac of rounds 1-3"}
+                except Exception:
+                    pass
         if discopt is not None:
             out["discopt"] = discopt
         if want_cpu:

@@ -48,8 +48,9 @@ TREPAMD_LIB=trep_amd/libtrepamd_prof.so timeout 300 python tools/phase_profile_l
 timeout 300 python tools/step_latency.py > $out/step_latency.json 2> $out/step_latency.err
 # phase profile of the specialised rollout kernel (diagnostic -DTG_PROFILE builds made on the build box: tools/collect_r04.sh expects them)
 F="-DSPEC_ARGS_IN_MEMORY -DTG_GJ_INLINE -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-mfma-vgpr-form -DTG_PROFILE"
-(echo "# system-specialised rollout kernel, structured Newton solve gj_bbd (profiling build: -DTG_PROFILE adds s_memtime stamps)"; TREPAMD_LIB=trep_amd/libtrepamd_prof.so TREPAMD_SPEC_FLAGS="$F" timeout 200 python tools/phase_profile.py;
- echo; echo "# the same with round 3's solver gj_panel (-DTG_NO_BBD)"; TREPAMD_LIB=trep_amd/libtrepamd_prof.so TREPAMD_SPEC_FLAGS="$F -DTG_NO_BBD" timeout 200 python tools/phase_profile.py;
+(echo "# system-specialised rollout kernel: structured Newton solve gj_bbd, Newton matrix in composite form (profiling build: -DTG_PROFILE adds s_memtime stamps; 'newton init' = composite phases A + B, 'newton pairs' = C + D)"; TREPAMD_LIB=trep_amd/libtrepamd_prof.so TREPAMD_SPEC_FLAGS="$F" timeout 200 python tools/phase_profile.py;
+ echo; echo "# the same with the (body, item, item) pair loop (-DTG_NO_CMP)"; TREPAMD_LIB=trep_amd/libtrepamd_prof.so TREPAMD_SPEC_FLAGS="$F -DTG_NO_CMP" timeout 200 python tools/phase_profile.py;
+ echo; echo "# ... and with round 3's solver gj_panel (-DTG_NO_BBD -DTG_NO_CMP)"; TREPAMD_LIB=trep_amd/libtrepamd_prof.so TREPAMD_SPEC_FLAGS="$F -DTG_NO_BBD -DTG_NO_CMP" timeout 200 python tools/phase_profile.py;
  echo; echo "# generic rollout kernel"; TREPAMD_LIB=trep_amd/libtrepamd_prof.so TREPAMD_NO_SPECIALIZE=1 timeout 200 python tools/phase_profile.py) > $out/phase_profile.txt 2>&1
 bash tools/gpu_prof_derivs.sh $tag/prof_derivs > /dev/null 2>&1
 ls -la $out; cat $out/bench.json | cut -c1-600; head -12 $out/kernel_stats.csv

@@ -7,7 +7,7 @@ python __graft_entry__.py > /dev/null
 make -s -C trep_amd/csrc prof
 tools/micro/build.sh > /dev/null
 F="-DSPEC_ARGS_IN_MEMORY -DTG_GJ_INLINE -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-mfma-vgpr-form -DTG_PROFILE"
-for extra in "" " -DTG_NO_BBD" " -DSPEC_DERIVATIVES"; do     # (the last one: tools/gpu_prof_derivs.sh)
+for extra in "" " -DTG_NO_CMP" " -DTG_NO_BBD -DTG_NO_CMP" " -DSPEC_DERIVATIVES"; do     # (the last one: tools/gpu_prof_derivs.sh)
     TREPAMD_LIB=trep_amd/libtrepamd_prof.so TREPAMD_SPEC_FLAGS="$F$extra" python -c "
 import sys; sys.path.insert(0, '.')
 from trep_amd import specialize, systems
