@@ -25,10 +25,15 @@ for S in (32, 256):
     for m in range(nk):
         A[:, :, nq + nd + m, nd + m] = -100.0; B[:, :, nd + m, m] = 1.0; B[:, :, nq + nd + m, m] = 100.0
     dA.set(A); dB.set(B)
-    for affine, structured in ((False, False), (True, False), (False, True), (True, True)):
+    nxh = 2 * nd + nk
+    hz = 0.02 * rng.standard_normal((S, N, nxh + nU, nxh + nU)); hz = hz + np.swapaxes(hz, 2, 3)
+    dhz = pool.upload(hz)
+    for affine, structured, newton in ((False, False, False), (True, False, False), (False, True, False), (True, True, False), (True, True, True), (True, False, True)):
         p = _lib.LqProblem()
         if structured:
             p.ds_nd, p.ds_nk, p.ds_nu = nd, nk, 0
+        if newton:      # the Newton model: curvature blocks read from HZ on the fly
+            p.hz_dev, p.hz_R, p.hz_nx = dhz.ptr, nxh + nU, nxh
         p.n_problems, p.horizon, p.nX, p.nU = S, N, nX, nU
         p.A_dev, p.B_dev, p.Q_dev, p.Qf_dev, p.R_dev, p.K_dev, p.C_dev = dA.ptr, dB.ptr, dQ.ptr, dQ.ptr, dR.ptr, dK.ptr, dC.ptr
         if affine:
@@ -40,6 +45,6 @@ for S in (32, 256):
             _lib.check(L.tg_tv_lq(0, ctypes.byref(p)))
             L.tg_device_synchronize(0)
             best = min(best, time.perf_counter() - t0)
-        out["S%d_%s%s_us_per_k" % (S, "lq" if affine else "lqr", "_dsystem" if structured else "")] = round(best / N * 1e6, 2)
+        out["S%d_%s%s%s_us_per_k" % (S, "lq" if affine else "lqr", "_newton_model" if newton else "", "_dsystem" if structured else "")] = round(best / N * 1e6, 2)
     pool.close()
 print(json.dumps(out))

@@ -1253,10 +1253,6 @@ struct Core {
         double *A = S + P.o_Df, *CMP = S + P.o_cmp, *SW = S + P.o_csw, *CZ = S + P.o_ccz, *BW = S + P.o_sc;
         static_assert(16 * NB <= SP::o_gB - SP::o_sc, "newton_matrix_composite: body entries do not fit the dead pose area");
         const int *rep = (const int *)(S + P.o_cmpt);
-        // the pair records of all trips: requested now, used three phases later
-        int prec[TP];
-#pragma unroll
-        for (int u = 0; u < TP; u++) prec[u] = P.cmp_pair[lane + u * TEAM < NP ? lane + u * TEAM : 0];
         // ---- phase A.  (i) lane (body b, axis r): the body's world entries -- M, C_r = m p_r, row r of D = R I R' + m (|p|^2 1 - p p'),
         //      f_r = (R m v_B)_r, tau_r = (R I w_B)_r + (p x f)_r -- written straight to BW (nothing there is read in this phase);
         if (on && lane < 3 * NB) {
@@ -1307,6 +1303,10 @@ struct Core {
             }
         }
         TG_SYNC();
+        // the pair records of all trips: requested here (behind the phase that holds twelve twist components in registers), used two phases later
+        int prec[TP];
+#pragma unroll
+        for (int u = 0; u < TP; u++) prec[u] = P.cmp_pair[lane + u * TEAM < NP ? lane + u * TEAM : 0];
         // ---- phase B: twists to SW; composites of the subtree groups (lane = entry; membership is compile-time) to CMP
         if (on && lane < nd) {
 #pragma unroll
