@@ -135,7 +135,7 @@ struct DevProg {
     // subtree group of config k (configs with the same set of bodies below them share one); cmp_goff / cmp_gbody: the bodies of each
     // group; cmp_pair [n_cmpairs]: a | b << 16 for every dynamic config pair with a on the path to b; LDS (inside the J / W area, dead
     // once the residual is formed): o_cmp 16 doubles per group, o_csw 12 per config (s, w), o_ccz 15 per config (I s, Z, G x g)
-    int cmp_ok, n_cgroups, n_cmpairs, o_cmp, o_csw, o_ccz, o_cbw, o_cmpt;   // o_cbw: per-body world entries (16 per body, J / W area); o_cmpt: per config item | body << 12 | group << 20 (ints), behind the plan tables
+    int cmp_ok, n_cgroups, n_cmpairs, o_cmp, o_csw, o_ccz, o_cmpt;   // o_cmpt: per config item | body << 12 | group << 20 (ints), behind the plan tables (the per-body world entries go to the dead joint-pose area)
     int cmp_gmask[32];        // bit F of cmp_gmask[g]: body F belongs to subtree group g
     const int *cmp_rep, *cmp_grp, *cmp_goff, *cmp_gbody, *cmp_pair;
     int bbd_ok, bbd_g, bbd_ng, bbd_nb, bbd_t, o_bbd;
@@ -679,7 +679,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     off = std::max(off, P.d_lds_per_team);
     P.e_lds_per_team = (off + 1) & ~1;
     {   // composite form of the Newton matrix (see DevProg::cmp_*)
-        P.cmp_ok = 0; P.n_cgroups = 0; P.n_cmpairs = 0; P.o_cmp = P.o_csw = P.o_ccz = P.o_cbw = P.o_cmpt = 0;
+        P.cmp_ok = 0; P.n_cgroups = 0; P.n_cmpairs = 0; P.o_cmp = P.o_csw = P.o_ccz = P.o_cmpt = 0;
         for (int i = 0; i < 32; i++) P.cmp_gmask[i] = 0;
         H.cmp_rep.assign(std::max(nd, 1), -1); H.cmp_grp.assign(std::max(nd, 1), 0);
         std::vector<std::vector<int>> below(nd);            // bodies below each dynamic config
@@ -710,10 +710,11 @@ inline HostProgram build_program(const tg_system_desc *d) {
                 if (a == c) break;
             }
         }
-        const int need = 16 * (int)group_of.size() + 27 * nd + 16 * nb;
-        if (all_rep && nd >= 8 && nd <= 64 && nb <= 32 && group_of.size() <= 32 && from_pairs == from_cmp && need <= 12 * nitems && nitems < 4096) {
+        const int need = 16 * (int)group_of.size() + 27 * nd;                      // J / W area
+        if (all_rep && nd >= 8 && nd <= 64 && nb <= 32 && group_of.size() <= 32 && from_pairs == from_cmp && need <= 12 * nitems && nitems < 4096 &&
+            16 * nb <= 2 * nj + std::max(12 * nj, 2 * nitems)) {      // (the per-body entries: sin / cos + joint-pose area, dead by then)
             P.cmp_ok = 1; P.n_cgroups = (int)group_of.size(); P.n_cmpairs = (int)H.cmp_pair.size();
-            P.o_cmp = P.o_J; P.o_csw = P.o_cmp + 16 * P.n_cgroups; P.o_ccz = P.o_csw + 12 * nd; P.o_cbw = P.o_ccz + 15 * nd;
+            P.o_cmp = P.o_J; P.o_csw = P.o_cmp + 16 * P.n_cgroups; P.o_ccz = P.o_csw + 12 * nd;
             for (auto &g : group_of) for (int b : g.first) P.cmp_gmask[g.second] |= 1 << b;
         }
     }
