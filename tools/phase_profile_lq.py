@@ -43,5 +43,5 @@ for affine, structured in ((False, False), (True, False), (False, True), (True, 
     _lib.check(L.tg_lq_profile(0, out))
     v = np.array(list(out)[:8], dtype=float)
     print("%s nX=%d nU=%d N=%d S=%d: %.1f ms, %.1f us per k; cycles per k %.0f" % (("LQ (affine)" if affine else "LQR") + (" with the DSystem structure" if structured else " dense"), nX, nU, N, S, el * 1e3, el / N * 1e6, v.sum() / N))
-    for n_, c in zip(["P.A tile, B'P, B'b", "PA->LDS, gamma, Kpart", "Gauss-Jordan (nU x nU)", "K out, new P tile (A'PA - Kpart'K), new b", "P, b, next A/B into LDS", "symmetrise", "(mfma kernel) solve of wave 0 without the barrier", "(DSystem kernel) k-loop of phase 1 alone"], v):
+    for n_, c in zip(["P.A tile, B'P, B'b", "PA->LDS, gamma, Kpart", "Gauss-Jordan (nU x nU)", "K out, new P tile (A'PA - Kpart'K), new b", "P, b, next A/B into LDS", "symmetrise", "(mfma kernel) solve of wave 0 without the barrier", "(DSystem kernel) phase 3 barrier wait (factorisation vs tiles), before the replay"], v):
         print("  %-44s %10.0f /k  %5.1f%%" % (n_, c / N, 100 * c / v.sum()))

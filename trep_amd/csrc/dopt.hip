@@ -600,6 +600,77 @@ __device__ __forceinline__ bool lq_factor_rows_spd(double *G_generic, int ldw, i
     return true;
 }
 
+// The same unpivoted factorisation with TWO matrix rows per lane (rows 2 i and 2 i + 1 in lane i < NR / 2 <= 16): the pivot row of step k then sits
+// in lane k / 2 of the first 16-lane DPP row, and the elimination is `v_fmac_f64_dpp ... row_newbcast:k/2` -- one instruction per (row, column)
+// instead of two v_readlane + one FMA, no SGPR hazards.  And it leaves gamma^-1 itself (in-place Gauss-Jordan inversion, over gamma in G) instead of
+// the multipliers: the replay of the elimination on the 1 + nX right-hand sides -- 18 steps of two v_readlane + one FMA per column on 18 of 64
+// lanes, the longest phase of the step (17 k cycles) -- becomes a product gamma^-1 [r | Kpart] on the matrix cores (lq_apply_inverse).  Same guards
+// as lq_factor_rows_spd; nothing is written unless all of them passed (the caller then falls back to the pivoted factorisation + replay).
+template <int L>
+__device__ __forceinline__ double lq_bcast16(double v) {
+    return __longlong_as_double(__builtin_amdgcn_update_dpp((long long)0, __double_as_longlong(v), 0x150 + L, 0xf, 0xf, true));
+}
+template <int L>
+__device__ __forceinline__ void lq_fmac16(double &a, double b, double c) {      // a += (lane L's b) * c
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(b), "v"(c), "n"(L));
+}
+template <int K, int NR>
+__device__ __forceinline__ void lq_spd2_steps(double (&m0)[NR], double (&m1)[NR], int lane, int nU, double &inv0, double &inv1) {
+    if constexpr (K < NR) {
+        if (K < nU) {      // (uniform)
+            constexpr int L = K >> 1;
+            constexpr bool ODD = (K & 1) != 0;
+            const double piv = lq_bcast16<L>(ODD ? m1[K] : m0[K]);
+            double inv = __builtin_amdgcn_rcp(piv);
+            { const double e = fma(-piv, inv, 1.0); inv = fma(inv, fma(e, e, e), inv); }
+            const bool pl = lane == L;
+            double n0 = -(m0[K] * inv), n1 = -(m1[K] * inv);      // minus the multipliers of the lane's two rows
+            if (ODD) { n1 = pl ? 0.0 : n1; inv1 = pl ? inv : inv1; } else { n0 = pl ? 0.0 : n0; inv0 = pl ? inv : inv0; }
+            // IN-PLACE Gauss-Jordan inversion: column K of the matrix is dead after this step and becomes column K of the inverse's
+            // numerator (pivot row: 1, other rows: minus their multiplier); the columns j < K already are such columns and are updated
+            // like the live matrix columns j > K
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                if (j == K) continue;
+                if (ODD) { lq_fmac16<L>(m0[j], m1[j], n0); lq_fmac16<L>(m1[j], m1[j], n1); }
+                else { lq_fmac16<L>(m1[j], m0[j], n1); lq_fmac16<L>(m0[j], m0[j], n0); }
+            }
+            m0[K] = (!ODD && pl) ? 1.0 : n0; m1[K] = (ODD && pl) ? 1.0 : n1;
+        }
+        lq_spd2_steps<K + 1, NR>(m0, m1, lane, nU, inv0, inv1);
+    }
+}
+template <int NR>
+__device__ __forceinline__ bool lq_factor_rows_spd2(double *G_generic, int ldw, int nU, int lane, double *fac_generic) {
+    static_assert(NR % 2 == 0 && NR <= 32, "two rows per lane on one 16-lane DPP row");
+    typedef __attribute__((address_space(3))) double lds_double;
+    typedef __attribute__((address_space(3))) int lds_int;
+    lds_double *G = (lds_double *)G_generic, *dinv_s = (lds_double *)fac_generic;
+    lds_int *col_s = (lds_int *)(dinv_s + 32), *piv_s = col_s + 32;
+    const int r0 = 2 * (lane & 15), r1 = r0 + 1;
+    const bool have = lane < NR / 2, in0 = have && r0 < nU, in1 = have && r1 < nU;
+    double m0[NR], m1[NR], a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const double x0 = G[(in0 ? r0 : 0) * ldw + (j < nU ? j : 0)], x1 = G[(in1 ? r1 : 0) * ldw + (j < nU ? j : 0)];
+        m0[j] = (in0 && j < nU) ? x0 : ((have && !in0 && j == r0) ? 1.0 : 0.0);
+        m1[j] = (in1 && j < nU) ? x1 : ((have && !in1 && j == r1) ? 1.0 : 0.0);
+        a0 = fmax(a0, fabs(m0[j])); a1 = fmax(a1, fabs(m1[j]));
+    }
+    double inv0 = 0.0, inv1 = 0.0;
+    lq_spd2_steps<0, NR>(m0, m1, lane, nU, inv0, inv1);
+    // the guards: |pivot| > 2^-20 of the row's largest entry, from the reciprocal kept by each row (a zero pivot gives inf / NaN: fails)
+    const bool bad = (in0 && !(fabs(inv0) * (9.5367431640625e-07 * a0) < 1.0)) || (in1 && !(fabs(inv1) * (9.5367431640625e-07 * a1) < 1.0));
+    if (__any(bad ? 1 : 0)) return false;
+#pragma unroll
+    for (int k = 0; k < NR; k++) if (k < nU) {      // gamma^-1 [row][k] = numerator / pivot of the row
+        if (in0) G[r0 * ldw + k] = m0[k] * inv0;
+        if (in1) G[r1 * ldw + k] = m1[k] * inv1;
+    }
+    (void)piv_s; (void)col_s; (void)dinv_s;
+    return true;
+}
+
 template <int NR, int SL>
 __device__ __forceinline__ void lq_apply_rows(const double *G_generic, int ldw, int nU, int rhs_lo, int rhs_n, double *Ks_generic, int ldx,
                                               double *Cs_generic, int lane, const double *fac_generic) {
@@ -989,7 +1060,7 @@ struct LqDsLayout {
         Ks = o; o += nUp * ldx;                                             // K_k [nUp][ldx]; before the solve: P B [ldx][nUp]
         G = o; o += nUp * ldw;
         bv = o; o += ldx; bn = o; o += ldx; wv = o; o += nUp; rv = o; o += nUp; rn = o; o += nUp;
-        fac = o; o += 32 + 16 + 16;
+        fac = o; o += 32 + 16 + 16 + 2;      // (+ the form flag of lq_factor_call)
         total = o;
     }
 };
@@ -1012,7 +1083,10 @@ template <int NR>
 __device__ __noinline__ void lq_factor_call(double *G, int ldw, int nU, int lane, double *fac, int *sing) {
     // (arguments of a call travel in vector registers: say that the sizes are wave-uniform, or every `k < nU` becomes a divergent branch)
     ldw = __builtin_amdgcn_readfirstlane(ldw); nU = __builtin_amdgcn_readfirstlane(nU);
-    if (!lq_factor_rows_spd<NR>(G, ldw, nU, lane, fac)) lq_factor_pivoted_call<NR>(G, ldw, nU, lane, fac, sing);
+    // fac[64] (as an int): 1 = G's gamma block holds gamma^-1 (lq_apply_inverse), 0 = the multipliers of the pivoted factorisation (lq_apply_rows)
+    const bool inverse = lq_factor_rows_spd2<NR>(G, ldw, nU, lane, fac);
+    if (!inverse) lq_factor_pivoted_call<NR>(G, ldw, nU, lane, fac, sing);
+    if (lane == 0) *reinterpret_cast<int *>(fac + 64) = inverse ? 1 : 0;
 }
 
 // Launch arguments re-read per phase: the struct sits at the head of the kernel-argument segment; reading it through a laundered
@@ -1079,7 +1153,9 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_ds(const tg_lq_problem a0) {
     int cur = 0, k = a0.horizon - 1;
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
     constexpr int T1 = 4;                              // chains per wave in phase 1 (P A and P B tiles in one list: at most 32 tiles, see tg_tv_lq)
-    constexpr int NTRI = NT * (NT + 1) / 2, TW = NW - 1, TSYM = (NTRI + TW - 1) / TW;
+    // phase 3: wave 0 factorises gamma; the wave that shares its SIMD (a workgroup's waves are dealt to the four SIMDs in turn: wave 4) stays out of
+    // the tile work -- every dependent fp64 operation of the factorisation otherwise queues behind a 64-cycle matrix-core instruction of its neighbour
+    constexpr int NTRI = NT * (NT + 1) / 2, TW = NW - 2, TSYM = (NTRI + TW - 1) / TW;
     constexpr int TMAX = T1 > TSYM ? T1 : TSYM;
     v4d acc[TMAX];
     {
@@ -1103,8 +1179,8 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_ds(const tg_lq_problem a0) {
         LQ_DS_PHASE;
 #pragma unroll
         for (int i = 0; i < TSYM; i++) {
-            const int t = (wave - 1) + TW * i;
-            ok_[i] = t < NTRI && wave > 0;
+            const int t = (wave < 4 ? wave - 1 : wave - 2) + TW * i;
+            ok_[i] = t < NTRI && wave != 0 && wave != 4;
             int tr = 0, tt = ok_[i] ? t : 0;
 #pragma unroll
             for (int r = 0; r < NT; r++) if (tt >= NT - r && tr == r) { tt -= NT - r; tr = r + 1; }
@@ -1161,7 +1237,7 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_ds(const tg_lq_problem a0) {
                 }
                 if (k0 < KC) mm(a0, b0);
             }
-            LQ_STAMP(7);      // (diagnostic build: the k-loop alone)
+
             // the single-entry rows outside the compact rows: one (P A tile: the v row of a Qk column) or two (P B tile: the Qk and the v row of
             // a rho column) extra terms per element.  Branch-free -- an element without such a row reads row 0 with a zero coefficient --
             // and all loads ahead of the FMAs: as guarded code this was ~50 basic blocks of one LDS round trip each (6.5 k cycles)
@@ -1316,7 +1392,7 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_ds(const tg_lq_problem a0) {
         {   // ---- phase 3: wave 0 factorises gamma while the others accumulate Q_k + A'(P A) on the upper-triangle tiles --------------
             LQ_DS_PHASE;
             if (wave == 0) lq_factor_call<NR>(G, ldw, nU, lane, fac, &s_sing);
-            else {
+            else if (wave != 4) {
                 const double *Qk = a.Q_dev + (size_t)s * a.Q_seed_stride + (size_t)k * a.Q_step_stride;
                 // the weights Q_k (+ curvature) come from global memory: requested here, added behind the chains (as the chains' starting
                 // values they put a global-memory latency in front of the first matrix-core instruction)
@@ -1394,6 +1470,27 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_ds(const tg_lq_problem a0) {
             LQ_DS_PHASE;
             const int rhs_total = 1 + ldc, slice = (rhs_total + NW - 1) / NW;
             const int lo = wave * slice, nrhs = lo < rhs_total ? (rhs_total - lo < slice ? rhs_total - lo : slice) : 0;
+            LQ_STAMP(7);      // (diagnostic build: up to here the wait for the factorisation / the tiles; from here the gains)
+            if (*reinterpret_cast<const int *>(fac + 64)) {
+                // [C | K] = gamma^-1 [r + B'b | Kpart] on the matrix cores: NUT x NTC tiles of K (five k-steps each), C as 18 dot products
+                for (int t = wave; t < NUT * NTC; t += NW) {
+                    const int tu = t / NTC, tj = t - tu * NTC, u = 16 * tu + lr, col = 16 * tj + lr;
+                    v4d c = zero4;
+                    for (int v0 = 0; v0 < nUp; v0 += 4) {
+                        const double x = G[(u < nU ? u : 0) * ldw + (v0 + lk < nU ? v0 + lk : 0)];
+                        const double av = (u < nU && v0 + lk < nU) ? x : 0.0;                  // gamma^-1 [u][v]
+                        const double bw = G[(v0 + lk) * ldw + nU + 1 + col];                    // Kpart [v][col] (rows nU .. nUp-1 of G are zero)
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bw, c, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { const int uo = 16 * tu + lk + 4 * r; if (uo < nU) Ks[uo * ldx + col] = c[r]; }
+                }
+                if (tid < nU) {
+                    double acc = 0.0;
+                    for (int v = 0; v < nU; v++) acc = fma(G[tid * ldw + v], G[v * ldw + nU], acc);
+                    wv[tid] = acc;
+                }
+            } else
             lq_apply_rows<NR, (16 * NT + 1 + NW - 1) / NW>(G, ldw, nU, lo, nrhs, Ks, ldx, wv, lane, fac);
             LQ_LDS_SYNC();
             LQ_STAMP(2);
