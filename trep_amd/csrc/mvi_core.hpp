@@ -145,6 +145,9 @@ namespace tg {
 // the structured Newton solve needs its plan as compile-time constants: system-specialised schedules (SpecProg: static members) only
 template <class P, class = void> struct tg_static_bbd { static constexpr bool value = false; };
 template <class P> struct tg_static_bbd<P, typename std::enable_if<(P::bbd_ok >= 0)>::type> { static constexpr bool value = P::bbd_ok != 0; };
+// any system-specialised schedule (sizes are static members)
+template <class P, class = void> struct tg_is_spec { static constexpr bool value = false; };
+template <class P> struct tg_is_spec<P, typename std::enable_if<(P::nq >= 0)>::type> { static constexpr bool value = true; };
 // ... and so does the composite assembly of the Newton matrix (its group sums are unrolled over compile-time membership masks)
 template <class P, class = void> struct tg_static_cmp { static constexpr bool value = false; };
 template <class P> struct tg_static_cmp<P, typename std::enable_if<(P::cmp_ok >= 0)>::type> { static constexpr bool value = P::cmp_ok != 0 && P::tab_ok != 0; };
@@ -978,6 +981,16 @@ struct Core {
         if (on && lane < P.nd) {
             const int i = lane;
             double ldq = 0.0, lddq = 0.0;
+            if constexpr (tg_is_spec<typename std::remove_cv<PROG>::type>::value) {
+                // compile-time trip count (the most items any config has) with all loads ahead of the adds: as a loop over [n0, n1) every
+                // term waits out its own LDS read (ten in a row for a torso config).  Same order of the same additions.
+                typedef typename std::remove_cv<PROG>::type SP;
+                double ta_[SP::max_cfg_items > 0 ? SP::max_cfg_items : 1], tb_[SP::max_cfg_items > 0 ? SP::max_cfg_items : 1];
+#pragma unroll
+                for (int u = 0; u < SP::max_cfg_items; u++) { const int n = rt.n0 + u < rt.n1 ? rt.n0 + u : rt.n0; ta_[u] = terms[2 * n]; tb_[u] = terms[2 * n + 1]; }
+#pragma unroll
+                for (int u = 0; u < SP::max_cfg_items; u++) if (rt.n0 + u < rt.n1) { lddq += ta_[u]; ldq += tb_[u]; }
+            } else
             for (int n = rt.n0; n < rt.n1; n++) { lddq += terms[2 * n]; ldq += terms[2 * n + 1]; }
             S[P.o_Ldq + i] = ldq; S[P.o_Lddq + i] = lddq;
             double force = -tdamp * S[P.o_dq + i];

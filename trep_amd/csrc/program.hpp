@@ -138,6 +138,7 @@ struct DevProg {
     int cmp_ok, n_cgroups, n_cmpairs, o_cmp, o_csw, o_ccz, o_cmpt;   // o_cmpt: per config item | body << 12 | group << 20 (ints), behind the plan tables (the per-body world entries go to the dead joint-pose area)
     int cmp_gmask[32];        // bit F of cmp_gmask[g]: body F belongs to subtree group g
     const int *cmp_rep, *cmp_grp, *cmp_goff, *cmp_gbody, *cmp_pair;
+    int max_cfg_items;        // most items any dynamic config has (= bodies below it): trip count of the specialised residual sum
     int bbd_ok, bbd_g, bbd_ng, bbd_nb, bbd_t, o_bbd;
     int bbd_tvar[16];         // image index of trailing variable i
     const int *bbd_tab;
@@ -678,6 +679,8 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.e_o_wT = take(P.n_wpair); P.e_o_Hu = take(nw ? nq * P.nu : 0);   // point forces: w-contracted F.d3p per pair, -dt/2 w.F_dudq [nq][nu]
     off = std::max(off, P.d_lds_per_team);
     P.e_lds_per_team = (off + 1) & ~1;
+    P.max_cfg_items = 0;
+    for (int c = 0; c < nd; c++) P.max_cfg_items = std::max(P.max_cfg_items, H.cfg_item_off[c + 1] - H.cfg_item_off[c]);
     {   // composite form of the Newton matrix (see DevProg::cmp_*)
         P.cmp_ok = 0; P.n_cgroups = 0; P.n_cmpairs = 0; P.o_cmp = P.o_csw = P.o_ccz = P.o_cmpt = 0;
         for (int i = 0; i < 32; i++) P.cmp_gmask[i] = 0;
