@@ -145,9 +145,21 @@ namespace tg {
 // the structured Newton solve needs its plan as compile-time constants: system-specialised schedules (SpecProg: static members) only
 template <class P, class = void> struct tg_static_bbd { static constexpr bool value = false; };
 template <class P> struct tg_static_bbd<P, typename std::enable_if<(P::bbd_ok >= 0)>::type> { static constexpr bool value = P::bbd_ok != 0; };
+// lane K of every quad (four neighbouring lanes) to the whole quad: two 32-bit DPP moves (quad_perm has no 64-bit form)
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int K> __device__ __forceinline__ double tg_quad_bcast(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, K * 0x55, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, K * 0x55, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+#endif
 // any system-specialised schedule (sizes are static members)
 template <class P, class = void> struct tg_is_spec { static constexpr bool value = false; };
 template <class P> struct tg_is_spec<P, typename std::enable_if<(P::nq >= 0)>::type> { static constexpr bool value = true; };
+// ... whose chain schedule has a quad-lane sweep plan (program.hpp, sw_*)
+template <class P, class = void> struct tg_static_sweep { static constexpr bool value = false; };
+template <class P> struct tg_static_sweep<P, typename std::enable_if<(P::sw_ok > 0)>::type> { static constexpr bool value = true; };
 // ... and so does the composite assembly of the Newton matrix (its group sums are unrolled over compile-time membership masks)
 template <class P, class = void> struct tg_static_cmp { static constexpr bool value = false; };
 template <class P> struct tg_static_cmp<P, typename std::enable_if<(P::cmp_ok >= 0)>::type> { static constexpr bool value = P::cmp_ok != 0 && P::tab_ok != 0; };
@@ -636,6 +648,15 @@ struct Core {
         TG_SYNC();
         TG_STAMP(15);
         const int *sched = (const int *)(S + P.o_sched);
+#if !defined(TG_NO_QUAD_SWEEP)
+        if constexpr (tg_static_sweep<typename std::remove_cv<PROG>::type>::value) {
+            typedef typename std::remove_cv<PROG>::type SP;
+            const int l = tg_opaque(lane);
+            const int q = l < 60 ? l / 12 : 4, rc = l < 60 ? l - 12 * q : 0;
+            chain_round_quads<SP, 0>(on, sched, q, rc >> 2, rc & 3, l < 60);
+            return;
+        }
+#endif
         if (P.sched_ok == 2) {
             // at most 8 chains per round: lanes 0-31 sweep the midpoint poses, lanes 32-63 the q2 poses -- one row recurrence
             // per lane, so the instruction stream of a chain step is half that of two recurrences side by side
@@ -716,6 +737,56 @@ struct Core {
                 }
             }
             TG_SYNC();
+        }
+    }
+    // ---- the chain rounds with the 3 x 4 entries of a running pose on twelve lanes (system-specialised kernels) ----
+    // Lane (r, c) of an instance (one chain of one pose set; five instances per pass) carries entry (r, c) of the pose: a chain step is
+    //   G(r, c) <- sum_k G(r, k) L(k, c) (+ G(r, 3) for c = 3),
+    // with G(r, k) read from lane k of the lane's own quad (DPP quad_perm) and column c of the local transform L -- three doubles per step, so
+    // a whole chain's columns fit in registers and are ALL requested before the recurrence starts.  The row-per-lane sweep above needs
+    // all twelve entries of L per step and lane, cannot hold more than one step's worth, and pays an LDS round trip per chain step (ten in a
+    // row for the puppet); here a round costs one.  Passes of a round are independent and interleaved.  Same products in the same order.
+    template <class SP, int RD> TG_HD void chain_round_quads(bool on, const int *sched, int q, int r, int c, bool act) {
+        if constexpr (RD < SP::n_rounds) {
+            PROG &P = tg_fresh(this->P);
+            constexpr int NP = SP::sw_np[RD], ML = SP::sw_maxlen;
+            if (on) {
+                double m[4][ML][3], p[4];
+                int base[4], len[4];
+#pragma unroll
+                for (int ps = 0; ps < 4; ps++) {
+                    if (ps < NP) {
+                        const int inst = 5 * ps + q, slot = inst >> 1;
+                        const int w0 = sched[2 * (16 * RD + slot)], opar = sched[2 * (16 * RD + slot) + 1];
+                        len[ps] = w0 >> 16;
+                        base[ps] = ((inst & 1) ? P.o_W : P.o_G) + (w0 & 0xFFFF);
+                        const double pv = S[((inst & 1) ? P.o_W : P.o_G) + (opar >= 0 ? opar : 0) + 4 * r + c];
+                        p[ps] = opar >= 0 ? pv : (r == c ? 1.0 : 0.0);
+#pragma unroll
+                        for (int s = 0; s < ML; s++) {
+                            if (s < SP::sw_len[4 * RD + ps]) {
+                                const int o = base[ps] + 12 * (s < len[ps] ? s : 0) + c;
+                                m[ps][s][0] = S[o]; m[ps][s][1] = S[o + 4]; m[ps][s][2] = S[o + 8];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < ML; s++) {
+#pragma unroll
+                    for (int ps = 0; ps < 4; ps++) {
+                        if (ps < NP && s < SP::sw_len[4 * RD + ps]) {
+                            const double b0 = tg_quad_bcast<0>(p[ps]), b1 = tg_quad_bcast<1>(p[ps]), b2 = tg_quad_bcast<2>(p[ps]);
+                            const double t_ = b0 * m[ps][s][0] + b1 * m[ps][s][1] + b2 * m[ps][s][2];
+                            const double v = c == 3 ? t_ + p[ps] : t_;
+                            if (act && s < len[ps]) S[base[ps] + 12 * s + 4 * r + c] = v;
+                            p[ps] = v;
+                        }
+                    }
+                }
+            }
+            TG_SYNC();
+            chain_round_quads<SP, RD + 1>(on, sched, q, r, c, act);
         }
     }
     // the dual sweep needs the chain schedule in LDS and room for the second pose set in the J / W areas

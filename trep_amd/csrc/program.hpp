@@ -138,6 +138,12 @@ struct DevProg {
     int cmp_ok, n_cgroups, n_cmpairs, o_cmp, o_csw, o_ccz, o_cmpt;   // o_cmpt: per config item | body << 12 | group << 20 (ints), behind the plan tables (the per-body world entries go to the dead joint-pose area)
     int cmp_gmask[32];        // bit F of cmp_gmask[g]: body F belongs to subtree group g
     const int *cmp_rep, *cmp_grp, *cmp_goff, *cmp_gbody, *cmp_pair;
+    // quad-lane chain sweep of the specialised dual pose sweep (mvi_core.hpp, chain_round_quads): a round's 2 x chains instances (chain slot
+    // i / 2 of pose set i % 2) go five to a pass (twelve lanes = the 3 x 4 entries of the running pose each); sw_np[r] passes in round r,
+    // sw_len[4 r + p] the longest chain of pass p (the unrolled trip count), sw_maxlen the longest of all
+    int sw_ok, sw_maxlen;
+    int sw_np[4];
+    int sw_len[16];
     int max_cfg_items;        // most items any dynamic config has (= bodies below it): trip count of the specialised residual sum
     int bbd_ok, bbd_g, bbd_ng, bbd_nb, bbd_t, o_bbd;
     int bbd_tvar[16];         // image index of trailing variable i
@@ -559,6 +565,26 @@ inline HostProgram build_program(const tg_system_desc *d) {
         for (int r = 0; r < P.n_rounds; r++) if (H.round_off[r + 1] - H.round_off[r] > 8) P.sched_ok = 1;
     }
     P.o_sched = take(P.sched_ok ? 16 * P.n_rounds : 0);   // two ints per (round, slot)
+    {   // quad-lane sweep plan: at most four rounds of at most four passes, at most 16 chain steps' worth of local-transform columns
+        // in registers per round
+        P.sw_ok = (P.sched_ok && P.n_rounds >= 1 && P.n_rounds <= 4) ? 1 : 0;
+        P.sw_maxlen = 0;
+        for (int i = 0; i < 4; i++) P.sw_np[i] = 0;
+        for (int i = 0; i < 16; i++) P.sw_len[i] = 0;
+        for (int r = 0; r < P.n_rounds && P.sw_ok; r++) {
+            const int nch = H.round_off[r + 1] - H.round_off[r], np = (2 * nch + 4) / 5;
+            if (np > 4) { P.sw_ok = 0; break; }
+            P.sw_np[r] = np;
+            int total = 0;
+            for (int p = 0; p < np; p++) {
+                int len = 0;
+                for (int q = 0; q < 5; q++) { const int slot = (5 * p + q) >> 1; if (slot < nch) len = std::max(len, H.ch_len[H.round_off[r] + slot]); }
+                P.sw_len[4 * r + p] = len; total += len;
+                P.sw_maxlen = std::max(P.sw_maxlen, len);
+            }
+            if (total > 16) P.sw_ok = 0;
+        }
+    }
     P.df_ld = (P.nf + 1) | 1;  // augmented with the right-hand side; odd stride avoids LDS bank conflicts
     const int shared0 = off;
     P.o_Df = take(P.nf * P.df_ld);
