@@ -149,8 +149,8 @@ template <class P> struct tg_static_bbd<P, typename std::enable_if<(P::bbd_ok >=
 #if defined(__HIP_DEVICE_COMPILE__)
 template <int K> __device__ __forceinline__ double tg_quad_bcast(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, K * 0x55, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, K * 0x55, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, K * 0x55, 0xF, 0xF, true);     // (bound_ctrl: no tied `old` operand, hence no copy ahead of the move)
+    hi = __builtin_amdgcn_update_dpp(0, hi, K * 0x55, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 #endif
@@ -630,6 +630,17 @@ struct Core {
         }
         TG_SYNC();
         TG_STAMP(5);
+#if !defined(TG_NO_QUAD_SWEEP)
+        // quad-lane chain rounds (chain_round_quads): the lane's instance of every pass of the first round, requested a phase ahead
+        SwDesc sw0;
+        int swq = 4, swrc = 0;
+        bool swact = false;
+        if constexpr (tg_static_sweep<typename std::remove_cv<PROG>::type>::value) {
+            const int l = tg_opaque(lane);
+            swact = l < 60; swq = swact ? l / 12 : 4; swrc = swact ? l - 12 * swq : 0;
+            sw0 = sw_fetch<typename std::remove_cv<PROG>::type, 0>((const int *)(S + P.o_sched), swq);
+        }
+#endif
         for (int b0 = 0; b0 < n24; b0 += 4 * TEAM) {       // (uniform trip count: unrolled when the schedule is compiled in)
             const Rows nxt = b0 + 4 * TEAM < n24 ? rows_of(b0 + 4 * TEAM + lane) : cur;
             if (on) {
@@ -651,9 +662,7 @@ struct Core {
 #if !defined(TG_NO_QUAD_SWEEP)
         if constexpr (tg_static_sweep<typename std::remove_cv<PROG>::type>::value) {
             typedef typename std::remove_cv<PROG>::type SP;
-            const int l = tg_opaque(lane);
-            const int q = l < 60 ? l / 12 : 4, rc = l < 60 ? l - 12 * q : 0;
-            chain_round_quads<SP, 0>(on, sched, q, rc >> 2, rc & 3, l < 60);
+            chain_round_quads<SP, 0>(on, sched, sw0, swq, swrc >> 2, swrc & 3, swact);
             return;
         }
 #endif
@@ -746,26 +755,44 @@ struct Core {
     // a whole chain's columns fit in registers and are ALL requested before the recurrence starts.  The row-per-lane sweep above needs
     // all twelve entries of L per step and lane, cannot hold more than one step's worth, and pays an LDS round trip per chain step (ten in a
     // row for the puppet); here a round costs one.  Passes of a round are independent and interleaved.  Same products in the same order.
-    template <class SP, int RD> TG_HD void chain_round_quads(bool on, const int *sched, int q, int r, int c, bool act) {
+    struct SwDesc { int w0[4], par[4]; };      // per pass: 12 * first joint | chain length << 16, 12 * parent joint (or -1) of the lane's instance
+    template <class SP, int RD> TG_HD SwDesc sw_fetch(const int *sched, int q) const {
+        SwDesc d;
+#pragma unroll
+        for (int ps = 0; ps < 4; ps++) {
+            d.w0[ps] = 0; d.par[ps] = -1;
+            if (ps < SP::sw_np[RD < 4 ? RD : 0]) {
+                const int slot = (5 * ps + q) >> 1;
+                d.w0[ps] = sched[2 * (16 * RD + slot)]; d.par[ps] = sched[2 * (16 * RD + slot) + 1];
+            }
+        }
+        return d;
+    }
+    // (the round's descriptors arrive fetched -- by the previous round, the first round's by the local-transform pass -- and the next
+    // round's are requested before this round's columns: no LDS round trip between "which chain" and "its transforms")
+    template <class SP, int RD> TG_HD void chain_round_quads(bool on, const int *sched, const SwDesc &d, int q, int r, int c, bool act) {
         if constexpr (RD < SP::n_rounds) {
             PROG &P = tg_fresh(this->P);
             constexpr int NP = SP::sw_np[RD], ML = SP::sw_maxlen;
+            SwDesc nxt = d;
+            if constexpr (RD + 1 < SP::n_rounds) nxt = sw_fetch<SP, RD + 1>(sched, q);
             if (on) {
                 double m[4][ML][3], p[4];
-                int base[4], len[4];
+                int base[4], lim[4];
+                const int dead = P.o_sc + (lane < 2 * P.n_joints ? lane : 0);
 #pragma unroll
                 for (int ps = 0; ps < 4; ps++) {
                     if (ps < NP) {
-                        const int inst = 5 * ps + q, slot = inst >> 1;
-                        const int w0 = sched[2 * (16 * RD + slot)], opar = sched[2 * (16 * RD + slot) + 1];
-                        len[ps] = w0 >> 16;
-                        base[ps] = ((inst & 1) ? P.o_W : P.o_G) + (w0 & 0xFFFF);
-                        const double pv = S[((inst & 1) ? P.o_W : P.o_G) + (opar >= 0 ? opar : 0) + 4 * r + c];
+                        const int set = ((5 * ps + q) & 1) ? P.o_W : P.o_G, opar = d.par[ps];
+                        lim[ps] = act ? d.w0[ps] >> 16 : 0;
+                        base[ps] = set + (d.w0[ps] & 0xFFFF);
+                        const double pv = S[set + (opar >= 0 ? opar : 0) + 4 * r + c];
                         p[ps] = opar >= 0 ? pv : (r == c ? 1.0 : 0.0);
 #pragma unroll
                         for (int s = 0; s < ML; s++) {
                             if (s < SP::sw_len[4 * RD + ps]) {
-                                const int o = base[ps] + 12 * (s < len[ps] ? s : 0) + c;
+                                // (past the end of a shorter chain of the pass: whatever follows it in LDS -- never stored)
+                                const int o = base[ps] + 12 * s + c;
                                 m[ps][s][0] = S[o]; m[ps][s][1] = S[o + 4]; m[ps][s][2] = S[o + 8];
                             }
                         }
@@ -777,16 +804,18 @@ struct Core {
                     for (int ps = 0; ps < 4; ps++) {
                         if (ps < NP && s < SP::sw_len[4 * RD + ps]) {
                             const double b0 = tg_quad_bcast<0>(p[ps]), b1 = tg_quad_bcast<1>(p[ps]), b2 = tg_quad_bcast<2>(p[ps]);
-                            const double t_ = b0 * m[ps][s][0] + b1 * m[ps][s][1] + b2 * m[ps][s][2];
-                            const double v = c == 3 ? t_ + p[ps] : t_;
-                            if (act && s < len[ps]) S[base[ps] + 12 * s + 4 * r + c] = v;
+                            const double last = c == 3 ? p[ps] : 0.0;     // (selected before the products: off the recurrence's critical path)
+                            const double v = fma(b2, m[ps][s][2], fma(b1, m[ps][s][1], b0 * m[ps][s][0])) + last;
+                            // branch-free store (lanes past their chain's end write a dead word of the sin/cos area): a guarded store
+                            // would put every (step, pass) in a basic block of its own and the passes could no longer interleave
+                            S[s < lim[ps] ? base[ps] + 12 * s + 4 * r + c : dead] = v;
                             p[ps] = v;
                         }
                     }
                 }
             }
             TG_SYNC();
-            chain_round_quads<SP, RD + 1>(on, sched, q, r, c, act);
+            chain_round_quads<SP, RD + 1>(on, sched, nxt, q, r, c, act);
         }
     }
     // the dual sweep needs the chain schedule in LDS and room for the second pose set in the J / W areas
