@@ -7,8 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import trep_amd
 from trep_amd import systems, _lib
 
-NAMES = ["update+rates+step setup", "pose sweep: chains (dual) | whole (mid)", "attach+jacobians", "velocities", "residual", "sin/cos (dual sweep) | pose sweep (q1/q2)",
-         "attach+constraints", "newton init", "newton pairs", "GJ scales", "GJ pivot+swap", "GJ eliminate",
+NAMES = ["newton update + rates", "pose sweep: chains (dual) | whole (mid)", "attach+jacobians", "velocities", "residual", "sin/cos (dual sweep) | pose sweep (q1/q2)",
+         "attach+constraints", "newton init", "newton pairs", "step set-up, result rows | GJ scales (generic assembly)", "GJ pivot+swap", "GJ eliminate",
          "converged?", "tail", "Gauss-Jordan (registers)", "local transforms (dual sweep)"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 50

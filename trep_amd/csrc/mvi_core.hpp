@@ -457,8 +457,9 @@ struct Core {
                     if (r_ == rot) { if (seen == rank) jj = j; seen++; }
                 }
                 jck[u] = pos < 2 * P.n_joints ? (P.j_cfg[jj] | (P.j_kind[jj] << 12) | (jj << 16) | (set << 28)) : 0;
-                const int n = lane + u * TEAM < P.n_dh ? lane + u * TEAM : 0;
-                if (P.n_dh) { tck[u][0] = P.dh_pack[8 * (size_t)n]; tck[u][1] = P.dh_pack[8 * (size_t)n + 1]; }
+                // dh items of the dynamic configs (program.hpp, dhr_pack): constraint | item index << 8, config
+                const int n = lane + u * TEAM < P.n_dhr ? lane + u * TEAM : 0;
+                if (P.n_dhr) { tck[u][0] = P.dhr_pack[8 * (size_t)n] | (P.dhr_pack[8 * (size_t)n + 7] << 8); tck[u][1] = P.dhr_pack[8 * (size_t)n + 1]; }
             }
             const int b = lane < 6 * P.n_bodies ? lane / 6 : 0;
             bio[0] = P.b_item_off[b]; bio[1] = P.b_item_off[b + 1];
@@ -872,9 +873,10 @@ struct Core {
         t.e1 = P.c_e1[c]; t.e2 = P.c_e2[c]; t.type = P.c_type[c]; t.comp = P.c_comp[c]; t.cfg = P.c_cfg[c]; t.dist = P.c_dist[c];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const int *rec = P.dh_pack + 8 * (size_t)(l + u * TEAM < P.n_dh ? l + u * TEAM : 0);
+            const int *rec = P.dhr_pack + 8 * (size_t)(l + u * TEAM < P.n_dhr ? l + u * TEAM : 0);
 #pragma unroll
-            for (int i = 0; i < 6; i++) t.rec[u][i] = rec[i];
+            for (int i = 1; i < 6; i++) t.rec[u][i] = rec[i];
+            t.rec[u][0] = rec[7];                               // the item's index in Dh2
         }
         return t;
     }
@@ -947,8 +949,9 @@ struct Core {
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                const int n = lane + u * TEAM;
-                if (n < P.n_dh) {
+                // (only the items of the dynamic configs: nothing in the rollout reads Dh with respect to a kinematic config)
+                if (u * TEAM < P.n_dhr && lane + u * TEAM < P.n_dhr) {
+                    const int n = ct.rec[u][0];
                     const int k = ct.rec[u][1], oj = ct.rec[u][2], w = ct.rec[u][3], oe1 = ct.rec[u][4], oe2 = ct.rec[u][5];
                     const int side = w & 0xFF, kind = (w >> 8) & 0xFF, type = (w >> 16) & 0xFF, comp = w >> 24;
                     const int ojc = oj < 0 ? 0 : oj;
@@ -1481,8 +1484,8 @@ struct Core {
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                const int n = lane + u * TEAM, c = tck[u][0], k = tck[u][1];
-                if (n < P.n_dh && k < nd) { A[k * ld + nd + c] = -S[P.o_Dh1 + n]; A[(nd + c) * ld + k] = S[P.o_Dh2 + n]; }
+                const int n = tck[u][0] >> 8, c = tck[u][0] & 0xFF, k = tck[u][1];
+                if (u * TEAM < P.n_dhr && lane + u * TEAM < P.n_dhr) { A[k * ld + nd + c] = -S[P.o_Dh1 + n]; A[(nd + c) * ld + k] = S[P.o_Dh2 + n]; }
             }
         }
         const double qdt = 0.25 * dt, rdt = 1.0 / dt;
@@ -1537,8 +1540,8 @@ struct Core {
                 }
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    const int n = lane + u * TEAM, c = tck[u][0], k = tck[u][1];
-                    if (n < P.n_dh && k < nd) { A[k * ld + nd + c] = -S[P.o_Dh1 + n]; A[(nd + c) * ld + k] = S[P.o_Dh2 + n]; }
+                    const int n = tck[u][0] >> 8, c = tck[u][0] & 0xFF, k = tck[u][1];
+                    if (u * TEAM < P.n_dhr && lane + u * TEAM < P.n_dhr) { A[k * ld + nd + c] = -S[P.o_Dh1 + n]; A[(nd + c) * ld + k] = S[P.o_Dh2 + n]; }
                 }
             }
         } else
@@ -4500,6 +4503,9 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
         }
         int iterations = 0;
         bool done = !on;
+#if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        { long long t_ = (long long)__builtin_amdgcn_s_memtime(); core.prof[9] += t_ - core.prof_last; core.prof_last = t_; }
+#endif
         for (;;) {
             PROG &P = tg_fresh(P0);
             const int nd = P.nd, nc = P.nc;

@@ -62,6 +62,10 @@ struct DevProg {
     //   dh_pack[2n]  = {constraint, config, 12*joint (or -1), side | joint kind << 8 | constraint type << 16 | component << 24}
     //   dh_pack[2n+1]= {3*end point 1, 3*end point 2, length config (or -1), 0}
     const int *it_pack, *dh_pack;
+    // the dh items the ROLLOUT needs -- those of the dynamic configs (the residual and the Newton matrix never touch Dh with respect to a
+    // kinematic config) -- in dh_pack's layout, word 7 = the item's index n (where its value goes in Dh1 / Dh2); n_dhr of them
+    const int *dhr_pack;
+    int n_dhr;
     // second-derivative kernel, constraint part: for constraint c and end point E (0/1) the dh items whose joint lies on
     // the end point's path, sorted root-first: cpath_items[cpath_off[2c+E] .. cpath_off[2c+E+1]); dh_pos[2n+E] = position
     // of dh item n in that list or -1.  o_cps: LDS scratch (6 doubles per listed item), aliased with the dead J/W area.
@@ -156,7 +160,7 @@ struct HostProgram {
     std::vector<double> j_pre;
     std::vector<int> b_anchor;
     std::vector<double> b_C, b_inertia;
-    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4, tri4, cpair4, it_pack, dh_pack, cpath_off, cpath_items, dh_pos, tchunk, tri_off;
+    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4, tri4, cpair4, it_pack, dh_pack, cpath_off, cpath_items, dh_pos, tchunk, tri_off, dhr_pack;
     std::vector<int> wp_a, wp_b, wt_a, wt_b, wt_split, wcp4;
     std::vector<int> e_anchor;
     std::vector<double> e_off;
@@ -489,6 +493,11 @@ inline HostProgram build_program(const tg_system_desc *d) {
         H.dh_pack.push_back(H.dh_side[n] | ((j >= 0 ? H.j_kind[j] : 0) << 8) | (H.c_type[c] << 16) | ((H.c_comp[c] & 0xFF) << 24));
         H.dh_pack.push_back(3 * H.c_e1[c]); H.dh_pack.push_back(3 * H.c_e2[c]); H.dh_pack.push_back(H.c_cfg[c]); H.dh_pack.push_back(0);
     }
+    for (int n = 0; n < n_dh_con; n++) {
+        if (H.dh_cfg[n] >= nd) continue;
+        for (int w = 0; w < 7; w++) H.dhr_pack.push_back(H.dh_pack[8 * (size_t)n + w]);
+        H.dhr_pack.push_back(n);
+    }
     int n_cpair_con = 0, n_cpair_spr = 0;
     for (int c = 0; c <= nel; c++) {
         if (c == nc) n_cpair_con = (int)(H.cpair4.size() / 4);
@@ -524,7 +533,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     DevProg &P = H.p;
     P.nq = nq; P.nd = nd; P.nk = d->n_kin; P.nu = d->n_inputs; P.nc = nc; P.nf = nd + nc; P.nX = nq + nd + d->n_kin;
     P.n_joints = nj; P.n_levels = n_levels; P.n_bodies = nb; P.n_items = nitems; P.n_pairs = (int)H.pair_a.size();
-    P.n_endpoints = (int)H.e_anchor.size(); P.n_dh = n_dh_con; P.n_cf = (int)H.cf_cfg.size();
+    P.n_endpoints = (int)H.e_anchor.size(); P.n_dh = n_dh_con; P.n_dhr = (int)(H.dhr_pack.size() / 8); P.n_cf = (int)H.cf_cfg.size();
     P.n_springs = ns; P.n_sdh = n_dh_spr - n_dh_con;
     P.n_wrenches = nw; P.n_wdh = (int)H.dh_c.size() - n_dh_spr;
     P.n_cfgitems = (int)H.cfg_items.size();
@@ -801,7 +810,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
     X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in) X(wr_kind) X(ncs_i) \
-    X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4) X(bbd_tab) X(cmp_rep) X(cmp_grp) X(cmp_goff) X(cmp_gbody) X(cmp_pair)
+    X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4) X(bbd_tab) X(cmp_rep) X(cmp_grp) X(cmp_goff) X(cmp_gbody) X(cmp_pair) X(dhr_pack)
 #define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c) X(wr_Rloc) X(ncs_mb) X(ncs_tab)
 
 inline void HostProgram::pack() {
