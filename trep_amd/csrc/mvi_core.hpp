@@ -376,6 +376,7 @@ struct Core {
     int sc_rot2 = 0;   // number of (pose set, rotary joint) items of the dual sin/cos pass: they come first in the lane order
     double tdamp = 0.0;
     long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool rates_ready = false;      // o_dq already holds (q2 - q1) / dt when eval_both_tab starts
     long long prof_last = 0;
 
     int wave = 0, nw = 1;   // helper-wave kernels: index of this wavefront within the trajectory's workgroup, number of waves (uniform)
@@ -904,8 +905,10 @@ struct Core {
     TG_HD void eval_both_tab(bool on) {
         PROG &P = tg_fresh(this->P);
         const AttachTab at = fetch_attach();
-        if (on) TG_FOR(i, P.nq) S[P.o_dq + i] = (S[P.o_q2 + i] - S[P.o_q1 + i]) / dt;
-        TG_SYNC();
+        if (!rates_ready) {      // (the rollout forms the rates in its step set-up and in the Newton update)
+            if (on) TG_FOR(i, P.nq) S[P.o_dq + i] = (S[P.o_q2 + i] - S[P.o_q1 + i]) / dt;
+            TG_SYNC();
+        }
         TG_STAMP(0);
         pose_sweep_dual(on);
         TG_STAMP(1);
@@ -4443,6 +4446,10 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
     }
     bool failed = false;
     int status = TG_OK, total_iters = 0;
+    // open-loop inputs and kinematic targets of the NEXT step, requested while this step's Newton loop runs (one value per lane when they
+    // fit a team): read at the step's start they are two HBM round trips in a row on every step's critical path
+    double pre_u = 0.0, pre_k = 0.0;
+    bool pre_ok = false;
     for (int step = 0; step < A.n_steps; step++) {
         PROG &P = tg_fresh_step(P0);      // per step: nothing of the schedule / the arguments stays in SGPRs across steps
         ARGS &A = tg_fresh_args(A0);
@@ -4483,19 +4490,30 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
             } else {
                 TG_FOR(i, nq) S[P.o_q1 + i] = S[P.o_q2 + i];
             }
-            TG_FOR(i, nu) S[P.o_u + i] = A.Kproj ? S[P.o_nu + i] : A.U[(t * A.n_steps + step) * nu + i];
+            if (pre_ok) { if (lane < nu) S[P.o_u + lane] = pre_u; }
+            else TG_FOR(i, nu) S[P.o_u + i] = A.Kproj ? S[P.o_nu + i] : A.U[(t * A.n_steps + step) * nu + i];
             // the momentum entering the last step is the state's p1 afterwards (midpointvi.py:189)
             if (step == A.n_steps - 1) TG_FOR(i, nd) A.p1[t * nd + i] = S[P.o_p1 + i];
         }
         TG_SYNC();
         if (on) {
-            TG_FOR(i, nk) S[P.o_q2 + nd + i] = A.Kproj ? S[P.o_nu + nu + i] : A.K[(t * A.n_steps + step) * nk + i];
+            if (pre_ok) { if (lane < nk) S[P.o_q2 + nd + lane] = pre_k; }
+            else TG_FOR(i, nk) S[P.o_q2 + nd + i] = A.Kproj ? S[P.o_nu + nu + i] : A.K[(t * A.n_steps + step) * nk + i];
             if (A.q2_hint && step == 0) TG_FOR(i, nd) S[P.o_q2 + i] = A.q2_hint[t * nd + i];
             if (A.lam_hint && step == 0) TG_FOR(i, nc) S[P.o_lam + i] = A.lam_hint[t * nc + i];
         }
         TG_SYNC();
         // Dh at q1, held fixed during the solve (midpointvi.c:705-707).  After the first step it is the
         // Dh2 of the previous step's converged q2 (same point, same inputs), so only step 0 sweeps.
+        // rates dq = (q2 - q1) / dt of the first evaluation: here (no reader before the barriers below) and, for the later evaluations, in the
+        // Newton update itself -- a phase of its own at the head of every evaluation otherwise (eval_both_tab)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_DUAL_SWEEP)
+        const bool fuse_rates = core.dual_ok() && P.tab_ok;
+#else
+        const bool fuse_rates = false;
+#endif
+        core.rates_ready = fuse_rates;
+        if (fuse_rates && on) TG_FOR(i, nq) S[P.o_dq + i] = (S[P.o_q2 + i] - S[P.o_q1 + i]) / dt;
         if (step == 0) core.eval_constraints(on, 1, false, S + P.o_Dh1);
         else if (nc) {
             if (on) TG_FOR(i, P.n_dh) S[P.o_Dh1 + i] = S[P.o_Dh2 + i];
@@ -4503,6 +4521,12 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
         }
         int iterations = 0;
         bool done = !on;
+        pre_ok = false;
+        if (TEAM == 64 && on && !A.Kproj && nu <= TEAM && nk <= TEAM && step + 1 < A.n_steps) {
+            if (lane < nu) pre_u = A.U[(t * A.n_steps + step + 1) * nu + lane];
+            if (lane < nk) pre_k = A.K[(t * A.n_steps + step + 1) * nk + lane];
+            pre_ok = true;
+        }
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
         { long long t_ = (long long)__builtin_amdgcn_s_memtime(); core.prof[9] += t_ - core.prof_last; core.prof_last = t_; }
 #endif
@@ -4591,6 +4615,8 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
 #endif
             if (!done && !ok) { done = true; failed = true; status = TG_SINGULAR; }
             if (!done) {
+                if (fuse_rates) TG_FOR(i, nd) { const double v = S[P.o_q2 + i] - S[P.o_Df + i * P.df_ld + P.nf]; S[P.o_q2 + i] = v; S[P.o_dq + i] = (v - S[P.o_q1 + i]) / dt; }
+                else
                 TG_FOR(i, nd) S[P.o_q2 + i] -= S[P.o_Df + i * P.df_ld + P.nf];
                 TG_FOR(c, nc) S[P.o_lam + c] -= S[P.o_Df + (nd + c) * P.df_ld + P.nf];
                 iterations++;
