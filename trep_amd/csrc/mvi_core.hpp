@@ -385,7 +385,11 @@ struct Core {
         lo = first; hi = last;
         if (nw > 1) { lo = wave ? split : first; hi = wave ? last : split; }
     }
-    TG_HD Core(PROG &p, double *s, int l, double dt_) : P(p), S(s), lane(l), dt(dt_), oGc(p.o_G) {}
+    TG_HD Core(PROG &p, double *s, int l, double dt_) : P(p), S(s), lane(l), dt(dt_), oGc(p.o_G), inv_dt(1.0 / dt_) {}
+    // x / dt with the step's reciprocal (inv_dt follows dt): the quotient estimate and one residual correction -- three
+    // dependent operations instead of the ten of the division sequence; the correctly rounded quotient (Markstein's final step)
+    double inv_dt;
+    TG_HD double over_dt(double x) const { const double q = x * inv_dt; return fma(fma(-q, dt, x), inv_dt, q); }
 
     // Phase loop over n independent items, two per lane and trip: compute(i) only READS and returns its results,
     // store(i, r) writes them.  Both items' loads are issued before either item's stores -- the compiler cannot
@@ -1491,7 +1495,7 @@ struct Core {
                 if (u * TEAM < P.n_dhr && lane + u * TEAM < P.n_dhr) { A[k * ld + nd + c] = -S[P.o_Dh1 + n]; A[(nd + c) * ld + k] = S[P.o_Dh2 + n]; }
             }
         }
-        const double qdt = 0.25 * dt, rdt = 1.0 / dt;
+        const double qdt = 0.25 * dt, rdt = inv_dt;
 #pragma unroll
         for (int u = 0; u < TP; u++) {
             if (on && lane + u * TEAM < NP) {
@@ -4455,7 +4459,7 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
         ARGS &A = tg_fresh_args(A0);
         const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nX = P.nX;
         const double dt_prev = dt;             // step size of the step that produced the incoming state (feedback: v = dq_k / dt_prev)
-        if (A.dt_steps && A.dt_period == 0) { dt = A.dt_steps[step]; core.dt = dt; }   // non-uniform time base (dsystem.py:229-274 takes any t)
+        if (A.dt_steps && A.dt_period == 0) { dt = A.dt_steps[step]; core.dt = dt; core.inv_dt = 1.0 / dt; }   // non-uniform time base (dsystem.py:229-274 takes any t)
         const bool on = live && !failed;
         if (A.Kproj) {  // feedback inputs from the state entering this step (before the shift: v needs q1)
             const int nU = nu + nk;
@@ -4513,7 +4517,7 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
         const bool fuse_rates = false;
 #endif
         core.rates_ready = fuse_rates;
-        if (fuse_rates && on) TG_FOR(i, nq) S[P.o_dq + i] = (S[P.o_q2 + i] - S[P.o_q1 + i]) / dt;
+        if (fuse_rates && on) TG_FOR(i, nq) S[P.o_dq + i] = core.over_dt(S[P.o_q2 + i] - S[P.o_q1 + i]);
         if (step == 0) core.eval_constraints(on, 1, false, S + P.o_Dh1);
         else if (nc) {
             if (on) TG_FOR(i, P.n_dh) S[P.o_Dh1 + i] = S[P.o_Dh2 + i];
@@ -4615,7 +4619,7 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
 #endif
             if (!done && !ok) { done = true; failed = true; status = TG_SINGULAR; }
             if (!done) {
-                if (fuse_rates) TG_FOR(i, nd) { const double v = S[P.o_q2 + i] - S[P.o_Df + i * P.df_ld + P.nf]; S[P.o_q2 + i] = v; S[P.o_dq + i] = (v - S[P.o_q1 + i]) / dt; }
+                if (fuse_rates) TG_FOR(i, nd) { const double v = S[P.o_q2 + i] - S[P.o_Df + i * P.df_ld + P.nf]; S[P.o_q2 + i] = v; S[P.o_dq + i] = core.over_dt(v - S[P.o_q1 + i]); }
                 else
                 TG_FOR(i, nd) S[P.o_q2 + i] -= S[P.o_Df + i * P.df_ld + P.nf];
                 TG_FOR(c, nc) S[P.o_lam + c] -= S[P.o_Df + (nd + c) * P.df_ld + P.nf];
