@@ -4461,7 +4461,57 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
         const double dt_prev = dt;             // step size of the step that produced the incoming state (feedback: v = dq_k / dt_prev)
         if (A.dt_steps && A.dt_period == 0) { dt = A.dt_steps[step]; core.dt = dt; core.inv_dt = 1.0 / dt; }   // non-uniform time base (dsystem.py:229-274 takes any t)
         const bool on = live && !failed;
-        if (A.Kproj) {  // feedback inputs from the state entering this step (before the shift: v needs q1)
+        bool fb_done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (TEAM == 64 && A.Kproj && 2 * (nu + nk) <= TEAM && nX <= 32 * (TEAM / (nu + nk) > 4 ? 4 : TEAM / (nu + nk)) && nX + 4 * (nu + nk) <= 6 * P.n_items) {
+            // feedback inputs u = bU - K (x - bX) with the gain rows spread over the wavefront: `parts` lanes per row, each with its slice of
+            // the row in flight at once and four partial sums; the state error is formed once (one lane per entry, coalesced reference
+            // read) in the dead Jacobian area.  One lane per row walks 80 entries in ten dependent batches of gain-row loads.
+            const int nU = nu + nk, parts = TEAM / nU > 4 ? 4 : TEAM / nU, chunk = (nX + parts - 1) / parts;
+            double *dx = S + P.o_J, *part = dx + nX;
+            const int l = tg_opaque(lane);
+            const int j = l / parts, pt = l - j * parts, i0 = pt * chunk;
+            const bool mine = l < parts * nU;
+            const size_t grp = A.group_map ? (size_t)A.group_map[t / A.group_size] : (size_t)(t / A.group_size);
+            const double *Kr = A.Kproj + ((grp * A.n_steps + step) * nU + (mine ? j : 0)) * nX;
+            if (on && step > 0) {
+                const double *bx = A.bX + (t * (size_t)(A.n_steps + 1) + step) * nX;
+                const double dtp = dt_prev;
+                TG_FOR(i, nX) {
+                    double x;
+                    if (i < nq) x = S[P.o_q2 + i];
+                    else if (i < nq + nd) x = S[P.o_p1 + i - nq];
+                    else x = dtp != 0.0 ? (S[P.o_q2 + nd + (i - nq - nd)] - S[P.o_q1 + nd + (i - nq - nd)]) / dtp : 0.0;
+                    dx[i] = x - bx[i];
+                }
+            }
+            TG_SYNC();
+            if (on && step > 0 && mine) {
+                double kv[32];
+#pragma unroll
+                for (int u = 0; u < 32; u++) if (u < chunk) kv[u] = Kr[i0 + u < nX ? i0 + u : 0];
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int u = 0; u < 32; u += 4) {
+                    if (u < chunk) a0 = fma(kv[u], i0 + u < nX ? dx[i0 + u < nX ? i0 + u : 0] : 0.0, a0);
+                    if (u + 1 < chunk) a1 = fma(kv[u + 1], i0 + u + 1 < nX ? dx[i0 + u + 1 < nX ? i0 + u + 1 : 0] : 0.0, a1);
+                    if (u + 2 < chunk) a2 = fma(kv[u + 2], i0 + u + 2 < nX ? dx[i0 + u + 2 < nX ? i0 + u + 2 : 0] : 0.0, a2);
+                    if (u + 3 < chunk) a3 = fma(kv[u + 3], i0 + u + 3 < nX ? dx[i0 + u + 3 < nX ? i0 + u + 3 : 0] : 0.0, a3);
+                }
+                part[pt * nU + j] = (a0 + a1) + (a2 + a3);
+            }
+            TG_SYNC();
+            if (on && l < nU) {
+                double acc = A.bU[(t * A.n_steps + step) * nU + l];
+                if (step > 0) for (int q = 0; q < parts; q++) acc -= part[q * nU + l];   // X_0 = bX_0 by definition of the projection: no correction at k = 0
+                S[P.o_nu + l] = acc;
+                if (A.Uout) A.Uout[(t * A.n_steps + step) * nU + l] = acc;
+            }
+            TG_SYNC();
+            fb_done = true;
+        }
+#endif
+        if (A.Kproj && !fb_done) {  // feedback inputs from the state entering this step (before the shift: v needs q1)
             const int nU = nu + nk;
             if (on) TG_FOR(j, nU) {
                 const size_t grp = A.group_map ? (size_t)A.group_map[t / A.group_size] : (size_t)(t / A.group_size);
