@@ -760,7 +760,8 @@ struct Core {
     // with G(r, k) read from lane k of the lane's own quad (DPP quad_perm) and column c of the local transform L -- three doubles per step, so
     // a whole chain's columns fit in registers and are ALL requested before the recurrence starts.  The row-per-lane sweep above needs
     // all twelve entries of L per step and lane, cannot hold more than one step's worth, and pays an LDS round trip per chain step (ten in a
-    // row for the puppet); here a round costs one.  Passes of a round are independent and interleaved.  Same products in the same order.
+    // row for the puppet); here a round costs one.  Passes of a round are independent and interleaved.  Same products; the translation
+    // entry G(r, 3) opens the sum instead of closing it (three dependent operations per step instead of four).
     struct SwDesc { int w0[4], par[4]; };      // per pass: 12 * first joint | chain length << 16, 12 * parent joint (or -1) of the lane's instance
     template <class SP, int RD> TG_HD SwDesc sw_fetch(const int *sched, int q) const {
         SwDesc d;
@@ -810,8 +811,8 @@ struct Core {
                     for (int ps = 0; ps < 4; ps++) {
                         if (ps < NP && s < SP::sw_len[4 * RD + ps]) {
                             const double b0 = tg_quad_bcast<0>(p[ps]), b1 = tg_quad_bcast<1>(p[ps]), b2 = tg_quad_bcast<2>(p[ps]);
-                            const double last = c == 3 ? p[ps] : 0.0;     // (selected before the products: off the recurrence's critical path)
-                            const double v = fma(b2, m[ps][s][2], fma(b1, m[ps][s][1], b0 * m[ps][s][0])) + last;
+                            const double last = c == 3 ? p[ps] : 0.0;
+                            const double v = fma(b2, m[ps][s][2], fma(b1, m[ps][s][1], fma(b0, m[ps][s][0], last)));
                             // branch-free store (lanes past their chain's end write a dead word of the sin/cos area): a guarded store
                             // would put every (step, pass) in a basic block of its own and the passes could no longer interleave
                             S[s < lim[ps] ? base[ps] + 12 * s + 4 * r + c : dead] = v;
