@@ -26,7 +26,8 @@ L.tg_batch_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 _lib.check(L.tg_batch_profile(mvi._h, out))
 v = np.array(list(out), dtype=float)
 it, st = mvi.status()
-print("B=%d N=%d  its/step %.2f  total cycles (traj 0) %.3e  per step %.0f" % (B, N, it.mean() / N, v.sum(), v.sum() / N))
+ticks = v[13]; v[13] = 0.0          # rollout kernels: slot 13 = s_memrealtime ticks (100 MHz) of trajectory 0
+print("B=%d N=%d  its/step %.2f  total cycles (traj 0) %.3e  per step %.0f   shader clock %.0f MHz (cycles / 100 MHz wall-clock ticks)" % (B, N, it.mean() / N, v.sum(), v.sum() / N, 100.0 * v.sum() / max(ticks, 1.0)))
 for n, c in zip(NAMES, v):
     if c:
         print("  %-44s %12.0f  %5.1f%%  %8.0f /step" % (n, c, 100 * c / v.sum(), c / N))

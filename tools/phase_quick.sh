@@ -9,5 +9,5 @@ import sys; sys.path.insert(0, '.')
 from trep_amd import specialize, systems
 print(specialize.build(systems.puppet()))"
 else
-    TREPAMD_LIB=trep_amd/libtrepamd_prof.so TREPAMD_SPEC_FLAGS="$F" timeout 200 python tools/phase_profile.py
+    TREPAMD_LIB=trep_amd/libtrepamd_prof.so TREPAMD_SPEC_FLAGS="$F" timeout 200 python tools/phase_profile.py "$@"
 fi

@@ -98,6 +98,9 @@ __device__ __forceinline__ int tg_opaque(int x) { asm volatile("" : "+v"(x)); re
 #else
 inline int tg_opaque(int x) { return x; }
 #endif
+#ifndef TG_LT_TRIPS
+#define TG_LT_TRIPS 4
+#endif
 #define TG_FOR(idx, n) for (int idx = tg_opaque(lane); idx < (n); idx += TEAM)
 // the same over all the waves of a trajectory (helper-wave kernels; `wave` is 0 and `nw` 1 everywhere else)
 #define TG_FORW(idx, n) for (int idx = tg_opaque(lane + TEAM * wave); idx < (n); idx += TEAM * nw)
@@ -112,6 +115,9 @@ extern "C" __device__ __attribute__((const)) unsigned int __ockl_wfred_max_u32(u
 // Never enabled in the product library; the stamps never feed an output value.
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define TG_STAMP(id) do { long long t_ = (long long)__builtin_amdgcn_s_memtime(); prof[id] += t_ - prof_last; prof_last = t_; } while (0)
+#ifndef TG_PROF_TRAJ
+#define TG_PROF_TRAJ 0      // which trajectory of a rollout launch reports its counters
+#endif
 #else
 #define TG_STAMP(id) ((void)0)
 #endif
@@ -594,48 +600,6 @@ struct Core {
         // coefficient rows of local-transform entry idx2 (of the 2 x 12 x n_joints of both pose sets; clamped past the end).  They
         // come from global memory (hundreds of cycles), so every trip's rows are requested one trip ahead -- the first
         // trip's before the sin/cos pass, which does not need them.
-        struct Rows { double k0[4], k1[4], k2[4]; int j[4]; };
-        auto rows_of = [&](int first) {
-            Rows r;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int idx2 = first + u * TEAM;
-                const int idx = idx2 < n24 ? (idx2 >= n12 ? idx2 - n12 : idx2) : 0;
-                const int j = idx / 12, e = idx % 12;
-                const double *k = P.jcoef + 4 * (size_t)(16 * j + e);
-                r.k0[u] = k[0]; r.k1[u] = k[1]; r.k2[u] = k[2]; r.j[u] = j;
-            }
-            return r;
-        };
-        Rows cur = rows_of(lane);
-        if (P.tab_ok) {
-            if (on) {
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const int idx = lane + u * TEAM;
-                    if (idx < 2 * nj) {
-                        const bool second = (jck[u] >> 28) != 0;
-                        const int j = (jck[u] >> 16) & 0xFFF, kind = (jck[u] >> 12) & 0xF;
-                        const double x = qval(second ? dsB : dsA, jck[u] & 0xFFF);
-                        double *dst = (second ? sc2 : sc) + 2 * j;
-                        if (u * TEAM < sc_rot2) {          // (wave-uniform) a trip with rotary joints in it
-                            if (kind >= TG_RX) tg_sincos(x, &dst[0], &dst[1]);
-                            else { dst[0] = x; dst[1] = 0.0; }
-                        } else { dst[0] = x; dst[1] = 0.0; }
-                    }
-                }
-            }
-        } else
-        if (on) TG_FOR(idx, 2 * nj) {
-            const bool second = idx >= nj;
-            const int j = second ? idx - nj : idx;
-            const double x = qval(second ? dsB : dsA, P.j_cfg[j]);
-            double *dst = (second ? sc2 : sc) + 2 * j;
-            if (P.j_kind[j] >= TG_RX) tg_sincos(x, &dst[0], &dst[1]);
-            else { dst[0] = x; dst[1] = 0.0; }
-        }
-        TG_SYNC();
-        TG_STAMP(5);
 #if !defined(TG_NO_QUAD_SWEEP)
         // quad-lane chain rounds (chain_round_quads): the lane's instance of every pass of the first round, requested a phase ahead
         SwDesc sw0;
@@ -647,11 +611,90 @@ struct Core {
             sw0 = sw_fetch<typename std::remove_cv<PROG>::type, 0>((const int *)(S + P.o_sched), swq);
         }
 #endif
-        for (int b0 = 0; b0 < n24; b0 += 4 * TEAM) {       // (uniform trip count: unrolled when the schedule is compiled in)
-            const Rows nxt = b0 + 4 * TEAM < n24 ? rows_of(b0 + 4 * TEAM + lane) : cur;
+        if (P.tab_ok) {
+            // One lane per (pose set, joint): sin / cos of the joint coordinate AND the joint's local transform pre_j lg(q) in the same
+            // phase.  With the pre-transform's columns in the order (axis a, b = a + 1, c = a + 2, translation) -- rows (A, B, C, D) of
+            // P.j_prm -- the local transform is, row by row,
+            //     rotary:     column a = A,  b = B cos + C sin,  c = C cos - B sin,  translation = D
+            //     prismatic:  columns a, b, c = A, B, C,  translation = D + A q
+            // i.e. twelve numbers, six (three) operations and twelve stores per joint, against twelve table rows of three coefficients,
+            // twelve evaluations A + B cos + C sin and a trip through LDS for the sin / cos values entry by entry (13 wavefront trips for
+            // the puppet's 2 x 34 joints, the rows from global memory batch after batch).  Same numbers.
+            double pr[2][12];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const double *src = P.j_prm + 12 * (size_t)((jck[u] >> 16) & 0xFFF);
+#pragma unroll
+                for (int e = 0; e < 12; e++) pr[u][e] = src[e];
+            }
             if (on) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < 2; u++) {
+                    const int idx = lane + u * TEAM;
+                    if (u * TEAM < 2 * nj && idx < 2 * nj) {
+                        const bool second = (jck[u] >> 28) != 0;
+                        const int j = (jck[u] >> 16) & 0xFFF, kind = (jck[u] >> 12) & 0xF;
+                        const double x = qval(second ? dsB : dsA, jck[u] & 0xFFF);
+                        const bool rotary = kind >= TG_RX;
+                        const int a = rotary ? kind - TG_RX : kind - TG_TX, b = a == 2 ? 0 : a + 1, c = a == 0 ? 2 : a - 1;
+                        double *g = (second ? G2 : G) + 12 * j;
+                        if (u * TEAM < sc_rot2) {          // (wave-uniform) a trip with rotary joints in it
+                            double sn = 0.0, cs = 1.0;
+                            if (rotary) tg_sincos(x, &sn, &cs);
+                            const double tq = rotary ? 0.0 : x;
+#pragma unroll
+                            for (int l = 0; l < 3; l++) {
+                                const double A_ = pr[u][4 * l], B_ = pr[u][4 * l + 1], C_ = pr[u][4 * l + 2], D_ = pr[u][4 * l + 3];
+                                g[4 * l + a] = A_;
+                                g[4 * l + b] = rotary ? fma(C_, sn, B_ * cs) : B_;
+                                g[4 * l + c] = rotary ? fma(-B_, sn, C_ * cs) : C_;
+                                g[4 * l + 3] = fma(A_, tq, D_);
+                            }
+                        } else {
+#pragma unroll
+                            for (int l = 0; l < 3; l++) {
+                                const double A_ = pr[u][4 * l], B_ = pr[u][4 * l + 1], C_ = pr[u][4 * l + 2], D_ = pr[u][4 * l + 3];
+                                g[4 * l + a] = A_; g[4 * l + b] = B_; g[4 * l + c] = C_;
+                                g[4 * l + 3] = fma(A_, x, D_);
+                            }
+                        }
+                    }
+                }
+            }
+            TG_SYNC();
+            TG_STAMP(5);
+            TG_STAMP(15);
+        } else {
+        constexpr int LT = TG_LT_TRIPS;        // trips of the wavefront per batch of coefficient rows
+        struct Rows { double k0[LT], k1[LT], k2[LT]; int j[LT]; };
+        auto rows_of = [&](int first) {
+            Rows r;
+#pragma unroll
+            for (int u = 0; u < LT; u++) {
+                const int idx2 = first + u * TEAM;
+                const int idx = idx2 < n24 ? (idx2 >= n12 ? idx2 - n12 : idx2) : 0;
+                const int j = idx / 12, e = idx % 12;
+                const double *k = P.jcoef + 4 * (size_t)(16 * j + e);
+                r.k0[u] = k[0]; r.k1[u] = k[1]; r.k2[u] = k[2]; r.j[u] = j;
+            }
+            return r;
+        };
+        Rows cur = rows_of(lane);
+        if (on) TG_FOR(idx, 2 * nj) {
+            const bool second = idx >= nj;
+            const int j = second ? idx - nj : idx;
+            const double x = qval(second ? dsB : dsA, P.j_cfg[j]);
+            double *dst = (second ? sc2 : sc) + 2 * j;
+            if (P.j_kind[j] >= TG_RX) tg_sincos(x, &dst[0], &dst[1]);
+            else { dst[0] = x; dst[1] = 0.0; }
+        }
+        TG_SYNC();
+        TG_STAMP(5);
+        for (int b0 = 0; b0 < n24; b0 += LT * TEAM) {       // (uniform trip count: unrolled when the schedule is compiled in)
+            const Rows nxt = b0 + LT * TEAM < n24 ? rows_of(b0 + LT * TEAM + lane) : cur;
+            if (on) {
+#pragma unroll
+                for (int u = 0; u < LT; u++) {
                     const int idx2 = b0 + lane + u * TEAM;
                     if (idx2 < n24) {
                         const bool second = idx2 >= n12;
@@ -664,6 +707,7 @@ struct Core {
         }
         TG_SYNC();
         TG_STAMP(15);
+        }
         const int *sched = (const int *)(S + P.o_sched);
 #if !defined(TG_NO_QUAD_SWEEP)
         if constexpr (tg_static_sweep<typename std::remove_cv<PROG>::type>::value) {
@@ -4385,6 +4429,7 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
     if (wave == 0) core.init_sweep_schedule(MODE == MODE_ROLLOUT);
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     core.prof_last = (long long)__builtin_amdgcn_s_memtime();
+    const long long prof_rt0 = (long long)__builtin_amdgcn_s_memrealtime();     // 100 MHz wall clock: total cycles / these ticks = the shader clock
 #endif
 
     // ---- load state ----------------------------------------------------------------------------------
@@ -4693,9 +4738,8 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
     }
     // ---- write back q1, q2, p2, lambda1, u1 (p1 was stored when the last step started) ----------------------
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-    if (A.prof_out && traj == 0 && lane == 0) {
-        long long t_ = (long long)__builtin_amdgcn_s_memtime();
-        core.prof[13] += t_ - core.prof_last;
+    if (A.prof_out && traj == TG_PROF_TRAJ && lane == 0) {
+        core.prof[13] = (long long)__builtin_amdgcn_s_memrealtime() - prof_rt0;    // (rollout: slot 13 carries the wall-clock ticks instead of the few tail cycles)
         for (int i = 0; i < 16; i++) A.prof_out[i] = core.prof[i];
     }
 #endif

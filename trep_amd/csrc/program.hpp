@@ -42,6 +42,7 @@ struct DevProg {
     const int *j_pre_ident;   // [n_joints] 1 if the constant pre-transform is the identity
     const double *j_pre;      // [n_joints*12]
     const double *jcoef;      // [n_joints*16*4]: local transform entry e = A + B cos q + C sin q + D q
+    const double *j_prm;      // [n_joints*12]: the constant pre-transform of joint j with its columns in the order (axis a, a + 1, a + 2, translation)
     const int *b_anchor;      // [n_bodies] joint or -1
     const double *b_C;        // [n_bodies*12]
     const double *b_inertia;  // [n_bodies*4]
@@ -173,6 +174,7 @@ struct HostProgram {
     std::vector<int> wr_in, wr_kind;
     std::vector<int> cf_cfg, cf_in;
     std::vector<double> jcoef;      // [n_joints*16*4] local-transform coefficients (see pose_sweep)
+    std::vector<double> j_prm;      // [n_joints*12] pre-transform, columns permuted to (axis, next, next-but-one, translation) (see pose_sweep_dual)
     int max_depth = 0;
     // all tables packed into two pools; bind() points a DevProg's table pointers into (copies of) them
     std::vector<int> ipool;
@@ -335,6 +337,15 @@ inline HostProgram build_program(const tg_system_desc *d) {
                     else k[0] = pre[4 * l + c];
                 }
             }
+    }
+    H.j_prm.assign(12 * (size_t)nj, 0.0);
+    for (int j = 0; j < nj; j++) {
+        const double *pre = &H.j_pre[12 * (size_t)j];
+        const int kind = H.j_kind[j], a = kind <= TG_TZ ? kind - TG_TX : kind - TG_RX;
+        for (int l = 0; l < 3; l++) {
+            double *o = &H.j_prm[12 * (size_t)j + 4 * l];
+            o[0] = pre[4 * l + a]; o[1] = pre[4 * l + (a + 1) % 3]; o[2] = pre[4 * l + (a + 2) % 3]; o[3] = pre[4 * l + 3];
+        }
     }
     // bodies and (body, path config) items
     const int nb = d->n_masses;
@@ -811,7 +822,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
     X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in) X(wr_kind) X(ncs_i) \
     X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4) X(bbd_tab) X(cmp_rep) X(cmp_grp) X(cmp_goff) X(cmp_gbody) X(cmp_pair) X(dhr_pack)
-#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c) X(wr_Rloc) X(ncs_mb) X(ncs_tab)
+#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(j_prm) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c) X(wr_Rloc) X(ncs_mb) X(ncs_tab)
 
 inline void HostProgram::pack() {
     ipool.clear(); dpool.clear(); ioff.clear(); doff.clear();
