@@ -12,6 +12,9 @@
 #include <cstdlib>
 #include <vector>
 
+#if defined(TG_BBD_STAMPS)
+namespace tg { __device__ long long tg_bbd_stamps[8]; }
+#endif
 #include "mvi_core.hpp"
 #include "bbd.hpp"
 
@@ -136,6 +139,14 @@ int main(int argc, char **argv) {
         printf("variant %d (%s): %d waves/CU  %.3f ms  -> %.0f ns per solve per resident wave; s_memtime ticks/solve %.0f; worst scaled residual %.2e; not-ok %d\n",
                variant, variant == 0 ? "gj_panel" : "gj_bbd", per_cu, best, best * 1e6 / (2.0 * reps), cavg / reps, worst, bad);
     }
+#if defined(TG_BBD_STAMPS)
+    {   // build with EXTRA=-DTG_BBD_STAMPS: cycles of workgroup 0 between the stages of gj_bbd (3 timed launches x reps solves)
+        long long st[8];
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(tg::tg_bbd_stamps), sizeof(st));
+        const char *names[6] = {"stage 0: tables, rows -> registers", "stage 1: own columns", "stage 2: Schur updates (LDS atomics)", "stage 2: trailing rows + U", "stage 2: trailing elimination", "stage 3: back-substitution, stores"};
+        for (int i = 0; i < 6; i++) printf("  %-40s %8.0f cycles per solve\n", names[i], (double)st[i] / (3.0 * reps));
+    }
+#endif
     double dmax = 0.0;
     for (int m = 0; m < 64; m++) for (int i = 0; i < NF; i++)
         dmax = std::fmax(dmax, std::fabs(x[m * 32 + i] - x[(64 + m) * 32 + i]) / (1e-300 + std::fabs(x[m * 32 + i])));

@@ -4,6 +4,13 @@
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 namespace tg {
 
+// diagnostic builds (tools/micro/bbd_bench.hip -DTG_BBD_STAMPS): cycle stamps between the stages of gj_bbd
+#if defined(TG_BBD_STAMPS)      // (the including file defines  __device__ long long tg::tg_bbd_stamps[8])
+#define BBD_STAMP(i) do { long long t_ = (long long)__builtin_amdgcn_s_memtime(); if (lane == 0 && blockIdx.x == 0) tg_bbd_stamps[i] += t_ - bbd_t0; bbd_t0 = t_; } while (0)
+#else
+#define BBD_STAMP(i) ((void)0)
+#endif
+
 // lane k of every 16-lane row broadcast to the row (DPP row_newbcast; K is a compile-time constant)
 template <int K>
 __device__ __forceinline__ double bbd_bcast(double v) {
@@ -53,6 +60,9 @@ __device__ __noinline__ bool gj_bbd(double *A_generic, const int *tab_generic, d
     lds_double *A = (lds_double *)A_generic, *U = (lds_double *)scratch_generic, *XT = U + T * (T + 1);
     lds_int *tab = (lds_int *)tab_generic;
     constexpr int NCOL = NG + NB + 1, UL = T + 1;
+#if defined(TG_BBD_STAMPS)
+    long long bbd_t0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
     constexpr double GUARD = 9.5367431640625e-07;   // 2^-20
     const int g = lane >> 4, r = lane & 15;
     const int wl = tab[lane];
@@ -85,11 +95,13 @@ __device__ __noinline__ bool gj_bbd(double *A_generic, const int *tab_generic, d
         if (j < T) tmax = fmax(tmax, fabs(tr[j]));
     }
     for (int e = lane; e < T * UL; e += 64) U[e] = 0.0;
+    BBD_STAMP(0);
     // ---- stage 1: the groups' own columns
     double myrp = 0.0;
     bbd_steps<0, NG, NCOL>(a, r, myrp);
     // a lane that never was a pivot lane keeps 1 / pivot = 0 and passes; a zero pivot gives inf (or NaN further down): fails
     bool bad = !(fabs(myrp) * (GUARD * amax) < 1.0);
+    BBD_STAMP(1);
     // ---- stage 2: Schur updates of the border rows into U, then the trailing system
     if (trow >= 0) {
 #pragma unroll
@@ -99,11 +111,14 @@ __device__ __noinline__ bool gj_bbd(double *A_generic, const int *tab_generic, d
         }
     }
     asm volatile("" ::: "memory");
+    BBD_STAMP(2);
     double trp = 0.0;
     if (lane < 16) {
 #pragma unroll
         for (int j = 0; j <= T; j++) { const double u = U[(tl ? lane : 0) * UL + j]; tr[j] += tl ? u : 0.0; }
+        BBD_STAMP(3);
         bbd_steps<0, T, T + 1>(tr, r, trp);
+        BBD_STAMP(4);
         bad = bad || !(fabs(trp) * (GUARD * tmax) < 1.0);
         if (tl) XT[lane] = tr[T] * trp;
     }
@@ -121,6 +136,7 @@ __device__ __noinline__ bool gj_bbd(double *A_generic, const int *tab_generic, d
         A[ro + NF] = s * myrp;
     }
     __syncthreads();
+    BBD_STAMP(5);
     return true;
 }
 
