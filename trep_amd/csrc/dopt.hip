@@ -1723,6 +1723,112 @@ __global__ __launch_bounds__(SW_T) void k_tangent(int N, int nX, int nU, const i
     }
 }
 
+// The same rollout with the matrices in REGISTERS and the dot products spread over lanes: thread (row i, part p = tid & 3) keeps a
+// quarter of row i of A_k and of B_k, thread (input j, part tid & 7) an eighth of row j of K_k -- loaded straight from global memory
+// (a wavefront reads 16 whole rows, contiguous), one step ahead -- and the partial sums meet through DPP (quad_perm / row_half_mirror).
+// k_tangent stages A, B, K in LDS every step and has one lane walk a whole row, an LDS round trip per four entries: 8 us a step
+// where the arithmetic is 0.2.  Needs 4 nX and 8 nU threads (nX <= 96, nU <= 32).
+constexpr int TR_MAX_CA = 24, TR_MAX_CB = 8, TR_MAX_CK = 12;   // most columns of A / B / K a thread holds (k_tangent_rows<CA, CB, CK>: the sizes compiled in)
+template <int CTRL> __device__ __forceinline__ double tr_dpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// Thread (row i, part p) holds columns p, p + 4, p + 8, ... of its row (a quad reads 32 contiguous bytes per load); loads are unconditional
+// -- rows and columns past the end are clamped to the last one and meet the ZERO padding of dX / dU in LDS -- because a guarded global
+// load becomes a basic block of its own (47 of them per step, each with its address arithmetic and exec-mask juggling).
+template <int CA, int CB, int CK> struct TangentRegs {
+    static constexpr int TR_CA = CA, TR_CB = CB, TR_CK = CK;
+    double a[TR_CA], b[TR_CB], k[TR_CK], cq, cr, cc;     // matrix slices; q_k[i], r_k[j], C_k[j] of the thread's row
+    __device__ __forceinline__ void load(const double *Ak, const double *Bk, const double *Kk, const double *Ck, const double *qk, const double *rk,
+                                         int nX, int nU, int row, int pa, int nca, int ncb, int jrow, int pk, int nck) {
+        const double *ar = Ak + (size_t)(row < nX ? row : nX - 1) * nX, *br = Bk + (size_t)(row < nX ? row : nX - 1) * nU;
+        const double *kr = Kk + (size_t)(jrow < nU ? jrow : nU - 1) * nX;
+#pragma unroll
+        for (int c = 0; c < TR_CA; c++) if (c < nca) { const int col = pa + 4 * c; a[c] = ar[col < nX ? col : nX - 1]; }
+#pragma unroll
+        for (int c = 0; c < TR_CB; c++) if (c < ncb) { const int col = pa + 4 * c; b[c] = br[col < nU ? col : nU - 1]; }
+#pragma unroll
+        for (int c = 0; c < TR_CK; c++) if (c < nck) { const int col = pk + 8 * c; k[c] = kr[col < nX ? col : nX - 1]; }
+        cq = qk[row < nX ? row : nX - 1];
+        cr = rk[jrow < nU ? jrow : nU - 1];
+        cc = Ck[jrow < nU ? jrow : nU - 1];
+    }
+};
+template <int TR_CA, int TR_CB, int TR_CK>
+__global__ __launch_bounds__(384) void k_tangent_rows(int N, int nX, int nU, const int *sel, const double *A, const double *B,
+                                                      const double *K, const double *C, const double *q, const double *r,
+                                                      double *dX, double *dU, double *dcost) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, nt = blockDim.x, s = sel ? sel[blockIdx.x] : blockIdx.x;
+    const int row = tid >> 2, pa = tid & 3, nca = (nX + 3) >> 2, ncb = (nU + 3) >> 2;
+    const int jrow = tid >> 3, pk = tid & 7, nck = (nX + 7) >> 3;
+    const int px = 8 * nck, pu = 4 * ncb;                       // padded lengths of dX and dU in LDS (the padding stays zero)
+    double *x0 = lds, *x1 = x0 + px, *u = x1 + px, *red = u + pu;
+    const size_t sN = (size_t)s * N;
+    for (int i = tid; i < 2 * px + pu; i += nt) lds[i] = 0.0;
+    for (int i = tid; i < nX; i += nt) dX[(sN + s) * nX + i] = 0.0;
+    double part = 0.0;
+    TangentRegs<TR_CA, TR_CB, TR_CK> cur, nxt;
+    cur.load(A + sN * (size_t)nX * nX, B + sN * (size_t)nX * nU, K + sN * (size_t)nU * nX, C + sN * nU, q + (sN + s) * nX, r + sN * nU, nX, nU, row, pa, nca, ncb, jrow, pk, nck);
+    __syncthreads();
+    double *x = x0, *xn = x1;
+    for (int k = 0; k < N; k++) {
+        const size_t kn = sN + (k + 1 < N ? k + 1 : k);
+        nxt.load(A + kn * (size_t)nX * nX, B + kn * (size_t)nX * nU, K + kn * (size_t)nU * nX, C + kn * nU, q + (kn + s) * nX, r + kn * nU, nX, nU, row, pa, nca, ncb, jrow, pk, nck);
+        // ---- dU = -K dX - C: eight lanes per input
+        {
+            double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < TR_CK; c += 2) {
+                if (c < nck) v0 = fma(cur.k[c], x[pk + 8 * c], v0);
+                if (c + 1 < nck) v1 = fma(cur.k[c + 1], x[pk + 8 * (c + 1)], v1);
+            }
+            double v = v0 + v1;
+            v += tr_dpp<0xB1>(v); v += tr_dpp<0x4E>(v); v += tr_dpp<0x141>(v);     // quad xor 1, xor 2, mirror of the half row
+            if (jrow < nU && pk == 0) {
+                const double uj = -cur.cc - v;
+                u[jrow] = uj;
+                dU[(sN + k) * nU + jrow] = uj;
+                part = fma(cur.cr, uj, part);
+            }
+        }
+        if (row < nX && pa == 0) part = fma(cur.cq, x[row], part);
+        __syncthreads();
+        // ---- dX' = A dX + B dU: four lanes per state
+        {
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+#pragma unroll
+            for (int c = 0; c < TR_CA; c += 4) {
+                if (c < nca) v0 = fma(cur.a[c], x[pa + 4 * c], v0);
+                if (c + 1 < nca) v1 = fma(cur.a[c + 1], x[pa + 4 * (c + 1)], v1);
+                if (c + 2 < nca) v2 = fma(cur.a[c + 2], x[pa + 4 * (c + 2)], v2);
+                if (c + 3 < nca) v3 = fma(cur.a[c + 3], x[pa + 4 * (c + 3)], v3);
+            }
+#pragma unroll
+            for (int c = 0; c < TR_CB; c += 2) {
+                if (c < ncb) v0 = fma(cur.b[c], u[pa + 4 * c], v0);
+                if (c + 1 < ncb) v1 = fma(cur.b[c + 1], u[pa + 4 * (c + 1)], v1);
+            }
+            double v = (v0 + v1) + (v2 + v3);
+            v += tr_dpp<0xB1>(v); v += tr_dpp<0x4E>(v);
+            if (row < nX && pa == 0) { xn[row] = v; dX[(sN + s + k + 1) * nX + row] = v; }
+        }
+        __syncthreads();
+        double *t_ = x; x = xn; xn = t_;
+        cur = nxt;
+    }
+    if (tid < nX) part = fma(q[(sN + s + N) * nX + tid], x[tid], part);
+    red[tid] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double t_ = 0.0;
+        for (int i = 0; i < nt; i++) t_ += red[i];
+        dcost[s] = t_;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Quadratic tracking cost (dcost.py:5-118): l = 1/2 (x-xd)'Q(x-xd) + 1/2 (u-ud)'R(u-ud), m = 1/2 (x-xd)'Qf(x-xd).
 // Trajectory t of `group` candidates per seed compares against the reference of seed t / group.
@@ -2049,6 +2155,24 @@ int tg_tangent_rollout(int32_t device, int32_t n_problems, int32_t horizon, int3
                        const double *r_dev, double *dX_dev, double *dU_dev, double *dcost_dev) {
     if (n_problems <= 0 || horizon <= 0 || !A_dev || !B_dev || !K_dev || !C_dev || !q_dev || !r_dev || !dX_dev || !dU_dev || !dcost_dev)
         return fail(TG_ERR_INVALID, "bad arguments");
+    if (nX <= 4 * TR_MAX_CA && nU <= 4 * TR_MAX_CB && nX <= 8 * TR_MAX_CK && nX >= 1 && nU >= 1 && !std::getenv("TREPAMD_TANGENT_LDS")) {     // rows in registers (k_tangent_rows)
+        int nt = 4 * nX > 8 * nU ? 4 * nX : 8 * nU;
+        nt = (nt + 63) & ~63;
+        if (nt <= 384) {
+            HIP_TRY(hipSetDevice(device));
+            const size_t ldsr = sizeof(double) * (2 * (size_t)(8 * ((nX + 7) / 8)) + 4 * ((nU + 3) / 4) + nt);
+            const int nca = (nX + 3) / 4, ncb = (nU + 3) / 4, nck = (nX + 7) / 8;
+#define LAUNCH_TR(CA_, CB_, CK_)                                                                                                              \
+            hipLaunchKernelGGL((k_tangent_rows<CA_, CB_, CK_>), dim3(n_problems), dim3(nt), ldsr, dopt_stream(device), horizon, nX, nU, select_dev, \
+                               A_dev, B_dev, K_dev, C_dev, q_dev, r_dev, dX_dev, dU_dev, dcost_dev)
+            if (nca <= 8 && ncb <= 4 && nck <= 4) LAUNCH_TR(8, 4, 4);
+            else if (nca <= 20 && ncb <= 6 && nck <= 10) LAUNCH_TR(20, 6, 10);       // the puppet's nX = 80, nU = 18
+            else LAUNCH_TR(24, 8, 12);
+#undef LAUNCH_TR
+            HIP_TRY(hipGetLastError());
+            return TG_SUCCESS;
+        }
+    }
     const int lda = nX | 1;
     const size_t lds = sizeof(double) * ((size_t)nX * lda + (size_t)nX * nU + (size_t)nU * lda + 2 * nX + nU + SW_T);
     if (lds > 160 * 1024 - 64 || nX > 96 || nX * nU > 12 * SW_T) return fail(TG_ERR_UNSUPPORTED, "state dimension too large");
