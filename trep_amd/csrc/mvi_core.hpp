@@ -153,6 +153,15 @@ template <class P, class = void> struct tg_static_bbd { static constexpr bool va
 template <class P> struct tg_static_bbd<P, typename std::enable_if<(P::bbd_ok >= 0)>::type> { static constexpr bool value = P::bbd_ok != 0; };
 // lane K of every quad (four neighbouring lanes) to the whole quad: two 32-bit DPP moves (quad_perm has no 64-bit form)
 #if defined(__HIP_DEVICE_COMPILE__)
+template <int CTRL> __device__ __forceinline__ double tg_dpp_f64(double x) {      // any DPP control on a double (lanes without a source read 0)
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double tg_readlane_f64(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
 template <int K> __device__ __forceinline__ double tg_quad_bcast(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
     lo = __builtin_amdgcn_update_dpp(0, lo, K * 0x55, 0xF, 0xF, true);     // (bound_ctrl: no tied `old` operand, hence no copy ahead of the move)
@@ -383,6 +392,8 @@ struct Core {
     double tdamp = 0.0;
     long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool rates_ready = false;      // o_dq already holds (q2 - q1) / dt when eval_both_tab starts
+    double res_f2 = 0.0;           // eval_both_tab: square of the residual entry this lane formed (0 past nd) ...
+    bool res_hoff = false;         // ... and whether the constraint this lane evaluated is outside its tolerance: solved_fused()
     long long prof_last = 0;
 
     int wave = 0, nw = 1;   // helper-wave kernels: index of this wavefront within the trajectory's workgroup, number of waves (uniform)
@@ -998,7 +1009,8 @@ struct Core {
                     h = (vx * vx + vy * vy + vz * vz) - len * len;
                 }
                 S[P.o_f + P.nd + lane] = h;
-            }
+                res_hoff = fabs(h) > S[P.o_ctol + lane];
+            } else res_hoff = false;
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 // (only the items of the dynamic configs: nothing in the rollout reads Dh with respect to a kinematic config)
@@ -1036,7 +1048,8 @@ struct Core {
                 }
             }
         }
-        TG_SYNC();
+        // (no barrier: the Jacobian columns below read the body poses and the midpoint joint poses, write J / dqi / gam -- nothing the
+        // constraint rows above touch)
         TG_STAMP(6);
         // ---- body Jacobian columns and body-frame gravity: jacobians ----
         const ResTab rt = fetch_residual();
@@ -1100,36 +1113,32 @@ struct Core {
             S[P.o_vB + lane] = acc;
         }
         TG_SYNC();
-        if (on) {
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int i = lane + u * TEAM;
-                if (i < P.n_items) {
-                    double *W = S + P.o_W + 6 * i;
-                    const double *J = S + P.o_J + 6 * i;
-                    const double Pp[6] = {W[0], W[1], W[2], W[3], W[4], W[5]};
-                    bracket(Pp, J, W);
-                }
-            }
-        }
-        TG_SYNC();
         TG_STAMP(3);
-        // ---- L_dq, L_ddq and the dynamic part of the residual: residual_dyn ----
+        // ---- W = [P, J] of every item (velocities' second half) and, from it in registers, L_dq, L_ddq terms: residual_dyn ----
+        // (the item's lane forms the bracket, uses it and stores it for the Newton matrix: as a phase of its own the bracket costs a
+        // barrier and a second trip of J and W through LDS)
         double *terms = S + P.o_G;
         if (on) {
-            double ta[2], tb[2];
+            double ta[2], tb[2], Wv[2][6];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int i = lane + u * TEAM < P.n_items ? lane + u * TEAM : lane;
                 const int b = it.rec[u][0];
                 const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b;
-                const double *J = S + P.o_J + 6 * i, *W = S + P.o_W + 6 * i, *gam = S + P.o_gam + 3 * b;
-                ta[u] = inner6(I, J, v);
-                tb[u] = inner6(I, W, v) + I[0] * (gam[0] * J[0] + gam[1] * J[1] + gam[2] * J[2]);
+                const double *J = S + P.o_J + 6 * i, *Pw = S + P.o_W + 6 * i, *gam = S + P.o_gam + 3 * b;
+                const double Jr[6] = {J[0], J[1], J[2], J[3], J[4], J[5]}, Pp[6] = {Pw[0], Pw[1], Pw[2], Pw[3], Pw[4], Pw[5]};
+                bracket(Pp, Jr, Wv[u]);
+                ta[u] = inner6(I, Jr, v);
+                tb[u] = inner6(I, Wv[u], v) + I[0] * (gam[0] * Jr[0] + gam[1] * Jr[1] + gam[2] * Jr[2]);
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                if (lane + u * TEAM < P.n_items) { const int slot = it.rec[u][3] >> 16; terms[2 * slot] = ta[u]; terms[2 * slot + 1] = tb[u]; }
+                if (lane + u * TEAM < P.n_items) {
+                    const int slot = it.rec[u][3] >> 16; terms[2 * slot] = ta[u]; terms[2 * slot + 1] = tb[u];
+                    double *W = S + P.o_W + 6 * (lane + u * TEAM);
+#pragma unroll
+                    for (int r = 0; r < 6; r++) W[r] = Wv[u][r];
+                }
             }
         }
         TG_SYNC();
@@ -1159,9 +1168,23 @@ struct Core {
                 }
             }
             S[P.o_f + i] = f;
-        }
-        TG_SYNC();
+            res_f2 = f * f;
+        } else res_f2 = 0.0;
+        // (no barrier: the convergence test that follows works from res_f2 / res_hoff in registers -- solved_fused -- and the next reader
+        // of f, the Newton matrix's last phase, is several barriers away)
         TG_STAMP(4);
+    }
+    // midpointvi.c:709-716 on the values eval_both_tab left in registers: |f_dynamic|_2 <= tolerance (as |f|^2 <= tolerance^2: no square
+    // root on the critical path) and every constraint inside its own tolerance.  The sum goes along DPP row shifts; as solved() -- every
+    // lane re-reading f from LDS behind a barrier and summing it in four chains -- the test cost as much as a phase of the evaluation.
+    TG_HD bool solved_fused(double tolerance) const {
+        double v = res_f2;
+        v += tg_dpp_f64<0x111>(v); v += tg_dpp_f64<0x112>(v); v += tg_dpp_f64<0x114>(v); v += tg_dpp_f64<0x118>(v);   // row_shr 1, 2, 4, 8
+        double norm2 = tg_readlane_f64(v, 15);
+        if (P.nd > 16) norm2 += tg_readlane_f64(v, 31);
+        if (P.nd > 32) norm2 += tg_readlane_f64(v, 47);
+        if (P.nd > 48) norm2 += tg_readlane_f64(v, 63);
+        return !(norm2 > tolerance * tolerance) && !__any(res_hoff ? 1 : 0);
     }
 #endif
 
@@ -4641,6 +4664,10 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
                 core.eval_midpoint(!done);
                 core.eval_constraints(!done, 2, true, S + P.o_Dh2);
             }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_DUAL_SWEEP)
+            if (core.dual_ok() && P.tab_ok) { if (!done && core.solved_fused(A.tolerance)) done = true; }
+            else
+#endif
             if (!done && core.solved(A.tolerance)) done = true;
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
             { long long t_ = (long long)__builtin_amdgcn_s_memtime(); core.prof[12] += t_ - core.prof_last; core.prof_last = t_; }
