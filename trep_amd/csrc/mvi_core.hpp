@@ -917,14 +917,12 @@ struct Core {
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int ii = l + u * TEAM < 12 * P.n_bodies ? l + u * TEAM : 0;
-            const int b = ii / 12, e = ii % 12, c = e & 3;
-            const double *C = P.b_C + 12 * b;
-            t.ce[u] = C[e]; t.c0[u] = C[c]; t.c1[u] = C[4 + c]; t.c2[u] = C[8 + c]; t.ga[u] = P.b_anchor[b];
+            const double *C = P.at_d + 4 * (size_t)ii;
+            t.ce[u] = C[0]; t.c0[u] = C[1]; t.c1[u] = C[2]; t.c2[u] = C[3]; t.ga[u] = P.at_i[ii];
         }
         const int ii = l < 3 * P.n_endpoints ? l : 0;
-        const int e = ii / 3, r = ii % 3;
-        const double *o = P.e_off + 3 * e;
-        t.o0 = o[0]; t.o1 = o[1]; t.o2 = o[2]; t.orr = o[r]; t.ea = P.e_anchor[e];
+        const double *o = P.ae_d + 4 * (size_t)ii;
+        t.o0 = o[0]; t.o1 = o[1]; t.o2 = o[2]; t.orr = o[3]; t.ea = P.ae_i[ii];
         return t;
     }
     TG_HD ConTab fetch_constraints() const {

@@ -63,6 +63,11 @@ struct DevProg {
     //   dh_pack[2n]  = {constraint, config, 12*joint (or -1), side | joint kind << 8 | constraint type << 16 | component << 24}
     //   dh_pack[2n+1]= {3*end point 1, 3*end point 2, length config (or -1), 0}
     const int *it_pack, *dh_pack;
+    // rows of the attach phase as the lanes read them (eval_both_tab, fetch_attach): at_d[4 i] = {C_b[e], C_b[c], C_b[4 + c], C_b[8 + c]} of body
+    // entry i = 12 b + e (c = e & 3), at_i[i] = the body's anchor joint; ae_d[4 i] = {o_0, o_1, o_2, o_r} of end-point coordinate i = 3 e + r,
+    // ae_i[i] = its anchor joint -- one vector load per row instead of four scalar ones behind a division by 12
+    const double *at_d, *ae_d;
+    const int *at_i, *ae_i;
     // the dh items the ROLLOUT needs -- those of the dynamic configs (the residual and the Newton matrix never touch Dh with respect to a
     // kinematic config) -- in dh_pack's layout, word 7 = the item's index n (where its value goes in Dh1 / Dh2); n_dhr of them
     const int *dhr_pack;
@@ -161,7 +166,7 @@ struct HostProgram {
     std::vector<double> j_pre;
     std::vector<int> b_anchor;
     std::vector<double> b_C, b_inertia;
-    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4, tri4, cpair4, it_pack, dh_pack, cpath_off, cpath_items, dh_pos, tchunk, tri_off, dhr_pack;
+    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4, tri4, cpair4, it_pack, dh_pack, cpath_off, cpath_items, dh_pos, tchunk, tri_off, dhr_pack, at_i, ae_i;
     std::vector<int> wp_a, wp_b, wt_a, wt_b, wt_split, wcp4;
     std::vector<int> e_anchor;
     std::vector<double> e_off;
@@ -174,6 +179,7 @@ struct HostProgram {
     std::vector<int> wr_in, wr_kind;
     std::vector<int> cf_cfg, cf_in;
     std::vector<double> jcoef;      // [n_joints*16*4] local-transform coefficients (see pose_sweep)
+    std::vector<double> at_d, ae_d;   // attach-phase rows (DevProg::at_d / ae_d)
     std::vector<double> j_prm;      // [n_joints*12] pre-transform, columns permuted to (axis, next, next-but-one, translation) (see pose_sweep_dual)
     int max_depth = 0;
     // all tables packed into two pools; bind() points a DevProg's table pointers into (copies of) them
@@ -504,6 +510,20 @@ inline HostProgram build_program(const tg_system_desc *d) {
         H.dh_pack.push_back(H.dh_side[n] | ((j >= 0 ? H.j_kind[j] : 0) << 8) | (H.c_type[c] << 16) | ((H.c_comp[c] & 0xFF) << 24));
         H.dh_pack.push_back(3 * H.c_e1[c]); H.dh_pack.push_back(3 * H.c_e2[c]); H.dh_pack.push_back(H.c_cfg[c]); H.dh_pack.push_back(0);
     }
+    for (int i = 0; i < 12 * (int)H.b_anchor.size(); i++) {
+        const int b = i / 12, e = i % 12, c = e & 3;
+        const double *C = &H.b_C[12 * (size_t)b];
+        H.at_d.push_back(C[e]); H.at_d.push_back(C[c]); H.at_d.push_back(C[4 + c]); H.at_d.push_back(C[8 + c]);
+        H.at_i.push_back(H.b_anchor[b]);
+    }
+    for (int i = 0; i < 3 * (int)H.e_anchor.size(); i++) {
+        const int e = i / 3, r = i % 3;
+        const double *o = &H.e_off[3 * (size_t)e];
+        H.ae_d.push_back(o[0]); H.ae_d.push_back(o[1]); H.ae_d.push_back(o[2]); H.ae_d.push_back(o[r]);
+        H.ae_i.push_back(H.e_anchor[e]);
+    }
+    if (H.at_i.empty()) { H.at_i.push_back(-1); H.at_d.assign(4, 0.0); }
+    if (H.ae_i.empty()) { H.ae_i.push_back(-1); H.ae_d.assign(4, 0.0); }
     for (int n = 0; n < n_dh_con; n++) {
         if (H.dh_cfg[n] >= nd) continue;
         for (int w = 0; w < 7; w++) H.dhr_pack.push_back(H.dh_pack[8 * (size_t)n + w]);
@@ -821,8 +841,8 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
     X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in) X(wr_kind) X(ncs_i) \
-    X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4) X(bbd_tab) X(cmp_rep) X(cmp_grp) X(cmp_goff) X(cmp_gbody) X(cmp_pair) X(dhr_pack)
-#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(j_prm) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c) X(wr_Rloc) X(ncs_mb) X(ncs_tab)
+    X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4) X(bbd_tab) X(cmp_rep) X(cmp_grp) X(cmp_goff) X(cmp_gbody) X(cmp_pair) X(dhr_pack) X(at_i) X(ae_i)
+#define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(j_prm) X(at_d) X(ae_d) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c) X(wr_Rloc) X(ncs_mb) X(ncs_tab)
 
 inline void HostProgram::pack() {
     ipool.clear(); dpool.clear(); ioff.clear(); doff.clear();
