@@ -174,6 +174,48 @@ def test_tv_lq_with_dsystem_structure(nd, nk, nu, N, S):
     assert L.tg_tv_lq(0, ctypes.byref(p)) != 0
 
 
+@pytest.mark.parametrize("nX,nU", [(6, 2), (30, 9), (37, 5), (80, 18), (91, 27), (96, 32)])
+def test_tangent_rollout_sizes(nX, nU, monkeypatch):
+    """tg_tangent_rollout (doptimizer.py:391-402, 262-270) against numpy over the slice sizes k_tangent_rows is compiled for (odd sizes: the
+    clamped last columns meet the zero padding), with a selection list, and against the LDS-staged kernel it replaces."""
+    from trep_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(100 * nX + nU)
+    S, N = 3, 23
+    A = rng.standard_normal((S, N, nX, nX)) * (0.9 / np.sqrt(nX)); B = rng.standard_normal((S, N, nX, nU)) * 0.3
+    K = rng.standard_normal((S, N, nU, nX)) * 0.1; C = rng.standard_normal((S, N, nU))
+    q = rng.standard_normal((S, N + 1, nX)); r = rng.standard_normal((S, N, nU))
+    sel = np.array([2, 0], dtype=np.int32)
+    pool = _pool()
+    try:
+        d = dict((k, pool.upload(v)) for k, v in dict(A=A, B=B, K=K, C=C, q=q, r=r).items())
+        dsel = pool.upload(sel, np.int32)
+        out = {}
+        for variant in ("rows", "lds"):
+            if variant == "lds":
+                monkeypatch.setenv("TREPAMD_TANGENT_LDS", "1")
+            ddX, ddU, ddc = pool.upload(np.full((S, N + 1, nX), np.nan)), pool.upload(np.full((S, N, nU), np.nan)), pool.upload(np.full((S,), np.nan))
+            _lib.check(L.tg_tangent_rollout(0, len(sel), N, nX, nU, dsel.ptr, d["A"].ptr, d["B"].ptr, d["K"].ptr, d["C"].ptr, d["q"].ptr, d["r"].ptr,
+                                            ddX.ptr, ddU.ptr, ddc.ptr))
+            out[variant] = (ddX.get(), ddU.get(), ddc.get())
+        dX, dU, dc = out["rows"]
+        assert np.isnan(dX[1]).all() and np.isnan(dU[1]).all() and np.isnan(dc[1])      # not selected: untouched
+        for s in sel:
+            x = np.zeros(nX); ref = 0.0
+            for k in range(N):
+                assert relerr(dX[s, k], x) < 1e-11 or not x.any()
+                u = -K[s, k].dot(x) - C[s, k]
+                assert relerr(dU[s, k], u) < 1e-11
+                ref += q[s, k].dot(x) + r[s, k].dot(u)
+                x = A[s, k].dot(x) + B[s, k].dot(u)
+            assert relerr(dX[s, N], x) < 1e-11
+            ref += q[s, N].dot(x)
+            assert abs(dc[s] - ref) < 1e-10 * max(1.0, abs(ref))
+            assert relerr(dX[s], out["lds"][0][s]) < 1e-12 and relerr(dU[s], out["lds"][1][s]) < 1e-12
+    finally:
+        pool.close()
+
+
 def test_sweeps_and_cost_match_numpy():
     from trep_amd import _lib
     from trep_amd.discopt import DCost
