@@ -262,6 +262,10 @@ class BatchDOptimizer(object):
         """The projection gain and, beside it on a second stream, the quasi-Newton direction of EVERY seed into the second
         set of direction buffers (needs q, r: call gradients_and_cost first).  Leaves (dcost, failed) in _quasi_ready."""
         S, N, nX, nU = self.S, self.N, self.nX, self.nU
+        # fork: everything the two sweeps read (A, B from the linearisation's stream, q, r from the cost kernels) is complete before the
+        # lanes start -- an explicit device synchronisation (tens of microseconds against sweeps of tens of milliseconds) instead of
+        # relying on how blocking streams order themselves against the default stream; the join below is explicit as well
+        self._check(self.L.tg_device_synchronize(self.device))
         try:
             self._check(self.L.tg_dopt_use_stream(self.device, 1))
             self.projection_gain(with_adjoint, collect=False)
