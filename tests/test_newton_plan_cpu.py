@@ -87,3 +87,47 @@ def test_every_structural_nonzero_is_covered_by_the_plan(name):
 def test_small_systems_have_no_plan(name):
     plan, pat, tab, _ = _plan(name)
     assert plan["ok"] == 0 and not pat.any() and not tab.any()
+
+
+def _spec_constants(system):
+    """static constexpr ints of the system's specialisation header (tg_system_spec_header: host side, no compiler involved)"""
+    import re
+    from trep_amd import specialize
+    text = specialize.header(system)
+    return {m.group(1): int(m.group(2)) for m in re.finditer(r"static constexpr int (\w+) = (-?\d+);", text)}, text
+
+
+def test_puppet_sweep_plan_and_rollout_item_lists():
+    """What the re-cut evaluation phases of the specialised rollout kernel are compiled against (DevProg sw_*, n_dhr, max_cfg_items):
+    the quad-lane chain sweep's passes -- a round's 2 x chains instances five to a pass, the longest chain of a pass as its unrolled trip
+    count -- and the constraint-derivative items of the dynamic configs only."""
+    from trep_amd import systems
+    c, text = _spec_constants(systems.puppet())
+    assert c["sw_ok"] == 1 and c["n_rounds"] == 2
+    # round 0: the torso chain (6 joints) and six two-joint string-hook chains -> 14 instances in 3 passes; round 1: four limbs of 4 joints
+    assert [c["sw_np_%d" % i] for i in range(4)] == [3, 2, 0, 0]
+    assert [c["sw_len_%d" % i] for i in range(8)] == [6, 2, 2, 0, 4, 4, 0, 0]
+    assert c["sw_maxlen"] == 6
+    # 68 (constraint, config) items, 18 of them of kinematic configs (six string lengths, twelve hook coordinates)
+    assert c["n_dh"] == 68 and c["n_dhr"] == 50 and c["nk"] == 18
+    assert c["max_cfg_items"] == 10 and c["n_items"] == 88 and c["n_joints"] == 34
+    for name in ("j_prm", "at_d", "ae_d", "at_i", "ae_i", "dhr_pack"):
+        assert "*%s = " % name in text, name
+
+
+@pytest.mark.parametrize("name", ["pendulum", "cart", "scissor_lift", "puppet_basic"])
+def test_sweep_plans_of_the_other_baseline_systems(name):
+    from trep_amd import systems
+    system = {"pendulum": lambda: systems.pendulum(1), "cart": systems.pend_on_cart, "scissor_lift": lambda: systems.scissor_lift(4),
+              "puppet_basic": systems.puppet_basic}[name]()
+    c, _ = _spec_constants(system)
+    assert c["n_dhr"] <= c["n_dh"]
+    if c["sw_ok"]:
+        rounds = c["n_rounds"]
+        assert 1 <= rounds <= 4
+        for r in range(rounds):
+            np_r = c["sw_np_%d" % r]
+            assert 1 <= np_r <= 4
+            assert sum(c["sw_len_%d" % (4 * r + p)] for p in range(np_r)) <= 16
+            assert all(1 <= c["sw_len_%d" % (4 * r + p)] <= c["sw_maxlen"] for p in range(np_r))
+            assert all(c["sw_len_%d" % (4 * r + p)] == 0 for p in range(np_r, 4))
