@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(int reps, const double *A_in, c
         for (int e = lane; e < NF * LD; e += 64) lds[e] = pristine[e];
         __syncthreads();
         if (VARIANT == 0) ok &= tg::Core<64>::gj_panel<28, false>(true, lds, NF, LD, lane, scratch, nullptr);
-        else ok &= tg::gj_bbd<NF, LD, BB_NG, BB_NB, BB_T>(lds, tab, scratch, lane, TVar{});
+        else ok &= tg::gj_bbd<NF, LD, BB_NG, BB_NB, BB_T>(lds, tg::bbd_rows<BB_NG + BB_NB>(tab, lane), scratch, lane, TVar{});
         __syncthreads();
     }
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();

@@ -50,26 +50,38 @@ __device__ __forceinline__ void bbd_steps(double (&a)[NCOL], int r, double &myrp
     }
 }
 
-// Solve the dense image A [NF][LD] (right-hand side in column NF) along the plan staged in LDS at `tab` (BbdPlan::tab).
+// Solve the dense image A [NF][LD] (right-hand side in column NF) along the plan whose rows for this lane are `rows` (bbd_rows).
 // scratch: T * (T + 1) + T doubles of LDS outside the image.  Returns true and leaves x_i in A[i][NF] if every guard held;
 // otherwise returns false with the image untouched.
-template <int NF, int LD, int NG, int NB, int T, class TVAR>
-__device__ __noinline__ bool gj_bbd(double *A_generic, const int *tab_generic, double *scratch_generic, int lane, TVAR tvar) {
-    typedef __attribute__((address_space(3))) double lds_double;
+// The lane's rows of the plan tables (BbdPlan::tab staged in LDS): constants of the lane, so a caller can request them long before the
+// solve (the rollout does, ahead of the matrix assembly) and the solve starts with the row loads instead of a table round trip.
+template <int NGB> struct BbdRows { int wl; int wc[NGB]; };
+template <int NGB>
+__device__ __forceinline__ BbdRows<NGB> bbd_rows(const int *tab_generic, int lane) {
     typedef __attribute__((address_space(3))) const int lds_int;
-    lds_double *A = (lds_double *)A_generic, *U = (lds_double *)scratch_generic, *XT = U + T * (T + 1);
     lds_int *tab = (lds_int *)tab_generic;
+    BbdRows<NGB> t;
+    t.wl = tab[lane];
+#pragma unroll
+    for (int j = 0; j < NGB; j++) t.wc[j] = tab[64 + 16 * (lane >> 4) + j];
+    return t;
+}
+
+template <int NF, int LD, int NG, int NB, int T, class TVAR>
+__device__ __noinline__ bool gj_bbd(double *A_generic, BbdRows<NG + NB> rows, double *scratch_generic, int lane, TVAR tvar) {
+    typedef __attribute__((address_space(3))) double lds_double;
+    lds_double *A = (lds_double *)A_generic, *U = (lds_double *)scratch_generic, *XT = U + T * (T + 1);
     constexpr int NCOL = NG + NB + 1, UL = T + 1;
 #if defined(TG_BBD_STAMPS)
     long long bbd_t0 = (long long)__builtin_amdgcn_s_memtime();
 #endif
     constexpr double GUARD = 9.5367431640625e-07;   // 2^-20
     const int g = lane >> 4, r = lane & 15;
-    const int wl = tab[lane];
+    const int wl = rows.wl;
     const int row = (wl & 0xFF) - 1, trow = ((wl >> 8) & 0xFF) - 1, timg = ((wl >> 16) & 0xFF) - 1;
     int wc[NG + NB];
 #pragma unroll
-    for (int j = 0; j < NG + NB; j++) wc[j] = tab[64 + 16 * g + j];
+    for (int j = 0; j < NG + NB; j++) wc[j] = rows.wc[j];
     // ---- stage 0: registers.  own rows: everything; border rows: the own columns only (the rest accumulates the Schur update)
     double a[NCOL];
     const bool own = r < NG, have = row >= 0;

@@ -151,6 +151,9 @@ namespace tg {
 // the structured Newton solve needs its plan as compile-time constants: system-specialised schedules (SpecProg: static members) only
 template <class P, class = void> struct tg_static_bbd { static constexpr bool value = false; };
 template <class P> struct tg_static_bbd<P, typename std::enable_if<(P::bbd_ok >= 0)>::type> { static constexpr bool value = P::bbd_ok != 0; };
+// number of (own + border) columns of the plan (1 where there is no plan: the type of an unused variable)
+template <bool USE, class P, class = void> struct tg_static_bbd_cols { static constexpr int value = 1; };
+template <class P> struct tg_static_bbd_cols<true, P, typename std::enable_if<(P::bbd_ok > 0)>::type> { static constexpr int value = P::bbd_ng + P::bbd_nb; };
 // lane K of every quad (four neighbouring lanes) to the whole quad: two 32-bit DPP moves (quad_perm has no 64-bit form)
 #if defined(__HIP_DEVICE_COMPILE__)
 template <int CTRL> __device__ __forceinline__ double tg_dpp_f64(double x) {      // any DPP control on a double (lanes without a source read 0)
@@ -1551,10 +1554,7 @@ struct Core {
         // ---- phase D: the constant entries (right-hand side, damping, -Dh1' / Dh2) and the config pairs: one lane per pair, one pair per
         //      entry and its transpose (the damping joins the diagonal pair's sum as an LDS add of its own: same wave, fixed order)
         if (on) {
-            if (lane < nf) {
-                A[lane * ld + nf] = S[P.o_f + lane];
-                if (lane < nd) lds_add(&A[lane * ld + lane], -tdamp);
-            }
+            if (lane < nf) A[lane * ld + nf] = S[P.o_f + lane];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int n = tck[u][0] >> 8, c = tck[u][0] & 0xFF, k = tck[u][1];
@@ -1575,8 +1575,10 @@ struct Core {
 #pragma unroll
                 for (int r = 0; r < 6; r++) { mab = fma(s_[r], i_[r], mab); lqq = fma(w_[r], z_[r], lqq); cab = fma(s_[r], z_[r], cab); cba = fma(w_[r], i_[r], cba); }
                 const double sym = qdt * lqq - rdt * mab, skew = 0.5 * (cba - cab);
-                lds_add(&A[a * ld + b], sym + (a != b ? skew : 0.0));
-                if (a != b) lds_add(&A[b * ld + a], sym - skew);
+                // one lane per entry and its transpose: plain stores.  The first nd pairs are the diagonal ones in config order (program.hpp),
+                // so lane c of the first trip adds config c's damping from its own table row
+                if (u == 0 && a == b) A[a * ld + a] = sym - tdamp;
+                else { A[a * ld + b] = sym + (a != b ? skew : 0.0); if (a != b) A[b * ld + a] = sym - skew; }
             }
         }
         TG_SYNC();
@@ -4677,6 +4679,12 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
 #else
             if (done) break;
 #endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_BBD)
+            // the structured solve's table rows of this lane, requested ahead of the matrix assembly
+            BbdRows<tg_static_bbd_cols<TEAM == 64 && PIVOT == 0, typename std::remove_cv<PROG>::type>::value> bbd_tab_rows;
+            if constexpr (TEAM == 64 && PIVOT == 0 && tg_static_bbd<typename std::remove_cv<PROG>::type>::value)
+                bbd_tab_rows = bbd_rows<tg_static_bbd_cols<true, typename std::remove_cv<PROG>::type>::value>((const int *)(S + P.o_bbd), lane);
+#endif
             core.newton_matrix(!done);
             bool ok;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -4688,7 +4696,7 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
                 // leaves the image untouched and the pivoting solver below takes over (a full-wave team: done is false here and
                 // the branch is uniform).  Scratch: the Jacobian columns, dead between the matrix's assembly and the next evaluation.
                 typedef typename std::remove_cv<PROG>::type SP;
-                bbd_done = gj_bbd<SP::nf, SP::df_ld, SP::bbd_ng, SP::bbd_nb, SP::bbd_t>(S + P.o_Df, (const int *)(S + P.o_bbd), S + P.o_J, lane, P.bbd_tvar);
+                bbd_done = gj_bbd<SP::nf, SP::df_ld, SP::bbd_ng, SP::bbd_nb, SP::bbd_t>(S + P.o_Df, bbd_tab_rows, S + P.o_J, lane, P.bbd_tvar);
                 ok = true;
             }
 #endif

@@ -771,12 +771,15 @@ inline HostProgram build_program(const tg_system_desc *d) {
         }
         std::vector<unsigned char> from_pairs((size_t)nd * nd, 0), from_cmp((size_t)nd * nd, 0);
         for (int n = 0; n < P.n_npairs; n++) from_pairs[(size_t)(H.pair4[4 * n + 2] & 0xFFFF) * nd + (H.pair4[4 * n + 2] >> 16)] = 1;
-        for (int c = 0; c < nd && all_rep; c++) {           // ancestors of c (and c itself) along the path of its representative item's body
+        // the diagonal pairs (c, c) first, in config order: lane c of the first trip then holds config c's damping already (tdamp), and
+        // every entry of the inertial block is written by exactly one lane -- plain stores, no LDS atomics
+        for (int c = 0; c < nd && all_rep; c++) { H.cmp_pair.push_back(c | (c << 16)); from_cmp[(size_t)c * nd + c] = 1; }
+        for (int c = 0; c < nd && all_rep; c++) {           // proper ancestors of c along the path of its representative item's body
             const int b = H.it_body[H.cmp_rep[c]];
             for (int it = H.b_item_off[b]; it < H.b_item_off[b + 1]; it++) {
                 const int a = H.it_cfg[it];
-                if (a < nd) { H.cmp_pair.push_back(a | (c << 16)); from_cmp[(size_t)a * nd + c] = 1; }
                 if (a == c) break;
+                if (a < nd) { H.cmp_pair.push_back(a | (c << 16)); from_cmp[(size_t)a * nd + c] = 1; }
             }
         }
         const int need = 16 * (int)group_of.size() + 27 * nd;                      // J / W area

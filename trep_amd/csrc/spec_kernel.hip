@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64, 2) void k_spec_debug_solve(const double *A_in, 
         int *tab = (int *)(S + P.o_bbd);
         for (int e = lane; e < 128; e += 64) tab[e] = P.bbd_tab[e];
         __syncthreads();
-        if (!skip_structured && tg::gj_bbd<nf, ld, SpecProg::bbd_ng, SpecProg::bbd_nb, SpecProg::bbd_t>(S + P.o_Df, tab, S + P.o_J, lane, P.bbd_tvar)) { ok = true; path = 1; }
+        if (!skip_structured && tg::gj_bbd<nf, ld, SpecProg::bbd_ng, SpecProg::bbd_nb, SpecProg::bbd_t>(S + P.o_Df, tg::bbd_rows<SpecProg::bbd_ng + SpecProg::bbd_nb>(tab, lane), S + P.o_J, lane, P.bbd_tvar)) { ok = true; path = 1; }
     }
     __syncthreads();
     if (!ok) {
