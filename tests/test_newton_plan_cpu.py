@@ -104,14 +104,20 @@ def test_puppet_sweep_plan_and_rollout_item_lists():
     from trep_amd import systems
     c, text = _spec_constants(systems.puppet())
     assert c["sw_ok"] == 1 and c["n_rounds"] == 2
-    # round 0: the torso chain (6 joints) and six two-joint string-hook chains -> 14 instances in 3 passes; round 1: four limbs of 4 joints
-    assert [c["sw_np_%d" % i] for i in range(4)] == [3, 2, 0, 0]
-    assert [c["sw_len_%d" % i] for i in range(8)] == [6, 2, 2, 0, 4, 4, 0, 0]
+    # round 0: the torso chain (6 joints) in both pose sets and the six two-joint string-hook chains at q2 only (no body hangs below a
+    # hook: its midpoint pose is never read) -> 8 instances in 2 passes; round 1: four limbs of 4 joints in both sets
+    assert [c["sw_np_%d" % i] for i in range(4)] == [2, 2, 0, 0]
+    assert [c["sw_len_%d" % i] for i in range(8)] == [6, 2, 0, 0, 4, 4, 0, 0]
     assert c["sw_maxlen"] == 6
+    inst = [c["sw_inst_%d" % i] for i in range(80)]
+    assert inst[:8] == [512, 768] + [768 + s for s in range(1, 7)] and not any(inst[8:20])       # slot | set << 8 | 1 << 9
+    assert inst[20:28] == [512, 768, 513, 769, 514, 770, 515, 771] and not any(inst[28:])
+    # 2 x 34 (pose set, joint) items, 14 of them never read by the rollout: one trip of the wavefront instead of two
+    assert c["n_sj"] == 54 and c["n_sj_rot"] == 36
     # 68 (constraint, config) items, 18 of them of kinematic configs (six string lengths, twelve hook coordinates)
     assert c["n_dh"] == 68 and c["n_dhr"] == 50 and c["nk"] == 18
     assert c["max_cfg_items"] == 10 and c["n_items"] == 88 and c["n_joints"] == 34
-    for name in ("j_prm", "at_d", "ae_d", "at_i", "ae_i", "dhr_pack"):
+    for name in ("j_prm", "at_d", "ae_d", "at_i", "ae_i", "dhr_pack", "sj_list", "sj_full"):
         assert "*%s = " % name in text, name
 
 

@@ -392,6 +392,8 @@ struct Core {
     // constant Newton-matrix entries (damping of this row, (constraint, config) of the lane's two Dh items, first pair record)
     int jck[2] = {0, 0}, bio[2] = {0, 0}, tck[2][2] = {{0, 0}, {0, 0}}, tpair[4] = {0, 0, 0, 0};
     int sc_rot2 = 0;   // number of (pose set, rotary joint) items of the dual sin/cos pass: they come first in the lane order
+    int sj_n = 0;      // number of (pose set, joint) items of that pass (init_sweep_schedule)
+    bool sj_quads = false;   // the quad-lane chain rounds follow the rollout's instance plan (sw_inst): rollout kernels only
     double tdamp = 0.0;
     long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool rates_ready = false;      // o_dq already holds (q2 - q1) / dt when eval_both_tab starts
@@ -467,21 +469,17 @@ struct Core {
             // Lane order of the 2 x n_joints (pose set, joint) items of the sin/cos pass: the rotary joints of both pose sets first,
             // then the prismatic ones -- so that the second trip of the wavefront (puppet: 68 items, 38 of them rotary) has no
             // sin/cos to evaluate and skips that code.  jck: config | kind << 12 | joint << 16 | pose set << 28.
-            int n_rot = 0;
-            for (int j = 0; j < P.n_joints; j++) n_rot += P.j_kind[j] >= TG_RX ? 1 : 0;
-            sc_rot2 = 2 * n_rot;
+            // The (pose set, joint) items of the dual sin/cos + local-transform pass, rotary ones first (so that a trip without rotary joints
+            // skips that code): host-made lists (program.hpp) -- the rollout's holds only the poses it reads (sj_list), the derivative
+            // kernels' every joint in both sets (sj_full).  jck: config | kind << 12 | joint << 16 | pose set << 28.
+            sj_n = rollout ? P.n_sj : 2 * P.n_joints;
+            if (rollout) sc_rot2 = P.n_sj_rot;
+            else { int n_rot = 0; for (int j = 0; j < P.n_joints; j++) n_rot += P.j_kind[j] >= TG_RX ? 1 : 0; sc_rot2 = 2 * n_rot; }
+            sj_quads = rollout;
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int pos = lane + u * TEAM;
-                const bool rot = pos < 2 * n_rot;
-                const int per_set = rot ? n_rot : P.n_joints - n_rot, t = rot ? pos : pos - 2 * n_rot;
-                const int set = (per_set > 0 && t >= per_set) ? 1 : 0, rank = t - set * per_set;
-                int jj = 0, seen = 0;
-                for (int j = 0; j < P.n_joints; j++) {
-                    const bool r_ = P.j_kind[j] >= TG_RX;
-                    if (r_ == rot) { if (seen == rank) jj = j; seen++; }
-                }
-                jck[u] = pos < 2 * P.n_joints ? (P.j_cfg[jj] | (P.j_kind[jj] << 12) | (jj << 16) | (set << 28)) : 0;
+                jck[u] = pos < sj_n ? (rollout ? P.sj_list[pos] : P.sj_full[pos]) : 0;
                 // dh items of the dynamic configs (program.hpp, dhr_pack): constraint | item index << 8, config
                 const int n = lane + u * TEAM < P.n_dhr ? lane + u * TEAM : 0;
                 if (P.n_dhr) { tck[u][0] = P.dhr_pack[8 * (size_t)n] | (P.dhr_pack[8 * (size_t)n + 7] << 8); tck[u][1] = P.dhr_pack[8 * (size_t)n + 1]; }
@@ -606,8 +604,9 @@ struct Core {
     // through the same phases: the second pose set lives in the W area and its sin/cos in the J area (both dead until
     // the Jacobians / prefix velocities are formed), every chain lane carries the two row recurrences side by side
     // (two independent FMA chains per lane), and the local-transform pass covers 2 x 12 x n_joints entries.
-    TG_HD void pose_sweep_dual(bool on) {
+    TG_HD void pose_sweep_dual(bool on, bool rollout_lists) {
         PROG &P = tg_fresh(this->P);
+        const int sjn = rollout_lists ? P.n_sj : 2 * P.n_joints;     // (what init_sweep_schedule filled jck from)
         double *sc = S + P.o_sc, *sc2 = S + P.o_J, *G = S + P.o_G, *G2 = S + P.o_W;
         const int nj = P.n_joints;
         const int n12 = 12 * nj, n24 = 2 * n12;
@@ -620,9 +619,11 @@ struct Core {
         int swq = 4, swrc = 0;
         bool swact = false;
         if constexpr (tg_static_sweep<typename std::remove_cv<PROG>::type>::value) {
-            const int l = tg_opaque(lane);
-            swact = l < 60; swq = swact ? l / 12 : 4; swrc = swact ? l - 12 * swq : 0;
-            sw0 = sw_fetch<typename std::remove_cv<PROG>::type, 0>((const int *)(S + P.o_sched), swq);
+            if (rollout_lists) {
+                const int l = tg_opaque(lane);
+                swact = l < 60; swq = swact ? l / 12 : 4; swrc = swact ? l - 12 * swq : 0;
+                sw0 = sw_fetch<typename std::remove_cv<PROG>::type, 0>((const int *)(S + P.o_sched), swq);
+            }
         }
 #endif
         if (P.tab_ok) {
@@ -645,7 +646,7 @@ struct Core {
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const int idx = lane + u * TEAM;
-                    if (u * TEAM < 2 * nj && idx < 2 * nj) {
+                    if (u * TEAM < sjn && idx < sjn) {
                         const bool second = (jck[u] >> 28) != 0;
                         const int j = (jck[u] >> 16) & 0xFFF, kind = (jck[u] >> 12) & 0xF;
                         const double x = qval(second ? dsB : dsA, jck[u] & 0xFFF);
@@ -725,9 +726,11 @@ struct Core {
         const int *sched = (const int *)(S + P.o_sched);
 #if !defined(TG_NO_QUAD_SWEEP)
         if constexpr (tg_static_sweep<typename std::remove_cv<PROG>::type>::value) {
-            typedef typename std::remove_cv<PROG>::type SP;
-            chain_round_quads<SP, 0>(on, sched, sw0, swq, swrc >> 2, swrc & 3, swact);
-            return;
+            if (rollout_lists) {     // (the instance plan lists the chains the ROLLOUT reads; the derivative kernels sweep every chain below)
+                typedef typename std::remove_cv<PROG>::type SP;
+                chain_round_quads<SP, 0>(on, sched, sw0, swq, swrc >> 2, swrc & 3, swact);
+                return;
+            }
         }
 #endif
         if (P.sched_ok == 2) {
@@ -821,13 +824,19 @@ struct Core {
     // row for the puppet); here a round costs one.  Passes of a round are independent and interleaved.  Same products; the translation
     // entry G(r, 3) opens the sum instead of closing it (three dependent operations per step instead of four).
     struct SwDesc { int w0[4], par[4]; };      // per pass: 12 * first joint | chain length << 16, 12 * parent joint (or -1) of the lane's instance
+    // instance q (the lane's, 0 .. 4) of the pass whose five plan words start at `base`: chain slot | pose set << 8; a lane without an
+    // instance gets slot 15, which the schedule leaves empty (length 0).  The plan words are compile-time constants: four selects.
+    template <class SP> TG_HD static int sw_code(int base, int q) {
+        auto w = [&](int i) { const int c = SP::sw_inst[base + i]; return c ? (c & 0x1FF) : 15; };
+        return q == 0 ? w(0) : q == 1 ? w(1) : q == 2 ? w(2) : q == 3 ? w(3) : w(4);
+    }
     template <class SP, int RD> TG_HD SwDesc sw_fetch(const int *sched, int q) const {
         SwDesc d;
 #pragma unroll
         for (int ps = 0; ps < 4; ps++) {
             d.w0[ps] = 0; d.par[ps] = -1;
             if (ps < SP::sw_np[RD < 4 ? RD : 0]) {
-                const int slot = (5 * ps + q) >> 1;
+                const int slot = sw_code<SP>((4 * RD + ps) * 5, q) & 0xFF;
                 d.w0[ps] = sched[2 * (16 * RD + slot)]; d.par[ps] = sched[2 * (16 * RD + slot) + 1];
             }
         }
@@ -848,7 +857,7 @@ struct Core {
 #pragma unroll
                 for (int ps = 0; ps < 4; ps++) {
                     if (ps < NP) {
-                        const int set = ((5 * ps + q) & 1) ? P.o_W : P.o_G, opar = d.par[ps];
+                        const int set = (sw_code<SP>((4 * RD + ps) * 5, q) >> 8) ? P.o_W : P.o_G, opar = d.par[ps];
                         lim[ps] = act ? d.w0[ps] >> 16 : 0;
                         base[ps] = set + (d.w0[ps] & 0xFFFF);
                         const double pv = S[set + (opar >= 0 ? opar : 0) + 4 * r + c];
@@ -892,7 +901,7 @@ struct Core {
         if (on) TG_FOR(i, P.nq) S[P.o_dq + i] = (S[P.o_q2 + i] - S[P.o_q1 + i]) / dt;
         TG_SYNC();
         TG_STAMP(0);
-        pose_sweep_dual(on);
+        pose_sweep_dual(on, true);
         TG_STAMP(1);
         oGc = P.o_W;
         attach_points(on, true, true);            // bodies from the midpoint poses, end points from the q2 poses
@@ -971,7 +980,7 @@ struct Core {
             TG_SYNC();
         }
         TG_STAMP(0);
-        pose_sweep_dual(on);
+        pose_sweep_dual(on, true);
         TG_STAMP(1);
         const double *G = S + P.o_G, *G2 = S + P.o_W;
         // ---- body poses (midpoint) and constraint end points (q2 poses): attach_points ----
@@ -2472,7 +2481,7 @@ struct Core {
             if (dual_ok()) {      // the q1 and the q2 poses in one fused sweep (second set in the W area, dead until the midpoint evaluation)
                 if (w0) {
                     dsA = 1; dsB = 2;
-                    pose_sweep_dual(on);
+                    pose_sweep_dual(on, false);
                     dsA = 0;
                     attach_points(on, false, true);
                     constraints(on, 1, false, Dh1, nq);

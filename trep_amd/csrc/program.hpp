@@ -154,6 +154,13 @@ struct DevProg {
     int sw_ok, sw_maxlen;
     int sw_np[4];
     int sw_len[16];
+    int sw_inst[80];          // instance q of pass p of round r, [(4 r + p) * 5 + q]: chain slot | pose set << 8 | 1 << 9 (0: none)
+    // the (pose set, joint) items the ROLLOUT's dual sweep needs -- midpoint poses of the joints that carry a body, q2 poses of the joints
+    // on the way to a constraint end point -- rotary ones first: config | kind << 12 | joint << 16 | pose set << 28 (sj_list), n_sj of them,
+    // the first n_sj_rot rotary
+    int n_sj, n_sj_rot;
+    const int *sj_list;
+    const int *sj_full;       // the same for EVERY joint in both pose sets (2 n_joints items, the first 2 x rotary ones rotary): the derivative kernels' dual sweep
     int max_cfg_items;        // most items any dynamic config has (= bodies below it): trip count of the specialised residual sum
     int bbd_ok, bbd_g, bbd_ng, bbd_nb, bbd_t, o_bbd;
     int bbd_tvar[16];         // image index of trailing variable i
@@ -166,7 +173,7 @@ struct HostProgram {
     std::vector<double> j_pre;
     std::vector<int> b_anchor;
     std::vector<double> b_C, b_inertia;
-    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4, tri4, cpair4, it_pack, dh_pack, cpath_off, cpath_items, dh_pos, tchunk, tri_off, dhr_pack, at_i, ae_i;
+    std::vector<int> b_item_off, b_pair_off, it_body, it_joint, it_cfg, pair_a, pair_b, cfg_item_off, cfg_items, it_slot, pair4, tri4, cpair4, it_pack, dh_pack, cpath_off, cpath_items, dh_pos, tchunk, tri_off, dhr_pack, at_i, ae_i, sj_list, sj_full;
     std::vector<int> wp_a, wp_b, wt_a, wt_b, wt_split, wcp4;
     std::vector<int> e_anchor;
     std::vector<double> e_off;
@@ -605,20 +612,47 @@ inline HostProgram build_program(const tg_system_desc *d) {
         for (int r = 0; r < P.n_rounds; r++) if (H.round_off[r + 1] - H.round_off[r] > 8) P.sched_ok = 1;
     }
     P.o_sched = take(P.sched_ok ? 16 * P.n_rounds : 0);   // two ints per (round, slot)
+    std::vector<int> pose_need(nj, 0);      // bit 0: the midpoint pose of joint j is read (a body hangs below it), bit 1: its q2 pose (a constraint end point does)
+    for (int k : H.it_joint) pose_need[k] |= 1;
+    for (int e : H.e_anchor) for (int k = e; k >= 0; k = H.j_parent[k]) pose_need[k] |= 2;
+    for (int k = nj - 1; k >= 0; k--) if (H.j_parent[k] >= 0) pose_need[H.j_parent[k]] |= pose_need[k];      // (ancestors: they are, by construction; kept explicit)
+    for (int rot = 1; rot >= 0; rot--)
+        for (int set = 0; set < 2; set++)
+            for (int k = 0; k < nj; k++)
+                if (((H.j_kind[k] >= TG_RX) ? 1 : 0) == rot && (pose_need[k] >> set & 1))
+                    H.sj_list.push_back(H.j_cfg[k] | (H.j_kind[k] << 12) | (k << 16) | (set << 28));
+    for (int rot = 1; rot >= 0; rot--)
+        for (int set = 0; set < 2; set++)
+            for (int k = 0; k < nj; k++)
+                if (((H.j_kind[k] >= TG_RX) ? 1 : 0) == rot) H.sj_full.push_back(H.j_cfg[k] | (H.j_kind[k] << 12) | (k << 16) | (set << 28));
+    if (H.sj_full.empty()) H.sj_full.push_back(0);
+    P.n_sj = (int)H.sj_list.size();
+    P.n_sj_rot = 0;
+    for (int w : H.sj_list) P.n_sj_rot += (((w >> 12) & 0xF) >= TG_RX) ? 1 : 0;
+    if (H.sj_list.empty()) H.sj_list.push_back(0);
     {   // quad-lane sweep plan: at most four rounds of at most four passes, at most 16 chain steps' worth of local-transform columns
-        // in registers per round
+        // in registers per round.  An instance is one chain of one pose set; only the needed ones (pose_need of the chain's first joint)
         P.sw_ok = (P.sched_ok && P.n_rounds >= 1 && P.n_rounds <= 4) ? 1 : 0;
         P.sw_maxlen = 0;
         for (int i = 0; i < 4; i++) P.sw_np[i] = 0;
         for (int i = 0; i < 16; i++) P.sw_len[i] = 0;
+        for (int i = 0; i < 80; i++) P.sw_inst[i] = 0;
         for (int r = 0; r < P.n_rounds && P.sw_ok; r++) {
-            const int nch = H.round_off[r + 1] - H.round_off[r], np = (2 * nch + 4) / 5;
-            if (np > 4) { P.sw_ok = 0; break; }
+            const int nch = H.round_off[r + 1] - H.round_off[r];
+            std::vector<int> inst;
+            for (int slot = 0; slot < nch; slot++)
+                for (int set = 0; set < 2; set++)
+                    if (pose_need[H.ch_first[H.round_off[r] + slot]] >> set & 1) inst.push_back(slot | (set << 8) | (1 << 9));
+            const int np = ((int)inst.size() + 4) / 5;
+            if (np > 4 || nch > 15) { P.sw_ok = 0; break; }      // (slot 15 of a round stays empty: what a lane without an instance reads)
             P.sw_np[r] = np;
             int total = 0;
             for (int p = 0; p < np; p++) {
                 int len = 0;
-                for (int q = 0; q < 5; q++) { const int slot = (5 * p + q) >> 1; if (slot < nch) len = std::max(len, H.ch_len[H.round_off[r] + slot]); }
+                for (int q = 0; q < 5 && 5 * p + q < (int)inst.size(); q++) {
+                    P.sw_inst[(4 * r + p) * 5 + q] = inst[5 * p + q];
+                    len = std::max(len, H.ch_len[H.round_off[r] + (inst[5 * p + q] & 0xFF)]);
+                }
                 P.sw_len[4 * r + p] = len; total += len;
                 P.sw_maxlen = std::max(P.sw_maxlen, len);
             }
@@ -844,7 +878,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
     X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in) X(wr_kind) X(ncs_i) \
-    X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4) X(bbd_tab) X(cmp_rep) X(cmp_grp) X(cmp_goff) X(cmp_gbody) X(cmp_pair) X(dhr_pack) X(at_i) X(ae_i)
+    X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4) X(bbd_tab) X(cmp_rep) X(cmp_grp) X(cmp_goff) X(cmp_gbody) X(cmp_pair) X(dhr_pack) X(at_i) X(ae_i) X(sj_list) X(sj_full)
 #define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(j_prm) X(at_d) X(ae_d) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c) X(wr_Rloc) X(ncs_mb) X(ncs_tab)
 
 inline void HostProgram::pack() {
