@@ -394,6 +394,10 @@ struct Core {
     int sc_rot2 = 0;   // number of (pose set, rotary joint) items of the dual sin/cos pass: they come first in the lane order
     int sj_n = 0;      // number of (pose set, joint) items of that pass (init_sweep_schedule)
     bool sj_quads = false;   // the quad-lane chain rounds follow the rollout's instance plan (sw_inst): rollout kernels only
+    // quad-lane chain rounds, constants of the lane for the whole kernel (init_sweep_schedule): the instance it carries in pass p of round r
+    // (swc[4 r + p]: chain slot | pose set << 8; slot 15 = none) and its place in the instance (entry (swr, swc_) of the 3 x 4 pose)
+    int swc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, swr = 0, swcol = 0;
+    bool swact = false;
     double tdamp = 0.0;
     long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool rates_ready = false;      // o_dq already holds (q2 - q1) / dt when eval_both_tab starts
@@ -476,6 +480,17 @@ struct Core {
             if (rollout) sc_rot2 = P.n_sj_rot;
             else { int n_rot = 0; for (int j = 0; j < P.n_joints; j++) n_rot += P.j_kind[j] >= TG_RX ? 1 : 0; sc_rot2 = 2 * n_rot; }
             sj_quads = rollout;
+            if constexpr (tg_static_sweep<typename std::remove_cv<PROG>::type>::value) {
+                typedef typename std::remove_cv<PROG>::type SP;
+                if (rollout) {
+                    const int l = tg_opaque(lane);
+                    swact = l < 60;
+                    const int q = swact ? l / 12 : 4, rc = swact ? l - 12 * q : 0;
+                    swr = rc >> 2; swcol = rc & 3;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) swc[i] = (i & 3) < SP::sw_np[i >> 2] ? sw_code<SP>(i * 5, q) : 15;
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int pos = lane + u * TEAM;
@@ -616,14 +631,8 @@ struct Core {
 #if !defined(TG_NO_QUAD_SWEEP)
         // quad-lane chain rounds (chain_round_quads): the lane's instance of every pass of the first round, requested a phase ahead
         SwDesc sw0;
-        int swq = 4, swrc = 0;
-        bool swact = false;
         if constexpr (tg_static_sweep<typename std::remove_cv<PROG>::type>::value) {
-            if (rollout_lists) {
-                const int l = tg_opaque(lane);
-                swact = l < 60; swq = swact ? l / 12 : 4; swrc = swact ? l - 12 * swq : 0;
-                sw0 = sw_fetch<typename std::remove_cv<PROG>::type, 0>((const int *)(S + P.o_sched), swq);
-            }
+            if (rollout_lists) sw0 = sw_fetch<typename std::remove_cv<PROG>::type, 0>((const int *)(S + P.o_sched));
         }
 #endif
         if (P.tab_ok) {
@@ -728,7 +737,7 @@ struct Core {
         if constexpr (tg_static_sweep<typename std::remove_cv<PROG>::type>::value) {
             if (rollout_lists) {     // (the instance plan lists the chains the ROLLOUT reads; the derivative kernels sweep every chain below)
                 typedef typename std::remove_cv<PROG>::type SP;
-                chain_round_quads<SP, 0>(on, sched, sw0, swq, swrc >> 2, swrc & 3, swact);
+                chain_round_quads<SP, 0>(on, sched, sw0);
                 return;
             }
         }
@@ -830,13 +839,13 @@ struct Core {
         auto w = [&](int i) { const int c = SP::sw_inst[base + i]; return c ? (c & 0x1FF) : 15; };
         return q == 0 ? w(0) : q == 1 ? w(1) : q == 2 ? w(2) : q == 3 ? w(3) : w(4);
     }
-    template <class SP, int RD> TG_HD SwDesc sw_fetch(const int *sched, int q) const {
+    template <class SP, int RD> TG_HD SwDesc sw_fetch(const int *sched) const {
         SwDesc d;
 #pragma unroll
         for (int ps = 0; ps < 4; ps++) {
             d.w0[ps] = 0; d.par[ps] = -1;
             if (ps < SP::sw_np[RD < 4 ? RD : 0]) {
-                const int slot = sw_code<SP>((4 * RD + ps) * 5, q) & 0xFF;
+                const int slot = swc[4 * (RD < 4 ? RD : 0) + ps] & 0xFF;
                 d.w0[ps] = sched[2 * (16 * RD + slot)]; d.par[ps] = sched[2 * (16 * RD + slot) + 1];
             }
         }
@@ -844,12 +853,14 @@ struct Core {
     }
     // (the round's descriptors arrive fetched -- by the previous round, the first round's by the local-transform pass -- and the next
     // round's are requested before this round's columns: no LDS round trip between "which chain" and "its transforms")
-    template <class SP, int RD> TG_HD void chain_round_quads(bool on, const int *sched, const SwDesc &d, int q, int r, int c, bool act) {
+    template <class SP, int RD> TG_HD void chain_round_quads(bool on, const int *sched, const SwDesc &d) {
         if constexpr (RD < SP::n_rounds) {
             PROG &P = tg_fresh(this->P);
             constexpr int NP = SP::sw_np[RD], ML = SP::sw_maxlen;
             SwDesc nxt = d;
-            if constexpr (RD + 1 < SP::n_rounds) nxt = sw_fetch<SP, RD + 1>(sched, q);
+            if constexpr (RD + 1 < SP::n_rounds) nxt = sw_fetch<SP, RD + 1>(sched);
+            const int r = swr, c = swcol;
+            const bool act = swact;
             if (on) {
                 double m[4][ML][3], p[4];
                 int base[4], lim[4];
@@ -857,7 +868,7 @@ struct Core {
 #pragma unroll
                 for (int ps = 0; ps < 4; ps++) {
                     if (ps < NP) {
-                        const int set = (sw_code<SP>((4 * RD + ps) * 5, q) >> 8) ? P.o_W : P.o_G, opar = d.par[ps];
+                        const int set = (swc[4 * RD + ps] >> 8) ? P.o_W : P.o_G, opar = d.par[ps];
                         lim[ps] = act ? d.w0[ps] >> 16 : 0;
                         base[ps] = set + (d.w0[ps] & 0xFFFF);
                         const double pv = S[set + (opar >= 0 ? opar : 0) + 4 * r + c];
@@ -889,7 +900,7 @@ struct Core {
                 }
             }
             TG_SYNC();
-            chain_round_quads<SP, RD + 1>(on, sched, nxt, q, r, c, act);
+            chain_round_quads<SP, RD + 1>(on, sched, nxt);
         }
     }
     // the dual sweep needs the chain schedule in LDS and room for the second pose set in the J / W areas
