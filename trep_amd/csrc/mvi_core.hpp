@@ -175,6 +175,9 @@ template <int K> __device__ __forceinline__ double tg_quad_bcast(double x) {
 // any system-specialised schedule (sizes are static members)
 template <class P, class = void> struct tg_is_spec { static constexpr bool value = false; };
 template <class P> struct tg_is_spec<P, typename std::enable_if<(P::nq >= 0)>::type> { static constexpr bool value = true; };
+// ... whose item areas J and W start on an even double (16-byte LDS accesses of an item's six doubles)
+template <class P, class = void> struct tg_items_aligned { static constexpr bool value = false; };
+template <class P> struct tg_items_aligned<P, typename std::enable_if<(P::nq >= 0)>::type> { static constexpr bool value = (P::o_J % 2 == 0) && (P::o_W % 2 == 0); };
 // ... whose chain schedule has a quad-lane sweep plan (program.hpp, sw_*)
 template <class P, class = void> struct tg_static_sweep { static constexpr bool value = false; };
 template <class P> struct tg_static_sweep<P, typename std::enable_if<(P::sw_ok > 0)>::type> { static constexpr bool value = true; };
@@ -983,7 +986,32 @@ struct Core {
         return t;
     }
 
+    // Six doubles of an item (its Jacobian column J, its W) as three 16-byte LDS accesses where the area starts on an even double (the
+    // specialised kernels check it at compile time): at the items' 48-byte stride a 16-byte access is conflict free, an 8-byte one is
+    // two-way and a ds_read2_b64 pair four times the LDS cycles of the 16-byte read (profiles/r04_lds_conflicts.txt)
+    template <bool VEC> TG_HD static void ld6(const double *p, double (&x)[6]) {
+        if constexpr (VEC) {
+            typedef double tg_d2 __attribute__((ext_vector_type(2)));
+            const tg_d2 *q = reinterpret_cast<const tg_d2 *>(p);
+            const tg_d2 a = q[0], b = q[1], c = q[2];
+            x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y; x[4] = c.x; x[5] = c.y;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 6; r++) x[r] = p[r];
+        }
+    }
+    template <bool VEC> TG_HD static void st6(double *p, const double (&x)[6]) {
+        if constexpr (VEC) {
+            typedef double tg_d2 __attribute__((ext_vector_type(2)));
+            tg_d2 *q = reinterpret_cast<tg_d2 *>(p);
+            q[0] = tg_d2{x[0], x[1]}; q[1] = tg_d2{x[2], x[3]}; q[2] = tg_d2{x[4], x[5]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 6; r++) p[r] = x[r];
+        }
+    }
     TG_HD void eval_both_tab(bool on) {
+        constexpr bool VJ = tg_items_aligned<typename std::remove_cv<PROG>::type>::value;
         PROG &P = tg_fresh(this->P);
         const AttachTab at = fetch_attach();
         if (!rates_ready) {      // (the rollout forms the rates in its step set-up and in the Newton update)
@@ -1100,9 +1128,7 @@ struct Core {
             for (int u = 0; u < 2; u++) {
                 const int i = lane + u * TEAM;
                 if (i < P.n_items) {
-                    double *J = S + P.o_J + 6 * i;
-#pragma unroll
-                    for (int r = 0; r < 6; r++) J[r] = Jv[u][r];
+                    st6<VJ>(S + P.o_J + 6 * i, Jv[u]);
                     S[P.o_dqi + i] = dqv[u];
                 }
             }
@@ -1147,7 +1173,8 @@ struct Core {
                 const int b = it.rec[u][0];
                 const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b;
                 const double *J = S + P.o_J + 6 * i, *Pw = S + P.o_W + 6 * i, *gam = S + P.o_gam + 3 * b;
-                const double Jr[6] = {J[0], J[1], J[2], J[3], J[4], J[5]}, Pp[6] = {Pw[0], Pw[1], Pw[2], Pw[3], Pw[4], Pw[5]};
+                double Jr[6], Pp[6];
+                ld6<VJ>(J, Jr); ld6<VJ>(Pw, Pp);
                 bracket(Pp, Jr, Wv[u]);
                 ta[u] = inner6(I, Jr, v);
                 tb[u] = inner6(I, Wv[u], v) + I[0] * (gam[0] * Jr[0] + gam[1] * Jr[1] + gam[2] * Jr[2]);
@@ -1156,9 +1183,7 @@ struct Core {
             for (int u = 0; u < 2; u++) {
                 if (lane + u * TEAM < P.n_items) {
                     const int slot = it.rec[u][3] >> 16; terms[2 * slot] = ta[u]; terms[2 * slot + 1] = tb[u];
-                    double *W = S + P.o_W + 6 * (lane + u * TEAM);
-#pragma unroll
-                    for (int r = 0; r < 6; r++) W[r] = Wv[u][r];
+                    st6<VJ>(S + P.o_W + 6 * (lane + u * TEAM), Wv[u]);
                 }
             }
         }
@@ -1463,7 +1488,11 @@ struct Core {
         // scratch: per-body world entries BW in the dead joint-pose area of the union (the body poses next to it are still needed; the whole
         // union becomes the matrix image two phases on); composites, world twists and per-config vectors in the J / W area
         double *A = S + P.o_Df, *CMP = S + P.o_cmp, *SW = S + P.o_csw, *CZ = S + P.o_ccz, *BW = S + P.o_sc;
-        static_assert(16 * NB <= SP::o_gB - SP::o_sc, "newton_matrix_composite: body entries do not fit the dead pose area");
+        // record strides: 17 doubles per body (16 put every second body on the same LDS banks); the twists keep 12 per config -- 13 would be
+        // conflict free (profiles/r04_lds_conflicts.txt) but turns the pair lanes' six 16-byte reads of a twist pair into twelve 8-byte ones:
+        // measured slower (37.3 against 36.6 ms)
+        constexpr int BWS = 17, SWS = 12;
+        static_assert(BWS * NB <= SP::o_gB - SP::o_sc, "newton_matrix_composite: body entries do not fit the dead pose area");
         const int *rep = (const int *)(S + P.o_cmpt);
         // ---- phase A.  (i) lane (body b, axis r): the body's world entries -- M, C_r = m p_r, row r of D = R I R' + m (|p|^2 1 - p p'),
         //      f_r = (R m v_B)_r, tau_r = (R I w_B)_r + (p x f)_r -- written straight to BW (nothing there is read in this phase);
@@ -1480,7 +1509,7 @@ struct Core {
             }
             const double tx = t[0] + (py * f[2] - pz * f[1]), ty = t[1] + (pz * f[0] - px * f[2]), tz = t[2] + (px * f[1] - py * f[0]);
             const double p2 = px * px + py * py + pz * pz;
-            double *o = BW + 16 * b;
+            double *o = BW + BWS * b;
             if (r == 0) o[0] = m;
             o[1 + r] = m * pr;
             // D row r, columns j >= r: entries 4 + (xx xy xz | yy yz | zz)
@@ -1522,14 +1551,14 @@ struct Core {
         // ---- phase B: twists to SW; composites of the subtree groups (lane = entry; membership is compile-time) to CMP
         if (on && lane < nd) {
 #pragma unroll
-            for (int r = 0; r < 12; r++) SW[12 * lane + r] = sw[r];
+            for (int r = 0; r < 12; r++) SW[SWS * lane + r] = sw[r];
         }
         if (on && lane < 16) {
 #pragma unroll
             for (int g = 0; g < NG; g++) {
                 double acc = 0.0;
 #pragma unroll
-                for (int b = 0; b < NB; b++) if ((P.cmp_gmask[g] >> b) & 1) acc += BW[16 * b + lane];
+                for (int b = 0; b < NB; b++) if ((P.cmp_gmask[g] >> b) & 1) acc += BW[BWS * b + lane];
                 CMP[16 * g + lane] = acc;
             }
         }
@@ -1547,7 +1576,7 @@ struct Core {
             const double *c = CMP + 16 * (rep[lane] >> 20);
             const double M = c[0], Cx = c[1], Cy = c[2], Cz = c[3], Dxx = c[4], Dxy = c[5], Dxz = c[6], Dyy = c[7], Dyz = c[8], Dzz = c[9];
             const double h0 = c[10], h1 = c[11], h2 = c[12], h3 = c[13], h4 = c[14], h5 = c[15];
-            const double *s = SW + 12 * lane, *w = s + 6;
+            const double *s = SW + SWS * lane, *w = s + 6;
             auto apply = [&](const double *x, double *y) {      // spatial inertia times twist
                 y[0] = M * x[0] - (Cy * x[5] - Cz * x[4]); y[1] = M * x[1] - (Cz * x[3] - Cx * x[5]); y[2] = M * x[2] - (Cx * x[4] - Cy * x[3]);
                 y[3] = (Cy * x[2] - Cz * x[1]) + Dxx * x[3] + Dxy * x[4] + Dxz * x[5];
@@ -1586,7 +1615,7 @@ struct Core {
         for (int u = 0; u < TP; u++) {
             if (on && lane + u * TEAM < NP) {
                 const int a = prec[u] & 0xFFFF, b = prec[u] >> 16;
-                const double *sa = SW + 12 * a, *wa = sa + 6, *Is = CZ + 15 * b, *Z = Is + 6, *GG = Is + 12;
+                const double *sa = SW + SWS * a, *wa = sa + 6, *Is = CZ + 15 * b, *Z = Is + 6, *GG = Is + 12;
                 double s_[6], w_[6], i_[6], z_[6];
 #pragma unroll
                 for (int r = 0; r < 6; r++) { s_[r] = sa[r]; w_[r] = wa[r]; i_[r] = Is[r]; z_[r] = Z[r]; }

@@ -590,6 +590,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.dh_ld = 0;
     P.o_q1 = take(nq); P.o_q2 = take(nq); P.o_p1 = take(nd); P.o_lam = take(nc); P.o_u = take(P.nu); P.o_dq = take(nq);
     P.o_f = take(P.nf);
+    off = (off + 1) & ~1;     // J and W on an even double: 16-byte LDS accesses of an item's six doubles (mvi_core.hpp, ld6 / st6)
     P.o_J = take(6 * nitems); P.o_W = take(6 * nitems); P.o_vB = take(6 * nb); P.o_gam = take(3 * nb);
     P.o_Ldq = take(nd); P.o_Lddq = take(nd); P.o_Dh1 = take(P.n_dh); P.o_Dh2 = take(P.n_dh);  // compact: one value per (constraint, dependent config) item
     P.o_scal = take(P.nf); P.o_misc = take(2); P.o_nu = take(P.nu + P.nk);
@@ -818,7 +819,7 @@ inline HostProgram build_program(const tg_system_desc *d) {
         }
         const int need = 16 * (int)group_of.size() + 27 * nd;                      // J / W area
         if (all_rep && nd >= 8 && nd <= 64 && nb <= 32 && group_of.size() <= 32 && from_pairs == from_cmp && need <= 12 * nitems && nitems < 4096 &&
-            16 * nb <= 2 * nj + std::max(12 * nj, 2 * nitems)) {      // (the per-body entries: sin / cos + joint-pose area, dead by then)
+            17 * nb <= 2 * nj + std::max(12 * nj, 2 * nitems)) {      // (the per-body entries, 17 doubles apart: sin / cos + joint-pose area, dead by then)
             P.cmp_ok = 1; P.n_cgroups = (int)group_of.size(); P.n_cmpairs = (int)H.cmp_pair.size();
             P.o_cmp = P.o_J; P.o_csw = P.o_cmp + 16 * P.n_cgroups; P.o_ccz = P.o_csw + 12 * nd;
             for (auto &g : group_of) for (int b : g.first) P.cmp_gmask[g.second] |= 1 << b;
