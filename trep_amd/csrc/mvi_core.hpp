@@ -98,6 +98,9 @@ __device__ __forceinline__ int tg_opaque(int x) { asm volatile("" : "+v"(x)); re
 #else
 inline int tg_opaque(int x) { return x; }
 #endif
+#ifndef TG_PREFIX_GROUP
+#define TG_PREFIX_GROUP 5
+#endif
 #ifndef TG_LT_TRIPS
 #define TG_LT_TRIPS 4
 #endif
@@ -1145,15 +1148,16 @@ struct Core {
             const int m = lane % 6;
             const int first = bio[0], last = bio[1];
             double acc = 0.0;
-            for (int k = first; k < last; k += 4) {
-                double jv[4], dv[4];
+            constexpr int PG = TG_PREFIX_GROUP;     // items whose operands are requested together
+            for (int k = first; k < last; k += PG) {
+                double jv[PG], dv[PG];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < PG; u++) {
                     const int kk = k + u < last ? k + u : last - 1;
                     jv[u] = S[P.o_J + 6 * kk + m]; dv[u] = S[P.o_dqi + kk];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < PG; u++) {
                     if (k + u < last) { S[P.o_W + 6 * (k + u) + m] = acc; acc = fma(jv[u], dv[u], acc); }
                 }
             }
