@@ -51,7 +51,7 @@ def build_secondary(args, rank):
         system = systems.puppet_basic()
         ics = np.load(os.path.join(ROOT, "tests", "golden", "puppet_basic.npz"))["ic_set"]
         Q0 = np.tile(np.roll(ics, rank, axis=0), ((B + len(ics) - 1) // len(ics), 1))[:B]
-        return system, Q0, None, None, dt
+        return system, Q0, None, None, dt      # only len(ics) = 16 DISTINCT poses: reported as such (distinct_initial_conditions)
     system = systems.scissor_lift(4)
     rng = np.random.default_rng(20250 + 5 + 1000 * rank)
     th = rng.uniform(0.03 * np.pi, 0.12 * np.pi, B)
@@ -241,7 +241,7 @@ def dry_run_rank(args, world, rank):
     shard arithmetic -- and nothing else.  Used by the CPU test of the self-launcher (no GPU, no RCCL)."""
     import hashlib
     from trep_amd import rccl
-    from trep_amd.distributed import shard_bounds
+    from trep_amd.distributed import shard_bounds, padded_rows
     blob, path = rccl.exchange_unique_id(rank, world, lambda: os.urandom(rccl.ID_BYTES), timeout=60.0)
     digest = hashlib.sha256(blob).hexdigest()[:16]
     mine = "%s.rank%d" % (path, rank)
@@ -374,7 +374,7 @@ def main():
         _oracle.build()
     import trep_amd  # noqa: F401
 
-    from trep_amd.distributed import shard_bounds
+    from trep_amd.distributed import shard_bounds, padded_rows
     N = args.rollout_steps
     U = None
     if args.system == "puppet":
@@ -398,7 +398,7 @@ def main():
     def shard_of_global():    # this rank's slice of ONE global batch of --batch trajectories (strong scaling)
         lo, hi = shard_bounds(B, rank, world)
         return (Q0[lo:hi], None if U is None else U[lo:hi], None if K is None else K[lo:hi], hi - lo,
-                shard_bounds(B, 0, world)[1])
+                padded_rows(B, world))
 
     modes = [args.scaling] + ([("strong" if args.scaling == "weak" else "weak")] if world > 1 else [])
     results = {}
@@ -444,7 +444,7 @@ def main():
                                    ", batch=%d rollouts %s x %d DEL steps, dt=0.01" % (B, "per GPU" if args.scaling == "weak" else "in total", N),
                        "global_batch": global_batch, "rollout_steps": N, "parallelism": "batch-shard x%d" % world,
                        "collective": "RCCL all-gather of terminal states (C ABI tg_comm_*, no torch)" if comm is not None else None,
-                       "distinct_initial_conditions": global_batch,
+                       "distinct_initial_conditions": int(len(np.unique(np.ascontiguousarray(Q0), axis=0))) * (world if args.scaling == "weak" and args.system != "puppet-basic" else 1),
                        "team": r["info"]["team"], "lds_bytes_per_trajectory": r["info"]["lds_bytes_per_trajectory"],
                        "newton_iterations_per_step": r["newton_iterations"] / float(b_local * N), "failed_trajectories": r["failed"],
                        "writes_X": not args.no_x, "newton_initial_guess": args.predictor,
@@ -494,11 +494,20 @@ def main():
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         missing = [k for k in expected_line_keys(args, world) if k not in out]
-        assert not missing, "bench.py line lacks %s" % missing
+        if missing:       # the measured line is printed whatever the self-check says; the ranks still meet at the barrier below
+            out["line_self_check"] = "missing keys: %s" % missing
+            sys.stderr.write("bench.py: line lacks %s\n" % missing)
         print(json.dumps(out))
+        sys.stdout.flush()
+    else:
+        missing = []
     if comm is not None:
-        comm.barrier()
-        comm.close()
+        try:
+            comm.barrier()
+        finally:
+            comm.close()
+    if missing:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

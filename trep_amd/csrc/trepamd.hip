@@ -1159,17 +1159,21 @@ int tg_batch_debug_newton_solve(tg_batch *b, int32_t n_mats, int32_t skip_struct
     const int nf = b->P.nf;
     HIP_TRY(hipSetDevice(b->device));
     double *dA = nullptr, *dx = nullptr; int *dp = nullptr;
-    HIP_TRY(hipMalloc(&dA, sizeof(double) * (size_t)n_mats * nf * (nf + 1))); HIP_TRY(hipMalloc(&dx, sizeof(double) * (size_t)n_mats * nf));
-    HIP_TRY(hipMalloc(&dp, sizeof(int) * (size_t)n_mats));
-    HIP_TRY(hipMemcpy(dA, A_aug_host, sizeof(double) * (size_t)n_mats * nf * (nf + 1), hipMemcpyHostToDevice));
-    const int rc = fn(dA, dx, dp, n_mats, skip_structured);
-    hipError_t e = hipDeviceSynchronize();
-    if (rc == 0 && e == hipSuccess) {
-        hipMemcpy(x_host, dx, sizeof(double) * (size_t)n_mats * nf, hipMemcpyDeviceToHost);
-        hipMemcpy(path_host, dp, sizeof(int) * (size_t)n_mats, hipMemcpyDeviceToHost);
+    const size_t nA = sizeof(double) * (size_t)n_mats * nf * (nf + 1), nx = sizeof(double) * (size_t)n_mats * nf, np = sizeof(int) * (size_t)n_mats;
+    const char *what = nullptr;         /* one exit: whatever was allocated is freed on every path */
+    int rc = 0;
+    if (hipMalloc(&dA, nA) != hipSuccess || hipMalloc(&dx, nx) != hipSuccess || hipMalloc(&dp, np) != hipSuccess) what = "solve hook: device allocation failed";
+    if (!what && hipMemcpy(dA, A_aug_host, nA, hipMemcpyHostToDevice) != hipSuccess) what = "solve hook: upload failed";
+    if (!what) {
+        rc = fn(dA, dx, dp, n_mats, skip_structured);
+        if (hipDeviceSynchronize() != hipSuccess || rc != 0) what = "solve hook launch failed";
     }
-    hipFree(dA); hipFree(dx); hipFree(dp);
-    if (rc != 0 || e != hipSuccess) return fail(TG_ERR_HIP, "solve hook launch failed");
+    if (!what && (hipMemcpy(x_host, dx, nx, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(path_host, dp, np, hipMemcpyDeviceToHost) != hipSuccess))
+        what = "solve hook: download failed";
+    if (dA) hipFree(dA);
+    if (dx) hipFree(dx);
+    if (dp) hipFree(dp);
+    if (what) { (void)hipGetLastError(); return fail(TG_ERR_HIP, what); }
     return TG_SUCCESS;
 }
 

@@ -58,6 +58,16 @@ class _DeviceArray(object):
             _lib.check(self.pool.L.tg_memcpy_d2h(self.pool.device, out.ctypes.data, self.ptr, self.nbytes))
         return out
 
+    def get_block(self, index):
+        """One leading-index block (e.g. A[s, k]) without downloading the whole array."""
+        index = tuple(int(i) for i in index)
+        sub = self.shape[len(index):]
+        out = np.zeros(sub, dtype=self.dtype)
+        flat = int(np.ravel_multi_index(index, self.shape[:len(index)])) * out.nbytes
+        if out.nbytes:
+            _lib.check(self.pool.L.tg_memcpy_d2h(self.pool.device, out.ctypes.data, int(self.ptr) + flat, out.nbytes))
+        return out
+
 
 class _DevicePool(object):
     def __init__(self, device):
@@ -124,6 +134,7 @@ class BatchDOptimizer(object):
         # block structure of DSystem.fdx / fdu (dsystem.py:284-317) for the LQ sweeps: TREPAMD_LQ_DENSE=1 runs them dense
         nd_, nk_ = len(sysm.dyn_configs), len(sysm.kin_configs)
         self._ds = (nd_, nk_, nU - nk_) if (2 * (nd_ + nk_) == nX and os.environ.get("TREPAMD_LQ_DENSE", "0") != "1") else (0, 0, 0)
+        self._ds_checked = False          # the skipped blocks of A_k / B_k are looked at once, after the first linearisation
         # engines: horizon batch (one trajectory per (seed, step)) and candidate batch
         if armijo_chunk is None:   # fill the GPU once (256 CUs x 8 wavefronts) but never more than the search needs
             armijo_chunk = int(min(self.armijo_max_iterations, max(1, 2048 // S)))
@@ -207,9 +218,38 @@ class BatchDOptimizer(object):
         self._check(self.L.tg_batch_set_from_trajectories(self.lin._h, self.S, self.N, self.t0, self.dt, self.X.ptr, self.U.ptr, 200))
         _, status = self.lin.status()
         self._check(self.L.tg_batch_linearize(self.lin._h, self.A.ptr, self.B.ptr))
+        if self._ds[0] and not self._ds_checked:
+            self._check_ds_structure()
         # per seed: a seed with a failed DEL solve anywhere along its horizon has no linearisation (the reference raises
         # ConvergenceError out of DSystem.set for that one problem); the other seeds are unaffected
         return (status.reshape(self.S, self.N) != 0).any(axis=1)
+
+    def _check_ds_structure(self):
+        """One-off (first linearisation): the structured LQ sweep skips A's Qk rows / v columns and B's single-entry rows on the promise
+        that they hold EXACT zeros (tg_lq_problem::ds_*).  The promise is the linearisation kernel's; this looks at three (seed, step)
+        blocks and falls back to the dense sweep -- loudly -- if it is ever broken (TREPAMD_LQ_DENSE=1 is the manual override)."""
+        nd, nk, nu = self._ds
+        nq, nX = nd + nk, self.nX
+        ok = True
+        for s, k in {(0, 0), (self.S - 1, self.N - 1), (self.S // 2, self.N // 2)}:
+            A, B = self.A.get_block((s, k)), self.B.get_block((s, k))
+            rows_qk, rows_v = slice(nd, nq), slice(nq + nd, nX)
+            skipA = A.copy()
+            skipA[:nd, :nq + nd] = 0.0
+            skipA[nq:nq + nd, :nq + nd] = 0.0                      # dense Qd and p rows over the [Q, p] columns
+            skipA[rows_v, nd:nq] -= np.diag(np.diag(A[rows_v, nd:nq]))  # a v row holds one entry: its Qk column
+            skipB = B.copy()
+            skipB[:nd] = 0.0
+            skipB[nq:nq + nd] = 0.0                                # dense Qd and p rows
+            skipB[rows_qk, nu:] -= np.diag(np.diag(B[rows_qk, nu:]))    # Qk and v rows: one entry each, their rho column
+            skipB[rows_v, nu:] -= np.diag(np.diag(B[rows_v, nu:]))
+            ok = ok and not skipA.any() and not skipB.any()
+        self._ds_checked = True
+        if not ok:
+            import warnings
+            warnings.warn("BatchDOptimizer: A_k / B_k do not have the DSystem block structure the structured LQ sweep assumes; "
+                          "using the dense sweep")
+            self._ds = (0, 0, 0)
 
     def _lq(self, seeds, Q, Qf, R, hz, affine, K, C=None, status=None, collect=True, b_next=None):
         sel, n = self._select(seeds)

@@ -114,3 +114,27 @@ def build(system, force=False, verbose=False):
 
 def is_built(system):
     return os.path.exists(library_path(system)[0])
+
+
+def prune(systems_to_keep, verbose=False):
+    """Remove every cached specialisation (library + header) under ``trep_amd/_spec/`` whose key none of `systems_to_keep` produces with
+    the current sources and flags: a source edit changes every key, and the stale libraries would otherwise travel with the package
+    (they are harmless -- ``tg_batch_load_specialized`` checks the key -- but they were 23 MB at the end of round 4).  Returns the
+    removed file names."""
+    if not os.path.isdir(CACHE):
+        return []
+    keep = set()
+    for system in systems_to_keep:
+        base = os.path.basename(library_path(system)[0])[:-3]
+        keep.update((base + ".so", base + ".hpp"))
+    gone = []
+    for name in sorted(os.listdir(CACHE)):
+        if name not in keep and ".tmp" not in name:
+            try:
+                os.remove(os.path.join(CACHE, name))
+                gone.append(name)
+            except OSError:
+                pass
+    if verbose:
+        print("specialize.prune: removed %d stale files, kept %d" % (len(gone), len(keep)))
+    return gone
