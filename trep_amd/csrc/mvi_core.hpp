@@ -192,6 +192,12 @@ template <class P> struct tg_static_sweep<P, typename std::enable_if<(P::sw_ok >
 template <class P, class = void> struct tg_static_cmp { static constexpr bool value = false; };
 template <class P> struct tg_static_cmp<P, typename std::enable_if<(P::cmp_ok >= 0)>::type> { static constexpr bool value = P::cmp_ok != 0 && P::tab_ok != 0; };
 
+// ... and the world-frame evaluation of the rollout's residual (program.hpp, wev_*; -DTG_NO_WEV keeps the (body, config) item phases)
+template <class P, class = void> struct tg_static_wev { static constexpr bool value = false; };
+#if !defined(TG_NO_WEV) && !defined(TG_NO_CMP)
+template <class P> struct tg_static_wev<P, typename std::enable_if<(P::wev_ok >= 0)>::type> { static constexpr bool value = P::wev_ok != 0 && P::cmp_ok != 0 && P::tab_ok != 0; };
+#endif
+
 enum { MODE_ROLLOUT = 0, MODE_CALC_P2 = 1, MODE_CALC_F = 2, MODE_DERIV1 = 3, MODE_DERIV2Z = 4, MODE_DYNAMICS = 5, MODE_DYN_DERIV1 = 6, MODE_ENERGY = 7, MODE_LAGRANGIAN = 8 };
 
 struct RunArgs {
@@ -409,6 +415,11 @@ struct Core {
     int swc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, swr = 0, swcol = 0;
     bool swact = false;
     double tdamp = 0.0;
+    // world-frame evaluation (eval_world): the lane's row of P.wev_lane and its config-pair records, constants of the lane for the whole
+    // kernel; w_k = [V_k^-, s_k] of the lane's config between the evaluation and the Newton matrix
+    int wvl[4] = {0, 0, 0, 0}, wpair[4] = {0, 0, 0, 0};
+    double wev_w[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    bool wev_on = false;      // the last evaluation was eval_world (rollout kernels): the Newton matrix continues from its LDS / register state
     long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool rates_ready = false;      // o_dq already holds (q2 - q1) / dt when eval_both_tab starts
     double res_f2 = 0.0;           // eval_both_tab: square of the residual entry this lane formed (0 past nd) ...
@@ -512,6 +523,16 @@ struct Core {
             const int b = lane < 6 * P.n_bodies ? lane / 6 : 0;
             bio[0] = P.b_item_off[b]; bio[1] = P.b_item_off[b + 1];
             tdamp = P.damp[lane < P.nd ? lane : 0];
+            if constexpr (tg_static_wev<typename std::remove_cv<PROG>::type>::value) {
+                typedef typename std::remove_cv<PROG>::type SP;
+                static_assert((SP::n_cmpairs + TEAM - 1) / TEAM <= 4, "eval_world: at most four trips of config pairs");
+                if (rollout) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) wvl[i] = P.wev_lane[4 * lane + i];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) wpair[u] = P.cmp_pair[lane + u * TEAM < SP::n_cmpairs ? lane + u * TEAM : 0];
+                }
+            }
             if (P.n_npairs) { const int *p0 = P.pair4 + 4 * (size_t)(lane < P.n_npairs ? lane : 0); tpair[0] = p0[0]; tpair[1] = p0[1]; tpair[2] = p0[2]; tpair[3] = p0[3]; }
         }
 #endif
@@ -1242,6 +1263,231 @@ struct Core {
         if (P.nd > 48) norm2 += tg_readlane_f64(v, 63);
         return !(norm2 > tolerance * tolerance) && !__any(res_hoff ? 1 : 0);
     }
+
+    // ---- the evaluation of a rollout's Newton iteration in WORLD-frame form (round 5; system-specialised kernels with P.wev_ok) ----
+    // eval_both_tab evaluates the Lagrangian terms of the residual per (body, path config) ITEM (88 for the puppet: two wavefront trips
+    // for the Jacobian columns, a serial prefix sum per body, two trips for the brackets and the inner products, a per-config sum) and the
+    // composite Newton matrix then re-derives world-frame twists and momenta from those body-frame quantities.  The same numbers per CONFIG:
+    //     s_k   world twist of joint k (velocity of the point at the world origin, angular velocity), read off the joint's world pose,
+    //     V_k^- = sum of s_j dq_j over the configs j above k on its path,   w_k = [V_k^-, s_k]   (= Ad(g_F) W_{F,k} for every body F below k),
+    //     H_k   = sum over the bodies F below k of their spatial momentum about the world origin,  (M_k, C_k) their mass and first moment:
+    //     L_ddq_k = s_k . H_k,        L_dq_k = w_k . H_k + g . (M_k v_k + omega_k x C_k)           (system.c:129-202; gravity.c:27-40)
+    // -- the quantities the composite matrix needs anyway (newton_matrix_world takes them from here).  Phases:
+    //   E3  body poses / constraint end points (as attach_points), and lane k < nd: s_k and u_k = s_k dq_k from the midpoint pose of joint k;
+    //   E4  constraint values and Dh2 at q2 (as constraints), and one "sum u over my list" per lane: config lanes get V_k^- and form w_k
+    //       (kept in registers), lane (body b, axis r) gets the body's world twist and writes its world inertia / momentum entries;
+    //   E5  subtree composites (16 lanes, compile-time membership);
+    //   E6  lane k < nd: L_dq, L_ddq, forces, the residual entry.
+    // Five phases of one trip each instead of eight (three of them two trips); verified against the reference's L_dq / L_ddq in
+    // tools/proto/world_eval.py (1e-16) before it was written here.  The derivative kernels keep the item form (they need J and W).
+    template <int D0, int D1> TG_HD void wev_sum(const double *SW, double (&V)[6]) const {
+        // V += the u-halves of list entries D0 .. D1-1 (padded entries point at the all-zero record): every load before the adds
+        if constexpr (D0 < D1) {
+            double x[D1 - D0][6];
+#pragma unroll
+            for (int d = D0; d < D1; d++) {
+                const int idx = (wvl[d >> 2] >> (8 * (d & 3))) & 0xFF;
+                ld6<true>(SW + 12 * idx + 6, x[d - D0]);
+            }
+#pragma unroll
+            for (int d = D0; d < D1; d++) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) V[r] += x[d - D0][r];
+            }
+        }
+    }
+    TG_HD void eval_world(bool on) {
+        typedef typename std::remove_cv<PROG>::type SP;
+        constexpr int nd = SP::nd, NB = SP::n_bodies, NG = SP::n_cgroups, MAXD = SP::wev_depth;
+        static_assert(TEAM == 64 && nd + 3 * NB <= 64 && nd < 64, "eval_world: one lane per config and per (body, axis)");
+        static_assert((SP::o_csw & 1) == 0 && (SP::o_gB & 1) == 0 && (SP::o_I & 1) == 0 && (SP::o_cmp & 1) == 0, "eval_world: 16-byte LDS accesses");
+        PROG &P = tg_fresh(this->P);
+        const AttachTab at = fetch_attach();
+        if (!rates_ready) {
+            if (on) TG_FOR(i, P.nq) S[P.o_dq + i] = (S[P.o_q2 + i] - S[P.o_q1 + i]) / dt;
+            TG_SYNC();
+        }
+        TG_STAMP(0);
+        pose_sweep_dual(on, true);
+        TG_STAMP(1);
+        const double *G = S + P.o_G, *G2 = S + P.o_W;
+        double *SW = S + P.o_csw, *CMP = S + P.o_cmp, *BW = S + P.o_sc;
+        constexpr int BWS = 17;
+        static_assert(BWS * NB <= SP::o_gB - SP::o_sc, "eval_world: body entries do not fit the dead pose area");
+        // ---- E3: body poses (midpoint), constraint end points (q2 poses), world twists of the configs ----
+        const ConTab ct = fetch_constraints();
+        if (on) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int idx = lane + u * TEAM;
+                if (idx < 12 * P.n_bodies) {
+                    const int e = idx % 12, r = e >> 2, c = e & 3;
+                    const int anchor = at.ga[u];
+                    const double *g = G + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
+                    const double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+                    const double val = g0 * at.c0[u] + g1 * at.c1[u] + g2 * at.c2[u] + (c == 3 ? g3 : 0.0);
+                    S[P.o_gB + idx] = anchor < 0 ? at.ce[u] : val;
+                }
+            }
+            if (lane < 3 * P.n_endpoints) {
+                const int r = lane % 3;
+                const double *g = G2 + 12 * (at.ea < 0 ? 0 : at.ea) + 4 * r;
+                const double val = g[0] * at.o0 + g[1] * at.o1 + g[2] * at.o2 + g[3];
+                S[P.o_pE + lane] = at.ea < 0 ? at.orr : val;
+            }
+            if (lane <= nd) {       // (lane nd writes the all-zero record the padded list entries point at)
+                const bool real = lane < nd;
+                const int oj = real ? wvl[3] & 0xFFFF : 0, kind = real ? (wvl[3] >> 16) & 0xFF : (int)TG_TX;
+                const bool prismatic = kind <= TG_TZ;
+                const int ax = prismatic ? kind - TG_TX : kind - TG_RX;
+                const double *gj = G + oj;
+                const double a0 = gj[ax], a1 = gj[4 + ax], a2 = gj[8 + ax];
+                const double px = gj[3], py = gj[7], pz = gj[11];
+                const double dqk = real ? S[P.o_dq + (real ? lane : 0)] : 0.0;
+                double sv[6], uv[6];
+                // rotary: angular velocity a about the joint's origin p: the point at the world origin moves with a x (0 - p) = p x a
+                sv[0] = prismatic ? a0 : py * a2 - pz * a1; sv[1] = prismatic ? a1 : pz * a0 - px * a2; sv[2] = prismatic ? a2 : px * a1 - py * a0;
+                sv[3] = prismatic ? 0.0 : a0; sv[4] = prismatic ? 0.0 : a1; sv[5] = prismatic ? 0.0 : a2;
+#pragma unroll
+                for (int r = 0; r < 6; r++) { sv[r] = real ? sv[r] : 0.0; uv[r] = sv[r] * dqk; }
+                st6<true>(SW + 12 * lane, sv);
+                st6<true>(SW + 12 * lane + 6, uv);
+            }
+        }
+        TG_SYNC();
+        TG_STAMP(2);
+        // ---- E4: constraint values and Dh2 at q2 (constraints(on, 2, true, Dh2, 0)) ----
+        const ResTab rt = fetch_residual();
+        if (on) {
+            if (lane < P.nc) {
+                const double *a = S + P.o_pE + 3 * ct.e1, *b = S + P.o_pE + 3 * ct.e2;
+                const double vx = a[0] - b[0], vy = a[1] - b[1], vz = a[2] - b[2];
+                double h;
+                if (ct.type == TG_CONSTRAINT_POINT) h = ct.comp == 0 ? vx : (ct.comp == 1 ? vy : vz);
+                else {
+                    const double len = ct.cfg >= 0 ? S[P.o_q2 + (ct.cfg >= 0 ? ct.cfg : 0)] : ct.dist;
+                    h = (vx * vx + vy * vy + vz * vz) - len * len;
+                }
+                S[P.o_f + P.nd + lane] = h;
+                res_hoff = fabs(h) > S[P.o_ctol + lane];
+            } else res_hoff = false;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (u * TEAM < P.n_dhr && lane + u * TEAM < P.n_dhr) {
+                    const int n = ct.rec[u][0];
+                    const int k = ct.rec[u][1], oj = ct.rec[u][2], w = ct.rec[u][3], oe1 = ct.rec[u][4], oe2 = ct.rec[u][5];
+                    const int side = w & 0xFF, kind = (w >> 8) & 0xFF, type = (w >> 16) & 0xFF, comp = w >> 24;
+                    const int ojc = oj < 0 ? 0 : oj;
+                    double d1[3], d2[3];
+                    const double *gj = G2 + ojc;
+                    const bool prismatic = kind <= TG_TZ;
+                    const int ax = prismatic ? kind - TG_TX : kind - TG_RX;
+                    const double wx = gj[ax], wy = gj[4 + ax], wz = gj[8 + ax];
+                    {
+                        const double *pe = S + P.o_pE + oe1;
+                        const double dx = pe[0] - gj[3], dy = pe[1] - gj[7], dz = pe[2] - gj[11];
+                        d1[0] = prismatic ? wx : wy * dz - wz * dy; d1[1] = prismatic ? wy : wz * dx - wx * dz; d1[2] = prismatic ? wz : wx * dy - wy * dx;
+                    }
+                    {
+                        const double *pe = S + P.o_pE + oe2;
+                        const double dx = pe[0] - gj[3], dy = pe[1] - gj[7], dz = pe[2] - gj[11];
+                        d2[0] = prismatic ? wx : wy * dz - wz * dy; d2[1] = prismatic ? wy : wz * dx - wx * dz; d2[2] = prismatic ? wz : wx * dy - wy * dx;
+                    }
+                    const double s1 = (side & 1) ? 1.0 : 0.0, s2 = (side & 2) ? 1.0 : 0.0;
+                    const double dx = s1 * d1[0] - s2 * d2[0], dy = s1 * d1[1] - s2 * d2[1], dz = s1 * d1[2] - s2 * d2[2];
+                    double val;
+                    if (type == TG_CONSTRAINT_POINT) val = comp == 0 ? dx : (comp == 1 ? dy : dz);
+                    else {
+                        const double *a = S + P.o_pE + oe1, *b = S + P.o_pE + oe2;
+                        val = (a[0] - b[0]) * dx + (a[1] - b[1]) * dy + (a[2] - b[2]) * dz;
+                        if (side & 4) val -= S[P.o_q2 + k];
+                        val *= 2.0;
+                    }
+                    S[P.o_Dh2 + n] = val;
+                }
+            }
+            // ---- E4, second half: the lane's list sum; w_k = [V_k^-, s_k] (config lanes), world inertia / momentum entries (body lanes)
+            if (lane < nd + 3 * NB) {
+                double V[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                constexpr int HALF = (MAXD + 1) / 2;
+                wev_sum<0, HALF>(SW, V);
+                wev_sum<HALF, MAXD>(SW, V);
+                if (lane < nd) {
+                    double sk[6];
+                    ld6<true>(SW + 12 * lane, sk);
+                    bracket(V, sk, wev_w);
+                } else {
+                    const int b = wvl[3] & 0xFF, r = (wvl[3] >> 8) & 3;
+                    const double *gb = S + P.o_gB + 12 * b, *I = S + P.o_I + 4 * b;
+                    const double m = I[0], I1 = I[1], I2 = I[2], I3 = I[3];
+                    double R[3][3], p[3];
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { R[i][0] = gb[4 * i]; R[i][1] = gb[4 * i + 1]; R[i][2] = gb[4 * i + 2]; p[i] = gb[4 * i + 3]; }
+                    const double Rr0 = gb[4 * r], Rr1 = gb[4 * r + 1], Rr2 = gb[4 * r + 2], pr = gb[4 * r + 3];
+                    // momentum about the world origin: f = m (v + omega x p),  tau = R I R' omega + p x f
+                    const double f0 = m * (V[0] + (V[4] * p[2] - V[5] * p[1])), f1 = m * (V[1] + (V[5] * p[0] - V[3] * p[2])), f2 = m * (V[2] + (V[3] * p[1] - V[4] * p[0]));
+                    const double wb0 = I1 * (R[0][0] * V[3] + R[1][0] * V[4] + R[2][0] * V[5]);
+                    const double wb1 = I2 * (R[0][1] * V[3] + R[1][1] * V[4] + R[2][1] * V[5]);
+                    const double wb2 = I3 * (R[0][2] * V[3] + R[1][2] * V[4] + R[2][2] * V[5]);
+                    const double cr = r == 0 ? p[1] * f2 - p[2] * f1 : (r == 1 ? p[2] * f0 - p[0] * f2 : p[0] * f1 - p[1] * f0);
+                    const double tau = (Rr0 * wb0 + Rr1 * wb1 + Rr2 * wb2) + cr;
+                    const double p2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+                    double *o = BW + BWS * b;
+                    if (r == 0) o[0] = m;
+                    o[1 + r] = m * pr;
+                    // D = R I R' + m (|p|^2 1 - p p'), row r, columns j >= r: entries 4 + (xx xy xz | yy yz | zz)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        const double dv = Rr0 * I1 * R[j][0] + Rr1 * I2 * R[j][1] + Rr2 * I3 * R[j][2] + m * ((j == r ? p2 : 0.0) - pr * p[j]);
+                        if (j >= r) o[4 + (r == 0 ? j : (r == 1 ? 2 + j : 5))] = dv;
+                    }
+                    o[10 + r] = r == 0 ? f0 : (r == 1 ? f1 : f2);
+                    o[13 + r] = tau;
+                }
+            }
+        }
+        TG_SYNC();
+        TG_STAMP(6);
+        // ---- E5: composites of the subtree groups (lane = entry; membership is compile-time) ----
+        if (on && lane < 16) {
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int b = 0; b < NB; b++) if ((P.cmp_gmask[g] >> b) & 1) acc += BW[BWS * b + lane];
+                CMP[16 * g + lane] = acc;
+            }
+        }
+        TG_SYNC();
+        TG_STAMP(3);
+        // ---- E6: L_dq, L_ddq and the residual entry of config k ----
+        if (on && lane < nd) {
+            const double *c = CMP + 16 * ((wvl[3] >> 24) & 0x7F);
+            const double M = c[0], Cx = c[1], Cy = c[2], Cz = c[3];
+            const double h0 = c[10], h1 = c[11], h2 = c[12], h3 = c[13], h4 = c[14], h5 = c[15];
+            double sk[6];
+            ld6<true>(SW + 12 * lane, sk);
+            const double lddq = sk[0] * h0 + sk[1] * h1 + sk[2] * h2 + sk[3] * h3 + sk[4] * h4 + sk[5] * h5;
+            const double Gx = M * sk[0] + (sk[4] * Cz - sk[5] * Cy), Gy = M * sk[1] + (sk[5] * Cx - sk[3] * Cz), Gz = M * sk[2] + (sk[3] * Cy - sk[4] * Cx);
+            const double ldq = (wev_w[0] * h0 + wev_w[1] * h1 + wev_w[2] * h2 + wev_w[3] * h3 + wev_w[4] * h4 + wev_w[5] * h5) +
+                               (P.grav[0] * Gx + P.grav[1] * Gy + P.grav[2] * Gz);
+            const int i = lane;
+            S[P.o_Ldq + i] = ldq; S[P.o_Lddq + i] = lddq;
+            double force = -tdamp * S[P.o_dq + i];
+            for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
+            double f = S[P.o_p1 + i] + (0.5 * dt * ldq - lddq) + dt * force;
+#pragma unroll
+            for (int cc = 0; cc < 8; cc++) {
+                if (cc < P.nc) {
+                    const int n = rt.look[cc];
+                    f -= (n >= 0 ? S[P.o_lam + cc] : 0.0) * S[P.o_Dh1 + (n >= 0 ? n : 0)];
+                }
+            }
+            S[P.o_f + i] = f;
+            res_f2 = f * f;
+        } else res_f2 = 0.0;
+        TG_STAMP(4);
+    }
 #endif
 
     // ---- poses of the massive frames and positions of the constraint end points --------------------
@@ -1643,11 +1889,91 @@ struct Core {
         TG_SYNC();
         TG_STAMP(8);
     }
+
+    // The Newton matrix after eval_world: phases C and D of newton_matrix_composite -- the twists s_k are in LDS already, w_k in the lane's
+    // registers, the composites in CMP -- so the two phases that re-derived them from the body-frame items (A, B) are gone.
+    TG_HD void newton_matrix_world(bool on) {
+        PROG &P = tg_fresh(this->P);
+        typedef typename std::remove_cv<PROG>::type SP;
+        constexpr int nd = SP::nd, nf = SP::nf, ld = SP::df_ld, NP = SP::n_cmpairs;
+        constexpr int TP = (NP + TEAM - 1) / TEAM;
+        double *A = S + P.o_Df, *CMP = S + P.o_cmp, *SW = S + P.o_csw, *CZ = S + P.o_ccz;
+        constexpr int SWS = 12;
+        // ---- phase C: the image (the whole union: poses and per-body entries are dead now) is cleared; per config b: I s_b, Z_b = Y_b + I w_b, GG_b
+        {
+            typedef double tg_d2 __attribute__((ext_vector_type(2)));
+            static_assert(((SP::o_Df | (nf * ld)) & 1) == 0, "newton_matrix_world: image not 16-byte aligned");
+            tg_d2 *A2 = reinterpret_cast<tg_d2 *>(A);
+            const tg_d2 z2 = {0.0, 0.0};
+            if (on) TG_FOR(i, (nf * ld) >> 1) A2[i] = z2;
+        }
+        if (on && lane < nd) {
+            const double *c = CMP + 16 * ((wvl[3] >> 24) & 0x7F);
+            const double M = c[0], Cx = c[1], Cy = c[2], Cz = c[3], Dxx = c[4], Dxy = c[5], Dxz = c[6], Dyy = c[7], Dyz = c[8], Dzz = c[9];
+            const double h0 = c[10], h1 = c[11], h2 = c[12], h3 = c[13], h4 = c[14], h5 = c[15];
+            double s[6];
+            ld6<true>(SW + SWS * lane, s);
+            const double *w = wev_w;
+            auto apply = [&](const double *x, double *y) {      // spatial inertia times twist
+                y[0] = M * x[0] - (Cy * x[5] - Cz * x[4]); y[1] = M * x[1] - (Cz * x[3] - Cx * x[5]); y[2] = M * x[2] - (Cx * x[4] - Cy * x[3]);
+                y[3] = (Cy * x[2] - Cz * x[1]) + Dxx * x[3] + Dxy * x[4] + Dxz * x[5];
+                y[4] = (Cz * x[0] - Cx * x[2]) + Dxy * x[3] + Dyy * x[4] + Dyz * x[5];
+                y[5] = (Cx * x[1] - Cy * x[0]) + Dxz * x[3] + Dyz * x[4] + Dzz * x[5];
+            };
+            double Is[6], Iw[6];
+            apply(s, Is); apply(w, Iw);
+            const double b0 = s[0], b1 = s[1], b2 = s[2], b3 = s[3], b4 = s[4], b5 = s[5];
+            double Z[6];
+            Z[0] = Iw[0] + (b4 * h2 - b5 * h1); Z[1] = Iw[1] + (b5 * h0 - b3 * h2); Z[2] = Iw[2] + (b3 * h1 - b4 * h0);
+            Z[3] = Iw[3] + (b1 * h2 - b2 * h1) + (b4 * h5 - b5 * h4);
+            Z[4] = Iw[4] + (b2 * h0 - b0 * h2) + (b5 * h3 - b3 * h5);
+            Z[5] = Iw[5] + (b0 * h1 - b1 * h0) + (b3 * h4 - b4 * h3);
+            const double Gx = M * b0 + (b4 * Cz - b5 * Cy), Gy = M * b1 + (b5 * Cx - b3 * Cz), Gz = M * b2 + (b3 * Cy - b4 * Cx);
+            const double gx = P.grav[0], gy = P.grav[1], gz = P.grav[2];
+            double *o = CZ + 15 * lane;
+#pragma unroll
+            for (int r = 0; r < 6; r++) { o[r] = Is[r]; o[6 + r] = Z[r]; }
+            o[12] = Gy * gz - Gz * gy; o[13] = Gz * gx - Gx * gz; o[14] = Gx * gy - Gy * gx;
+            st6<true>(SW + SWS * lane + 6, wev_w);        // (the u-half of the record: its readers finished two barriers ago)
+        }
+        TG_SYNC();
+        TG_STAMP(7);
+        // ---- phase D: the constant entries (right-hand side, damping, -Dh1' / Dh2) and the config pairs: one lane per pair
+        if (on) {
+            if (lane < nf) A[lane * ld + nf] = S[P.o_f + lane];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int n = tck[u][0] >> 8, c = tck[u][0] & 0xFF, k = tck[u][1];
+                if (u * TEAM < P.n_dhr && lane + u * TEAM < P.n_dhr) { A[k * ld + nd + c] = -S[P.o_Dh1 + n]; A[(nd + c) * ld + k] = S[P.o_Dh2 + n]; }
+            }
+        }
+        const double qdt = 0.25 * dt, rdt = inv_dt;
+#pragma unroll
+        for (int u = 0; u < TP; u++) {
+            if (on && lane + u * TEAM < NP) {
+                const int a = wpair[u] & 0xFFFF, b = wpair[u] >> 16;
+                const double *sa = SW + SWS * a, *wa = sa + 6, *Is = CZ + 15 * b, *Z = Is + 6, *GG = Is + 12;
+                double s_[6], w_[6], i_[6], z_[6];
+#pragma unroll
+                for (int r = 0; r < 6; r++) { s_[r] = sa[r]; w_[r] = wa[r]; i_[r] = Is[r]; z_[r] = Z[r]; }
+                const double g0 = GG[0], g1 = GG[1], g2 = GG[2];
+                double mab = 0.0, lqq = s_[3] * g0 + s_[4] * g1 + s_[5] * g2, cab = 0.0, cba = 0.0;
+#pragma unroll
+                for (int r = 0; r < 6; r++) { mab = fma(s_[r], i_[r], mab); lqq = fma(w_[r], z_[r], lqq); cab = fma(s_[r], z_[r], cab); cba = fma(w_[r], i_[r], cba); }
+                const double sym = qdt * lqq - rdt * mab, skew = 0.5 * (cba - cab);
+                if (u == 0 && a == b) A[a * ld + a] = sym - tdamp;
+                else { A[a * ld + b] = sym + (a != b ? skew : 0.0); if (a != b) A[b * ld + a] = sym - skew; }
+            }
+        }
+        TG_SYNC();
+        TG_STAMP(8);
+    }
 #endif
 
     // ---- Newton matrix [Df | f] (midpointvi.c:577-670) ---------------------------------------------------
     TG_HD void newton_matrix(bool on) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_CMP)
+        if constexpr (TEAM == 64 && !SPRINGS && tg_static_wev<typename std::remove_cv<PROG>::type>::value) { if (wev_on) { newton_matrix_world(on); return; } }
         if constexpr (TEAM == 64 && !SPRINGS && tg_static_cmp<typename std::remove_cv<PROG>::type>::value) { newton_matrix_composite(on); return; }
 #endif
         PROG &P = tg_fresh(this->P);
@@ -4716,7 +5042,8 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
             PROG &P = tg_fresh(P0);
             const int nd = P.nd, nc = P.nc;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(TG_NO_DUAL_SWEEP)
-            if (core.dual_ok()) { if (P.tab_ok) core.eval_both_tab(!done); else core.eval_both(!done); }
+            if constexpr (TEAM == 64 && !SPRINGS && tg_static_wev<typename std::remove_cv<PROG>::type>::value) { core.wev_on = true; core.eval_world(!done); }
+            else if (core.dual_ok()) { if (P.tab_ok) core.eval_both_tab(!done); else core.eval_both(!done); }
             else
 #endif
             {

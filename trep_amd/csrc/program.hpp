@@ -165,6 +165,13 @@ struct DevProg {
     int bbd_ok, bbd_g, bbd_ng, bbd_nb, bbd_t, o_bbd;
     int bbd_tvar[16];         // image index of trailing variable i
     const int *bbd_tab;
+    // world-frame evaluation of the rollout's residual (system-specialised kernels, mvi_core.hpp eval_world): the Lagrangian terms of
+    // system.c:129-202 per CONFIG from world-frame joint twists and the composite momentum of the subtree below it, instead of per
+    // (body, config) item.  wev_lane [64][4]: lane l < nd is config l -- words 0..2 = its proper ancestors on the path, root first, one
+    // byte each, padded with nd (the all-zero record), word 3 = 12 * joint | kind << 16 | subtree group << 24; lane nd + 3 b + r is
+    // (body b, axis r) -- words 0..2 = the configs of the body's path, word 3 = b | r << 8.  wev_depth: longest list.
+    int wev_ok, wev_depth;
+    const int *wev_lane;
 };
 
 struct HostProgram {
@@ -181,7 +188,7 @@ struct HostProgram {
     std::vector<double> c_dist, c_tol;
     std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
     std::vector<double> damp, cs_k, cs_kq0, cs_c0, s_k, s_x0, s_c, c_nloc, wr_const, wr_Rloc, ncs_mb, ncs_tab;
-    std::vector<int> ncs_i, bbd_tab, cmp_rep, cmp_grp, cmp_goff, cmp_gbody, cmp_pair;
+    std::vector<int> ncs_i, bbd_tab, cmp_rep, cmp_grp, cmp_goff, cmp_gbody, cmp_pair, wev_lane;
     std::vector<unsigned char> newton_pattern;   // [nf * nf] structural non-zeros of the Newton matrix (symmetrised), host side only
     std::vector<int> wr_in, wr_kind;
     std::vector<int> cf_cfg, cf_in;
@@ -825,6 +832,49 @@ inline HostProgram build_program(const tg_system_desc *d) {
             for (auto &g : group_of) for (int b : g.first) P.cmp_gmask[g.second] |= 1 << b;
         }
     }
+    {   // world-frame evaluation (DevProg::wev_*): needs the composite form (groups, pairs), every (body, path config) item on a
+        // DYNAMIC config (a kinematic config above a body would need a twist and a rate but has no residual row), one lane per config
+        // and per (body, axis), lists of at most 12 entries, and the twists + the zero record inside the J area (the q2 poses of the
+        // dual sweep sit in the W area while they are read)
+        P.wev_ok = 0; P.wev_depth = 0;
+        H.wev_lane.assign(256, 0);
+        bool ok = P.cmp_ok && P.tab_ok && P.sw_ok && P.sched_ok && nd + 3 * nb <= 64 && nd < 63 && nc > 0 && 6 * nitems >= 12 * nj && ns == 0 && nw == 0 && !P.has_cs;
+        for (int it = 0; it < nitems && ok; it++) if (H.it_cfg[it] >= nd) ok = false;
+        if (ok && 16 * P.n_cgroups + 12 * (nd + 1) > 6 * nitems) ok = false;
+        if (ok && 16 * P.n_cgroups + 12 * (nd + 1) + 15 * nd > 12 * nitems) ok = false;
+        std::vector<std::vector<int>> lists(64);
+        if (ok) {
+            for (int c = 0; c < nd; c++) {
+                const int b = H.it_body[H.cmp_rep[c]];
+                for (int it = H.b_item_off[b]; it < H.b_item_off[b + 1] && H.it_cfg[it] != c; it++) lists[c].push_back(H.it_cfg[it]);
+                // a tree: the ancestors of config c are the same along every body's path
+                for (int b2 = 0; b2 < nb; b2++) {
+                    std::vector<int> other;
+                    bool has = false;
+                    for (int it = H.b_item_off[b2]; it < H.b_item_off[b2 + 1]; it++) { if (H.it_cfg[it] == c) { has = true; break; } other.push_back(H.it_cfg[it]); }
+                    if (has && other != lists[c]) ok = false;
+                }
+            }
+            for (int b = 0; b < nb; b++)
+                for (int r = 0; r < 3; r++)
+                    for (int it = H.b_item_off[b]; it < H.b_item_off[b + 1]; it++) lists[nd + 3 * b + r].push_back(H.it_cfg[it]);
+            for (auto &l : lists) P.wev_depth = std::max(P.wev_depth, (int)l.size());
+            if (P.wev_depth > 12 || P.wev_depth < 1) ok = false;
+        }
+        if (ok) {
+            for (int l = 0; l < 64; l++) {
+                int w[3] = {0, 0, 0};
+                for (int e = 0; e < 12; e++) w[e >> 2] |= (e < (int)lists[l].size() ? lists[l][e] : nd) << (8 * (e & 3));
+                for (int i = 0; i < 3; i++) H.wev_lane[4 * l + i] = w[i];
+                if (l < nd) {
+                    const int j = joint_of_cfg[l];
+                    H.wev_lane[4 * l + 3] = (12 * j) | (H.j_kind[j] << 16) | (H.cmp_grp[l] << 24);
+                } else if (l < nd + 3 * nb) H.wev_lane[4 * l + 3] = ((l - nd) / 3) | (((l - nd) % 3) << 8);
+            }
+            P.wev_ok = 1;
+            P.o_ccz = P.o_csw + 12 * (nd + 1);      // one more twist record: the all-zero one the padded list entries point at
+        }
+    }
     {   // structured Newton solve: structural pattern of [[Df11, -Dh1^T], [Dh2, 0]] (newton_matrix in mvi_core.hpp writes exactly these
         // entries) -> bordered-block-diagonal plan.  Full-wave systems of the size gj_panel serves; the solver's scratch (trailing
         // system + border solution) lives in the dead J / W area.
@@ -879,7 +929,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
     X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in) X(wr_kind) X(ncs_i) \
-    X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4) X(bbd_tab) X(cmp_rep) X(cmp_grp) X(cmp_goff) X(cmp_gbody) X(cmp_pair) X(dhr_pack) X(at_i) X(ae_i) X(sj_list) X(sj_full)
+    X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4) X(bbd_tab) X(cmp_rep) X(cmp_grp) X(cmp_goff) X(cmp_gbody) X(cmp_pair) X(dhr_pack) X(at_i) X(ae_i) X(sj_list) X(sj_full) X(wev_lane)
 #define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(j_prm) X(at_d) X(ae_d) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c) X(wr_Rloc) X(ncs_mb) X(ncs_tab)
 
 inline void HostProgram::pack() {
