@@ -1299,10 +1299,23 @@ struct Core {
     TG_HD void eval_world(bool on) {
         typedef typename std::remove_cv<PROG>::type SP;
         constexpr int nd = SP::nd, NB = SP::n_bodies, NG = SP::n_cgroups, MAXD = SP::wev_depth;
-        static_assert(TEAM == 64 && nd + 3 * NB <= 64 && nd < 64, "eval_world: one lane per config and per (body, axis)");
-        static_assert((SP::o_csw & 1) == 0 && (SP::o_gB & 1) == 0 && (SP::o_I & 1) == 0 && (SP::o_cmp & 1) == 0, "eval_world: 16-byte LDS accesses");
+        static_assert(TEAM == 64 && nd + 3 * NB < 64, "eval_world: one lane per config and per (body, axis), and the last lane free");
+        static_assert((SP::o_csw & 1) == 0 && (SP::o_I & 1) == 0 && (SP::o_cmp & 1) == 0 && (SP::o_G & 1) == 0, "eval_world: 16-byte LDS accesses");
         PROG &P = tg_fresh(this->P);
-        const AttachTab at = fetch_attach();
+        // table rows of E3, requested ahead of the pose sweep: the end point's anchor row (as fetch_attach), the body lane's constant offset
+        const int l0 = tg_opaque(lane);
+        const bool blane = l0 >= nd && l0 < nd + 3 * NB;
+        const int wb_ = blane ? wvl[3] & 0xFF : 0, wr_ = blane ? (wvl[3] >> 8) & 3 : 0;
+        double eo0, eo1, eo2, eor; int eanc;
+        {
+            const int ii = l0 < 3 * P.n_endpoints ? l0 : 0;
+            const double *o = P.ae_d + 4 * (size_t)ii;
+            eo0 = o[0]; eo1 = o[1]; eo2 = o[2]; eor = o[3]; eanc = P.ae_i[ii];
+        }
+        double Cb[12];
+#pragma unroll
+        for (int e = 0; e < 12; e++) Cb[e] = P.b_C[12 * (size_t)wb_ + e];
+        const int banc = P.b_anchor[wb_];
         if (!rates_ready) {
             if (on) TG_FOR(i, P.nq) S[P.o_dq + i] = (S[P.o_q2 + i] - S[P.o_q1 + i]) / dt;
             TG_SYNC();
@@ -1311,32 +1324,26 @@ struct Core {
         pose_sweep_dual(on, true);
         TG_STAMP(1);
         const double *G = S + P.o_G, *G2 = S + P.o_W;
-        double *SW = S + P.o_csw, *CMP = S + P.o_cmp, *BW = S + P.o_sc;
+        // per-body world entries: behind the q2 poses in the W area (with the dead body-velocity / gravity vectors that follow it) -- the body
+        // lanes write them while other lanes still read the midpoint poses
+        double *SW = S + P.o_csw, *CMP = S + P.o_cmp, *BW = S + P.o_W + 12 * P.n_joints;
         constexpr int BWS = 17;
-        static_assert(BWS * NB <= SP::o_gB - SP::o_sc, "eval_world: body entries do not fit the dead pose area");
-        // ---- E3: body poses (midpoint), constraint end points (q2 poses), world twists of the configs ----
+        static_assert(12 * SP::n_joints + BWS * NB <= 6 * SP::n_items + 9 * NB, "eval_world: body entries do not fit behind the q2 poses");
+        // ---- E3: constraint end points (q2 poses); lane k <= nd: world twist of config k; lane (body b, axis r): the body's world pose
+        //      from its anchor joint's, and from it the mass entries of the body -- M, C_r = m p_r, row r of D = R I R' + m (|p|^2 1 - p p')
+        //      (kept in registers for the momentum, which needs the body's velocity: E4)
         const ConTab ct = fetch_constraints();
+        double bD0 = 0.0, bD1 = 0.0, bD2 = 0.0, bC0 = 0.0, bC1 = 0.0, bC2 = 0.0, bm = 0.0;
         if (on) {
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int idx = lane + u * TEAM;
-                if (idx < 12 * P.n_bodies) {
-                    const int e = idx % 12, r = e >> 2, c = e & 3;
-                    const int anchor = at.ga[u];
-                    const double *g = G + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
-                    const double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
-                    const double val = g0 * at.c0[u] + g1 * at.c1[u] + g2 * at.c2[u] + (c == 3 ? g3 : 0.0);
-                    S[P.o_gB + idx] = anchor < 0 ? at.ce[u] : val;
-                }
-            }
             if (lane < 3 * P.n_endpoints) {
                 const int r = lane % 3;
-                const double *g = G2 + 12 * (at.ea < 0 ? 0 : at.ea) + 4 * r;
-                const double val = g[0] * at.o0 + g[1] * at.o1 + g[2] * at.o2 + g[3];
-                S[P.o_pE + lane] = at.ea < 0 ? at.orr : val;
+                const double *g = G2 + 12 * (eanc < 0 ? 0 : eanc) + 4 * r;
+                const double val = g[0] * eo0 + g[1] * eo1 + g[2] * eo2 + g[3];
+                S[P.o_pE + lane] = eanc < 0 ? eor : val;
             }
-            if (lane <= nd) {       // (lane nd writes the all-zero record the padded list entries point at)
+            if (lane < nd || lane == TEAM - 1) {       // (the last lane, which has no other role, writes the all-zero record the padded list entries point at)
                 const bool real = lane < nd;
+                const int rec = real ? lane : nd;
                 const int oj = real ? wvl[3] & 0xFFFF : 0, kind = real ? (wvl[3] >> 16) & 0xFF : (int)TG_TX;
                 const bool prismatic = kind <= TG_TZ;
                 const int ax = prismatic ? kind - TG_TX : kind - TG_RX;
@@ -1350,8 +1357,45 @@ struct Core {
                 sv[3] = prismatic ? 0.0 : a0; sv[4] = prismatic ? 0.0 : a1; sv[5] = prismatic ? 0.0 : a2;
 #pragma unroll
                 for (int r = 0; r < 6; r++) { sv[r] = real ? sv[r] : 0.0; uv[r] = sv[r] * dqk; }
-                st6<true>(SW + 12 * lane, sv);
-                st6<true>(SW + 12 * lane + 6, uv);
+                st6<true>(SW + 12 * rec, sv);
+                st6<true>(SW + 12 * rec + 6, uv);
+            } else if (blane) {
+                const int b = wb_, r = wr_;
+                const double *ga = G + 12 * (banc < 0 ? 0 : banc);
+                double Ga[12];
+                {
+                    typedef double tg_d2 __attribute__((ext_vector_type(2)));
+                    const tg_d2 *q = reinterpret_cast<const tg_d2 *>(ga);
+#pragma unroll
+                    for (int e = 0; e < 6; e++) { const tg_d2 v = q[e]; Ga[2 * e] = v.x; Ga[2 * e + 1] = v.y; }
+                }
+                if (banc < 0) {
+#pragma unroll
+                    for (int e = 0; e < 12; e++) Ga[e] = (e == 0 || e == 5 || e == 10) ? 1.0 : 0.0;
+                }
+                // world pose of the body: R = Ra Rc, p = Ra pc + pa
+                double R[3][3], p[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+#pragma unroll
+                    for (int j = 0; j < 3; j++) R[i][j] = Ga[4 * i] * Cb[j] + Ga[4 * i + 1] * Cb[4 + j] + Ga[4 * i + 2] * Cb[8 + j];
+                    p[i] = Ga[4 * i] * Cb[3] + Ga[4 * i + 1] * Cb[7] + Ga[4 * i + 2] * Cb[11] + Ga[4 * i + 3];
+                }
+                const double *I = S + P.o_I + 4 * b;
+                const double m = I[0], I1 = I[1], I2 = I[2], I3 = I[3];
+                const double Rr0 = r == 0 ? R[0][0] : (r == 1 ? R[1][0] : R[2][0]), Rr1 = r == 0 ? R[0][1] : (r == 1 ? R[1][1] : R[2][1]);
+                const double Rr2 = r == 0 ? R[0][2] : (r == 1 ? R[1][2] : R[2][2]), pr = r == 0 ? p[0] : (r == 1 ? p[1] : p[2]);
+                const double p2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+                double Dr[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) Dr[j] = Rr0 * I1 * R[j][0] + Rr1 * I2 * R[j][1] + Rr2 * I3 * R[j][2] + m * ((j == r ? p2 : 0.0) - pr * p[j]);
+                double *o = BW + BWS * b;
+                if (r == 0) o[0] = m;
+                o[1 + r] = m * pr;
+                // D row r, columns j >= r: entries 4 + (xx xy xz | yy yz | zz)
+#pragma unroll
+                for (int j = 0; j < 3; j++) if (j >= r) o[4 + (r == 0 ? j : (r == 1 ? 2 + j : 5))] = Dr[j];
+                bD0 = Dr[0]; bD1 = Dr[1]; bD2 = Dr[2]; bC0 = m * p[0]; bC1 = m * p[1]; bC2 = m * p[2]; bm = m;
             }
         }
         TG_SYNC();
@@ -1406,8 +1450,9 @@ struct Core {
                     S[P.o_Dh2 + n] = val;
                 }
             }
-            // ---- E4, second half: the lane's list sum; w_k = [V_k^-, s_k] (config lanes), world inertia / momentum entries (body lanes)
-            if (lane < nd + 3 * NB) {
+            // ---- E4, second half: the lane's list sum (every lane: a lane without a role sums the zero record); w_k = [V_k^-, s_k] (config
+            //      lanes), the body's momentum about the world origin f = M v - C x omega, tau = C x v + D omega (body lanes: rows r)
+            {
                 double V[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                 constexpr int HALF = (MAXD + 1) / 2;
                 wev_sum<0, HALF>(SW, V);
@@ -1416,33 +1461,15 @@ struct Core {
                     double sk[6];
                     ld6<true>(SW + 12 * lane, sk);
                     bracket(V, sk, wev_w);
-                } else {
-                    const int b = wvl[3] & 0xFF, r = (wvl[3] >> 8) & 3;
-                    const double *gb = S + P.o_gB + 12 * b, *I = S + P.o_I + 4 * b;
-                    const double m = I[0], I1 = I[1], I2 = I[2], I3 = I[3];
-                    double R[3][3], p[3];
-#pragma unroll
-                    for (int i = 0; i < 3; i++) { R[i][0] = gb[4 * i]; R[i][1] = gb[4 * i + 1]; R[i][2] = gb[4 * i + 2]; p[i] = gb[4 * i + 3]; }
-                    const double Rr0 = gb[4 * r], Rr1 = gb[4 * r + 1], Rr2 = gb[4 * r + 2], pr = gb[4 * r + 3];
-                    // momentum about the world origin: f = m (v + omega x p),  tau = R I R' omega + p x f
-                    const double f0 = m * (V[0] + (V[4] * p[2] - V[5] * p[1])), f1 = m * (V[1] + (V[5] * p[0] - V[3] * p[2])), f2 = m * (V[2] + (V[3] * p[1] - V[4] * p[0]));
-                    const double wb0 = I1 * (R[0][0] * V[3] + R[1][0] * V[4] + R[2][0] * V[5]);
-                    const double wb1 = I2 * (R[0][1] * V[3] + R[1][1] * V[4] + R[2][1] * V[5]);
-                    const double wb2 = I3 * (R[0][2] * V[3] + R[1][2] * V[4] + R[2][2] * V[5]);
-                    const double cr = r == 0 ? p[1] * f2 - p[2] * f1 : (r == 1 ? p[2] * f0 - p[0] * f2 : p[0] * f1 - p[1] * f0);
-                    const double tau = (Rr0 * wb0 + Rr1 * wb1 + Rr2 * wb2) + cr;
-                    const double p2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
-                    double *o = BW + BWS * b;
-                    if (r == 0) o[0] = m;
-                    o[1 + r] = m * pr;
-                    // D = R I R' + m (|p|^2 1 - p p'), row r, columns j >= r: entries 4 + (xx xy xz | yy yz | zz)
-#pragma unroll
-                    for (int j = 0; j < 3; j++) {
-                        const double dv = Rr0 * I1 * R[j][0] + Rr1 * I2 * R[j][1] + Rr2 * I3 * R[j][2] + m * ((j == r ? p2 : 0.0) - pr * p[j]);
-                        if (j >= r) o[4 + (r == 0 ? j : (r == 1 ? 2 + j : 5))] = dv;
-                    }
-                    o[10 + r] = r == 0 ? f0 : (r == 1 ? f1 : f2);
-                    o[13 + r] = tau;
+                } else if (blane) {
+                    const int r = wr_;
+                    const double cw0 = bC1 * V[5] - bC2 * V[4], cw1 = bC2 * V[3] - bC0 * V[5], cw2 = bC0 * V[4] - bC1 * V[3];   // C x omega
+                    const double cv0 = bC1 * V[2] - bC2 * V[1], cv1 = bC2 * V[0] - bC0 * V[2], cv2 = bC0 * V[1] - bC1 * V[0];   // C x v
+                    const double fr = bm * (r == 0 ? V[0] : (r == 1 ? V[1] : V[2])) - (r == 0 ? cw0 : (r == 1 ? cw1 : cw2));
+                    const double tr = (r == 0 ? cv0 : (r == 1 ? cv1 : cv2)) + (bD0 * V[3] + bD1 * V[4] + bD2 * V[5]);
+                    double *o = BW + BWS * wb_;
+                    o[10 + r] = fr;
+                    o[13 + r] = tr;
                 }
             }
         }

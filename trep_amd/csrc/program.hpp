@@ -838,9 +838,10 @@ inline HostProgram build_program(const tg_system_desc *d) {
         // dual sweep sit in the W area while they are read)
         P.wev_ok = 0; P.wev_depth = 0;
         H.wev_lane.assign(256, 0);
-        bool ok = P.cmp_ok && P.tab_ok && P.sw_ok && P.sched_ok && nd + 3 * nb <= 64 && nd < 63 && nc > 0 && 6 * nitems >= 12 * nj && ns == 0 && nw == 0 && !P.has_cs;
+        bool ok = P.cmp_ok && P.tab_ok && P.sw_ok && P.sched_ok && nd + 3 * nb < 64 && nc > 0 && 6 * nitems >= 12 * nj && ns == 0 && nw == 0 && !P.has_cs;
         for (int it = 0; it < nitems && ok; it++) if (H.it_cfg[it] >= nd) ok = false;
         if (ok && 16 * P.n_cgroups + 12 * (nd + 1) > 6 * nitems) ok = false;
+        if (ok && 12 * nj + 17 * nb > 6 * nitems + 9 * nb) ok = false;      // per-body world entries behind the q2 poses (W, vB, gam areas)
         if (ok && 16 * P.n_cgroups + 12 * (nd + 1) + 15 * nd > 12 * nitems) ok = false;
         std::vector<std::vector<int>> lists(64);
         if (ok) {
