@@ -1475,7 +1475,20 @@ struct Core {
         }
         TG_SYNC();
         TG_STAMP(6);
-        // ---- E5: composites of the subtree groups (lane = entry; membership is compile-time) ----
+        // ---- E5: composites of the subtree groups (lane = entry; membership is compile-time).  The union of poses and Newton image is dead
+        //      from here to the next evaluation (its last readers were the constraint lanes of E4): the image is cleared here, by lanes
+        //      that would idle, instead of at the head of the assembly (wasted by a step's last evaluation: one in four)
+        {
+            typedef double tg_d2 __attribute__((ext_vector_type(2)));
+            static_assert(((SP::o_Df | (SP::nf * SP::df_ld)) & 1) == 0, "eval_world: image not 16-byte aligned");
+            tg_d2 *A2 = reinterpret_cast<tg_d2 *>(S + P.o_Df);
+            const tg_d2 z2 = {0.0, 0.0};
+#if defined(TG_WEV_CLEAR_EARLY)
+            if (on) TG_FOR(i, (SP::nf * SP::df_ld) >> 1) A2[i] = z2;
+#else
+            (void)A2; (void)z2;
+#endif
+        }
         if (on && lane < 16) {
 #pragma unroll
             for (int g = 0; g < NG; g++) {
@@ -1487,17 +1500,19 @@ struct Core {
         }
         TG_SYNC();
         TG_STAMP(3);
-        // ---- E6: L_dq, L_ddq and the residual entry of config k ----
+        // ---- E6: L_dq, L_ddq and the residual entry of config k; and, from the same operands, what the Newton matrix's pair lanes need of
+        //      config k: I s_k, Z_k = Y_k + I w_k, GG_k (phase C of newton_matrix_composite; one evaluation in four does not use them) ----
         if (on && lane < nd) {
             const double *c = CMP + 16 * ((wvl[3] >> 24) & 0x7F);
-            const double M = c[0], Cx = c[1], Cy = c[2], Cz = c[3];
+            const double M = c[0], Cx = c[1], Cy = c[2], Cz = c[3], Dxx = c[4], Dxy = c[5], Dxz = c[6], Dyy = c[7], Dyz = c[8], Dzz = c[9];
             const double h0 = c[10], h1 = c[11], h2 = c[12], h3 = c[13], h4 = c[14], h5 = c[15];
             double sk[6];
             ld6<true>(SW + 12 * lane, sk);
+            const double *w = wev_w;
             const double lddq = sk[0] * h0 + sk[1] * h1 + sk[2] * h2 + sk[3] * h3 + sk[4] * h4 + sk[5] * h5;
             const double Gx = M * sk[0] + (sk[4] * Cz - sk[5] * Cy), Gy = M * sk[1] + (sk[5] * Cx - sk[3] * Cz), Gz = M * sk[2] + (sk[3] * Cy - sk[4] * Cx);
-            const double ldq = (wev_w[0] * h0 + wev_w[1] * h1 + wev_w[2] * h2 + wev_w[3] * h3 + wev_w[4] * h4 + wev_w[5] * h5) +
-                               (P.grav[0] * Gx + P.grav[1] * Gy + P.grav[2] * Gz);
+            const double gx = P.grav[0], gy = P.grav[1], gz = P.grav[2];
+            const double ldq = (w[0] * h0 + w[1] * h1 + w[2] * h2 + w[3] * h3 + w[4] * h4 + w[5] * h5) + (gx * Gx + gy * Gy + gz * Gz);
             const int i = lane;
             S[P.o_Ldq + i] = ldq; S[P.o_Lddq + i] = lddq;
             double force = -tdamp * S[P.o_dq + i];
@@ -1512,6 +1527,29 @@ struct Core {
             }
             S[P.o_f + i] = f;
             res_f2 = f * f;
+#if defined(TG_WEV_MERGE_C)
+            auto apply = [&](const double *x, double *y) {      // spatial inertia times twist
+                y[0] = M * x[0] - (Cy * x[5] - Cz * x[4]); y[1] = M * x[1] - (Cz * x[3] - Cx * x[5]); y[2] = M * x[2] - (Cx * x[4] - Cy * x[3]);
+                y[3] = (Cy * x[2] - Cz * x[1]) + Dxx * x[3] + Dxy * x[4] + Dxz * x[5];
+                y[4] = (Cz * x[0] - Cx * x[2]) + Dxy * x[3] + Dyy * x[4] + Dyz * x[5];
+                y[5] = (Cx * x[1] - Cy * x[0]) + Dxz * x[3] + Dyz * x[4] + Dzz * x[5];
+            };
+            double Is[6], Iw[6];
+            apply(sk, Is); apply(w, Iw);
+            const double b0 = sk[0], b1 = sk[1], b2 = sk[2], b3 = sk[3], b4 = sk[4], b5 = sk[5];
+            double Z[6];
+            Z[0] = Iw[0] + (b4 * h2 - b5 * h1); Z[1] = Iw[1] + (b5 * h0 - b3 * h2); Z[2] = Iw[2] + (b3 * h1 - b4 * h0);
+            Z[3] = Iw[3] + (b1 * h2 - b2 * h1) + (b4 * h5 - b5 * h4);
+            Z[4] = Iw[4] + (b2 * h0 - b0 * h2) + (b5 * h3 - b3 * h5);
+            Z[5] = Iw[5] + (b0 * h1 - b1 * h0) + (b3 * h4 - b4 * h3);
+            double *o = S + P.o_ccz + 15 * lane;
+#pragma unroll
+            for (int r = 0; r < 6; r++) { o[r] = Is[r]; o[6 + r] = Z[r]; }
+            o[12] = Gy * gz - Gz * gy; o[13] = Gz * gx - Gx * gz; o[14] = Gx * gy - Gy * gx;
+            st6<true>(SW + 12 * lane + 6, wev_w);        // (the u-half of the record: its readers finished two barriers ago)
+#else
+            (void)Dxx; (void)Dxy; (void)Dxz; (void)Dyy; (void)Dyz; (void)Dzz;
+#endif
         } else res_f2 = 0.0;
         TG_STAMP(4);
     }
@@ -1924,24 +1962,27 @@ struct Core {
         typedef typename std::remove_cv<PROG>::type SP;
         constexpr int nd = SP::nd, nf = SP::nf, ld = SP::df_ld, NP = SP::n_cmpairs;
         constexpr int TP = (NP + TEAM - 1) / TEAM;
-        double *A = S + P.o_Df, *CMP = S + P.o_cmp, *SW = S + P.o_csw, *CZ = S + P.o_ccz;
+        double *A = S + P.o_Df, *SW = S + P.o_csw, *CZ = S + P.o_ccz;
         constexpr int SWS = 12;
-        // ---- phase C: the image (the whole union: poses and per-body entries are dead now) is cleared; per config b: I s_b, Z_b = Y_b + I w_b, GG_b
+        // phase C: the image is cleared, per config b: I s_b, Z_b = Y_b + I w_b, GG_b (measured variants, both slower: -DTG_WEV_MERGE_C forms the per-config vectors in
+        // eval_world's last phase -- 30.4 against 30.0 ms: every evaluation then pays for them --, -DTG_WEV_CLEAR_EARLY clears the image in E5)
+#if !defined(TG_WEV_CLEAR_EARLY)
         {
             typedef double tg_d2 __attribute__((ext_vector_type(2)));
-            static_assert(((SP::o_Df | (nf * ld)) & 1) == 0, "newton_matrix_world: image not 16-byte aligned");
             tg_d2 *A2 = reinterpret_cast<tg_d2 *>(A);
             const tg_d2 z2 = {0.0, 0.0};
             if (on) TG_FOR(i, (nf * ld) >> 1) A2[i] = z2;
         }
+#endif
+#if !defined(TG_WEV_MERGE_C)
         if (on && lane < nd) {
-            const double *c = CMP + 16 * ((wvl[3] >> 24) & 0x7F);
+            const double *c = S + P.o_cmp + 16 * ((wvl[3] >> 24) & 0x7F);
             const double M = c[0], Cx = c[1], Cy = c[2], Cz = c[3], Dxx = c[4], Dxy = c[5], Dxz = c[6], Dyy = c[7], Dyz = c[8], Dzz = c[9];
             const double h0 = c[10], h1 = c[11], h2 = c[12], h3 = c[13], h4 = c[14], h5 = c[15];
             double s[6];
             ld6<true>(SW + SWS * lane, s);
             const double *w = wev_w;
-            auto apply = [&](const double *x, double *y) {      // spatial inertia times twist
+            auto apply = [&](const double *x, double *y) {
                 y[0] = M * x[0] - (Cy * x[5] - Cz * x[4]); y[1] = M * x[1] - (Cz * x[3] - Cx * x[5]); y[2] = M * x[2] - (Cx * x[4] - Cy * x[3]);
                 y[3] = (Cy * x[2] - Cz * x[1]) + Dxx * x[3] + Dxy * x[4] + Dxz * x[5];
                 y[4] = (Cz * x[0] - Cx * x[2]) + Dxy * x[3] + Dyy * x[4] + Dyz * x[5];
@@ -1961,8 +2002,9 @@ struct Core {
 #pragma unroll
             for (int r = 0; r < 6; r++) { o[r] = Is[r]; o[6 + r] = Z[r]; }
             o[12] = Gy * gz - Gz * gy; o[13] = Gz * gx - Gx * gz; o[14] = Gx * gy - Gy * gx;
-            st6<true>(SW + SWS * lane + 6, wev_w);        // (the u-half of the record: its readers finished two barriers ago)
+            st6<true>(SW + SWS * lane + 6, wev_w);
         }
+#endif
         TG_SYNC();
         TG_STAMP(7);
         // ---- phase D: the constant entries (right-hand side, damping, -Dh1' / Dh2) and the config pairs: one lane per pair
