@@ -33,8 +33,13 @@ template <int MODE> constexpr int spec_waves() { return ((MODE == tg::MODE_DERIV
 static_assert(TG_NW >= 1 && TG_NW <= 2, "helper waves: the pair lists of program.hpp are split in exactly two parts (wave_part, wp_* / wt_* / wcp4)");
 static_assert(TG_NW == 1 || SPEC_TEAM == 64, "helper waves are for full-wave teams (trep_amd/specialize.py passes TG_HELPER_WAVES only then)");
 
+// waves per SIMD the rollout kernel is compiled for (its register budget: 2 -> 256, 3 -> 168): -DTG_ROLLOUT_WAVES=3 is an occupancy
+// experiment (tools/ab_spec.sh), not a product setting -- the LDS slice of a trajectory allows 8 per CU = 2 per SIMD
+#ifndef TG_ROLLOUT_WAVES
+#define TG_ROLLOUT_WAVES 2
+#endif
 template <int MODE, int PIVOT = 0>
-__global__ __launch_bounds__(64 * spec_waves<MODE>(), (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z) ? 1 : 2) void k_spec(SPEC_KERNEL_ARGS) {
+__global__ __launch_bounds__(64 * spec_waves<MODE>(), (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z) ? 1 : TG_ROLLOUT_WAVES) void k_spec(SPEC_KERNEL_ARGS) {
     SPEC_ARGS_REF;
 double *lds = tg_lds_base();
     const SpecProg P{};
