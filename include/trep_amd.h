@@ -378,6 +378,8 @@ int tg_batch_rollout_closed_loop_subset(tg_batch *b, int32_t n_trajectories, int
 int tg_batch_linearize(tg_batch *b, double *A_dev, double *B_dev);
 /* tg_batch_deriv2_contract with device-resident z [batch][nX] and hz [batch][R][R]. */
 int tg_batch_deriv2_contract_device(tg_batch *b, const double *z_dev, double *hz_dev);
+/* ... for the trajectories s * horizon + k, k_begin <= k < k_end, of a batch of seeds * horizon trajectories only (same arrays, same layout) */
+int tg_batch_deriv2_contract_device_range(tg_batch *b, const double *z_dev, double *hz_dev, int32_t horizon, int32_t k_begin, int32_t k_end);
 
 /* Time-varying LQ problem (reference trep/discopt/dlqr.py:41-81; with q_dev = r_dev = NULL and no curvature it
  * is solve_tv_lqr, dlqr.py:9-38).  Weights: Q_k = Q_dev[s*Q_seed_stride + k*Q_step_stride + ...] (strides in
@@ -407,6 +409,12 @@ typedef struct tg_lq_problem {
                                            * rows hold one entry each (their rho column).  The sweep then skips those blocks in its matrix products
                                            * (about half of the matrix-core work at the puppet's sizes); they must hold exact zeros.  ds_nd = 0: dense.
                                            * Requires nX = 2 (ds_nd + ds_nk), nU = ds_nu + ds_nk. */
+    int32_t k_begin, k_end;               /* optional: sweep only the steps k_end - 1 ... k_begin of the horizon (k_end = 0: all of it).  Every array
+                                           * keeps its full-horizon layout.  With k_end < horizon the sweep starts from ... */
+    const double *Pt_dev, *bt_dev;        /* ... (P, b) at step k_end: [S][nX][nX], [S][nX] -- the P0_dev / b0_dev an earlier launch over the steps
+                                           * [k_end, ...) wrote (which, with k_begin > 0, are (P, b) at step k_begin).  A horizon swept in chunks
+                                           * this way gives bit for bit the gains of one sweep: the pipelined Newton step of BatchDOptimizer runs the
+                                           * projection sweep, the second derivatives and the Newton-model sweep chunk by chunk in three stream lanes */
 } tg_lq_problem;
 int tg_tv_lq(int32_t device, const tg_lq_problem *problem);
 
@@ -447,6 +455,10 @@ int tg_copy_rows(int32_t device, int32_t n_rows, uint64_t row_doubles, const int
  * quasi-Newton LQ sweep of a step this way when the GPU has idle CUs (the reference runs them one after the other,
  * doptimizer.py:462-480; the results do not depend on it). */
 int tg_dopt_use_stream(int32_t device, int32_t lane);
+/* lanes 1 .. 4: the lane's HIP stream (hipStream_t as void *) -- e.g. for tg_batch_set_stream --, and "lane `waiter` continues after
+ * everything enqueued so far in lane `signal`" (an event, no host synchronisation) */
+void *tg_dopt_lane_stream(int32_t device, int32_t lane);
+int tg_dopt_lane_wait(int32_t device, int32_t waiter, int32_t signal);
 int tg_device_synchronize(int32_t device);
 
 /* ---- multi-GPU: one process per GPU, batch sharded, one collective ----------------------

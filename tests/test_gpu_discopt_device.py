@@ -174,6 +174,64 @@ def test_tv_lq_with_dsystem_structure(nd, nk, nu, N, S):
     assert L.tg_tv_lq(0, ctypes.byref(p)) != 0
 
 
+@pytest.mark.parametrize("kernel", ["structured", "dense", "legacy"])
+def test_tv_lq_swept_in_chunks_is_the_same_sweep(kernel, monkeypatch):
+    """tg_lq_problem::k_begin / k_end / Pt_dev / bt_dev: the horizon swept in three launches, each continuing from the (P, b) the previous one
+    left through P0_dev / b0_dev, gives BIT FOR BIT the gains, affine terms, adjoint rows (b_next_dev) and (P_0, b_0) of one sweep -- for the
+    DSystem-structured kernel, the dense matrix-core kernel and the VALU kernel -- and a sweep that ends before the horizon without the
+    (P, b) behind it is refused.  (The pipelined Newton step of BatchDOptimizer rests on this.)"""
+    from trep_amd import _lib
+    L = _lib.lib()
+    if kernel == "legacy":
+        monkeypatch.setenv("TREPAMD_LQ_LEGACY", "1")
+    nd, nk, nu, N, S = 22, 18, 0, 37, 3
+    nX, nU, nxh = 2 * (nd + nk), nu + nk, 2 * nd + nk
+    rng = np.random.default_rng(77)
+    A, B, Q, Qf, R, q, r, hz = _random_problem(rng, S, N, nX, nU, nxh)
+    A, B = _dsystem_structure(rng, A, B, nd, nk, nu)
+    pool = _pool()
+    try:
+        dA, dB, dQ, dQf, dR = pool.upload(A), pool.upload(B), pool.upload(Q), pool.upload(Qf), pool.upload(R)
+        dq, dr, dhz = pool.upload(q), pool.upload(r), pool.upload(hz)
+
+        def problem(dK, dC, dZ, dst):
+            p = _lib.LqProblem()
+            p.n_problems, p.horizon, p.nX, p.nU = S, N, nX, nU
+            p.A_dev, p.B_dev = dA.ptr, dB.ptr
+            p.Q_dev, p.Qf_dev, p.R_dev = dQ.ptr, dQf.ptr, dR.ptr
+            p.q_dev, p.r_dev = dq.ptr, dr.ptr
+            p.hz_dev, p.hz_R, p.hz_nx = dhz.ptr, nxh + nU, nxh
+            p.K_dev, p.C_dev, p.b_next_dev, p.status_dev = dK.ptr, dC.ptr, dZ.ptr, dst.ptr
+            if kernel == "structured":
+                p.ds_nd, p.ds_nk, p.ds_nu = nd, nk, nu
+            return p
+        outs = []
+        for chunks in ([(0, N)], [(25, N), (9, 25), (0, 9)]):
+            dK, dC, dZ, dst = pool.empty((S, N, nU, nX)), pool.empty((S, N, nU)), pool.empty((S, N, nX)), pool.empty((S,), np.int32)
+            carry = [(pool.empty((S, nX, nX)), pool.empty((S, nX))) for _ in range(2)]
+            for c, (k0, k1) in enumerate(chunks):
+                p = problem(dK, dC, dZ, dst)
+                p.P0_dev, p.b0_dev = carry[c % 2][0].ptr, carry[c % 2][1].ptr
+                if len(chunks) > 1:
+                    p.k_begin, p.k_end = k0, k1
+                if c > 0:
+                    p.Pt_dev, p.bt_dev = carry[(c - 1) % 2][0].ptr, carry[(c - 1) % 2][1].ptr
+                _lib.check(L.tg_tv_lq(0, ctypes.byref(p)))
+            last = carry[(len(chunks) - 1) % 2]
+            assert (dst.get() == 0).all()
+            outs.append((dK.get(), dC.get(), dZ.get(), last[0].get(), last[1].get()))
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b)
+        for s in range(S):      # ... and it is the right sweep
+            Kh, Ch, Ph, bh = _host_lq(A[s], B[s], Q, Qf, R, q[s], r[s], hz[s], nxh)
+            assert relerr(outs[1][0][s], Kh) < 1e-9 and relerr(outs[1][3][s], Ph) < 1e-9
+        p = problem(dK, dC, dZ, dst)
+        p.k_begin, p.k_end = 0, N - 3
+        assert L.tg_tv_lq(0, ctypes.byref(p)) != 0
+    finally:
+        pool.close()
+
+
 @pytest.mark.parametrize("nX,nU", [(6, 2), (30, 9), (37, 5), (80, 18), (91, 27), (96, 32)])
 def test_tangent_rollout_sizes(nX, nU, monkeypatch):
     """tg_tangent_rollout (doptimizer.py:391-402, 262-270) against numpy over the slice sizes k_tangent_rows is compiled for (odd sizes: the
@@ -387,8 +445,10 @@ def test_adjoint_comes_out_of_the_projection_sweep():
 
 def test_side_by_side_sweeps_change_nothing():
     """overlap_sweeps: projection gain and quasi-Newton sweep on two streams (default with few seeds) against one after the
-    other -- same kernels on the same inputs, so every number of every step is bit-equal, including a step in which some
-    seeds fall back from the Newton to the quasi-Newton direction (taken from the side-by-side sweep's buffers)."""
+    other; pipeline_newton: the projection sweep, the second derivatives and the Newton-model sweep chunk by chunk of the horizon
+    in three stream lanes (tg_lq_problem::k_begin / Pt_dev) against one after the other -- same kernels on the same inputs, so
+    every number of every step is bit-equal, including a step in which some seeds fall back from the Newton to the quasi-Newton
+    direction (taken from the side-by-side sweep's buffers)."""
     import trep_amd
     from trep_amd import discopt
     S = 5
@@ -397,31 +457,41 @@ def test_side_by_side_sweeps_change_nothing():
     X0 = np.repeat(g["X0"][None], S, axis=0)
     U0 = np.repeat(g["U0"][None], S, axis=0)
     trace = []
-    for overlap in (False, True):
-        opt = discopt.BatchDOptimizer(dsys, Xd, Ud, g["Q"], g["R"], armijo_chunk=2, overlap_sweeps=overlap)
-        assert opt.overlap == overlap
+    for overlap, pipeline in ((False, False), (True, False), (True, True)):
+        opt = discopt.BatchDOptimizer(dsys, Xd, Ud, g["Q"], g["R"], armijo_chunk=2, overlap_sweeps=overlap, pipeline_newton=pipeline)
+        assert opt.overlap == overlap and opt.pipeline == pipeline
+        opt.pipeline_chunks = 5
         try:
             opt.set_trajectories(X0, U0)
             out = []
             for m in ["quasi", "newton", ["newton", "quasi", "steepest", "newton", "quasi"]]:
                 r = opt.step(m)
                 out.append((r.cost0, r.dcost0, r.cost1, r.armijo, list(r.method)) + opt.get_trajectories())
+            if pipeline:
+                assert len(opt._chunks()) > 1
             # a Newton step whose model is forced indefinite for two seeds: they fall back to the quasi direction
-            real = opt.descent_direction
+            real, real_take = opt.descent_direction, opt._take_newton_direction
             def sabotaged(seeds, method):
                 real(seeds, method)
                 if method == "newton":
                     dc = opt.dcost.get(); dc[[1, 3]] = 1.0; opt.dcost.set(dc)
+            def sabotaged_take(seeds):
+                dc = np.array(real_take(seeds))
+                idx = np.arange(S) if seeds is None else np.asarray(seeds)
+                dc[np.isin(idx, [1, 3])] = 1.0
+                return dc
             opt.descent_direction = sabotaged
+            opt._take_newton_direction = sabotaged_take
             r = opt.step("newton")
             assert list(r.method) == ["newton", "quasi", "newton", "quasi", "newton"] and not r.failed.any()
             out.append((r.cost0, r.dcost0, r.cost1, r.armijo, list(r.method)) + opt.get_trajectories())
             trace.append(out)
         finally:
             opt.close()
-    for a, b in zip(*trace):
-        for x, y in zip(a, b):
-            assert np.array_equal(np.asarray(x), np.asarray(y))
+    for other in trace[1:]:
+        for a, b in zip(trace[0], other):
+            for x, y in zip(a, b):
+                assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
 def test_batch_optimizer_matches_sequential_puppet():

@@ -37,7 +37,8 @@ class LqProblem(ctypes.Structure):
                 ("q_dev", ctypes.c_void_p), ("r_dev", ctypes.c_void_p),
                 ("K_dev", ctypes.c_void_p), ("C_dev", ctypes.c_void_p), ("P0_dev", ctypes.c_void_p), ("b0_dev", ctypes.c_void_p),
                 ("status_dev", ctypes.c_void_p), ("b_next_dev", ctypes.c_void_p),
-                ("ds_nd", ctypes.c_int32), ("ds_nk", ctypes.c_int32), ("ds_nu", ctypes.c_int32)]
+                ("ds_nd", ctypes.c_int32), ("ds_nk", ctypes.c_int32), ("ds_nu", ctypes.c_int32),
+                ("k_begin", ctypes.c_int32), ("k_end", ctypes.c_int32), ("Pt_dev", ctypes.c_void_p), ("bt_dev", ctypes.c_void_p)]
 
 
 _vp, _i32, _f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_double
@@ -105,6 +106,7 @@ _SIGNATURES = {
     "tg_batch_linearize": (ctypes.c_int, [_vp, _vp, _vp]),
     "tg_batch_initialize_from_state_device": (ctypes.c_int, [_vp, _f64, _vp, ctypes.c_uint64]),
     "tg_batch_deriv2_contract_device": (ctypes.c_int, [_vp, _vp, _vp]),
+    "tg_batch_deriv2_contract_device_range": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32]),
     "tg_tv_lq": (ctypes.c_int, [_i32, ctypes.POINTER(LqProblem)]),
     "tg_adjoint_sweep": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tg_tangent_rollout": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -115,6 +117,8 @@ _SIGNATURES = {
     "tg_copy_rows": (ctypes.c_int, [_i32, _i32, ctypes.c_uint64, _vp, _vp, _vp, _vp]),
     "tg_device_synchronize": (ctypes.c_int, [_i32]),
     "tg_dopt_use_stream": (ctypes.c_int, [_i32, _i32]),
+    "tg_dopt_lane_stream": (_vp, [_i32, _i32]),
+    "tg_dopt_lane_wait": (ctypes.c_int, [_i32, _i32, _i32]),
     # multi-GPU: RCCL all-gather / scalar reductions (csrc/comm.hip)
     "tg_comm_unique_id": (ctypes.c_int, [_vp]),
     "tg_comm_create": (_vp, [_i32, _i32, _i32, _vp]),
@@ -141,6 +145,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise LibraryError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        # HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and two streams that share a queue run
+        # one after the other.  The device-resident optimiser keeps up to four sweeps / kernels in flight in stream lanes of their own beside
+        # the batches' streams (discopt/batch_doptimizer.py): with four queues the lanes collide and its pipelined Newton step runs at the
+        # speed of the unpipelined one (67 instead of 39 ms at 32 seeds, measured).  A default only -- a value the user has set is kept --,
+        # and it must be in the environment before the HIP runtime initialises, i.e. before the library that links it is loaded.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         L = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in _SIGNATURES.items():
             fn = getattr(L, name)

@@ -84,8 +84,14 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
     const size_t sN = (size_t)s * N;
     const bool affine = a.q_dev != nullptr;
     const int nxh = a.hz_nx, hzR = a.hz_R;
-    // terminal condition P_N = Qf, b_N = q_N
-    {
+    // terminal condition P_N = Qf, b_N = q_N -- or, for a sweep over the steps [k_begin, k_end) of the horizon (tg_lq_problem::k_*), the
+    // (P, b) an earlier launch left at step k_end (its P0 / b0 outputs)
+    const int kb = a.k_begin, ke = a.k_end > 0 ? a.k_end : N;
+    if (a.Pt_dev) {
+        const double *Pt = a.Pt_dev + (size_t)s * nX * nX;
+        for (int e = tid; e < nX * nX; e += LQ_T) Pm[(e / nX) * ldx + e % nX] = Pt[e];
+        if (affine && a.bt_dev) for (int i = tid; i < nX; i += LQ_T) bv[i] = a.bt_dev[(size_t)s * nX + i];
+    } else {
         const double *Qf = a.Qf_dev + (size_t)s * a.Qf_seed_stride;
         for (int e = tid; e < nX * nX; e += LQ_T) Pm[(e / nX) * ldx + e % nX] = Qf[e];
         if (affine) for (int i = tid; i < nX; i += LQ_T) bv[i] = a.q_dev[(sN + s + N) * nX + i];
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
 #pragma unroll
         for (int i = 0; i < PB; i++) { const int e = tid + i * LQ_T; if (e < nX * nU) Bm[e] = preB[i]; }
     };
-    prefetch(N - 1);
+    prefetch(ke - 1);
     commit();
     __syncthreads();
 
@@ -126,8 +132,8 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
 #if defined(TG_PROFILE)
     long long lq_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lq_last = (long long)__builtin_amdgcn_s_memtime();
 #endif
-    for (int k = N - 1; k >= 0; k--) {
-        if (k > 0) prefetch(k - 1);
+    for (int k = ke - 1; k >= kb; k--) {
+        if (k > kb) prefetch(k - 1);
         const double *hz = a.hz_dev ? a.hz_dev + (sN + k) * (size_t)hzR * hzR : nullptr;
         if (a.b_next_dev && affine) for (int i = tid; i < nX; i += LQ_T) a.b_next_dev[(sN + k) * nX + i] = bv[i];    // b_{k+1}
         // ---- phase 1: PA tile (registers), B'P, B'b ----------------------------------------------------
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
                 for (int j = 0; j < TS; j++) Pm[(i0 + i) * ldx + j0 + j] = acc[TS * i + j];
         }
         if (affine) for (int i = tid; i < nX; i += LQ_T) bv[i] = bn[i];
-        if (k > 0) commit();
+        if (k > kb) commit();
         __syncthreads();
         LQ_STAMP(4);
         // ---- phase 6: P <- (P + P')/2, one thread per unordered pair --------------------------------------------
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(LQ_T) void k_tv_lq(const tg_lq_problem a) {
 #endif
     if (a.P0_dev) for (int e = tid; e < nX * nX; e += LQ_T) a.P0_dev[(size_t)s * nX * nX + e] = Pm[(e / nX) * ldx + e % nX];
     if (a.b0_dev && affine) for (int i = tid; i < nX; i += LQ_T) a.b0_dev[(size_t)s * nX + i] = bv[i];
-    if (a.status_dev && tid == 0) a.status_dev[s] = s_sing ? TG_SINGULAR : TG_OK;
+    if (a.status_dev && tid == 0) a.status_dev[s] = (s_sing || (a.Pt_dev && a.status_dev[s] != TG_OK)) ? TG_SINGULAR : TG_OK;      // (a later chunk of a chunked sweep keeps an earlier chunk's verdict)
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -745,7 +751,12 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
     const size_t sN = (size_t)s * N;
     const bool affine = a.q_dev != nullptr;
     const int nxh = a.hz_nx, hzR = a.hz_R;
-    {
+    const int kb = a.k_begin, ke = a.k_end > 0 ? a.k_end : N;      // the steps of this launch (tg_lq_problem::k_*)
+    if (a.Pt_dev) {
+        const double *Pt = a.Pt_dev + (size_t)s * nX * nX;
+        for (int e = tid; e < nX * nX; e += LQM_T) Pm[(e / nX) * ldx + e % nX] = Pt[e];
+        if (affine && a.bt_dev) for (int i = tid; i < nX; i += LQM_T) bv[i] = a.bt_dev[(size_t)s * nX + i];
+    } else {
         const double *Qf = a.Qf_dev + (size_t)s * a.Qf_seed_stride;
         for (int e = tid; e < nX * nX; e += LQM_T) Pm[(e / nX) * ldx + e % nX] = Qf[e];
         if (affine) for (int i = tid; i < nX; i += LQM_T) bv[i] = a.q_dev[(sN + s + N) * nX + i];
@@ -777,7 +788,7 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
 #pragma unroll
         for (int i = 0; i < PBN; i++) { const int e = tid + i * LQM_T; if (e < nX * nU) Bm[e] = preB[i]; }
     };
-    prefetch(N - 1);
+    prefetch(ke - 1);
     commit();
     __syncthreads();
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
@@ -786,8 +797,8 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
 #if defined(TG_PROFILE)
     long long lq_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lq_last = (long long)__builtin_amdgcn_s_memtime();
 #endif
-    for (int k = N - 1; k >= 0; k--) {
-        if (k > 0) prefetch(k - 1);
+    for (int k = ke - 1; k >= kb; k--) {
+        if (k > kb) prefetch(k - 1);
         const double *hz = a.hz_dev ? a.hz_dev + (sN + k) * (size_t)hzR * hzR : nullptr;
         if (a.b_next_dev && affine) for (int i = tid; i < nX; i += LQM_T) a.b_next_dev[(sN + k) * nX + i] = bv[i];    // b_{k+1}
         // ---- phase 1: P A tiles (registers), P B -> LDS, B'b ---------------------------------------------------
@@ -1001,7 +1012,7 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
             }
         }
         if (affine) for (int i = tid; i < nX; i += LQM_T) bv[i] = bn[i];
-        if (k > 0) commit();
+        if (k > kb) commit();
         __syncthreads();
         LQ_STAMP(4);
         // ---- phase 6: the lower triangle is the mirror of the upper one -------------------------------------------------
@@ -1023,7 +1034,7 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_mfma(const tg_lq_problem a) {
 #endif
     if (a.P0_dev) for (int e = tid; e < nX * nX; e += LQM_T) a.P0_dev[(size_t)s * nX * nX + e] = Pm[(e / nX) * ldx + e % nX];
     if (a.b0_dev && affine) for (int i = tid; i < nX; i += LQM_T) a.b0_dev[(size_t)s * nX + i] = bv[i];
-    if (a.status_dev && tid == 0) a.status_dev[s] = s_sing ? TG_SINGULAR : TG_OK;
+    if (a.status_dev && tid == 0) a.status_dev[s] = (s_sing || (a.Pt_dev && a.status_dev[s] != TG_OK)) ? TG_SINGULAR : TG_OK;      // (a later chunk of a chunked sweep keeps an earlier chunk's verdict)
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1150,7 +1161,8 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_ds(const tg_lq_problem a0) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     constexpr int ldx = 16 * NT, NW = LQM_T / 64;
     const int s = __builtin_amdgcn_readfirstlane(a0.select_dev ? a0.select_dev[blockIdx.x] : (int)blockIdx.x);
-    int cur = 0, k = a0.horizon - 1;
+    const int kb = a0.k_begin, ke = a0.k_end > 0 ? a0.k_end : a0.horizon;      // the steps of this launch (tg_lq_problem::k_*)
+    int cur = 0, k = ke - 1;
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
     constexpr int T1 = 4;                              // chains per wave in phase 1 (P A and P B tiles in one list: at most 32 tiles, see tg_tv_lq)
     // phase 3: wave 0 factorises gamma; the wave that shares its SIMD (a workgroup's waves are dealt to the four SIMDs in turn: wave 4) stays out of
@@ -1163,13 +1175,19 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_ds(const tg_lq_problem a0) {
         for (int i = tid; i < L.total; i += LQM_T) lds[i] = 0.0;
         if (tid == 0) s_sing = 0;
         __syncthreads();
-        const double *Qf = a.Qf_dev + (size_t)s * a.Qf_seed_stride;
-        for (int e = tid; e < nX * nX; e += LQM_T) Pm[(e / nX) * ldx + e % nX] = Qf[e];
-        if (affine) for (int i = tid; i < nX; i += LQM_T) bv[i] = a.q_dev[(sN + s + N) * nX + i];
-        fill_AD(N - 1, lds + L.AD);
-        fill_B(N - 1);
-        if (tid < nq - nd) lds[L.avs + tid] = load_av(N - 1);
-        if (affine && tid < nU) lds[L.rn + tid] = a.r_dev[(sN + N - 1) * nU + tid];
+        if (a.Pt_dev) {
+            const double *Pt = a.Pt_dev + (size_t)s * nX * nX;
+            for (int e = tid; e < nX * nX; e += LQM_T) Pm[(e / nX) * ldx + e % nX] = Pt[e];
+            if (affine && a.bt_dev) for (int i = tid; i < nX; i += LQM_T) bv[i] = a.bt_dev[(size_t)s * nX + i];
+        } else {
+            const double *Qf = a.Qf_dev + (size_t)s * a.Qf_seed_stride;
+            for (int e = tid; e < nX * nX; e += LQM_T) Pm[(e / nX) * ldx + e % nX] = Qf[e];
+            if (affine) for (int i = tid; i < nX; i += LQM_T) bv[i] = a.q_dev[(sN + s + N) * nX + i];
+        }
+        fill_AD(ke - 1, lds + L.AD);
+        fill_B(ke - 1);
+        if (tid < nq - nd) lds[L.avs + tid] = load_av(ke - 1);
+        if (affine && tid < nU) lds[L.rn + tid] = a.r_dev[(sN + ke - 1) * nU + tid];
         __syncthreads();
     }
     // the upper-triangle tiles of the new P that this wave owns in phases 3 .. 5 (wave 0 factorises gamma meanwhile)
@@ -1191,11 +1209,11 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_ds(const tg_lq_problem a0) {
 #if defined(TG_PROFILE)
     long long lq_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lq_last = (long long)__builtin_amdgcn_s_memtime();
 #endif
-    for (; k >= 0; k--) {
+    for (; k >= kb; k--) {
         double pav = 0.0, prn = 0.0;      // A[v_m][Qk_m] and r of step k - 1: requested at the head of the step, committed at its end
         {   // ---- phase 1: T = P A (NT x NTC tiles) and P B (NT x NUT tiles) as one list of chains ------------------------------------------
             LQ_DS_PHASE;
-            if (k > 0) { fill_AD(k - 1, lds + L.AD + (cur ^ 1) * L.adsz); pav = load_av(k - 1); if (affine && tid < nU) prn = a.r_dev[(sN + k - 1) * nU + tid]; }
+            if (k > kb) { fill_AD(k - 1, lds + L.AD + (cur ^ 1) * L.adsz); pav = load_av(k - 1); if (affine && tid < nU) prn = a.r_dev[(sN + k - 1) * nU + tid]; }
             if (a.b_next_dev && affine) for (int i = tid; i < nX; i += LQM_T) a.b_next_dev[(sN + k) * nX + i] = bv[i];    // b_{k+1}
             const int n_pa = NT * NTC, n_all = n_pa + NT * NUT;
             int t1_[T1], tc_[T1], bs_[T1];
@@ -1387,7 +1405,7 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_ds(const tg_lq_problem a0) {
             if (tid < nU && !bb_in_tile) { const double rw = affine ? wv[tid] + rv[tid] : 0.0; rv[tid] = rw; G[tid * ldw + nU] = rw; }   // r_k + B'b
             LQ_LDS_SYNC();
             LQ_STAMP(1);
-            if (k > 0) fill_B(k - 1);      // B_k is dead from here on
+            if (k > kb) fill_B(k - 1);      // B_k is dead from here on
         }
         {   // ---- phase 3: wave 0 factorises gamma while the others accumulate Q_k + A'(P A) on the upper-triangle tiles --------------
             LQ_DS_PHASE;
@@ -1542,8 +1560,8 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_ds(const tg_lq_problem a0) {
                 }
             }
             if (affine) for (int i = tid; i < nX; i += LQM_T) bv[i] = bn[i];
-            if (k > 0 && tid < nq - nd) lds[L.avs + (cur ^ 1) * 32 + tid] = pav;
-            if (k > 0 && affine && tid < nU) lds[L.rn + tid] = prn;
+            if (k > kb && tid < nq - nd) lds[L.avs + (cur ^ 1) * 32 + tid] = pav;
+            if (k > kb && affine && tid < nU) lds[L.rn + tid] = prn;
             LQ_LDS_SYNC();
             LQ_STAMP(4);
             for (int d = 1 + wave; d < nX; d += NW)
@@ -1566,7 +1584,7 @@ __global__ __launch_bounds__(LQM_T) void k_tv_lq_ds(const tg_lq_problem a0) {
         LQ_DS_PHASE;
         if (a.P0_dev) for (int e = tid; e < nX * nX; e += LQM_T) a.P0_dev[(size_t)s * nX * nX + e] = Pm[(e / nX) * ldx + e % nX];
         if (a.b0_dev && affine) for (int i = tid; i < nX; i += LQM_T) a.b0_dev[(size_t)s * nX + i] = bv[i];
-        if (a.status_dev && tid == 0) a.status_dev[s] = s_sing ? TG_SINGULAR : TG_OK;
+        if (a.status_dev && tid == 0) a.status_dev[s] = (s_sing || (a.Pt_dev && a.status_dev[s] != TG_OK)) ? TG_SINGULAR : TG_OK;      // (a later chunk of a chunked sweep keeps an earlier chunk's verdict)
     }
 }
 
@@ -2025,16 +2043,18 @@ namespace {
 // switching lanes (kernels on lanes 1 and 2 run side by side) and joins by going back to lane 0 -- no events to manage.
 thread_local int g_lane = 0;
 std::mutex g_lane_mutex;
-std::map<int, std::array<hipStream_t, 2>> g_lane_streams;
-hipStream_t dopt_stream(int device) {
-    if (g_lane == 0) return nullptr;
+constexpr int DOPT_LANES = 4;
+std::map<int, std::array<hipStream_t, DOPT_LANES>> g_lane_streams;
+hipStream_t dopt_lane_stream(int device, int lane) {
+    if (lane <= 0 || lane > DOPT_LANES) return nullptr;
     std::lock_guard<std::mutex> lock(g_lane_mutex);
     auto it = g_lane_streams.find(device);
-    if (it == g_lane_streams.end()) it = g_lane_streams.emplace(device, std::array<hipStream_t, 2>{nullptr, nullptr}).first;
-    hipStream_t &st = it->second[g_lane - 1];
+    if (it == g_lane_streams.end()) { std::array<hipStream_t, DOPT_LANES> none{}; it = g_lane_streams.emplace(device, none).first; }
+    hipStream_t &st = it->second[lane - 1];
     if (!st && hipStreamCreate(&st) != hipSuccess) st = nullptr;     // (falls back to the default stream: still correct)
     return st;
 }
+hipStream_t dopt_stream(int device) { return dopt_lane_stream(device, g_lane); }
 }  // namespace
 
 extern "C" {
@@ -2045,6 +2065,9 @@ int tg_tv_lq(int32_t device, const tg_lq_problem *p) {
     if ((p->q_dev == nullptr) != (p->r_dev == nullptr)) return fail(TG_ERR_INVALID, "q and r must be given together");
     if (p->hz_dev && (p->hz_R < p->hz_nx + p->nU || p->hz_nx > p->nX)) return fail(TG_ERR_INVALID, "bad curvature block sizes");
     if (p->nU > 64) return fail(TG_ERR_UNSUPPORTED, "more than 64 inputs");
+    if (p->k_begin < 0 || p->k_end < 0 || p->k_end > p->horizon || (p->k_end > 0 && p->k_begin >= p->k_end) || (p->k_end == 0 && p->k_begin != 0))
+        return fail(TG_ERR_INVALID, "bad step range of the sweep");
+    if (p->k_end > 0 && p->k_end < p->horizon && !p->Pt_dev) return fail(TG_ERR_INVALID, "a sweep that ends before the horizon needs the terminal (P, b) of the steps behind it");
     if (p->ds_nd < 0 || p->ds_nk < 0 || p->ds_nu < 0 || (p->ds_nd > 0 && (2 * (p->ds_nd + p->ds_nk) != p->nX || p->ds_nu + p->ds_nk != p->nU)))
         return fail(TG_ERR_INVALID, "DSystem block structure does not match nX / nU");
     // size class: tile size TS with nX <= 16*TS (one tile per thread), prefetch registers RI*CI >= nX*ceil(nX/32)/8
@@ -2266,8 +2289,30 @@ int tg_device_synchronize(int32_t device) {
 
 int tg_dopt_use_stream(int32_t device, int32_t lane) {
     (void)device;
-    if (lane < 0 || lane > 2) return fail(TG_ERR_INVALID, "stream lane must be 0 (default stream), 1 or 2");
+    if (lane < 0 || lane > DOPT_LANES) return fail(TG_ERR_INVALID, "stream lane must be 0 (default stream) .. 4");
     g_lane = lane;
+    return TG_SUCCESS;
+}
+
+/* The HIP stream of lane 1 .. 4 (hipStream_t as void *; created on first use), e.g. for tg_batch_set_stream: a batch's kernels then
+ * run in that lane. */
+void *tg_dopt_lane_stream(int32_t device, int32_t lane) {
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    return (void *)dopt_lane_stream(device, lane);
+}
+
+/* Order lane `waiter` after everything enqueued so far in lane `signal` (an event; no host synchronisation).  Lanes 1 .. 4. */
+int tg_dopt_lane_wait(int32_t device, int32_t waiter, int32_t signal) {
+    if (waiter < 1 || waiter > DOPT_LANES || signal < 1 || signal > DOPT_LANES || waiter == signal) return fail(TG_ERR_INVALID, "bad stream lanes");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t sw = dopt_lane_stream(device, waiter), ss = dopt_lane_stream(device, signal);
+    if (!sw || !ss) return fail(TG_ERR_HIP, "stream lane not available");
+    hipEvent_t ev = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, ss);
+    if (e == hipSuccess) e = hipStreamWaitEvent(sw, ev, 0);
+    hipEventDestroy(ev);          // (released once the recorded work has completed)
+    if (e != hipSuccess) return fail(TG_ERR_HIP, "event between stream lanes failed");
     return TG_SUCCESS;
 }
 }  // extern "C"

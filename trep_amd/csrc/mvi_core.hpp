@@ -235,7 +235,15 @@ struct RunArgs {
     double *lag1_out, *lag2_out;           // MODE_LAGRANGIAN: [batch][2][nq] (L_dq, L_ddq) and [batch][3][nq][nq] (L_dqdq, L_ddqdq, L_ddqddq), zeroed by the caller
     double *mirror;                        // rollout, optional: host-visible copy of the final state, (q2 [batch][nq] | p2 [batch][nd] | lambda1 [batch][nc] |
                                            // int32 iterations [batch] | int32 status [batch]) -- pinned host memory written by the kernel (tg_batch_step)
+    // launch over a SUBSET of the batch's trajectories (the k-chunks of the pipelined discopt Newton step): workgroup-trajectory i < remap_count
+    // is trajectory (i / remap_len) * remap_stride + remap_off + i % remap_len of the batch; remap_len = 0: the identity
+    int remap_len, remap_stride, remap_off, remap_count;
 };
+// which trajectory of the batch a launch's i-th trajectory is (RunArgs::remap_*); A.batch for an index past the subset (an idle team)
+template <class ARGS> TG_HD int tg_remap_trajectory(const ARGS &A, int i) {
+    if (A.remap_len <= 0) return i;
+    return i < A.remap_count ? (i / A.remap_len) * A.remap_stride + A.remap_off + i % A.remap_len : A.batch;
+}
 
 // The kernels read the schedule (DevProg) and the launch arguments (RunArgs) through CONSTANT-address-space references:
 // every field access is then a scalar load from the kernel-argument segment.  Left alone the optimiser hoists all of those

@@ -49,7 +49,7 @@ double *lds = tg_lds_base();
         team = 0; lane = threadIdx.x & 63;
     }
     const int block = MODE == tg::MODE_ROLLOUT ? tg_xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-    const int traj = block * (64 / SPEC_TEAM) + team;
+    const int traj = tg::tg_remap_trajectory(A, block * (64 / SPEC_TEAM) + team);
     constexpr int stride = MODE == tg::MODE_DERIV2Z ? SpecProg::e_lds_per_team : (MODE == tg::MODE_DERIV1 ? SpecProg::d_lds_per_team : SpecProg::lds_per_team);
     tg::run_trajectory<SPEC_TEAM, MODE, SPEC_SPRINGS, const SpecProg, std::remove_reference<decltype(A)>::type, PIVOT>(P, A, lds + (size_t)team * stride, lane, traj, wave, spec_waves<MODE>());
 }

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DE
     tg::CProg &P = *(tg::CProg *)Pg;
     const int team = threadIdx.x / TEAM, lane = threadIdx.x % TEAM;
     const int block = MODE == tg::MODE_ROLLOUT ? tg_xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-    const int traj = block * (64 / TEAM) + team;
+    const int traj = tg::tg_remap_trajectory(A, block * (64 / TEAM) + team);
     const int stride = MODE == tg::MODE_DERIV2Z ? P.e_lds_per_team : (MODE == tg::MODE_DERIV1 ? P.d_lds_per_team : (MODE == tg::MODE_DYN_DERIV1 ? P.g_lds_per_team : P.lds_per_team));
     tg::run_trajectory<TEAM, MODE, SPRINGS>(P, A, lds + (size_t)team * stride, lane, traj);
 }
@@ -206,7 +206,7 @@ int launch_team(tg_batch *b, const tg::RunArgs &A, int grid, size_t lds) {
 int launch(tg_batch *b, tg::RunArgs &A) {
     b->mirror_valid = false;
     const int team = b->sys->team, per_block = 64 / team;
-    const int grid = (A.batch + per_block - 1) / per_block;
+    const int grid = ((A.remap_len > 0 ? A.remap_count : A.batch) + per_block - 1) / per_block;
     const int per_team = A.mode == tg::MODE_DERIV2Z ? b->P.e_lds_per_team : (A.mode == tg::MODE_DERIV1 ? b->P.d_lds_per_team : (A.mode == tg::MODE_DYN_DERIV1 ? b->P.g_lds_per_team : b->P.lds_per_team));
     const size_t lds = (size_t)per_block * per_team * sizeof(double);
     if (lds > 160 * 1024) return fail(TG_ERR_UNSUPPORTED, "system too large for the LDS-resident kernel");
@@ -950,6 +950,18 @@ int tg_batch_deriv2_contract_device(tg_batch *b, const double *z_dev, double *hz
     HIP_TRY(hipSetDevice(b->device));
     tg::RunArgs A = base_args(b, tg::MODE_DERIV2Z);
     A.z = z_dev; A.hz = hz_dev;
+    return launch(b, A);
+}
+
+int tg_batch_deriv2_contract_device_range(tg_batch *b, const double *z_dev, double *hz_dev, int32_t horizon, int32_t k_begin, int32_t k_end) {
+    if (!b || !z_dev || !hz_dev) return fail(TG_ERR_INVALID, "null argument");
+    if (horizon <= 0 || b->batch % horizon != 0 || k_begin < 0 || k_end > horizon || k_begin >= k_end) return fail(TG_ERR_INVALID, "bad step range");
+    if (b->P.n_true_springs) return fail(TG_ERR_UNSUPPORTED, "V_dqdqdq() is undefined for LinearSpring (as in the reference): no second derivatives");
+    if (b->t2 == b->t1) return fail(TG_ERR_STATE, "Integrator has not solved the next time step yet.");
+    HIP_TRY(hipSetDevice(b->device));
+    tg::RunArgs A = base_args(b, tg::MODE_DERIV2Z);
+    A.z = z_dev; A.hz = hz_dev;
+    A.remap_len = k_end - k_begin; A.remap_stride = horizon; A.remap_off = k_begin; A.remap_count = (b->batch / horizon) * (k_end - k_begin);
     return launch(b, A);
 }
 

@@ -103,7 +103,7 @@ class BatchDOptimizer(object):
 
 
     def __init__(self, dsys, Xd, Ud, Q, R, Qf=None, device=0, armijo_chunk=None, first_method_iterations=10,
-                 predictor="reference", overlap_sweeps="auto"):
+                 predictor="reference", overlap_sweeps="auto", pipeline_newton="auto"):
         self.dsys = dsys
         ds = dsys
         Xd = np.asarray(Xd, dtype=float)
@@ -167,6 +167,23 @@ class BatchDOptimizer(object):
             self.K2, self.C2 = pool.empty((S, N, nU, nX)), pool.empty((S, N, nU))
             self.dX2, self.dU2 = pool.empty((S, N + 1, nX)), pool.empty((S, N, nU))
             self.dcost2, self.lq_status2 = pool.empty((S,)), pool.empty((S,), np.int32)
+        # pipelined Newton step (whenever the sweeps run side by side, i.e. the seeds leave half of the CUs idle): the projection sweep,
+        # the z-contracted second derivatives and the Newton-model sweep run chunk by chunk of the horizon in three stream lanes, the
+        # quasi-Newton sweep in a fourth (projection_quasi_and_newton_model).  TREPAMD_NEWTON_PIPELINE=0/1 overrides, TREPAMD_NEWTON_CHUNKS
+        env_pipe = os.environ.get("TREPAMD_NEWTON_PIPELINE")
+        if pipeline_newton == "auto":
+            self.pipeline = self.overlap if env_pipe is None else (env_pipe == "1" and self.overlap)      # (128 seeds on 256 CUs still gain 5 %)
+        else:
+            self.pipeline = bool(pipeline_newton) and self.overlap
+        self.pipeline_chunks = int(os.environ.get("TREPAMD_NEWTON_CHUNKS", "8"))
+        if self.pipeline:
+            self.Pc = [(pool.empty((S, nX, nX)), pool.empty((S, nX))) for _ in range(4)]      # (P, b) carried between the chunks: two per sweep
+            self.lq_status3 = pool.empty((S,), np.int32)
+            stream = self.L.tg_dopt_lane_stream(device, 3)
+            if not stream:
+                raise _lib.LibraryError(self.L.tg_last_error().decode())
+            self.lin.set_stream(stream)       # the horizon batch's kernels (linearisation, second derivatives) run in lane 3
+        self._newton_ready = None     # (dcost [S], failed [S]) of the pipelined Newton model of this step, or None
         self._quasi_ready = None      # (dcost [S], failed [S]) of the side-by-side quasi sweep of this step, or None
         self._adjoint_ready = False   # Z holds the adjoint of the current iterate (written by the projection sweep)
         self.fuse_adjoint = os.environ.get("TREPAMD_SEPARATE_ADJOINT") is None      # (the env switch is for A/B measurements)
@@ -251,7 +268,9 @@ class BatchDOptimizer(object):
                           "using the dense sweep")
             self._ds = (0, 0, 0)
 
-    def _lq(self, seeds, Q, Qf, R, hz, affine, K, C=None, status=None, collect=True, b_next=None):
+    def _lq(self, seeds, Q, Qf, R, hz, affine, K, C=None, status=None, collect=True, b_next=None, k_range=None, terminal=None, carry=None):
+        """k_range = (k0, k1): sweep only the steps k1 - 1 ... k0; terminal = (P, b) device arrays at step k1 (None: the horizon's end);
+        carry = (P, b) arrays that receive (P, b) at step k0 (tg_lq_problem::k_begin / k_end / Pt_dev / bt_dev / P0_dev / b0_dev)."""
         sel, n = self._select(seeds)
         if n == 0:
             return
@@ -267,7 +286,9 @@ class BatchDOptimizer(object):
         p.hz_R, p.hz_nx = self._R, self._nxh
         p.q_dev, p.r_dev = (self.q.ptr, self.r.ptr) if affine else (None, None)
         p.K_dev, p.C_dev = K.ptr, (C.ptr if C is not None else None)
-        p.P0_dev = p.b0_dev = None
+        p.P0_dev, p.b0_dev = (carry[0].ptr, carry[1].ptr) if carry is not None else (None, None)
+        p.k_begin, p.k_end = (int(k_range[0]), int(k_range[1])) if k_range is not None else (0, 0)
+        p.Pt_dev, p.bt_dev = (terminal[0].ptr, terminal[1].ptr) if terminal is not None else (None, None)
         p.b_next_dev = b_next.ptr if (b_next is not None and affine) else None
         p.status_dev = status.ptr
         p.ds_nd, p.ds_nk, p.ds_nu = self._ds
@@ -320,6 +341,67 @@ class BatchDOptimizer(object):
         failed = np.zeros(S, dtype=bool)
         self._lq_collect(None, self.lq_status2, into=failed)
         self._quasi_ready = (self.dcost2.get(), failed)
+
+    def _chunks(self):
+        """The horizon cut into pipeline_chunks ranges of steps, last range first (the sweeps run backwards)."""
+        n = max(1, min(self.pipeline_chunks, self.N // 16))
+        edges = np.linspace(0, self.N, n + 1).astype(int)
+        return [(int(edges[i]), int(edges[i + 1])) for i in range(n)][::-1]
+
+    def projection_quasi_and_newton_model(self):
+        """Everything between the linearisation and the line search of a Newton step, for EVERY seed, as a pipeline over chunks of the
+        horizon (needs q, r: gradients_and_cost first):
+
+            lane 1  projection gain with the adjoint z riding on it        chunk c: steps [k0, k1)
+            lane 3  second derivatives contracted with z                   chunk c after lane 1's chunk c        (the horizon batch's stream)
+            lane 4  LQ sweep of the Newton model, then its tangent rollout  chunk c after lane 3's chunk c
+            lane 2  quasi-Newton LQ sweep + tangent rollout (the fallback direction), whole horizon
+
+        A sweep continues a chunk from the (P, b) the previous chunk left (tg_lq_problem::Pt_dev), so gains and directions are bit for bit
+        those of the three sweeps run one after the other (doptimizer.py:319-402 runs them in that order); what changes is that the
+        seed-count-independent serial time of a Newton step is one sweep (plus a chunk of each of the others) instead of three.
+        Leaves the Newton direction in dX, dU (_newton_ready) and the quasi direction in the second buffers (_quasi_ready)."""
+        S, N, nX, nU = self.S, self.N, self.nX, self.nU
+        self._ensure_newton_buffers()
+        L, dev = self.L, self.device
+        self._check(L.tg_device_synchronize(dev))
+        chunks = self._chunks()
+        try:
+            self._check(L.tg_dopt_use_stream(dev, 2))
+            self._lq(None, self.Q, self.Qf, self.R, None, True, self.K2, self.C2, status=self.lq_status2, collect=False)
+            self._check(L.tg_tangent_rollout(dev, S, N, nX, nU, None, self.A.ptr, self.B.ptr, self.K2.ptr, self.C2.ptr,
+                                             self.q.ptr, self.r.ptr, self.dX2.ptr, self.dU2.ptr, self.dcost2.ptr))
+            for c, (k0, k1) in enumerate(chunks):
+                first = c == 0
+                self._check(L.tg_dopt_use_stream(dev, 1))
+                self._lq(None, self.Ix, self.Ix, self.Iu, None, True, self.Kproj, None, collect=False, b_next=self.Z, k_range=(k0, k1),
+                         terminal=None if first else self.Pc[(c - 1) % 2], carry=self.Pc[c % 2])
+                self._check(L.tg_dopt_lane_wait(dev, 3, 1))
+                self._check(L.tg_batch_deriv2_contract_device_range(self.lin._h, self.Z.ptr, self.HZ.ptr, N, k0, k1))
+                self._check(L.tg_dopt_lane_wait(dev, 4, 3))
+                self._check(L.tg_dopt_use_stream(dev, 4))
+                self._lq(None, self.Q, self.Qf, self.R, self.HZ, True, self.K, self.C, status=self.lq_status3, collect=False, k_range=(k0, k1),
+                         terminal=None if first else self.Pc[2 + (c - 1) % 2], carry=self.Pc[2 + c % 2])
+            self._check(L.tg_tangent_rollout(dev, S, N, nX, nU, None, self.A.ptr, self.B.ptr, self.K.ptr, self.C.ptr,
+                                             self.q.ptr, self.r.ptr, self.dX.ptr, self.dU.ptr, self.dcost.ptr))
+        finally:
+            self._check(L.tg_dopt_use_stream(dev, 0))
+        self._check(L.tg_device_synchronize(dev))
+        self._adjoint_ready = True
+        self._lq_collect(None, self.lq_status)
+        failed = np.zeros(S, dtype=bool)
+        self._lq_collect(None, self.lq_status2, into=failed)
+        self._quasi_ready = (self.dcost2.get(), failed)
+        failed3 = np.zeros(S, dtype=bool)
+        self._lq_collect(None, self.lq_status3, into=failed3)
+        self._newton_ready = (self.dcost.get(), failed3)
+
+    def _take_newton_direction(self, seeds):
+        """dcost of `seeds` for the Newton direction the pipeline left in dX, dU (rows of other seeds are overwritten by whoever takes them)."""
+        dc, failed = self._newton_ready
+        idx = np.arange(self.S) if seeds is None else np.asarray(seeds, dtype=np.int64)
+        self._lq_failed[idx[failed[idx]]] = True
+        return dc[idx]
 
     def _take_quasi_direction(self, seeds):
         """dX, dU of `seeds` (None = all) <- the quasi direction computed beside the projection gain; returns their dcost."""
@@ -433,7 +515,10 @@ class BatchDOptimizer(object):
         self._quasi_ready = None
         cost0 = self.gradients_and_cost()                       # (q, r do not depend on the projection gain; the sweeps below use them)
         newton = self.fuse_adjoint and any(m == "newton" for m in methods[active])    # then the projection sweep also carries the adjoint
-        if self.overlap and any(m in ("quasi", "newton") for m in methods[active]):
+        self._newton_ready = None
+        if self.pipeline and newton:
+            self.projection_quasi_and_newton_model()
+        elif self.overlap and any(m in ("quasi", "newton") for m in methods[active]):
             self.projection_gain_and_quasi_direction(with_adjoint=newton)
         else:
             self.projection_gain(with_adjoint=newton)
@@ -448,6 +533,9 @@ class BatchDOptimizer(object):
                     continue
                 if name == "quasi" and self._quasi_ready is not None:
                     dcost0[seeds] = self._take_quasi_direction(None if len(seeds) == S else seeds)
+                    continue
+                if name == "newton" and self._newton_ready is not None:
+                    dcost0[seeds] = self._take_newton_direction(None if len(seeds) == S else seeds)
                     continue
                 self.descent_direction(None if len(seeds) == S else seeds, name)
                 dc = self.dcost.get()
