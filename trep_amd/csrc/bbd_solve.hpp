@@ -134,7 +134,11 @@ __device__ __noinline__ bool gj_bbd(double *A_generic, BbdRows<NG + NB> rows, do
         bad = bad || !(fabs(trp) * (GUARD * tmax) < 1.0);
         if (tl) XT[lane] = tr[T] * trp;
     }
+#if !defined(TG_MOCK_TIMING)      // (timing mock, mvi_core.hpp: the guards are evaluated and ignored)
     if (__any(bad ? 1 : 0)) return false;
+#else
+    asm volatile("" :: "v"(bad ? 1 : 0));
+#endif
     asm volatile("" ::: "memory");
     // ---- stage 3: solutions.  trailing variables straight, own variables by back-substitution from the border's
     if (tl) A[to + NF] = tr[T] * trp;

@@ -107,8 +107,13 @@ int launch_mode(const tg::RunArgs *A, tg::RunArgs *slot, int grid, size_t lds, h
 
 extern "C" {
 const int *tg_spec_sizes(void) {
+#if defined(TG_MOCK_REAL_LDS)      // timing mock with aliased LDS areas (tools/mock_third_wave.py): answer with the real schedule's slice
+    constexpr int lds_doubles = TG_MOCK_REAL_LDS;
+#else
+    constexpr int lds_doubles = SpecProg::lds_per_team;
+#endif
     static const int s[8] = {(int)sizeof(tg::DevProg), (int)sizeof(tg::RunArgs), SpecProg::nq, SpecProg::nd, SpecProg::nc, SpecProg::n_items,
-                             SpecProg::n_pairs, SpecProg::lds_per_team};
+                             SpecProg::n_pairs, lds_doubles};
     return s;
 }
 // hash of the generated header this library was compiled against (tg_system_spec_key; trep_amd/specialize.py passes it)
@@ -138,6 +143,9 @@ int tg_spec_debug_solve(const double *A_dev, double *x_dev, int *path_dev, int n
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int tg_spec_launch(int mode, const tg::RunArgs *A, tg::RunArgs *device_slot, int grid, size_t lds, void *stream) {
+#if defined(TG_MOCK_TIMING)     // the mock's header aliases LDS areas: its slice is smaller than the one the host computed from the real schedule
+    if (mode == tg::MODE_ROLLOUT) lds = sizeof(double) * (size_t)SpecProg::lds_per_team * (64 / SPEC_TEAM);
+#endif
     switch (mode) {
     case tg::MODE_ROLLOUT:
         return A->exact_pivot ? launch_mode<tg::MODE_ROLLOUT, 1>(A, device_slot, grid, lds, (hipStream_t)stream)
