@@ -67,8 +67,15 @@ __device__ __forceinline__ BbdRows<NGB> bbd_rows(const int *tab_generic, int lan
     return t;
 }
 
-template <int NF, int LD, int NG, int NB, int T, class TVAR>
-__device__ __noinline__ bool gj_bbd(double *A_generic, BbdRows<NG + NB> rows, double *scratch_generic, int lane, TVAR tvar) {
+// The Newton update applied by the solver's own lanes (rollout kernels): the lane that forms x_i also forms q2_i - x_i and the rate
+// (q2_i - q1_i) / dt, or lambda_c - x_{nd + c} -- as a phase of its own the update is an LDS round trip and a barrier behind the solve.
+// nd = 0: no update (the solutions only go to the image's right-hand-side column, where every caller can read them).
+// The LDS offsets of the operands relative to the image are compile-time (BbdUpd: q2, q1, dq, lambda1 minus the image's offset; ND = 0: no
+// update -- the solutions only go to the image's right-hand-side column, where every caller can read them); only dt and 1 / dt travel.
+template <int ND_, int Q2_, int Q1_, int DQ_, int LAM_> struct BbdUpd { static constexpr int nd = ND_, q2 = Q2_, q1 = Q1_, dq = DQ_, lam = LAM_; };
+typedef BbdUpd<0, 0, 0, 0, 0> BbdNoUpdate;
+template <int NF, int LD, int NG, int NB, int T, class UP = BbdNoUpdate, class TVAR = const int *>
+__device__ __noinline__ bool gj_bbd(double *A_generic, BbdRows<NG + NB> rows, double *scratch_generic, int lane, TVAR tvar, double up_dt = 0.0, double up_inv_dt = 0.0) {
     typedef __attribute__((address_space(3))) double lds_double;
     lds_double *A = (lds_double *)A_generic, *U = (lds_double *)scratch_generic, *XT = U + T * (T + 1);
     constexpr int NCOL = NG + NB + 1, UL = T + 1;
@@ -83,6 +90,15 @@ __device__ __noinline__ bool gj_bbd(double *A_generic, BbdRows<NG + NB> rows, do
 #pragma unroll
     for (int j = 0; j < NG + NB; j++) wc[j] = rows.wc[j];
     // ---- stage 0: registers.  own rows: everything; border rows: the own columns only (the rest accumulates the Schur update)
+    // operands of the fused update, requested with the rows (the variable of this lane: an own row's, or -- lanes < T -- trailing variable `lane`)
+    // (a lane can hold two variables: an own row of its group, always a config, and -- lanes < T -- trailing variable `lane`)
+    const bool ut_cfg = lane < T && timg < UP::nd, ut_lam = lane < T && timg >= UP::nd, uo = r < NG && row >= 0;
+    double ut_q2 = 0.0, ut_q1 = 0.0, ut_lam_v = 0.0, uo_q2 = 0.0, uo_q1 = 0.0;
+    if constexpr (UP::nd > 0) {
+        const int ci = ut_cfg ? timg : 0, li = ut_lam ? timg - UP::nd : 0, oi = uo ? row : 0;
+        ut_q2 = A[UP::q2 + ci]; ut_q1 = A[UP::q1 + ci]; ut_lam_v = A[UP::lam + li];
+        uo_q2 = A[UP::q2 + oi]; uo_q1 = A[UP::q1 + oi];
+    }
     double a[NCOL];
     const bool own = r < NG, have = row >= 0;
     const int ro = (have ? row : 0) * LD;
@@ -141,7 +157,9 @@ __device__ __noinline__ bool gj_bbd(double *A_generic, BbdRows<NG + NB> rows, do
 #endif
     asm volatile("" ::: "memory");
     // ---- stage 3: solutions.  trailing variables straight, own variables by back-substitution from the border's
-    if (tl) A[to + NF] = tr[T] * trp;
+    const double xt = tr[T] * trp;
+    if (tl) A[to + NF] = xt;
+    double xo = 0.0;
     if (own && have) {
         double s = a[NG + NB];
 #pragma unroll
@@ -149,7 +167,14 @@ __device__ __noinline__ bool gj_bbd(double *A_generic, BbdRows<NG + NB> rows, do
             const int tc = ((wc[j] >> 8) & 0xFF) - 1;
             s = fma(-a[j], XT[tc >= 0 ? tc : 0], s);     // (a border column that does not exist holds zeros)
         }
-        A[ro + NF] = s * myrp;
+        xo = s * myrp;
+        A[ro + NF] = xo;
+    }
+    if constexpr (UP::nd > 0) {
+        auto rate = [&](double v, double q1v) { const double d = v - q1v, q = d * up_inv_dt; return fma(fma(-q, up_dt, d), up_inv_dt, q); };   // Core::over_dt
+        if (ut_cfg) { const double v = ut_q2 - xt; A[UP::q2 + timg] = v; A[UP::dq + timg] = rate(v, ut_q1); }
+        if (ut_lam) A[UP::lam + timg - UP::nd] = ut_lam_v - xt;
+        if (uo) { const double v = uo_q2 - xo; A[UP::q2 + row] = v; A[UP::dq + row] = rate(v, uo_q1); }
     }
     __syncthreads();
     BBD_STAMP(5);

@@ -5158,7 +5158,7 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
             bool ok;
 #if defined(__HIP_DEVICE_COMPILE__)
             const int nb4 = (P.nf + 3) >> 2;   // matrix size in blocks of 4 rows
-            bool bbd_done = false;
+            bool bbd_done = false, bbd_updated = false;
 #if !defined(TG_NO_BBD)
             if constexpr (TEAM == 64 && PIVOT == 0 && tg_static_bbd<typename std::remove_cv<PROG>::type>::value) {
                 // structured solve along the system's bordered-block-diagonal plan (bbd.hpp): no pivot search; a failed pivot guard
@@ -5166,7 +5166,17 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
                 // the branch is uniform).  Scratch: the Jacobian columns, dead between the matrix's assembly and the next evaluation.
                 typedef typename std::remove_cv<PROG>::type SP;
                 __builtin_amdgcn_s_setprio(TG_CHAIN_PRIO);
+#if !defined(TG_BBD_FUSED_UPDATE) || defined(TG_MOCK_TIMING)
                 bbd_done = gj_bbd<SP::nf, SP::df_ld, SP::bbd_ng, SP::bbd_nb, SP::bbd_t>(S + P.o_Df, bbd_tab_rows, S + P.o_J, lane, P.bbd_tvar);
+#else
+                // -DTG_BBD_FUSED_UPDATE (measured: 30.03 against 30.01 ms, i.e. nothing, for 2 spilled registers; off by default): the Newton update
+                // rides on the solve's last stage in the kernels whose update also forms the rates (implied by the world-frame evaluation's conditions)
+                typedef BbdUpd<SP::nd, SP::o_q2 - SP::o_Df, SP::o_q1 - SP::o_Df, SP::o_dq - SP::o_Df, SP::o_lam - SP::o_Df> Upd;
+                if constexpr (tg_static_wev<SP>::value) {
+                    bbd_done = gj_bbd<SP::nf, SP::df_ld, SP::bbd_ng, SP::bbd_nb, SP::bbd_t, Upd>(S + P.o_Df, bbd_tab_rows, S + P.o_J, lane, P.bbd_tvar, core.dt, core.inv_dt);
+                    bbd_updated = bbd_done;
+                } else bbd_done = gj_bbd<SP::nf, SP::df_ld, SP::bbd_ng, SP::bbd_nb, SP::bbd_t>(S + P.o_Df, bbd_tab_rows, S + P.o_J, lane, P.bbd_tvar);
+#endif
                 __builtin_amdgcn_s_setprio(0);
                 ok = true;
 #if defined(TG_MOCK_TIMING)
@@ -5231,10 +5241,16 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
             }
 #else
             if (!done) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (bbd_updated) { }      // (the structured solve applied the update itself)
+                else
+#endif
+                {
                 if (fuse_rates) TG_FOR(i, nd) { const double v = S[P.o_q2 + i] - S[P.o_Df + i * P.df_ld + P.nf]; S[P.o_q2 + i] = v; S[P.o_dq + i] = core.over_dt(v - S[P.o_q1 + i]); }
                 else
                 TG_FOR(i, nd) S[P.o_q2 + i] -= S[P.o_Df + i * P.df_ld + P.nf];
                 TG_FOR(c, nc) S[P.o_lam + c] -= S[P.o_Df + (nd + c) * P.df_ld + P.nf];
+                }
                 iterations++;
             }
 #endif
