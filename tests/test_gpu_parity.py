@@ -977,6 +977,54 @@ def test_structured_newton_solve_matches_the_pivoting_solvers(name):
     assert ps[0] == -1 and rc != 0, (ps, rc)
 
 
+def test_packed_newton_image_variant(monkeypatch):
+    """-DTG_BBD_PACKED (opt-in build of the specialised puppet kernel, compiled here by hipcc): the Newton matrix written straight into the
+    structured solve's own row order (csrc/bbd.hpp, BbdPacked) instead of the dense image.  The solver hook on the system's own pattern
+    (dense input scattered through the plan's map), the fallback after a failed guard (the packed image unpacked for the pivoting
+    solver) and a 100-step rollout against the default kernel: same Newton iteration counts, states equal to 1e-12."""
+    import trep_amd
+    from trep_amd import specialize, systems
+    system, _ = build("puppet40")
+    B, N = 32, 100
+    Q0 = systems.puppet_initial_conditions(system, B, seed=9)
+    K = systems.puppet_string_schedule(system, Q0[:, system.nQd:], N, DT)
+    runs = []
+    for packed in (False, True):
+        if packed:
+            monkeypatch.setenv("TREPAMD_SPEC_FLAGS", specialize.DEFAULT_FLAGS + " -DTG_BBD_PACKED")
+        mvi = trep_amd.BatchMidpointVI(system, B, specialize=True)
+        mvi.initialize_from_configs(0.0, Q0, DT, Q0)
+        X = mvi.rollout(N, DT, None, K)
+        it, st = mvi.status()
+        assert (st == 0).all()
+        _assert_kernels(mvi.kernel_info(), True, ("rollout",))
+        runs.append((X, it))
+        if packed:
+            one = trep_amd.BatchMidpointVI(system, 1, specialize=True)
+            plan, pat, tab = _newton_plan(one)
+            nf, nd = plan["nf"], plan["nd"]
+            rng = np.random.default_rng(31)
+            mats = [_newton_like(rng, pat, nd) for _ in range(16)]
+            rhs = [rng.standard_normal(nf) * np.where(np.arange(nf) < nd, 1.0, 1e-3) for _ in mats]
+            aug = np.array([np.hstack([A, b[:, None]]) for A, b in zip(mats, rhs)])
+            x, path = _kernel_newton_solve(one, aug)
+            assert (path == 1).all(), path
+            for A, b, xs in zip(mats, rhs, x):
+                xn = np.linalg.solve(A, b)
+                assert np.abs(xs - xn).max() < 1e-10 * np.abs(xn).max()
+            own = [((tab[i] & 0xFF) - 1) for i in range(16) if i < plan["ng"] and (tab[i] & 0xFF)]
+            a, c = [(i, j) for i in own for j in own if i < j and pat[i, j]][0]
+            A = mats[0].copy(); b = rhs[0]
+            A[a, a] = 0.0; A[c, c] = 0.0; A[a, c] = A[c, a] = -300.0          # a zero pivot inside a block: the guard hands over
+            xg, pg = _kernel_newton_solve(one, np.hstack([A, b[:, None]])[None])
+            xn = np.linalg.solve(A, b)
+            assert pg[0] == 2 and np.abs(xg[0] - xn).max() < 1e-10 * np.abs(xn).max(), pg
+            one.close()
+        mvi.close()
+    assert np.array_equal(runs[0][1], runs[1][1])
+    assert relerr(runs[0][0], runs[1][0]) < 1e-12
+
+
 def test_structured_newton_solve_is_what_the_rollout_runs():
     """The puppet rollout with the structured solve (default) and with the pivoting solver (exact pivot rule: the structured solve
     is compiled out of that kernel) take the same number of Newton iterations and agree to 1e-10 over 200 steps."""

@@ -22,6 +22,7 @@ files = {}
 cur = None
 inside = False
 counts = collections.defaultdict(lambda: collections.Counter())
+seq = []
 F64 = re.compile(r"^v_(fma|mul|add|fmac|max|min|rcp|ldexp|frexp|fract|rndne|trunc|cvt.*f64|cmp.*f64|div|sqrt|rsq).*_f64|^v_.*_f64")
 for ln in open(path):
     t = ln.strip()
@@ -59,6 +60,7 @@ for ln in open(path):
     else:
         cls = "mem"
     counts[cur][cls] += 1
+    seq.append((cur, cls))
 
 GROUPS = []
 if "--ranges" in sys.argv:
@@ -68,9 +70,19 @@ if "--ranges" in sys.argv:
 cols = ["fp64", "valu_int", "cndmask", "mov", "dpp/lane", "salu", "branch", "wait", "lds", "mem"]
 if GROUPS:
     agg = collections.defaultdict(collections.Counter)
-    for (f, l), c in counts.items():
-        g = "other files" if f != "mvi_core.hpp" else next((n for n, a, b in GROUPS if a <= l <= b), "mvi_core other")
-        agg[g].update(c)
+    if "--inherit" in sys.argv:
+        # helper lines (fma() in the HIP math header, the DPP / 16-byte access helpers, ...) count for the phase whose line came last in
+        # program order: `seq` holds (location, class) in the order the instructions stand in the text
+        cur_g = "prologue"
+        for (f, l), cls in seq:
+            g = None if f != "mvi_core.hpp" else next((n for n, a, b in GROUPS if a <= l <= b), None)
+            if g is not None:
+                cur_g = g
+            agg[cur_g][cls] += 1
+    else:
+        for (f, l), c in counts.items():
+            g = "other files" if f != "mvi_core.hpp" else next((n for n, a, b in GROUPS if a <= l <= b), "mvi_core other")
+            agg[g].update(c)
     print("%-34s" % "group" + "".join("%9s" % c for c in cols) + "    total")
     for g, c in sorted(agg.items(), key=lambda kv: -sum(kv[1].values())):
         print("%-34s" % g + "".join("%9d" % c[k] for k in cols) + "%9d" % sum(c.values()))

@@ -160,5 +160,58 @@ inline BbdPlan bbd_plan(int nf, int nd, const std::vector<unsigned char> &patter
     return P;
 }
 
+// ---- the image in the solver's own order ("packed": round 5) -----------------------------------------------------------------------
+// The solver reads the dense image [nf][ld] by gathered 8-byte loads -- per entry a table field, an address and two selects (padding rows,
+// border rows' untouched columns): a fifth of its vector instructions.  In the packed image every lane's row [own | border | rhs] is one
+// run of 16-byte-aligned doubles, padded to NC2, group g row r at (g * NR + r) * NC2 (NR = ng + nb; four groups are always laid out), the
+// trailing system's row i at TB + i * TC2 (16 rows: rows t .. 15 stay zero), the solution vector XS [nf] wherever the caller has nf
+// doubles (offset `xs` from the image; the rollout kernels use the dense solvers' scale vector).  Zero is what the
+// writer's clear leaves; the identity entries of padding rows are listed in `ones`.  Every structural entry of the dense matrix has
+// exactly one place: map[i * (nf + 1) + j] (j = nf: the right-hand side), -1 where the plan has none (an entry that must be zero).
+struct BbdPacked {
+    int ok = 0, nr = 0, nc2 = 0, tb = 0, tc2 = 0, xs = 0, size = 0;
+    std::vector<int> map, ones;
+};
+inline BbdPacked bbd_pack(const BbdPlan &P, int nf) {
+    BbdPacked K;
+    if (!P.ok) return K;
+    const int NG = P.ng, NB = P.nb, T = P.t;
+    // row strides: even (16-byte loads) and not a multiple of four doubles -- at 12 doubles (96 bytes) the 16-byte accesses of lanes eight
+    // rows apart meet on the same banks (two-way conflicts: profiles/r04_lds_conflicts.txt), at 14 they do not
+    auto stride = [](int n) { int s = (n + 1) & ~1; if (s % 4 == 0) s += 2; return s; };
+    K.nr = NG + NB; K.nc2 = stride(NG + NB + 1); K.tb = 4 * K.nr * K.nc2; K.tc2 = stride(T + 1);
+    K.xs = K.tb + (T + 1) * K.tc2; K.size = (K.xs + 1) & ~1;        // (trailing rows 0 .. t-1 and one zero row for the lanes past them; the caller places XS)
+    K.map.assign((size_t)nf * (nf + 1), -1);
+    std::vector<int> tindex(nf, -1);
+    for (int g = 0; g < 4; g++)
+        for (int r = 0; r < 16; r++) {
+            const int w = P.tab[16 * g + r], row = (w & 0xFF) - 1, trow = ((w >> 8) & 0xFF) - 1;
+            if (row >= 0 && trow >= 0) tindex[row] = trow;
+        }
+    for (int i = 0; i < T; i++) tindex[P.tvar[i]] = i;
+    for (int g = 0; g < 4; g++) {
+        // column j of group g holds variable colvar[j] (own 0 .. NG-1, border NG .. NG+NB-1)
+        int colvar[16];
+        for (int j = 0; j < 16; j++) colvar[j] = (P.tab[64 + 16 * g + j] & 0xFF) - 1;
+        for (int r = 0; r < K.nr; r++) {
+            const int row = (P.tab[16 * g + r] & 0xFF) - 1, base = (g * K.nr + r) * K.nc2;
+            if (row < 0) { if (r < NG) K.ones.push_back(base + r); continue; }      // a padding own row: identity
+            if (r < NG) {       // an own row: every column
+                for (int j = 0; j < K.nr; j++) if (colvar[j] >= 0) K.map[(size_t)row * (nf + 1) + colvar[j]] = base + j;
+                K.map[(size_t)row * (nf + 1) + nf] = base + K.nr;
+            } else {            // a border row of the group: its own columns only (the rest accumulates the Schur update from zero)
+                for (int j = 0; j < NG; j++) if (colvar[j] >= 0) K.map[(size_t)row * (nf + 1) + colvar[j]] = base + j;
+            }
+        }
+    }
+    for (int i = 0; i < T; i++) {
+        for (int j = 0; j < T; j++) K.map[(size_t)P.tvar[i] * (nf + 1) + P.tvar[j]] = K.tb + i * K.tc2 + j;
+        K.map[(size_t)P.tvar[i] * (nf + 1) + nf] = K.tb + i * K.tc2 + T;
+    }
+    if (K.ones.empty()) K.ones.push_back(-1);
+    K.ok = 1;
+    return K;
+}
+
 }  // namespace tg
 

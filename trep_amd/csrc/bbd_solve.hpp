@@ -72,10 +72,19 @@ __device__ __forceinline__ BbdRows<NGB> bbd_rows(const int *tab_generic, int lan
 // nd = 0: no update (the solutions only go to the image's right-hand-side column, where every caller can read them).
 // The LDS offsets of the operands relative to the image are compile-time (BbdUpd: q2, q1, dq, lambda1 minus the image's offset; ND = 0: no
 // update -- the solutions only go to the image's right-hand-side column, where every caller can read them); only dt and 1 / dt travel.
+#if defined(TG_BBD_INLINE)      // (A/B switch: the structured solve inlined into its caller instead of an out-of-line call with its own register allocation)
+#define TG_BBD_ATTR __forceinline__
+#else
+#define TG_BBD_ATTR __noinline__
+#endif
 template <int ND_, int Q2_, int Q1_, int DQ_, int LAM_> struct BbdUpd { static constexpr int nd = ND_, q2 = Q2_, q1 = Q1_, dq = DQ_, lam = LAM_; };
 typedef BbdUpd<0, 0, 0, 0, 0> BbdNoUpdate;
-template <int NF, int LD, int NG, int NB, int T, class UP = BbdNoUpdate, class TVAR = const int *>
-__device__ __noinline__ bool gj_bbd(double *A_generic, BbdRows<NG + NB> rows, double *scratch_generic, int lane, TVAR tvar, double up_dt = 0.0, double up_inv_dt = 0.0) {
+// Where the solver finds its rows: the dense image [NF][LD] (gathered by the plan tables), or the image in its own order (bbd.hpp,
+// BbdPacked): row r of group g at (g * NR + r) * NC2, trailing row i at TB + i * TC2, solutions to XS + variable
+struct BbdDenseImage { static constexpr bool packed = false; static constexpr int nr = 0, nc2 = 0, tb = 0, tc2 = 0, xs = 0; };
+template <int NR_, int NC2_, int TB_, int TC2_, int XS_> struct BbdPackedImage { static constexpr bool packed = true; static constexpr int nr = NR_, nc2 = NC2_, tb = TB_, tc2 = TC2_, xs = XS_; };
+template <int NF, int LD, int NG, int NB, int T, class UP = BbdNoUpdate, class IMG = BbdDenseImage, class TVAR = const int *>
+__device__ TG_BBD_ATTR bool gj_bbd(double *A_generic, BbdRows<NG + NB> rows, double *scratch_generic, int lane, TVAR tvar, double up_dt = 0.0, double up_inv_dt = 0.0) {
     typedef __attribute__((address_space(3))) double lds_double;
     lds_double *A = (lds_double *)A_generic, *U = (lds_double *)scratch_generic, *XT = U + T * (T + 1);
     constexpr int NCOL = NG + NB + 1, UL = T + 1;
@@ -103,6 +112,34 @@ __device__ __noinline__ bool gj_bbd(double *A_generic, BbdRows<NG + NB> rows, do
     const bool own = r < NG, have = row >= 0;
     const int ro = (have ? row : 0) * LD;
     double amax = 0.0;
+    double tr[T + 1];
+    const bool tl = lane < T;
+    const int to = (tl ? timg : 0) * LD;
+    double tmax = 0.0;
+    if constexpr (IMG::packed) {
+        // the lane's row is one run of doubles (16-byte loads); a lane past the group's rows re-reads row 0 (finite numbers nobody uses), the
+        // padding rows' identity entries and the border rows' zero columns are in the image
+        typedef double bbd_d2 __attribute__((ext_vector_type(2)));
+        static_assert(NCOL <= IMG::nc2 && T + 1 <= IMG::tc2 && (IMG::nc2 & 1) == 0 && (IMG::tc2 & 1) == 0, "gj_bbd: packed row strides");
+        const __attribute__((address_space(3))) bbd_d2 *pr = (const __attribute__((address_space(3))) bbd_d2 *)(A + (g * IMG::nr + (r < IMG::nr ? r : 0)) * IMG::nc2);
+#pragma unroll
+        for (int j = 0; j < NCOL; j += 2) {
+            const bbd_d2 v = pr[j >> 1];
+            a[j] = v.x;
+            if (j + 1 < NCOL) a[j + 1] = v.y;
+        }
+#pragma unroll
+        for (int j = 0; j < NG + NB; j++) amax = fmax(amax, fabs(a[j]));
+        const __attribute__((address_space(3))) bbd_d2 *pt = (const __attribute__((address_space(3))) bbd_d2 *)(A + IMG::tb + (lane < T ? lane : T) * IMG::tc2);      // (lanes past the system: the zero row)
+#pragma unroll
+        for (int j = 0; j <= T; j += 2) {
+            const bbd_d2 v = pt[j >> 1];
+            tr[j] = v.x;
+            if (j + 1 <= T) tr[j + 1] = v.y;
+        }
+#pragma unroll
+        for (int j = 0; j < T; j++) tmax = fmax(tmax, fabs(tr[j]));
+    } else {
 #pragma unroll
     for (int j = 0; j < NCOL; j++) {
         const int col = j < NG + NB ? (wc[j] & 0xFF) - 1 : NF;
@@ -112,15 +149,12 @@ __device__ __noinline__ bool gj_bbd(double *A_generic, BbdRows<NG + NB> rows, do
         if (j < NG + NB) amax = fmax(amax, fabs(a[j]));
     }
     // the trailing system: lane i < T of the first row holds row tvar[i]
-    double tr[T + 1];
-    const bool tl = lane < T;
-    const int to = (tl ? timg : 0) * LD;
-    double tmax = 0.0;
 #pragma unroll
     for (int j = 0; j <= T; j++) {
         const double v = A[to + (j < T ? tvar[j] : NF)];
         tr[j] = tl ? v : ((lane < 16 && j == lane) ? 1.0 : 0.0);
         if (j < T) tmax = fmax(tmax, fabs(tr[j]));
+    }
     }
     for (int e = lane; e < T * UL; e += 64) U[e] = 0.0;
     BBD_STAMP(0);
@@ -158,7 +192,7 @@ __device__ __noinline__ bool gj_bbd(double *A_generic, BbdRows<NG + NB> rows, do
     asm volatile("" ::: "memory");
     // ---- stage 3: solutions.  trailing variables straight, own variables by back-substitution from the border's
     const double xt = tr[T] * trp;
-    if (tl) A[to + NF] = xt;
+    if (tl) A[IMG::packed ? IMG::xs + timg : to + NF] = xt;
     double xo = 0.0;
     if (own && have) {
         double s = a[NG + NB];
@@ -168,7 +202,7 @@ __device__ __noinline__ bool gj_bbd(double *A_generic, BbdRows<NG + NB> rows, do
             s = fma(-a[j], XT[tc >= 0 ? tc : 0], s);     // (a border column that does not exist holds zeros)
         }
         xo = s * myrp;
-        A[ro + NF] = xo;
+        A[IMG::packed ? IMG::xs + row : ro + NF] = xo;
     }
     if constexpr (UP::nd > 0) {
         auto rate = [&](double v, double q1v) { const double d = v - q1v, q = d * up_inv_dt; return fma(fma(-q, up_dt, d), up_inv_dt, q); };   // Core::over_dt

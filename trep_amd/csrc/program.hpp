@@ -172,6 +172,12 @@ struct DevProg {
     // (body b, axis r) -- words 0..2 = the configs of the body's path, word 3 = b | r << 8.  wev_depth: longest list.
     int wev_ok, wev_depth;
     const int *wev_lane;
+    // the Newton image in the structured solve's own order (bbd.hpp, BbdPacked; kernels with the world-frame evaluation): sizes, the dense
+    // -> packed map [nf * (nf + 1)] (test hook), the addresses of the identity entries (bbd_pk_nones of them), and the writers' tables:
+    // wev_pairx [n_cmpairs] a | b << 6 | packed address of (a, b) << 12 | of (b, a) << 22;  wev_dhx [n_dhr] Dh item n | address of
+    // (config, constraint) << 8 | of (constraint, config) << 18;  the right-hand side of variable i at bbd_map[i * (nf + 1) + nf]
+    int bbd_pk_ok, bbd_pk_nr, bbd_pk_nc2, bbd_pk_tb, bbd_pk_tc2, bbd_pk_xs, bbd_pk_size, bbd_pk_nones;
+    const int *bbd_map, *bbd_ones, *wev_pairx, *wev_dhx;
 };
 
 struct HostProgram {
@@ -188,7 +194,7 @@ struct HostProgram {
     std::vector<double> c_dist, c_tol;
     std::vector<int> dh_c, dh_cfg, dh_joint, dh_side, dh_lookup, cu_off;
     std::vector<double> damp, cs_k, cs_kq0, cs_c0, s_k, s_x0, s_c, c_nloc, wr_const, wr_Rloc, ncs_mb, ncs_tab;
-    std::vector<int> ncs_i, bbd_tab, cmp_rep, cmp_grp, cmp_goff, cmp_gbody, cmp_pair, wev_lane;
+    std::vector<int> ncs_i, bbd_tab, cmp_rep, cmp_grp, cmp_goff, cmp_gbody, cmp_pair, wev_lane, bbd_map, bbd_ones, wev_pairx, wev_dhx;
     std::vector<unsigned char> newton_pattern;   // [nf * nf] structural non-zeros of the Newton matrix (symmetrised), host side only
     std::vector<int> wr_in, wr_kind;
     std::vector<int> cf_cfg, cf_in;
@@ -903,6 +909,38 @@ inline HostProgram build_program(const tg_system_desc *d) {
                 P.lds_per_team += 64;
             }
         }
+        {   // packed image (BbdPacked): only with the world-frame evaluation (its Newton-matrix phases are the writer), if it fits the union
+            P.bbd_pk_ok = 0; P.bbd_pk_nr = P.bbd_pk_nc2 = P.bbd_pk_tb = P.bbd_pk_tc2 = P.bbd_pk_xs = P.bbd_pk_size = P.bbd_pk_nones = 0;
+            H.bbd_map.assign(1, -1); H.bbd_ones.assign(1, -1); H.wev_pairx.assign(1, 0); H.wev_dhx.assign(1, 0);
+            if (P.bbd_ok && P.wev_ok) {
+                BbdPlan plan;
+                plan.ok = 1; plan.g = P.bbd_g; plan.ng = P.bbd_ng; plan.nb = P.bbd_nb; plan.t = P.bbd_t;
+                for (int i = 0; i < 16; i++) plan.tvar[i] = P.bbd_tvar[i];
+                for (int i = 0; i < 128; i++) plan.tab[i] = H.bbd_tab[i];
+                const BbdPacked K = bbd_pack(plan, nf);
+                bool ok = K.ok && K.size <= P.nf * P.df_ld && K.size < 1024 && nd < 64 && P.n_dh < 256 && (int)K.ones.size() <= 64 &&
+                          P.bbd_t * (P.bbd_t + 2) <= 17 * nb;        // (the solve's scratch moves behind the q2 poses: the twists stay intact for a fallback)
+                std::vector<int> pairx, dhx;
+                for (int n = 0; n < P.n_cmpairs && ok; n++) {
+                    const int a = H.cmp_pair[n] & 0xFFFF, b = H.cmp_pair[n] >> 16;
+                    const int ab = K.map[(size_t)a * (nf + 1) + b], ba = K.map[(size_t)b * (nf + 1) + a];
+                    if (ab < 0 || ba < 0) { ok = false; break; }
+                    pairx.push_back((int)((unsigned)a | ((unsigned)b << 6) | ((unsigned)ab << 12) | ((unsigned)ba << 22)));
+                }
+                for (int n = 0; n < P.n_dhr && ok; n++) {
+                    const int c = H.dhr_pack[8 * (size_t)n], k = H.dhr_pack[8 * (size_t)n + 1], item = H.dhr_pack[8 * (size_t)n + 7];
+                    const int kc = K.map[(size_t)k * (nf + 1) + nd + c], ck = K.map[(size_t)(nd + c) * (nf + 1) + k];
+                    if (kc < 0 || ck < 0) { ok = false; break; }
+                    dhx.push_back(item | (kc << 8) | (ck << 18));
+                }
+                for (int i = 0; i < nf && ok; i++) if (K.map[(size_t)i * (nf + 1) + nf] < 0) ok = false;
+                if (ok) {
+                    P.bbd_pk_ok = 1; P.bbd_pk_nr = K.nr; P.bbd_pk_nc2 = K.nc2; P.bbd_pk_tb = K.tb; P.bbd_pk_tc2 = K.tc2; P.bbd_pk_xs = P.o_scal - P.o_Df; P.bbd_pk_size = K.size;      // (the solution vector: the dense solvers' scale vector, nf doubles, unused by these kernels)
+                    P.bbd_pk_nones = K.ones[0] < 0 ? 0 : (int)K.ones.size();
+                    H.bbd_map = K.map; H.bbd_ones = K.ones; H.wev_pairx = pairx.empty() ? std::vector<int>(1, 0) : pairx; H.wev_dhx = dhx.empty() ? std::vector<int>(1, 0) : dhx;
+                }
+            }
+        }
         if (P.cmp_ok) {     // representative (item | body << 16) of every dynamic config, staged like the plan tables (rollout kernels only)
             P.o_cmpt = P.lds_per_team;
             P.lds_per_team += (nd + 1) / 2;
@@ -930,7 +968,7 @@ inline void pool_append(std::vector<T> &pool, std::vector<size_t> &offs, const s
     X(it_joint) X(it_cfg) X(pair_a) X(pair_b) X(cfg_item_off) X(cfg_items) X(e_anchor) X(c_type) X(c_e1) X(c_e2) \
     X(c_cfg) X(c_comp) X(dh_c) X(dh_cfg) X(dh_joint) X(dh_side) X(cf_cfg) X(cf_in) X(dh_lookup) X(cu_off) X(it_slot) X(pair4) \
     X(tri4) X(cpair4) X(it_pack) X(dh_pack) X(cpath_off) X(cpath_items) X(dh_pos) X(tchunk) X(tri_off) X(wr_in) X(wr_kind) X(ncs_i) \
-    X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4) X(bbd_tab) X(cmp_rep) X(cmp_grp) X(cmp_goff) X(cmp_gbody) X(cmp_pair) X(dhr_pack) X(at_i) X(ae_i) X(sj_list) X(sj_full) X(wev_lane)
+    X(wp_a) X(wp_b) X(wt_a) X(wt_b) X(wt_split) X(wcp4) X(bbd_tab) X(cmp_rep) X(cmp_grp) X(cmp_goff) X(cmp_gbody) X(cmp_pair) X(dhr_pack) X(at_i) X(ae_i) X(sj_list) X(sj_full) X(wev_lane) X(bbd_map) X(bbd_ones) X(wev_pairx) X(wev_dhx)
 #define TG_DBL_TABLES(X) X(j_pre) X(jcoef) X(j_prm) X(at_d) X(ae_d) X(b_C) X(b_inertia) X(e_off) X(c_dist) X(c_tol) X(damp) X(cs_k) X(cs_kq0) X(cs_c0) X(s_k) X(s_x0) X(c_nloc) X(wr_const) X(s_c) X(wr_Rloc) X(ncs_mb) X(ncs_tab)
 
 inline void HostProgram::pack() {

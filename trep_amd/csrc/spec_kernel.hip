@@ -64,17 +64,30 @@ __global__ __launch_bounds__(64, 2) void k_spec_debug_solve(const double *A_in, 
     constexpr int nf = SpecProg::nf, ld = SpecProg::df_ld, nb4 = (nf + 3) >> 2;
     const int lane = threadIdx.x;
     const double *src = A_in + (size_t)blockIdx.x * nf * (nf + 1);
-    for (int e = lane; e < nf * ld; e += 64) S[P.o_Df + e] = 0.0;
-    __syncthreads();
-    for (int e = lane; e < nf * (nf + 1); e += 64) S[P.o_Df + (e / (nf + 1)) * ld + e % (nf + 1)] = src[e];
+    constexpr bool PKI = tg::tg_static_pk<SpecProg>::value;     // the rollout kernel solves the image in the plan's own order (bbd.hpp, BbdPacked)
+    auto load_dense = [&]() {
+        for (int e = lane; e < nf * ld; e += 64) S[P.o_Df + e] = 0.0;
+        __syncthreads();
+        for (int e = lane; e < nf * (nf + 1); e += 64) S[P.o_Df + (e / (nf + 1)) * ld + e % (nf + 1)] = src[e];
+    };
     int path = 0;
     bool ok = false;
     if constexpr (SPEC_TEAM == 64 && SpecProg::bbd_ok != 0) {
         int *tab = (int *)(S + P.o_bbd);
         for (int e = lane; e < 128; e += 64) tab[e] = P.bbd_tab[e];
+        if constexpr (PKI) {     // the caller's dense matrix scattered to the packed places (entries without a place must be structural zeros)
+            for (int e = lane; e < SpecProg::bbd_pk_size; e += 64) S[P.o_Df + e] = 0.0;
+            __syncthreads();
+            for (int e = lane; e < nf * (nf + 1); e += 64) { const int at = P.bbd_map[e]; if (at >= 0) S[P.o_Df + at] = src[e]; }
+            for (int e = lane; e < SpecProg::bbd_pk_nones; e += 64) S[P.o_Df + P.bbd_ones[e]] = 1.0;
+        } else load_dense();
         __syncthreads();
-        if (!skip_structured && tg::gj_bbd<nf, ld, SpecProg::bbd_ng, SpecProg::bbd_nb, SpecProg::bbd_t>(S + P.o_Df, tg::bbd_rows<SpecProg::bbd_ng + SpecProg::bbd_nb>(tab, lane), S + P.o_J, lane, P.bbd_tvar)) { ok = true; path = 1; }
-    }
+        typedef typename std::conditional<PKI, tg::BbdPackedImage<SpecProg::bbd_pk_nr, SpecProg::bbd_pk_nc2, SpecProg::bbd_pk_tb, SpecProg::bbd_pk_tc2, SpecProg::bbd_pk_xs>, tg::BbdDenseImage>::type Img;
+        if (!skip_structured && tg::gj_bbd<nf, ld, SpecProg::bbd_ng, SpecProg::bbd_nb, SpecProg::bbd_t, tg::BbdNoUpdate, Img>(S + P.o_Df, tg::bbd_rows<SpecProg::bbd_ng + SpecProg::bbd_nb>(tab, lane), PKI ? S + P.o_W + 12 * P.n_joints : S + P.o_J, lane, P.bbd_tvar)) { ok = true; path = 1; }
+        __syncthreads();
+        if (PKI && ok && lane < nf) x_out[(size_t)blockIdx.x * nf + lane] = S[P.o_Df + SpecProg::bbd_pk_xs + lane];
+        if (PKI && !ok) load_dense();
+    } else load_dense();
     __syncthreads();
     if (!ok) {
         if constexpr (SPEC_TEAM == 64 && nb4 >= 5 && nf <= 31 && 12 * SpecProg::n_items >= 128) ok = tg::Core<64>::gj_panel<4 * nb4>(true, S + P.o_Df, nf, ld, lane, S + P.o_J);
@@ -82,7 +95,7 @@ __global__ __launch_bounds__(64, 2) void k_spec_debug_solve(const double *A_in, 
         path = ok ? 2 : -1;
     }
     __syncthreads();
-    if (lane < nf) x_out[(size_t)blockIdx.x * nf + lane] = S[P.o_Df + lane * ld + nf];
+    if (lane < nf && !(PKI && path == 1)) x_out[(size_t)blockIdx.x * nf + lane] = S[P.o_Df + lane * ld + nf];
     if (lane == 0) path_out[blockIdx.x] = path;
 #endif
 }
