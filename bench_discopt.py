@@ -115,6 +115,9 @@ def measure(seeds, horizon, quasi=1, newton=1, comm=None, device=0, armijo_chunk
         timed("cost + gradients", opt.gradients_and_cost)
         if opt.overlap:      # what a step really runs with S <= 128 seeds: the two independent sweeps on two streams
             timed("projection gain || quasi LQ sweep + tangent rollout (side by side, replaces the two alone)", opt.projection_gain_and_quasi_direction)
+        if getattr(opt, "pipeline", False):      # ... and what a Newton step runs instead of the next two stages, one after the other
+            timed("projection | quasi | second derivatives | Newton LQ + tangent, pipelined over chunks of the horizon (replaces the side-by-side stage and the next two)",
+                  opt.projection_quasi_and_newton_model)
         timed("newton curvature (adjoint + S*N deriv2z)", opt.newton_curvature, None)
         timed("LQ sweep + tangent rollout", lambda: (opt._lq(None, opt.Q, opt.Qf, opt.R, opt.HZ, True, opt.K, opt.C),
                                                       opt.descent_direction(None, "quasi")))
@@ -125,7 +128,8 @@ def measure(seeds, horizon, quasi=1, newton=1, comm=None, device=0, armijo_chunk
         "n_gpus": world, "dtype": "f64", "data": "synthetic", "scaling": "strong",
         "config": {"workload": "puppet-optimization.py problem, nX=80 nU=18, N=%d, %d seeds batched on the device (%d per GPU), %d quasi + %d newton steps each"
                                % (N, seeds, S, quasi, newton), "armijo_chunk": opt.M,
-                   "newton_initial_guess": predictor, "sweeps_side_by_side": bool(opt.overlap)},
+                   "newton_initial_guess": predictor, "sweeps_side_by_side": bool(opt.overlap),
+                   "newton_step_pipelined_over_horizon_chunks": bool(getattr(opt, "pipeline", False)), "pipeline_chunks": len(opt._chunks()) if getattr(opt, "pipeline", False) else 0},
         "seed_iterations_counted": good_iters, "elapsed_s": elapsed,
         "mean_final_cost_successful_seeds": float(np.mean(final_cost[final_ok])) if final_ok.any() else None,
         "s_per_batched_quasi_step": float(np.mean(per["quasi"])) if per["quasi"] else None,

@@ -82,8 +82,11 @@ def test_rollout_matches_reference(name):
     lam = mvi.lambda1
     for b, (prefix, _, _, _) in enumerate(trajs):
         assert relerr(X[b, :, :nq], g[prefix + "Q"]) < TOL, name
-        assert relerr(X[b, :, nq:nq + nd], g[prefix + "P"]) < 1e-9, name
-        assert relerr(lam[b], g[prefix + "LAM"][n]) < 1e-7
+        # observed on the round-5 library over all 18 systems (tools/observed_tolerances.py): q <= 3.7e-13, p <= 1.3e-12, lambda1 <= 2.8e-11
+        # (the scissor lift: the multipliers are conditioned by 1 / dt^2); the wide random sweep (profiles/r05_stress_parity.txt, 1152
+        # trajectories per system and kernel variant against the oracle) sees p <= 2.8e-11, lambda1 <= 4.7e-11
+        assert relerr(X[b, :, nq:nq + nd], g[prefix + "P"]) < TOL, name
+        assert relerr(lam[b], g[prefix + "LAM"][n]) < 3e-10
         assert abs(int(iters[b]) - int(g[prefix + "IT"].sum())) <= max(2, n // 100)
     t1, t2 = mvi.times()
     assert abs(t2 - (n + 1) * DT) < 1e-12 and abs(t1 - n * DT) < 1e-12
@@ -105,7 +108,7 @@ def test_stepwise_api_matches_reference(name):
         assert abs(it - IT[k]) <= (0 if k < 100 else 1)
         assert relerr(mvi.q2, Q[k + 1]) < 1e-11
         assert relerr(mvi.p2, P[k + 1]) < 1e-10
-        assert relerr(mvi.lambda1, LAM[k + 1]) < 1e-8
+        assert relerr(mvi.lambda1, LAM[k + 1]) < 1e-10       # (observed: <= 6.4e-12, scissor lift)
         assert relerr(mvi.q1, Q[k]) == 0.0 and relerr(mvi.p1, P[k]) == 0.0
 
 
@@ -220,7 +223,8 @@ def test_long_chain_matches_oracle(links, B, N):
         assert abs(tot - iters[b]) <= (1 if links <= 20 else N)
         o.calc_deriv1()
         for n in ("q2_dq1", "q2_dp1", "p2_dq1", "p2_dp1"):
-            # derivatives are taken at the converged state, which itself agrees to ~1e-10 (sensitivity ~1e3 here)
+            # derivatives are taken at the converged state, which itself agrees to ~1e-12, and the chain's sensitivity grows with its
+            # length: observed 1.4e-9 at 20 links, 8.4e-8 at 36 (tools/observed_tolerances.py) -- the bounds are one decade above that
             assert relerr(mvi.deriv1(n)[b], o.deriv1(n)) < (1e-8 if links <= 20 else 1e-6), (links, b, n)
     mvi.close()
 
@@ -578,7 +582,7 @@ def test_full_size_properties_cart_and_scissor(name):
     for b in (0, 1000, 4000):
         o.initialize_from_configs(0.0, Q0[b], DT, Q0[b])
         Xo, _ = o.rollout(N, DT, None if U is None else U[b], None)
-        assert relerr(X[b], Xo) < (1e-9 if name == "cart" else TOL), (b, relerr(X[b], Xo))   # the cart is chaotic over 200 driven steps
+        assert relerr(X[b], Xo) < TOL, (b, relerr(X[b], Xo))   # (observed: cart 5e-14, scissor lift 2.7e-12 over 200 steps)
     mvi.close(); sub.close()
 
 
