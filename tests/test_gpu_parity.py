@@ -981,8 +981,8 @@ def test_structured_newton_solve_matches_the_pivoting_solvers(name):
     assert ps[0] == -1 and rc != 0, (ps, rc)
 
 
-def test_packed_newton_image_variant(monkeypatch):
-    """-DTG_BBD_PACKED (opt-in build of the specialised puppet kernel, compiled here by hipcc): the Newton matrix written straight into the
+def test_packed_newton_image_and_item_form_variants(monkeypatch):
+    """Two compile-time variants of the specialised puppet kernel against the default one.  -DTG_BBD_PACKED (opt-in build of the specialised puppet kernel, compiled here by hipcc): the Newton matrix written straight into the
     structured solve's own row order (csrc/bbd.hpp, BbdPacked) instead of the dense image.  The solver hook on the system's own pattern
     (dense input scattered through the plan's map), the fallback after a failed guard (the packed image unpacked for the pivoting
     solver) and a 100-step rollout against the default kernel: same Newton iteration counts, states equal to 1e-12."""
@@ -993,9 +993,11 @@ def test_packed_newton_image_variant(monkeypatch):
     Q0 = systems.puppet_initial_conditions(system, B, seed=9)
     K = systems.puppet_string_schedule(system, Q0[:, system.nQd:], N, DT)
     runs = []
-    for packed in (False, True):
+    for packed in (False, True, None):
         if packed:
             monkeypatch.setenv("TREPAMD_SPEC_FLAGS", specialize.DEFAULT_FLAGS + " -DTG_BBD_PACKED")
+        elif packed is None:        # ... and the (body, config) item form of rounds 1-4 with the composite matrix: the same kernel source without eval_world
+            monkeypatch.setenv("TREPAMD_SPEC_FLAGS", specialize.DEFAULT_FLAGS + " -DTG_NO_WEV")
         mvi = trep_amd.BatchMidpointVI(system, B, specialize=True)
         mvi.initialize_from_configs(0.0, Q0, DT, Q0)
         X = mvi.rollout(N, DT, None, K)
@@ -1025,8 +1027,9 @@ def test_packed_newton_image_variant(monkeypatch):
             assert pg[0] == 2 and np.abs(xg[0] - xn).max() < 1e-10 * np.abs(xn).max(), pg
             one.close()
         mvi.close()
-    assert np.array_equal(runs[0][1], runs[1][1])
+    assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][1], runs[2][1])
     assert relerr(runs[0][0], runs[1][0]) < 1e-12
+    assert relerr(runs[0][0], runs[2][0]) < 1e-11       # world-frame against item form: a different (algebraically equal) evaluation
 
 
 def test_structured_newton_solve_is_what_the_rollout_runs():
