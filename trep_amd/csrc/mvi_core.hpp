@@ -1321,7 +1321,7 @@ struct Core {
             for (int d = D0; d < D1; d++) {
 #pragma unroll
                 for (int r = 0; r < 6; r++) V[r] += x[d - D0][r];
-            }
+            }      // (pairwise sums -- a shorter dependent chain -- measured: no difference)
         }
     }
     TG_HD void eval_world(bool on) {
@@ -1401,12 +1401,18 @@ struct Core {
 #pragma unroll
                     for (int e = 0; e < 12; e++) Ga[e] = (e == 0 || e == 5 || e == 10) ? 1.0 : 0.0;
                 }
-                // world pose of the body: R = Ra Rc, p = Ra pc + pa
+                // world pose of the body: R = Ra Rc, p = Ra pc + pa (Rc = 1 for every body of most models -- the masses sit at translated frames:
+                // a compile-time property of the schedule, wev_rc_ident)
+#if defined(TG_WEV_NO_RC_IDENT)
+                constexpr bool RCI = false;
+#else
+                constexpr bool RCI = SP::wev_rc_ident != 0;
+#endif
                 double R[3][3], p[3];
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
 #pragma unroll
-                    for (int j = 0; j < 3; j++) R[i][j] = Ga[4 * i] * Cb[j] + Ga[4 * i + 1] * Cb[4 + j] + Ga[4 * i + 2] * Cb[8 + j];
+                    for (int j = 0; j < 3; j++) R[i][j] = RCI ? Ga[4 * i + j] : Ga[4 * i] * Cb[j] + Ga[4 * i + 1] * Cb[4 + j] + Ga[4 * i + 2] * Cb[8 + j];
                     p[i] = Ga[4 * i] * Cb[3] + Ga[4 * i + 1] * Cb[7] + Ga[4 * i + 2] * Cb[11] + Ga[4 * i + 3];
                 }
                 const double *I = S + P.o_I + 4 * b;

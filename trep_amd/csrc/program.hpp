@@ -170,7 +170,7 @@ struct DevProg {
     // (body, config) item.  wev_lane [64][4]: lane l < nd is config l -- words 0..2 = its proper ancestors on the path, root first, one
     // byte each, padded with nd (the all-zero record), word 3 = 12 * joint | kind << 16 | subtree group << 24; lane nd + 3 b + r is
     // (body b, axis r) -- words 0..2 = the configs of the body's path, word 3 = b | r << 8.  wev_depth: longest list.
-    int wev_ok, wev_depth;
+    int wev_ok, wev_depth, wev_rc_ident;      // wev_rc_ident: every body's constant offset from its anchor joint is a pure translation
     const int *wev_lane;
     // the Newton image in the structured solve's own order (bbd.hpp, BbdPacked; kernels with the world-frame evaluation): sizes, the dense
     // -> packed map [nf * (nf + 1)] (test hook), the addresses of the identity entries (bbd_pk_nones of them), and the writers' tables:
@@ -842,7 +842,11 @@ inline HostProgram build_program(const tg_system_desc *d) {
         // DYNAMIC config (a kinematic config above a body would need a twist and a rate but has no residual row), one lane per config
         // and per (body, axis), lists of at most 12 entries, and the twists + the zero record inside the J area (the q2 poses of the
         // dual sweep sit in the W area while they are read)
-        P.wev_ok = 0; P.wev_depth = 0;
+        P.wev_ok = 0; P.wev_depth = 0; P.wev_rc_ident = 1;
+        for (int b = 0; b < nb; b++) {
+            const double *C = &H.b_C[12 * (size_t)b];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) if (C[4 * i + j] != (i == j ? 1.0 : 0.0)) P.wev_rc_ident = 0;
+        }
         H.wev_lane.assign(256, 0);
         bool ok = P.cmp_ok && P.tab_ok && P.sw_ok && P.sched_ok && nd + 3 * nb < 64 && nc > 0 && 6 * nitems >= 12 * nj && ns == 0 && nw == 0 && !P.has_cs;
         for (int it = 0; it < nitems && ok; it++) if (H.it_cfg[it] >= nd) ok = false;
