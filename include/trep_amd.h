@@ -213,6 +213,11 @@ int tg_batch_rollout_closed_loop(tg_batch *b, int32_t n_steps, double dt, const 
                                  int32_t max_iterations);
 int tg_batch_rollout_stats(tg_batch *b, int64_t *total_iterations, int32_t *n_failed);
 int tg_batch_status(tg_batch *b, int32_t *iterations_out, int32_t *status_out);
+/* Per trajectory, for the last rollout / step launch: how many of its Newton systems (reference: one LU_decomp per Newton iteration,
+ * midpointvi.c:720-733) the structured solve of a specialised kernel handed to the pivoting solver because a pivot guard failed.
+ * Results are the same either way; a batch that reports fallbacks for most systems (time steps <= 1e-3, very heavy bodies) would run
+ * faster with tg_batch_set_pivot_rule(b, 1) or without a specialised kernel.  Zeros from kernels without a structured solve. */
+int tg_batch_solver_fallbacks(tg_batch *b, int32_t *fallbacks_out);
 
 /* Device-side snapshot / restore of the whole integrator state (q1,q2,p1,p2,lambda1,u1,t1,t2):
  * asynchronous device-to-device copies on the batch's stream.  Lets a caller replay rollouts from

@@ -1032,6 +1032,38 @@ def test_packed_newton_image_and_item_form_variants(monkeypatch):
     assert relerr(runs[0][0], runs[2][0]) < 1e-11       # world-frame against item form: a different (algebraically equal) evaluation
 
 
+def test_structured_solve_reports_its_fallbacks():
+    """tg_batch_solver_fallbacks: from the benchmark's dt = 0.01 down to 1e-4 no Newton system of a puppet rollout fails a pivot guard; at
+    dt = 1e-5 the constraints' Schur pivots (which scale like dt^2 |Dh|^2 / m against |Dh|) fall below the 2^-20 guard and EVERY system
+    goes to the pivoting solver (tools/probe_fallbacks.py: 0 / 0 / 0 / all / all at 1e-2 ... 1e-6) -- reported, and still the oracle's
+    trajectory."""
+    import trep_amd
+    from trep_amd import systems, descriptor
+    from oracle.oracle import OracleMVI
+    system, d = build("puppet40")
+    B, N = 16, 20
+    Q0 = systems.puppet_initial_conditions(system, B, seed=3)
+    for dt, expect_fallbacks in ((DT, False), (1e-4, False), (1e-5, True)):
+        K = systems.puppet_string_schedule(system, Q0[:, system.nQd:], N, dt)
+        mvi = trep_amd.BatchMidpointVI(system, B, specialize=True)
+        mvi.initialize_from_configs(0.0, Q0, dt, Q0)
+        X = mvi.rollout(N, dt, None, K)
+        it, st = mvi.status()
+        fb = mvi.solver_fallbacks()
+        assert (st == 0).all()
+        if expect_fallbacks:
+            assert (fb == it).all(), (fb, it)          # every Newton system of every trajectory
+        else:
+            assert (fb == 0).all(), fb
+        o = OracleMVI(d)
+        o.initialize_from_configs(0.0, Q0[0], dt, Q0[0])
+        Xo, _ = o.rollout(N, dt, None, K[0])
+        nq = d.n_configs
+        assert relerr(X[0][:, :nq], Xo[:, :nq]) < TOL
+        assert relerr(X[0][:, nq:], Xo[:, nq:]) < (TOL if dt == DT else 1e-7)       # (momenta and rates are conditioned by 1 / dt)
+        mvi.close()
+
+
 def test_structured_newton_solve_is_what_the_rollout_runs():
     """The puppet rollout with the structured solve (default) and with the pivoting solver (exact pivot rule: the structured solve
     is compiled out of that kernel) take the same number of Newton iterations and agree to 1e-10 over 200 steps."""

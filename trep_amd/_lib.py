@@ -72,6 +72,7 @@ _SIGNATURES = {
                                                     ctypes.c_void_p, ctypes.c_int32]),
     "tg_batch_rollout_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), _c_ip]),
     "tg_batch_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "tg_batch_solver_fallbacks": (ctypes.c_int, [ctypes.c_void_p, _c_ip]),
     "tg_batch_deriv1": (ctypes.c_int, [ctypes.c_void_p]),
     "tg_batch_deriv2_contract": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tg_batch_dynamics": (ctypes.c_int, [ctypes.c_void_p] * 8),

@@ -247,6 +247,8 @@ struct RunArgs {
     // launch over a SUBSET of the batch's trajectories (the k-chunks of the pipelined discopt Newton step): workgroup-trajectory i < remap_count
     // is trajectory (i / remap_len) * remap_stride + remap_off + i % remap_len of the batch; remap_len = 0: the identity
     int remap_len, remap_stride, remap_off, remap_count;
+    int *fallbacks;                        // rollout / step, optional: [batch] how many Newton systems of this launch the structured solve handed to the pivoting solver
+                                           // (a failed pivot guard: correct, but slower than either solver alone)
 };
 // which trajectory of the batch a launch's i-th trajectory is (RunArgs::remap_*); A.batch for an index past the subset (an idle team)
 template <class ARGS> TG_HD int tg_remap_trajectory(const ARGS &A, int i) {
@@ -5016,7 +5018,7 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
         TG_FOR(i, nX) A.X[o0 + i] = A.bX[o0 + i];
     }
     bool failed = false;
-    int status = TG_OK, total_iters = 0;
+    int status = TG_OK, total_iters = 0, n_fallback = 0;
     // open-loop inputs and kinematic targets of the NEXT step, requested while this step's Newton loop runs (one value per lane when they
     // fit a team): read at the step's start they are two HBM round trips in a row on every step's critical path
     double pre_u = 0.0, pre_k = 0.0;
@@ -5219,6 +5221,7 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
                     bbd_updated = bbd_done;
                 } else bbd_done = gj_bbd<SP::nf, SP::df_ld, SP::bbd_ng, SP::bbd_nb, SP::bbd_t, BbdNoUpdate, Img>(S + P.o_Df, bbd_tab_rows, bscr, lane, P.bbd_tvar);
 #endif
+                if (!bbd_done) n_fallback++;
                 if constexpr (PKI) {
                     // guard failed (rare): the pivoting solver wants the dense image -- the packed one (untouched by the failed solve) unpacked
                     // through the plan's map; the two overlap, so every lane first reads its share, then writes it
@@ -5359,7 +5362,7 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
         TG_FOR(i, nd) A.p2[t * nd + i] = S[P.o_p1 + i];
         TG_FOR(i, nc) A.lam[t * nc + i] = S[P.o_lam + i];
         TG_FOR(i, nu) A.u1[t * nu + i] = S[P.o_u + i];
-        if (lane == 0) { A.iters[t] = total_iters; A.status[t] = status; }
+        if (lane == 0) { A.iters[t] = total_iters; A.status[t] = status; if (A.fallbacks) A.fallbacks[t] = n_fallback; }
         if (A.mirror) {
             const size_t Bn = (size_t)A.batch;
             double *m = A.mirror;

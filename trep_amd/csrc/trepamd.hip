@@ -84,7 +84,7 @@ struct tg_batch {
     double *d_dbls = nullptr;
     double *q1 = nullptr, *q2 = nullptr, *p1 = nullptr, *p2 = nullptr, *lam = nullptr, *u1 = nullptr;
     double *stage_u = nullptr, *stage_k = nullptr, *stage_qh = nullptr, *stage_lh = nullptr, *f_out = nullptr;
-    int *iters = nullptr, *status = nullptr;
+    int *iters = nullptr, *status = nullptr, *fallbacks = nullptr;
     double *z_dev = nullptr, *hz_dev = nullptr, *zl_dev = nullptr;
     double *dyn = nullptr;     // staging of the host-facing continuous-dynamics call: q, dq, u, ddq_k, ddq, lambda
     double *dyn_d1 = nullptr;  // ... and of its eight first-derivative arrays
@@ -284,7 +284,7 @@ tg::RunArgs base_args(tg_batch *b, int mode) {
     A.dt_steps = b->dt_host.empty() ? nullptr : b->dt_dev;
     A.dt_period = (b->dt_by_trajectory && !b->dt_host.empty()) ? (int)b->dt_host.size() : 0;
     A.q1 = b->q1; A.q2 = b->q2; A.p1 = b->p1; A.p2 = b->p2; A.lam = b->lam; A.u1 = b->u1;
-    A.iters = b->iters; A.status = b->status; A.f_out = b->f_out;
+    A.iters = b->iters; A.status = b->status; A.f_out = b->f_out; A.fallbacks = b->fallbacks;
     A.prof_out = b->prof;
     for (int i = 0; i < 12; i++) A.d1[i] = b->d1[i];
     A.z = b->z_dev; A.hz = b->hz_dev;
@@ -456,6 +456,7 @@ tg_batch *tg_batch_create(tg_system *sys, int32_t batch, int32_t device) {
     dalloc(&b->snap, B * (2 * (size_t)P.nq + 2 * (size_t)P.nd + P.nc + P.nu));
     if (ok) ok = hipMalloc(&b->iters, B * sizeof(int)) == hipSuccess && hipMalloc(&b->status, B * sizeof(int)) == hipSuccess &&
                  hipMemset(b->iters, 0, B * sizeof(int)) == hipSuccess && hipMemset(b->status, 0, B * sizeof(int)) == hipSuccess;
+    if (ok) ok = hipMalloc(&b->fallbacks, B * sizeof(int)) == hipSuccess && hipMemset(b->fallbacks, 0, B * sizeof(int)) == hipSuccess;
 #if defined(TG_PROFILE)
     if (ok) ok = hipMalloc(&b->prof, 16 * sizeof(long long)) == hipSuccess && hipMemset(b->prof, 0, 16 * sizeof(long long)) == hipSuccess;
 #endif
@@ -471,7 +472,7 @@ void tg_batch_destroy(tg_batch *b) {
     for (auto &e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : b->pool) hipEventDestroy(e);
     void *ptrs[] = {b->d_args, b->dt_dev, b->d_prog, b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
-                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->snap, b->z_dev, b->hz_dev, b->zl_dev, b->dyn, b->dyn_ints, b->dyn_d1, b->energy, b->lag,
+                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->fallbacks, b->snap, b->z_dev, b->hz_dev, b->zl_dev, b->dyn, b->dyn_ints, b->dyn_d1, b->energy, b->lag,
                     b->d1[0], b->d1[1], b->d1[2], b->d1[3], b->d1[4], b->d1[5], b->d1[6], b->d1[7], b->d1[8], b->d1[9], b->d1[10], b->d1[11]};
     for (void *p : ptrs) if (p) hipFree(p);
     if (b->h_args) hipHostFree(b->h_args);
@@ -549,6 +550,17 @@ int tg_batch_calc_f(tg_batch *b, double *f_host) {
     int rc = launch(b, A);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(f_host, b->f_out, (size_t)b->batch * b->P.nf * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return TG_SUCCESS;
+}
+
+/* Per trajectory: how many Newton systems of the last rollout / step launch the structured solve (bbd.hpp) handed to the pivoting
+ * solver because a pivot guard failed.  Zero for kernels without a structured solve.  Results are correct either way; a batch that
+ * reports fallbacks on most systems (very small time steps, very heavy bodies) runs slower than with the pivoting solver alone. */
+int tg_batch_solver_fallbacks(tg_batch *b, int32_t *fallbacks_out) {
+    if (!b || !fallbacks_out) return fail(TG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpyAsync(fallbacks_out, b->fallbacks, (size_t)b->batch * sizeof(int), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return TG_SUCCESS;
 }

@@ -490,6 +490,13 @@ class BatchMidpointVI(object):
         _lib.check(self._L.tg_batch_status(self._h, iters.ctypes.data, status.ctypes.data))
         return iters, status
 
+    def solver_fallbacks(self):
+        """Per trajectory: Newton systems of the last rollout / step launch that the structured solve of the specialised kernel handed
+        to the pivoting solver (a failed pivot guard; results are unaffected).  tg_batch_solver_fallbacks."""
+        out = np.zeros(self.batch, dtype=np.int32)
+        _lib.check(self._L.tg_batch_solver_fallbacks(self._h, out.ctypes.data_as(_lib._c_ip)))
+        return out
+
     def synchronize(self):
         _lib.check(self._L.tg_batch_synchronize(self._h))
 
