@@ -350,6 +350,23 @@ int tg_batch_dynamics_deriv1_device(tg_batch *b, const double *q_dev, const doub
  * system.py:852-925).  first [B][2][nq] = (L_dq, L_ddq); second [B][3][nq][nq] = (L_dqdq, L_ddqdq with the velocity
  * config as the row and the configuration config as the column, L_ddqddq). */
 int tg_batch_lagrangian(tg_batch *b, const double *q_host, const double *dq_host, double *first_host, double *second_host);
+/* Forward-mode (dual-number) runs of the two calls above: every elementary operation of the analytic kernel carries its exact
+ * derivative along one input variable per trajectory (csrc/dual.hpp) -- no step size, no truncation error.  seed [B]: the
+ * variable, numbered q [nq] | dq [nq] | ddq_k [nk] | u [nu] (-1: none, the outputs are then zero).  The outputs have the layout
+ * of the plain call and hold the DERIVATIVE of each entry along that variable:
+ *   tg_batch_dynamics_deriv1_forward -- the second derivatives of the continuous dynamics: replaces calc_dynamics_deriv2
+ *     (system.c:1301-2029; M_dqdq, D_dqdq ... lambda_dudu, f_dudu) behind System.f_dqdq() ... lambda_dudu() (system.py:982-1078):
+ *     d f_dq / d q_j = f_dqdq[., j], d f_ddq / d q_j = f_ddqdq[., j], d f_ddq / d dq_j = f_ddqddq[., j], ... one variable per trajectory;
+ *   tg_batch_lagrangian_forward -- the third derivatives of the Lagrangian (one seed: System_L_dqdqdq, L_ddqdqdq, L_ddqddqdq,
+ *     system.c:204-268, 336-393, 491-530) and the fourth (seed2 not NULL: L_ddqdqdqdq, L_ddqddqdqdq, system.c:395-457, 532-622),
+ *     behind System.L_dqdqdq() ... L_ddqddqdqdq() (system.py:869-949).
+ * One wavefront per trajectory whatever the system's team size; TG_ERR_UNSUPPORTED if the dual-number slice exceeds the LDS. */
+int tg_batch_dynamics_deriv1_forward(tg_batch *b, const double *q_host, const double *dq_host, const double *u_host,
+                                     const double *ddqk_host, const int32_t *seed_host, double *f_dq, double *f_ddq,
+                                     double *f_dddk, double *f_du, double *lambda_dq, double *lambda_ddq,
+                                     double *lambda_dddk, double *lambda_du, int32_t *status_host);
+int tg_batch_lagrangian_forward(tg_batch *b, const double *q_host, const double *dq_host, const int32_t *seed1_host,
+                                const int32_t *seed2_host, double *first_host, double *second_host);
 
 /* Initial guess of the Newton iteration in the device-resident rollouts.  0 (default): the reference's, q2 <- the previous
  * q2 (midpointvi.py:188-197) -- iteration counts then match the reference's.  1: constant-velocity extrapolation

@@ -16,6 +16,20 @@ struct Emu {
 };
 }  // namespace
 
+// The forward-mode kernels (run_forward: the continuous-dynamics modes on dual numbers), order 1 or 2.
+template <class Real> static void emu_forward(Emu *e, const tg::RunArgs *args) {
+    std::vector<Real> lds((size_t)std::max(e->P.lds_per_team, e->P.g_lds_per_team));
+    for (int t = 0; t < args->batch; t++) {
+        std::fill(lds.begin(), lds.end(), Real(0.0));
+        switch (args->mode) {
+        case tg::MODE_DYNAMICS: tg::run_forward<1, tg::MODE_DYNAMICS, true>(e->P, *args, lds.data(), 0, t); break;
+        case tg::MODE_DYN_DERIV1: tg::run_forward<1, tg::MODE_DYN_DERIV1, true>(e->P, *args, lds.data(), 0, t); break;
+        case tg::MODE_ENERGY: tg::run_forward<1, tg::MODE_ENERGY, true>(e->P, *args, lds.data(), 0, t); break;
+        default: tg::run_forward<1, tg::MODE_LAGRANGIAN, true>(e->P, *args, lds.data(), 0, t); break;
+        }
+    }
+}
+
 extern "C" {
 
 void *emu_create(const tg_system_desc *d) {
@@ -55,5 +69,10 @@ void emu_run(void *h, const tg::RunArgs *args) {
         default: tg::run_trajectory<1, tg::MODE_DERIV2Z, true>(e->P, *args, lds.data(), 0, t); break;
         }
     }
+}
+
+void emu_run_forward(void *h, const tg::RunArgs *args, int order) {
+    if (order == 2) emu_forward<tgdual::Dual<tgdual::Dual<double>>>((Emu *)h, args);
+    else emu_forward<tgdual::Dual<double>>((Emu *)h, args);
 }
 }

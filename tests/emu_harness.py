@@ -22,7 +22,9 @@ class RunArgs(ctypes.Structure):
                 ("q1", _D), ("q2", _D), ("p1", _D), ("p2", _D), ("lam", _D), ("u1", _D),
                 ("U", _D), ("K", _D), ("q2_hint", _D), ("lam_hint", _D), ("Kproj", _D), ("bX", _D), ("bU", _D), ("Uout", _D), ("group_size", ctypes.c_int), ("group_map", _I), ("X", _D), ("f_out", _D),
                 ("d1", _D * 12), ("A_out", _D), ("B_out", _D), ("z", _D), ("hz", _D), ("iters", _I), ("status", _I), ("prof_out", ctypes.c_void_p), ("dt_steps", _D), ("dt_period", ctypes.c_int), ("exact_pivot", ctypes.c_int),
-                ("zl", _D), ("dq_in", _D), ("ddqk_in", _D), ("ddq_out", _D), ("lam_out", _D), ("g1", _D * 8), ("energy_out", _D), ("lag1_out", _D), ("lag2_out", _D), ("mirror", _D)]
+                ("zl", _D), ("dq_in", _D), ("ddqk_in", _D), ("ddq_out", _D), ("lam_out", _D), ("g1", _D * 8), ("energy_out", _D), ("lag1_out", _D), ("lag2_out", _D), ("mirror", _D),
+                ("remap_len", ctypes.c_int), ("remap_stride", ctypes.c_int), ("remap_off", ctypes.c_int), ("remap_count", ctypes.c_int),
+                ("fallbacks", _I), ("seed1", _I), ("seed2", _I)]
 
 
 def lib():
@@ -32,7 +34,8 @@ def lib():
         srcs = [os.path.join(_HERE, "emu", "emu.cpp"),
                 os.path.join(_ROOT, "trep_amd", "csrc", "mvi_core.hpp"),
                 os.path.join(_ROOT, "trep_amd", "csrc", "program.hpp"),
-                os.path.join(_ROOT, "trep_amd", "csrc", "bbd.hpp")]
+                os.path.join(_ROOT, "trep_amd", "csrc", "bbd.hpp"),
+                os.path.join(_ROOT, "trep_amd", "csrc", "dual.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]], check=True)
         L = ctypes.CDLL(so)
@@ -40,6 +43,7 @@ def lib():
         L.emu_create.argtypes = [ctypes.c_void_p]
         L.emu_destroy.argtypes = [ctypes.c_void_p]
         L.emu_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.emu_run_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.emu_lds_doubles.argtypes = [ctypes.c_void_p]
         _LIB = L
     return _LIB
@@ -83,6 +87,19 @@ class EmuBatch(object):
         a.iters = self.iters.ctypes.data_as(_I)
         a.status = self.status.ctypes.data_as(_I)
         return a
+
+    def _run(self, a, seeds=None):
+        """The kernel body over the batch; seeds = (seed1,) or (seed1, seed2) [B] int32 arrays: the forward-mode kernel (run_forward) instead,
+        whose outputs are the derivatives along those input variables (numbered q | dq | ddq_k | u)."""
+        if seeds is None:
+            self.L.emu_run(self.h, ctypes.byref(a))
+            return
+        keep = [np.ascontiguousarray(s_, dtype=np.int32) for s_ in seeds]
+        assert all(k.shape == (self.B,) for k in keep)
+        a.seed1 = keep[0].ctypes.data_as(_I)
+        if len(keep) > 1:
+            a.seed2 = keep[1].ctypes.data_as(_I)
+        self.L.emu_run_forward(self.h, ctypes.byref(a), len(keep))
 
     def initialize_from_configs(self, t0, Q0, t1, Q1):
         self.t1, self.t2 = t0, t1
@@ -158,18 +175,18 @@ class EmuBatch(object):
         self.L.emu_run(self.h, ctypes.byref(a))
         return out
 
-    def lagrangian(self, Q, dQ):
-        """(L1 [B][2][nq], L2 [B][3][nq][nq]): first and second derivatives of the Lagrangian of every state."""
+    def lagrangian(self, Q, dQ, seeds=None):
+        """(L1 [B][2][nq], L2 [B][3][nq][nq]): first and second derivatives of the Lagrangian of every state (seeds: their derivatives)."""
         Q = np.ascontiguousarray(Q, dtype=float)
         dQ = np.ascontiguousarray(dQ, dtype=float)
         o1, o2 = np.zeros((self.B, 2, self.nq)), np.zeros((self.B, 3, self.nq, self.nq))
         a = self._args(8)
         a.q1 = a.q2 = _p(Q)
         a.dq_in, a.lag1_out, a.lag2_out = _p(dQ), _p(o1), _p(o2)
-        self.L.emu_run(self.h, ctypes.byref(a))
+        self._run(a, seeds)
         return o1, o2
 
-    def dynamics_deriv1(self, Q, dQ, U=None, ddK=None):
+    def dynamics_deriv1(self, Q, dQ, U=None, ddK=None, seeds=None):
         """First derivatives of the continuous dynamics, in the layout of the reference's accessors
         (System.f_dq() ...): dict of [B][output][derivative variable] arrays."""
         Q = np.ascontiguousarray(Q, dtype=float)
@@ -188,7 +205,7 @@ class EmuBatch(object):
             arr = np.zeros((self.B, rows[g & 3], width))
             arrs[("f_" if g < 4 else "lam_") + names[g & 3]] = arr
             a.g1[g] = arr.ctypes.data_as(_D) if arr.size else ctypes.cast(0, _D)
-        self.L.emu_run(self.h, ctypes.byref(a))
+        self._run(a, seeds)
         return dict((k, np.swapaxes(v, 1, 2)) for k, v in arrs.items()), self.status.copy()
 
     def deriv2z(self, Z, ZL=None):

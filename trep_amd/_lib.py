@@ -81,6 +81,8 @@ _SIGNATURES = {
     "tg_batch_dynamics_deriv1_device": (ctypes.c_int, [ctypes.c_void_p] * 7),
     "tg_batch_energy": (ctypes.c_int, [ctypes.c_void_p] * 4),
     "tg_batch_lagrangian": (ctypes.c_int, [ctypes.c_void_p] * 5),
+    "tg_batch_lagrangian_forward": (ctypes.c_int, [ctypes.c_void_p] * 7),
+    "tg_batch_dynamics_deriv1_forward": (ctypes.c_int, [ctypes.c_void_p] * 15),
     "tg_batch_set_predictor": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "tg_batch_deriv2_contract_lambda": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tg_batch_snapshot": (ctypes.c_int, [ctypes.c_void_p]),

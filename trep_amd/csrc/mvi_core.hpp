@@ -21,6 +21,7 @@
 #include <cmath>
 
 #include "program.hpp"
+#include "dual.hpp"
 
 #if defined(__HIPCC__)
 #define TG_HD __host__ __device__ __forceinline__
@@ -249,6 +250,10 @@ struct RunArgs {
     int remap_len, remap_stride, remap_off, remap_count;
     int *fallbacks;                        // rollout / step, optional: [batch] how many Newton systems of this launch the structured solve handed to the pivoting solver
                                            // (a failed pivot guard: correct, but slower than either solver alone)
+    // forward-mode kernels (run_forward): per trajectory the input variable each direction follows, numbered q [nq] | dq [nq] | ddq_k [nk] | u [nu]
+    // (-1: none); seed2 null for first-order kernels.  The outputs (g1 / ddq_out / lam_out / lag1_out / lag2_out / energy_out) then receive the
+    // derivative of the quantity along seed1 (and seed2) instead of the quantity.
+    const int *seed1, *seed2;
 };
 // which trajectory of the batch a launch's i-th trajectory is (RunArgs::remap_*); A.batch for an index past the subset (an idle team)
 template <class ARGS> TG_HD int tg_remap_trajectory(const ARGS &A, int i) {
@@ -322,8 +327,14 @@ TG_HD void tg_sincos(double x, double *s, double *c) {
     *c = ((q + 1) & 2) ? -cc : cc;
 }
 
+template <class T> TG_HD void tg_sincos(const tgdual::Dual<T> &x, tgdual::Dual<T> *s, tgdual::Dual<T> *c) {
+    T sv, cv;
+    tg_sincos(x.v, &sv, &cv);
+    *s = tgdual::Dual<T>(sv, cv * x.d);
+    *c = tgdual::Dual<T>(cv, -(sv * x.d));
+}
 // [a,b] = ad_a b for twists stored (v, w)
-TG_HD void bracket(const double *a, const double *b, double *r) {
+template <class RA, class RB, class RR> TG_HD void bracket(const RA *a, const RB *b, RR *r) {
     r[0] = a[4] * b[2] - a[5] * b[1] + a[1] * b[5] - a[2] * b[4];
     r[1] = a[5] * b[0] - a[3] * b[2] + a[2] * b[3] - a[0] * b[5];
     r[2] = a[3] * b[1] - a[4] * b[0] + a[0] * b[4] - a[1] * b[3];
@@ -332,6 +343,7 @@ TG_HD void bracket(const double *a, const double *b, double *r) {
     r[5] = a[3] * b[4] - a[4] * b[3];
 }
 // accumulate into LDS from several lanes at once
+template <class T, class V> TG_HD void lds_add(tgdual::Dual<T> *p, const V &v);
 TG_HD void lds_add(double *p, double v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -340,6 +352,10 @@ TG_HD void lds_add(double *p, double v) {
 #endif
 }
 // accumulate into a global output from several lanes / bodies
+template <class T, class V> TG_HD void lds_add(tgdual::Dual<T> *p, const V &v) {   // (forward-mode scalars: part by part)
+    const tgdual::Dual<T> x(v);
+    lds_add(&p->v, x.v); lds_add(&p->d, x.d);
+}
 TG_HD void gl_add(double *p, double v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicAdd(p, v);
@@ -347,7 +363,7 @@ TG_HD void gl_add(double *p, double v) {
     *p += v;
 #endif
 }
-TG_HD double inner6(const double *I, const double *a, const double *b) {
+template <class RI, class RA, class RB> TG_HD auto inner6(const RI *I, const RA *a, const RB *b) -> decltype(I[0] * (a[0] * b[0])) {
     return I[0] * (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]) + I[1] * (a[3] * b[3]) + I[2] * (a[4] * b[4]) +
            I[3] * (a[5] * b[5]);
 }
@@ -379,7 +395,9 @@ TG_HD void team_argmax(double &v, int &i) {
 // that the spring-free kernels keep their instruction stream and register allocation.
 template <int V> struct IntTag { static constexpr int value = V; };
 
-template <int TEAM, bool SPRINGS = false, class PROG = CProg>
+// Real: the scalar the trajectory's LDS slice holds -- double everywhere except the forward-mode kernels of the continuous dynamics (dual.hpp),
+// which run dynamics / dyn_deriv1 / lagrangian and what those call on Dual numbers; every other member is only ever instantiated for double.
+template <int TEAM, bool SPRINGS = false, class PROG = CProg, class Real = double>
 struct Core {
     TG_HD bool has_cs() const { return SPRINGS && P.has_cs; }
     // Potentials on a single config: d1 = V_dq, d2 = V_dqdq, d3 = V_dqdqdq of config i at the value q.  ConfigSpring
@@ -387,26 +405,26 @@ struct Core {
     // (nonlinear_config_spring.c:24-61): -y(x), -y'(x) m, +y''(x) m^2 with x = m q + b and y the piecewise quintic of
     // trep/spline.py (table rows: left knot, a..f; piece = number of later pieces whose left knot is <= x, spline.c:8-22).
     // The sign of the third derivative is the reference's (-ddy * -m * m, :48-58), not the derivative of the second.
-    TG_HD void cs_eval(int i, double q, double &d1, double &d2, double &d3) const {
+    TG_HD void cs_eval(int i, Real q, Real &d1, Real &d2, Real &d3) const {
         d1 = P.cs_k[i] * q - P.cs_kq0[i]; d2 = P.cs_k[i]; d3 = 0.0;
         for (int sp = 0; sp < P.n_ncs; sp++) {
             if (P.ncs_i[3 * sp] != i) continue;
-            const double m = P.ncs_mb[2 * sp], x = m * q + P.ncs_mb[2 * sp + 1];
+            const Real m = P.ncs_mb[2 * sp], x = m * q + P.ncs_mb[2 * sp + 1];
             const double *tab = P.ncs_tab + 7 * (size_t)P.ncs_i[3 * sp + 1];
             const int pieces = P.ncs_i[3 * sp + 2];
             int seg = 0;
             for (int j = 1; j < pieces; j++) seg += x >= tab[7 * j] ? 1 : 0;
             const double *c = tab + 7 * seg;
-            const double t = x - c[0];
-            const double y = c[1] * t * t * t * t * t + c[2] * t * t * t * t + c[3] * t * t * t + c[4] * t * t + c[5] * t + c[6];
-            const double dy = 5 * c[1] * t * t * t * t + 4 * c[2] * t * t * t + 3 * c[3] * t * t + 2 * c[4] * t + 1 * c[5];
-            const double ddy = 20 * c[1] * t * t * t + 12 * c[2] * t * t + 6 * c[3] * t + 2 * c[4];
+            const Real t = x - c[0];
+            const Real y = c[1] * t * t * t * t * t + c[2] * t * t * t * t + c[3] * t * t * t + c[4] * t * t + c[5] * t + c[6];
+            const Real dy = 5 * c[1] * t * t * t * t + 4 * c[2] * t * t * t + 3 * c[3] * t * t + 2 * c[4] * t + 1 * c[5];
+            const Real ddy = 20 * c[1] * t * t * t + 12 * c[2] * t * t + 6 * c[3] * t + 2 * c[4];
             d1 -= y; d2 -= dy * m; d3 += ddy * m * m;
         }
     }
-    TG_HD double cs_d1(int i, double q) const { double a, b, c; cs_eval(i, q, a, b, c); return a; }
-    TG_HD double cs_d2(int i, double q) const { double a, b, c; cs_eval(i, q, a, b, c); return b; }
-    TG_HD double cs_d3(int i, double q) const { double a, b, c; cs_eval(i, q, a, b, c); return c; }
+    TG_HD Real cs_d1(int i, Real q) const { Real a, b, c; cs_eval(i, q, a, b, c); return a; }
+    TG_HD Real cs_d2(int i, Real q) const { Real a, b, c; cs_eval(i, q, a, b, c); return b; }
+    TG_HD Real cs_d3(int i, Real q) const { Real a, b, c; cs_eval(i, q, a, b, c); return c; }
     TG_HD int n_springs() const { return SPRINGS ? P.n_springs : 0; }
     TG_HD int n_spair() const { return SPRINGS ? P.n_spair : 0; }
     TG_HD int n_sdh() const { return SPRINGS ? P.n_sdh : 0; }
@@ -417,8 +435,10 @@ struct Core {
     TG_HD int n_wpair() const { return SPRINGS ? P.n_wpair : 0; }
     const double *d2w = nullptr;   // adjoint weights while the second-derivative kernel evaluates the midpoint, else null
     PROG &P;
-    double *S;
+    Real *S;
     int lane;
+    int seed1 = -1, seed2 = -1;   // forward-mode kernels: the input variables (0 .. 2 nq + nk + nu: q, dq, ddq_k, u) the two directions follow
+    TG_HD Real seeded(double v, int var) const { return tgdual::Seed<Real>::make(v, var == seed1, var == seed2); }
     double dt;
     int oGc;   // LDS offset of the joint poses that the end-point / constraint evaluation reads (P.o_G, or the second pose set of a dual sweep)
     int dsA = 0, dsB = 2;   // which configurations the two pose sets of pose_sweep_dual belong to (qval selectors: 0 midpoint, 1 q1, 2 q2)
@@ -453,7 +473,7 @@ struct Core {
         lo = first; hi = last;
         if (nw > 1) { lo = wave ? split : first; hi = wave ? last : split; }
     }
-    TG_HD Core(PROG &p, double *s, int l, double dt_) : P(p), S(s), lane(l), dt(dt_), oGc(p.o_G), inv_dt(1.0 / dt_) {}
+    TG_HD Core(PROG &p, Real *s, int l, double dt_) : P(p), S(s), lane(l), dt(dt_), oGc(p.o_G), inv_dt(1.0 / dt_) {}
     // x / dt with the step's reciprocal (inv_dt follows dt): the quotient estimate and one residual correction -- three
     // dependent operations instead of the ten of the division sequence; the correctly rounded quotient (Markstein's final step)
     double inv_dt;
@@ -475,8 +495,8 @@ struct Core {
     }
 
     // configuration value at the evaluation point: 0 midpoint, 1 q1, 2 q2 (midpointvi.c:401-457)
-    TG_HD double qval(int sel, int c) const {
-        double a = S[P.o_q1 + c], b = S[P.o_q2 + c];
+    TG_HD Real qval(int sel, int c) const {
+        Real a = S[P.o_q1 + c], b = S[P.o_q2 + c];
         return sel == 0 ? 0.5 * (b + a) : (sel == 1 ? a : b);
     }
 
@@ -582,9 +602,9 @@ struct Core {
 
     TG_HD void pose_sweep(bool on, int sel) {
         PROG &P = tg_fresh(this->P);
-        double *sc = S + P.o_sc, *G = S + P.o_G;
+        Real *sc = S + P.o_sc, *G = S + P.o_G;
         if (on) TG_FOR(j, P.n_joints) {
-            const double x = qval(sel, P.j_cfg[j]);
+            const Real x = qval(sel, P.j_cfg[j]);
             if (P.j_kind[j] >= TG_RX) tg_sincos(x, &sc[2 * j], &sc[2 * j + 1]);
             else { sc[2 * j] = x; sc[2 * j + 1] = 0.0; }
         }
@@ -627,23 +647,23 @@ struct Core {
                         o0 = 12 * P.ch_first[ch]; len = P.ch_len[ch]; opar = P.ch_parent[ch] >= 0 ? 12 * P.ch_parent[ch] : -1;
                     }
                     if (row < 3 && len > 0) {
-                        double p0, p1, p2, p3;
-                        if (opar >= 0) { const double *gp = G + opar + 4 * row; p0 = gp[0]; p1 = gp[1]; p2 = gp[2]; p3 = gp[3]; }
+                        Real p0, p1, p2, p3;
+                        if (opar >= 0) { const Real *gp = G + opar + 4 * row; p0 = gp[0]; p1 = gp[1]; p2 = gp[2]; p3 = gp[3]; }
                         else { p0 = row == 0 ? 1.0 : 0.0; p1 = row == 1 ? 1.0 : 0.0; p2 = row == 2 ? 1.0 : 0.0; p3 = 0.0; }
-                        double m[12];
+                        Real m[12];
 #pragma unroll
                         for (int e = 0; e < 12; e++) m[e] = G[o0 + e];
                         for (int s = 0; s < len; s++) {
-                            double *gj = G + o0 + 12 * s;
-                            double n[12];                                // next local transform: loads before this step's stores
-                            const double *gn = s + 1 < len ? gj + 12 : gj;
+                            Real *gj = G + o0 + 12 * s;
+                            Real n[12];                                // next local transform: loads before this step's stores
+                            const Real *gn = s + 1 < len ? gj + 12 : gj;
 #pragma unroll
                             for (int e = 0; e < 12; e++) n[e] = gn[e];
-                            const double v0 = p0 * m[0] + p1 * m[4] + p2 * m[8];
-                            const double v1 = p0 * m[1] + p1 * m[5] + p2 * m[9];
-                            const double v2 = p0 * m[2] + p1 * m[6] + p2 * m[10];
-                            const double v3 = p0 * m[3] + p1 * m[7] + p2 * m[11] + p3;
-                            double *out = gj + 4 * row;
+                            const Real v0 = p0 * m[0] + p1 * m[4] + p2 * m[8];
+                            const Real v1 = p0 * m[1] + p1 * m[5] + p2 * m[9];
+                            const Real v2 = p0 * m[2] + p1 * m[6] + p2 * m[10];
+                            const Real v3 = p0 * m[3] + p1 * m[7] + p2 * m[11] + p3;
+                            Real *out = gj + 4 * row;
                             out[0] = v0; out[1] = v1; out[2] = v2; out[3] = v3;
                             p0 = v0; p1 = v1; p2 = v2; p3 = v3;
 #pragma unroll
@@ -661,12 +681,12 @@ struct Core {
             if (on) TG_FOR(idx, 4 * cnt) {
                 const int j = P.lvl_joints[l0 + (idx >> 2)], cc = idx & 3;
                 if (P.j_parent[j] < 0) continue;
-                const double *gp = G + 12 * P.j_parent[j];
-                double *gj = G + 12 * j;
-                const double m0 = gj[cc], m1 = gj[4 + cc], m2 = gj[8 + cc], u3 = (cc == 3) ? 1.0 : 0.0;
-                const double v0 = gp[0] * m0 + gp[1] * m1 + gp[2] * m2 + u3 * gp[3];
-                const double v1 = gp[4] * m0 + gp[5] * m1 + gp[6] * m2 + u3 * gp[7];
-                const double v2 = gp[8] * m0 + gp[9] * m1 + gp[10] * m2 + u3 * gp[11];
+                const Real *gp = G + 12 * P.j_parent[j];
+                Real *gj = G + 12 * j;
+                const Real m0 = gj[cc], m1 = gj[4 + cc], m2 = gj[8 + cc], u3 = (cc == 3) ? 1.0 : 0.0;
+                const Real v0 = gp[0] * m0 + gp[1] * m1 + gp[2] * m2 + u3 * gp[3];
+                const Real v1 = gp[4] * m0 + gp[5] * m1 + gp[6] * m2 + u3 * gp[7];
+                const Real v2 = gp[8] * m0 + gp[9] * m1 + gp[10] * m2 + u3 * gp[11];
                 gj[cc] = v0; gj[4 + cc] = v1; gj[8 + cc] = v2;
             }
             TG_SYNC();
@@ -1594,7 +1614,7 @@ struct Core {
     // ---- poses of the massive frames and positions of the constraint end points --------------------
     TG_HD void attach_points(bool on, bool bodies, bool endpoints) {
         PROG &P = tg_fresh(this->P);
-        const double *G = S + P.o_G;
+        const Real *G = S + P.o_G;
         // Branch-free: an unanchored frame (anchor < 0: fixed to the world) reads joint 0 and weights it out.  A branch
         // would split the loop body into basic blocks that each wait for their own loads.
         if (on && bodies) TG_FOR(idx, 12 * P.n_bodies) {
@@ -1602,9 +1622,9 @@ struct Core {
             const double *C = P.b_C + 12 * b;
             const int anchor = P.b_anchor[b];
             const double ce = C[e], c0 = C[c], c1 = C[4 + c], c2 = C[8 + c];
-            const double *g = G + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
-            const double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
-            const double val = g0 * c0 + g1 * c1 + g2 * c2 + (c == 3 ? g3 : 0.0);
+            const Real *g = G + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
+            const Real g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+            const Real val = g0 * c0 + g1 * c1 + g2 * c2 + (c == 3 ? g3 : 0.0);
             S[P.o_gB + idx] = anchor < 0 ? ce : val;
         }
         if (on && endpoints) TG_FOR(idx, 3 * P.n_endpoints) {
@@ -1612,24 +1632,24 @@ struct Core {
             const double *o = P.e_off + 3 * e;
             const int anchor = P.e_anchor[e];
             const double o0 = o[0], o1 = o[1], o2 = o[2], orr = o[r];
-            const double *g = S + oGc + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
-            const double val = g[0] * o0 + g[1] * o1 + g[2] * o2 + g[3];
+            const Real *g = S + oGc + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
+            const Real val = g[0] * o0 + g[1] * o1 + g[2] * o2 + g[3];
             S[P.o_pE + idx] = anchor < 0 ? orr : val;
         }
         if (on && endpoints && n_wrenches()) TG_FOR(idx, 9 * P.n_wrenches) {   // world rotation of every wrench frame
             const int w = idx / 9, r = (idx % 9) / 3, cc = idx % 3;
             const double *Rl = P.wr_Rloc + 9 * w;
             const int anchor = P.e_anchor[P.c_e1[P.nc + n_springs() + w]];
-            const double *g = G + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
-            const double val = g[0] * Rl[cc] + g[1] * Rl[3 + cc] + g[2] * Rl[6 + cc];
+            const Real *g = G + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
+            const Real val = g[0] * Rl[cc] + g[1] * Rl[3 + cc] + g[2] * Rl[6 + cc];
             S[P.o_wR + idx] = anchor < 0 ? Rl[3 * r + cc] : val;
         }
         if (on && endpoints && has_plane()) TG_FOR(idx, 3 * P.nc) {   // world normal of every plane constraint
             const int c = idx / 3, r = idx % 3;
             const double *nl = P.c_nloc + 3 * c;
             const int anchor = P.e_anchor[P.c_e1[c]];
-            const double *g = G + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
-            const double val = g[0] * nl[0] + g[1] * nl[1] + g[2] * nl[2];
+            const Real *g = G + 12 * (anchor < 0 ? 0 : anchor) + 4 * r;
+            const Real val = g[0] * nl[0] + g[1] * nl[1] + g[2] * nl[2];
             S[P.o_nE + idx] = anchor < 0 ? nl[r] : val;
         }
         TG_SYNC();
@@ -1638,18 +1658,18 @@ struct Core {
     // ---- body Jacobian columns J_{F,k} and gravity in body coordinates ------------------------------
     TG_HD void jacobians(bool on) {
         PROG &P = tg_fresh(this->P);
-        const double *G = S + P.o_G;
-        struct JacOut { double J[6], dq; };
+        const Real *G = S + P.o_G;
+        struct JacOut { Real J[6], dq; };
         if (on) for_pairs(P.n_items, [&](int it) {
             const int *rec = P.it_pack + 4 * (size_t)it;
             const int b = rec[0], oj = rec[1], kind = rec[2], cfg = rec[3] & 0xFFFF;
-            const double *gb = S + P.o_gB + 12 * b, *gj = G + oj;
+            const Real *gb = S + P.o_gB + 12 * b, *gj = G + oj;
             // branch-free: the joint axis column is read either way (column kind-TX or kind-RX of the joint pose)
             const bool prismatic = kind <= TG_TZ;
             const int ax = prismatic ? kind - TG_TX : kind - TG_RX;
-            const double a0 = gj[ax], a1 = gj[4 + ax], a2 = gj[8 + ax];
-            const double dx = gb[3] - gj[3], dy = gb[7] - gj[7], dz = gb[11] - gj[11];
-            double lin[3], ang[3];
+            const Real a0 = gj[ax], a1 = gj[4 + ax], a2 = gj[8 + ax];
+            const Real dx = gb[3] - gj[3], dy = gb[7] - gj[7], dz = gb[11] - gj[11];
+            Real lin[3], ang[3];
             ang[0] = prismatic ? 0.0 : a0; ang[1] = prismatic ? 0.0 : a1; ang[2] = prismatic ? 0.0 : a2;
             lin[0] = prismatic ? a0 : a1 * dz - a2 * dy;
             lin[1] = prismatic ? a1 : a2 * dx - a0 * dz;
@@ -1662,13 +1682,13 @@ struct Core {
             o.dq = S[P.o_dq + cfg];  // rate of the item's config, for the prefix sums
             return o;
         }, [&](int it, const JacOut &o) {
-            double *J = S + P.o_J + 6 * it;
+            Real *J = S + P.o_J + 6 * it;
             for (int r = 0; r < 6; r++) J[r] = o.J[r];
             S[P.o_dqi + it] = o.dq;
         });
         if (on) TG_FOR(idx, 3 * P.n_bodies) {
             const int b = idx / 3, r = idx % 3;
-            const double *gb = S + P.o_gB + 12 * b;
+            const Real *gb = S + P.o_gB + 12 * b;
             S[P.o_gam + idx] = gb[r] * P.grav[0] + gb[4 + r] * P.grav[1] + gb[8 + r] * P.grav[2];
         }
         TG_SYNC();
@@ -1683,11 +1703,11 @@ struct Core {
         if (on) TG_FOR(idx, 6 * P.n_bodies) {
             const int b = idx / 6, m = idx % 6;
             const int first = P.b_item_off[b], last = P.b_item_off[b + 1];
-            double acc = 0.0;
+            Real acc = 0.0;
             // four items per trip, their loads ahead of the stores (an LDS store may alias the next load as far as the compiler
             // knows, so a load-fma-store loop waits out the LDS latency once per item)
             for (int k = first; k < last; k += 4) {
-                double jv[4], dv[4];
+                Real jv[4], dv[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int kk = k + u < last ? k + u : last - 1;
@@ -1702,9 +1722,9 @@ struct Core {
         }
         TG_SYNC();
         if (on) TG_FOR(it, P.n_items) {
-            double *W = S + P.o_W + 6 * it;
-            const double *J = S + P.o_J + 6 * it;
-            const double Pp[6] = {W[0], W[1], W[2], W[3], W[4], W[5]};
+            Real *W = S + P.o_W + 6 * it;
+            const Real *J = S + P.o_J + 6 * it;
+            const Real Pp[6] = {W[0], W[1], W[2], W[3], W[4], W[5]};
             bracket(Pp, J, W);
         }
         TG_SYNC();
@@ -1750,26 +1770,26 @@ struct Core {
     }
 
     // d p_E / d q_k in world coordinates
-    TG_HD void dpos(int e, int j, double *d) const {
-        const double *gj = S + P.o_G + 12 * j;
+    TG_HD void dpos(int e, int j, Real *d) const {
+        const Real *gj = S + P.o_G + 12 * j;
         const int kind = P.j_kind[j];
         if (kind <= TG_TZ) { const int a = kind - TG_TX; d[0] = gj[a]; d[1] = gj[4 + a]; d[2] = gj[8 + a]; }
         else {
             const int a = kind - TG_RX;
-            const double wx = gj[a], wy = gj[4 + a], wz = gj[8 + a];
-            const double *pe = S + P.o_pE + 3 * e;
-            const double dx = pe[0] - gj[3], dy = pe[1] - gj[7], dz = pe[2] - gj[11];
+            const Real wx = gj[a], wy = gj[4 + a], wz = gj[8 + a];
+            const Real *pe = S + P.o_pE + 3 * e;
+            const Real dx = pe[0] - gj[3], dy = pe[1] - gj[7], dz = pe[2] - gj[11];
             d[0] = wy * dz - wz * dy; d[1] = wz * dx - wx * dz; d[2] = wx * dy - wy * dx;
         }
     }
 
     // same with the joint given by its pose offset and kind, the end point by its offset (packed dh records)
-    TG_HD void dpos_rec(int oe, int oj, int kind, double *d) const {
-        const double *gj = S + oGc + oj, *pe = S + P.o_pE + oe;
+    TG_HD void dpos_rec(int oe, int oj, int kind, Real *d) const {
+        const Real *gj = S + oGc + oj, *pe = S + P.o_pE + oe;
         const bool prismatic = kind <= TG_TZ;
         const int a = prismatic ? kind - TG_TX : kind - TG_RX;
-        const double wx = gj[a], wy = gj[4 + a], wz = gj[8 + a];
-        const double dx = pe[0] - gj[3], dy = pe[1] - gj[7], dz = pe[2] - gj[11];
+        const Real wx = gj[a], wy = gj[4 + a], wz = gj[8 + a];
+        const Real dx = pe[0] - gj[3], dy = pe[1] - gj[7], dz = pe[2] - gj[11];
         d[0] = prismatic ? wx : wy * dz - wz * dy;
         d[1] = prismatic ? wy : wz * dx - wx * dz;
         d[2] = prismatic ? wz : wx * dy - wy * dx;
@@ -1777,16 +1797,16 @@ struct Core {
 
     // ---- constraint values (into f[nd..]) and Jacobian Dh (into dest) at the swept state -------------
     // distance.c:16-63, point.c:16-38.  `sel` picks the config vector for the length configs.
-    TG_HD void constraints(bool on, int sel, bool want_h, double *Dh, int ld) {
+    TG_HD void constraints(bool on, int sel, bool want_h, Real *Dh, int ld) {
         PROG &P = tg_fresh(this->P);
         if (on && want_h) TG_FOR(c, P.nc) {
-            const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
-            const double vx = a[0] - b[0], vy = a[1] - b[1], vz = a[2] - b[2];
-            double h;
-            if (has_plane() && P.c_type[c] == TG_CONSTRAINT_PLANE) { const double *nw = S + P.o_nE + 3 * c; h = nw[0] * vx + nw[1] * vy + nw[2] * vz; }
+            const Real *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
+            const Real vx = a[0] - b[0], vy = a[1] - b[1], vz = a[2] - b[2];
+            Real h;
+            if (has_plane() && P.c_type[c] == TG_CONSTRAINT_PLANE) { const Real *nw = S + P.o_nE + 3 * c; h = nw[0] * vx + nw[1] * vy + nw[2] * vz; }
             else if (P.c_type[c] == TG_CONSTRAINT_POINT) h = P.c_comp[c] == 0 ? vx : (P.c_comp[c] == 1 ? vy : vz);
             else {
-                const double len = P.c_cfg[c] >= 0 ? qval(sel, P.c_cfg[c]) : P.c_dist[c];
+                const Real len = P.c_cfg[c] >= 0 ? qval(sel, P.c_cfg[c]) : P.c_dist[c];
                 h = (vx * vx + vy * vy + vz * vz) - len * len;
             }
             S[P.o_f + P.nd + c] = h;
@@ -1795,24 +1815,24 @@ struct Core {
             const int *rec = P.dh_pack + 8 * (size_t)n;   // one record instead of chained table look-ups
             const int c = rec[0], k = rec[1], oj = rec[2], w = rec[3], oe1 = rec[4], oe2 = rec[5];
             const int side = w & 0xFF, kind = (w >> 8) & 0xFF, type = (w >> 16) & 0xFF, comp = w >> 24;
-            double d1[3], d2[3];
+            Real d1[3], d2[3];
             const int ojc = oj < 0 ? 0 : oj;                 // the length config drives no joint: both sides weighted out
             dpos_rec(oe1, ojc, kind, d1);
             dpos_rec(oe2, ojc, kind, d2);
-            const double s1 = (side & 1) ? 1.0 : 0.0, s2 = (side & 2) ? 1.0 : 0.0;
-            const double dx = s1 * d1[0] - s2 * d2[0], dy = s1 * d1[1] - s2 * d2[1], dz = s1 * d1[2] - s2 * d2[2];
-            double val;
+            const Real s1 = (side & 1) ? 1.0 : 0.0, s2 = (side & 2) ? 1.0 : 0.0;
+            const Real dx = s1 * d1[0] - s2 * d2[0], dy = s1 * d1[1] - s2 * d2[1], dz = s1 * d1[2] - s2 * d2[2];
+            Real val;
             if (has_plane() && type == TG_CONSTRAINT_PLANE) {   // plane.c:28-45: (dR n) . (p1 - p2) + (R n) . d(p1 - p2)
-                const double *nw = S + P.o_nE + 3 * c, *a = S + P.o_pE + oe1, *b = S + P.o_pE + oe2, *gj = S + P.o_G + ojc;
+                const Real *nw = S + P.o_nE + 3 * c, *a = S + P.o_pE + oe1, *b = S + P.o_pE + oe2, *gj = S + P.o_G + ojc;
                 const bool turns = kind >= TG_RX && (side & 1);
                 const int ax = kind >= TG_RX ? kind - TG_RX : 0;
-                const double wx = turns ? gj[ax] : 0.0, wy = turns ? gj[4 + ax] : 0.0, wz = turns ? gj[8 + ax] : 0.0;
-                const double n1x = wy * nw[2] - wz * nw[1], n1y = wz * nw[0] - wx * nw[2], n1z = wx * nw[1] - wy * nw[0];
+                const Real wx = turns ? gj[ax] : 0.0, wy = turns ? gj[4 + ax] : 0.0, wz = turns ? gj[8 + ax] : 0.0;
+                const Real n1x = wy * nw[2] - wz * nw[1], n1y = wz * nw[0] - wx * nw[2], n1z = wx * nw[1] - wy * nw[0];
                 val = n1x * (a[0] - b[0]) + n1y * (a[1] - b[1]) + n1z * (a[2] - b[2]) + nw[0] * dx + nw[1] * dy + nw[2] * dz;
             }
             else if (type == TG_CONSTRAINT_POINT) val = comp == 0 ? dx : (comp == 1 ? dy : dz);
             else {
-                const double *a = S + P.o_pE + oe1, *b = S + P.o_pE + oe2;
+                const Real *a = S + P.o_pE + oe1, *b = S + P.o_pE + oe2;
                 val = (a[0] - b[0]) * dx + (a[1] - b[1]) * dy + (a[2] - b[2]) * dz;
                 if (side & 4) val -= qval(sel, k);
                 val *= 2.0;
@@ -2201,11 +2221,11 @@ struct Core {
     //      columns divided through, i.e. A[i][n + r] = x_i.
     //      Lane mapping is 2-D (row group x power-of-two column tile) so the inner loops need no
     //      integer division; the pivot is an arg-max butterfly over the team.
-    TG_HD bool gauss_jordan(bool on, double *A, int n, int n_rhs, int ld, double *scal) {
+    TG_HD bool gauss_jordan(bool on, Real *A, int n, int n_rhs, int ld, Real *scal) {
         bool ok = true;
         if (on) TG_FOR(i, n) {
-            double s = -1.0;
-            for (int j = 0; j < n; j++) { const double a = fabs(A[i * ld + j]); if (a > s) s = a; }
+            Real s = -1.0;
+            for (int j = 0; j < n; j++) { const Real a = fabs(A[i * ld + j]); if (a > s) s = a; }
             scal[i] = 1.0 / s;
         }
         TG_SYNC();
@@ -2216,7 +2236,7 @@ struct Core {
             int piv = k;
             if (on && ok) {
                 for (int i = k + lane; i < n; i += TEAM) {
-                    const double a = fabs(A[i * ld + k] * scal[i]);
+                    const double a = tgdual::primal(fabs(A[i * ld + k] * scal[i]));
                     if (a > best) { best = a; piv = i; }
                 }
             }
@@ -2225,7 +2245,7 @@ struct Core {
             const bool go = on && ok;
             if (go && piv != k) {
                 for (int j = k + lane; j < w; j += TEAM) {
-                    const double t = A[k * ld + j]; A[k * ld + j] = A[piv * ld + j]; A[piv * ld + j] = t;
+                    const Real t = A[k * ld + j]; A[k * ld + j] = A[piv * ld + j]; A[piv * ld + j] = t;
                 }
                 if (lane == 0) scal[piv] = scal[k];
             }
@@ -2236,25 +2256,25 @@ struct Core {
                 const int cwl = tile_log2<TEAM>(cols);   // column tile = 2^cwl lanes, rows share the rest
                 const int cw = 1 << cwl, rstep = TEAM >> cwl;
                 const int jc = lane & (cw - 1);
-                const double rinv = 1.0 / A[k * ld + k];
+                const Real rinv = 1.0 / A[k * ld + k];
                 // A lane keeps its column(s): the pivot-row entry is loaded once.  Rows are taken four at a time with
                 // all LDS loads issued before the first store: the compiler must assume that a store may alias the
                 // next load, so a load-store-load-store sequence would pay the full LDS latency per row.
                 for (int j = k + 1 + jc; j < w; j += cw) {
-                    const double pk = A[k * ld + j];
+                    const Real pk = A[k * ld + j];
                     const int i0 = lane >> cwl;
                     int i = i0;
                     for (; i + 3 * rstep < n; i += 4 * rstep) {
                         const int r0 = i, r1 = i + rstep, r2 = i + 2 * rstep, r3 = i + 3 * rstep;
-                        const double l0 = A[r0 * ld + k], l1 = A[r1 * ld + k], l2 = A[r2 * ld + k], l3 = A[r3 * ld + k];
-                        const double a0 = A[r0 * ld + j], a1 = A[r1 * ld + j], a2 = A[r2 * ld + j], a3 = A[r3 * ld + j];
+                        const Real l0 = A[r0 * ld + k], l1 = A[r1 * ld + k], l2 = A[r2 * ld + k], l3 = A[r3 * ld + k];
+                        const Real a0 = A[r0 * ld + j], a1 = A[r1 * ld + j], a2 = A[r2 * ld + j], a3 = A[r3 * ld + j];
                         if (r0 != k) A[r0 * ld + j] = fma(-(l0 * rinv), pk, a0);
                         if (r1 != k) A[r1 * ld + j] = fma(-(l1 * rinv), pk, a1);
                         if (r2 != k) A[r2 * ld + j] = fma(-(l2 * rinv), pk, a2);
                         if (r3 != k) A[r3 * ld + j] = fma(-(l3 * rinv), pk, a3);
                     }
                     for (; i < n; i += rstep) {
-                        const double l = A[i * ld + k] * rinv, a = A[i * ld + j];
+                        const Real l = A[i * ld + k] * rinv, a = A[i * ld + j];
                         if (i != k) A[i * ld + j] = fma(-l, pk, a);
                     }
                 }
@@ -2272,8 +2292,8 @@ struct Core {
                 int i = lane >> cwl;
                 for (; i + 3 * rstep < n; i += 4 * rstep) {
                     const int r0 = i, r1 = i + rstep, r2 = i + 2 * rstep, r3 = i + 3 * rstep;
-                    const double d0 = scal[r0], d1 = scal[r1], d2 = scal[r2], d3 = scal[r3];
-                    const double a0 = A[r0 * ld + j], a1 = A[r1 * ld + j], a2 = A[r2 * ld + j], a3 = A[r3 * ld + j];
+                    const Real d0 = scal[r0], d1 = scal[r1], d2 = scal[r2], d3 = scal[r3];
+                    const Real a0 = A[r0 * ld + j], a1 = A[r1 * ld + j], a2 = A[r2 * ld + j], a3 = A[r3 * ld + j];
                     A[r0 * ld + j] = a0 * d0; A[r1 * ld + j] = a1 * d1; A[r2 * ld + j] = a2 * d2; A[r3 * ld + j] = a3 * d3;
                 }
                 for (; i < n; i += rstep) A[i * ld + j] *= scal[i];
@@ -3374,36 +3394,36 @@ struct Core {
     // first-derivative tangents y (slot-2 configs) and l (multipliers); G1[i][c] = sum_o w_o DDh1T[i][o][c].
     // Third-order Lagrangian derivatives come from nested brackets: d3v = [[W_i,J_j],J_k], d2J_i = [[J_i,J_j],J_k].
     // =====================================================================================================
-    TG_HD void pos_d2(int e, int ja, int jb, double *out) const {  // d2 p_E / dq_a dq_b, ja nearer the root
+    TG_HD void pos_d2(int e, int ja, int jb, Real *out) const {  // d2 p_E / dq_a dq_b, ja nearer the root
         out[0] = out[1] = out[2] = 0.0;
         if (P.j_kind[ja] < TG_RX) return;
-        const double *ga = S + P.o_G + 12 * ja;
+        const Real *ga = S + P.o_G + 12 * ja;
         const int ax = P.j_kind[ja] - TG_RX;
-        const double wx = ga[ax], wy = ga[4 + ax], wz = ga[8 + ax];
-        double d[3];
+        const Real wx = ga[ax], wy = ga[4 + ax], wz = ga[8 + ax];
+        Real d[3];
         dpos(e, jb, d);
         out[0] = wy * d[2] - wz * d[1]; out[1] = wz * d[0] - wx * d[2]; out[2] = wx * d[1] - wy * d[0];
     }
-    TG_HD void pos_d3(int e, int ja, int jb, int jc, double *out) const {  // ja <= jb <= jc along the path
+    TG_HD void pos_d3(int e, int ja, int jb, int jc, Real *out) const {  // ja <= jb <= jc along the path
         out[0] = out[1] = out[2] = 0.0;
         if (P.j_kind[ja] < TG_RX) return;
-        double d[3];
+        Real d[3];
         pos_d2(e, jb, jc, d);
-        const double *ga = S + P.o_G + 12 * ja;
+        const Real *ga = S + P.o_G + 12 * ja;
         const int ax = P.j_kind[ja] - TG_RX;
-        const double wx = ga[ax], wy = ga[4 + ax], wz = ga[8 + ax];
+        const Real wx = ga[ax], wy = ga[4 + ax], wz = ga[8 + ax];
         out[0] = wy * d[2] - wz * d[1]; out[1] = wz * d[0] - wx * d[2]; out[2] = wx * d[1] - wy * d[0];
     }
     // difference (end point 1 - end point 2) of the 1st/2nd/3rd position derivative of constraint c
-    TG_HD void cdiff1(int c, int n, double *v) const {
-        double a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+    TG_HD void cdiff1(int c, int n, Real *v) const {
+        Real a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
         const int s = P.dh_side[n], j = P.dh_joint[n];
         if (j >= 0 && (s & 1)) dpos(P.c_e1[c], j, a);
         if (j >= 0 && (s & 2)) dpos(P.c_e2[c], j, b);
         v[0] = a[0] - b[0]; v[1] = a[1] - b[1]; v[2] = a[2] - b[2];
     }
-    TG_HD void cdiff2(int c, int n1, int n2, double *v) const {
-        double a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+    TG_HD void cdiff2(int c, int n1, int n2, Real *v) const {
+        Real a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
         int j1 = P.dh_joint[n1], j2 = P.dh_joint[n2];
         const int s = P.dh_side[n1] & P.dh_side[n2];
         if (j1 >= 0 && j2 >= 0) {
@@ -3413,8 +3433,8 @@ struct Core {
         }
         v[0] = a[0] - b[0]; v[1] = a[1] - b[1]; v[2] = a[2] - b[2];
     }
-    TG_HD void cdiff3(int c, int n1, int n2, int n3, double *v) const {
-        double a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+    TG_HD void cdiff3(int c, int n1, int n2, int n3, Real *v) const {
+        Real a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
         int j1 = P.dh_joint[n1], j2 = P.dh_joint[n2], j3 = P.dh_joint[n3];
         const int s = P.dh_side[n1] & P.dh_side[n2] & P.dh_side[n3];
         if (j1 >= 0 && j2 >= 0 && j3 >= 0) {
@@ -3431,18 +3451,18 @@ struct Core {
     // poses, because the matrix is assembled after the poses are gone.  Poses and end points must be valid.
     TG_HD void spring_terms(bool on) {
         if (n_springs() == 0) return;
-        double *sV = S + P.o_sV, *sH = S + P.o_sH;
+        Real *sV = S + P.o_sV, *sH = S + P.o_sH;
         if (on) TG_FOR(i, P.nq) sV[i] = 0.0;
         TG_SYNC();
         if (on) {
             TG_FOR(n, n_sdh()) {
                 const int m = P.n_dh + n, c = P.dh_c[m], k = P.dh_cfg[m], sp = c - P.nc;
-                const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
-                const double v[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
-                const double x = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-                double v1[3];
+                const Real *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
+                const Real v[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+                const Real x = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                Real v1[3];
                 cdiff1(c, m, v1);
-                const double dx = (1.0 / x) * (v[0] * v1[0] + v[1] * v1[1] + v[2] * v1[2]);
+                const Real dx = (1.0 / x) * (v[0] * v1[0] + v[1] * v1[1] + v[2] * v1[2]);
                 if (has_damper()) S[P.o_sX + n] = dx == dx ? dx : 0.0;
                 if (dx != dx && P.s_x0[sp] == 0.0) continue;   // coincident end points of a zero-length spring (:44-45)
                 lds_add(&sV[k], P.s_k[sp] * (x - P.s_x0[sp]) * dx);
@@ -3450,15 +3470,15 @@ struct Core {
             TG_FOR(pp, n_spair()) {
                 const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
                 const int c = pw[0], na = pw[1], nb = pw[2], sp = c - P.nc;
-                const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
-                const double v[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
-                const double x = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-                double vi[3], vj[3], vij[3];
+                const Real *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
+                const Real v[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+                const Real x = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                Real vi[3], vj[3], vij[3];
                 cdiff1(c, na, vi); cdiff1(c, nb, vj); cdiff2(c, na, nb, vij);
-                const double vvi = v[0] * vi[0] + v[1] * vi[1] + v[2] * vi[2];
-                const double dix = (1.0 / x) * vvi;
-                const double djx = (1.0 / x) * (v[0] * vj[0] + v[1] * vj[1] + v[2] * vj[2]);
-                const double ddx = -djx / (x * x) * vvi + 1.0 / x * (vj[0] * vi[0] + vj[1] * vi[1] + vj[2] * vi[2]) +
+                const Real vvi = v[0] * vi[0] + v[1] * vi[1] + v[2] * vi[2];
+                const Real dix = (1.0 / x) * vvi;
+                const Real djx = (1.0 / x) * (v[0] * vj[0] + v[1] * vj[1] + v[2] * vj[2]);
+                const Real ddx = -djx / (x * x) * vvi + 1.0 / x * (vj[0] * vi[0] + vj[1] * vi[1] + vj[2] * vi[2]) +
                                    1.0 / x * (v[0] * vij[0] + v[1] * vij[1] + v[2] * vij[2]);
                 sH[pp] = P.s_k[sp] * dix * djx + P.s_k[sp] * (x - P.s_x0[sp]) * ddx;
                 if (has_damper()) S[P.o_sXX + pp] = ddx;
@@ -3466,7 +3486,7 @@ struct Core {
         }
         TG_SYNC();
         if (has_damper()) {   // lineardamper.c:12-45: rate of every element, d(rate)/dq per item, generalized force
-            const double *dqv = S + P.o_dq;
+            const Real *dqv = S + P.o_dq;
             if (on) {
                 TG_FOR(i, n_springs()) S[P.o_svel + i] = 0.0;
                 TG_FOR(i, n_sdh()) S[P.o_sVq + i] = 0.0;
@@ -3481,7 +3501,7 @@ struct Core {
                 TG_FOR(pp, n_spair()) {
                     const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
                     const int na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
-                    const double xab = S[P.o_sXX + pp];
+                    const Real xab = S[P.o_sXX + pp];
                     lds_add(&S[P.o_sVq + (na - P.n_dh)], xab * dqv[kb]);
                     if (na != nb) lds_add(&S[P.o_sVq + (nb - P.n_dh)], xab * dqv[ka]);
                 }
@@ -3497,17 +3517,17 @@ struct Core {
     }
 
     // d3|p1 - p2| / dq_a dq_b dq_c of spring element c for three of its dh items (tapemeasure.c:98-168); poses alive
-    TG_HD double length_d3(int c, int na, int nb, int nc_) const {
-        const double *pa = S + P.o_pE + 3 * P.c_e1[c], *pb = S + P.o_pE + 3 * P.c_e2[c];
-        const double v[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
-        double a[3], b[3], cc[3], ab[3], ac[3], bc[3], abc[3];
+    TG_HD Real length_d3(int c, int na, int nb, int nc_) const {
+        const Real *pa = S + P.o_pE + 3 * P.c_e1[c], *pb = S + P.o_pE + 3 * P.c_e2[c];
+        const Real v[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+        Real a[3], b[3], cc[3], ab[3], ac[3], bc[3], abc[3];
         cdiff1(c, na, a); cdiff1(c, nb, b); cdiff1(c, nc_, cc);
         cdiff2(c, na, nb, ab); cdiff2(c, na, nc_, ac); cdiff2(c, nb, nc_, bc);
         cdiff3(c, na, nb, nc_, abc);
-        const double x = sqrt(dot3(v, v));
-        const double xa = dot3(v, a) / x, xb = dot3(v, b) / x, xc = dot3(v, cc) / x;
-        const double xab = (dot3(a, b) + dot3(v, ab) - xa * xb) / x, xac = (dot3(a, cc) + dot3(v, ac) - xa * xc) / x;
-        const double xbc = (dot3(b, cc) + dot3(v, bc) - xb * xc) / x;
+        const Real x = sqrt(dot3(v, v));
+        const Real xa = dot3(v, a) / x, xb = dot3(v, b) / x, xc = dot3(v, cc) / x;
+        const Real xab = (dot3(a, b) + dot3(v, ab) - xa * xb) / x, xac = (dot3(a, cc) + dot3(v, ac) - xa * xc) / x;
+        const Real xbc = (dot3(b, cc) + dot3(v, bc) - xb * xc) / x;
         return (dot3(ac, b) + dot3(a, bc) + dot3(cc, ab) + dot3(v, abc) - xac * xb - xa * xbc - xab * xc) / x;
     }
     // Second-derivative kernel, dampers (lineardamper.c:47-92 contracted with the adjoint weights w): per element pair
@@ -3515,8 +3535,8 @@ struct Core {
     // (R is symmetric in (a, b) because the reference's f_ddqdq uses length_dq(q2) where length_dqdq(q, q2) is meant,
     // :88 -- reproduced).  Needs the poses and the first-order damper quantities.
     TG_HD void damper_second(bool on) {
-        double *sT = S + P.e_o_sT, *WX = S + P.e_o_sWX, *WXq = S + P.e_o_sWXq;
-        const double *dqv = S + P.o_dq;
+        Real *sT = S + P.e_o_sT, *WX = S + P.e_o_sWX, *WXq = S + P.e_o_sWXq;
+        const Real *dqv = S + P.o_dq;
         if (on) {
             TG_FOR(i, 2 * n_springs()) WX[i] = 0.0;
             TG_FOR(i, n_sdh()) WXq[i] = 0.0;
@@ -3530,7 +3550,7 @@ struct Core {
             TG_FOR(pp, n_spair()) {
                 const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
                 const int na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
-                const double xab = S[P.o_sXX + pp];
+                const Real xab = S[P.o_sXX + pp];
                 if (kb < P.nd) lds_add(&WXq[na - P.n_dh], d2w[kb] * xab);
                 if (na != nb && ka < P.nd) lds_add(&WXq[nb - P.n_dh], d2w[ka] * xab);
             }
@@ -3539,11 +3559,11 @@ struct Core {
         if (on) TG_FOR(pp, n_spair()) {
             const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
             const int c = pw[0], sp = c - P.nc, na = pw[1], nb = pw[2], ia = na - P.n_dh, ib = nb - P.n_dh;
-            const double cc = P.s_c[sp], vel = S[P.o_svel + sp], xa = S[P.o_sX + ia], xb = S[P.o_sX + ib], xab = S[P.o_sXX + pp];
-            double vab = 0.0, wxab = 0.0;
+            const Real cc = P.s_c[sp], vel = S[P.o_svel + sp], xa = S[P.o_sX + ia], xb = S[P.o_sX + ib], xab = S[P.o_sXX + pp];
+            Real vab = 0.0, wxab = 0.0;
             for (int no = P.cu_off[c]; no < P.cu_off[c + 1]; no++) {
                 const int ko = P.dh_cfg[no];
-                const double x3 = length_d3(c, no, na, nb);
+                const Real x3 = length_d3(c, no, na, nb);
                 vab += x3 * dqv[ko];
                 if (ko < P.nd) wxab += d2w[ko] * x3;
             }
@@ -3554,10 +3574,10 @@ struct Core {
     }
 
     // derivatives of the damper force of the element pair pp = (na, nb): F_dq(a; b), F_dq(b; a) and F_ddq (symmetric)
-    TG_HD void damper_pair(int pp, double &fq_ab, double &fq_ba, double &fdd) const {
+    TG_HD void damper_pair(int pp, Real &fq_ab, Real &fq_ba, Real &fdd) const {
         const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
         const int sp = pw[0] - P.nc, ia = pw[1] - P.n_dh, ib = pw[2] - P.n_dh;
-        const double c = P.s_c[sp], vel = S[P.o_svel + sp], xa = S[P.o_sX + ia], xb = S[P.o_sX + ib], xab = S[P.o_sXX + pp];
+        const Real c = P.s_c[sp], vel = S[P.o_svel + sp], xa = S[P.o_sX + ia], xb = S[P.o_sX + ib], xab = S[P.o_sXX + pp];
         fq_ab = -c * (S[P.o_sVq + ib] * xa + vel * xab);
         fq_ba = -c * (S[P.o_sVq + ia] * xb + vel * xab);
         fdd = -c * xa * xb;
@@ -3569,17 +3589,17 @@ struct Core {
     // when joint b comes before joint a on the path -- not symmetric, so wH holds F_dq(a; b) and F_dq(b; a).
     // the six coefficients of wrench element c for its dh item n: (dp/dq, axis) for a HybridWrench, the joint's spatial
     // twist (dp/dq - axis x p, axis) for a SpatialWrench (spatialwrench.c:16-38: unhat(g_dq g^-1))
-    TG_HD void wrench_coeff(int c, int n, int kind, double *xi) const {
+    TG_HD void wrench_coeff(int c, int n, int kind, Real *xi) const {
         cdiff1(c, n, xi);
         plane_axis(n, xi + 3);
         if (kind == 1) {
-            const double *p = S + P.o_pE + 3 * P.c_e1[c];
-            double t_[3];
+            const Real *p = S + P.o_pE + 3 * P.c_e1[c];
+            Real t_[3];
             cross3(xi + 3, p, t_);
             xi[0] -= t_[0]; xi[1] -= t_[1]; xi[2] -= t_[2];
         } else if (kind == 2) {   // BodyWrench (bodywrench.c:16-38, unhat(g^-1 g_dq)): the same two vectors in the frame's axes
-            const double *R = S + P.o_wR + 9 * (c - P.nc - n_springs());
-            const double a[6] = {xi[0], xi[1], xi[2], xi[3], xi[4], xi[5]};
+            const Real *R = S + P.o_wR + 9 * (c - P.nc - n_springs());
+            const Real a[6] = {xi[0], xi[1], xi[2], xi[3], xi[4], xi[5]};
             for (int i = 0; i < 3; i++) {
                 xi[i] = R[i] * a[0] + R[3 + i] * a[1] + R[6 + i] * a[2];
                 xi[3 + i] = R[i] * a[3] + R[3 + i] * a[4] + R[6 + i] * a[5];
@@ -3588,7 +3608,7 @@ struct Core {
     }
     TG_HD void wrench_terms(bool on) {
         if (n_wrenches() == 0) return;
-        double *wF = S + P.o_wF, *wH = S + P.o_wH, *wD = S + P.o_wD;
+        Real *wF = S + P.o_wF, *wH = S + P.o_wH, *wD = S + P.o_wD;
         const int m0 = P.n_dh + n_sdh(), p0 = P.n_cpair + n_spair(), c0 = P.nc + n_springs();
         if (on) TG_FOR(i, P.nd) wF[i] = 0.0;
         TG_SYNC();
@@ -3596,7 +3616,7 @@ struct Core {
         if (on) {
             TG_FOR(n, n_wdh()) {
                 const int m = m0 + n, c = P.dh_c[m], k = P.dh_cfg[m], w = c - c0;
-                double xi[6], f = 0.0;
+                Real xi[6], f = 0.0;
                 wrench_coeff(c, m, P.wr_kind[w], xi);
                 for (int r = 0; r < 6; r++) { wD[6 * n + r] = xi[r]; f += component(w, r) * xi[r]; }
                 if (k < P.nd) lds_add(&wF[k], f);
@@ -3610,26 +3630,26 @@ struct Core {
                     // after a.  Nothing symmetric.  With br = [xi_a, xi_b]:
                     const int kind = P.wr_kind[w];
                     const bool body = kind == 2;
-                    double Wv[6], xa[6], xb[6], br[6];
+                    Real Wv[6], xa[6], xb[6], br[6];
                     for (int r = 0; r < 6; r++) Wv[r] = component(w, r);
                     wrench_coeff(c, na, kind, xa); wrench_coeff(c, nb, kind, xb);
                     bracket(xa, xb, br);
-                    double t_ab = 0.0;
+                    Real t_ab = 0.0;
                     for (int r = 0; r < 6; r++) t_ab += Wv[r] * br[r];
                     const bool d_ab = body ? ja < jb : jb < ja;   // does coefficient a depend on joint b?
                     const bool d_ba = body ? jb < ja : ja < jb;   // does coefficient b depend on joint a?
-                    const double sg = body ? 1.0 : -1.0;          // d xi_a/dq_b = sg br,  d xi_b/dq_a = -sg br
+                    const Real sg = body ? 1.0 : -1.0;          // d xi_a/dq_b = sg br,  d xi_b/dq_a = -sg br
                     wH[2 * pp] = d_ab ? sg * t_ab : 0.0;
                     wH[2 * pp + 1] = d_ba ? -sg * t_ab : 0.0;
                     if (d2w) {
-                        double acc = 0.0;
+                        Real acc = 0.0;
                         const int n1 = ja <= jb ? na : nb, n2 = ja <= jb ? nb : na, j1 = ja <= jb ? ja : jb, j2 = ja <= jb ? jb : ja;
-                        double x1[6], x2[6];
+                        Real x1[6], x2[6];
                         wrench_coeff(c, n1, kind, x1); wrench_coeff(c, n2, kind, x2);
                         for (int no = P.cu_off[c]; no < P.cu_off[c + 1]; no++) {
                             const int ko = P.dh_cfg[no], jo = P.dh_joint[no];
                             if (ko >= P.nd || !(body ? jo < j1 : j2 < jo)) continue;
-                            double xo[6], u1[6], u2[6], term = 0.0;
+                            Real xo[6], u1[6], u2[6], term = 0.0;
                             wrench_coeff(c, no, kind, xo);
                             if (body) { bracket(xo, x1, u1); bracket(u1, x2, u2); }     // [[xi_o, xi_1], xi_2]
                             else { bracket(x2, xo, u1); bracket(x1, u1, u2); }          // [xi_1, [xi_2, xi_o]]
@@ -3637,7 +3657,7 @@ struct Core {
                             acc += d2w[ko] * term;
                         }
                         S[P.e_o_wT + pp] = acc;
-                        double *Hu = S + P.e_o_Hu;
+                        Real *Hu = S + P.e_o_Hu;
                         for (int s6 = 0; s6 < 6; s6++) {
                             const int in = P.wr_in[6 * w + s6];
                             if (in < 0) continue;
@@ -3648,28 +3668,28 @@ struct Core {
                     }
                     continue;
                 }
-                const double F[3] = {component(w, 0), component(w, 1), component(w, 2)};
-                const double tq[3] = {component(w, 3), component(w, 4), component(w, 5)};
-                double d2[3], oa[3], ob[3], x_ab[3];
+                const Real F[3] = {component(w, 0), component(w, 1), component(w, 2)};
+                const Real tq[3] = {component(w, 3), component(w, 4), component(w, 5)};
+                Real d2[3], oa[3], ob[3], x_ab[3];
                 cdiff2(c, na, nb, d2);
                 plane_axis(na, oa); plane_axis(nb, ob);
                 cross3(oa, ob, x_ab);                                   // om_a x om_b
-                const double hs = dot3(F, d2), t_ab = dot3(tq, x_ab);
+                const Real hs = dot3(F, d2), t_ab = dot3(tq, x_ab);
                 wH[2 * pp] = hs + (jb < ja ? -t_ab : 0.0);             // F_dq(a; b): tau . (om_b x om_a), b before a
                 wH[2 * pp + 1] = hs + (ja < jb ? t_ab : 0.0);          // F_dq(b; a): tau . (om_a x om_b), a before b
                 if (d2w) {   // second-derivative kernel: sum_o w_o F_dqdq(o; a, b) and -dt/2 sum_o w_o F_dudq(o, u; .)
-                    double acc = 0.0;
+                    Real acc = 0.0;
                     const int n1 = ja <= jb ? na : nb, n2 = ja <= jb ? nb : na, j2 = ja <= jb ? jb : ja;   // n1 at or before n2
-                    double o1[3], o2[3];
+                    Real o1[3], o2[3];
                     plane_axis(n1, o1); plane_axis(n2, o2);
                     for (int no = P.cu_off[c]; no < P.cu_off[c + 1]; no++) {
                         const int ko = P.dh_cfg[no];
                         if (ko >= P.nd) continue;
-                        double d3[3];
+                        Real d3[3];
                         cdiff3(c, na, nb, no, d3);
-                        double term = dot3(F, d3);
+                        Real term = dot3(F, d3);
                         if (j2 < P.dh_joint[no]) {                       // both before o: d2 om_o = om_1 x (om_2 x om_o)
-                            double oo[3], u1[3], u2[3];
+                            Real oo[3], u1[3], u2[3];
                             plane_axis(no, oo);
                             cross3(o2, oo, u1); cross3(o1, u1, u2);
                             term += dot3(tq, u2);
@@ -3677,13 +3697,13 @@ struct Core {
                         acc += d2w[ko] * term;
                     }
                     S[P.e_o_wT + pp] = acc;
-                    double *Hu = S + P.e_o_Hu;
+                    Real *Hu = S + P.e_o_Hu;
                     for (int s6 = 0; s6 < 6; s6++) {
                         const int in = P.wr_in[6 * w + s6];
                         if (in < 0) continue;
                         // F_dudq(o = b, u; a) and F_dudq(o = a, u; b): d2p component (symmetric) or the axis derivative
-                        const double to_b = s6 < 3 ? d2[s6] : (ja < jb ? x_ab[s6 - 3] : 0.0);
-                        const double to_a = s6 < 3 ? d2[s6] : (jb < ja ? -x_ab[s6 - 3] : 0.0);
+                        const Real to_b = s6 < 3 ? d2[s6] : (ja < jb ? x_ab[s6 - 3] : 0.0);
+                        const Real to_a = s6 < 3 ? d2[s6] : (jb < ja ? -x_ab[s6 - 3] : 0.0);
                         if (kb < P.nd) lds_add(&Hu[ka * P.nu + in], -0.5 * dt * d2w[kb] * to_b);
                         if (na != nb && ka < P.nd) lds_add(&Hu[kb * P.nu + in], -0.5 * dt * d2w[ka] * to_a);
                     }
@@ -3696,29 +3716,29 @@ struct Core {
     // ---- plane constraints: derivatives of the world normal n = R_plane n_local w.r.t. the joints of the plane frame's
     //      path: d n/dq_a = w_a x n, d2 n/dq_a dq_b = w_a x (w_b x n) (a at or before b), ... (w: world axis of a rotary
     //      joint; prismatic joints and joints that only move the point frame contribute nothing)
-    TG_HD void plane_axis(int n, double *w) const {
+    TG_HD void plane_axis(int n, Real *w) const {
         const int j = P.dh_joint[n];
         w[0] = w[1] = w[2] = 0.0;
         if (j < 0 || !(P.dh_side[n] & 1) || P.j_kind[j] < TG_RX) return;
-        const double *gj = S + P.o_G + 12 * j;
+        const Real *gj = S + P.o_G + 12 * j;
         const int ax = P.j_kind[j] - TG_RX;
         w[0] = gj[ax]; w[1] = gj[4 + ax]; w[2] = gj[8 + ax];
     }
-    TG_HD static void cross3(const double *a, const double *b, double *r) {
+    TG_HD static void cross3(const Real *a, const Real *b, Real *r) {
         r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0];
     }
-    TG_HD static double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+    TG_HD static Real dot3(const Real *a, const Real *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
     // k-th derivative of the normal w.r.t. the dh items n[0..k-1] (any order)
-    TG_HD void plane_dn(int c, int k, const int *n, double *out) const {
+    TG_HD void plane_dn(int c, int k, const int *n, Real *out) const {
         int o[3] = {k > 0 ? n[0] : 0, k > 1 ? n[1] : 0, k > 2 ? n[2] : 0};
         auto later = [&](int x, int y) { return P.dh_joint[x] > P.dh_joint[y]; };
         if (k > 1 && later(o[0], o[1])) { const int t_ = o[0]; o[0] = o[1]; o[1] = t_; }
         if (k > 2 && later(o[1], o[2])) { const int t_ = o[1]; o[1] = o[2]; o[2] = t_; }
         if (k > 1 && later(o[0], o[1])) { const int t_ = o[0]; o[0] = o[1]; o[1] = t_; }
-        const double *nw = S + P.o_nE + 3 * c;
-        double cur[3] = {nw[0], nw[1], nw[2]};
+        const Real *nw = S + P.o_nE + 3 * c;
+        Real cur[3] = {nw[0], nw[1], nw[2]};
         for (int i = k - 1; i >= 0; i--) {   // innermost cross product belongs to the joint farthest down the path
-            double w[3], nxt[3];
+            Real w[3], nxt[3];
             plane_axis(o[i], w);
             cross3(w, cur, nxt);
             cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
@@ -3726,15 +3746,15 @@ struct Core {
         out[0] = cur[0]; out[1] = cur[1]; out[2] = cur[2];
     }
     // Leibniz expansion of d^k (n . D) over the dh items n[0..k-1], D = p_plane - p_point (plane.c:28-167)
-    TG_HD double plane_dk(int c, int k, const int *n) const {
-        double acc = 0.0;
+    TG_HD Real plane_dk(int c, int k, const int *n) const {
+        Real acc = 0.0;
         for (int mask = 0; mask < (1 << k); mask++) {
             int a[3], b[3], na = 0, nb = 0;
             for (int i = 0; i < k; i++) { if (mask & (1 << i)) a[na++] = n[i]; else b[nb++] = n[i]; }
-            double dn[3], dd[3];
+            Real dn[3], dd[3];
             plane_dn(c, na, a, dn);
             if (nb == 0) {
-                const double *pa = S + P.o_pE + 3 * P.c_e1[c], *pb = S + P.o_pE + 3 * P.c_e2[c];
+                const Real *pa = S + P.o_pE + 3 * P.c_e1[c], *pb = S + P.o_pE + 3 * P.c_e2[c];
                 dd[0] = pa[0] - pb[0]; dd[1] = pa[1] - pb[1]; dd[2] = pa[2] - pb[2];
             } else if (nb == 1) cdiff1(c, b[0], dd);
             else if (nb == 2) cdiff2(c, b[0], b[1], dd);
@@ -3745,29 +3765,29 @@ struct Core {
     }
 
     // h_c,dqdq for two dependent configs given by their dh items (distance.c:65-98, point.c:40-46)
-    TG_HD double con_d2(int c, int n1, int n2) const {
+    TG_HD Real con_d2(int c, int n1, int n2) const {
         if (has_plane() && P.c_type[c] == TG_CONSTRAINT_PLANE) { const int n[2] = {n1, n2}; return plane_dk(c, 2, n); }
-        double v12[3];
+        Real v12[3];
         cdiff2(c, n1, n2, v12);
         if (P.c_type[c] == TG_CONSTRAINT_POINT) return v12[P.c_comp[c]];
-        double v1[3], v2[3];
+        Real v1[3], v2[3];
         cdiff1(c, n1, v1); cdiff1(c, n2, v2);
-        const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
-        double h = v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2] + (a[0] - b[0]) * v12[0] + (a[1] - b[1]) * v12[1] + (a[2] - b[2]) * v12[2];
+        const Real *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
+        Real h = v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2] + (a[0] - b[0]) * v12[0] + (a[1] - b[1]) * v12[1] + (a[2] - b[2]) * v12[2];
         if ((P.dh_side[n1] & 4) && n1 == n2) h -= 1.0;
         return 2.0 * h;
     }
     // h_c,dqdqdq (distance.c:100-133, point.c:48-54); zero when any argument is the string-length config
-    TG_HD double con_d3(int c, int n1, int n2, int n3) const {
+    TG_HD Real con_d3(int c, int n1, int n2, int n3) const {
         if (P.dh_joint[n1] < 0 || P.dh_joint[n2] < 0 || P.dh_joint[n3] < 0) return 0.0;
         if (has_plane() && P.c_type[c] == TG_CONSTRAINT_PLANE) { const int n[3] = {n1, n2, n3}; return plane_dk(c, 3, n); }
-        double v123[3];
+        Real v123[3];
         cdiff3(c, n1, n2, n3, v123);
         if (P.c_type[c] == TG_CONSTRAINT_POINT) return v123[P.c_comp[c]];
-        double v1[3], v2[3], v3[3], v12[3], v13[3], v23[3];
+        Real v1[3], v2[3], v3[3], v12[3], v13[3], v23[3];
         cdiff1(c, n1, v1); cdiff1(c, n2, v2); cdiff1(c, n3, v3);
         cdiff2(c, n1, n2, v12); cdiff2(c, n1, n3, v13); cdiff2(c, n2, n3, v23);
-        const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
+        const Real *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
         return 2.0 * (v1[0] * v23[0] + v1[1] * v23[1] + v1[2] * v23[2] + v2[0] * v13[0] + v2[1] * v13[1] + v2[2] * v13[2] +
                       v3[0] * v12[0] + v3[1] * v12[1] + v3[2] * v12[2] +
                       (a[0] - b[0]) * v123[0] + (a[1] - b[1]) * v123[1] + (a[2] - b[2]) * v123[2]);
@@ -4497,7 +4517,7 @@ struct Core {
     TG_HD bool solve_kkt(bool on) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const int nb4 = (P.nf + 3) >> 2;   // matrix size in blocks of 4 rows
-        if (TEAM >= 4 && 4 * nb4 <= TEAM && nb4 <= 8) {
+        if constexpr (std::is_same<Real, double>::value) if (TEAM >= 4 && 4 * nb4 <= TEAM && nb4 <= 8) {
             double *Ad = S + P.o_Df;
             switch (nb4) {
             case 1: return Core<TEAM>::template gj_rows<4>(on, Ad, P.nf, P.df_ld, lane);
@@ -4529,10 +4549,10 @@ struct Core {
         const int nq = P.nq, nd = P.nd, nk = P.nk, nc = P.nc, nf = P.nf, ld = P.df_ld;
         // The KKT matrix shares its storage with the poses (program.hpp, LDS layout): the right-hand side is
         // accumulated in f while the poses are alive, the matrix is assembled afterwards from J and the Dh items.
-        double *K = S + P.o_Df, *rhs = S + P.o_f, *ddk = S + P.o_nu + P.nu;
+        Real *K = S + P.o_Df, *rhs = S + P.o_f, *ddk = S + P.o_nu + P.nu;
         if (on) {
-            TG_FOR(i, nq) S[P.o_dq + i] = A.dq_in[t * nq + i];
-            TG_FOR(i, nk) ddk[i] = A.ddqk_in[t * nk + i];
+            TG_FOR(i, nq) S[P.o_dq + i] = seeded(A.dq_in[t * nq + i], nq + i);
+            TG_FOR(i, nk) ddk[i] = seeded(A.ddqk_in[t * nk + i], 2 * nq + i);
             TG_FOR(i, nf) rhs[i] = 0.0;
         }
         TG_SYNC();
@@ -4550,7 +4570,7 @@ struct Core {
                 TG_FOR(pp, P.n_cpair) {
                     const int *pw = P.cpair4 + 4 * (size_t)pp;
                     const int c = pw[0], na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
-                    const double h = con_d2(c, na, nb) * S[P.o_dq + ka] * S[P.o_dq + kb];
+                    const Real h = con_d2(c, na, nb) * S[P.o_dq + ka] * S[P.o_dq + kb];
                     lds_add(&rhs[nd + c], na != nb ? -2.0 * h : -h);
                 }
             }
@@ -4559,10 +4579,10 @@ struct Core {
         jacobians(on);
         velocities(on);
         // S_F per body, in the (now dead) joint pose area
-        double *SF = S + P.o_G;
+        Real *SF = S + P.o_G;
         if (on) TG_FOR(idx, 6 * P.n_bodies) {
             const int b = idx / 6, m = idx % 6;
-            double acc = 0.0;
+            Real acc = 0.0;
             for (int k = P.b_item_off[b]; k < P.b_item_off[b + 1]; k++) {
                 const int cfg = P.it_pack[4 * (size_t)k + 3] & 0xFFFF;
                 acc += S[P.o_W + 6 * k + m] * S[P.o_dq + cfg] + (cfg >= nd ? S[P.o_J + 6 * k + m] * ddk[cfg - nd] : 0.0);
@@ -4573,15 +4593,15 @@ struct Core {
         if (on) {
             TG_FOR(it, P.n_items) {
                 const int b = P.it_pack[4 * (size_t)it], cfg = P.it_pack[4 * (size_t)it + 3] & 0xFFFF;
-                const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
-                const double *J = S + P.o_J + 6 * it;
-                double jv[6];
+                const Real *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
+                const Real *J = S + P.o_J + 6 * it;
+                Real jv[6];
                 bracket(J, v, jv);
-                const double term = I[0] * (gam[0] * J[0] + gam[1] * J[1] + gam[2] * J[2]) - inner6(I, J, SF + 6 * b) - inner6(I, jv, v);
+                const Real term = I[0] * (gam[0] * J[0] + gam[1] * J[1] + gam[2] * J[2]) - inner6(I, J, SF + 6 * b) - inner6(I, jv, v);
                 if (cfg < nd) lds_add(&rhs[cfg], term);
             }
             TG_FOR(i, nd) {
-                double force = -P.damp[i] * S[P.o_dq + i];
+                Real force = -P.damp[i] * S[P.o_dq + i];
                 for (int k = 0; k < P.n_cf; k++) if (P.cf_cfg[k] == i) force += S[P.o_u + P.cf_in[k]];
                 if (has_cs()) force -= cs_d1(i, S[P.o_q2 + i]);
                 if (n_springs()) force -= S[P.o_sV + i];
@@ -4602,24 +4622,24 @@ struct Core {
             TG_FOR(pp, P.n_npairs) {   // M = [L_ddqddq] (system.c:459-489)
                 const int *pw = P.pair4 + 4 * (size_t)pp;
                 const int ia = pw[0], ib = pw[1], ca = pw[2] & 0xFFFF, cb = pw[2] >> 16, b = pw[3];
-                const double mab = inner6(S + P.o_I + 4 * b, S + P.o_J + 6 * ia, S + P.o_J + 6 * ib);
+                const Real mab = inner6(S + P.o_I + 4 * b, S + P.o_J + 6 * ia, S + P.o_J + 6 * ib);
                 lds_add(&K[ca * ld + cb], mab);
                 if (ia != ib) lds_add(&K[cb * ld + ca], mab);
             }
         }
         TG_SYNC();
         const bool ok = solve_kkt(on);
-        if (on && ok && A.ddq_out) TG_FOR(i, nd) A.ddq_out[t * nd + i] = K[i * ld + nf];
-        if (on && ok && A.lam_out) TG_FOR(c, nc) A.lam_out[t * nc + c] = K[(nd + c) * ld + nf];
+        if (on && ok && A.ddq_out) TG_FOR(i, nd) A.ddq_out[t * nd + i] = tgdual::top(K[i * ld + nf]);
+        if (on && ok && A.lam_out) TG_FOR(c, nc) A.lam_out[t * nc + c] = tgdual::top(K[(nd + c) * ld + nf]);
         return ok;
     }
 
     // Kinetic and potential energy at (q, dq) (System_total_energy / System_L, system.c:78-127): T = sum 1/2 <v_F, I v_F>,
     // V = -sum m g.p_F + config springs + two-point springs.  One lane per term, summed through an LDS atomic.
     TG_HD void energy(bool on, CArgs &A, size_t t) {
-        double *acc = S + P.o_f;   // [0] = T, [1] = V
+        Real *acc = S + P.o_f;   // [0] = T, [1] = V
         if (on) {
-            TG_FOR(i, P.nq) S[P.o_dq + i] = A.dq_in[t * P.nq + i];
+            TG_FOR(i, P.nq) S[P.o_dq + i] = seeded(A.dq_in[t * P.nq + i], P.nq + i);
             if (lane == 0) { acc[0] = 0.0; acc[1] = 0.0; }
         }
         TG_SYNC();
@@ -4629,23 +4649,23 @@ struct Core {
         velocities(on);
         if (on) {
             TG_FOR(b, P.n_bodies) {
-                const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gb = S + P.o_gB + 12 * b;
+                const Real *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gb = S + P.o_gB + 12 * b;
                 lds_add(&acc[0], 0.5 * inner6(I, v, v));
                 lds_add(&acc[1], -I[0] * (P.grav[0] * gb[3] + P.grav[1] * gb[7] + P.grav[2] * gb[11]));
             }
             if (has_cs()) TG_FOR(i, P.nq) {
-                const double q = S[P.o_q2 + i];
+                const Real q = S[P.o_q2 + i];
                 lds_add(&acc[1], 0.5 * P.cs_k[i] * q * q - P.cs_kq0[i] * q + P.cs_c0[i]);   // (a NonlinearConfigSpring's V() is 0 in the reference, :15-22)
             }
             TG_FOR(sp, n_springs()) {
                 const int c = P.nc + sp;
-                const double *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
-                const double x = sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
+                const Real *a = S + P.o_pE + 3 * P.c_e1[c], *b = S + P.o_pE + 3 * P.c_e2[c];
+                const Real x = sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
                 lds_add(&acc[1], 0.5 * P.s_k[sp] * (x - P.s_x0[sp]) * (x - P.s_x0[sp]));
             }
         }
         TG_SYNC();
-        if (on && lane == 0) { A.energy_out[2 * t] = acc[0]; A.energy_out[2 * t + 1] = acc[1]; }
+        if (on && lane == 0) { A.energy_out[2 * t] = tgdual::top(acc[0]); A.energy_out[2 * t + 1] = tgdual::top(acc[1]); }
     }
 
     // First and second derivatives of the Lagrangian for every config / pair of configs at (q, dq) (System_L_dq ...
@@ -4653,7 +4673,7 @@ struct Core {
     // (zeroed) output arrays.  lag1 = [L_dq | L_ddq], lag2 = [L_dqdq | L_ddqdq (dq row, q column) | L_ddqddq].
     TG_HD void lagrangian(bool on, CArgs &A, size_t t) {
         const int nq = P.nq;
-        if (on) TG_FOR(i, nq) S[P.o_dq + i] = A.dq_in[t * nq + i];
+        if (on) TG_FOR(i, nq) S[P.o_dq + i] = seeded(A.dq_in[t * nq + i], nq + i);
         TG_SYNC();
         pose_sweep(on, 2);
         attach_points(on, true, n_springs() > 0);
@@ -4664,45 +4684,45 @@ struct Core {
         if (on) {
             TG_FOR(it, P.n_items) {
                 const int b = P.it_pack[4 * (size_t)it], cfg = P.it_pack[4 * (size_t)it + 3] & 0xFFFF;
-                const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
-                const double *J = S + P.o_J + 6 * it, *W = S + P.o_W + 6 * it;
-                gl_add(&o1[cfg], inner6(I, W, v) + I[0] * (gam[0] * J[0] + gam[1] * J[1] + gam[2] * J[2]));
-                gl_add(&o1[nq + cfg], inner6(I, J, v));
+                const Real *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
+                const Real *J = S + P.o_J + 6 * it, *W = S + P.o_W + 6 * it;
+                gl_add(&o1[cfg], tgdual::top(inner6(I, W, v) + I[0] * (gam[0] * J[0] + gam[1] * J[1] + gam[2] * J[2])));
+                gl_add(&o1[nq + cfg], tgdual::top(inner6(I, J, v)));
             }
             TG_FOR(pp, P.n_pairs) {
                 const int ia = P.pair_a[pp], ib = P.pair_b[pp];
                 const int b = P.it_pack[4 * (size_t)ia], ca = P.it_pack[4 * (size_t)ia + 3] & 0xFFFF, cb = P.it_pack[4 * (size_t)ib + 3] & 0xFFFF;
-                const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
-                const double *Ja = S + P.o_J + 6 * ia, *Jb = S + P.o_J + 6 * ib, *Wa = S + P.o_W + 6 * ia, *Wb = S + P.o_W + 6 * ib;
-                double tb[6];
+                const Real *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b;
+                const Real *Ja = S + P.o_J + 6 * ia, *Jb = S + P.o_J + 6 * ib, *Wa = S + P.o_W + 6 * ia, *Wb = S + P.o_W + 6 * ib;
+                Real tb[6];
                 bracket(Wa, Jb, tb);
-                const double lqq = inner6(I, tb, v) + inner6(I, Wa, Wb) +
+                const Real lqq = inner6(I, tb, v) + inner6(I, Wa, Wb) +
                                    I[0] * (gam[0] * (Ja[4] * Jb[2] - Ja[5] * Jb[1]) + gam[1] * (Ja[5] * Jb[0] - Ja[3] * Jb[2]) +
                                            gam[2] * (Ja[3] * Jb[1] - Ja[4] * Jb[0]));
-                const double mab = inner6(I, Ja, Jb);
+                const Real mab = inner6(I, Ja, Jb);
                 bracket(Ja, Jb, tb);
-                const double c_ab = inner6(I, tb, v) + inner6(I, Ja, Wb), c_ba = inner6(I, Jb, Wa);
-                gl_add(&o2[(size_t)ca * nq + cb], lqq);
-                gl_add(&o2[((size_t)nq + ca) * nq + cb], c_ab);
-                gl_add(&o2[((size_t)2 * nq + ca) * nq + cb], mab);
+                const Real c_ab = inner6(I, tb, v) + inner6(I, Ja, Wb), c_ba = inner6(I, Jb, Wa);
+                gl_add(&o2[(size_t)ca * nq + cb], tgdual::top(lqq));
+                gl_add(&o2[((size_t)nq + ca) * nq + cb], tgdual::top(c_ab));
+                gl_add(&o2[((size_t)2 * nq + ca) * nq + cb], tgdual::top(mab));
                 if (ia != ib) {
-                    gl_add(&o2[(size_t)cb * nq + ca], lqq);
-                    gl_add(&o2[((size_t)nq + cb) * nq + ca], c_ba);
-                    gl_add(&o2[((size_t)2 * nq + cb) * nq + ca], mab);
+                    gl_add(&o2[(size_t)cb * nq + ca], tgdual::top(lqq));
+                    gl_add(&o2[((size_t)nq + cb) * nq + ca], tgdual::top(c_ba));
+                    gl_add(&o2[((size_t)2 * nq + cb) * nq + ca], tgdual::top(mab));
                 }
             }
             if (has_cs()) TG_FOR(i, nq) {
-                double d1_, d2_, d3_;
+                Real d1_, d2_, d3_;
                 cs_eval(i, S[P.o_q2 + i], d1_, d2_, d3_);
-                gl_add(&o1[i], -d1_);
-                gl_add(&o2[(size_t)i * nq + i], -d2_);
+                gl_add(&o1[i], tgdual::top(-d1_));
+                gl_add(&o2[(size_t)i * nq + i], tgdual::top(-d2_));
             }
-            if (n_springs()) TG_FOR(i, nq) gl_add(&o1[i], -S[P.o_sV + i]);
+            if (n_springs()) TG_FOR(i, nq) gl_add(&o1[i], tgdual::top(-S[P.o_sV + i]));
             TG_FOR(pp, n_spair()) {
                 const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
                 const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
-                gl_add(&o2[(size_t)ka * nq + kb], -S[P.o_sH + pp]);
-                if (pw[1] != pw[2]) gl_add(&o2[(size_t)kb * nq + ka], -S[P.o_sH + pp]);
+                gl_add(&o2[(size_t)ka * nq + kb], tgdual::top(-S[P.o_sH + pp]));
+                if (pw[1] != pw[2]) gl_add(&o2[(size_t)kb * nq + ka], tgdual::top(-S[P.o_sH + pp]));
             }
         }
     }
@@ -4721,8 +4741,8 @@ struct Core {
     // =====================================================================================================
     TG_HD bool dyn_deriv1(bool on, CArgs &A, size_t t) {
         const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nf = P.nf, ld = P.g_ld;
-        double *AUG = S + P.g_o_AUG, *X = S + P.g_o_X, *aF = S + P.g_o_aF, *xs = S + P.g_o_x, *acc = xs + nf;
-        const double *dq = S + P.o_dq;
+        Real *AUG = S + P.g_o_AUG, *X = S + P.g_o_X, *aF = S + P.g_o_aF, *xs = S + P.g_o_x, *acc = xs + nf;
+        const Real *dq = S + P.o_dq;
         const int c_q = nf, c_dq = nf + nq, c_k = nf + 2 * nq, c_u = c_k + nk;
         const bool ok0 = dynamics(on, A, t);
         if (on) TG_FOR(r, nf) xs[r] = S[P.o_Df + r * P.df_ld + nf];
@@ -4738,14 +4758,14 @@ struct Core {
         if (nc && on) {
             TG_FOR(n, P.n_dh) {
                 const int c = P.dh_pack[8 * (size_t)n], k = P.dh_pack[8 * (size_t)n + 1];
-                const double a = S[P.o_Dh2 + n];
+                const Real a = S[P.o_Dh2 + n];
                 if (k < nd) { AUG[k * ld + nd + c] = -a; AUG[(nd + c) * ld + k] = a; }
                 else AUG[(nd + c) * ld + c_k + (k - nd)] = -a;                       // -dg/d(ddq_k)
             }
             TG_FOR(pp, P.n_cpair) {
                 const int *pw = P.cpair4 + 4 * (size_t)pp;
                 const int c = pw[0], na = pw[1], nb = pw[2], ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
-                const double h2 = con_d2(c, na, nb), lam = xs[nd + c];
+                const Real h2 = con_d2(c, na, nb), lam = xs[nd + c];
                 const int row = (nd + c) * ld;
                 if (ka < nd) lds_add(&AUG[ka * ld + c_q + kb], lam * h2);           // d(Ad^T lambda)/dq
                 lds_add(&AUG[row + c_q + kb], -h2 * acc[ka]);                        // -d(A ddq)/dq
@@ -4760,8 +4780,8 @@ struct Core {
                 const int n = idx / P.g_max_cu, c = P.dh_c[n], k = P.dh_cfg[n];         // one lane per (item k, item i), j >= i
                 const int ni = P.cu_off[c] + idx % P.g_max_cu;
                 if (ni >= P.cu_off[c + 1]) continue;
-                const double dqi = dq[P.dh_cfg[ni]];
-                double sum = 0.0;
+                const Real dqi = dq[P.dh_cfg[ni]];
+                Real sum = 0.0;
                 for (int nj = ni; nj < P.cu_off[c + 1]; nj++)
                     sum += (nj == ni ? 1.0 : 2.0) * con_d3(c, ni, nj, n) * dq[P.dh_cfg[nj]];
                 lds_add(&AUG[(nd + c) * ld + c_q + k], -sum * dqi);
@@ -4772,13 +4792,13 @@ struct Core {
         // PX_k = sum_{j<k} (W_j dq_j + J_j ddq_j) in registers and leaves X_k = da_F/dq_k = [PX_k, J_k] + [W_k, v - P_k]
         // (only X is stored: 6 doubles per item instead of 18 keeps the kernel at two wavefronts per CU)
         if (on) TG_FOR(b, P.n_bodies) {
-            const double *v = S + P.o_vB + 6 * b;
-            double pr[6] = {0, 0, 0, 0, 0, 0}, px[6] = {0, 0, 0, 0, 0, 0};
+            const Real *v = S + P.o_vB + 6 * b;
+            Real pr[6] = {0, 0, 0, 0, 0, 0}, px[6] = {0, 0, 0, 0, 0, 0};
             for (int k = P.b_item_off[b]; k < P.b_item_off[b + 1]; k++) {
                 const int cfg = P.it_pack[4 * (size_t)k + 3] & 0xFFFF;
-                const double *J = S + P.o_J + 6 * k, *W = S + P.o_W + 6 * k;
-                const double dqk = dq[cfg], ak = acc[cfg];
-                double vm[6], t1[6], t2[6];
+                const Real *J = S + P.o_J + 6 * k, *W = S + P.o_W + 6 * k;
+                const Real dqk = dq[cfg], ak = acc[cfg];
+                Real vm[6], t1[6], t2[6];
                 for (int m = 0; m < 6; m++) vm[m] = v[m] - pr[m];
                 bracket(px, J, t1);
                 bracket(W, vm, t2);
@@ -4795,25 +4815,25 @@ struct Core {
             TG_FOR(pp, P.n_pairs) {
                 const int x = P.pair_a[pp], y = P.pair_b[pp];   // x at or before y on the path
                 const int b = P.it_pack[4 * (size_t)x];
-                const double *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b, *aFb = aF + 6 * b;
-                const double *Jx = S + P.o_J + 6 * x, *Jy = S + P.o_J + 6 * y;
+                const Real *I = S + P.o_I + 4 * b, *v = S + P.o_vB + 6 * b, *gam = S + P.o_gam + 3 * b, *aFb = aF + 6 * b;
+                const Real *Jx = S + P.o_J + 6 * x, *Jy = S + P.o_J + 6 * y;
                 // gravity: d(m gam.J_a)/dq_k = m gam.(w_x x v_y), symmetric in (a, k)
-                const double g2 = I[0] * (gam[0] * (Jx[4] * Jy[2] - Jx[5] * Jy[1]) + gam[1] * (Jx[5] * Jy[0] - Jx[3] * Jy[2]) +
+                const Real g2 = I[0] * (gam[0] * (Jx[4] * Jy[2] - Jx[5] * Jy[1]) + gam[1] * (Jx[5] * Jy[0] - Jx[3] * Jy[2]) +
                                           gam[2] * (Jx[3] * Jy[1] - Jx[4] * Jy[0]));
                 auto emit = [&](int a, int k, bool k_later) {
                     const int ca = P.it_pack[4 * (size_t)a + 3] & 0xFFFF, ck = P.it_pack[4 * (size_t)k + 3] & 0xFFFF;
                     if (ca >= nd) return;
-                    const double *Ja = S + P.o_J + 6 * a, *Jk = S + P.o_J + 6 * k, *Wk = S + P.o_W + 6 * k, *dAk = X + 6 * k;
-                    double br[6], jav[6], jaw[6], jkv[6];
+                    const Real *Ja = S + P.o_J + 6 * a, *Jk = S + P.o_J + 6 * k, *Wk = S + P.o_W + 6 * k, *dAk = X + 6 * k;
+                    Real br[6], jav[6], jaw[6], jkv[6];
                     bracket(Ja, Jk, br); bracket(Ja, v, jav); bracket(Ja, Wk, jaw); bracket(Jk, v, jkv);
-                    double tq = g2 - inner6(I, Ja, dAk) - inner6(I, jaw, v) - inner6(I, jav, Wk);
+                    Real tq = g2 - inner6(I, Ja, dAk) - inner6(I, jaw, v) - inner6(I, jav, Wk);
                     if (k_later) {   // dJ_a/dq_k = [J_a, J_k] only for joints after a
-                        double djv[6];
+                        Real djv[6];
                         bracket(br, v, djv);
                         tq -= inner6(I, br, aFb) + inner6(I, djv, v);
                     }
-                    const double td = -(2.0 * inner6(I, Ja, Wk) + inner6(I, Ja, jkv)) - inner6(I, br, v) - inner6(I, jav, Jk);
-                    const double mak = inner6(I, Ja, Jk);
+                    const Real td = -(2.0 * inner6(I, Ja, Wk) + inner6(I, Ja, jkv)) - inner6(I, br, v) - inner6(I, jav, Jk);
+                    const Real mak = inner6(I, Ja, Jk);
                     lds_add(&AUG[ca * ld + c_q + ck], tq);
                     lds_add(&AUG[ca * ld + c_dq + ck], td);
                     if (ck < nd) lds_add(&AUG[ca * ld + ck], mak);
@@ -4844,11 +4864,11 @@ struct Core {
             TG_FOR(pp, n_spair()) {
                 const int *pw = P.cpair4 + 4 * (size_t)(P.n_cpair + pp);
                 const int ka = pw[3] & 0xFFFF, kb = pw[3] >> 16;
-                const double h = S[P.o_sH + pp];
+                const Real h = S[P.o_sH + pp];
                 if (ka < nd) lds_add(&AUG[ka * ld + c_q + kb], -h);
                 if (pw[1] != pw[2] && kb < nd) lds_add(&AUG[kb * ld + c_q + ka], -h);
                 if (has_damper()) {
-                    double fab, fba, fdd;
+                    Real fab, fba, fdd;
                     damper_pair(pp, fab, fba, fdd);
                     if (ka < nd) { lds_add(&AUG[ka * ld + c_q + kb], fab); lds_add(&AUG[ka * ld + c_dq + kb], fdd); }
                     if (pw[1] != pw[2] && kb < nd) { lds_add(&AUG[kb * ld + c_q + ka], fba); lds_add(&AUG[kb * ld + c_dq + ka], fdd); }
@@ -4860,11 +4880,13 @@ struct Core {
         const int R = P.g_nrhs;
 #if defined(__HIP_DEVICE_COMPILE__)
         const int w = nf + R, nb4 = (nf + 3) >> 2;
+        if constexpr (!std::is_same<Real, double>::value) ok = gauss_jordan(on, AUG, nf, R, ld, S + P.o_scal);   // (forward-mode scalars: the generic solver)
+        else
         if (TEAM == 64 && nf > 16 && nf <= 31 && w <= 128 && 12 * P.n_joints >= 200) {
             // 17..31 unknowns, up to 128 columns: panels of four columns, every right-hand side in the rank-4 matrix-core update
             // (gj_panel_rhs: what the first-derivative kernel of the discrete path uses; gj_cols below spends 28 x 56 lane-wide FMAs
             // plus the pivot-column traffic per pivot step on the same system)
-            double *sc = S + P.o_G;   // the joint poses are dead during the solve
+            Real *sc = S + P.o_G;   // the joint poses are dead during the solve
             switch (nb4) {
             case 5: ok = Core<64, SPRINGS, PROG>::template gj_panel_rhs<20, 8>(on, AUG, nf, w, ld, lane, sc); break;
             case 6: ok = Core<64, SPRINGS, PROG>::template gj_panel_rhs<24, 8>(on, AUG, nf, w, ld, lane, sc); break;
@@ -4873,7 +4895,7 @@ struct Core {
             }
         } else
         if (TEAM == 64 && w <= 128 && nb4 <= 8 && P.gjc_ok) {
-            double *sc = S + P.o_G;   // the joint poses are dead during the solve
+            Real *sc = S + P.o_G;   // the joint poses are dead during the solve
             switch (nb4) {
             case 1: ok = Core<TEAM>::template gj_cols<4>(on, AUG, nf, w, ld, sc, lane); break;
             case 2: ok = Core<TEAM>::template gj_cols<8>(on, AUG, nf, w, ld, sc, lane); break;
@@ -4896,7 +4918,7 @@ struct Core {
                 dst += t * (size_t)rows[v] * width;
                 TG_FOR(idx, rows[v] * width) {
                     const int k = idx / width, o = idx % width;
-                    dst[idx] = AUG[(r0 + o) * ld + col0[v] + k];
+                    dst[idx] = tgdual::top(AUG[(r0 + o) * ld + col0[v] + k]);
                 }
             }
         }
@@ -4931,6 +4953,42 @@ struct Core {
         TG_STAMP(6);
     }
 };
+
+// One trajectory of a FORWARD-MODE launch of a continuous-dynamics mode (dual.hpp): the state (q, dq, ddq_k, u) is loaded with unit
+// directions on the variables RunArgs::seed1 / seed2 name, the mode's own code runs on Real = Dual<double> (one direction) or
+// Dual<Dual<double>> (two), and its outputs receive the highest-order coefficient: with MODE_DYN_DERIV1 the second derivatives of the
+// continuous dynamics (reference calc_dynamics_deriv2, system.c:1301-2029), one input variable per trajectory; with MODE_LAGRANGIAN the
+// third- and fourth-order derivatives of the Lagrangian (System_L_dqdqdq ... System_L_ddqddqdqdq, system.c:204-622).  S: the team's LDS
+// slice in units of Real (the same layout as the mode's double kernel).
+template <int TEAM, int MODE, bool SPRINGS, class PROG, class ARGS, class Real>
+TG_HD void run_forward(PROG &P, ARGS &A, Real *S, int lane, int traj) {
+    static_assert(MODE == MODE_DYNAMICS || MODE == MODE_DYN_DERIV1 || MODE == MODE_LAGRANGIAN || MODE == MODE_ENERGY, "run_forward: continuous-dynamics modes only");
+    const int nq = P.nq, nk = P.nk, nu = P.nu;
+    const bool live = traj < A.batch;
+    const size_t t = (size_t)(live ? traj : 0);
+    Core<TEAM, SPRINGS, PROG, Real> core(P, S, lane, A.t2 - A.t1);
+    core.seed1 = A.seed1 ? A.seed1[t] : -1;
+    core.seed2 = A.seed2 ? A.seed2[t] : -1;
+    core.init_sweep_schedule(false);
+    if (live) {
+        TG_FOR(i, nq) { const Real q = core.seeded(A.q2[t * nq + i], i); S[P.o_q1 + i] = q; S[P.o_q2 + i] = q; }
+        TG_FOR(i, P.nd) S[P.o_p1 + i] = 0.0;
+        TG_FOR(i, P.nc) S[P.o_lam + i] = 0.0;
+        TG_FOR(i, nu) S[P.o_u + i] = core.seeded(A.u1[t * nu + i], 2 * nq + nk + i);
+        TG_FOR(i, P.n_dh) { S[P.o_Dh1 + i] = 0.0; S[P.o_Dh2 + i] = 0.0; }
+    }
+    TG_SYNC();
+    if constexpr (MODE == MODE_LAGRANGIAN) core.lagrangian(live, A, t);
+    if constexpr (MODE == MODE_ENERGY) core.energy(live, A, t);
+    if constexpr (MODE == MODE_DYN_DERIV1) {
+        const bool ok = core.dyn_deriv1(live, A, t);
+        if (live && lane == 0) { A.iters[t] = 0; A.status[t] = ok ? TG_OK : TG_SINGULAR; }
+    }
+    if constexpr (MODE == MODE_DYNAMICS) {
+        const bool ok = core.dynamics(live, A, t);
+        if (live && lane == 0) { A.iters[t] = 0; A.status[t] = ok ? TG_OK : TG_SINGULAR; }
+    }
+}
 
 // One trajectory (team) of a launch.  `traj` may be >= batch (idle team): it still takes part in
 // every TG_SYNC.

@@ -47,6 +47,15 @@ __global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DE
     tg::run_trajectory<TEAM, MODE, SPRINGS>(P, A, lds + (size_t)team * stride, lane, traj);
 }
 
+// Forward-mode kernels of the continuous dynamics (mvi_core.hpp, run_forward; dual.hpp): one wavefront per trajectory, the trajectory's
+// LDS slice in units of Real.  Not a hot path (the reference's calc_dynamics_deriv2 is O(nq^4) per state): full-wave teams only.
+template <int MODE, bool SPRINGS, class Real>
+__global__ __launch_bounds__(64, 1) void k_forward(const tg::DevProg *__restrict__ Pg, const tg::RunArgs A) {
+    Real *lds = (Real *)tg_lds_base();
+    tg::CProg &P = *(tg::CProg *)Pg;
+    tg::run_forward<64, MODE, SPRINGS>(P, A, lds, (int)threadIdx.x, (int)blockIdx.x);
+}
+
 }  // namespace
 
 struct tg_system {
@@ -91,6 +100,7 @@ struct tg_batch {
     double *energy = nullptr;  // [batch][2] output of tg_batch_energy
     double *lag = nullptr;     // outputs of tg_batch_lagrangian
     int *dyn_ints = nullptr;   // its status / iteration words (the integrator's own stay untouched)
+    int *seeds = nullptr;      // [2][batch] direction variables of the forward-mode calls
     double *d1[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool have_d1 = false;
     long long *prof = nullptr; // diagnostic build only (TG_PROFILE)
@@ -255,6 +265,54 @@ int launch(tg_batch *b, tg::RunArgs &A) {
         b->events.emplace_back(e0, e1);
     }
     return rc;
+}
+
+#if !defined(TG_PROFILE)
+template <int MODE, bool SPRINGS, class Real>
+int launch_forward_variant(tg_batch *b, const tg::RunArgs &A, size_t lds) {
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_forward<MODE, SPRINGS, Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_forward<MODE, SPRINGS, Real>), dim3(A.batch), dim3(64), lds, b->stream, b->d_prog, A);
+    return TG_SUCCESS;
+}
+template <int MODE, class Real>
+int launch_forward_mode(tg_batch *b, const tg::RunArgs &A) {
+    const int per_team = std::max(b->P.lds_per_team, MODE == tg::MODE_DYN_DERIV1 ? b->P.g_lds_per_team : 0);
+    const size_t lds = (size_t)per_team * sizeof(Real);
+    if (lds > 160 * 1024) return fail(TG_ERR_UNSUPPORTED, "system too large for the LDS-resident forward-mode kernel");
+    const bool springs = b->P.has_cs || b->P.n_springs || b->P.has_plane || b->P.n_wrenches;
+    int rc = springs ? launch_forward_variant<MODE, true, Real>(b, A, lds) : launch_forward_variant<MODE, false, Real>(b, A, lds);
+    if (rc == TG_SUCCESS && hipGetLastError() != hipSuccess) rc = fail(TG_ERR_HIP, "kernel launch failed");
+    return rc;
+}
+#endif
+// A continuous-dynamics mode on dual numbers: A.seed1 (and A.seed2 for order 2) name the direction variable(s) of every trajectory.
+int launch_forward(tg_batch *b, const tg::RunArgs &A, int order) {
+#if defined(TG_PROFILE)
+    (void)b; (void)A; (void)order;
+    return fail(TG_ERR_UNSUPPORTED, "the profiling build has no forward-mode kernels");
+#else
+    typedef tgdual::Dual<double> D1;
+    typedef tgdual::Dual<D1> D2;
+    b->mirror_valid = false;
+    if (A.mode == tg::MODE_DYN_DERIV1 && order == 1) return launch_forward_mode<tg::MODE_DYN_DERIV1, D1>(b, A);
+    if (A.mode == tg::MODE_LAGRANGIAN && order == 1) return launch_forward_mode<tg::MODE_LAGRANGIAN, D1>(b, A);
+    if (A.mode == tg::MODE_LAGRANGIAN && order == 2) return launch_forward_mode<tg::MODE_LAGRANGIAN, D2>(b, A);
+    return fail(TG_ERR_INVALID, "forward mode: first derivatives of the dynamics (order 1) or the Lagrangian (order 1, 2)");
+#endif
+}
+// the direction variables of a forward-mode call, checked and copied to the device; null seed2: first order
+int stage_seeds(tg_batch *b, const int32_t *seed1_host, const int32_t *seed2_host) {
+    const size_t B = (size_t)b->batch;
+    const int nvar = 2 * b->P.nq + b->P.nk + b->P.nu;
+    for (size_t i = 0; i < B; i++) {
+        if (seed1_host[i] < -1 || seed1_host[i] >= nvar) return fail(TG_ERR_INVALID, "direction variable out of range (q | dq | ddq_k | u)");
+        if (seed2_host && (seed2_host[i] < -1 || seed2_host[i] >= nvar)) return fail(TG_ERR_INVALID, "direction variable out of range (q | dq | ddq_k | u)");
+    }
+    if (!b->seeds) HIP_TRY(hipMalloc(&b->seeds, 2 * B * sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(b->seeds, seed1_host, B * sizeof(int), hipMemcpyHostToDevice, b->stream));
+    if (seed2_host) HIP_TRY(hipMemcpyAsync(b->seeds + B, seed2_host, B * sizeof(int), hipMemcpyHostToDevice, b->stream));
+    return TG_SUCCESS;
 }
 
 // Host-facing derivative outputs: the twelve first-derivative arrays and the contraction buffers.  Allocated on
@@ -472,7 +530,7 @@ void tg_batch_destroy(tg_batch *b) {
     for (auto &e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : b->pool) hipEventDestroy(e);
     void *ptrs[] = {b->d_args, b->dt_dev, b->d_prog, b->d_ints, b->d_dbls, b->q1, b->q2, b->p1, b->p2, b->lam, b->u1, b->stage_u, b->stage_k,
-                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->fallbacks, b->snap, b->z_dev, b->hz_dev, b->zl_dev, b->dyn, b->dyn_ints, b->dyn_d1, b->energy, b->lag,
+                    b->stage_qh, b->stage_lh, b->f_out, b->iters, b->status, b->fallbacks, b->snap, b->z_dev, b->hz_dev, b->zl_dev, b->dyn, b->dyn_ints, b->seeds, b->dyn_d1, b->energy, b->lag,
                     b->d1[0], b->d1[1], b->d1[2], b->d1[3], b->d1[4], b->d1[5], b->d1[6], b->d1[7], b->d1[8], b->d1[9], b->d1[10], b->d1[11]};
     for (void *p : ptrs) if (p) hipFree(p);
     if (b->h_args) hipHostFree(b->h_args);
@@ -832,7 +890,7 @@ int tg_batch_dynamics_device(tg_batch *b, const double *q_dev, const double *dq_
     return launch(b, A);
 }
 
-int tg_batch_lagrangian(tg_batch *b, const double *q_host, const double *dq_host, double *first_host, double *second_host) {
+static int lagrangian_host(tg_batch *b, const double *q_host, const double *dq_host, const int32_t *seed1_host, const int32_t *seed2_host, double *first_host, double *second_host) {
     if (!b || !q_host || !dq_host || !first_host || !second_host) return fail(TG_ERR_INVALID, "null argument");
     const tg::DevProg &P = b->P;
     HIP_TRY(hipSetDevice(b->device));
@@ -848,11 +906,24 @@ int tg_batch_lagrangian(tg_batch *b, const double *q_host, const double *dq_host
     tg::RunArgs A = base_args(b, tg::MODE_LAGRANGIAN);
     A.q1 = A.q2 = q; A.dq_in = dq; A.lag1_out = o1; A.lag2_out = o2;
     A.iters = b->dyn_ints; A.status = b->dyn_ints + b->batch;
-    if (int rc = launch(b, A)) return rc;
+    if (seed1_host) {
+        if (int rc = stage_seeds(b, seed1_host, seed2_host)) return rc;
+        A.seed1 = b->seeds; A.seed2 = seed2_host ? b->seeds + B : nullptr;
+        if (int rc = launch_forward(b, A, seed2_host ? 2 : 1)) return rc;
+    } else if (int rc = launch(b, A)) return rc;
     HIP_TRY(hipMemcpyAsync(first_host, o1, 2 * B * nq * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipMemcpyAsync(second_host, o2, 3 * B * nq * nq * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return TG_SUCCESS;
+}
+
+int tg_batch_lagrangian(tg_batch *b, const double *q_host, const double *dq_host, double *first_host, double *second_host) {
+    return lagrangian_host(b, q_host, dq_host, nullptr, nullptr, first_host, second_host);
+}
+int tg_batch_lagrangian_forward(tg_batch *b, const double *q_host, const double *dq_host, const int32_t *seed1_host, const int32_t *seed2_host,
+                                double *first_host, double *second_host) {
+    if (!seed1_host) return fail(TG_ERR_INVALID, "null argument");
+    return lagrangian_host(b, q_host, dq_host, seed1_host, seed2_host, first_host, second_host);
 }
 
 int tg_batch_set_predictor(tg_batch *b, int32_t mode) {
@@ -882,8 +953,8 @@ int tg_batch_energy(tg_batch *b, const double *q_host, const double *dq_host, do
     return TG_SUCCESS;
 }
 
-int tg_batch_dynamics_deriv1_device(tg_batch *b, const double *q_dev, const double *dq_dev, const double *u_dev, const double *ddqk_dev,
-                                    double *const out_dev[8], int32_t *status_dev) {
+static int dyn_deriv1_device(tg_batch *b, const double *q_dev, const double *dq_dev, const double *u_dev, const double *ddqk_dev, const int *seed_dev,
+                             double *const out_dev[8], int32_t *status_dev) {
     if (!b || !q_dev || !dq_dev || !out_dev) return fail(TG_ERR_INVALID, "null argument");
     const tg::DevProg &P = b->P;
     if ((P.nu && !u_dev) || (P.nk && !ddqk_dev)) return fail(TG_ERR_INVALID, "null argument");
@@ -895,12 +966,17 @@ int tg_batch_dynamics_deriv1_device(tg_batch *b, const double *q_dev, const doub
     A.dq_in = dq_dev; A.ddqk_in = ddqk_dev; A.ddq_out = nullptr; A.lam_out = nullptr;
     for (int g = 0; g < 8; g++) A.g1[g] = out_dev[g];
     A.iters = b->dyn_ints; A.status = status_dev ? status_dev : b->dyn_ints + b->batch;
+    if (seed_dev) { A.seed1 = seed_dev; return launch_forward(b, A, 1); }
     return launch(b, A);
 }
+int tg_batch_dynamics_deriv1_device(tg_batch *b, const double *q_dev, const double *dq_dev, const double *u_dev, const double *ddqk_dev,
+                                    double *const out_dev[8], int32_t *status_dev) {
+    return dyn_deriv1_device(b, q_dev, dq_dev, u_dev, ddqk_dev, nullptr, out_dev, status_dev);
+}
 
-int tg_batch_dynamics_deriv1(tg_batch *b, const double *q_host, const double *dq_host, const double *u_host, const double *ddqk_host,
-                             double *f_dq, double *f_ddq, double *f_dddk, double *f_du,
-                             double *lambda_dq, double *lambda_ddq, double *lambda_dddk, double *lambda_du, int32_t *status_host) {
+static int dyn_deriv1_host(tg_batch *b, const double *q_host, const double *dq_host, const double *u_host, const double *ddqk_host, const int32_t *seed_host,
+                           double *f_dq, double *f_ddq, double *f_dddk, double *f_du,
+                           double *lambda_dq, double *lambda_ddq, double *lambda_dddk, double *lambda_du, int32_t *status_host) {
     if (!b || !q_host || !dq_host) return fail(TG_ERR_INVALID, "null argument");
     const tg::DevProg &P = b->P;
     if ((P.nu && !u_host) || (P.nk && !ddqk_host)) return fail(TG_ERR_INVALID, "null argument");
@@ -925,12 +1001,24 @@ int tg_batch_dynamics_deriv1(tg_batch *b, const double *q_host, const double *dq
         dev[g] = (host[g] && cnt[g]) ? b->dyn_d1 + off : nullptr;
         off += cnt[g];
     }
-    if (int rc = tg_batch_dynamics_deriv1_device(b, q, dq, nu ? u : nullptr, nk ? ddk : nullptr, dev, nullptr)) return rc;
+    if (seed_host) { if (int rc = stage_seeds(b, seed_host, nullptr)) return rc; }
+    if (int rc = dyn_deriv1_device(b, q, dq, nu ? u : nullptr, nk ? ddk : nullptr, seed_host ? b->seeds : nullptr, dev, nullptr)) return rc;
     for (int g = 0; g < 8; g++)
         if (dev[g]) HIP_TRY(hipMemcpyAsync(host[g], dev[g], cnt[g] * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     if (status_host) HIP_TRY(hipMemcpyAsync(status_host, b->dyn_ints + B, B * sizeof(int), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return TG_SUCCESS;
+}
+int tg_batch_dynamics_deriv1(tg_batch *b, const double *q_host, const double *dq_host, const double *u_host, const double *ddqk_host,
+                             double *f_dq, double *f_ddq, double *f_dddk, double *f_du,
+                             double *lambda_dq, double *lambda_ddq, double *lambda_dddk, double *lambda_du, int32_t *status_host) {
+    return dyn_deriv1_host(b, q_host, dq_host, u_host, ddqk_host, nullptr, f_dq, f_ddq, f_dddk, f_du, lambda_dq, lambda_ddq, lambda_dddk, lambda_du, status_host);
+}
+int tg_batch_dynamics_deriv1_forward(tg_batch *b, const double *q_host, const double *dq_host, const double *u_host, const double *ddqk_host,
+                                     const int32_t *seed_host, double *f_dq, double *f_ddq, double *f_dddk, double *f_du,
+                                     double *lambda_dq, double *lambda_ddq, double *lambda_dddk, double *lambda_du, int32_t *status_host) {
+    if (!seed_host) return fail(TG_ERR_INVALID, "null argument");
+    return dyn_deriv1_host(b, q_host, dq_host, u_host, ddqk_host, seed_host, f_dq, f_ddq, f_dddk, f_du, lambda_dq, lambda_ddq, lambda_dddk, lambda_du, status_host);
 }
 
 int tg_batch_dynamics(tg_batch *b, const double *q_host, const double *dq_host, const double *u_host, const double *ddqk_host,

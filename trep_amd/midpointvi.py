@@ -423,15 +423,30 @@ class BatchMidpointVI(object):
                                              _lib.ptr(ddq), _lib.ptr(lam), status.ctypes.data))
         return ddq, lam, status
 
-    def lagrangian(self, Q, dQ):
+    def _seeds(self, seeds, most):
+        """(seed1,) or (seed1, seed2) -> contiguous int32 [B] arrays: the input variable each trajectory's direction follows, numbered
+        q [nq] | dq [nq] | ddq_k [nk] | u [nu] (forward-mode kernels, csrc/dual.hpp)."""
+        if not 1 <= len(seeds) <= most:
+            raise ValueError("between one and %d direction arrays" % most)
+        out = [np.ascontiguousarray(np.broadcast_to(np.asarray(s_, dtype=np.int32), (self._batch,))) for s_ in seeds]
+        return out
+
+    def lagrangian(self, Q, dQ, seeds=None):
         """First and second derivatives of the Lagrangian of B states: dict with L_dq, L_ddq [B][nq] and L_dqdq,
-        L_ddqdq (velocity config = row), L_ddqddq [B][nq][nq] (System.L_dq() ... L_ddqddq(), system.py:852-925)."""
+        L_ddqdq (velocity config = row), L_ddqddq [B][nq][nq] (System.L_dq() ... L_ddqddq(), system.py:852-925).
+        seeds = (s1,) or (s1, s2): the exact derivative of every entry along input variable s1[b] (and s2[b]) instead --
+        the third- and fourth-order derivatives System.L_dqdqdq() ... L_ddqddqdqdq() (system.py:869-949)."""
         self.refresh()
         B = self._batch
         Q = _lib.as_f64(np.broadcast_to(np.asarray(Q, dtype=float), (B, self.nq)), (B, self.nq))
         dQ = _lib.as_f64(np.broadcast_to(np.asarray(dQ, dtype=float), (B, self.nq)), (B, self.nq))
         o1, o2 = np.zeros((B, 2, self.nq)), np.zeros((B, 3, self.nq, self.nq))
-        _lib.check(self._L.tg_batch_lagrangian(self._h, _lib.ptr(Q), _lib.ptr(dQ), _lib.ptr(o1), _lib.ptr(o2)))
+        if seeds is None:
+            _lib.check(self._L.tg_batch_lagrangian(self._h, _lib.ptr(Q), _lib.ptr(dQ), _lib.ptr(o1), _lib.ptr(o2)))
+        else:
+            sd = self._seeds(seeds, 2)
+            _lib.check(self._L.tg_batch_lagrangian_forward(self._h, _lib.ptr(Q), _lib.ptr(dQ), sd[0].ctypes.data,
+                                                           sd[1].ctypes.data if len(sd) > 1 else None, _lib.ptr(o1), _lib.ptr(o2)))
         return {"L_dq": o1[:, 0], "L_ddq": o1[:, 1], "L_dqdq": o2[:, 0], "L_ddqdq": o2[:, 1], "L_ddqddq": o2[:, 2]}
 
     @property
@@ -461,9 +476,11 @@ class BatchMidpointVI(object):
 
     DYN_D1_NAMES = ("f_dq", "f_ddq", "f_dddk", "f_du", "lambda_dq", "lambda_ddq", "lambda_dddk", "lambda_du")
 
-    def dynamics_deriv1(self, Q, dQ, U=None, ddQk=None):
+    def dynamics_deriv1(self, Q, dQ, U=None, ddQk=None, seeds=None):
         """First derivatives of the continuous dynamics of B states at once (System.f_dq() ... lambda_du() of the
-        reference, system.py:961-1044).  Returns ({name: [B][output][derivative variable]}, status [B])."""
+        reference, system.py:961-1044).  Returns ({name: [B][output][derivative variable]}, status [B]).
+        seeds = (s,): the exact derivative of every entry along input variable s[b] instead (the first-derivative kernel on dual
+        numbers): the second derivatives System.f_dqdq() ... lambda_dudu() (system.py:982-1078), one variable per trajectory."""
         self.refresh()
         B = self._batch
         Q = _lib.as_f64(np.broadcast_to(np.asarray(Q, dtype=float), (B, self.nq)), (B, self.nq))
@@ -473,8 +490,13 @@ class BatchMidpointVI(object):
         rows = (self.nq, self.nq, self.nk, self.nu)
         outs = [np.zeros((B, rows[g & 3], self.nd if g < 4 else self.nc)) for g in range(8)]
         status = np.zeros(B, dtype=np.int32)
-        _lib.check(self._L.tg_batch_dynamics_deriv1(self._h, _lib.ptr(Q), _lib.ptr(dQ), _lib.ptr(U), _lib.ptr(K),
-                                                    *([_lib.ptr(o) for o in outs] + [status.ctypes.data])))
+        if seeds is None:
+            _lib.check(self._L.tg_batch_dynamics_deriv1(self._h, _lib.ptr(Q), _lib.ptr(dQ), _lib.ptr(U), _lib.ptr(K),
+                                                        *([_lib.ptr(o) for o in outs] + [status.ctypes.data])))
+        else:
+            sd = self._seeds(seeds, 1)
+            _lib.check(self._L.tg_batch_dynamics_deriv1_forward(self._h, _lib.ptr(Q), _lib.ptr(dQ), _lib.ptr(U), _lib.ptr(K), sd[0].ctypes.data,
+                                                                *([_lib.ptr(o) for o in outs] + [status.ctypes.data])))
         return dict((n, np.swapaxes(o, 1, 2)) for n, o in zip(self.DYN_D1_NAMES, outs)), status
 
     def snapshot(self):

@@ -28,7 +28,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 CACHE = os.path.join(_HERE, "_spec")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-_SOURCES = ["spec_kernel.hip", "mvi_core.hpp", "program.hpp", "bbd.hpp", "bbd_solve.hpp"]
+_SOURCES = ["spec_kernel.hip", "mvi_core.hpp", "program.hpp", "bbd.hpp", "bbd_solve.hpp", "dual.hpp"]
 # -amdgpu-mfma-vgpr-form: the matrix-core accumulators of the out-of-line solvers (gj_panel) stay in VGPRs.  As AGPRs they are ADDED to the
 # rollout kernel's own 254 VGPRs (288 registers: ONE wave per SIMD instead of two -- 76 instead of 51 ms per benchmark launch)
 DEFAULT_FLAGS = ("-DSPEC_ARGS_IN_MEMORY -DSPEC_DERIVATIVES -DTG_GJ_INLINE -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp "

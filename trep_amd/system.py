@@ -10,7 +10,7 @@ cache_index, config.masses) are exactly what the device library consumes
 the reference (tests/test_topology.py).
 
 Next to the hot path the class also offers the continuous dynamics -- ``f``, ``lambda_``, their first
-derivatives (analytic kernels) and second derivatives (batched differences of the first-derivative kernel), energies
+derivatives (analytic kernels) and second derivatives (the first-derivative kernel on dual numbers: exact), energies
 and Lagrangian derivatives -- ``satisfy_constraints`` (SLSQP on the host, gradients from the device) and the
 trajectory ``.mat`` files (``save_trajectory`` / ``load_trajectory``).
 """
@@ -20,42 +20,34 @@ from .config import Config, Input
 from .frame import Frame, WORLD
 
 
-def dynamics_deriv2_from_deriv1(deriv1, q, dq, u, ddqk, step=1e-4):
-    """Second derivatives of the continuous dynamics from a batched evaluator of the analytic FIRST derivatives.
+def dynamics_deriv2_forward(deriv1_forward, q, dq, u, ddqk):
+    """Second derivatives of the continuous dynamics from a batched FORWARD-MODE evaluator of the analytic first derivatives.
 
-    deriv1(Q [M][nq], dQ [M][nq], U [M][nu], ddK [M][nk]) -> {"f_dq": [M][nd][nq], "f_ddq", "f_dddk" [M][nd][nk], "f_du",
-    "lambda_dq" [M][nc][nq], ...} (BatchMidpointVI.dynamics_deriv1 without the status; the tests also drive it with the
-    oracle and the host emulation).  Fourth-order central differences over q, dq and u: M = 4 (2 nq + nu) states in one
-    call.  Returns the reference's fourteen arrays, [first variable][second variable][output] (system.py:982-1078)."""
+    deriv1_forward(Q [M][nq], dQ [M][nq], U [M][nu], ddK [M][nk], seed [M]) -> {"f_dq": [M][nd][nq], "f_ddq", "f_dddk" [M][nd][nk],
+    "f_du", "lambda_dq" [M][nc][nq], ...}: for state m the exact derivative of every first-derivative array along input variable
+    seed[m] (numbered q | dq | ddq_k | u) -- BatchMidpointVI.dynamics_deriv1(..., seeds=(seed,)), i.e. the first-derivative kernel run
+    on dual numbers (csrc/dual.hpp); the tests also drive it with the host emulation of that kernel.  One state per variable of
+    (q, dq, u): M = 2 nq + nu states in one call, no step size.  Returns the reference's fourteen arrays, [first variable][second
+    variable][output] (system.py:982-1078)."""
     q, dq, u, ddqk = (np.asarray(a, dtype=float) for a in (q, dq, u, ddqk))
-    nq, nu = len(q), len(u)
+    nq, nu, nk = len(q), len(u), len(ddqk)
     nv = 2 * nq + nu
-    x0 = np.concatenate([q, dq, u])
-    h = step * np.maximum(1.0, np.abs(x0))
-    X = np.repeat(x0[None], 4 * nv, axis=0)
-    for v in range(nv):
-        X[4 * v:4 * v + 4, v] += np.array([-2.0, -1.0, 1.0, 2.0]) * h[v]
-    d = deriv1(X[:, :nq], X[:, nq:2 * nq], X[:, 2 * nq:], np.repeat(ddqk[None], 4 * nv, axis=0))
-    w = np.array([1.0, -8.0, 8.0, -1.0]) / 12.0
+    seed = np.concatenate([np.arange(2 * nq), 2 * nq + nk + np.arange(nu)]).astype(np.int32)
+    rep = lambda a: np.repeat(a[None], nv, axis=0)
+    d = deriv1_forward(rep(q), rep(dq), rep(u), rep(ddqk), seed)
 
-    def diff(name, lo, hi):
+    def part(name, lo, hi):
         """d(name[output][var1]) / d x_v for v in [lo, hi): -> [var1][v][output]"""
-        a = np.asarray(d[name])
-        a = a.reshape(nv, 4, *a.shape[1:])[lo:hi]                              # [v][stencil][out][var1]
-        g = np.tensordot(a, w, axes=([1], [0])) / h[lo:hi, None, None]         # [v][out][var1]
-        return np.ascontiguousarray(np.transpose(g, (2, 0, 1)))
+        return np.ascontiguousarray(np.transpose(np.asarray(d[name])[lo:hi], (2, 0, 1)))
     out = {}
     for pre in ("f", "lambda"):
-        out[pre + "_dqdq"] = diff(pre + "_dq", 0, nq)
-        out[pre + "_ddqdq"] = diff(pre + "_ddq", 0, nq)
-        out[pre + "_ddqddq"] = diff(pre + "_ddq", nq, 2 * nq)
-        out[pre + "_dddkdq"] = diff(pre + "_dddk", 0, nq)
-        out[pre + "_dudq"] = diff(pre + "_du", 0, nq)
-        out[pre + "_duddq"] = diff(pre + "_du", nq, 2 * nq)
-        out[pre + "_dudu"] = diff(pre + "_du", 2 * nq, 2 * nq + nu)
-        for sym in ("_dqdq", "_ddqddq", "_dudu"):     # symmetric by construction in the reference (filled by symmetry)
-            a = out[pre + sym]
-            out[pre + sym] = 0.5 * (a + np.transpose(a, (1, 0, 2)))
+        out[pre + "_dqdq"] = part(pre + "_dq", 0, nq)
+        out[pre + "_ddqdq"] = part(pre + "_ddq", 0, nq)
+        out[pre + "_ddqddq"] = part(pre + "_ddq", nq, 2 * nq)
+        out[pre + "_dddkdq"] = part(pre + "_dddk", 0, nq)
+        out[pre + "_dudq"] = part(pre + "_du", 0, nq)
+        out[pre + "_duddq"] = part(pre + "_du", nq, 2 * nq)
+        out[pre + "_dudu"] = part(pre + "_du", 2 * nq, 2 * nq + nu)
     return out
 
 
@@ -460,48 +452,20 @@ class System(object):
         return float(self._lagrangian()["L_ddqddq"][dq1.index, dq2.index])
 
     # -- third- and fourth-order derivatives of the Lagrangian (system.py:869-949; System_L_dqdqdq ... L_ddqddqdqdq, system.c:204-557)
-    def _lagrangian_batch(self, Q):
-        """L_dqdq, L_ddqdq, L_ddqddq [M][nq][nq] at the configurations Q [M][nq] (M <= 8) with the current rates."""
+    def _L_higher(self, name, i, j, wrt):
+        """d^n (name[i][j]) / dq_wrt[0] (dq_wrt[1]) with name in L_dqdq / L_ddqdq / L_ddqddq, n = len(wrt) in (1, 2): the
+        reference reads these from its third- and fourth-order frame tables; here the ANALYTIC second-order arrays of the
+        Lagrangian kernel are differentiated exactly -- the same kernel on dual numbers (csrc/dual.hpp: one direction for the
+        third order, two nested ones for the fourth), no step size.  Agreement with the reference: rounding (1e-13)."""
         from .midpointvi import BatchMidpointVI
         eng = getattr(self, "_lag_engine", None)
         if eng is None or self._lag_engine_version != self._structure_version:
             if eng is not None:
                 eng.close()
-            eng = self._lag_engine = BatchMidpointVI(self, 8)
+            eng = self._lag_engine = BatchMidpointVI(self, 1)
             self._lag_engine_version = self._structure_version
-        Qp = np.repeat(self.q[None], 8, axis=0)
-        Qp[:len(Q)] = Q
-        return eng.lagrangian(Qp, np.repeat(self.dq[None], 8, axis=0))
-
-    def _L_higher(self, name, i, j, wrt):
-        """d^n (name[i][j]) / dq_wrt[0] (dq_wrt[1]) with name in L_dqdq / L_ddqdq / L_ddqddq, n = len(wrt) in (1, 2): the
-        reference evaluates these from its third- and fourth-order frame tables; the device formulation has no such tables
-        (DESIGN.md section 3), so the ANALYTIC second-order arrays of the Lagrangian kernel are differenced -- fourth-order
-        central stencils, all stencil points in one launch.  Agreement with the reference: about 1e-10 (third order),
-        1e-7 (fourth order) relative to the largest entry."""
-        q0 = self.q
-        h = 1e-3 * np.maximum(1.0, np.abs(q0))
-        if len(wrt) == 1:
-            k = wrt[0]
-            Q = np.repeat(q0[None], 4, axis=0)
-            Q[:, k] += np.array([-2.0, -1.0, 1.0, 2.0]) * h[k]
-            f = self._lagrangian_batch(Q)[name][:4, i, j]
-            return float(np.dot(f, [1.0, -8.0, 8.0, -1.0]) / (12.0 * h[k]))
-        k, l = wrt
-        if k == l:
-            Q = np.repeat(q0[None], 5, axis=0)
-            Q[:, k] += np.array([-2.0, -1.0, 0.0, 1.0, 2.0]) * h[k]
-            f = self._lagrangian_batch(Q)[name][:5, i, j]
-            return float(np.dot(f, [-1.0, 16.0, -30.0, 16.0, -1.0]) / (12.0 * h[k] ** 2))
-        Q = np.repeat(q0[None], 8, axis=0)
-        signs = [(1, 1), (1, -1), (-1, 1), (-1, -1)]
-        for n, (a, b) in enumerate(signs):
-            Q[n, k] += a * h[k]; Q[n, l] += b * h[l]
-            Q[4 + n, k] += 2 * a * h[k]; Q[4 + n, l] += 2 * b * h[l]
-        f = self._lagrangian_batch(Q)[name][:, i, j]
-        d1 = (f[0] - f[1] - f[2] + f[3]) / (4.0 * h[k] * h[l])
-        d2 = (f[4] - f[5] - f[6] + f[7]) / (16.0 * h[k] * h[l])
-        return float((4.0 * d1 - d2) / 3.0)          # Richardson: the h^2 terms of the two mixed differences cancel
+        seeds = tuple(np.array([k], dtype=np.int32) for k in wrt)      # configuration variables come first in the numbering
+        return float(eng.lagrangian(self.q[None], self.dq[None], seeds=seeds)[name][0, i, j])
 
     def L_dqdqdq(self, q1, q2, q3):
         value = self._L_higher("L_dqdq", q1.index, q2.index, (q3.index,))
@@ -563,30 +527,28 @@ class System(object):
         """All fourteen second-derivative arrays of ddq = f(q, dq, u, ddq_k) and lambda at the current state, laid out
         like the reference's ([first variable][second variable][output]).
 
-        The reference assembles them from fourth-order Lagrangian tables (M_dqdq is nq^4 entries).  Here they are the
-        derivatives of the ANALYTIC first-derivative arrays (MODE_DYN_DERIV1) with respect to q, dq and u, taken with
-        a fourth-order central difference: the 4 * (2 nq + nu) perturbed states form one batch, i.e. one launch of the
-        first-derivative kernel.  Truncation is O(h^4) with h = 1e-4 (relative to max(1, |x|)), round-off
-        eps |f'| / h: agreement with the reference is 1e-12 ... 3e-10 relative to each array's largest entry on the test
-        systems (tested at 1e-8).  An analytic kernel (nested brackets one order above deriv2z) is future work.
+        The reference assembles them from fourth-order Lagrangian tables (M_dqdq is nq^4 entries, system.c:1301-2029).  Here
+        they are the exact derivatives of the analytic first-derivative arrays (MODE_DYN_DERIV1) along each of q, dq and u:
+        the first-derivative kernel run on dual numbers (csrc/dual.hpp), one input variable per trajectory, 2 nq + nu
+        trajectories in one launch.  No step size and no truncation: agreement with the reference is rounding (1e-13
+        relative to each array's largest entry on the test systems, tested at 1e-10).
         Systems with a LinearDamper: the reference's own f_ddqdq is inconsistent with its first derivatives there
-        (lineardamper.c:88 uses length_dq where length_dqdq is meant); these are the derivatives of the first derivatives."""
+        (lineardamper.c:88 uses length_dq where length_dqdq is meant); _apply_reference_conventions carries that over."""
         from .midpointvi import BatchMidpointVI
         self._dynamics()                       # the reference's side effect on Config.ddq; builds the engine
-        nq, nd, nk, nu, nc = self.nQ, self.nQd, self.nQk, self.nu, self.nc
-        nv = 2 * nq + nu
+        nv = 2 * self.nQ + self.nu
         eng = getattr(self, "_dyn2_engine", None)
-        if eng is None or self._dyn2_engine_version != self._structure_version or eng.batch != 4 * nv:
+        if eng is None or self._dyn2_engine_version != self._structure_version or eng.batch != nv:
             if eng is not None:
                 eng.close()
-            eng = self._dyn2_engine = BatchMidpointVI(self, 4 * nv)
+            eng = self._dyn2_engine = BatchMidpointVI(self, nv)
             self._dyn2_engine_version = self._structure_version
-        def deriv1(Q, dQ, U, ddK):
-            d, status = eng.dynamics_deriv1(Q, dQ, U, ddK)
+        def deriv1_forward(Q, dQ, U, ddK, seed):
+            d, status = eng.dynamics_deriv1(Q, dQ, U, ddK, seeds=(seed,))
             if (status != 0).any():
                 raise ValueError("singular inertia or constraint matrix")
             return d
-        out = dynamics_deriv2_from_deriv1(deriv1, self.q, self.dq, self.u, self.ddqk)
+        out = dynamics_deriv2_forward(deriv1_forward, self.q, self.dq, self.u, self.ddqk)
         if getattr(self, "reference_conventions", True):      # False: the derivatives consistent with this library's own first derivatives
             self._apply_reference_conventions(out)
         return out
@@ -601,7 +563,7 @@ class System(object):
 
         A force second derivative enters the dynamics' second derivatives only through D (system.c:775-795) and D only linearly:
         d(ddq) = M^-1 (dD + Ad^T d(lambda)), d(lambda) = -(Ad M^-1 Ad^T)^-1 Ad M^-1 dD (system.c:840-892).  So the reference's arrays
-        are the consistent ones (differences of the analytic first derivatives) plus that linear response to the difference
+        are the consistent ones (derivatives of the analytic first derivatives) plus that linear response to the difference
         between the reference's element derivative and the consistent one."""
         from .dynamics import LinearDamper, NonlinearConfigSpring
         from . import element_queries as _eq
