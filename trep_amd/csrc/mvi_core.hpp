@@ -4745,6 +4745,7 @@ struct Core {
         const Real *dq = S + P.o_dq;
         const int c_q = nf, c_dq = nf + nq, c_k = nf + 2 * nq, c_u = c_k + nk;
         const bool ok0 = dynamics(on, A, t);
+        const bool path_sums = nc > 0 && 12 * nc <= 6 * P.n_items;      // (the constraint path sums below live in the X area)
         if (on) TG_FOR(r, nf) xs[r] = S[P.o_Df + r * P.df_ld + nf];
         TG_SYNC();
         if (on) {
@@ -4776,8 +4777,11 @@ struct Core {
                     lds_add(&AUG[row + c_dq + kb], -2.0 * h2 * dq[ka]);
                 }
             }
-            TG_FOR(idx, P.n_dh * P.g_max_cu) {                                       // -d(dq^T H dq)/dq: third derivatives,
-                const int n = idx / P.g_max_cu, c = P.dh_c[n], k = P.dh_cfg[n];         // one lane per (item k, item i), j >= i
+            // -d(dq^T H dq)/dq_k = -sum_ij h_c,dqdqdq(i, j, k) dq_i dq_j, plane constraints (and systems whose scratch is too small for the
+            // path sums below): term by term, one lane per (item k, item i), j >= i
+            TG_FOR(idx, P.n_dh * P.g_max_cu) {
+                const int n = idx / P.g_max_cu, c = P.dh_c[n], k = P.dh_cfg[n];
+                if (path_sums && !(has_plane() && P.c_type[c] == TG_CONSTRAINT_PLANE)) continue;
                 const int ni = P.cu_off[c] + idx % P.g_max_cu;
                 if (ni >= P.cu_off[c + 1]) continue;
                 const Real dqi = dq[P.dh_cfg[ni]];
@@ -4788,6 +4792,82 @@ struct Core {
             }
         }
         TG_SYNC();
+        if (path_sums) {
+            // The same contraction for distance and point constraints in O(path length) per end point instead of O(n^3) third derivatives per
+            // constraint (76 % of this kernel on the puppet, where a string depends on up to 14 configs).  For an end point p with the joints t of
+            // its path ordered root-first, D_t = dp/dq_t and Om_t the world axis of joint t (0 if prismatic): d2p(x <= y) = Om_x x D_y,
+            // d3p(x <= y <= z) = Om_x x (Om_y x D_z).  With the running sums along the path
+            //   W_k = sum_{t<=k} Om_t dq_t,   al_k = sum_{t<=k} W_{t-1} x Om_t dq_t,   T_k = sum_{t>k} D_t dq_t,   C_k = sum_{t>k} dq_t Om_t x (D_t dq_t + 2 T_t)
+            // the contracted derivatives of the point are
+            //   a = sum_t D_t dq_t,   c = sum_ij d2p(i, j) dq_i dq_j = C_0,
+            //   a_k = sum_i d2p(i, k) dq_i = W_k x D_k + Om_k x T_k,
+            //   c_k = sum_ij d3p(i, j, k) dq_i dq_j = W_k x (W_k x D_k) + al_k x D_k + 2 W_k x (Om_k x T_k) + Om_k x C_k
+            // (both i, j at or before k: Jacobi's identity turns the ordered double sum into the first two terms) and, v = p_1 - p_2 and the
+            // differences of a, c, a_k, c_k over the two end points,  sum_ij h_ijk dq_i dq_j = 2 (2 a_k . a + v_k . c + v . c_k)  for a distance
+            // constraint (distance.c:100-133), (c_k)_comp for a point constraint (point.c:48-54).  Pass 1: a and c per (constraint, end point);
+            // pass 2: each end point's lane walks its path forwards (W, al), then backwards (W, al by subtraction) and adds its part of every item's entry.
+            Real *tot = X;      // [2 nc][6]: a, c of the whole path (X is written after this phase)
+            auto item = [&](int n, int E, Real *D, Real *Om, Real &rate, int &cfg) {
+                const int *rec = P.dh_pack + 8 * (size_t)n;
+                const int oj = rec[2], kind = (rec[3] >> 8) & 0xFF;
+                cfg = rec[1];
+                dpos_rec(rec[4 + E], oj, kind, D);
+                if (kind >= TG_RX) { const Real *gj = S + P.o_G + oj; const int ax = kind - TG_RX; Om[0] = gj[ax]; Om[1] = gj[4 + ax]; Om[2] = gj[8 + ax]; }
+                else { Om[0] = Om[1] = Om[2] = 0.0; }
+                rate = dq[cfg];
+            };
+            if (on) TG_FOR(ce, 2 * nc) {
+                const int t0 = P.cpath_off[ce], t1 = P.cpath_off[ce + 1], E = ce & 1;
+                Real T[3] = {0, 0, 0}, C[3] = {0, 0, 0}, D[3], Om[3], r, x[3], y[3];
+                int cfg;
+                for (int t = t1 - 1; t >= t0; t--) {
+                    item(P.cpath_items[t], E, D, Om, r, cfg);
+                    for (int m = 0; m < 3; m++) y[m] = r * D[m] + 2.0 * T[m];
+                    cross3(Om, y, x);
+                    for (int m = 0; m < 3; m++) { C[m] += r * x[m]; T[m] += r * D[m]; }
+                }
+                Real *o = tot + 6 * ce;
+                for (int m = 0; m < 3; m++) { o[m] = T[m]; o[3 + m] = C[m]; }
+            }
+            TG_SYNC();
+            if (on) TG_FOR(ce, 2 * nc) {
+                const int c = ce >> 1, E = ce & 1, t0 = P.cpath_off[ce], t1 = P.cpath_off[ce + 1];
+                if (has_plane() && P.c_type[c] == TG_CONSTRAINT_PLANE) continue;
+                const bool point = P.c_type[c] == TG_CONSTRAINT_POINT;
+                const Real *o1 = tot + 12 * c, *o2 = o1 + 6;
+                const Real *p1 = S + P.o_pE + 3 * P.c_e1[c], *p2 = S + P.o_pE + 3 * P.c_e2[c];
+                Real a[3], cc[3], v[3], W[3] = {0, 0, 0}, al[3] = {0, 0, 0}, T[3] = {0, 0, 0}, C[3] = {0, 0, 0}, D[3], Om[3], r, x[3], y[3], z[3], ak[3], ck[3];
+                for (int m = 0; m < 3; m++) { a[m] = o1[m] - o2[m]; cc[m] = o1[3 + m] - o2[3 + m]; v[m] = p1[m] - p2[m]; }
+                const Real sg = E ? -1.0 : 1.0;
+                int cfg;
+                for (int t = t0; t < t1; t++) {      // W and al of the whole path
+                    item(P.cpath_items[t], E, D, Om, r, cfg);
+                    cross3(W, Om, x);
+                    for (int m = 0; m < 3; m++) { al[m] += r * x[m]; W[m] += r * Om[m]; }
+                }
+                for (int t = t1 - 1; t >= t0; t--) {
+                    item(P.cpath_items[t], E, D, Om, r, cfg);
+                    cross3(W, D, x);                 // W_k x D_k
+                    cross3(Om, T, y);                // Om_k x T_k
+                    for (int m = 0; m < 3; m++) ak[m] = x[m] + y[m];
+                    cross3(W, x, ck);                // W_k x (W_k x D_k)
+                    cross3(al, D, z);
+                    for (int m = 0; m < 3; m++) ck[m] += z[m];
+                    cross3(W, y, z);
+                    for (int m = 0; m < 3; m++) ck[m] += 2.0 * z[m];
+                    cross3(Om, C, z);
+                    for (int m = 0; m < 3; m++) ck[m] += z[m];
+                    const Real h3 = point ? ck[P.c_comp[c]] : 2.0 * (2.0 * dot3(ak, a) + dot3(D, cc) + dot3(v, ck));
+                    lds_add(&AUG[(nd + c) * ld + c_q + cfg], -(sg * h3));
+                    for (int m = 0; m < 3; m++) z[m] = r * D[m] + 2.0 * T[m];
+                    cross3(Om, z, x);
+                    for (int m = 0; m < 3; m++) { C[m] += r * x[m]; T[m] += r * D[m]; W[m] -= r * Om[m]; }
+                    cross3(W, Om, x);                // W_{k-1} x Om_k
+                    for (int m = 0; m < 3; m++) al[m] -= r * x[m];
+                }
+            }
+            TG_SYNC();
+        }
         // One lane per body walks its path with the two running prefixes P_k = sum_{j<k} J_j dq_j and
         // PX_k = sum_{j<k} (W_j dq_j + J_j ddq_j) in registers and leaves X_k = da_F/dq_k = [PX_k, J_k] + [W_k, v - P_k]
         // (only X is stored: 6 doubles per item instead of 18 keeps the kernel at two wavefronts per CU)
