@@ -467,6 +467,7 @@ struct Core {
     bool res_hoff = false;         // ... and whether the constraint this lane evaluated is outside its tolerance: solved_fused()
     long long prof_last = 0;
 
+    bool d1_compact = false;   // first-derivative kernel: the compact slice (DevProg::a_*; run_trajectory sets it for MODE_DERIV1 when the schedule allows)
     int wave = 0, nw = 1;   // helper-wave kernels: index of this wavefront within the trajectory's workgroup, number of waves (uniform)
     // this wave's part [lo, hi) of a two-part pair list (program.hpp, wp_* / wt_* / wcp4): the parts never meet at a table entry
     TG_HD void wave_part(int first, int split, int last, int &lo, int &hi) const {
@@ -2973,14 +2974,15 @@ struct Core {
     TG_HD bool deriv1_solve(bool on, bool extra) {
         const bool w0 = wave == 0;
         const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nf = P.nf;
-        const int ld = P.d_aug_ld, R = P.d_nrhs;
-        double *AUG = S + P.d_o_AUG, *T12 = S + P.d_o_T12, *T22 = S + P.d_o_T22;
-        double *Dh1 = S + P.d_o_Dh1, *Dh2 = S + P.d_o_Dh2;
+        const bool cpt = d1_compact;      // compact slice: T12 in the pose union, Dh1 / Dh2 where T22 goes later, both tables cleared late
+        const int ld = cpt ? P.a_aug_ld : P.d_aug_ld, R = P.d_nrhs;
+        double *AUG = S + (cpt ? P.a_o_AUG : P.d_o_AUG), *T12 = S + (cpt ? P.a_o_T12 : P.d_o_T12), *T22 = S + (cpt ? P.a_o_T22 : P.d_o_T22);
+        double *Dh1 = cpt ? T22 : S + P.d_o_Dh1, *Dh2 = cpt ? T22 + nc * nq : S + P.d_o_Dh2;
         const int c_q1 = nf, c_p1 = nf + nq, c_u1 = nf + nq + nd, c_k2 = nf + nq + nd + nu;
         if (on) {
             if (wave == nw - 1) {
                 TG_FOR(i, nf * ld) AUG[i] = 0.0;
-                TG_FOR(i, nq * nd) { T12[i] = 0.0; T22[i] = 0.0; }
+                if (!cpt) TG_FOR(i, nq * nd) { T12[i] = 0.0; T22[i] = 0.0; }
             }
             if (w0) TG_FOR(i, nc * nq) { Dh1[i] = 0.0; Dh2[i] = 0.0; }
         }
@@ -3044,6 +3046,10 @@ struct Core {
             }
         }
         TG_WSYNC();
+        if (cpt) {     // the poses and the full-width Jacobians are dead: their places become the two tables
+            if (on) TG_FORW(i, nq * nd) { T12[i] = 0.0; T22[i] = 0.0; }
+            TG_WSYNC();
+        }
         // second-order discrete-Lagrangian tables from the (item,item) pairs (calc_deriv1_cache :749-861):
         //   a = dt/4 L_qq, b = L_dqdq/dt, c(r,o) = 1/2 L(dq_r, q_o);  D1D1 = a+b-c-cT, D2D1 = a-b+c-cT,
         //   D1D2 = a-b-c+cT, D2D2 = a+b+c+cT.
@@ -3116,8 +3122,9 @@ struct Core {
     // remaining force terms and the solve (one wave)
     TG_HD bool kkt_rest(bool on, bool extra) {
         const int nq = P.nq, nd = P.nd, nu = P.nu, nc = P.nc, nf = P.nf;
-        const int ld = P.d_aug_ld, R = P.d_nrhs;
-        double *AUG = S + P.d_o_AUG, *T12 = S + P.d_o_T12, *T22 = S + P.d_o_T22;
+        const bool cpt = d1_compact;
+        const int ld = cpt ? P.a_aug_ld : P.d_aug_ld, R = P.d_nrhs;
+        double *AUG = S + (cpt ? P.a_o_AUG : P.d_o_AUG), *T12 = S + (cpt ? P.a_o_T12 : P.d_o_T12), *T22 = S + (cpt ? P.a_o_T22 : P.d_o_T22);
         const int c_q1 = nf, c_u1 = nf + nq + nd, c_k2 = nf + nq + nd + nu;
         const double qdt = 0.25 * dt;
         if (n_wrenches()) {   // D1 fm2 = D2 fm2 = dt/2 F_dq into the q1 columns and M2 / the k2 columns; D3 fm2 = dt F_du
@@ -3186,7 +3193,7 @@ struct Core {
             constexpr int NF = SP::nf, W0 = SP::nf + SP::d_nrhs, W1 = W0 + SP::nc;
             if constexpr (TEAM == 64 && NF > 16 && NF <= 31 && W1 <= 128) {
                 constexpr int NP = ((NF + 3) >> 2) << 2;
-                double *sc = S + P.o_G;   // the joint poses are dead during the solve
+                double *sc = S + (cpt ? P.o_J : P.o_G);   // the joint poses (compact slice, where T12 sits there: the Jacobians) are dead during the solve
                 if (extra) return Core<64, SPRINGS, PROG>::template gj_panel_rhs<NP, (W1 + 15) / 16>(on, AUG, NF, W1, ld, lane, sc);
                 return Core<64, SPRINGS, PROG>::template gj_panel_rhs<NP, (W0 + 15) / 16>(on, AUG, NF, W0, ld, lane, sc);
             }
@@ -3196,7 +3203,7 @@ struct Core {
         {   // small KKT matrix, many right-hand sides: register-resident column elimination (whole wavefront)
             const int w = nf + R + (extra ? nc : 0), nb4 = (nf + 3) >> 2;
             if (TEAM == 64 && w <= 128 && nb4 <= 8 && P.gjc_ok) {
-                double *sc = S + P.o_G;   // the joint poses are dead during the solve
+                double *sc = S + (cpt ? P.o_J : P.o_G);   // the joint poses / the Jacobians are dead during the solve
                 switch (nb4) {
                 case 1: return Core<TEAM>::template gj_cols<4>(on, AUG, nf, w, ld, sc, lane);
                 case 2: return Core<TEAM>::template gj_cols<8>(on, AUG, nf, w, ld, sc, lane);
@@ -3215,8 +3222,9 @@ struct Core {
 
     TG_HD void deriv1(bool on, CArgs &A, size_t t) {
         const int nq = P.nq, nd = P.nd, nk = P.nk, nu = P.nu, nc = P.nc, nf = P.nf;
-        const int ld = P.d_aug_ld, R = P.d_nrhs;
-        double *AUG = S + P.d_o_AUG, *T12 = S + P.d_o_T12, *T22 = S + P.d_o_T22;
+        const bool cpt = d1_compact;
+        const int ld = cpt ? P.a_aug_ld : P.d_aug_ld, R = P.d_nrhs;
+        double *AUG = S + (cpt ? P.a_o_AUG : P.d_o_AUG), *T12 = S + (cpt ? P.a_o_T12 : P.d_o_T12), *T22 = S + (cpt ? P.a_o_T22 : P.d_o_T22);
         const bool ok = deriv1_solve(on, false);
         const bool w0 = wave == 0;
         TG_STAMP(11);     // everything since the pair loop: the KKT solve
@@ -5087,6 +5095,7 @@ TG_HD void run_trajectory(PROG &P0, ARGS &A0, double *S, int lane, int traj, int
     if (A.dt_steps && A.dt_period > 0) dt = A.dt_steps[t % (size_t)A.dt_period];   // per-trajectory step size (k-parallel linearisation)
     Core<TEAM, SPRINGS, PROG> core(P, S, lane, dt);
     core.wave = wave; core.nw = nw;
+    core.d1_compact = MODE == MODE_DERIV1 && P.a_ok != 0;
     if (wave == 0) core.init_sweep_schedule(MODE == MODE_ROLLOUT);
 #if defined(TG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     core.prof_last = (long long)__builtin_amdgcn_s_memtime();

@@ -178,6 +178,13 @@ struct DevProg {
     // (config, constraint) << 8 | of (constraint, config) << 18;  the right-hand side of variable i at bbd_map[i * (nf + 1) + nf]
     int bbd_pk_ok, bbd_pk_nr, bbd_pk_nc2, bbd_pk_tb, bbd_pk_tc2, bbd_pk_xs, bbd_pk_size, bbd_pk_nones;
     const int *bbd_map, *bbd_ones, *wev_pairx, *wev_dhx;
+    // COMPACT slice of the first-derivative kernel (MODE_DERIV1 only; a_ok): with the step layout's pose union [o_sc, end of the base region)
+    // dead once the midpoint is evaluated, and the two D.D2L2 tables only filled by the (item, item) pair loop after that, the table T12 moves
+    // INTO the pose union, the full-width constraint Jacobians Dh1 / Dh2 (dead after the KKT matrix's constant blocks) into the place T22 takes
+    // later, and the KKT image loses the nc unit columns only the second-derivative kernel appends: puppet 63.2 -> 51.5 KB per trajectory, i.e.
+    // three resident workgroups per CU instead of two (measured with timing mocks first: -28 % kernel time).  The tables are cleared late
+    // (after the constant blocks) in this layout; the second-derivative kernel keeps the d_* / e_* layout.
+    int a_ok, a_o_T12, a_o_AUG, a_aug_ld, a_o_T22, a_lds_per_team;
 };
 
 struct HostProgram {
@@ -783,6 +790,18 @@ inline HostProgram build_program(const tg_system_desc *d) {
     P.gjc_ok = (std::max(12 * nj, 2 * nitems) >= 4 * 32) ? 1 : 0;   // gj_cols scratch (128 doubles) lives in the dead pose area
     P.d_o_T12 = take(nq * nd); P.d_o_T22 = take(nq * nd);
     P.d_lds_per_team = (off + 1) & ~1;
+    {   // compact slice of the first-derivative kernel (DevProg::a_*)
+        const int hole0 = P.o_sc, base_end = P.d_o_Dh1;     // the pose union and what follows it up to the end of the base region
+        P.a_o_T12 = hole0;
+        P.a_o_AUG = (std::max(base_end, hole0 + nq * nd) + 1) & ~1;
+        P.a_aug_ld = (P.nf + P.d_nrhs) | 1;
+        P.a_o_T22 = (P.a_o_AUG + P.nf * P.a_aug_ld + 1) & ~1;
+        P.a_lds_per_team = (P.a_o_T22 + nq * nd + 1) & ~1;
+        const bool plain = !P.has_cs && ns == 0 && nw == 0 && !has_plane && !P.has_damper;
+        // (the solver's scratch moves from the pose area to the Jacobian area: 200 doubles)
+        P.a_ok = (plain && 2 * nc * nq <= nq * nd && 6 * nitems >= 200 && P.a_lds_per_team < P.d_lds_per_team) ? 1 : 0;
+        if (!P.a_ok) { P.a_o_T12 = P.d_o_T12; P.a_o_AUG = P.d_o_AUG; P.a_aug_ld = P.d_aug_ld; P.a_o_T22 = P.d_o_T22; P.a_lds_per_team = P.d_lds_per_team; }
+    }
     // second-derivative (z-contracted) kernel: starts where the two D.D2L2 tables of the deriv1 layout are (they are
     // dead once the adjoint's right-hand side is formed); H11 / H22 are symmetric and stored packed.  Puppet-40:
     // 79.8 KB per trajectory -> two wavefronts per CU.

@@ -35,11 +35,15 @@ static_assert(TG_NW == 1 || SPEC_TEAM == 64, "helper waves are for full-wave tea
 
 // waves per SIMD the rollout kernel is compiled for (its register budget: 2 -> 256, 3 -> 168): -DTG_ROLLOUT_WAVES=3 is an occupancy
 // experiment (tools/ab_spec.sh), not a product setting -- the LDS slice of a trajectory allows 8 per CU = 2 per SIMD
+#ifndef TG_DERIV_WAVES
+#define TG_DERIV_WAVES 1      // wavefronts per SIMD the second-derivative kernel's register allocation leaves room for (its LDS slice allows one; the first-
+                              // derivative kernel: two when its compact slice lets three workgroups of two waves share a CU)
+#endif
 #ifndef TG_ROLLOUT_WAVES
 #define TG_ROLLOUT_WAVES 2
 #endif
 template <int MODE, int PIVOT = 0>
-__global__ __launch_bounds__(64 * spec_waves<MODE>(), (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DERIV2Z) ? 1 : TG_ROLLOUT_WAVES) void k_spec(SPEC_KERNEL_ARGS) {
+__global__ __launch_bounds__(64 * spec_waves<MODE>(), MODE == tg::MODE_DERIV1 ? (SpecProg::a_ok ? 2 : 1) : (MODE == tg::MODE_DERIV2Z ? TG_DERIV_WAVES : TG_ROLLOUT_WAVES)) void k_spec(SPEC_KERNEL_ARGS) {
     SPEC_ARGS_REF;
 double *lds = tg_lds_base();
     const SpecProg P{};
@@ -50,7 +54,7 @@ double *lds = tg_lds_base();
     }
     const int block = MODE == tg::MODE_ROLLOUT ? tg_xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int traj = tg::tg_remap_trajectory(A, block * (64 / SPEC_TEAM) + team);
-    constexpr int stride = MODE == tg::MODE_DERIV2Z ? SpecProg::e_lds_per_team : (MODE == tg::MODE_DERIV1 ? SpecProg::d_lds_per_team : SpecProg::lds_per_team);
+    constexpr int stride = MODE == tg::MODE_DERIV2Z ? SpecProg::e_lds_per_team : (MODE == tg::MODE_DERIV1 ? SpecProg::a_lds_per_team : SpecProg::lds_per_team);
     tg::run_trajectory<SPEC_TEAM, MODE, SPEC_SPRINGS, const SpecProg, std::remove_reference<decltype(A)>::type, PIVOT>(P, A, lds + (size_t)team * stride, lane, traj, wave, spec_waves<MODE>());
 }
 
@@ -158,6 +162,12 @@ int tg_spec_debug_solve(const double *A_dev, double *x_dev, int *path_dev, int n
 int tg_spec_launch(int mode, const tg::RunArgs *A, tg::RunArgs *device_slot, int grid, size_t lds, void *stream) {
 #if defined(TG_MOCK_TIMING)     // the mock's header aliases LDS areas: its slice is smaller than the one the host computed from the real schedule
     if (mode == tg::MODE_ROLLOUT) lds = sizeof(double) * (size_t)SpecProg::lds_per_team * (64 / SPEC_TEAM);
+#endif
+#if defined(TG_MOCK_LDS_D1)   // timing mock: another LDS size (another number of resident workgroups) for the first-derivative kernel; wrong numbers
+    if (mode == tg::MODE_DERIV1) lds = TG_MOCK_LDS_D1;
+#endif
+#if defined(TG_MOCK_LDS_D2)
+    if (mode == tg::MODE_DERIV2Z) lds = TG_MOCK_LDS_D2;
 #endif
     switch (mode) {
     case tg::MODE_ROLLOUT:

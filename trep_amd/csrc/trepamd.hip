@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64, (MODE == tg::MODE_DERIV1 || MODE == tg::MODE_DE
     const int team = threadIdx.x / TEAM, lane = threadIdx.x % TEAM;
     const int block = MODE == tg::MODE_ROLLOUT ? tg_xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int traj = tg::tg_remap_trajectory(A, block * (64 / TEAM) + team);
-    const int stride = MODE == tg::MODE_DERIV2Z ? P.e_lds_per_team : (MODE == tg::MODE_DERIV1 ? P.d_lds_per_team : (MODE == tg::MODE_DYN_DERIV1 ? P.g_lds_per_team : P.lds_per_team));
+    const int stride = MODE == tg::MODE_DERIV2Z ? P.e_lds_per_team : (MODE == tg::MODE_DERIV1 ? P.a_lds_per_team : (MODE == tg::MODE_DYN_DERIV1 ? P.g_lds_per_team : P.lds_per_team));
     tg::run_trajectory<TEAM, MODE, SPRINGS>(P, A, lds + (size_t)team * stride, lane, traj);
 }
 
@@ -217,7 +217,7 @@ int launch(tg_batch *b, tg::RunArgs &A) {
     b->mirror_valid = false;
     const int team = b->sys->team, per_block = 64 / team;
     const int grid = ((A.remap_len > 0 ? A.remap_count : A.batch) + per_block - 1) / per_block;
-    const int per_team = A.mode == tg::MODE_DERIV2Z ? b->P.e_lds_per_team : (A.mode == tg::MODE_DERIV1 ? b->P.d_lds_per_team : (A.mode == tg::MODE_DYN_DERIV1 ? b->P.g_lds_per_team : b->P.lds_per_team));
+    const int per_team = A.mode == tg::MODE_DERIV2Z ? b->P.e_lds_per_team : (A.mode == tg::MODE_DERIV1 ? b->P.a_lds_per_team : (A.mode == tg::MODE_DYN_DERIV1 ? b->P.g_lds_per_team : b->P.lds_per_team));
     const size_t lds = (size_t)per_block * per_team * sizeof(double);
     if (lds > 160 * 1024) return fail(TG_ERR_UNSUPPORTED, "system too large for the LDS-resident kernel");
     // HIP-event timing is opt-in (the first tg_batch_timing call switches it on): a plain MidpointVI.step() loop creates
