@@ -494,6 +494,48 @@ def test_side_by_side_sweeps_change_nothing():
                 assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
+def test_armijo_speculation_depth_changes_nothing():
+    """The first Armijo round only speculates twice as far as the last step with the same method needed (BatchDOptimizer.step): which
+    candidate every seed accepts, its cost and its trajectory are those of the full-depth search, bit for bit -- also when a seed needs
+    more candidates than the shortened first round holds."""
+    import trep_amd
+    from trep_amd import discopt
+    S = 5
+    g, system, Xd, Ud = _cart_problem(S)
+    dsys = discopt.DSystem(trep_amd.MidpointVI(system), g["t"])
+    X0 = np.repeat(g["X0"][None], S, axis=0)
+    U0 = np.repeat(g["U0"][None], S, axis=0)
+    trace, depths = [], []
+    for adaptive in (False, True):
+        opt = discopt.BatchDOptimizer(dsys, Xd, Ud, g["Q"], g["R"], armijo_chunk=12)
+        real = opt.armijo_chunk
+        seen = []
+        def spy(m0, seeds=None, count=None, real=real, seen=seen):
+            seen.append((m0, count))
+            return real(m0, seeds, count)
+        opt.armijo_chunk = spy
+        try:
+            opt.set_trajectories(X0, U0)
+            out = []
+            for i, m in enumerate(["quasi", "quasi", "newton", "newton", "quasi", "newton"]):
+                if not adaptive:
+                    opt._armijo_hint.clear()
+                elif i == 4:
+                    opt._armijo_hint["quasi"] = 0        # a hint that is too optimistic: the first round holds 4 candidates
+                r = opt.step(m)
+                assert not r.failed.any()
+                out.append((r.cost0, r.dcost0, r.cost1, r.armijo) + opt.get_trajectories())
+            trace.append(out)
+            depths.append(seen)
+        finally:
+            opt.close()
+    for a, b in zip(*trace):
+        for x, y in zip(a, b):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+    assert all(count == 12 for m0, count in depths[0] if m0 == 0)
+    assert any(count < 12 for m0, count in depths[1] if m0 == 0)
+
+
 def test_batch_optimizer_matches_sequential_puppet():
     import trep_amd
     from trep_amd import systems, discopt

@@ -120,6 +120,7 @@ class BatchDOptimizer(object):
         self.armijo_beta = 0.7
         self.armijo_alpha = 0.00001
         self.armijo_max_iterations = 30
+        self._armijo_hint = {}
         self.descent_tolerance = 1e-6
         self.first_method_iterations = first_method_iterations
         self.first_method = "quasi"
@@ -552,13 +553,20 @@ class BatchDOptimizer(object):
         cost1 = np.where(active, cost0, np.nan)
         armijo = np.full(S, -1)
         search = active & ~done
+        searched = search.copy()
         m0 = 0
+        # How far the first round speculates: M candidates per seed fill the GPU, but a projection at one wave per SIMD takes 30 us per DEL
+        # step and at two 38 -- so when the last step with the same method accepted early everywhere (quasi-Newton steps: m <= 3 on the
+        # puppet), the first round only goes twice as far as that step needed.  Which candidate a seed accepts does not depend on the
+        # batching: the candidates are still tried in order, a seed that needs more gets them in the next round.
+        hints = [self._armijo_hint.get(m) for m in set(methods[search])]
+        first = self.M if (not hints or any(h is None for h in hints)) else max(4, 2 * (max(hints) + 1))
         while search.any() and m0 < self.armijo_max_iterations:
             # first round: every seed, M candidates each (one full wave of the GPU); later rounds: only the seeds
             # still searching, with as many of their remaining candidates as fit into the candidate batch
             if m0 == 0:
-                seeds, count = np.arange(S), min(self.M, self.armijo_max_iterations)
-                costs, ok = self.armijo_chunk(0)
+                seeds, count = np.arange(S), min(self.M, self.armijo_max_iterations, first)
+                costs, ok = self.armijo_chunk(0, None, count)
             else:
                 seeds = np.nonzero(search)[0]
                 count = int(min(self.armijo_max_iterations - m0, max(1, (S * self.M) // len(seeds))))
@@ -582,6 +590,9 @@ class BatchDOptimizer(object):
         # a seed whose search is exhausted is where the reference raises ConvergenceError("Armijo Failed to
         # Converge") (doptimizer.py:456-459); here it is flagged and left unchanged, the other seeds carry on
         failed = search | broken
+        for m in set(methods[searched]):          # the deepest accepted candidate of this step, per method: the next step's speculation depth
+            took = armijo[searched & (methods == m) & (armijo >= 0)]
+            self._armijo_hint[m] = int(took.max()) if len(took) and not (search & (methods == m)).any() else None
         self.iteration += 1
         shown = active | broken
         return self.step_return(done | failed, np.where(shown, cost0, np.nan), dcost0, np.where(broken, cost0, cost1), list(methods), armijo, failed)
