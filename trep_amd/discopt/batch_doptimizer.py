@@ -176,7 +176,7 @@ class BatchDOptimizer(object):
             self.pipeline = self.overlap if env_pipe is None else (env_pipe == "1" and self.overlap)      # (128 seeds on 256 CUs still gain 5 %)
         else:
             self.pipeline = bool(pipeline_newton) and self.overlap
-        self.pipeline_chunks = int(os.environ.get("TREPAMD_NEWTON_CHUNKS", "8"))
+        self.pipeline_chunks = int(os.environ.get("TREPAMD_NEWTON_CHUNKS", "24"))
         if self.pipeline:
             self.Pc = [(pool.empty((S, nX, nX)), pool.empty((S, nX))) for _ in range(4)]      # (P, b) carried between the chunks: two per sweep
             self.lq_status3 = pool.empty((S,), np.int32)
