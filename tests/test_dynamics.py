@@ -347,6 +347,44 @@ def test_gpu_dynamics_second_derivatives_match_reference(name):
 
 
 @pytest.mark.gpu
+def test_gpu_forward_mode_entry_points_check_their_directions():
+    """tg_batch_dynamics_deriv1_forward / tg_batch_lagrangian_forward: a direction variable outside q | dq | ddq_k | u is refused with
+    TG_ERR_INVALID and nothing is launched; -1 (no direction) gives exact zeros; the batched call agrees with the emulated kernel."""
+    import trep_amd
+    from emu_harness import EmuBatch
+    g = golden()
+    name = "scissor4"
+    system, d = build(name)
+    q, dq, u, ddqk = g[name + "_q"][0], g[name + "_dq"][0], g[name + "_u"][0], g[name + "_ddqk"][0]
+    nq, nk, nu = len(q), len(ddqk), len(u)
+    nvar = 2 * nq + nk + nu
+    B = 4
+    eng = trep_amd.BatchMidpointVI(system, B)
+    try:
+        seeds = np.array([-1, 0, nq + 1, nvar - 1], dtype=np.int32)
+        out, status = eng.dynamics_deriv1(q, dq, u, ddqk, seeds=(seeds,))
+        assert (status == 0).all()
+        assert all(np.all(v[0] == 0.0) for v in out.values())
+        e = EmuBatch(d, B)
+        rep = lambda a: np.repeat(np.asarray(a, dtype=float)[None], B, axis=0)
+        ref, _ = e.dynamics_deriv1(rep(q), rep(dq), rep(u), rep(ddqk), seeds=(seeds,))
+        for k, v in out.items():
+            r = ref[k.replace("lambda_", "lam_")]
+            assert relerr(v, r) < 1e-12, (k, relerr(v, r))
+        for bad in (nvar, -2):
+            with pytest.raises(Exception):
+                eng.dynamics_deriv1(q, dq, u, ddqk, seeds=(np.array([0, 0, bad, 0], dtype=np.int32),))
+            with pytest.raises(Exception):
+                eng.lagrangian(q, dq, seeds=(np.zeros(B, dtype=np.int32), np.array([0, bad, 0, 0], dtype=np.int32)))
+        with pytest.raises(ValueError):
+            eng.lagrangian(q, dq, seeds=())
+        third = eng.lagrangian(q, dq, seeds=(np.full(B, -1, dtype=np.int32),))
+        assert all(np.all(v == 0.0) for v in third.values())
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["pendulum5", "scissor4", "puppet40", "spring_arm", "plane_link", "nonlinear_spring_arm"])
 def test_gpu_higher_order_lagrangian_accessors_match_reference(name):
     """System.L_dqdqdq, L_ddqdqdq, L_ddqddqdq (third order) and L_ddqdqdqdq, L_ddqddqdqdq (fourth order), system.py:869-949:
