@@ -1756,39 +1756,55 @@ template <int CTRL> __device__ __forceinline__ double tr_dpp(double x) {
 // Thread (row i, part p) holds columns p, p + 4, p + 8, ... of its row (a quad reads 32 contiguous bytes per load); loads are unconditional
 // -- rows and columns past the end are clamped to the last one and meet the ZERO padding of dX / dU in LDS -- because a guarded global
 // load becomes a basic block of its own (47 of them per step, each with its address arithmetic and exec-mask juggling).
-template <int CA, int CB, int CK> struct TangentRegs {
+// PAIR (even nX and nU): the thread holds PAIRS of neighbouring columns -- 2 p, 2 p + 1, then 8 (A, B) or 16 (K) columns on -- and loads each
+// pair with one 16-byte instruction: half the vector-memory instructions per step.  The step is bound by them: without its loads the kernel
+// takes 1.7 us a step, with the 47 8-byte loads per thread 4.6 (32-byte pieces of 640-byte rows: the address coalescer, not HBM).
+template <int CA, int CB, int CK, bool PAIR = false> struct TangentRegs {
     static constexpr int TR_CA = CA, TR_CB = CB, TR_CK = CK;
     double a[TR_CA], b[TR_CB], k[TR_CK], cq, cr, cc;     // matrix slices; q_k[i], r_k[j], C_k[j] of the thread's row
+    // column of slot c of a part-p thread when parts are `np` wide: the plain interleave p + np c, or pairs (2 p + (c & 1)) + 2 np (c >> 1)
+    __device__ __forceinline__ static int col_of(int p, int c, int np) { return PAIR ? 2 * p + (c & 1) + 2 * np * (c >> 1) : p + np * c; }
     __device__ __forceinline__ void load(const double *Ak, const double *Bk, const double *Kk, const double *Ck, const double *qk, const double *rk,
                                          int nX, int nU, int row, int pa, int nca, int ncb, int jrow, int pk, int nck) {
         const double *ar = Ak + (size_t)(row < nX ? row : nX - 1) * nX, *br = Bk + (size_t)(row < nX ? row : nX - 1) * nU;
         const double *kr = Kk + (size_t)(jrow < nU ? jrow : nU - 1) * nX;
+        if constexpr (PAIR) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int c = 0; c < TR_CA; c += 2) if (c < nca) { const int col = col_of(pa, c, 4); const d2 v = *(const d2 *)(ar + (col < nX ? col : nX - 2)); a[c] = v[0]; a[c + 1] = v[1]; }
+#pragma unroll
+            for (int c = 0; c < TR_CB; c += 2) if (c < ncb) { const int col = col_of(pa, c, 4); const d2 v = *(const d2 *)(br + (col < nU ? col : nU - 2)); b[c] = v[0]; b[c + 1] = v[1]; }
+#pragma unroll
+            for (int c = 0; c < TR_CK; c += 2) if (c < nck) { const int col = col_of(pk, c, 8); const d2 v = *(const d2 *)(kr + (col < nX ? col : nX - 2)); k[c] = v[0]; k[c + 1] = v[1]; }
+        } else {
 #pragma unroll
         for (int c = 0; c < TR_CA; c++) if (c < nca) { const int col = pa + 4 * c; a[c] = ar[col < nX ? col : nX - 1]; }
 #pragma unroll
         for (int c = 0; c < TR_CB; c++) if (c < ncb) { const int col = pa + 4 * c; b[c] = br[col < nU ? col : nU - 1]; }
 #pragma unroll
         for (int c = 0; c < TR_CK; c++) if (c < nck) { const int col = pk + 8 * c; k[c] = kr[col < nX ? col : nX - 1]; }
+        }
         cq = qk[row < nX ? row : nX - 1];
         cr = rk[jrow < nU ? jrow : nU - 1];
         cc = Ck[jrow < nU ? jrow : nU - 1];
     }
 };
-template <int TR_CA, int TR_CB, int TR_CK>
+template <int TR_CA, int TR_CB, int TR_CK, bool PAIR = false>
 __global__ __launch_bounds__(384) void k_tangent_rows(int N, int nX, int nU, const int *sel, const double *A, const double *B,
                                                       const double *K, const double *C, const double *q, const double *r,
                                                       double *dX, double *dU, double *dcost) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x, nt = blockDim.x, s = sel ? sel[blockIdx.x] : blockIdx.x;
-    const int row = tid >> 2, pa = tid & 3, nca = (nX + 3) >> 2, ncb = (nU + 3) >> 2;
-    const int jrow = tid >> 3, pk = tid & 7, nck = (nX + 7) >> 3;
+    typedef TangentRegs<TR_CA, TR_CB, TR_CK, PAIR> Regs;
+    const int row = tid >> 2, pa = tid & 3, nca = PAIR ? 2 * ((nX + 7) >> 3) : (nX + 3) >> 2, ncb = PAIR ? 2 * ((nU + 7) >> 3) : (nU + 3) >> 2;
+    const int jrow = tid >> 3, pk = tid & 7, nck = PAIR ? 2 * ((nX + 15) >> 4) : (nX + 7) >> 3;
     const int px = 8 * nck, pu = 4 * ncb;                       // padded lengths of dX and dU in LDS (the padding stays zero)
     double *x0 = lds, *x1 = x0 + px, *u = x1 + px, *red = u + pu;
     const size_t sN = (size_t)s * N;
     for (int i = tid; i < 2 * px + pu; i += nt) lds[i] = 0.0;
     for (int i = tid; i < nX; i += nt) dX[(sN + s) * nX + i] = 0.0;
     double part = 0.0;
-    TangentRegs<TR_CA, TR_CB, TR_CK> cur, nxt;
+    Regs cur, nxt;
     cur.load(A + sN * (size_t)nX * nX, B + sN * (size_t)nX * nU, K + sN * (size_t)nU * nX, C + sN * nU, q + (sN + s) * nX, r + sN * nU, nX, nU, row, pa, nca, ncb, jrow, pk, nck);
     __syncthreads();
     double *x = x0, *xn = x1;
@@ -1800,8 +1816,8 @@ __global__ __launch_bounds__(384) void k_tangent_rows(int N, int nX, int nU, con
             double v0 = 0.0, v1 = 0.0;
 #pragma unroll
             for (int c = 0; c < TR_CK; c += 2) {
-                if (c < nck) v0 = fma(cur.k[c], x[pk + 8 * c], v0);
-                if (c + 1 < nck) v1 = fma(cur.k[c + 1], x[pk + 8 * (c + 1)], v1);
+                if (c < nck) v0 = fma(cur.k[c], x[Regs::col_of(pk, c, 8)], v0);
+                if (c + 1 < nck) v1 = fma(cur.k[c + 1], x[Regs::col_of(pk, c + 1, 8)], v1);
             }
             double v = v0 + v1;
             v += tr_dpp<0xB1>(v); v += tr_dpp<0x4E>(v); v += tr_dpp<0x141>(v);     // quad xor 1, xor 2, mirror of the half row
@@ -1819,15 +1835,15 @@ __global__ __launch_bounds__(384) void k_tangent_rows(int N, int nX, int nU, con
             double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
 #pragma unroll
             for (int c = 0; c < TR_CA; c += 4) {
-                if (c < nca) v0 = fma(cur.a[c], x[pa + 4 * c], v0);
-                if (c + 1 < nca) v1 = fma(cur.a[c + 1], x[pa + 4 * (c + 1)], v1);
-                if (c + 2 < nca) v2 = fma(cur.a[c + 2], x[pa + 4 * (c + 2)], v2);
-                if (c + 3 < nca) v3 = fma(cur.a[c + 3], x[pa + 4 * (c + 3)], v3);
+                if (c < nca) v0 = fma(cur.a[c], x[Regs::col_of(pa, c, 4)], v0);
+                if (c + 1 < nca) v1 = fma(cur.a[c + 1], x[Regs::col_of(pa, c + 1, 4)], v1);
+                if (c + 2 < nca) v2 = fma(cur.a[c + 2], x[Regs::col_of(pa, c + 2, 4)], v2);
+                if (c + 3 < nca) v3 = fma(cur.a[c + 3], x[Regs::col_of(pa, c + 3, 4)], v3);
             }
 #pragma unroll
             for (int c = 0; c < TR_CB; c += 2) {
-                if (c < ncb) v0 = fma(cur.b[c], u[pa + 4 * c], v0);
-                if (c + 1 < ncb) v1 = fma(cur.b[c + 1], u[pa + 4 * (c + 1)], v1);
+                if (c < ncb) v0 = fma(cur.b[c], u[Regs::col_of(pa, c, 4)], v0);
+                if (c + 1 < ncb) v1 = fma(cur.b[c + 1], u[Regs::col_of(pa, c + 1, 4)], v1);
             }
             double v = (v0 + v1) + (v2 + v3);
             v += tr_dpp<0xB1>(v); v += tr_dpp<0x4E>(v);
@@ -2183,14 +2199,21 @@ int tg_tangent_rollout(int32_t device, int32_t n_problems, int32_t horizon, int3
         nt = (nt + 63) & ~63;
         if (nt <= 384) {
             HIP_TRY(hipSetDevice(device));
-            const size_t ldsr = sizeof(double) * (2 * (size_t)(8 * ((nX + 7) / 8)) + 4 * ((nU + 3) / 4) + nt);
-            const int nca = (nX + 3) / 4, ncb = (nU + 3) / 4, nck = (nX + 7) / 8;
-#define LAUNCH_TR(CA_, CB_, CK_)                                                                                                              \
-            hipLaunchKernelGGL((k_tangent_rows<CA_, CB_, CK_>), dim3(n_problems), dim3(nt), ldsr, dopt_stream(device), horizon, nX, nU, select_dev, \
+            // even sizes: pairs of columns per thread, 16-byte loads (rows of A, B, K then start on 16-byte boundaries)
+            const bool pair = nX % 2 == 0 && nU % 2 == 0 && (((uintptr_t)A_dev | (uintptr_t)B_dev | (uintptr_t)K_dev) & 15) == 0 && !std::getenv("TREPAMD_TANGENT_NO_PAIRS");
+            const int nca = pair ? 2 * ((nX + 7) / 8) : (nX + 3) / 4, ncb = pair ? 2 * ((nU + 7) / 8) : (nU + 3) / 4, nck = pair ? 2 * ((nX + 15) / 16) : (nX + 7) / 8;
+            const size_t ldsr = sizeof(double) * (2 * (size_t)(8 * nck) + 4 * ncb + nt);
+#define LAUNCH_TR(CA_, CB_, CK_, PAIR_)                                                                                                              \
+            hipLaunchKernelGGL((k_tangent_rows<CA_, CB_, CK_, PAIR_>), dim3(n_problems), dim3(nt), ldsr, dopt_stream(device), horizon, nX, nU, select_dev, \
                                A_dev, B_dev, K_dev, C_dev, q_dev, r_dev, dX_dev, dU_dev, dcost_dev)
-            if (nca <= 8 && ncb <= 4 && nck <= 4) LAUNCH_TR(8, 4, 4);
-            else if (nca <= 20 && ncb <= 6 && nck <= 10) LAUNCH_TR(20, 6, 10);       // the puppet's nX = 80, nU = 18
-            else LAUNCH_TR(24, 8, 12);
+            if (pair) {
+                if (nca <= 8 && ncb <= 4 && nck <= 4) LAUNCH_TR(8, 4, 4, true);
+                else if (nca <= 20 && ncb <= 6 && nck <= 10) LAUNCH_TR(20, 6, 10, true);       // the puppet's nX = 80, nU = 18
+                else LAUNCH_TR(24, 8, 12, true);
+            }
+            else if (nca <= 8 && ncb <= 4 && nck <= 4) LAUNCH_TR(8, 4, 4, false);
+            else if (nca <= 20 && ncb <= 6 && nck <= 10) LAUNCH_TR(20, 6, 10, false);
+            else LAUNCH_TR(24, 8, 12, false);
 #undef LAUNCH_TR
             HIP_TRY(hipGetLastError());
             return TG_SUCCESS;
