@@ -14,7 +14,9 @@ for r in csv.DictReader(open(f)):
 names = ["store b64, consecutive doubles (reference)", "store b64, item stride 6 doubles (J, W, X)", "store b64, joint / config / body-pose stride 12 doubles (local transforms, twists)", "store b64, image row stride 29",
          "store b128, stride 6", "store b128, stride 12", "load b64, consecutive (reference)", "load b64, stride 6", "load b64, stride 12", "load b64, stride 29 (image rows)",
          "load 2 x b64 (ds_read2_b64), stride 6", "load 2 x b64, stride 12", "load b128, stride 6 (what the compiler emits for an item's J / W)", "load b128, stride 12",
-         "quad-lane sweep stores, round 0 pass 0 (puppet instances)", "quad-lane sweep stores, round 1 pass 0", "pair phase: twists of config a, b128 gather (12 a)", "pair phase: per-config vectors of b, b64 gather (15 b)", "pair phase: twists of a, b64 gather"]
+         "quad-lane sweep stores, round 0 pass 0 (puppet instances)", "quad-lane sweep stores, round 1 pass 0", "pair phase: twists of config a, b128 gather (12 a)", "pair phase: per-config vectors of b, b64 gather (15 b)", "pair phase: twists of a, b64 gather",
+         "store b64, stride 13 doubles (12-double records padded by one: not 16-byte aligned)", "store b64, stride 14 doubles (padded by two: 16-byte aligned)", "store b128, stride 14",
+         "load b64, stride 13", "load b64, stride 14", "load 2 x b64, stride 14", "load b128, stride 14"]
 N = 2048.0 * 4096.0     # wave instructions per pattern (the volatile loads compile to flat loads: SQ_INSTS_LDS does not count them)
 print("# LDS bank conflicts by access pattern (tools/micro/lds_conflicts.hip): 2048 waves x 4096 repetitions of ONE LDS instruction per pattern;")
 print("# SQ_LDS_IDX_ACTIVE and SQ_LDS_BANK_CONFLICT per wave instruction (stores count 4 cycles, loads 2 per conflict-free 64 x 8 bytes)")

@@ -112,6 +112,14 @@ int main() {
     RUN(r_gather, out, da, 12, 1)   // 17 twists of a, 16-byte reads
     RUN(r_gather, out, db, 15, 0)   // 18 per-config vectors of b, 8-byte reads (15-double records are not 16-byte aligned)
     RUN(r_gather, out, da, 12, 0)   // 19
+    // round 5: the strides the round-4 verdict asked about for 12-double records (poses, twists): 14 doubles keeps 16-byte alignment, 13 does not
+    RUN((w_b64<13>), out)     // 20
+    RUN((w_b64<14>), out)     // 21
+    RUN((w_b128<14>), out)    // 22
+    RUN((r_b64<13>), out)     // 23
+    RUN((r_b64<14>), out)     // 24
+    RUN((r_2b64<14>), out)    // 25
+    RUN((r_b128<14>), out)    // 26
     printf("done: %d repetitions x 2048 waves per pattern\n", REPS);
     return 0;
 }
